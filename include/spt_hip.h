@@ -1,0 +1,107 @@
+/*
+ * spt_hip.h — flat C ABI of libspt_hip.so, the MI355X (gfx950) hot path of
+ * Superpoint Transformer.
+ *
+ * Every entry point replaces one call the reference makes into an un-vendored
+ * native dependency (torch_scatter / torch_geometric / FRNN / pgeof) or one
+ * multi-launch Python composite of those calls.  Reference citations are
+ * file:line relative to drprojects/superpoint_transformer v3.0.0.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers owned by the caller (PyTorch's caching
+ *     allocator in practice); the library never allocates device memory.
+ *     Scratch comes from a caller-provided workspace (ws, ws_bytes) whose size
+ *     is returned by the paired *_workspace_bytes() query;
+ *   - every function is asynchronous on `stream` (a hipStream_t passed as
+ *     void*), re-entrant, and holds no global state besides the thread-local
+ *     last-error string;
+ *   - return value: 0 = ok, <0 = error (see spt_last_error()).  Nothing throws
+ *     across the boundary;
+ *   - row-major, contiguous tensors; f32 features; int64 indices as the
+ *     reference hands them over (NAGCast, src/transforms/data.py:54-150);
+ *     int32 perm/rowptr inside CSR views (N0 < 2^31 rows);
+ *   - segment ops take a CSR view (perm, rowptr) of an UNSORTED index built by
+ *     spt_csr_build(): rows of segment s are perm[rowptr[s] .. rowptr[s+1]) in
+ *     ascending original order (stable), so reductions are deterministic and
+ *     the arg-tie rule is "first occurrence" like torch_scatter's CPU kernel.
+ */
+#ifndef SPT_HIP_H
+#define SPT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* spt_stream_t; /* hipStream_t */
+
+enum spt_reduce_op {
+  SPT_SUM = 0,
+  SPT_MEAN = 1,
+  SPT_MIN = 2,
+  SPT_MAX = 3
+};
+
+/* Library ABI version (major*1000 + minor). */
+int spt_version(void);
+/* Thread-local description of the last error returned by this library. */
+const char* spt_last_error(void);
+
+/* ------------------------------------------------------------------------
+ * CSR view of an unsorted segment index.
+ * Replaces the implicit "group by index" that every torch_scatter COO kernel
+ * redoes with atomics (call sites: src/nn/pool.py:61-62, src/nn/norm.py:118-126,
+ * src/nn/attention.py:307,315, src/data/nag.py:97,108).
+ *   idx     [n]          int64, values in [0, num_seg)
+ *   perm    [n]          int32 out: stable argsort of idx
+ *   rowptr  [num_seg+1]  int32 out: segment s owns perm[rowptr[s]..rowptr[s+1])
+ * ---------------------------------------------------------------------- */
+size_t spt_csr_build_workspace_bytes(int64_t n, int64_t num_seg);
+int spt_csr_build(const int64_t* idx, int64_t n, int64_t num_seg,
+                  int32_t* perm, int32_t* rowptr,
+                  void* ws, size_t ws_bytes, spt_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Segment reduce  out[s,:] = reduce_{i in seg s} x[i,:]      (a1, a4, a8)
+ * Replaces torch_scatter.scatter / scatter_{sum,mean,min,max} and the PyG
+ * {Sum,Mean,Min,Max}Aggregation the pools dispatch to
+ * (src/nn/pool.py:61-82 <- src/nn/stage.py:429-431; src/nn/norm.py:118-126).
+ *   x    [n,c] f32      out [num_seg,c] f32
+ *   arg  [num_seg,c] int32 or NULL: for MIN/MAX the row index of the selected
+ *        element, n for an empty segment (torch_scatter's sentinel).
+ * Empty segments reduce to 0.  MEAN divides by max(count,1).
+ * ---------------------------------------------------------------------- */
+int spt_segcsr_reduce_f32(int op, const float* x, const int32_t* perm,
+                          const int32_t* rowptr, int64_t n, int64_t num_seg,
+                          int c, float* out, int32_t* arg, spt_stream_t stream);
+
+/* Backward of the above w.r.t. x (a2):
+ *   SUM : gx[i,:] = gout[idx[i],:]
+ *   MEAN: gx[i,:] = gout[idx[i],:] / max(count[idx[i]],1)
+ *   MIN/MAX: gx[i,c] = gout[idx[i],c] if arg[idx[i],c]==i else 0
+ * (torch_scatter routes the gradient to the single arg element.)           */
+int spt_segcsr_reduce_bwd_f32(int op, const float* gout, const int32_t* arg,
+                              const int64_t* idx, const int32_t* rowptr,
+                              int64_t n, int64_t num_seg, int c, float* gx,
+                              spt_stream_t stream);
+
+/* Bit-exact integer segment sum (a8: NAG.get_sub_size, src/data/nag.py:59-110). */
+int spt_segcsr_sum_i64(const int64_t* x, const int32_t* perm,
+                       const int32_t* rowptr, int64_t n, int64_t num_seg,
+                       int c, int64_t* out, spt_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Row gather  out[i,:] = x[idx[i],:]                               (a3)
+ * Replaces IndexUnpool (src/nn/unpool.py:12-13) and the parent->child
+ * broadcasts of src/nn/norm.py:132-133, src/nn/stage.py:269.  Its backward
+ * is spt_segcsr_reduce_f32(SPT_SUM) on the CSR view of idx.
+ * ---------------------------------------------------------------------- */
+int spt_gather_rows_f32(const float* x, const int64_t* idx, int64_t n,
+                        int64_t num_src, int c, float* out, spt_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPT_HIP_H */

@@ -1,0 +1,461 @@
+"""CPU oracle for the SPT hot path -- TEST INFRASTRUCTURE ONLY.
+
+Plain torch-CPU / numpy restatement of the reference's algorithms for the
+path of SURVEY.md section 8.  Only ``tests/``, ``__graft_entry__.smoke()``,
+``tests/golden/make_golden.py`` and ``bench.py``'s ``cpu_baseline`` leg may
+import this module; the product (``superpoint_transformer_amd``) never does.
+
+Every function cites the reference file:line it follows (paths relative to
+drprojects/superpoint_transformer v3.0.0).  Functions whose algorithm lives
+in an UN-VENDORED third-party dependency (torch_scatter, torch_geometric
+2.3.0, FRNN, pgeof -- install.sh:96-137; none installable here) restate the
+published semantics and are marked "[third-party restated]".
+
+Pinning status:
+  * pinned against the reference's OWN Python code: ``tests/golden/
+    make_golden.py`` imports the reference's modules verbatim (attention.py,
+    norm.py, pool.py, unpool.py, transformer.py, utils/scatter.py,
+    utils/nn.py, utils/geometry.py, utils/neighbors.py:knn_brute_force /
+    neighbors_dense_to_csr) from /root/reference and stores their outputs as
+    fixtures which ``tests/test_oracle_golden.py`` checks this file against;
+  * PARITY UNPINNED at the third-party boundary: the torch_scatter / PyG /
+    FRNN / pgeof binaries cannot be run here, and the reference's tests hold
+    no golden vector for them.
+
+All functions accept float32 or float64 tensors; tests evaluate the oracle in
+float64 to get a tolerance reference for the float32 kernels.
+"""
+import math
+
+import numpy as np
+import torch
+
+# --------------------------------------------------------------------------
+# torch_scatter                                       [third-party restated]
+# --------------------------------------------------------------------------
+
+
+def _dim_size(index, dim_size):
+    if dim_size is not None:
+        return int(dim_size)
+    return int(index.max()) + 1 if index.numel() > 0 else 0
+
+
+def _expand_index(index, src):
+    idx = index.view((-1,) + (1,) * (src.dim() - 1))
+    return idx.expand_as(src)
+
+
+def scatter_sum(src, index, dim=0, out=None, dim_size=None):
+    """torch_scatter.scatter_sum along dim 0 with a 1-D index (call sites:
+    src/nn/attention.py:315, src/data/nag.py:97,108, src/utils/scatter.py:30)."""
+    assert dim == 0 and out is None and index.dim() == 1
+    n = _dim_size(index, dim_size)
+    res = torch.zeros((n,) + tuple(src.shape[1:]), dtype=src.dtype)
+    if src.numel():
+        res.index_add_(0, index, src)
+    return res
+
+
+def scatter_mean(src, index, dim=0, out=None, dim_size=None):
+    """torch_scatter.scatter_mean: sum / clamp(count, 1); integer src floors
+    (call sites: src/utils/scatter.py:59, src/nn/norm.py:125)."""
+    n = _dim_size(index, dim_size)
+    s = scatter_sum(src, index, dim, out, n)
+    cnt = torch.bincount(index, minlength=n).clamp(min=1)
+    cnt = cnt.view((-1,) + (1,) * (src.dim() - 1))
+    if src.is_floating_point():
+        return s / cnt.to(src.dtype)
+    return torch.div(s, cnt, rounding_mode="floor")
+
+
+def _scatter_minmax(src, index, dim_size, is_max):
+    """torch_scatter.scatter_{min,max}: empty groups -> 0 and arg = src.size(0);
+    ties -> FIRST occurrence (torch_scatter's CPU kernel walks rows in order
+    with a strict comparison)."""
+    n = _dim_size(index, dim_size)
+    N = src.shape[0]
+    flat = src.reshape(N, -1)
+    C = flat.shape[1]
+    out = torch.zeros((n, C), dtype=src.dtype)
+    arg = torch.full((n, C), N, dtype=torch.int64)
+    if N:
+        red = torch.full((n, C), float("-inf") if is_max else float("inf"),
+                         dtype=src.dtype)
+        red.scatter_reduce_(0, index.view(-1, 1).expand(N, C), flat,
+                            "amax" if is_max else "amin", include_self=True)
+        hit = flat == red[index]
+        rows = torch.arange(N).view(-1, 1).expand(N, C)
+        cand = torch.where(hit, rows, torch.full_like(rows, N))
+        arg.scatter_reduce_(0, index.view(-1, 1).expand(N, C), cand, "amin",
+                            include_self=True)
+        nonempty = torch.bincount(index, minlength=n) > 0
+        out[nonempty] = red[nonempty]
+    shape = (n,) + tuple(src.shape[1:])
+    return out.reshape(shape), arg.reshape(shape)
+
+
+class _ScatterMinMax(torch.autograd.Function):
+    """Differentiable wrapper with torch_scatter's gradient rule: the whole
+    output gradient goes to the single arg element (no tie splitting)."""
+
+    @staticmethod
+    def forward(ctx, src, index, dim_size, is_max):
+        out, arg = _scatter_minmax(src.detach(), index, dim_size, is_max)
+        ctx.n = src.shape[0]
+        ctx.save_for_backward(arg)
+        ctx.mark_non_differentiable(arg)
+        return out, arg
+
+    @staticmethod
+    def backward(ctx, gout, _garg):
+        (arg,) = ctx.saved_tensors
+        return scatter_max_grad(gout, arg, ctx.n), None, None, None
+
+
+def scatter_max(src, index, dim=0, out=None, dim_size=None):
+    assert dim == 0 and out is None
+    return _ScatterMinMax.apply(src, index, dim_size, True)
+
+
+def scatter_min(src, index, dim=0, out=None, dim_size=None):
+    assert dim == 0 and out is None
+    return _ScatterMinMax.apply(src, index, dim_size, False)
+
+
+def scatter_std(src, index, dim=0, out=None, dim_size=None, unbiased=True):
+    """torch_scatter.scatter_std (src/transforms/graph.py:285,1036)."""
+    n = _dim_size(index, dim_size)
+    cnt = torch.bincount(index, minlength=n).to(src.dtype)
+    cnt = cnt.view((-1,) + (1,) * (src.dim() - 1))
+    mean = scatter_sum(src, index, 0, None, n) / cnt.clamp(min=1)
+    var = scatter_sum((src - mean[index]) ** 2, index, 0, None, n)
+    denom = (cnt - 1 if unbiased else cnt).clamp(min=1)
+    return (var / (denom + 1e-6)).sqrt()
+
+
+def scatter(src, index, dim=0, out=None, dim_size=None, reduce="sum"):
+    """torch_scatter.scatter (src/nn/norm.py:118-126)."""
+    if reduce in ("sum", "add"):
+        return scatter_sum(src, index, dim, out, dim_size)
+    if reduce == "mean":
+        return scatter_mean(src, index, dim, out, dim_size)
+    if reduce == "min":
+        return scatter_min(src, index, dim, out, dim_size)[0]
+    if reduce == "max":
+        return scatter_max(src, index, dim, out, dim_size)[0]
+    raise ValueError(reduce)
+
+
+def scatter_max_grad(gout, arg, n):
+    """Gradient rule of torch_scatter min/max: all of gout goes to the arg row."""
+    C = gout.reshape(gout.shape[0], -1).shape[1]
+    g = torch.zeros((n + 1, C), dtype=gout.dtype)
+    g.scatter_add_(0, arg.reshape(-1, C), gout.reshape(-1, C))
+    return g[:n].reshape((n,) + tuple(gout.shape[1:]))
+
+
+# --------------------------------------------------------------------------
+# CSR view (what spt_csr_build must produce)
+# --------------------------------------------------------------------------
+
+
+def csr_view(index, num_seg):
+    """Stable argsort + row pointers of an unsorted segment index."""
+    perm = torch.sort(index, stable=True).indices
+    counts = torch.bincount(index, minlength=num_seg)
+    rowptr = torch.zeros(num_seg + 1, dtype=torch.int64)
+    rowptr[1:] = counts.cumsum(0)
+    return perm.to(torch.int32), rowptr.to(torch.int32)
+
+
+# --------------------------------------------------------------------------
+# torch_geometric 2.3.0                                [third-party restated]
+# --------------------------------------------------------------------------
+
+
+def pyg_softmax(src, index, ptr=None, num_nodes=None, dim=0):
+    """torch_geometric.utils.softmax (src/nn/attention.py:307): max-subtract,
+    exp, segment sum + 1e-16, divide."""
+    assert dim == 0 and ptr is None
+    n = _dim_size(index, num_nodes)
+    src_max = scatter(src.detach(), index, 0, None, n, "max")
+    out = (src - src_max[index]).exp()
+    out_sum = scatter_sum(out, index, 0, None, n) + 1e-16
+    return out / out_sum[index]
+
+
+def graph_norm(x, batch, weight, bias, mean_scale, eps=1e-5, batch_size=None):
+    """torch_geometric.nn.norm.GraphNorm.forward (used through
+    src/nn/mlp.py:85-94 and src/nn/transformer.py:258-265)."""
+    if batch is None:
+        batch = torch.zeros(x.shape[0], dtype=torch.long)
+    if batch_size is None:
+        batch_size = int(batch.max()) + 1 if batch.numel() else 1
+    mean = scatter_mean(x, batch, 0, None, batch_size)
+    out = x - mean[batch] * mean_scale
+    var = scatter_mean(out * out, batch, 0, None, batch_size)
+    std = (var + eps).sqrt()[batch]
+    return weight * out / std + bias
+
+
+# --------------------------------------------------------------------------
+# src/utils/scatter.py, src/nn/norm.py, src/nn/unpool.py, src/nn/pool.py
+# --------------------------------------------------------------------------
+
+
+def scatter_mean_weighted(x, idx, w, dim_size=None):
+    """src/utils/scatter.py:17-38."""
+    x = x.view(-1, 1) if x.dim() == 1 else x
+    w = w.view(-1, 1).to(x.dtype)
+    wx = torch.cat((w, x * w), dim=1)
+    seg = scatter_sum(wx, idx, 0, None, dim_size)
+    w_seg = seg[:, 0].clone()
+    w_seg[w_seg == 0] = 1
+    return seg[:, 1:] / w_seg.view(-1, 1)
+
+
+def unit_sphere_norm(pos, idx, w=None, num_super=None, log_diameter=False):
+    """src/nn/norm.py:67-138 (UnitSphereNorm.forward)."""
+    if idx is None:  # norm.py:86-110
+        mn = pos.min(dim=0).values
+        mx = pos.max(dim=0).values
+        diameter = (mx - mn).max()
+        if w is None:
+            center = pos.mean(dim=0)
+        else:
+            ws = w.to(pos.dtype).sum()
+            ws = 1 if ws == 0 else ws
+            center = (pos * w.view(-1, 1).to(pos.dtype)).sum(dim=0) / ws
+        out = (pos - center.view(1, -1)) / (diameter + 1e-2)
+        diameter = diameter.view(1, 1)
+    else:  # norm.py:112-138
+        mn = scatter(pos, idx, 0, None, num_super, "min")
+        mx = scatter(pos, idx, 0, None, num_super, "max")
+        diam_seg = (mx - mn).max(dim=1).values
+        if w is None:
+            center_seg = scatter(pos, idx, 0, None, num_super, "mean")
+        else:
+            center_seg = scatter_mean_weighted(pos, idx, w, num_super)
+        out = (pos - center_seg[idx]) / (diam_seg[idx].view(-1, 1) + 1e-2)
+        diameter = diam_seg.view(-1, 1)
+    if log_diameter:
+        diameter = torch.log(diameter + 1)
+    return out, diameter
+
+
+def pool(x_child, index, num_pool, mode="max"):
+    """src/nn/pool.py:61-82 -> PyG Aggregation.reduce -> scatter."""
+    return scatter(x_child, index, 0, None, num_pool, mode)
+
+
+def index_unpool(x, idx):
+    """src/nn/unpool.py:12-13."""
+    return x.index_select(0, idx)
+
+
+def get_sub_size(super_indices, node_size_low=None):
+    """src/data/nag.py:59-110: chained integer scatter_sum up the hierarchy.
+    ``super_indices[i]`` maps level low+i to low+i+1.  Returns the list of
+    sizes for levels low+1 .. low+len(super_indices)."""
+    out = []
+    si0 = super_indices[0]
+    n1 = int(si0.max()) + 1
+    if node_size_low is not None:
+        sizes = scatter_sum(node_size_low, si0, 0, None, n1)
+    else:
+        sizes = torch.bincount(si0, minlength=n1)
+    out.append(sizes)
+    for si in super_indices[1:]:
+        sizes = scatter_sum(sizes, si, 0, None, int(si.max()) + 1)
+        out.append(sizes)
+    return out
+
+
+# --------------------------------------------------------------------------
+# src/utils/nn.py, src/nn/attention.py
+# --------------------------------------------------------------------------
+
+
+def qk_scale_dg(s, dim, num_heads):
+    """src/utils/nn.py:83-88 (qk_scale=None -> 'd.g')."""
+    D = (dim // num_heads) ** -0.5
+    # int64 ** -0.5 yields the DEFAULT dtype (float32) in the reference, even
+    # when the block itself runs in float64: keep that rounding.
+    G = (s.bincount() ** -0.5)[s].view(-1, 1, 1)
+    return D * G
+
+
+def self_attention(x, edge_index, edge_attr, p, num_heads, qk_dim):
+    """src/nn/attention.py:167-325 for the SPT configuration family
+    (k_rpe/q_rpe/v_rpe Linear on edge_attr, no delta-RPE, no sharing, no
+    dropout, qk_scale=None).  ``p`` maps parameter names to tensors:
+    qkv.weight/bias, k_rpe.*, q_rpe.*, v_rpe.* (each optional), out_proj.*
+    (optional)."""
+    N, E, H, D = x.shape[0], edge_index.shape[1], num_heads, qk_dim
+    DH = D * H
+    qkv = x @ p["qkv.weight"].t()
+    if p.get("qkv.bias") is not None:
+        qkv = qkv + p["qkv.bias"]
+    dim = qkv.shape[1] - 2 * DH
+    q = qkv[:, :DH].view(N, H, D)
+    k = qkv[:, DH:2 * DH].view(N, H, D)
+    v = qkv[:, 2 * DH:].view(N, H, -1)
+    s, t = edge_index[0], edge_index[1]
+    q, k, v = q[s], k[t], v[t]
+    q = q * qk_scale_dg(s, dim, H).to(q.dtype)        # attention.py:214
+
+    def lin(name):
+        y = edge_attr @ p[name + ".weight"].t()
+        if p.get(name + ".bias") is not None:
+            y = y + p[name + ".bias"]
+        return y
+
+    if p.get("k_rpe.weight") is not None and edge_attr is not None:
+        k = k + lin("k_rpe").view(E, H, -1)            # attention.py:225-232
+    if p.get("q_rpe.weight") is not None and edge_attr is not None:
+        q = q + lin("q_rpe").view(E, H, -1)            # attention.py:235-245
+    if p.get("v_rpe.weight") is not None and edge_attr is not None:
+        v = v + lin("v_rpe").view(E, H, -1)            # attention.py:294-301
+    compat = torch.einsum("ehd,ehd->eh", q, k)         # attention.py:304
+    attn = pyg_softmax(compat, s, num_nodes=N)         # attention.py:307
+    out = (v * attn.unsqueeze(-1)).reshape(E, dim)     # attention.py:314
+    out = scatter_sum(out, s, 0, None, N)              # attention.py:315
+    if p.get("out_proj.weight") is not None:           # attention.py:318-319
+        out = out @ p["out_proj.weight"].t() + p["out_proj.bias"]
+    return out
+
+
+# --------------------------------------------------------------------------
+# kNN: src/utils/neighbors.py
+# --------------------------------------------------------------------------
+
+
+def knn_brute_force(x_search, x_query, k, r_max=1.0):
+    """src/utils/neighbors.py:245-295 without batches: full distance matrix,
+    sort, first k, > r_max -> -1.  Ties keep torch.sort's order."""
+    d = (x_search.unsqueeze(0) - x_query.unsqueeze(1)).norm(dim=2)
+    d, nb = d.sort(dim=1, stable=True)
+    d, nb = d[:, :k].clone(), nb[:, :k].clone()
+    mask = d > r_max
+    d[mask] = -1
+    nb[mask] = -1
+    return nb, d
+
+
+def frnn_grid_points(query, search, K, r, strict=True):
+    """Contract of the un-vendored FRNN CUDA extension as the reference uses
+    it (src/utils/neighbors.py:24-48,90) [third-party restated]: for each
+    query the K nearest search points with squared distance < r^2, ascending
+    (ties: ascending index), idx padded with -1 and dists with -1.
+    Distances are SQUARED (pytorch3d convention FRNN inherits).  Computed in
+    float32 exactly like the kernel: d2 = dx*dx + dy*dy + dz*dz, sequential,
+    no fma."""
+    q = query.to(torch.float32)
+    s = search.to(torch.float32)
+    nq = q.shape[0]
+    idx = torch.full((nq, K), -1, dtype=torch.int64)
+    dist = torch.full((nq, K), -1.0, dtype=torch.float32)
+    r2 = np.float32(r) * np.float32(r)
+    sn = s.numpy()
+    chunk = max(1, (1 << 24) // max(1, s.shape[0]))
+    for a in range(0, nq, chunk):
+        qq = q[a:a + chunk].numpy()
+        dx = qq[:, None, 0] - sn[None, :, 0]
+        dy = qq[:, None, 1] - sn[None, :, 1]
+        dz = qq[:, None, 2] - sn[None, :, 2]
+        d2 = (dx * dx + dy * dy) + dz * dz          # float32, same order as kernel
+        ok = d2 < r2 if strict else d2 <= r2
+        d2m = np.where(ok, d2, np.float32(np.inf))
+        order = np.argsort(d2m, axis=1, kind="stable")[:, :K]
+        dsel = np.take_along_axis(d2m, order, axis=1)
+        good = np.isfinite(dsel)
+        kk = order.shape[1]
+        idx[a:a + chunk, :kk] = torch.from_numpy(np.where(good, order, -1))
+        dist[a:a + chunk, :kk] = torch.from_numpy(
+            np.where(good, dsel, np.float32(-1)).astype(np.float32))
+    return dist, idx
+
+
+def knn_1(xyz, k, r_max=1.0, self_is_neighbor=False):
+    """src/utils/neighbors.py:51-123 without batch/oversample: search k+1 and
+    drop column 0 (the point itself at distance 0)."""
+    k_search = k if self_is_neighbor else k + 1
+    dist, idx = frnn_grid_points(xyz, xyz, k_search, r_max)
+    if self_is_neighbor:
+        return idx, dist
+    return idx[:, 1:], dist[:, 1:]
+
+
+def neighbors_dense_to_csr(nn):
+    """src/utils/neighbors.py:668-684."""
+    k = nn.shape[1]
+    mask = nn < 0
+    sizes = k - mask.sum(dim=1)
+    ptr = torch.zeros(nn.shape[0] + 1, dtype=torch.int64)
+    ptr[1:] = sizes.cumsum(0)
+    return ptr, nn[~mask], sizes
+
+
+# --------------------------------------------------------------------------
+# geometric features: src/utils/scatter.py:41-125, src/utils/geometry.py
+# --------------------------------------------------------------------------
+
+
+def scatter_pca(x, idx, num_groups=None):
+    """src/utils/scatter.py:41-125 (algorithm='eigh'): population covariance
+    of each group, eigh(UPLO='U'), ascending eigenvalues, NaN -> (1,1,1)/I,
+    eigenvalues clamped at 0."""
+    n = _dim_size(idx, num_groups)
+    mean = scatter_mean(x, idx, 0, None, n)
+    xc = x - mean[idx]
+    ij = [(0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2)]
+    ut = torch.stack([xc[:, i] * xc[:, j] for i, j in ij], dim=1)
+    sizes = torch.bincount(idx, minlength=n)
+    ut = scatter_sum(ut, idx, 0, None, n) / sizes.view(-1, 1).to(x.dtype)
+    cov = torch.zeros((n, 3, 3), dtype=x.dtype)
+    for c, (i, j) in enumerate(ij):
+        cov[:, i, j] = ut[:, c]
+        cov[:, j, i] = ut[:, c]
+    bad = torch.isnan(cov).flatten(1).any(1)
+    cov[bad] = torch.eye(3, dtype=x.dtype)
+    val, vec = torch.linalg.eigh(cov, UPLO="U")
+    val[bad] = 1.0
+    vec[bad] = torch.eye(3, dtype=x.dtype)
+    return val.clamp(min=0), vec
+
+
+def geometric_features(xyz, nn, k_min=1, add_self_as_neighbor=True):
+    """src/utils/geometry.py:80-126 + :236-338 with k_step=-1 (the dataset
+    configs' setting, configs/datamodule/semantic/default.yaml:121-127):
+    returns f32[N,11] in pgeof's column order (geometry.py:165-174)
+    [lin, plan, scat, vert, nx, ny, nz, length, surface, volume, curvature]
+    AFTER the post-processing of geometry.py:121,124 (verticality*2, normal
+    flipped to z>=0)."""
+    N = xyz.shape[0]
+    if add_self_as_neighbor:                                   # geometry.py:95-96
+        nn = torch.cat((torch.arange(N).view(-1, 1), nn), dim=1)
+    ptr, val, sizes = neighbors_dense_to_csr(nn)               # geometry.py:347
+    idx = torch.repeat_interleave(torch.arange(N), ptr[1:] - ptr[:-1])
+    eigenval, eigenvec = scatter_pca(xyz[val], idx, N)         # geometry.py:354
+    normal = eigenvec[:, :, 0].clone()                         # geometry.py:290
+    l1 = eigenval[:, 2].sqrt()
+    l2 = eigenval[:, 1].sqrt()
+    l3 = eigenval[:, 0].sqrt()
+    lin = (l1 - l2) / (l1 + 1e-3)                              # geometry.py:300-306
+    plan = (l2 - l3) / (l1 + 1e-3)
+    scat = l3 / (l1 + 1e-3)
+    length = l1
+    surface = (l1 * l2 + 1e-6).sqrt()
+    volume = (l1 * l2 * l3 + 1e-9).pow(1 / 3)
+    curv = l3 / (l1 + l2 + l3 + 1e-3)
+    unary = (eigenvec.abs() * eigenval.unsqueeze(1)).sum(dim=2)  # geometry.py:308
+    vert = unary[:, 2] / (unary.norm(dim=1) + 1e-8)
+    small = sizes < k_min                                      # geometry.py:312-321
+    f = torch.stack([lin, plan, scat, vert, normal[:, 0], normal[:, 1],
+                     normal[:, 2], length, surface, volume, curv], dim=1)
+    f[small] = 0
+    f[:, 3] *= 2                                               # geometry.py:121
+    flip = f[:, 6] < 0                                         # geometry.py:124
+    f[flip, 4:7] *= -1
+    return f

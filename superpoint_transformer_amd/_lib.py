@@ -1,0 +1,75 @@
+"""ctypes binding of libspt_hip.so (C ABI declared in include/spt_hip.h).
+
+The library is the product: there is NO CPU or PyTorch fallback.  Importing
+this module without the built shared object raises, and every wrapper raises
+``RuntimeError`` with ``spt_last_error()`` on a non-zero status.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (loads torch's libamdhip64.so.7 first so ours binds to it)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libspt_hip.so")
+
+_c = ctypes
+_i64 = _c.c_int64
+_int = _c.c_int
+_p = _c.c_void_p
+_sz = _c.c_size_t
+
+# name -> (restype, argtypes).  Must list EVERY symbol of include/spt_hip.h:
+# tests/test_abi.py parses the header and checks both directions.
+SIGNATURES = {
+    "spt_version": (_int, []),
+    "spt_last_error": (_c.c_char_p, []),
+    "spt_csr_build_workspace_bytes": (_sz, [_i64, _i64]),
+    "spt_csr_build": (_int, [_p, _i64, _i64, _p, _p, _p, _sz, _p]),
+    "spt_segcsr_reduce_f32": (_int, [_int, _p, _p, _p, _i64, _i64, _int, _p, _p, _p]),
+    "spt_segcsr_reduce_bwd_f32": (_int, [_int, _p, _p, _p, _p, _i64, _i64, _int, _p, _p]),
+    "spt_segcsr_sum_i64": (_int, [_p, _p, _p, _i64, _i64, _int, _p, _p]),
+    "spt_gather_rows_f32": (_int, [_p, _p, _i64, _i64, _int, _p, _p]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` (hipcc --offload-arch=gfx950). There is no fallback path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a symbol
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def last_error():
+    return lib.spt_last_error().decode("utf-8", "replace")
+
+
+def check(status, what):
+    if status != 0:
+        raise RuntimeError(f"{what} failed ({status}): {last_error()}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (or None)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr(device=None):
+    """hipStream_t of torch's current stream, as an integer."""
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "superpoint_transformer_amd ops run on the MI355X only: got a "
+                f"{t.device} tensor (no CPU fallback is provided)")

@@ -1,0 +1,81 @@
+"""CSR views of unsorted segment indices, built once and reused.
+
+The reference regroups rows by index inside every torch_scatter call
+(src/nn/pool.py:61-62, src/nn/norm.py:118-126, src/nn/attention.py:307-315).
+Here ``csr_of(index, num_seg)`` runs the device radix sort
+(`spt_csr_build`) once and memoises the result ON the index tensor object, so
+the pool, UnitSphereNorm, unpool-backward and softmax-group uses of one
+``super_index`` share it.  The memo is invalidated by in-place edits
+(``Tensor._version``) and dies with the tensor object - it is never keyed on
+``data_ptr`` alone (the caching allocator recycles addresses).
+"""
+import torch
+
+from . import _lib
+
+_ATTR = "_spt_csr_memo"
+
+
+class SegmentCSR:
+    """(perm, rowptr) view of ``idx``: rows of segment ``s`` are
+    ``perm[rowptr[s]:rowptr[s+1]]`` in ascending original order."""
+
+    __slots__ = ("idx", "perm", "rowptr", "n", "num_seg")
+
+    def __init__(self, idx, perm, rowptr, n, num_seg):
+        self.idx = idx
+        self.perm = perm
+        self.rowptr = rowptr
+        self.n = n
+        self.num_seg = num_seg
+
+    def counts(self):
+        return (self.rowptr[1:] - self.rowptr[:-1])
+
+
+def build_csr(idx, num_seg):
+    """Run the device sort. ``idx``: int64 [n] on the GPU, values in [0, num_seg)."""
+    _lib.require_cuda(idx)
+    if idx.dim() != 1:
+        raise ValueError("segment index must be 1-D")
+    if idx.dtype != torch.int64:
+        idx = idx.long()
+    idx = idx.contiguous()
+    n = idx.numel()
+    num_seg = int(num_seg)
+    if num_seg < 1:
+        num_seg = 1
+    dev = idx.device
+    perm = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    rowptr = torch.empty(num_seg + 1, dtype=torch.int32, device=dev)
+    ws_bytes = _lib.lib.spt_csr_build_workspace_bytes(n, num_seg)
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        st = _lib.lib.spt_csr_build(
+            _lib.ptr(idx), n, num_seg, _lib.ptr(perm), _lib.ptr(rowptr),
+            _lib.ptr(ws), ws_bytes, _lib.stream_ptr(dev))
+    _lib.check(st, "spt_csr_build")
+    return SegmentCSR(idx, perm[:n], rowptr, n, num_seg)
+
+
+def csr_of(idx, num_seg=None):
+    """Memoised CSR of ``idx``.  ``num_seg=None`` costs a host sync
+    (``idx.max()+1``), exactly like torch_scatter's ``dim_size=None``."""
+    if isinstance(idx, SegmentCSR):
+        return idx
+    if num_seg is None:
+        num_seg = int(idx.max().item()) + 1 if idx.numel() > 0 else 1
+    num_seg = max(int(num_seg), 1)
+    memo = getattr(idx, _ATTR, None)
+    key = (idx._version, num_seg, idx.data_ptr(), idx.numel())
+    if memo is not None and key in memo:
+        return memo[key]
+    csr = build_csr(idx, num_seg)
+    if memo is None or any(k[0] != idx._version for k in memo):
+        memo = {}
+        try:
+            setattr(idx, _ATTR, memo)
+        except Exception:  # tensors that refuse attributes: just don't cache
+            return csr
+    memo[key] = csr
+    return csr

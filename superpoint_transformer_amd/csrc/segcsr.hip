@@ -1,0 +1,414 @@
+// Segment reduce over a CSR view (sum / mean / min / max, optional arg) and its
+// backward, plus the row gather that is both IndexUnpool's forward and the
+// backward of a segment sum.  gfx950: wave64, 16-byte lane accesses, one
+// sub-wave lane group per segment, shuffle tree across the group, no atomics.
+//
+// Reference semantics restated from torch_scatter (un-vendored; call sites
+// src/nn/pool.py:61-82, src/nn/norm.py:118-126, src/nn/unpool.py:12-13):
+// empty segment -> 0 (arg = n), mean divides by max(count,1), min/max gradient
+// goes to the arg element only, ties -> first occurrence (CPU kernel rule).
+#include <math.h>
+
+#include "common.hpp"
+
+namespace spt {
+
+template <int VEC>
+struct Vec;
+template <>
+struct Vec<1> {
+  float v[1];
+};
+template <>
+struct Vec<2> {
+  float v[2];
+};
+template <>
+struct Vec<4> {
+  float v[4];
+};
+
+template <int VEC>
+__device__ __forceinline__ Vec<VEC> ldv(const float* __restrict__ p) {
+  Vec<VEC> r;
+  if constexpr (VEC == 4) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
+  } else if constexpr (VEC == 2) {
+    const float2 t = *reinterpret_cast<const float2*>(p);
+    r.v[0] = t.x; r.v[1] = t.y;
+  } else {
+    r.v[0] = *p;
+  }
+  return r;
+}
+
+template <int VEC>
+__device__ __forceinline__ void stv(float* __restrict__ p, const Vec<VEC>& r) {
+  if constexpr (VEC == 4) {
+    *reinterpret_cast<float4*>(p) = make_float4(r.v[0], r.v[1], r.v[2], r.v[3]);
+  } else if constexpr (VEC == 2) {
+    *reinterpret_cast<float2*>(p) = make_float2(r.v[0], r.v[1]);
+  } else {
+    *p = r.v[0];
+  }
+}
+
+template <int VEC>
+__device__ __forceinline__ void sti(int32_t* __restrict__ p, const int32_t (&a)[VEC]) {
+  if constexpr (VEC == 4) {
+    *reinterpret_cast<int4*>(p) = make_int4(a[0], a[1], a[2], a[3]);
+  } else if constexpr (VEC == 2) {
+    *reinterpret_cast<int2*>(p) = make_int2(a[0], a[1]);
+  } else {
+    *p = a[0];
+  }
+}
+
+template <int OP>
+__device__ __forceinline__ float op_identity() {
+  if constexpr (OP == SPT_MIN) return INFINITY;
+  if constexpr (OP == SPT_MAX) return -INFINITY;
+  return 0.f;
+}
+
+// combine (v, r) into (acc, accr); r = original row index of v
+template <int OP, bool ARG>
+__device__ __forceinline__ void combine(float& acc, int32_t& accr, float v, int32_t r) {
+  if constexpr (OP == SPT_SUM || OP == SPT_MEAN) {
+    acc += v;
+  } else if constexpr (OP == SPT_MAX) {
+    if constexpr (ARG) {
+      const bool take = (v > acc) || (v == acc && r < accr);
+      acc = take ? v : acc;
+      accr = take ? r : accr;
+    } else {
+      acc = (v > acc) ? v : acc;
+    }
+  } else {
+    if constexpr (ARG) {
+      const bool take = (v < acc) || (v == acc && r < accr);
+      acc = take ? v : acc;
+      accr = take ? r : accr;
+    } else {
+      acc = (v < acc) ? v : acc;
+    }
+  }
+}
+
+// One lane group of G = LPR*RPG lanes per segment: LPR lanes span the channels
+// of a row (VEC floats each), RPG rows are in flight side by side, UNR deep.
+template <int OP, int VEC, bool ARG>
+__global__ __launch_bounds__(256) void segcsr_reduce_kernel(
+    const float* __restrict__ x, const int32_t* __restrict__ perm,
+    const int32_t* __restrict__ rowptr, int64_t n, int64_t num_seg, int c,
+    int lpr_log2, int rpg_log2, float* __restrict__ out,
+    int32_t* __restrict__ arg) {
+  constexpr int UNR = 4;
+  const int lane = threadIdx.x & 63;
+  const int g_log2 = lpr_log2 + rpg_log2;
+  const int lpr = 1 << lpr_log2;
+  const int rpg = 1 << rpg_log2;
+  const int spw = 64 >> g_log2;  // segments per wave
+  const int slot = lane >> g_log2;
+  const int lg = lane & ((1 << g_log2) - 1);
+  const int rsub = lg >> lpr_log2;
+  const int lr = lg & (lpr - 1);
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  const int ctile = lpr * VEC;
+
+  for (int64_t sbase = wave * spw; sbase < num_seg; sbase += nwaves * spw) {
+    const int64_t s = sbase + slot;
+    const bool sv = s < num_seg;
+    const int start = sv ? rowptr[s] : 0;
+    const int end = sv ? rowptr[s + 1] : 0;
+    for (int cb = 0; cb < c; cb += ctile) {
+      const int c0 = cb + lr * VEC;
+      const bool cv = c0 < c;
+      float acc[VEC];
+      int32_t accr[VEC];
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        acc[k] = op_identity<OP>();
+        accr[k] = 0x7fffffff;
+      }
+      for (int j = start + rsub; j < end; j += rpg * UNR) {
+        int32_t r[UNR];
+        Vec<VEC> v[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          const int jj = j + u * rpg;
+          r[u] = (jj < end) ? (perm ? perm[jj] : jj) : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+          if (r[u] >= 0 && cv) v[u] = ldv<VEC>(x + (int64_t)r[u] * c + c0);
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+          if (r[u] >= 0 && cv) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) combine<OP, ARG>(acc[k], accr[k], v[u].v[k], r[u]);
+          }
+      }
+      // tree across the RPG row slots of the group
+      for (int o = lpr; o < (1 << g_log2); o <<= 1) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+          const float ov = __shfl_xor(acc[k], o, 64);
+          if constexpr (ARG) {
+            const int32_t orr = __shfl_xor(accr[k], o, 64);
+            combine<OP, ARG>(acc[k], accr[k], ov, orr);
+          } else {
+            int32_t dummy = 0;
+            combine<OP, false>(acc[k], dummy, ov, 0);
+          }
+        }
+      }
+      if (sv && cv && rsub == 0) {
+        const int cnt = end - start;
+        Vec<VEC> o;
+        int32_t oa[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+          float val = acc[k];
+          if constexpr (OP == SPT_MEAN) val = val / (float)(cnt > 0 ? cnt : 1);
+          if constexpr (OP == SPT_MIN || OP == SPT_MAX) val = (cnt > 0) ? val : 0.f;
+          o.v[k] = val;
+          oa[k] = (cnt > 0 && accr[k] != 0x7fffffff) ? accr[k] : (int32_t)n;
+        }
+        stv<VEC>(out + s * c + c0, o);
+        if constexpr (ARG) sti<VEC>(arg + s * c + c0, oa);
+      }
+    }
+  }
+}
+
+// Row-parallel "gather with modifier":
+//   MODE 0: out[i,:] = src[idx[i],:]                      (gather / sum bwd)
+//   MODE 1: out[i,:] = src[idx[i],:] / max(count[idx[i]],1)   (mean bwd)
+//   MODE 2: out[i,c] = arg[idx[i],c]==i ? src[idx[i],c] : 0   (min/max bwd)
+template <int MODE, int VEC>
+__global__ __launch_bounds__(256) void gather_mod_kernel(
+    const float* __restrict__ src, const int32_t* __restrict__ arg,
+    const int64_t* __restrict__ idx, const int32_t* __restrict__ rowptr,
+    int64_t n, int c, int lpr_log2, float* __restrict__ out) {
+  constexpr int UNR = 4;
+  const int lane = threadIdx.x & 63;
+  const int lpr = 1 << lpr_log2;
+  const int rpw = 64 >> lpr_log2;  // rows per wave-instruction
+  const int rsub = lane >> lpr_log2;
+  const int lr = lane & (lpr - 1);
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  const int ctile = lpr * VEC;
+  for (int64_t rb = wave * rpw * UNR; rb < n; rb += nwaves * rpw * UNR) {
+    int64_t row[UNR];
+    int64_t p[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      row[u] = rb + u * rpw + rsub;
+      p[u] = (row[u] < n) ? idx[row[u]] : -1;
+    }
+    for (int cb = 0; cb < c; cb += ctile) {
+      const int c0 = cb + lr * VEC;
+      if (c0 >= c) continue;
+      Vec<VEC> v[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u)
+        if (p[u] >= 0) v[u] = ldv<VEC>(src + p[u] * c + c0);
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        if (p[u] < 0) continue;
+        if constexpr (MODE == 1) {
+          const int cnt = rowptr[p[u] + 1] - rowptr[p[u]];
+          const float d = (float)(cnt > 0 ? cnt : 1);
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) v[u].v[k] = v[u].v[k] / d;
+        }
+        if constexpr (MODE == 2) {
+#pragma unroll
+          for (int k = 0; k < VEC; ++k) {
+            const int32_t a = arg[p[u] * c + c0 + k];
+            v[u].v[k] = (a == (int32_t)row[u]) ? v[u].v[k] : 0.f;
+          }
+        }
+        stv<VEC>(out + row[u] * c + c0, v[u]);
+      }
+    }
+  }
+}
+
+__global__ void segcsr_sum_i64_kernel(const int64_t* __restrict__ x,
+                                      const int32_t* __restrict__ perm,
+                                      const int32_t* __restrict__ rowptr,
+                                      int64_t num_seg, int c,
+                                      int64_t* __restrict__ out) {
+  const int64_t total = num_seg * c;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const int64_t s = t / c;
+    const int ch = (int)(t - s * c);
+    int64_t acc = 0;
+    for (int j = rowptr[s]; j < rowptr[s + 1]; ++j) {
+      const int64_t r = perm ? perm[j] : j;
+      acc += x[r * c + ch];
+    }
+    out[t] = acc;
+  }
+}
+
+static inline int log2_floor(int64_t v) {
+  int b = 0;
+  while ((((int64_t)1) << (b + 1)) <= v) ++b;
+  return b;
+}
+static inline int log2_ceil(int64_t v) {
+  int b = 0;
+  while ((((int64_t)1) << b) < v) ++b;
+  return b;
+}
+
+struct RowShape {
+  int vec, lpr_log2;
+};
+static RowShape row_shape(int c) {
+  RowShape r;
+  r.vec = (c % 4 == 0) ? 4 : (c % 2 == 0) ? 2 : 1;
+  int lanes = c / r.vec;
+  if (lanes > 64) lanes = 64;
+  r.lpr_log2 = log2_ceil(lanes);
+  return r;
+}
+
+template <int OP, int VEC>
+static void launch_reduce(bool want_arg, const float* x, const int32_t* perm,
+                          const int32_t* rowptr, int64_t n, int64_t num_seg, int c,
+                          int lpr_log2, int rpg_log2, float* out, int32_t* arg,
+                          hipStream_t stream) {
+  const int spw = 64 >> (lpr_log2 + rpg_log2);
+  const int grid = stream_grid(ceil_div(num_seg, spw), 4);
+  if constexpr (OP == SPT_MIN || OP == SPT_MAX) {
+    if (want_arg) {
+      segcsr_reduce_kernel<OP, VEC, true><<<grid, 256, 0, stream>>>(
+          x, perm, rowptr, n, num_seg, c, lpr_log2, rpg_log2, out, arg);
+      return;
+    }
+  }
+  segcsr_reduce_kernel<OP, VEC, false><<<grid, 256, 0, stream>>>(
+      x, perm, rowptr, n, num_seg, c, lpr_log2, rpg_log2, out, arg);
+}
+
+template <int OP>
+static void launch_reduce_vec(int vec, bool want_arg, const float* x,
+                              const int32_t* perm, const int32_t* rowptr, int64_t n,
+                              int64_t num_seg, int c, int lpr_log2, int rpg_log2,
+                              float* out, int32_t* arg, hipStream_t stream) {
+  if (vec == 4)
+    launch_reduce<OP, 4>(want_arg, x, perm, rowptr, n, num_seg, c, lpr_log2, rpg_log2, out, arg, stream);
+  else if (vec == 2)
+    launch_reduce<OP, 2>(want_arg, x, perm, rowptr, n, num_seg, c, lpr_log2, rpg_log2, out, arg, stream);
+  else
+    launch_reduce<OP, 1>(want_arg, x, perm, rowptr, n, num_seg, c, lpr_log2, rpg_log2, out, arg, stream);
+}
+
+template <int MODE>
+static void launch_gather(int vec, const float* src, const int32_t* arg,
+                          const int64_t* idx, const int32_t* rowptr, int64_t n, int c,
+                          int lpr_log2, float* out, hipStream_t stream) {
+  const int rpw = 64 >> lpr_log2;
+  const int grid = stream_grid(ceil_div(n, (int64_t)rpw * 4), 4);
+  if (vec == 4)
+    gather_mod_kernel<MODE, 4><<<grid, 256, 0, stream>>>(src, arg, idx, rowptr, n, c, lpr_log2, out);
+  else if (vec == 2)
+    gather_mod_kernel<MODE, 2><<<grid, 256, 0, stream>>>(src, arg, idx, rowptr, n, c, lpr_log2, out);
+  else
+    gather_mod_kernel<MODE, 1><<<grid, 256, 0, stream>>>(src, arg, idx, rowptr, n, c, lpr_log2, out);
+}
+
+}  // namespace spt
+
+using namespace spt;
+
+extern "C" int spt_segcsr_reduce_f32(int op, const float* x, const int32_t* perm,
+                                     const int32_t* rowptr, int64_t n,
+                                     int64_t num_seg, int c, float* out,
+                                     int32_t* arg, spt_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPT_CHECK_ARG(op >= SPT_SUM && op <= SPT_MAX, "unknown op");
+  SPT_CHECK_ARG(n >= 0 && num_seg >= 0 && c >= 1, "bad shape");
+  SPT_CHECK_ARG(rowptr && out && (x || n == 0), "null pointer");
+  if (num_seg == 0) return 0;
+  const RowShape rs = row_shape(c);
+  // rows in flight per segment: aim at >= 4 rows per lane slot
+  const int64_t avg = (num_seg > 0) ? n / num_seg : 0;
+  int rpg_log2 = log2_floor(avg / 4 > 1 ? avg / 4 : 1);
+  if (rpg_log2 > 6 - rs.lpr_log2) rpg_log2 = 6 - rs.lpr_log2;
+  const bool want_arg = arg != nullptr;
+  switch (op) {
+    case SPT_SUM:
+      launch_reduce_vec<SPT_SUM>(rs.vec, false, x, perm, rowptr, n, num_seg, c, rs.lpr_log2, rpg_log2, out, arg, stream);
+      break;
+    case SPT_MEAN:
+      launch_reduce_vec<SPT_MEAN>(rs.vec, false, x, perm, rowptr, n, num_seg, c, rs.lpr_log2, rpg_log2, out, arg, stream);
+      break;
+    case SPT_MIN:
+      launch_reduce_vec<SPT_MIN>(rs.vec, want_arg, x, perm, rowptr, n, num_seg, c, rs.lpr_log2, rpg_log2, out, arg, stream);
+      break;
+    default:
+      launch_reduce_vec<SPT_MAX>(rs.vec, want_arg, x, perm, rowptr, n, num_seg, c, rs.lpr_log2, rpg_log2, out, arg, stream);
+      break;
+  }
+  SPT_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int spt_segcsr_reduce_bwd_f32(int op, const float* gout,
+                                         const int32_t* arg, const int64_t* idx,
+                                         const int32_t* rowptr, int64_t n,
+                                         int64_t num_seg, int c, float* gx,
+                                         spt_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPT_CHECK_ARG(op >= SPT_SUM && op <= SPT_MAX, "unknown op");
+  SPT_CHECK_ARG(n >= 0 && num_seg >= 0 && c >= 1, "bad shape");
+  if (n == 0) return 0;
+  SPT_CHECK_ARG(gout && idx && gx, "null pointer");
+  const RowShape rs = row_shape(c);
+  if (op == SPT_SUM) {
+    launch_gather<0>(rs.vec, gout, nullptr, idx, nullptr, n, c, rs.lpr_log2, gx, stream);
+  } else if (op == SPT_MEAN) {
+    SPT_CHECK_ARG(rowptr, "mean backward needs rowptr");
+    launch_gather<1>(rs.vec, gout, nullptr, idx, rowptr, n, c, rs.lpr_log2, gx, stream);
+  } else {
+    SPT_CHECK_ARG(arg, "min/max backward needs arg");
+    launch_gather<2>(rs.vec, gout, arg, idx, nullptr, n, c, rs.lpr_log2, gx, stream);
+  }
+  SPT_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int spt_gather_rows_f32(const float* x, const int64_t* idx, int64_t n,
+                                   int64_t num_src, int c, float* out,
+                                   spt_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPT_CHECK_ARG(n >= 0 && num_src >= 0 && c >= 1, "bad shape");
+  if (n == 0) return 0;
+  SPT_CHECK_ARG(x && idx && out, "null pointer");
+  const RowShape rs = row_shape(c);
+  launch_gather<0>(rs.vec, x, nullptr, idx, nullptr, n, c, rs.lpr_log2, out, stream);
+  SPT_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int spt_segcsr_sum_i64(const int64_t* x, const int32_t* perm,
+                                  const int32_t* rowptr, int64_t n, int64_t num_seg,
+                                  int c, int64_t* out, spt_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPT_CHECK_ARG(n >= 0 && num_seg >= 0 && c >= 1, "bad shape");
+  if (num_seg == 0) return 0;
+  SPT_CHECK_ARG(rowptr && out && (x || n == 0), "null pointer");
+  segcsr_sum_i64_kernel<<<stream_grid(num_seg * c, 256), 256, 0, stream>>>(
+      x, perm, rowptr, num_seg, c, out);
+  SPT_CHECK_LAUNCH();
+  return 0;
+}

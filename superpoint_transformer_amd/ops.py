@@ -1,0 +1,146 @@
+"""Functional, differentiable front-ends of the HIP segment kernels.
+
+Every function here launches a kernel of libspt_hip.so on torch's current
+stream; there is no eager-PyTorch path.
+"""
+import torch
+
+from . import _lib
+from .csr import SegmentCSR, csr_of
+
+_OPS = {"sum": 0, "add": 0, "mean": 1, "min": 2, "max": 3}
+
+
+def _as_rows(x):
+    """[n, ...] -> contiguous, 16B-aligned f32 [n, c] plus the trailing shape."""
+    tail = x.shape[1:]
+    x2 = x.reshape(x.shape[0], -1)
+    if x2.dtype != torch.float32:
+        x2 = x2.float()
+    x2 = x2.contiguous()
+    if x2.data_ptr() % 16:
+        x2 = x2.clone()
+    return x2, tail
+
+
+def _seg_reduce_fwd(x2, csr, op, want_arg):
+    n, c = x2.shape
+    out = torch.empty((csr.num_seg, c), dtype=torch.float32, device=x2.device)
+    arg = None
+    if want_arg and op in (2, 3):
+        arg = torch.empty((csr.num_seg, c), dtype=torch.int32, device=x2.device)
+    with torch.cuda.device(x2.device):
+        st = _lib.lib.spt_segcsr_reduce_f32(
+            op, _lib.ptr(x2), _lib.ptr(csr.perm), _lib.ptr(csr.rowptr), n,
+            csr.num_seg, c, _lib.ptr(out), _lib.ptr(arg), _lib.stream_ptr(x2.device))
+    _lib.check(st, "spt_segcsr_reduce_f32")
+    return out, arg
+
+
+def _seg_reduce_bwd(gout, arg, csr, op, n):
+    c = gout.shape[1]
+    gx = torch.empty((n, c), dtype=torch.float32, device=gout.device)
+    with torch.cuda.device(gout.device):
+        st = _lib.lib.spt_segcsr_reduce_bwd_f32(
+            op, _lib.ptr(gout), _lib.ptr(arg), _lib.ptr(csr.idx),
+            _lib.ptr(csr.rowptr), n, csr.num_seg, c, _lib.ptr(gx),
+            _lib.stream_ptr(gout.device))
+    _lib.check(st, "spt_segcsr_reduce_bwd_f32")
+    return gx
+
+
+def _gather_fwd(x2, idx):
+    n = idx.numel()
+    c = x2.shape[1]
+    out = torch.empty((n, c), dtype=torch.float32, device=x2.device)
+    with torch.cuda.device(x2.device):
+        st = _lib.lib.spt_gather_rows_f32(
+            _lib.ptr(x2), _lib.ptr(idx), n, x2.shape[0], c, _lib.ptr(out),
+            _lib.stream_ptr(x2.device))
+    _lib.check(st, "spt_gather_rows_f32")
+    return out
+
+
+class _SegmentReduce(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, csr, op, want_arg):
+        _lib.require_cuda(x)
+        x2, tail = _as_rows(x)
+        if x2.shape[0] != csr.n:
+            raise ValueError(
+                f"src has {x2.shape[0]} rows but the index has {csr.n}")
+        need_arg = op in (2, 3) and (want_arg or x.requires_grad)
+        out, arg = _seg_reduce_fwd(x2, csr, op, need_arg)
+        ctx.csr, ctx.op, ctx.n, ctx.tail, ctx.in_dtype = csr, op, x2.shape[0], tail, x.dtype
+        ctx.save_for_backward(arg)
+        out = out.reshape((csr.num_seg,) + tuple(tail)).to(x.dtype)
+        if arg is not None:
+            arg_out = arg.reshape((csr.num_seg,) + tuple(tail))
+            ctx.mark_non_differentiable(arg_out)
+            return out, arg_out
+        return out, None
+
+    @staticmethod
+    def backward(ctx, gout, _garg):
+        (arg,) = ctx.saved_tensors
+        g2, _ = _as_rows(gout)
+        gx = _seg_reduce_bwd(g2, arg, ctx.csr, ctx.op, ctx.n)
+        return gx.reshape((ctx.n,) + tuple(ctx.tail)).to(ctx.in_dtype), None, None, None
+
+
+class _GatherRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, idx, csr_holder):
+        _lib.require_cuda(x, idx)
+        x2, tail = _as_rows(x)
+        if idx.dtype != torch.int64:
+            idx = idx.long()
+        idx = idx.contiguous()
+        ctx.idx, ctx.holder = idx, csr_holder
+        ctx.num_src, ctx.tail, ctx.in_dtype = x2.shape[0], tail, x.dtype
+        out = _gather_fwd(x2, idx)
+        return out.reshape((idx.numel(),) + tuple(tail)).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, gout):
+        g2, _ = _as_rows(gout)
+        # backward of a gather is a segment sum over the CSR view of idx
+        csr = csr_of(ctx.holder if ctx.holder is not None else ctx.idx, ctx.num_src)
+        gx, _ = _seg_reduce_fwd(g2, csr, 0, False)
+        return gx.reshape((ctx.num_src,) + tuple(ctx.tail)).to(ctx.in_dtype), None, None
+
+
+def segment_reduce(x, index, num_seg=None, reduce="sum", return_arg=False):
+    """out[s] = reduce_{i: index[i]==s} x[i] along dim 0 (empty -> 0).
+
+    ``index`` is an int64 [n] tensor or a prebuilt :class:`SegmentCSR`.
+    For min/max and ``return_arg=True`` also returns the int32 arg rows
+    (``n`` for empty segments).
+    """
+    op = _OPS[reduce]
+    csr = csr_of(index, num_seg)
+    out, arg = _SegmentReduce.apply(x, csr, op, return_arg)
+    if return_arg:
+        return out, arg
+    return out
+
+
+def gather_rows(x, idx):
+    """out[i] = x[idx[i]]  (IndexUnpool forward; backward = segment sum)."""
+    return _GatherRows.apply(x, idx, idx)
+
+
+def segment_sum_i64(x, index, num_seg=None):
+    """Bit-exact int64 segment sum (NAG.get_sub_size chain)."""
+    _lib.require_cuda(x)
+    csr = csr_of(index, num_seg)
+    tail = x.shape[1:]
+    x2 = x.reshape(x.shape[0], -1).long().contiguous()
+    c = x2.shape[1]
+    out = torch.empty((csr.num_seg, c), dtype=torch.int64, device=x.device)
+    with torch.cuda.device(x.device):
+        st = _lib.lib.spt_segcsr_sum_i64(
+            _lib.ptr(x2), _lib.ptr(csr.perm), _lib.ptr(csr.rowptr), x2.shape[0],
+            csr.num_seg, c, _lib.ptr(out), _lib.stream_ptr(x.device))
+    _lib.check(st, "spt_segcsr_sum_i64")
+    return out.reshape((csr.num_seg,) + tuple(tail))
