@@ -1,0 +1,132 @@
+"""Seeded synthetic NAGs of S3DIS / DALES shape (bench + large-scale tests).
+
+Recipe of SURVEY.md section 8(d), with the ratios measured on the reference's
+demo room (notebooks/demo_nag_v3.h5): |P0|/|P1| = 34.87, |P1|/|P2| = 2.38;
+level-0 -> level-1 segment sizes ~ clip(round(LogNormal(3.04, 1.0)), 1, 300);
+upper levels 1 + Geometric; directed+self-loop degree ~ N(16.4, 5.8) at level
+1 and N(30, 9) at level 2.  Level-0 rows are SHUFFLED so that ``super_index``
+is unsorted like the reference's (12 705 runs for 1 192 segments in the demo
+room), and edge targets are non-local (median |s-t| ~ 0.23 N in the demo).
+
+Everything is generated with torch on the requested device from one seed, so
+every rank / run sees the same scene for the same (seed, sizes).
+"""
+import math
+
+import torch
+
+SCENES = {
+    # name: (N0, N1, N2, E1, E2, num_clouds)
+    "R": (41_568, 1_192, 501, 19_508, 14_965, 1),          # demo room shape
+    "T": (1_200_000, 35_000, 14_500, 575_000, 435_000, 4),  # S3DIS train batch
+    "S": (15_000_000, 428_571, 178_571, 7_030_000, 5_340_000, 1),  # full scene
+    "D": (12_000_000, 342_857, 142_857, 5_620_000, 4_270_000, 1),  # DALES tile
+}
+
+
+def _segment_sizes(gen, n_child, n_parent, kind, device):
+    """Positive integer sizes summing to n_child over n_parent segments."""
+    if kind == "lognormal":
+        z = torch.randn(n_parent, generator=gen, device=device)
+        s = torch.exp(3.04 + 1.0 * z).round().clamp_(1, 300)
+    else:
+        mean = n_child / n_parent
+        u = torch.rand(n_parent, generator=gen, device=device).clamp_(1e-9, 1 - 1e-9)
+        p = 1.0 / max(mean, 1.0 + 1e-6)
+        s = 1 + torch.floor(torch.log(u) / math.log(1 - p + 1e-12))
+    s = s.long()
+    # rescale proportionally (floor) so that the total never exceeds n_child,
+    # every segment keeps >= 1 row, then hand out the remainder at random
+    extra = s - 1
+    tot = int(extra.sum())
+    want = n_child - n_parent
+    assert want >= 0, "need at least one child per parent"
+    if tot > 0:
+        extra = (extra.double() * (want / tot)).floor().long()
+    s = 1 + extra
+    diff = n_child - int(s.sum())
+    if diff > 0:
+        add = torch.randint(0, n_parent, (diff,), generator=gen, device=device)
+        s = s + torch.bincount(add, minlength=n_parent)
+    assert int(s.sum()) == n_child and int(s.min()) >= 1
+    return s
+
+
+def _super_index(gen, n_child, n_parent, kind, device, shuffle):
+    sizes = _segment_sizes(gen, n_child, n_parent, kind, device)
+    idx = torch.repeat_interleave(torch.arange(n_parent, device=device), sizes)
+    if shuffle:
+        idx = idx[torch.randperm(n_child, generator=gen, device=device)]
+    return idx
+
+
+def _edges(gen, n, e_target, deg_mean, deg_std, device):
+    """[2,E] directed edges incl. both directions and self loops, in the
+    reference's final layout [i<j | j>i | loops] (transforms/graph.py:1268,
+    :1442-1446): row 0 (source = softmax group) is unsorted."""
+    m = max((e_target - n) // 2, 0)
+    a = torch.randint(0, n, (m,), generator=gen, device=device)
+    b = torch.randint(0, n, (m,), generator=gen, device=device)
+    keep = a != b
+    a, b = a[keep], b[keep]
+    lo, hi = torch.minimum(a, b), torch.maximum(a, b)
+    loops = torch.arange(n, device=device)
+    s = torch.cat([lo, hi, loops])
+    t = torch.cat([hi, lo, loops])
+    return torch.stack([s, t])
+
+
+class SyntheticNAG:
+    """Plain container: per-level dicts of tensors named like the reference's
+    Data attributes (pos, x, super_index, edge_index, edge_attr, node_size,
+    batch)."""
+
+    def __init__(self, levels, num_clouds):
+        self.levels = levels
+        self.num_clouds = num_clouds
+
+    def __getitem__(self, i):
+        return self.levels[i]
+
+    @property
+    def num_points(self):
+        return [lv["pos"].shape[0] for lv in self.levels]
+
+
+def make_nag(scene="S", seed=1234, device="cpu", sizes=None, point_dim=8,
+             edge_dim=18, scale=1.0):
+    """Build a 3-level synthetic NAG. ``scale`` < 1 shrinks every size
+    proportionally (CPU-baseline samples)."""
+    n0, n1, n2, e1, e2, b = sizes if sizes is not None else SCENES[scene]
+    if scale != 1.0:
+        n0, n1, n2 = (max(int(v * scale), 8) for v in (n0, n1, n2))
+        e1, e2 = max(int(e1 * scale), n1), max(int(e2 * scale), n2)
+    device = torch.device(device)
+    gen = torch.Generator(device=device).manual_seed(seed)
+    si0 = _super_index(gen, n0, n1, "lognormal", device, shuffle=True)
+    si1 = _super_index(gen, n1, n2, "geometric", device, shuffle=True)
+    # cloud (batch) ids: contiguous blocks of level-2 nodes, pushed down
+    b2 = (torch.arange(n2, device=device) * b // n2).long()
+    b1 = b2[si1]
+    b0 = b1[si0]
+
+    def rnd(*shape, s=1.0):
+        return torch.randn(*shape, generator=gen, device=device) * s
+
+    # positions: parents are random centres, children jitter around them
+    pos2 = torch.rand(n2, 3, generator=gen, device=device) * 40.0
+    pos1 = pos2[si1] + rnd(n1, 3, s=1.5)
+    pos0 = pos1[si0] + rnd(n0, 3, s=0.3)
+    ns1 = torch.bincount(si0, minlength=n1)
+    ns2 = torch.zeros(n2, dtype=torch.long, device=device).index_add_(0, si1, ns1)
+    ei1 = _edges(gen, n1, e1, 16.4, 5.8, device)
+    ei2 = _edges(gen, n2, e2, 30.0, 9.0, device)
+    levels = [
+        dict(pos=pos0, x=torch.rand(n0, point_dim, generator=gen, device=device),
+             super_index=si0, batch=b0),
+        dict(pos=pos1, x=rnd(n1, 4), super_index=si1, batch=b1, node_size=ns1,
+             edge_index=ei1, edge_attr=rnd(ei1.shape[1], edge_dim, s=0.3)),
+        dict(pos=pos2, x=rnd(n2, 4), super_index=None, batch=b2, node_size=ns2,
+             edge_index=ei2, edge_attr=rnd(ei2.shape[1], edge_dim, s=0.3)),
+    ]
+    return SyntheticNAG(levels, b)
