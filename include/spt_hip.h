@@ -83,9 +83,12 @@ int spt_segcsr_reduce_f32(int op, const float* x, const int32_t* perm,
  *   MIN/MAX: gx[i,c] = gout[idx[i],c] if arg[idx[i],c]==i else 0
  * (torch_scatter routes the gradient to the single arg element.)           */
 int spt_segcsr_reduce_bwd_f32(int op, const float* gout, const int32_t* arg,
-                              const int64_t* idx, const int32_t* rowptr,
-                              int64_t n, int64_t num_seg, int c, float* gx,
-                              spt_stream_t stream);
+                              const int64_t* idx, const int32_t* perm,
+                              const int32_t* rowptr, int64_t n, int64_t num_seg,
+                              int c, float* gx, spt_stream_t stream);
+
+/* Wide rows (>= 128 B) stream in CSR order when perm/rowptr are given (the
+ * parent row is read once per segment); narrow rows run in idx order. */
 
 /* Bit-exact integer segment sum (a8: NAG.get_sub_size, src/data/nag.py:59-110). */
 int spt_segcsr_sum_i64(const int64_t* x, const int32_t* perm,
@@ -100,6 +103,52 @@ int spt_segcsr_sum_i64(const int64_t* x, const int32_t* perm,
  * ---------------------------------------------------------------------- */
 int spt_gather_rows_f32(const float* x, const int64_t* idx, int64_t n,
                         int64_t num_src, int c, float* out, spt_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Fused UnitSphereNorm                                              (a4)
+ * Replaces UnitSphereNorm._forward_scatter / _forward
+ * (src/nn/norm.py:86-138 <- src/nn/stage.py:250) and its helper
+ * scatter_mean_weighted (src/utils/scatter.py:17-38): per segment bounding
+ * box -> diameter = max axis span; centre = (weighted) mean;
+ * pos_out = (pos - centre[idx]) / (diameter[idx] + 1e-2).
+ *   pos [n,3] f32; idx [n] int64 (NULL = one segment, norm.py:86-110);
+ *   (perm, rowptr) = CSR view of idx; w_f32 / w_i64: optional weights (at
+ *   most one non-NULL; int64 node_size is cast to f32 like the reference);
+ *   pos_out [n,3], diam [num_seg], center [num_seg,3] f32 out.
+ * Empty segment -> diameter 0, centre 0.  No gradient (positions are data).
+ * ---------------------------------------------------------------------- */
+int spt_unit_sphere_norm_f32(const float* pos, const int64_t* idx,
+                             const int32_t* perm, const int32_t* rowptr,
+                             const float* w_f32, const int64_t* w_i64,
+                             int64_t n, int64_t num_seg, float* pos_out,
+                             float* diam, float* center, spt_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * GraphNorm forward / backward, optionally fused with LeakyReLU      (a5)
+ * Replaces torch_geometric.nn.norm.GraphNorm (PyG 2.3.0, install.sh:100) as
+ * called from src/nn/mlp.py:85-94 (every MLP layer, followed by the
+ * LeakyReLU of mlp.py:46-50) and src/nn/transformer.py:258-265:
+ *   mu = mean_g x; o = x - mean_scale*mu[batch]; var = mean_g o^2;
+ *   y = weight * o / sqrt(var + eps) + bias;  y = leaky_relu(y, act_slope)
+ *   x [r,d] f32; batch [r] int64 in [0,num_graphs) or NULL (one graph);
+ *   act_slope = 1 disables the activation; mean, rstd [num_graphs,d] out
+ *   (saved for the backward).  Statistics accumulate in f64 with a
+ *   fixed-order reduction: results are run-to-run deterministic.
+ * ws: caller workspace of spt_graphnorm_workspace_bytes(r,d,num_graphs).
+ * ---------------------------------------------------------------------- */
+size_t spt_graphnorm_workspace_bytes(int64_t r, int d, int num_graphs);
+int spt_graphnorm_fwd_f32(const float* x, const int64_t* batch, int64_t r, int d,
+                          int num_graphs, const float* weight, const float* bias,
+                          const float* mean_scale, float eps, float act_slope,
+                          float* y, float* mean, float* rstd, void* ws,
+                          size_t ws_bytes, spt_stream_t stream);
+int spt_graphnorm_bwd_f32(const float* x, const float* gy, const int64_t* batch,
+                          int64_t r, int d, int num_graphs, const float* weight,
+                          const float* bias, const float* mean_scale,
+                          const float* mean, const float* rstd, float act_slope,
+                          float* gx, float* gweight, float* gbias,
+                          float* gmean_scale, void* ws, size_t ws_bytes,
+                          spt_stream_t stream);
 
 #ifdef __cplusplus
 }

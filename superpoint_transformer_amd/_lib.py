@@ -17,6 +17,7 @@ _i64 = _c.c_int64
 _int = _c.c_int
 _p = _c.c_void_p
 _sz = _c.c_size_t
+_f32 = _c.c_float
 
 # name -> (restype, argtypes).  Must list EVERY symbol of include/spt_hip.h:
 # tests/test_abi.py parses the header and checks both directions.
@@ -26,9 +27,15 @@ SIGNATURES = {
     "spt_csr_build_workspace_bytes": (_sz, [_i64, _i64]),
     "spt_csr_build": (_int, [_p, _i64, _i64, _p, _p, _p, _sz, _p]),
     "spt_segcsr_reduce_f32": (_int, [_int, _p, _p, _p, _i64, _i64, _int, _p, _p, _p]),
-    "spt_segcsr_reduce_bwd_f32": (_int, [_int, _p, _p, _p, _p, _i64, _i64, _int, _p, _p]),
+    "spt_segcsr_reduce_bwd_f32": (_int, [_int, _p, _p, _p, _p, _p, _i64, _i64, _int, _p, _p]),
     "spt_segcsr_sum_i64": (_int, [_p, _p, _p, _i64, _i64, _int, _p, _p]),
     "spt_gather_rows_f32": (_int, [_p, _p, _i64, _i64, _int, _p, _p]),
+    "spt_graphnorm_workspace_bytes": (_sz, [_i64, _int, _int]),
+    "spt_graphnorm_fwd_f32": (_int, [_p, _p, _i64, _int, _int, _p, _p, _p, _f32, _f32,
+                                     _p, _p, _p, _p, _sz, _p]),
+    "spt_graphnorm_bwd_f32": (_int, [_p, _p, _p, _i64, _int, _int, _p, _p, _p, _p, _p,
+                                     _f32, _p, _p, _p, _p, _p, _sz, _p]),
+    "spt_unit_sphere_norm_f32": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _p, _p, _p, _p]),
 }
 
 

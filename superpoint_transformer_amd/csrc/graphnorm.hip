@@ -1,0 +1,469 @@
+// GraphNorm forward / backward (torch_geometric.nn.norm.GraphNorm as used by
+// src/nn/mlp.py:85-94 and src/nn/transformer.py:258-265), optionally fused
+// with the LeakyReLU that follows it in every MLP layer (src/nn/mlp.py:46-50).
+//
+//   mu_g  = mean_{batch=g} x            o = x - alpha * mu_g[batch]
+//   var_g = mean_{batch=g} o^2          y = weight * o / sqrt(var_g + eps) + bias
+//
+// Regime: FEW (1..4) segments of up to 15 M rows each - the opposite of the
+// superpoint pooling kernels.  The reference spends 2 scatter-mean launches
+// with B-way atomic contention + 2 gathers + elementwise passes (~5 passes
+// over x).  Here: ONE statistics pass (f64 register accumulators per lane,
+// per-workgroup partial tables, deterministic fixed-order finalize) and ONE
+// apply pass => 2 reads + 1 write of x.  Backward has the same two-pass shape.
+#include <math.h>
+
+#include "common.hpp"
+
+namespace spt {
+
+constexpr int GN_THREADS = 256;
+constexpr int GN_MAX_BLOCKS = 1024;
+constexpr int GN_UNR = 4;
+
+struct GnShape {
+  int vec, lpr_log2, rpb;  // floats per lane, lanes per row (log2), rows per block-iteration
+};
+
+static bool gn_shape(int d, GnShape* s) {
+  s->vec = (d % 4 == 0) ? 4 : (d % 2 == 0) ? 2 : 1;
+  int lanes = d / s->vec;
+  int l2 = 0;
+  while ((1 << l2) < lanes) ++l2;
+  if (l2 > 8) return false;  // d > 1024 floats per row: not a GraphNorm shape of this model family
+  s->lpr_log2 = l2;
+  s->rpb = GN_THREADS >> l2;
+  return true;
+}
+
+template <int VEC>
+__device__ __forceinline__ void ld(const float* p, float (&v)[VEC]) {
+  if constexpr (VEC == 4) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  } else if constexpr (VEC == 2) {
+    const float2 t = *reinterpret_cast<const float2*>(p);
+    v[0] = t.x; v[1] = t.y;
+  } else {
+    v[0] = *p;
+  }
+}
+template <int VEC>
+__device__ __forceinline__ void st(float* p, const float (&v)[VEC]) {
+  if constexpr (VEC == 4) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  } else if constexpr (VEC == 2) {
+    *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]);
+  } else {
+    *p = v[0];
+  }
+}
+
+// ---- statistics pass ---------------------------------------------------------
+// Per (graph, channel): two f64 sums.  FWD: (sum x, sum x^2) + row count.
+// BWD: (sum g, sum g*o) with g = gy * leaky'(y), o = x - alpha*mu.
+// LDS table layout per block: [B][2*d + 1] doubles (last = row count).
+template <int VEC, bool BWD>
+__global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(
+    const float* __restrict__ x, const float* __restrict__ gy,
+    const int64_t* __restrict__ batch, int64_t R, int d, int B, int lpr_log2,
+    const float* __restrict__ am,     // [B,d] alpha*mu          (BWD)
+    const float* __restrict__ scale,  // [B,d] weight*rstd       (BWD, act mask)
+    const float* __restrict__ bias,   // [d]                     (BWD, act mask)
+    float slope, double* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) double tab[];
+  const int row_len = 2 * d + 1;
+  for (int i = threadIdx.x; i < B * row_len; i += GN_THREADS) tab[i] = 0.0;
+  __syncthreads();
+
+  const int lpr = 1 << lpr_log2;
+  const int rpb = GN_THREADS >> lpr_log2;
+  const int rsub = threadIdx.x >> lpr_log2;
+  const int lr = threadIdx.x & (lpr - 1);
+  const int c0 = lr * VEC;
+  const bool cv = c0 < d;
+
+  double s1[VEC], s2[VEC];
+  double cnt = 0.0;
+  int cur = 0;
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) s1[k] = s2[k] = 0.0;
+
+  auto flush = [&]() {
+    if (cv) {
+      double* t = tab + (size_t)cur * row_len;
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        if (s1[k] != 0.0) atomicAdd(&t[c0 + k], s1[k]);
+        if (s2[k] != 0.0) atomicAdd(&t[d + c0 + k], s2[k]);
+        s1[k] = s2[k] = 0.0;
+      }
+      if (lr == 0 && cnt != 0.0) atomicAdd(&t[2 * d], cnt);
+    }
+    cnt = 0.0;
+  };
+
+  const int64_t step = (int64_t)gridDim.x * rpb * GN_UNR;
+  for (int64_t rb = (int64_t)blockIdx.x * rpb * GN_UNR; rb < R; rb += step) {
+    int64_t row[GN_UNR];
+    int b[GN_UNR];
+    float v[GN_UNR][VEC], g[GN_UNR][VEC];
+#pragma unroll
+    for (int u = 0; u < GN_UNR; ++u) {
+      row[u] = rb + (int64_t)u * rpb + rsub;
+      const bool ok = row[u] < R;
+      b[u] = ok ? (batch ? (int)batch[row[u]] : 0) : -1;
+      if (ok && cv) {
+        ld<VEC>(x + row[u] * d + c0, v[u]);
+        if constexpr (BWD) ld<VEC>(gy + row[u] * d + c0, g[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < GN_UNR; ++u) {
+      if (b[u] < 0) continue;
+      if (b[u] != cur) {
+        flush();
+        cur = b[u];
+      }
+      cnt += 1.0;
+      if (!cv) continue;
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        if constexpr (!BWD) {
+          const double xv = (double)v[u][k];
+          s1[k] += xv;
+          s2[k] += xv * xv;
+        } else {
+          const int t = cur * d + c0 + k;
+          const float o = v[u][k] - am[t];
+          float gg = g[u][k];
+          if (slope != 1.f) {
+            const float y = fmaf(o, scale[t], bias[c0 + k]);
+            gg = (y > 0.f) ? gg : gg * slope;
+          }
+          s1[k] += (double)gg;
+          s2[k] += (double)gg * (double)o;
+        }
+      }
+    }
+  }
+  flush();
+  __syncthreads();
+  double* out = partial + (size_t)blockIdx.x * B * row_len;
+  for (int i = threadIdx.x; i < B * row_len; i += GN_THREADS) out[i] = tab[i];
+}
+
+// ---- finalize: fixed-order reduction of the per-block partial tables --------
+// grid = (B, ceil(row_len / 64)); 256 threads = 64 columns x 4 slices.
+__global__ __launch_bounds__(256) void gn_reduce_partials_kernel(
+    const double* __restrict__ partial, int nblocks, int B, int row_len,
+    double* __restrict__ total) {
+  __shared__ double sl[4][64];
+  const int b = blockIdx.x;
+  const int col = blockIdx.y * 64 + (threadIdx.x & 63);
+  const int slice = threadIdx.x >> 6;
+  double acc = 0.0;
+  if (col < row_len) {
+    const int per = (nblocks + 3) / 4;
+    const int lo = slice * per, hi = (lo + per < nblocks) ? lo + per : nblocks;
+    for (int k = lo; k < hi; ++k) acc += partial[((size_t)k * B + b) * row_len + col];
+  }
+  sl[slice][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (slice == 0 && col < row_len)
+    total[(size_t)b * row_len + col] = ((sl[0][threadIdx.x] + sl[1][threadIdx.x]) + sl[2][threadIdx.x]) + sl[3][threadIdx.x];
+}
+
+// forward tables from the totals
+__global__ void gn_fwd_tables_kernel(const double* __restrict__ total, int B, int d,
+                                     const float* __restrict__ weight,
+                                     const float* __restrict__ mean_scale, float eps,
+                                     float* __restrict__ mean, float* __restrict__ rstd,
+                                     float* __restrict__ am, float* __restrict__ scale) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= B * d) return;
+  const int b = t / d, c = t - b * d;
+  const double* row = total + (size_t)b * (2 * d + 1);
+  double n = row[2 * d];
+  if (n < 1.0) n = 1.0;                       // scatter_mean: clamp(count, 1)
+  const double mu = row[c] / n;
+  const double a = (double)mean_scale[c];
+  // E[(x - a mu)^2] = E[x^2] - (2a - a^2) mu^2
+  double var = row[d + c] / n - (2.0 * a - a * a) * mu * mu;
+  if (var < 0.0) var = 0.0;
+  const double rs = 1.0 / sqrt(var + (double)eps);
+  // (am, scale) derive from the f32-ROUNDED statistics so that the backward,
+  // which only has (mean, rstd), rebuilds bit-identical tables.
+  const float mu32 = (float)mu, rs32 = (float)rs;
+  mean[t] = mu32;
+  rstd[t] = rs32;
+  am[t] = (float)(a * (double)mu32);
+  scale[t] = (float)((double)weight[c] * (double)rs32);
+}
+
+__global__ void gn_rebuild_tables_kernel(const float* __restrict__ mean,
+                                         const float* __restrict__ rstd,
+                                         const float* __restrict__ weight,
+                                         const float* __restrict__ mean_scale, int B,
+                                         int d, float* __restrict__ am,
+                                         float* __restrict__ scale) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= B * d) return;
+  const int c = t % d;
+  am[t] = (float)((double)mean_scale[c] * (double)mean[t]);
+  scale[t] = (float)((double)weight[c] * (double)rstd[t]);
+}
+
+// y = (x - alpha*mu) * (weight*rstd) + bias ; optional LeakyReLU
+template <int VEC>
+__global__ __launch_bounds__(GN_THREADS) void gn_apply_fwd_kernel(
+    const float* __restrict__ x, const int64_t* __restrict__ batch, int64_t R, int d,
+    int lpr_log2, const float* __restrict__ am, const float* __restrict__ scale,
+    const float* __restrict__ bias, float slope, float* __restrict__ y) {
+  const int lpr = 1 << lpr_log2;
+  const int rpb = GN_THREADS >> lpr_log2;
+  const int rsub = threadIdx.x >> lpr_log2;
+  const int c0 = (threadIdx.x & (lpr - 1)) * VEC;
+  if (c0 >= d) return;
+  float bs[VEC];
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) bs[k] = bias[c0 + k];
+  const int64_t step = (int64_t)gridDim.x * rpb * GN_UNR;
+  for (int64_t rb = (int64_t)blockIdx.x * rpb * GN_UNR; rb < R; rb += step) {
+    float v[GN_UNR][VEC];
+    int b[GN_UNR];
+#pragma unroll
+    for (int u = 0; u < GN_UNR; ++u) {
+      const int64_t row = rb + (int64_t)u * rpb + rsub;
+      b[u] = (row < R) ? (batch ? (int)batch[row] : 0) : -1;
+      if (b[u] >= 0) ld<VEC>(x + row * d + c0, v[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < GN_UNR; ++u) {
+      if (b[u] < 0) continue;
+      const int64_t row = rb + (int64_t)u * rpb + rsub;
+      float o[VEC];
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        const int t = b[u] * d + c0 + k;
+        float yy = fmaf(v[u][k] - am[t], scale[t], bs[k]);
+        if (slope != 1.f) yy = (yy > 0.f) ? yy : yy * slope;
+        o[k] = yy;
+      }
+      st<VEC>(y + row * d + c0, o);
+    }
+  }
+}
+
+// backward tables:  gx = c1*g - c2*o - c3
+__global__ void gn_bwd_tables_kernel(const double* __restrict__ total, int B, int d,
+                                     const float* __restrict__ weight,
+                                     const float* __restrict__ mean_scale,
+                                     const float* __restrict__ mean,
+                                     const float* __restrict__ rstd,
+                                     float* __restrict__ c1, float* __restrict__ c2,
+                                     float* __restrict__ c3, float* __restrict__ gweight,
+                                     float* __restrict__ gbias, float* __restrict__ gms) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= d) return;
+  const double w = (double)weight[c], a = (double)mean_scale[c];
+  double gw = 0.0, gb = 0.0, ga = 0.0;
+  for (int b = 0; b < B; ++b) {
+    const double* row = total + (size_t)b * (2 * d + 1);
+    double n = row[2 * d];
+    if (n < 1.0) n = 1.0;
+    const double A = row[c], GO = row[d + c];
+    const double s = (double)rstd[b * d + c], mu = (double)mean[b * d + c];
+    const double k2 = w * s * s * s * GO / n;
+    const double sumdo = w * s * A - k2 * n * mu * (1.0 - a);
+    c1[b * d + c] = (float)(w * s);
+    c2[b * d + c] = (float)k2;
+    c3[b * d + c] = (float)(a * sumdo / n);
+    gw += s * GO;
+    gb += A;
+    ga += -mu * sumdo;
+  }
+  gweight[c] = (float)gw;
+  gbias[c] = (float)gb;
+  gms[c] = (float)ga;
+}
+
+template <int VEC>
+__global__ __launch_bounds__(GN_THREADS) void gn_apply_bwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ gy,
+    const int64_t* __restrict__ batch, int64_t R, int d, int lpr_log2,
+    const float* __restrict__ am, const float* __restrict__ scale,
+    const float* __restrict__ bias, float slope, const float* __restrict__ c1,
+    const float* __restrict__ c2, const float* __restrict__ c3,
+    float* __restrict__ gx) {
+  const int lpr = 1 << lpr_log2;
+  const int rpb = GN_THREADS >> lpr_log2;
+  const int rsub = threadIdx.x >> lpr_log2;
+  const int c0 = (threadIdx.x & (lpr - 1)) * VEC;
+  if (c0 >= d) return;
+  float bs[VEC];
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) bs[k] = bias[c0 + k];
+  const int64_t step = (int64_t)gridDim.x * rpb * GN_UNR;
+  for (int64_t rb = (int64_t)blockIdx.x * rpb * GN_UNR; rb < R; rb += step) {
+    float v[GN_UNR][VEC], g[GN_UNR][VEC];
+    int b[GN_UNR];
+#pragma unroll
+    for (int u = 0; u < GN_UNR; ++u) {
+      const int64_t row = rb + (int64_t)u * rpb + rsub;
+      b[u] = (row < R) ? (batch ? (int)batch[row] : 0) : -1;
+      if (b[u] >= 0) {
+        ld<VEC>(x + row * d + c0, v[u]);
+        ld<VEC>(gy + row * d + c0, g[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < GN_UNR; ++u) {
+      if (b[u] < 0) continue;
+      const int64_t row = rb + (int64_t)u * rpb + rsub;
+      float o[VEC];
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        const int t = b[u] * d + c0 + k;
+        const float oo = v[u][k] - am[t];
+        float gg = g[u][k];
+        if (slope != 1.f) {
+          const float yy = fmaf(oo, scale[t], bs[k]);
+          gg = (yy > 0.f) ? gg : gg * slope;
+        }
+        o[k] = fmaf(c1[t], gg, -fmaf(c2[t], oo, c3[t]));
+      }
+      st<VEC>(gx + row * d + c0, o);
+    }
+  }
+}
+
+struct GnPlan {
+  GnShape sh;
+  int nblocks, row_len;
+  size_t off_partial, off_total, off_am, off_scale, off_c1, off_c2, off_c3, total;
+};
+
+static bool gn_plan(int64_t R, int d, int B, GnPlan* p) {
+  if (!gn_shape(d, &p->sh)) return false;
+  p->row_len = 2 * d + 1;
+  int64_t nb = ceil_div(R > 0 ? R : 1, (int64_t)p->sh.rpb * GN_UNR);
+  if (nb > GN_MAX_BLOCKS) nb = GN_MAX_BLOCKS;
+  p->nblocks = (int)nb;
+  size_t o = 0;
+  p->off_partial = o; o += align_up((size_t)p->nblocks * B * p->row_len * 8, 256);
+  p->off_total = o;   o += align_up((size_t)B * p->row_len * 8, 256);
+  const size_t tb = align_up((size_t)B * d * 4, 256);
+  p->off_am = o; o += tb;
+  p->off_scale = o; o += tb;
+  p->off_c1 = o; o += tb;
+  p->off_c2 = o; o += tb;
+  p->off_c3 = o; o += tb;
+  p->total = o;
+  return true;
+}
+
+template <bool BWD>
+static void launch_stats(const GnPlan& p, const float* x, const float* gy,
+                         const int64_t* batch, int64_t R, int d, int B,
+                         const float* am, const float* scale, const float* bias,
+                         float slope, double* partial, hipStream_t stream) {
+  const size_t lds = (size_t)B * p.row_len * 8;
+  if (p.sh.vec == 4)
+    gn_stats_kernel<4, BWD><<<p.nblocks, GN_THREADS, lds, stream>>>(x, gy, batch, R, d, B, p.sh.lpr_log2, am, scale, bias, slope, partial);
+  else if (p.sh.vec == 2)
+    gn_stats_kernel<2, BWD><<<p.nblocks, GN_THREADS, lds, stream>>>(x, gy, batch, R, d, B, p.sh.lpr_log2, am, scale, bias, slope, partial);
+  else
+    gn_stats_kernel<1, BWD><<<p.nblocks, GN_THREADS, lds, stream>>>(x, gy, batch, R, d, B, p.sh.lpr_log2, am, scale, bias, slope, partial);
+}
+
+}  // namespace spt
+
+using namespace spt;
+
+extern "C" size_t spt_graphnorm_workspace_bytes(int64_t r, int d, int num_graphs) {
+  GnPlan p;
+  if (r < 0 || d < 1 || num_graphs < 1 || !gn_plan(r, d, num_graphs, &p)) return 0;
+  return p.total;
+}
+
+static int gn_check(int64_t r, int d, int B, const GnPlan& p, const void* ws, size_t ws_bytes) {
+  SPT_CHECK_ARG(ws && ws_bytes >= p.total, "workspace too small");
+  SPT_CHECK_ARG((size_t)B * p.row_len * 8 <= 64 * 1024, "num_graphs * dim too large for the LDS table");
+  return 0;
+}
+
+extern "C" int spt_graphnorm_fwd_f32(const float* x, const int64_t* batch, int64_t r,
+                                     int d, int num_graphs, const float* weight,
+                                     const float* bias, const float* mean_scale,
+                                     float eps, float act_slope, float* y,
+                                     float* mean, float* rstd, void* ws,
+                                     size_t ws_bytes, spt_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int B = num_graphs;
+  SPT_CHECK_ARG(r >= 0 && d >= 1 && B >= 1, "bad shape");
+  GnPlan p;
+  SPT_CHECK_ARG(gn_plan(r, d, B, &p), "dim > 1024 unsupported");
+  if (int e = gn_check(r, d, B, p, ws, ws_bytes)) return e;
+  SPT_CHECK_ARG(weight && bias && mean_scale && mean && rstd && (r == 0 || (x && y)), "null pointer");
+  char* base = (char*)ws;
+  double* partial = (double*)(base + p.off_partial);
+  double* total = (double*)(base + p.off_total);
+  float* am = (float*)(base + p.off_am);
+  float* scale = (float*)(base + p.off_scale);
+  launch_stats<false>(p, x, nullptr, batch, r, d, B, nullptr, nullptr, nullptr, 1.f, partial, stream);
+  gn_reduce_partials_kernel<<<dim3(B, (p.row_len + 63) / 64), 256, 0, stream>>>(partial, p.nblocks, B, p.row_len, total);
+  gn_fwd_tables_kernel<<<(B * d + 255) / 256, 256, 0, stream>>>(total, B, d, weight, mean_scale, eps, mean, rstd, am, scale);
+  if (r > 0) {
+    if (p.sh.vec == 4)
+      gn_apply_fwd_kernel<4><<<p.nblocks * 2, GN_THREADS, 0, stream>>>(x, batch, r, d, p.sh.lpr_log2, am, scale, bias, act_slope, y);
+    else if (p.sh.vec == 2)
+      gn_apply_fwd_kernel<2><<<p.nblocks * 2, GN_THREADS, 0, stream>>>(x, batch, r, d, p.sh.lpr_log2, am, scale, bias, act_slope, y);
+    else
+      gn_apply_fwd_kernel<1><<<p.nblocks * 2, GN_THREADS, 0, stream>>>(x, batch, r, d, p.sh.lpr_log2, am, scale, bias, act_slope, y);
+  }
+  SPT_CHECK_LAUNCH();
+  return 0;
+}
+
+// The backward recounts rows per graph in its own statistics pass, so no
+// forward state besides (mean, rstd) is needed.
+extern "C" int spt_graphnorm_bwd_f32(const float* x, const float* gy,
+                                     const int64_t* batch, int64_t r, int d,
+                                     int num_graphs, const float* weight,
+                                     const float* bias, const float* mean_scale,
+                                     const float* mean, const float* rstd,
+                                     float act_slope, float* gx, float* gweight,
+                                     float* gbias, float* gmean_scale, void* ws,
+                                     size_t ws_bytes, spt_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int B = num_graphs;
+  SPT_CHECK_ARG(r >= 0 && d >= 1 && B >= 1, "bad shape");
+  GnPlan p;
+  SPT_CHECK_ARG(gn_plan(r, d, B, &p), "dim > 1024 unsupported");
+  if (int e = gn_check(r, d, B, p, ws, ws_bytes)) return e;
+  SPT_CHECK_ARG(weight && bias && mean_scale && mean && rstd && gweight && gbias && gmean_scale && (r == 0 || (x && gy && gx)), "null pointer");
+  char* base = (char*)ws;
+  double* partial = (double*)(base + p.off_partial);
+  double* total = (double*)(base + p.off_total);
+  float* am = (float*)(base + p.off_am);
+  float* scale = (float*)(base + p.off_scale);
+  float* c1 = (float*)(base + p.off_c1);
+  float* c2 = (float*)(base + p.off_c2);
+  float* c3 = (float*)(base + p.off_c3);
+  // rebuild (alpha*mu, weight*rstd) from the saved statistics
+  gn_rebuild_tables_kernel<<<(B * d + 255) / 256, 256, 0, stream>>>(mean, rstd, weight, mean_scale, B, d, am, scale);
+  launch_stats<true>(p, x, gy, batch, r, d, B, am, scale, bias, act_slope, partial, stream);
+  gn_reduce_partials_kernel<<<dim3(B, (p.row_len + 63) / 64), 256, 0, stream>>>(partial, p.nblocks, B, p.row_len, total);
+  gn_bwd_tables_kernel<<<(d + 127) / 128, 128, 0, stream>>>(total, B, d, weight, mean_scale, mean, rstd, c1, c2, c3, gweight, gbias, gmean_scale);
+  if (r > 0) {
+    if (p.sh.vec == 4)
+      gn_apply_bwd_kernel<4><<<p.nblocks * 2, GN_THREADS, 0, stream>>>(x, gy, batch, r, d, p.sh.lpr_log2, am, scale, bias, act_slope, c1, c2, c3, gx);
+    else if (p.sh.vec == 2)
+      gn_apply_bwd_kernel<2><<<p.nblocks * 2, GN_THREADS, 0, stream>>>(x, gy, batch, r, d, p.sh.lpr_log2, am, scale, bias, act_slope, c1, c2, c3, gx);
+    else
+      gn_apply_bwd_kernel<1><<<p.nblocks * 2, GN_THREADS, 0, stream>>>(x, gy, batch, r, d, p.sh.lpr_log2, am, scale, bias, act_slope, c1, c2, c3, gx);
+  }
+  SPT_CHECK_LAUNCH();
+  return 0;
+}

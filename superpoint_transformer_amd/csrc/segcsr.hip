@@ -65,16 +65,33 @@ __device__ __forceinline__ void sti(int32_t* __restrict__ p, const int32_t (&a)[
   }
 }
 
+// SUM / MEAN accumulate in f64: a segment of any length then sums to the
+// correctly rounded f32 result whatever the lane-group shape (deterministic,
+// and never worse than the f32 atomics of the reference).  The kernel stays
+// HBM-bound: one v_cvt + one v_add_f64 per loaded float.
 template <int OP>
-__device__ __forceinline__ float op_identity() {
+struct AccT {
+  using type = float;
+};
+template <>
+struct AccT<SPT_SUM> {
+  using type = double;
+};
+template <>
+struct AccT<SPT_MEAN> {
+  using type = double;
+};
+
+template <int OP>
+__device__ __forceinline__ typename AccT<OP>::type op_identity() {
   if constexpr (OP == SPT_MIN) return INFINITY;
   if constexpr (OP == SPT_MAX) return -INFINITY;
-  return 0.f;
+  return 0;
 }
 
 // combine (v, r) into (acc, accr); r = original row index of v
-template <int OP, bool ARG>
-__device__ __forceinline__ void combine(float& acc, int32_t& accr, float v, int32_t r) {
+template <int OP, bool ARG, typename A>
+__device__ __forceinline__ void combine(A& acc, int32_t& accr, A v, int32_t r) {
   if constexpr (OP == SPT_SUM || OP == SPT_MEAN) {
     acc += v;
   } else if constexpr (OP == SPT_MAX) {
@@ -126,7 +143,8 @@ __global__ __launch_bounds__(256) void segcsr_reduce_kernel(
     for (int cb = 0; cb < c; cb += ctile) {
       const int c0 = cb + lr * VEC;
       const bool cv = c0 < c;
-      float acc[VEC];
+      using A = typename AccT<OP>::type;
+      A acc[VEC];
       int32_t accr[VEC];
 #pragma unroll
       for (int k = 0; k < VEC; ++k) {
@@ -148,20 +166,20 @@ __global__ __launch_bounds__(256) void segcsr_reduce_kernel(
         for (int u = 0; u < UNR; ++u)
           if (r[u] >= 0 && cv) {
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) combine<OP, ARG>(acc[k], accr[k], v[u].v[k], r[u]);
+            for (int k = 0; k < VEC; ++k) combine<OP, ARG, A>(acc[k], accr[k], (A)v[u].v[k], r[u]);
           }
       }
       // tree across the RPG row slots of the group
       for (int o = lpr; o < (1 << g_log2); o <<= 1) {
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
-          const float ov = __shfl_xor(acc[k], o, 64);
+          const A ov = __shfl_xor(acc[k], o, 64);
           if constexpr (ARG) {
             const int32_t orr = __shfl_xor(accr[k], o, 64);
-            combine<OP, ARG>(acc[k], accr[k], ov, orr);
+            combine<OP, ARG, A>(acc[k], accr[k], ov, orr);
           } else {
             int32_t dummy = 0;
-            combine<OP, false>(acc[k], dummy, ov, 0);
+            combine<OP, false, A>(acc[k], dummy, ov, 0);
           }
         }
       }
@@ -171,10 +189,10 @@ __global__ __launch_bounds__(256) void segcsr_reduce_kernel(
         int32_t oa[VEC];
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
-          float val = acc[k];
-          if constexpr (OP == SPT_MEAN) val = val / (float)(cnt > 0 ? cnt : 1);
+          A val = acc[k];
+          if constexpr (OP == SPT_MEAN) val = val / (A)(cnt > 0 ? cnt : 1);
           if constexpr (OP == SPT_MIN || OP == SPT_MAX) val = (cnt > 0) ? val : 0.f;
-          o.v[k] = val;
+          o.v[k] = (float)val;
           oa[k] = (cnt > 0 && accr[k] != 0x7fffffff) ? accr[k] : (int32_t)n;
         }
         stv<VEC>(out + s * c + c0, o);
@@ -239,6 +257,71 @@ __global__ __launch_bounds__(256) void gather_mod_kernel(
   }
 }
 
+// Backward in CSR order (wide rows): the parent's gout (and arg) row is loaded
+// ONCE per segment and streamed to its children through perm - no re-gather of
+// the parent row per child as in the idx-ordered kernel above.
+//   MODE 0: gx[r,:] = gout[s,:]          MODE 1: gout[s,:]/max(cnt,1)
+//   MODE 2: gx[r,c] = arg[s,c]==r ? gout[s,c] : 0
+template <int MODE, int VEC>
+__global__ __launch_bounds__(256) void segcsr_bwd_kernel(
+    const float* __restrict__ gout, const int32_t* __restrict__ arg,
+    const int32_t* __restrict__ perm, const int32_t* __restrict__ rowptr,
+    int64_t num_seg, int c, int lpr_log2, int rpg_log2, float* __restrict__ gx) {
+  constexpr int UNR = 4;
+  const int lane = threadIdx.x & 63;
+  const int g_log2 = lpr_log2 + rpg_log2;
+  const int lpr = 1 << lpr_log2;
+  const int rpg = 1 << rpg_log2;
+  const int spw = 64 >> g_log2;
+  const int slot = lane >> g_log2;
+  const int lg = lane & ((1 << g_log2) - 1);
+  const int rsub = lg >> lpr_log2;
+  const int lr = lg & (lpr - 1);
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  const int ctile = lpr * VEC;
+  for (int64_t sbase = wave * spw; sbase < num_seg; sbase += nwaves * spw) {
+    const int64_t s = sbase + slot;
+    const bool sv = s < num_seg;
+    const int start = sv ? rowptr[s] : 0;
+    const int end = sv ? rowptr[s + 1] : 0;
+    if (end == start) continue;
+    for (int cb = 0; cb < c; cb += ctile) {
+      const int c0 = cb + lr * VEC;
+      if (c0 >= c) continue;
+      Vec<VEC> g = ldv<VEC>(gout + s * c + c0);
+      int32_t a[VEC];
+      if constexpr (MODE == 1) {
+        const float d = (float)(end - start);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) g.v[k] = g.v[k] / d;
+      }
+      if constexpr (MODE == 2) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) a[k] = arg[s * c + c0 + k];
+      }
+      for (int j = start + rsub; j < end; j += rpg * UNR) {
+        int32_t r[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          const int jj = j + u * rpg;
+          r[u] = (jj < end) ? (perm ? perm[jj] : jj) : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          if (r[u] < 0) continue;
+          Vec<VEC> o = g;
+          if constexpr (MODE == 2) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) o.v[k] = (a[k] == r[u]) ? g.v[k] : 0.f;
+          }
+          stv<VEC>(gx + (int64_t)r[u] * c + c0, o);
+        }
+      }
+    }
+  }
+}
+
 __global__ void segcsr_sum_i64_kernel(const int64_t* __restrict__ x,
                                       const int32_t* __restrict__ perm,
                                       const int32_t* __restrict__ rowptr,
@@ -267,6 +350,14 @@ static inline int log2_ceil(int64_t v) {
   int b = 0;
   while ((((int64_t)1) << b) < v) ++b;
   return b;
+}
+
+static int rows_in_flight_log2(int64_t n, int64_t num_seg, int lpr_log2) {
+  // rows in flight per segment: aim at >= 4 rows per lane slot
+  const int64_t avg = (num_seg > 0) ? n / num_seg : 0;
+  int rpg_log2 = log2_floor(avg / 4 > 1 ? avg / 4 : 1);
+  if (rpg_log2 > 6 - lpr_log2) rpg_log2 = 6 - lpr_log2;
+  return rpg_log2;
 }
 
 struct RowShape {
@@ -313,6 +404,21 @@ static void launch_reduce_vec(int vec, bool want_arg, const float* x,
 }
 
 template <int MODE>
+static void launch_bwd_csr(int vec, const float* gout, const int32_t* arg,
+                           const int32_t* perm, const int32_t* rowptr,
+                           int64_t num_seg, int c, int lpr_log2, int rpg_log2,
+                           float* gx, hipStream_t stream) {
+  const int spw = 64 >> (lpr_log2 + rpg_log2);
+  const int grid = stream_grid(ceil_div(num_seg, spw), 4);
+  if (vec == 4)
+    segcsr_bwd_kernel<MODE, 4><<<grid, 256, 0, stream>>>(gout, arg, perm, rowptr, num_seg, c, lpr_log2, rpg_log2, gx);
+  else if (vec == 2)
+    segcsr_bwd_kernel<MODE, 2><<<grid, 256, 0, stream>>>(gout, arg, perm, rowptr, num_seg, c, lpr_log2, rpg_log2, gx);
+  else
+    segcsr_bwd_kernel<MODE, 1><<<grid, 256, 0, stream>>>(gout, arg, perm, rowptr, num_seg, c, lpr_log2, rpg_log2, gx);
+}
+
+template <int MODE>
 static void launch_gather(int vec, const float* src, const int32_t* arg,
                           const int64_t* idx, const int32_t* rowptr, int64_t n, int c,
                           int lpr_log2, float* out, hipStream_t stream) {
@@ -340,10 +446,7 @@ extern "C" int spt_segcsr_reduce_f32(int op, const float* x, const int32_t* perm
   SPT_CHECK_ARG(rowptr && out && (x || n == 0), "null pointer");
   if (num_seg == 0) return 0;
   const RowShape rs = row_shape(c);
-  // rows in flight per segment: aim at >= 4 rows per lane slot
-  const int64_t avg = (num_seg > 0) ? n / num_seg : 0;
-  int rpg_log2 = log2_floor(avg / 4 > 1 ? avg / 4 : 1);
-  if (rpg_log2 > 6 - rs.lpr_log2) rpg_log2 = 6 - rs.lpr_log2;
+  const int rpg_log2 = rows_in_flight_log2(n, num_seg, rs.lpr_log2);
   const bool want_arg = arg != nullptr;
   switch (op) {
     case SPT_SUM:
@@ -365,6 +468,7 @@ extern "C" int spt_segcsr_reduce_f32(int op, const float* x, const int32_t* perm
 
 extern "C" int spt_segcsr_reduce_bwd_f32(int op, const float* gout,
                                          const int32_t* arg, const int64_t* idx,
+                                         const int32_t* perm,
                                          const int32_t* rowptr, int64_t n,
                                          int64_t num_seg, int c, float* gx,
                                          spt_stream_t stream_) {
@@ -374,6 +478,20 @@ extern "C" int spt_segcsr_reduce_bwd_f32(int op, const float* gout,
   if (n == 0) return 0;
   SPT_CHECK_ARG(gout && idx && gx, "null pointer");
   const RowShape rs = row_shape(c);
+  // wide rows (>= one 128-B line) and every row owned by a segment: stream in
+  // CSR order; narrow rows keep coalesced idx-ordered writes.
+  if (perm && rowptr && c * 4 >= 128 && n / (num_seg > 0 ? num_seg : 1) >= 2) {
+    SPT_CHECK_ARG(op == SPT_SUM || op == SPT_MEAN || arg, "min/max backward needs arg");
+    const int rpg_log2 = rows_in_flight_log2(n, num_seg, rs.lpr_log2);
+    if (op == SPT_SUM)
+      launch_bwd_csr<0>(rs.vec, gout, nullptr, perm, rowptr, num_seg, c, rs.lpr_log2, rpg_log2, gx, stream);
+    else if (op == SPT_MEAN)
+      launch_bwd_csr<1>(rs.vec, gout, nullptr, perm, rowptr, num_seg, c, rs.lpr_log2, rpg_log2, gx, stream);
+    else
+      launch_bwd_csr<2>(rs.vec, gout, arg, perm, rowptr, num_seg, c, rs.lpr_log2, rpg_log2, gx, stream);
+    SPT_CHECK_LAUNCH();
+    return 0;
+  }
   if (op == SPT_SUM) {
     launch_gather<0>(rs.vec, gout, nullptr, idx, nullptr, n, c, rs.lpr_log2, gx, stream);
   } else if (op == SPT_MEAN) {

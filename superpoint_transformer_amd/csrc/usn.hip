@@ -1,0 +1,184 @@
+// Fused UnitSphereNorm (src/nn/norm.py:67-138).
+//
+// The reference runs scatter-min, scatter-max, scatter-mean (or cat + weighted
+// scatter-sum, src/utils/scatter.py:17-38), two gathers and the elementwise
+// normalisation as ~7 launches over `pos`.  Here: one segment pass over the
+// CSR view producing (center, diameter) per segment, one coalesced row pass
+// applying them.  Bounding boxes are bit-exact (min/max are order-free);
+// centres accumulate in f64, so they are at least as accurate as the f32
+// scatter they replace.
+#include <math.h>
+
+#include "common.hpp"
+
+namespace spt {
+
+struct Box {
+  float mn[3], mx[3];
+  double sw, sx[3];
+};
+
+__device__ __forceinline__ void box_init(Box& b) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    b.mn[k] = INFINITY;
+    b.mx[k] = -INFINITY;
+    b.sx[k] = 0.0;
+  }
+  b.sw = 0.0;
+}
+
+__device__ __forceinline__ void box_add(Box& b, float x, float y, float z, double w) {
+  b.mn[0] = fminf(b.mn[0], x); b.mx[0] = fmaxf(b.mx[0], x);
+  b.mn[1] = fminf(b.mn[1], y); b.mx[1] = fmaxf(b.mx[1], y);
+  b.mn[2] = fminf(b.mn[2], z); b.mx[2] = fmaxf(b.mx[2], z);
+  b.sw += w;
+  b.sx[0] += w * (double)x;
+  b.sx[1] += w * (double)y;
+  b.sx[2] += w * (double)z;
+}
+
+__device__ __forceinline__ void box_merge_xor(Box& b, int o) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    b.mn[k] = fminf(b.mn[k], __shfl_xor(b.mn[k], o, 64));
+    b.mx[k] = fmaxf(b.mx[k], __shfl_xor(b.mx[k], o, 64));
+    b.sx[k] += __shfl_xor(b.sx[k], o, 64);
+  }
+  b.sw += __shfl_xor(b.sw, o, 64);
+}
+
+__device__ __forceinline__ double row_weight(const float* wf, const int64_t* wi, int64_t r) {
+  if (wi) return (double)(float)wi[r];  // reference: w.float() (scatter.py:26)
+  if (wf) return (double)wf[r];
+  return 1.0;
+}
+
+__device__ __forceinline__ void box_finish(const Box& b, int cnt, float* center, float* diam) {
+  // norm.py:118-126: empty segment -> min = max = 0 -> diameter 0, centre 0;
+  // weighted mean divides by the weight sum, 0 replaced by 1 (scatter.py:35)
+  float d = 0.f;
+  if (cnt > 0) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) d = fmaxf(d, b.mx[k] - b.mn[k]);
+  }
+  const double den = (b.sw == 0.0) ? 1.0 : b.sw;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) center[k] = (float)(b.sx[k] / den);
+  *diam = d;
+}
+
+// One lane group of 2^g_log2 lanes per segment.
+__global__ __launch_bounds__(256) void usn_stats_group_kernel(
+    const float* __restrict__ pos, const int32_t* __restrict__ perm,
+    const int32_t* __restrict__ rowptr, const float* __restrict__ wf,
+    const int64_t* __restrict__ wi, int64_t num_seg, int g_log2,
+    float* __restrict__ center, float* __restrict__ diam) {
+  const int lane = threadIdx.x & 63;
+  const int g = 1 << g_log2;
+  const int spw = 64 >> g_log2;
+  const int slot = lane >> g_log2;
+  const int lg = lane & (g - 1);
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  for (int64_t sbase = wave * spw; sbase < num_seg; sbase += nwaves * spw) {
+    const int64_t s = sbase + slot;
+    const bool sv = s < num_seg;
+    const int start = sv ? rowptr[s] : 0;
+    const int end = sv ? rowptr[s + 1] : 0;
+    Box b;
+    box_init(b);
+    for (int j = start + lg; j < end; j += g) {
+      const int64_t r = perm ? perm[j] : j;
+      const float x = pos[r * 3], y = pos[r * 3 + 1], z = pos[r * 3 + 2];
+      box_add(b, x, y, z, row_weight(wf, wi, r));
+    }
+    for (int o = 1; o < g; o <<= 1) box_merge_xor(b, o);
+    if (sv && lg == 0) box_finish(b, end - start, center + s * 3, diam + s);
+  }
+}
+
+// One workgroup per segment (few, huge segments: idx=None / per-cloud norms).
+__global__ __launch_bounds__(256) void usn_stats_block_kernel(
+    const float* __restrict__ pos, const int32_t* __restrict__ perm,
+    const int32_t* __restrict__ rowptr, const float* __restrict__ wf,
+    const int64_t* __restrict__ wi, int64_t num_seg,
+    float* __restrict__ center, float* __restrict__ diam) {
+  __shared__ Box part[4];
+  for (int64_t s = blockIdx.x; s < num_seg; s += gridDim.x) {
+    const int start = rowptr[s], end = rowptr[s + 1];
+    Box b;
+    box_init(b);
+    for (int j = start + threadIdx.x; j < end; j += blockDim.x) {
+      const int64_t r = perm ? perm[j] : j;
+      box_add(b, pos[r * 3], pos[r * 3 + 1], pos[r * 3 + 2], row_weight(wf, wi, r));
+    }
+    for (int o = 1; o < 64; o <<= 1) box_merge_xor(b, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = b;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int w = 1; w < 4; ++w) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          b.mn[k] = fminf(b.mn[k], part[w].mn[k]);
+          b.mx[k] = fmaxf(b.mx[k], part[w].mx[k]);
+          b.sx[k] += part[w].sx[k];
+        }
+        b.sw += part[w].sw;
+      }
+      box_finish(b, end - start, center + s * 3, diam + s);
+    }
+  }
+}
+
+// out[i] = (pos[i] - center[idx[i]]) / (diam[idx[i]] + 1e-2)    norm.py:132-136
+__global__ __launch_bounds__(256) void usn_apply_kernel(
+    const float* __restrict__ pos, const int64_t* __restrict__ idx,
+    const float* __restrict__ center, const float* __restrict__ diam, int64_t n,
+    float* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int64_t s = idx ? idx[i] : 0;
+    const float d = diam[s] + 1e-2f;
+    out[i * 3 + 0] = (pos[i * 3 + 0] - center[s * 3 + 0]) / d;
+    out[i * 3 + 1] = (pos[i * 3 + 1] - center[s * 3 + 1]) / d;
+    out[i * 3 + 2] = (pos[i * 3 + 2] - center[s * 3 + 2]) / d;
+  }
+}
+
+}  // namespace spt
+
+using namespace spt;
+
+extern "C" int spt_unit_sphere_norm_f32(const float* pos, const int64_t* idx,
+                                        const int32_t* perm, const int32_t* rowptr,
+                                        const float* w_f32, const int64_t* w_i64,
+                                        int64_t n, int64_t num_seg, float* pos_out,
+                                        float* diam, float* center,
+                                        spt_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPT_CHECK_ARG(n >= 0 && num_seg >= 1, "bad shape");
+  SPT_CHECK_ARG(rowptr && diam && center, "null pointer");
+  SPT_CHECK_ARG(n == 0 || (pos && pos_out), "null pos");
+  SPT_CHECK_ARG(!(w_f32 && w_i64), "pass at most one weight array");
+  SPT_CHECK_ARG(idx || num_seg == 1, "idx may be null only for a single segment");
+  const int64_t avg = n / num_seg;
+  if (avg >= 2048) {
+    const int grid = (int)(num_seg < 4096 ? num_seg : 4096);
+    usn_stats_block_kernel<<<grid, 256, 0, stream>>>(pos, perm, rowptr, w_f32, w_i64,
+                                                     num_seg, center, diam);
+  } else {
+    int g_log2 = 0;
+    while (g_log2 < 6 && (((int64_t)4) << g_log2) <= avg) ++g_log2;  // ~4+ rows per lane
+    const int spw = 64 >> g_log2;
+    const int grid = stream_grid(ceil_div(num_seg, spw), 4);
+    usn_stats_group_kernel<<<grid, 256, 0, stream>>>(pos, perm, rowptr, w_f32, w_i64,
+                                                     num_seg, g_log2, center, diam);
+  }
+  if (n > 0)
+    usn_apply_kernel<<<stream_grid(n, 256), 256, 0, stream>>>(pos, idx, center, diam, n,
+                                                              pos_out);
+  SPT_CHECK_LAUNCH();
+  return 0;
+}

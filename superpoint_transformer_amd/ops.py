@@ -43,7 +43,7 @@ def _seg_reduce_bwd(gout, arg, csr, op, n):
     with torch.cuda.device(gout.device):
         st = _lib.lib.spt_segcsr_reduce_bwd_f32(
             op, _lib.ptr(gout), _lib.ptr(arg), _lib.ptr(csr.idx),
-            _lib.ptr(csr.rowptr), n, csr.num_seg, c, _lib.ptr(gx),
+            _lib.ptr(csr.perm), _lib.ptr(csr.rowptr), n, csr.num_seg, c, _lib.ptr(gx),
             _lib.stream_ptr(gout.device))
     _lib.check(st, "spt_segcsr_reduce_bwd_f32")
     return gx
@@ -144,3 +144,128 @@ def segment_sum_i64(x, index, num_seg=None):
             csr.num_seg, c, _lib.ptr(out), _lib.stream_ptr(x.device))
     _lib.check(st, "spt_segcsr_sum_i64")
     return out.reshape((csr.num_seg,) + tuple(tail))
+
+
+# ---------------------------------------------------------------------------
+# UnitSphereNorm (src/nn/norm.py:67-138)
+# ---------------------------------------------------------------------------
+def unit_sphere_norm(pos, idx, w=None, num_super=None):
+    """Returns (pos_normalised [n,3], diameter [num_super,1]) like
+    UnitSphereNorm.forward with log_diameter=False.  ``idx=None`` normalises
+    all rows together (norm.py:86-110).  No gradient: positions are data."""
+    _lib.require_cuda(pos)
+    pos = pos.detach()
+    if pos.dtype != torch.float32:
+        pos = pos.float()
+    pos = pos.contiguous()
+    n = pos.shape[0]
+    dev = pos.device
+    if idx is None:
+        num_seg = 1
+        perm = None
+        rowptr = torch.tensor([0, n], dtype=torch.int32, device=dev)
+        idx_t = None
+    else:
+        csr = csr_of(idx, num_super)
+        num_seg, perm, rowptr, idx_t = csr.num_seg, csr.perm, csr.rowptr, csr.idx
+    wf = wi = None
+    if w is not None:
+        w = w.detach().contiguous()
+        if w.dtype == torch.int64:
+            wi = w
+        elif w.is_floating_point():
+            wf = w.float()
+        else:
+            wi = w.long()
+    out = torch.empty_like(pos)
+    diam = torch.empty(num_seg, dtype=torch.float32, device=dev)
+    center = torch.empty((num_seg, 3), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        st = _lib.lib.spt_unit_sphere_norm_f32(
+            _lib.ptr(pos), _lib.ptr(idx_t), _lib.ptr(perm), _lib.ptr(rowptr),
+            _lib.ptr(wf), _lib.ptr(wi), n, num_seg, _lib.ptr(out), _lib.ptr(diam),
+            _lib.ptr(center), _lib.stream_ptr(dev))
+    _lib.check(st, "spt_unit_sphere_norm_f32")
+    return out, diam.view(-1, 1)
+
+
+# ---------------------------------------------------------------------------
+# GraphNorm (+ fused LeakyReLU)
+# ---------------------------------------------------------------------------
+_WS = {}
+
+
+def _workspace(nbytes, dev):
+    """Grow-only scratch buffer per (device, stream).  Kernels that share it
+    are ordered on the stream, so reuse across calls is safe."""
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev)
+        _WS[key] = buf
+    return buf
+
+
+class _GraphNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, batch, num_graphs, weight, bias, mean_scale, eps, slope):
+        _lib.require_cuda(x)
+        x2 = x.contiguous()
+        if x2.dtype != torch.float32:
+            x2 = x2.float()
+        r, d = x2.shape
+        dev = x2.device
+        if batch is not None:
+            batch = batch.contiguous()
+            if batch.dtype != torch.int64:
+                batch = batch.long()
+        w, b, a = (t.detach().float().contiguous() for t in (weight, bias, mean_scale))
+        y = torch.empty_like(x2)
+        mean = torch.empty((num_graphs, d), dtype=torch.float32, device=dev)
+        rstd = torch.empty((num_graphs, d), dtype=torch.float32, device=dev)
+        nb = _lib.lib.spt_graphnorm_workspace_bytes(r, d, num_graphs)
+        ws = _workspace(nb, dev)
+        with torch.cuda.device(dev):
+            st = _lib.lib.spt_graphnorm_fwd_f32(
+                _lib.ptr(x2), _lib.ptr(batch), r, d, num_graphs, _lib.ptr(w),
+                _lib.ptr(b), _lib.ptr(a), eps, slope, _lib.ptr(y), _lib.ptr(mean),
+                _lib.ptr(rstd), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+        _lib.check(st, "spt_graphnorm_fwd_f32")
+        ctx.save_for_backward(x2, batch, w, b, a, mean, rstd)
+        ctx.meta = (num_graphs, slope, x.dtype)
+        return y.to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, batch, w, b, a, mean, rstd = ctx.saved_tensors
+        num_graphs, slope, in_dtype = ctx.meta
+        r, d = x2.shape
+        dev = x2.device
+        gy = gy.contiguous().float()
+        gx = torch.empty_like(x2)
+        gw = torch.empty(d, dtype=torch.float32, device=dev)
+        gb = torch.empty(d, dtype=torch.float32, device=dev)
+        ga = torch.empty(d, dtype=torch.float32, device=dev)
+        nb = _lib.lib.spt_graphnorm_workspace_bytes(r, d, num_graphs)
+        ws = _workspace(nb, dev)
+        with torch.cuda.device(dev):
+            st = _lib.lib.spt_graphnorm_bwd_f32(
+                _lib.ptr(x2), _lib.ptr(gy), _lib.ptr(batch), r, d, num_graphs,
+                _lib.ptr(w), _lib.ptr(b), _lib.ptr(a), _lib.ptr(mean), _lib.ptr(rstd),
+                slope, _lib.ptr(gx), _lib.ptr(gw), _lib.ptr(gb), _lib.ptr(ga),
+                _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+        _lib.check(st, "spt_graphnorm_bwd_f32")
+        return gx.to(in_dtype), None, None, gw, gb, ga, None, None
+
+
+def graph_norm(x, batch, weight, bias, mean_scale, eps=1e-5, num_graphs=None,
+               act_slope=1.0):
+    """GraphNorm(x, batch) [+ LeakyReLU(act_slope) when act_slope != 1].
+    ``num_graphs=None`` costs a host sync (``batch.max()+1``) exactly like
+    PyG's GraphNorm; pass it to stay asynchronous."""
+    if batch is None:
+        num_graphs = 1
+    elif num_graphs is None:
+        num_graphs = int(batch.max().item()) + 1 if batch.numel() else 1
+    return _GraphNorm.apply(x, batch, int(num_graphs), weight, bias, mean_scale,
+                            float(eps), float(act_slope))

@@ -1,0 +1,96 @@
+"""GPU parity: fused UnitSphereNorm and GraphNorm (+LeakyReLU) against the CPU
+oracle (float64) and the golden fixture produced by the reference's norm.py.
+
+Bars: diameters bit-exact (bounding boxes are order-free f32 min/max);
+normalised positions, GraphNorm outputs and gradients within
+1e-5 * max(1, |ref|) of the float64 oracle."""
+import pytest
+import torch
+
+from conftest import load_golden, t64, tl
+from oracle import spt_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, ref64, tol=1e-5):
+    a = a.detach().cpu().double()
+    err = (a - ref64).abs() / ref64.abs().clamp(min=1)
+    assert err.max().item() <= tol, f"max scaled err {err.max().item():.3e}"
+
+
+def test_unit_sphere_norm_matches_reference_fixture(dev):
+    from superpoint_transformer_amd import ops
+    g = load_golden("unit_sphere_norm.npz")
+    pos64, idx, w, ns = t64(g["pos"]), tl(g["idx"]), tl(g["w"]), int(g["num_super"])
+    pos = pos64.float().to(dev)
+    for key, kw in (("unw", dict(idx=idx.to(dev), w=None, num_super=ns)),
+                    ("w", dict(idx=idx.to(dev), w=w.to(dev), num_super=ns)),
+                    ("none_w", dict(idx=None, w=w.to(dev))),
+                    ("none", dict(idx=None, w=None))):
+        o, d = ops.unit_sphere_norm(pos, **kw)
+        _close(o, t64(g["out_" + key]))
+        assert torch.equal(d.cpu(), t64(g["diam_" + key]).float()), key
+
+
+@pytest.mark.parametrize("n,nseg,weighted", [(1, 1, False), (5000, 37, True), (100000, 2900, False),
+                                             (100000, 40000, True), (30000, 3, True), (700, 900, False)])
+def test_unit_sphere_norm_random(n, nseg, weighted, dev):
+    from superpoint_transformer_amd import ops
+    g = torch.Generator().manual_seed(n + nseg)
+    pos = (torch.randn(n, 3, generator=g) * 5 + 20).float()
+    idx = torch.randint(0, nseg, (n,), generator=g)
+    w = torch.randint(0, 300, (n,), generator=g) if weighted else None
+    o, d = ops.unit_sphere_norm(pos.to(dev), idx.to(dev), None if w is None else w.to(dev), nseg)
+    ro, rd = O.unit_sphere_norm(pos.double(), idx, w, nseg)
+    _close(o, ro)
+    assert torch.equal(d.cpu(), rd.float())          # f32 boxes: exact
+
+
+@pytest.mark.parametrize("r,d,B,slope", [(1000, 64, 1, 1.0), (5000, 32, 3, 0.01), (40000, 128, 4, 0.01),
+                                         (777, 18, 2, 1.0), (3, 64, 2, 0.2), (20000, 132, 1, 0.01),
+                                         (9000, 7, 5, 1.0)])
+@pytest.mark.parametrize("sorted_batch", [True, False])
+def test_graph_norm_forward_backward(r, d, B, slope, sorted_batch, dev):
+    from superpoint_transformer_amd import ops
+    g = torch.Generator().manual_seed(r + d)
+    x = (torch.randn(r, d, generator=g) * 2 + 3).float()
+    batch = torch.randint(0, B, (r,), generator=g)
+    if sorted_batch:
+        batch = batch.sort().values
+    w = torch.randn(d, generator=g).float()
+    b = torch.randn(d, generator=g).float()
+    a = (1 + 0.3 * torch.randn(d, generator=g)).float()
+    gw = torch.randn(r, d, generator=g).float()
+
+    x64 = x.double().requires_grad_()
+    p64 = [t.double().requires_grad_() for t in (w, b, a)]
+    ref = O.graph_norm(x64, batch if B > 1 else None, *p64, eps=1e-5, batch_size=B)
+    if slope != 1.0:
+        # an element within f32 rounding of the LeakyReLU kink may legitimately
+        # take the other slope: give those no upstream gradient
+        gw = gw * (ref.detach().abs() > 1e-3).float()
+        ref = torch.nn.functional.leaky_relu(ref, slope)
+    (ref * gw.double()).sum().backward()
+
+    xd = x.to(dev).requires_grad_()
+    pd = [t.to(dev).requires_grad_() for t in (w, b, a)]
+    y = ops.graph_norm(xd, batch.to(dev) if B > 1 else None, *pd, eps=1e-5,
+                       num_graphs=B, act_slope=slope)
+    (y * gw.to(dev)).sum().backward()
+
+    _close(y, ref.detach())
+    _close(xd.grad, x64.grad, tol=2e-5)
+    for pg, rg in zip(pd, p64):
+        _close(pg.grad, rg.grad, tol=2e-5)
+
+
+def test_graph_norm_large_mean_is_stable(dev):
+    """|mean| >> std: the one-pass f64 statistics must not cancel."""
+    from superpoint_transformer_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(50000, 32, generator=g) * 0.01 + 1000.0).float()
+    ones, zeros = torch.ones(32), torch.zeros(32)
+    y = ops.graph_norm(x.to(dev), None, ones.to(dev), zeros.to(dev), ones.to(dev))
+    ref = O.graph_norm(x.double(), None, ones.double(), zeros.double(), ones.double())
+    _close(y, ref, tol=1e-3)   # f32 input spacing at 1000 is 6e-5 = 0.6% of sigma
