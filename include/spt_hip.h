@@ -150,6 +150,52 @@ int spt_graphnorm_bwd_f32(const float* x, const float* gy, const int64_t* batch,
                           float* gmean_scale, void* ws, size_t ws_bytes,
                           spt_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * Fused sparse graph self-attention with relative-pose encodings   (a6.2-a6.7)
+ * Replaces the body of SelfAttentionBlock.forward between the qkv and the
+ * out_proj Linear (src/nn/attention.py:202-315): edge gathers q[s], k[t], v[t],
+ * qk scaling (src/utils/nn.py:75-127), the k/q/v RPE Linears on edge_attr,
+ * the per-head dot product, torch_geometric.utils.softmax over the edges of
+ * each source node and the scatter_sum of the weighted values.
+ *   qkv        [n, 2*H*D + H*Dv] f32: output of the block's own qkv Linear,
+ *              columns [q | k | v], each head-major (attention.py:202-204)
+ *   erowptr    [n+1], eperm [e] (NULL = edges already grouped by source):
+ *              CSR view of edge_index[0] from spt_csr_build
+ *   tgt_sorted [e] int32: edge_index[1] in CSR order (tgt[eperm[j]])
+ *   edge_attr  [e, F] f32 in ORIGINAL edge order, or NULL (no RPE)
+ *   Wk,bk / Wq,bq / Wv,bv: k_rpe / q_rpe / v_rpe Linear parameters
+ *              ([H*D,F],[H*D],[H*Dv,F],[H*Dv]); any may be NULL (encoder absent)
+ *   scale_mode/scale_a: 0: a*deg^-0.5 ('d.g', 'g'), 1: a + deg^-0.5 ('d+g'),
+ *              2: a ('d' or a constant); deg(s) = erowptr[s+1]-erowptr[s]
+ *   out [n, H*Dv]; m, z [n, H]: running max / sum of the softmax, saved for
+ *              the backward (both NULL to skip).
+ * Built shapes: H*D <= 128, H*Dv <= 128, F in {18, 32}; anything else returns
+ * an error (never a silent fallback).  Forward is deterministic.
+ * Backward: gout [n, H*Dv] -> gqkv [n, ld] (zero-filled here; k/v columns use
+ * f32 atomics), gedge_attr [e, F], and the six RPE parameter gradients
+ * (NULL to skip one).  ws: spt_edge_attn_bwd_workspace_bytes().
+ * ---------------------------------------------------------------------- */
+int spt_edge_attn_fwd_f32(const float* qkv, int64_t n, int H, int D, int Dv,
+                          const int32_t* erowptr, const int32_t* eperm,
+                          const int32_t* tgt_sorted, int64_t e,
+                          const float* edge_attr, int F, const float* Wk,
+                          const float* bk, const float* Wq, const float* bq,
+                          const float* Wv, const float* bv, int scale_mode,
+                          float scale_a, float* out, float* m, float* z,
+                          spt_stream_t stream);
+size_t spt_edge_attn_bwd_workspace_bytes(int H, int D, int Dv, int F);
+int spt_edge_attn_bwd_f32(const float* qkv, int64_t n, int H, int D, int Dv,
+                          const int32_t* erowptr, const int32_t* eperm,
+                          const int32_t* tgt_sorted, int64_t e,
+                          const float* edge_attr, int F, const float* Wk,
+                          const float* bk, const float* Wq, const float* bq,
+                          const float* Wv, const float* bv, int scale_mode,
+                          float scale_a, const float* out, const float* m,
+                          const float* z, const float* gout, float* gqkv,
+                          float* gedge_attr, float* gWk, float* gbk, float* gWq,
+                          float* gbq, float* gWv, float* gbv, void* ws,
+                          size_t ws_bytes, spt_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

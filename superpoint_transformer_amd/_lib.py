@@ -35,6 +35,12 @@ SIGNATURES = {
                                      _p, _p, _p, _p, _sz, _p]),
     "spt_graphnorm_bwd_f32": (_int, [_p, _p, _p, _i64, _int, _int, _p, _p, _p, _p, _p,
                                      _f32, _p, _p, _p, _p, _p, _sz, _p]),
+    "spt_edge_attn_fwd_f32": (_int, [_p, _i64, _int, _int, _int, _p, _p, _p, _i64, _p, _int,
+                                     _p, _p, _p, _p, _p, _p, _int, _f32, _p, _p, _p, _p]),
+    "spt_edge_attn_bwd_workspace_bytes": (_sz, [_int, _int, _int, _int]),
+    "spt_edge_attn_bwd_f32": (_int, [_p, _i64, _int, _int, _int, _p, _p, _p, _i64, _p, _int,
+                                     _p, _p, _p, _p, _p, _p, _int, _f32, _p, _p, _p, _p,
+                                     _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "spt_unit_sphere_norm_f32": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _p, _p, _p, _p]),
 }
 

@@ -79,3 +79,39 @@ def csr_of(idx, num_seg=None):
             return csr
     memo[key] = csr
     return csr
+
+
+class EdgeCSR:
+    """Edges of an attention graph grouped by SOURCE node (edge_index[0] is the
+    softmax group and the output row, src/nn/attention.py:207-208,307,315):
+    ``erowptr`` [n+1], ``eperm`` [e] (stable), ``tgt_sorted`` [e] int32 =
+    edge_index[1] in CSR order."""
+
+    __slots__ = ("erowptr", "eperm", "tgt_sorted", "n", "e")
+
+    def __init__(self, erowptr, eperm, tgt_sorted, n, e):
+        self.erowptr, self.eperm, self.tgt_sorted, self.n, self.e = \
+            erowptr, eperm, tgt_sorted, n, e
+
+
+def edge_csr_of(edge_index, num_nodes):
+    """Memoised :class:`EdgeCSR` of a [2,E] ``edge_index`` (one device sort per
+    batch and level, shared by every transformer block of the stage)."""
+    if isinstance(edge_index, EdgeCSR):
+        return edge_index
+    memo = getattr(edge_index, _ATTR, None)
+    key = (edge_index._version, int(num_nodes), edge_index.data_ptr(), edge_index.shape[1])
+    if memo is not None and key in memo:
+        return memo[key]
+    view = build_csr(edge_index[0], num_nodes)
+    # plumbing: the targets in CSR order (one gather per batch and level)
+    tgt_sorted = edge_index[1].index_select(0, view.perm.long()).to(torch.int32)
+    ecsr = EdgeCSR(view.rowptr, view.perm, tgt_sorted, int(num_nodes), edge_index.shape[1])
+    if memo is None or any(k[0] != edge_index._version for k in memo):
+        memo = {}
+        try:
+            setattr(edge_index, _ATTR, memo)
+        except Exception:
+            return ecsr
+    memo[key] = ecsr
+    return ecsr

@@ -1,0 +1,703 @@
+// Fused sparse superpoint-graph self-attention with relative-pose encodings
+// (src/nn/attention.py:202-315): per source node s, over its outgoing edges e
+//
+//   q_e = q[s]*scale(s) + Wq ea_e + bq     k_e = k[t_e] + Wk ea_e + bk
+//   v_e = v[t_e] + Wv ea_e + bv            c_eh = <q_e[h,:], k_e[h,:]>
+//   a_eh = softmax_{e in out(s)}(c_eh)     out[s,h,:] = sum_e a_eh v_e[h,:]
+//
+// The reference materialises ~10 [E, C] f32 temporaries over ~25 launches
+// (gathers, 3 RPE Linears, einsum, PyG softmax = scatter-max/exp/scatter-sum,
+// scatter-sum with float atomics).  Here one wave owns one source node: its
+// lanes are the (head, dim) slots of q/k/v, the three RPE weight blocks live
+// in that lane's registers for the whole kernel, edge_attr tiles are staged
+// through LDS and broadcast, the softmax is online (running max / sum per
+// head) and nothing per-edge is ever written to HBM.  Edges are visited
+// through the CSR-by-source view (erowptr / eperm), so the result is
+// deterministic (no atomics in the forward).
+#include <math.h>
+
+#include "common.hpp"
+
+namespace spt {
+
+constexpr int EA_TE = 8;           // edges per LDS tile
+constexpr int EA_WAVES = 4;        // waves per workgroup
+
+struct AttnShape {
+  int H, D, Dv, QK, C;             // heads, qk dim, value dim, H*D, H*Dv
+  int lph_log2, lphv_log2;         // lanes per head (qk / v)
+};
+
+// lane-owned weight rows --------------------------------------------------------
+template <int PL, int F>
+__device__ __forceinline__ void load_rows(const float* __restrict__ W,
+                                          const float* __restrict__ b, int first,
+                                          int total, float (&w)[PL][F], float (&bb)[PL]) {
+#pragma unroll
+  for (int i = 0; i < PL; ++i) {
+    bb[i] = 0.f;
+#pragma unroll
+    for (int f = 0; f < F; ++f) w[i][f] = 0.f;
+  }
+  if (W == nullptr) return;  // wave-uniform
+#pragma unroll
+  for (int i = 0; i < PL; ++i) {
+    const int r = first + i;
+    const int rc = r < total ? r : total - 1;  // clamped: loads stay in bounds, no branches
+    const float keep = r < total ? 1.f : 0.f;
+    if (b) bb[i] = b[rc] * keep;
+#pragma unroll
+    for (int f = 0; f < F; ++f) w[i][f] = W[(size_t)rc * F + f] * keep;
+  }
+}
+
+__device__ __forceinline__ void lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// stage the edge_attr rows of one tile into this wave's LDS slab
+template <int F>
+__device__ __forceinline__ void stage_tile(const float* __restrict__ ea,
+                                           int e_lane /* edge id held by lane u<TE */,
+                                           int cnt, float* slab) {
+  const int lane = threadIdx.x & 63;
+  if constexpr (F % 4 == 0) {
+    constexpr int CH = F / 4;                 // float4 chunks per row
+    constexpr int TOT = EA_TE * CH;
+#pragma unroll
+    for (int p = 0; p < (TOT + 63) / 64; ++p) {
+      const int q = p * 64 + lane;
+      const int u = q / CH, ch = q - u * CH;
+      const int e = __shfl(e_lane, u < EA_TE ? u : 0, 64);
+      if (q < TOT && u < cnt) {
+        const float4 t = *reinterpret_cast<const float4*>(ea + (size_t)e * F + ch * 4);
+        *reinterpret_cast<float4*>(slab + u * F + ch * 4) = t;
+      }
+    }
+  } else {
+    constexpr int TOT = EA_TE * F;
+#pragma unroll
+    for (int p = 0; p < (TOT + 63) / 64; ++p) {
+      const int q = p * 64 + lane;
+      const int u = q / F, f = q - u * F;
+      const int e = __shfl(e_lane, u < EA_TE ? u : 0, 64);
+      if (q < TOT && u < cnt) slab[u * F + f] = ea[(size_t)e * F + f];
+    }
+  }
+}
+
+template <int PL, int F>
+__device__ __forceinline__ void rpe(const float (&w)[PL][F], const float (&b)[PL],
+                                    const float* row, float (&o)[PL]) {
+#pragma unroll
+  for (int i = 0; i < PL; ++i) o[i] = b[i];
+  if constexpr (F % 4 == 0) {
+#pragma unroll
+    for (int f = 0; f < F; f += 4) {
+      const float4 a = *reinterpret_cast<const float4*>(row + f);  // LDS broadcast
+#pragma unroll
+      for (int i = 0; i < PL; ++i) {
+        o[i] = fmaf(w[i][f + 0], a.x, o[i]);
+        o[i] = fmaf(w[i][f + 1], a.y, o[i]);
+        o[i] = fmaf(w[i][f + 2], a.z, o[i]);
+        o[i] = fmaf(w[i][f + 3], a.w, o[i]);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+      const float a = row[f];
+#pragma unroll
+      for (int i = 0; i < PL; ++i) o[i] = fmaf(w[i][f], a, o[i]);
+    }
+  }
+}
+
+__device__ __forceinline__ float qk_scale_of(int mode, float a, int deg) {
+  // src/utils/nn.py:83-127: D = (dim // num_heads)^-0.5, G = deg(s)^-0.5
+  const float g = 1.0f / sqrtf((float)deg);
+  if (mode == 0) return a * g;   // 'd.g' (default), 'g' with a = 1
+  if (mode == 1) return a + g;   // 'd+g'
+  return a;                      // 'd' or a user constant
+}
+
+// waves per SIMD the register-resident weight block leaves room for
+constexpr int ea_min_waves(int qpl, int vpl, int f) {
+  const int w = (2 * qpl + vpl) * f;
+  return w <= 96 ? 3 : (w <= 136 ? 2 : 1);
+}
+
+template <int QPL, int VPL, int F>
+__global__ __launch_bounds__(EA_WAVES * 64, ea_min_waves(QPL, VPL, F)) void edge_attn_fwd_kernel(
+    const float* __restrict__ qkv, int ld, int64_t N, AttnShape sh,
+    const int32_t* __restrict__ erowptr, const int32_t* __restrict__ eperm,
+    const int32_t* __restrict__ tgt, const float* __restrict__ ea,
+    const float* __restrict__ Wk, const float* __restrict__ bk,
+    const float* __restrict__ Wq, const float* __restrict__ bq,
+    const float* __restrict__ Wv, const float* __restrict__ bv, int scale_mode,
+    float scale_a, float* __restrict__ out, float* __restrict__ mbuf,
+    float* __restrict__ zbuf) {
+  // per-wave LDS slab: edge_attr tile | gathered k rows | gathered v rows
+  constexpr int KROW = 64 * QPL, VROW = 64 * VPL;
+  constexpr int SLAB = EA_TE * (F + KROW + VROW);
+  __shared__ __attribute__((aligned(16))) float slab_all[EA_WAVES][SLAB];
+  const int lane = threadIdx.x & 63;
+  const int wid = threadIdx.x >> 6;
+  float* slab = slab_all[wid];
+  float* kslab = slab + EA_TE * F;
+  float* vslab = kslab + EA_TE * KROW;
+
+  const int j0 = lane * QPL, c0 = lane * VPL;
+  const bool qv = j0 < sh.QK, vv = c0 < sh.C;
+  const bool has_rpe = ea != nullptr && (Wk || Wq || Wv);
+  float wk[QPL][F], wq[QPL][F], wv[VPL][F], bbk[QPL], bbq[QPL], bbv[VPL];
+  load_rows<QPL, F>(Wk, bk, j0, sh.QK, wk, bbk);
+  load_rows<QPL, F>(Wq, bq, j0, sh.QK, wq, bbq);
+  load_rows<VPL, F>(Wv, bv, c0, sh.C, wv, bbv);
+
+  const int lph = 1 << sh.lph_log2;
+  // lane whose softmax state belongs to the head of this lane's value slots
+  const int hv = vv ? c0 / sh.Dv : 0;
+  const int src_lane = (hv * sh.D) / QPL;
+  const int my_head = qv ? j0 / sh.D : 0;
+  const bool head_leader = qv && ((lane & (lph - 1)) == 0);
+
+  const int64_t wave = (int64_t)blockIdx.x * EA_WAVES + wid;
+  const int64_t nwaves = (int64_t)gridDim.x * EA_WAVES;
+  for (int64_t s = wave; s < N; s += nwaves) {
+    const int start = erowptr[s], end = erowptr[s + 1];
+    const int deg = end - start;
+    float qs[QPL];
+    const float scale = deg > 0 ? qk_scale_of(scale_mode, scale_a, deg) : 0.f;
+#pragma unroll
+    for (int i = 0; i < QPL; ++i) qs[i] = qv ? qkv[s * ld + j0 + i] * scale : 0.f;
+    float m = -INFINITY, z = 0.f;
+    float acc[VPL];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) acc[i] = 0.f;
+
+    for (int t0 = start; t0 < end; t0 += EA_TE) {
+      const int cnt = (end - t0 < EA_TE) ? end - t0 : EA_TE;
+      int e_lane = 0, t_lane = 0;
+      if (lane < cnt) {
+        e_lane = eperm ? eperm[t0 + lane] : t0 + lane;
+        t_lane = tgt[t0 + lane];
+      }
+      lds_fence();  // previous tile's LDS reads are done before we overwrite
+      {
+        float kt[EA_TE][QPL], vt[EA_TE][VPL];
+#pragma unroll
+        for (int u = 0; u < EA_TE; ++u) {
+          const int64_t t = __shfl(t_lane, u, 64);
+#pragma unroll
+          for (int i = 0; i < QPL; ++i)
+            kt[u][i] = (u < cnt && qv) ? qkv[t * ld + sh.QK + j0 + i] : 0.f;
+#pragma unroll
+          for (int i = 0; i < VPL; ++i)
+            vt[u][i] = (u < cnt && vv) ? qkv[t * ld + 2 * sh.QK + c0 + i] : 0.f;
+        }
+        if (has_rpe) stage_tile<F>(ea, e_lane, cnt, slab);
+#pragma unroll
+        for (int u = 0; u < EA_TE; ++u) {
+#pragma unroll
+          for (int i = 0; i < QPL; ++i) kslab[u * KROW + i * 64 + lane] = kt[u][i];
+#pragma unroll
+          for (int i = 0; i < VPL; ++i) vslab[u * VROW + i * 64 + lane] = vt[u][i];
+        }
+      }
+      lds_fence();
+#pragma unroll 1
+      for (int u = 0; u < cnt; ++u) {
+        float ke[QPL], qe[QPL], ve[VPL];
+        if (has_rpe) {
+          rpe<QPL, F>(wk, bbk, slab + u * F, ke);
+          rpe<QPL, F>(wq, bbq, slab + u * F, qe);
+          rpe<VPL, F>(wv, bbv, slab + u * F, ve);
+        } else {
+#pragma unroll
+          for (int i = 0; i < QPL; ++i) ke[i] = qe[i] = 0.f;
+#pragma unroll
+          for (int i = 0; i < VPL; ++i) ve[i] = 0.f;
+        }
+        float p = 0.f;
+#pragma unroll
+        for (int i = 0; i < QPL; ++i) {
+          ke[i] += kslab[u * KROW + i * 64 + lane];
+          qe[i] += qs[i];
+          p = fmaf(qe[i], ke[i], p);
+        }
+        for (int o = 1; o < lph; o <<= 1) p += __shfl_xor(p, o, 64);
+        // online softmax per head (state replicated on the head's lanes)
+        const float mn = fmaxf(m, p);
+        const float corr = expf(m - mn);
+        const float pe = expf(p - mn);
+        z = fmaf(z, corr, pe);
+        m = mn;
+        float corr_v = corr, pe_v = pe;
+        if (sh.lph_log2 != sh.lphv_log2) {
+          corr_v = __shfl(corr, src_lane, 64);
+          pe_v = __shfl(pe, src_lane, 64);
+        }
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) acc[i] = fmaf(acc[i], corr_v, pe_v * (ve[i] + vslab[u * VROW + i * 64 + lane]));
+      }
+    }
+    float zz = z;
+    if (sh.lph_log2 != sh.lphv_log2) zz = __shfl(z, src_lane, 64);
+    if (vv) {
+#pragma unroll
+      for (int i = 0; i < VPL; ++i) out[s * sh.C + c0 + i] = acc[i] / (zz + 1e-16f);
+    }
+    if (head_leader && mbuf) {
+      mbuf[s * sh.H + my_head] = m;
+      zbuf[s * sh.H + my_head] = z;
+    }
+  }
+}
+
+// ---- backward ------------------------------------------------------------------
+// One pass over the same CSR view.  Per edge the forward quantities are
+// recomputed from (m, z) saved per (node, head); then
+//   dv_e = a g_s            da = <g_s, v_e>_head      dc = a (da - delta_s)
+//   dq_e = dc k_e           dk_e = dc q_e             delta_s = <g_s, out_s>_head
+// dq accumulates in registers (one writer per node); dk / dv go to the target
+// row with hardware f32 atomics (the only non-deterministic sums of the
+// library, like the reference's scatter backward); d edge_attr is a wave
+// reduce-scatter of the lane partials; the RPE weight gradients accumulate in
+// the owner lane's registers for the whole kernel and leave as per-wave partial
+// tables that a fixed-order kernel reduces.
+template <int N>
+__device__ __forceinline__ void wave_reduce_scatter(float (&p)[N], int lane) {
+  // after the call lane l holds the full sum of column (l * N / 64 ...) in p[0]
+  // for N = 32: columns are owned by lane pairs; see index math at the caller.
+#pragma unroll
+  for (int half = N / 2, o = 32; half >= 1; half >>= 1, o >>= 1) {
+    const bool upper = (lane & o) != 0;
+#pragma unroll
+    for (int i = 0; i < half; ++i) {
+      const float send = upper ? p[i] : p[i + half];
+      const float keep = upper ? p[i + half] : p[i];
+      p[i] = keep + __shfl_xor(send, o, 64);
+    }
+  }
+}
+
+template <int QPL, int VPL, int F>
+__global__ __launch_bounds__(EA_WAVES * 64, 1) void edge_attn_bwd_kernel(
+    const float* __restrict__ qkv, int ld, int64_t N, AttnShape sh,
+    const int32_t* __restrict__ erowptr, const int32_t* __restrict__ eperm,
+    const int32_t* __restrict__ tgt, const float* __restrict__ ea,
+    const float* __restrict__ Wk, const float* __restrict__ bk,
+    const float* __restrict__ Wq, const float* __restrict__ bq,
+    const float* __restrict__ Wv, const float* __restrict__ bv, int scale_mode,
+    float scale_a, const float* __restrict__ out, const float* __restrict__ mbuf,
+    const float* __restrict__ zbuf, const float* __restrict__ gout,
+    float* __restrict__ gqkv, float* __restrict__ gea, float* __restrict__ partial) {
+  constexpr int KROW = 64 * QPL, VROW = 64 * VPL;
+  constexpr int SLAB = EA_TE * (F + KROW + VROW);
+  __shared__ __attribute__((aligned(16))) float slab_all[EA_WAVES][SLAB];
+  const int lane = threadIdx.x & 63;
+  const int wid = threadIdx.x >> 6;
+  float* slab = slab_all[wid];
+  float* kslab = slab + EA_TE * F;
+  float* vslab = kslab + EA_TE * KROW;
+
+  const int j0 = lane * QPL, c0 = lane * VPL;
+  const bool qv = j0 < sh.QK, vv = c0 < sh.C;
+  const bool has_rpe = ea != nullptr && (Wk || Wq || Wv);
+  float wk[QPL][F], wq[QPL][F], wv[VPL][F], bbk[QPL], bbq[QPL], bbv[VPL];
+  load_rows<QPL, F>(Wk, bk, j0, sh.QK, wk, bbk);
+  load_rows<QPL, F>(Wq, bq, j0, sh.QK, wq, bbq);
+  load_rows<VPL, F>(Wv, bv, c0, sh.C, wv, bbv);
+  float gwk[QPL][F], gwq[QPL][F], gwv[VPL][F], gbk[QPL], gbq[QPL], gbv[VPL];
+#pragma unroll
+  for (int i = 0; i < QPL; ++i) {
+    gbk[i] = gbq[i] = 0.f;
+#pragma unroll
+    for (int f = 0; f < F; ++f) gwk[i][f] = gwq[i][f] = 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    gbv[i] = 0.f;
+#pragma unroll
+    for (int f = 0; f < F; ++f) gwv[i][f] = 0.f;
+  }
+
+  const int lph = 1 << sh.lph_log2, lphv = 1 << sh.lphv_log2;
+  const bool aligned = sh.lph_log2 == sh.lphv_log2;
+  const int hv = vv ? c0 / sh.Dv : 0;
+  const int src_lane = (hv * sh.D) / QPL;            // qk lane holding my value head's state
+  const int my_head = qv ? j0 / sh.D : 0;
+  const int vsrc_lane = (my_head * sh.Dv) / VPL;     // v lane holding my qk head's value sums
+
+  const int64_t wave = (int64_t)blockIdx.x * EA_WAVES + wid;
+  const int64_t nwaves = (int64_t)gridDim.x * EA_WAVES;
+  for (int64_t s = wave; s < N; s += nwaves) {
+    const int start = erowptr[s], end = erowptr[s + 1];
+    const int deg = end - start;
+    const float scale = deg > 0 ? qk_scale_of(scale_mode, scale_a, deg) : 0.f;
+    float qs[QPL], dqa[QPL], g[VPL];
+#pragma unroll
+    for (int i = 0; i < QPL; ++i) {
+      qs[i] = qv ? qkv[s * ld + j0 + i] * scale : 0.f;
+      dqa[i] = 0.f;
+    }
+    float dl = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      g[i] = vv ? gout[s * sh.C + c0 + i] : 0.f;
+      dl = fmaf(g[i], vv ? out[s * sh.C + c0 + i] : 0.f, dl);
+    }
+    for (int o = 1; o < lphv; o <<= 1) dl += __shfl_xor(dl, o, 64);
+    const float delta = aligned ? dl : __shfl(dl, vsrc_lane, 64);
+    const float m = qv ? mbuf[s * sh.H + my_head] : 0.f;
+    const float zi = qv ? 1.0f / (zbuf[s * sh.H + my_head] + 1e-16f) : 0.f;
+
+    for (int t0 = start; t0 < end; t0 += EA_TE) {
+      const int cnt = (end - t0 < EA_TE) ? end - t0 : EA_TE;
+      int e_lane = 0, t_lane = 0;
+      if (lane < cnt) {
+        e_lane = eperm ? eperm[t0 + lane] : t0 + lane;
+        t_lane = tgt[t0 + lane];
+      }
+      lds_fence();
+      {
+        float kt[EA_TE][QPL], vt[EA_TE][VPL];
+#pragma unroll
+        for (int u = 0; u < EA_TE; ++u) {
+          const int64_t t = __shfl(t_lane, u, 64);
+#pragma unroll
+          for (int i = 0; i < QPL; ++i)
+            kt[u][i] = (u < cnt && qv) ? qkv[t * ld + sh.QK + j0 + i] : 0.f;
+#pragma unroll
+          for (int i = 0; i < VPL; ++i)
+            vt[u][i] = (u < cnt && vv) ? qkv[t * ld + 2 * sh.QK + c0 + i] : 0.f;
+        }
+        if (has_rpe) stage_tile<F>(ea, e_lane, cnt, slab);
+#pragma unroll
+        for (int u = 0; u < EA_TE; ++u) {
+#pragma unroll
+          for (int i = 0; i < QPL; ++i) kslab[u * KROW + i * 64 + lane] = kt[u][i];
+#pragma unroll
+          for (int i = 0; i < VPL; ++i) vslab[u * VROW + i * 64 + lane] = vt[u][i];
+        }
+      }
+      lds_fence();
+#pragma unroll 1
+      for (int u = 0; u < cnt; ++u) {
+        const float* row = slab + u * F;
+        float ke[QPL], qe[QPL], ve[VPL];
+        if (has_rpe) {
+          rpe<QPL, F>(wk, bbk, row, ke);
+          rpe<QPL, F>(wq, bbq, row, qe);
+          rpe<VPL, F>(wv, bbv, row, ve);
+        } else {
+#pragma unroll
+          for (int i = 0; i < QPL; ++i) ke[i] = qe[i] = 0.f;
+#pragma unroll
+          for (int i = 0; i < VPL; ++i) ve[i] = 0.f;
+        }
+        float p = 0.f;
+#pragma unroll
+        for (int i = 0; i < QPL; ++i) {
+          ke[i] += kslab[u * KROW + i * 64 + lane];
+          qe[i] += qs[i];
+          p = fmaf(qe[i], ke[i], p);
+        }
+        for (int o = 1; o < lph; o <<= 1) p += __shfl_xor(p, o, 64);
+        const float a = expf(p - m) * zi;                     // attention weight (qk lanes)
+        const float a_v = aligned ? a : __shfl(a, src_lane, 64);
+        float dv[VPL], da = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+          ve[i] += vslab[u * VROW + i * 64 + lane];
+          dv[i] = a_v * g[i];
+          da = fmaf(g[i], ve[i], da);
+        }
+        for (int o = 1; o < lphv; o <<= 1) da += __shfl_xor(da, o, 64);
+        const float da_q = aligned ? da : __shfl(da, vsrc_lane, 64);
+        const float dc = a * (da_q - delta);
+        float dq[QPL], dk[QPL];
+#pragma unroll
+        for (int i = 0; i < QPL; ++i) {
+          dq[i] = qv ? dc * ke[i] : 0.f;
+          dk[i] = qv ? dc * qe[i] : 0.f;
+          dqa[i] += dq[i];
+        }
+        // scatter to the target row
+        const int64_t t = __shfl(t_lane, u, 64);
+        if (qv) {
+#pragma unroll
+          for (int i = 0; i < QPL; ++i) unsafeAtomicAdd(gqkv + t * ld + sh.QK + j0 + i, dk[i]);
+        }
+        if (vv) {
+#pragma unroll
+          for (int i = 0; i < VPL; ++i) unsafeAtomicAdd(gqkv + t * ld + 2 * sh.QK + c0 + i, dv[i]);
+        }
+        if (has_rpe) {
+          // weight / bias gradients: owner-lane register accumulators
+#pragma unroll
+          for (int i = 0; i < QPL; ++i) {
+            gbk[i] += dk[i];
+            gbq[i] += dq[i];
+          }
+#pragma unroll
+          for (int i = 0; i < VPL; ++i) gbv[i] += dv[i];
+          float pf[F];
+          if constexpr (F % 4 == 0) {
+#pragma unroll
+            for (int f = 0; f < F; f += 4) {
+              const float4 av = *reinterpret_cast<const float4*>(row + f);
+              const float a4[4] = {av.x, av.y, av.z, av.w};
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                float acc = 0.f;
+#pragma unroll
+                for (int i = 0; i < QPL; ++i) {
+                  gwk[i][f + r] = fmaf(dk[i], a4[r], gwk[i][f + r]);
+                  gwq[i][f + r] = fmaf(dq[i], a4[r], gwq[i][f + r]);
+                  acc = fmaf(wk[i][f + r], dk[i], acc);
+                  acc = fmaf(wq[i][f + r], dq[i], acc);
+                }
+#pragma unroll
+                for (int i = 0; i < VPL; ++i) {
+                  gwv[i][f + r] = fmaf(dv[i], a4[r], gwv[i][f + r]);
+                  acc = fmaf(wv[i][f + r], dv[i], acc);
+                }
+                pf[f + r] = acc;
+              }
+            }
+          } else {
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+              const float av = row[f];
+              float acc = 0.f;
+#pragma unroll
+              for (int i = 0; i < QPL; ++i) {
+                gwk[i][f] = fmaf(dk[i], av, gwk[i][f]);
+                gwq[i][f] = fmaf(dq[i], av, gwq[i][f]);
+                acc = fmaf(wk[i][f], dk[i], acc);
+                acc = fmaf(wq[i][f], dq[i], acc);
+              }
+#pragma unroll
+              for (int i = 0; i < VPL; ++i) {
+                gwv[i][f] = fmaf(dv[i], av, gwv[i][f]);
+                acc = fmaf(wv[i][f], dv[i], acc);
+              }
+              pf[f] = acc;
+            }
+          }
+          // d edge_attr[e, f] = sum over lanes of pf[f]
+          const int64_t e = __shfl(e_lane, u, 64);
+          if constexpr (F == 32) {
+            wave_reduce_scatter<32>(pf, lane);
+            // column owned by this lane pair: bits 5..1 of the lane, MSB first
+            const int col = ((lane >> 5) & 1) * 16 + ((lane >> 4) & 1) * 8 +
+                            ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+            const float tot = pf[0] + __shfl_xor(pf[0], 1, 64);
+            if ((lane & 1) == 0) gea[e * F + col] = tot;
+          } else {
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+              const float tot = wave_reduce_sum(pf[f]);
+              if (lane == 0) gea[e * F + f] = tot;
+            }
+          }
+        }
+      }
+    }
+    if (qv) {
+#pragma unroll
+      for (int i = 0; i < QPL; ++i) gqkv[s * ld + j0 + i] = dqa[i] * scale;
+    }
+  }
+  // per-wave partial tables [rows = 2*QK + C][F + 1]
+  if (has_rpe && partial) {
+    float* pw = partial + (size_t)wave * (2 * sh.QK + sh.C) * (F + 1);
+    if (qv) {
+#pragma unroll
+      for (int i = 0; i < QPL; ++i) {
+        float* rk = pw + (size_t)(j0 + i) * (F + 1);
+        float* rq = pw + (size_t)(sh.QK + j0 + i) * (F + 1);
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+          rk[f] = gwk[i][f];
+          rq[f] = gwq[i][f];
+        }
+        rk[F] = gbk[i];
+        rq[F] = gbq[i];
+      }
+    }
+    if (vv) {
+#pragma unroll
+      for (int i = 0; i < VPL; ++i) {
+        float* rv = pw + (size_t)(2 * sh.QK + c0 + i) * (F + 1);
+#pragma unroll
+        for (int f = 0; f < F; ++f) rv[f] = gwv[i][f];
+        rv[F] = gbv[i];
+      }
+    }
+  }
+}
+
+// fixed-order sum of the per-wave partial tables: 64 columns x 4 slices per block
+__global__ __launch_bounds__(256) void attn_reduce_partials_kernel(
+    const float* __restrict__ partial, int nwaves, int len, float* __restrict__ total) {
+  __shared__ float sl[4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int slice = threadIdx.x >> 6;
+  float acc = 0.f;
+  if (col < len) {
+    const int per = (nwaves + 3) / 4;
+    const int lo = slice * per, hi = (lo + per < nwaves) ? lo + per : nwaves;
+    for (int k = lo; k < hi; ++k) acc += partial[(size_t)k * len + col];
+  }
+  sl[slice][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (slice == 0 && col < len)
+    total[col] = ((sl[0][threadIdx.x] + sl[1][threadIdx.x]) + sl[2][threadIdx.x]) + sl[3][threadIdx.x];
+}
+
+// split the reduced [rows][F+1] table into the six gradient tensors
+__global__ void attn_unpack_grads_kernel(const float* __restrict__ total, int QK, int C,
+                                         int F, float* __restrict__ gWk,
+                                         float* __restrict__ gbk, float* __restrict__ gWq,
+                                         float* __restrict__ gbq, float* __restrict__ gWv,
+                                         float* __restrict__ gbv) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int rows = 2 * QK + C;
+  if (t >= rows * (F + 1)) return;
+  const int r = t / (F + 1), f = t - r * (F + 1);
+  const float v = total[t];
+  float* W;
+  float* b;
+  int rr;
+  if (r < QK) { W = gWk; b = gbk; rr = r; }
+  else if (r < 2 * QK) { W = gWq; b = gbq; rr = r - QK; }
+  else { W = gWv; b = gbv; rr = r - 2 * QK; }
+  if (f < F) { if (W) W[(size_t)rr * F + f] = v; }
+  else if (b) b[rr] = v;
+}
+
+static bool attn_shape(int H, int D, int Dv, int qpl, int vpl, AttnShape* sh) {
+  sh->H = H; sh->D = D; sh->Dv = Dv; sh->QK = H * D; sh->C = H * Dv;
+  if (sh->QK > 64 * qpl || sh->C > 64 * vpl) return false;
+  if (D % qpl || Dv % vpl) return false;
+  const int lph = D / qpl, lphv = Dv / vpl;
+  if ((lph & (lph - 1)) || (lphv & (lphv - 1))) return false;
+  sh->lph_log2 = 0; while ((1 << sh->lph_log2) < lph) ++sh->lph_log2;
+  sh->lphv_log2 = 0; while ((1 << sh->lphv_log2) < lphv) ++sh->lphv_log2;
+  return true;
+}
+
+static inline int per_lane(int total) { return total <= 64 ? 1 : (total <= 128 ? 2 : 0); }
+
+}  // namespace spt
+
+using namespace spt;
+
+#define SPT_ATTN_DISPATCH(FN, ...)                                             \
+  do {                                                                         \
+    bool done__ = false;                                                       \
+    SPT_ATTN_CASE(FN, 1, 1, 32, __VA_ARGS__)                                   \
+    SPT_ATTN_CASE(FN, 1, 2, 32, __VA_ARGS__)                                   \
+    SPT_ATTN_CASE(FN, 2, 2, 32, __VA_ARGS__)                                   \
+    SPT_ATTN_CASE(FN, 1, 1, 18, __VA_ARGS__)                                   \
+    SPT_ATTN_CASE(FN, 1, 2, 18, __VA_ARGS__)                                   \
+    SPT_ATTN_CASE(FN, 2, 2, 18, __VA_ARGS__)                                   \
+    if (!done__)                                                               \
+      return ::spt::fail(-4, "%s: unsupported attention shape H=%d D=%d Dv=%d F=%d " \
+                         "(built: H*D<=128, H*Dv<=128, F in {18,32})", __func__, H, D, Dv, F); \
+  } while (0)
+
+extern "C" int spt_edge_attn_fwd_f32(const float* qkv, int64_t n, int H, int D, int Dv,
+                                     const int32_t* erowptr, const int32_t* eperm,
+                                     const int32_t* tgt_sorted, int64_t e,
+                                     const float* edge_attr, int F, const float* Wk,
+                                     const float* bk, const float* Wq, const float* bq,
+                                     const float* Wv, const float* bv, int scale_mode,
+                                     float scale_a, float* out, float* m, float* z,
+                                     spt_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPT_CHECK_ARG(n >= 0 && e >= 0 && H >= 1 && D >= 1 && Dv >= 1, "bad shape");
+  if (n == 0) return 0;
+  SPT_CHECK_ARG(qkv && erowptr && out && (tgt_sorted || e == 0), "null pointer");
+  SPT_CHECK_ARG((m == nullptr) == (z == nullptr), "pass both m and z or neither");
+  if (!edge_attr) F = 32;  // no RPE: any compiled F will do
+  const int qpl = per_lane(H * D), vpl = per_lane(H * Dv);
+  const int ld = 2 * H * D + H * Dv;
+  const int grid = (int)(ceil_div(n, EA_WAVES) < 256 * 8 ? ceil_div(n, EA_WAVES) : 256 * 8);
+#define SPT_ATTN_CASE(FN, Q, V, FF, ...)                                        \
+  if (!done__ && qpl == Q && vpl == V && F == FF) {                            \
+    AttnShape sh;                                                              \
+    if (attn_shape(H, D, Dv, Q, V, &sh)) {                                     \
+      FN<Q, V, FF><<<grid, EA_WAVES * 64, 0, stream>>>(__VA_ARGS__);           \
+      done__ = true;                                                           \
+    }                                                                          \
+  }
+  // `sh` is rebuilt inside each case; the kernel argument list refers to it
+  SPT_ATTN_DISPATCH(edge_attn_fwd_kernel, qkv, ld, n, sh, erowptr, eperm, tgt_sorted,
+                    edge_attr, Wk, bk, Wq, bq, Wv, bv, scale_mode, scale_a, out, m, z);
+#undef SPT_ATTN_CASE
+  SPT_CHECK_LAUNCH();
+  return 0;
+}
+
+constexpr int EA_BWD_BLOCKS = 256;  // one 4-wave workgroup per CU (1 wave per SIMD)
+
+extern "C" size_t spt_edge_attn_bwd_workspace_bytes(int H, int D, int Dv, int F) {
+  const size_t len = (size_t)(2 * H * D + H * Dv) * (F + 1);
+  return align_up((size_t)EA_BWD_BLOCKS * EA_WAVES * len * 4, 256) + align_up(len * 4, 256);
+}
+
+extern "C" int spt_edge_attn_bwd_f32(const float* qkv, int64_t n, int H, int D, int Dv,
+                                     const int32_t* erowptr, const int32_t* eperm,
+                                     const int32_t* tgt_sorted, int64_t e,
+                                     const float* edge_attr, int F, const float* Wk,
+                                     const float* bk, const float* Wq, const float* bq,
+                                     const float* Wv, const float* bv, int scale_mode,
+                                     float scale_a, const float* out, const float* m,
+                                     const float* z, const float* gout, float* gqkv,
+                                     float* gedge_attr, float* gWk, float* gbk,
+                                     float* gWq, float* gbq, float* gWv, float* gbv,
+                                     void* ws, size_t ws_bytes, spt_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPT_CHECK_ARG(n >= 0 && e >= 0 && H >= 1 && D >= 1 && Dv >= 1, "bad shape");
+  if (n == 0) return 0;
+  SPT_CHECK_ARG(qkv && erowptr && out && m && z && gout && gqkv && (tgt_sorted || e == 0), "null pointer");
+  const bool has_rpe = edge_attr && (Wk || Wq || Wv);
+  SPT_CHECK_ARG(!has_rpe || gedge_attr, "gedge_attr is required with RPE");
+  if (!edge_attr) F = 32;
+  const int qpl = per_lane(H * D), vpl = per_lane(H * Dv);
+  const int ld = 2 * H * D + H * Dv;
+  const size_t len = (size_t)ld * (F + 1);
+  const size_t need = spt_edge_attn_bwd_workspace_bytes(H, D, Dv, F);
+  SPT_CHECK_ARG(!has_rpe || (ws && ws_bytes >= need), "workspace too small");
+  float* partial = has_rpe ? (float*)ws : nullptr;
+  float* total = has_rpe ? (float*)((char*)ws + align_up((size_t)EA_BWD_BLOCKS * EA_WAVES * len * 4, 256)) : nullptr;
+  const int grid = (int)(ceil_div(n, EA_WAVES) < EA_BWD_BLOCKS ? ceil_div(n, EA_WAVES) : EA_BWD_BLOCKS);
+  // k / v columns of gqkv receive atomics: start from zero (q columns are overwritten)
+  hipMemsetAsync(gqkv, 0, (size_t)n * ld * 4, stream);
+#define SPT_ATTN_CASE(FN, Q, V, FF, ...)                                        \
+  if (!done__ && qpl == Q && vpl == V && F == FF) {                            \
+    AttnShape sh;                                                              \
+    if (attn_shape(H, D, Dv, Q, V, &sh)) {                                     \
+      FN<Q, V, FF><<<grid, EA_WAVES * 64, 0, stream>>>(__VA_ARGS__);           \
+      done__ = true;                                                           \
+    }                                                                          \
+  }
+  SPT_ATTN_DISPATCH(edge_attn_bwd_kernel, qkv, ld, n, sh, erowptr, eperm, tgt_sorted,
+                    edge_attr, Wk, bk, Wq, bq, Wv, bv, scale_mode, scale_a, out, m, z,
+                    gout, gqkv, gedge_attr, partial);
+#undef SPT_ATTN_CASE
+  if (has_rpe) {
+    attn_reduce_partials_kernel<<<(int)ceil_div((int64_t)len, 64), 256, 0, stream>>>(
+        partial, grid * EA_WAVES, (int)len, total);
+    attn_unpack_grads_kernel<<<(int)ceil_div((int64_t)len, 256), 256, 0, stream>>>(
+        total, H * D, H * Dv, F, gWk, gbk, gWq, gbq, gWv, gbv);
+  }
+  SPT_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,73 @@
+"""MLP / FFN / Classifier (src/nn/mlp.py).  Linear layers stay on rocBLAS via
+PyTorch; every ``GraphNorm -> LeakyReLU`` pair runs as ONE fused HIP pass."""
+from torch import nn
+
+from .norm import INDEX_BASED_NORMS, GraphNorm
+
+__all__ = ["MLP", "FFN", "Classifier"]
+
+
+def _mlp(dims, activation, last_activation, norm, last_norm, drop):
+    assert len(dims) >= 2
+    bias = norm is None
+    mods = []
+    for i in range(1, len(dims)):
+        mods.append(nn.Linear(dims[i - 1], dims[i], bias=bias))
+        if norm is not None and (last_norm or i < len(dims) - 1):
+            mods.append(norm(dims[i]))
+        if activation is not None and (last_activation or i < len(dims) - 1):
+            mods.append(activation)
+    if drop is not None and drop > 0:
+        mods.append(nn.Dropout(drop, inplace=True))
+    return nn.ModuleList(mods)
+
+
+class MLP(nn.Module):
+    """Linear -> norm -> activation stacks on [N, D] features (mlp.py:60-94).
+    Parameter paths are ``mlp.<i>.*`` like the reference."""
+
+    def __init__(self, dims, activation=nn.LeakyReLU(), last_activation=True,
+                 norm=GraphNorm, last_norm=True, drop=None):
+        super().__init__()
+        self.mlp = _mlp(dims, activation, last_activation, norm, last_norm, drop)
+        self.out_dim = dims[-1]
+
+    def forward(self, x, batch=None, batch_size=None):
+        mods = list(self.mlp)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, GraphNorm):
+                nxt = mods[i + 1] if i + 1 < len(mods) else None
+                if isinstance(nxt, nn.LeakyReLU):
+                    x = m(x, batch=batch, batch_size=batch_size,
+                          act_slope=nxt.negative_slope)
+                    i += 2
+                    continue
+                x = m(x, batch=batch, batch_size=batch_size)
+            elif isinstance(m, INDEX_BASED_NORMS):
+                x = m(x, batch=batch)
+            else:
+                x = m(x)
+            i += 1
+        return x
+
+
+class FFN(MLP):
+    """Two Linear layers, no norm, no last activation (mlp.py:97-125)."""
+
+    def __init__(self, dim, hidden_dim=None, out_dim=None, activation=nn.LeakyReLU(),
+                 drop=None):
+        hidden_dim = hidden_dim or dim
+        out_dim = out_dim or dim
+        super().__init__([dim, hidden_dim, out_dim], activation=activation,
+                         last_activation=False, norm=None, last_norm=False, drop=drop)
+
+
+class Classifier(nn.Module):
+    def __init__(self, in_dim, num_classes, bias=True):
+        super().__init__()
+        self.classifier = nn.Linear(in_dim, num_classes, bias=bias)
+
+    def forward(self, x):
+        return self.classifier(x)

@@ -1,0 +1,235 @@
+"""SPT backbone driver over NAG levels (src/models/components/spt.py:14-981).
+
+U-Net over the hierarchy: PointStage on level 0, DownNFuseStages (pool ->
+fuse -> transformer blocks) going up, UpNFuseStages (unpool -> fuse ->
+blocks) coming back down to level 1.  Constructor arguments and module names
+(``first_stage``, ``down_stages``, ``up_stages``, ``node_mlps``,
+``h_edge_mlps``, ``v_edge_mlps``) follow the reference so that its state
+dicts load.  ``nano=True`` (no level-0 stage) and the sparse-CNN point encoder
+are outside the hot path and raise."""
+from torch import nn
+
+from .fusion import CatFusion
+from .mlp import MLP
+from .norm import GraphNorm
+from .pool import pool_factory
+from .stage import DownNFuseStage, PointStage, UpNFuseStage
+from .transformer import VersionHolder
+
+__all__ = ["SPT"]
+
+
+def _listify(*args):
+    """spt.py `listify_with_reference`: broadcast scalars to the length of the
+    first (list) argument."""
+    ref = args[0]
+    if ref is None:
+        return [[] for _ in args]
+    if not isinstance(ref, (list, tuple)):
+        ref = [ref]
+    n = len(ref)
+    out = [list(ref)]
+    for a in args[1:]:
+        if isinstance(a, (list, tuple)) and len(a) == n:
+            out.append(list(a))
+        elif isinstance(a, (list, tuple)) and n == 0:
+            out.append([])
+        else:
+            out.append([a] * n)
+    return out
+
+
+def _mlps(layers, num_stage, activation, norm, shared):
+    if layers is None:
+        return [None] * num_stage
+    if shared:
+        return nn.ModuleList([MLP(layers, activation=activation, norm=norm)] * num_stage)
+    return nn.ModuleList([MLP(layers, activation=activation, norm=norm)
+                          for _ in range(num_stage)])
+
+
+def _rpe_per_stage(rpe, num_stages, in_dim, out_dim, stages_share):
+    if not isinstance(rpe, bool):
+        assert stages_share
+        return [rpe] * num_stages
+    if stages_share and rpe:
+        return [nn.Linear(in_dim, out_dim)] * num_stages
+    return [rpe] * num_stages
+
+
+def _get(data, key, default=None):
+    if isinstance(data, dict):
+        return data.get(key, default)
+    return getattr(data, key, default)
+
+
+class SPT(nn.Module):
+    def __init__(self, point_mlp=None, point_drop=None, nano=False, down_dim=None,
+                 down_pool_dim=None, down_in_mlp=None, down_out_mlp=None,
+                 down_mlp_drop=None, down_num_heads=1, down_num_blocks=0, down_ffn_ratio=4,
+                 down_residual_drop=None, down_attn_drop=None, down_drop_path=None,
+                 up_dim=None, up_in_mlp=None, up_out_mlp=None, up_mlp_drop=None,
+                 up_num_heads=1, up_num_blocks=0, up_ffn_ratio=4, up_residual_drop=None,
+                 up_attn_drop=None, up_drop_path=None, node_mlp=None, h_edge_mlp=None,
+                 v_edge_mlp=None, mlp_activation=nn.LeakyReLU(), mlp_norm=GraphNorm,
+                 qk_dim=8, qkv_bias=True, qk_scale=None, in_rpe_dim=18,
+                 activation=nn.LeakyReLU(), norm=GraphNorm, pre_norm=True, no_sa=False,
+                 no_ffn=False, k_rpe=False, q_rpe=False, v_rpe=False, k_delta_rpe=False,
+                 q_delta_rpe=False, qk_share_rpe=False, q_on_minus_rpe=False,
+                 share_hf_mlps=False, stages_share_rpe=False, blocks_share_rpe=False,
+                 heads_share_rpe=False, use_pos=True, use_node_hf=True, use_diameter=False,
+                 use_diameter_parent=False, pool="max", unpool="index", fusion="cat",
+                 norm_mode="graph", output_stage_wise=False, version="3.0.0", **ignored):
+        super().__init__()
+        if nano:
+            raise NotImplementedError("nano SPT (no level-0 stage) is not on the HIP path yet")
+        if norm_mode != "graph":
+            raise NotImplementedError("only norm_mode='graph' is built")
+        self.nano = False
+        self.use_pos, self.use_node_hf = use_pos, use_node_hf
+        self.use_diameter, self.use_diameter_parent = use_diameter, use_diameter_parent
+        self.output_stage_wise = output_stage_wise
+        self.version_holder = VersionHolder(version)
+
+        (down_dim, down_pool_dim, down_in_mlp, down_out_mlp, down_mlp_drop, down_num_heads,
+         down_num_blocks, down_ffn_ratio, down_residual_drop, down_attn_drop,
+         down_drop_path, pool) = _listify(
+            down_dim, down_pool_dim, down_in_mlp, down_out_mlp, down_mlp_drop,
+            down_num_heads, down_num_blocks, down_ffn_ratio, down_residual_drop,
+            down_attn_drop, down_drop_path, pool)
+        (up_dim, up_in_mlp, up_out_mlp, up_mlp_drop, up_num_heads, up_num_blocks,
+         up_ffn_ratio, up_residual_drop, up_attn_drop, up_drop_path) = _listify(
+            up_dim, up_in_mlp, up_out_mlp, up_mlp_drop, up_num_heads, up_num_blocks,
+            up_ffn_ratio, up_residual_drop, up_attn_drop, up_drop_path)
+        # in_mlp entries are themselves lists: _listify must not broadcast them
+        num_down, num_up = len(down_dim), len(up_dim)
+
+        needs_h_edge = any(b > 0 for b in down_num_blocks + up_num_blocks)
+        self.node_mlps = _mlps(node_mlp if use_node_hf else None, num_down, mlp_activation,
+                               mlp_norm, share_hf_mlps)
+        self.h_edge_mlps = _mlps(h_edge_mlp if needs_h_edge else None, num_down,
+                                 mlp_activation, mlp_norm, share_hf_mlps)
+        self.v_edge_mlps = _mlps(None, num_down, mlp_activation, mlp_norm, share_hf_mlps)
+
+        self.first_stage = PointStage(
+            point_mlp, mlp_activation=mlp_activation, mlp_norm=mlp_norm, mlp_drop=point_drop,
+            use_pos=use_pos, use_diameter_parent=use_diameter_parent,
+            version_holder=self.version_holder)
+        self.feature_fusion = CatFusion()
+
+        common = dict(mlp_activation=mlp_activation, mlp_norm=mlp_norm, qk_dim=qk_dim,
+                      qkv_bias=qkv_bias, qk_scale=qk_scale, in_rpe_dim=in_rpe_dim,
+                      activation=activation, norm=norm, pre_norm=pre_norm, no_sa=no_sa,
+                      no_ffn=no_ffn, v_rpe=v_rpe, k_delta_rpe=k_delta_rpe,
+                      q_delta_rpe=q_delta_rpe, qk_share_rpe=qk_share_rpe,
+                      q_on_minus_rpe=q_on_minus_rpe, use_pos=use_pos,
+                      use_diameter=use_diameter, use_diameter_parent=use_diameter_parent,
+                      blocks_share_rpe=blocks_share_rpe, heads_share_rpe=heads_share_rpe,
+                      version_holder=self.version_holder)
+        if num_down > 0:
+            dk = _rpe_per_stage(k_rpe, num_down, 18, qk_dim, stages_share_rpe)
+            dq = _rpe_per_stage(q_rpe and not (k_rpe and qk_share_rpe), num_down, 18, qk_dim,
+                                stages_share_rpe)
+            self.down_stages = nn.ModuleList([
+                DownNFuseStage(
+                    down_dim[i], num_blocks=down_num_blocks[i], in_mlp=down_in_mlp[i],
+                    out_mlp=down_out_mlp[i], mlp_drop=down_mlp_drop[i],
+                    num_heads=down_num_heads[i], ffn_ratio=down_ffn_ratio[i],
+                    residual_drop=down_residual_drop[i], attn_drop=down_attn_drop[i],
+                    drop_path=down_drop_path[i], k_rpe=dk[i], q_rpe=dq[i],
+                    pool=pool_factory(pool[i], down_pool_dim[i]), fusion=fusion, **common)
+                for i in range(num_down)])
+        else:
+            self.down_stages = None
+        if num_up > 0:
+            uk = _rpe_per_stage(k_rpe, num_up, 18, qk_dim, stages_share_rpe)
+            uq = _rpe_per_stage(q_rpe and not (k_rpe and qk_share_rpe), num_up, 18, qk_dim,
+                                stages_share_rpe)
+            self.up_stages = nn.ModuleList([
+                UpNFuseStage(
+                    up_dim[i], num_blocks=up_num_blocks[i], in_mlp=up_in_mlp[i],
+                    out_mlp=up_out_mlp[i], mlp_drop=up_mlp_drop[i], num_heads=up_num_heads[i],
+                    ffn_ratio=up_ffn_ratio[i], residual_drop=up_residual_drop[i],
+                    attn_drop=up_attn_drop[i], drop_path=up_drop_path[i], k_rpe=uk[i],
+                    q_rpe=uq[i], unpool=unpool, fusion=fusion, **common)
+                for i in range(num_up)])
+        else:
+            self.up_stages = None
+
+    @property
+    def num_down_stages(self):
+        return len(self.down_stages) if self.down_stages is not None else 0
+
+    @property
+    def num_up_stages(self):
+        return len(self.up_stages) if self.up_stages is not None else 0
+
+    @property
+    def out_dim(self):
+        if self.output_stage_wise:
+            return [s.out_dim for s in self.up_stages][::-1] + [self.down_stages[-1].out_dim]
+        if self.up_stages is not None:
+            return self.up_stages[-1].out_dim
+        if self.down_stages is not None:
+            return self.down_stages[-1].out_dim
+        return self.first_stage.out_dim
+
+    def forward(self, nag):
+        """``nag[i]`` exposes pos, x, super_index, node_size, batch, edge_index,
+        edge_attr (attributes or dict keys).  ``nag.num_clouds`` (optional) is
+        the number of clouds in the batch.  Returns level-1 features (or the
+        stage-wise list), like spt.py:760-879."""
+        B = _get(nag, "num_clouds", None) if not isinstance(nag, (list, tuple)) else None
+        levels = [nag[i] for i in range(self.num_down_stages + 1)]
+        sizes = [_get(lv, "pos").shape[0] for lv in levels]
+
+        def norm_index(lv):                                  # Data.norm_index('graph')
+            return _get(lv, "batch")
+
+        d0 = levels[0]
+        x, diameter = self.first_stage(                       # spt.py:894-913
+            _get(d0, "x") if self.use_node_hf else None, norm_index(d0),
+            pos=_get(d0, "pos"), node_size=_get(d0, "node_size"),
+            super_index=_get(d0, "super_index"), num_super=sizes[1] if len(sizes) > 1 else None,
+            num_graphs=B)
+
+        down_outputs, node_x, edge_attrs = [], {}, {}
+        for i_stage in range(self.num_down_stages):
+            i_level = i_stage + 1
+            lv = levels[i_level]
+            stage = self.down_stages[i_stage]
+            ni = norm_index(lv)
+            xh = _get(lv, "x")
+            if self.node_mlps[i_stage] is not None and xh is not None:     # spt.py:823-826
+                xh = self.node_mlps[i_stage](xh, batch=ni, batch_size=B)
+            ea = _get(lv, "edge_attr")
+            ei = _get(lv, "edge_index")
+            if self.h_edge_mlps[i_stage] is not None and ea is not None:   # spt.py:827-835
+                eb = None if ni is None else ni[ei[0]]
+                ea = self.h_edge_mlps[i_stage](ea, batch=eb, batch_size=B)
+            node_x[i_level], edge_attrs[i_level] = xh, ea
+            is_last = i_level == len(levels) - 1
+            x, diameter = stage(                                            # spt.py:915-930
+                xh if self.use_node_hf else None, x, ni, _get(levels[i_level - 1], "super_index"),
+                pos=_get(lv, "pos"), node_size=_get(lv, "node_size"),
+                super_index=None if is_last else _get(lv, "super_index"),
+                edge_index=ei, edge_attr=ea, num_super=sizes[i_level], num_graphs=B,
+                num_super_parent=None if is_last else sizes[i_level + 1])
+            down_outputs.append(x)
+
+        up_outputs = []
+        for i_stage in range(self.num_up_stages):                           # spt.py:860-868
+            i_level = self.num_down_stages - i_stage - 1
+            lv = levels[i_level]
+            x_skip = down_outputs[-(2 + i_stage)]
+            xh = node_x.get(i_level) if self.use_node_hf else None
+            x, _ = self.up_stages[i_stage](
+                self.feature_fusion(x_skip, xh), x, norm_index(lv), _get(lv, "super_index"),
+                pos=_get(lv, "pos"), node_size=_get(lv, "node_size"),
+                super_index=_get(lv, "super_index"), edge_index=_get(lv, "edge_index"),
+                edge_attr=edge_attrs.get(i_level), num_super=sizes[i_level + 1], num_graphs=B)
+            up_outputs.append(x)
+
+        if self.output_stage_wise:
+            return [x] + up_outputs[::-1][1:] + [down_outputs[-1]]
+        return x

@@ -6,7 +6,7 @@ stream; there is no eager-PyTorch path.
 import torch
 
 from . import _lib
-from .csr import SegmentCSR, csr_of
+from .csr import EdgeCSR, SegmentCSR, csr_of, edge_csr_of
 
 _OPS = {"sum": 0, "add": 0, "mean": 1, "min": 2, "max": 3}
 
@@ -269,3 +269,100 @@ def graph_norm(x, batch, weight, bias, mean_scale, eps=1e-5, num_graphs=None,
         num_graphs = int(batch.max().item()) + 1 if batch.numel() else 1
     return _GraphNorm.apply(x, batch, int(num_graphs), weight, bias, mean_scale,
                             float(eps), float(act_slope))
+
+
+# ---------------------------------------------------------------------------
+# Fused edge attention (src/nn/attention.py:202-315)
+# ---------------------------------------------------------------------------
+def _f32c(t):
+    if t is None:
+        return None
+    t = t.detach()
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+class _EdgeAttention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, ecsr, edge_attr, Wk, bk, Wq, bq, Wv, bv, H, D, scale_mode, scale_a):
+        _lib.require_cuda(qkv)
+        q2 = _f32c(qkv)
+        n, ld = q2.shape
+        Dv = (ld - 2 * H * D) // H
+        if 2 * H * D + H * Dv != ld or ecsr.n != n:
+            raise ValueError(f"qkv has shape {tuple(q2.shape)}: not [n={ecsr.n}, 2*H*D + H*Dv]")
+        dev = q2.device
+        ea = _f32c(edge_attr)
+        F = ea.shape[1] if ea is not None else 0
+        if ea is not None and ea.shape[0] != ecsr.e:
+            raise ValueError("edge_attr rows != number of edges")
+        ps = [_f32c(t) for t in (Wk, bk, Wq, bq, Wv, bv)]
+        out = torch.empty((n, H * Dv), dtype=torch.float32, device=dev)
+        m = torch.empty((n, H), dtype=torch.float32, device=dev)
+        z = torch.empty((n, H), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            st = _lib.lib.spt_edge_attn_fwd_f32(
+                _lib.ptr(q2), n, H, D, Dv, _lib.ptr(ecsr.erowptr), _lib.ptr(ecsr.eperm),
+                _lib.ptr(ecsr.tgt_sorted), ecsr.e, _lib.ptr(ea), F,
+                *[_lib.ptr(t) for t in ps], scale_mode, scale_a, _lib.ptr(out),
+                _lib.ptr(m), _lib.ptr(z), _lib.stream_ptr(dev))
+        _lib.check(st, "spt_edge_attn_fwd_f32")
+        ctx.save_for_backward(q2, ea, *[t for t in ps if t is not None], out, m, z)
+        ctx.present = [t is not None for t in ps]
+        ctx.has_ea = ea is not None
+        ctx.meta = (ecsr, H, D, Dv, F, scale_mode, scale_a, qkv.dtype,
+                    None if edge_attr is None else edge_attr.dtype)
+        return out.to(qkv.dtype)
+
+    @staticmethod
+    def backward(ctx, gout):
+        ecsr, H, D, Dv, F, scale_mode, scale_a, q_dtype, ea_dtype = ctx.meta
+        saved = list(ctx.saved_tensors)
+        q2 = saved.pop(0)
+        ea = saved.pop(0) if ctx.has_ea else None
+        if not ctx.has_ea:
+            saved.pop(0)
+        ps = [saved.pop(0) if pres else None for pres in ctx.present]
+        out, m, z = saved
+        n, ld = q2.shape
+        dev = q2.device
+        g = _f32c(gout)
+        gqkv = torch.empty_like(q2)
+        gea = torch.empty_like(ea) if ea is not None else None
+        gps = [torch.empty_like(t) if t is not None else None for t in ps]
+        nb = _lib.lib.spt_edge_attn_bwd_workspace_bytes(H, D, Dv, max(F, 1))
+        ws = _workspace(nb, dev)
+        with torch.cuda.device(dev):
+            st = _lib.lib.spt_edge_attn_bwd_f32(
+                _lib.ptr(q2), n, H, D, Dv, _lib.ptr(ecsr.erowptr), _lib.ptr(ecsr.eperm),
+                _lib.ptr(ecsr.tgt_sorted), ecsr.e, _lib.ptr(ea), F,
+                *[_lib.ptr(t) for t in ps], scale_mode, scale_a, _lib.ptr(out),
+                _lib.ptr(m), _lib.ptr(z), _lib.ptr(g), _lib.ptr(gqkv), _lib.ptr(gea),
+                *[_lib.ptr(t) for t in gps], _lib.ptr(ws), ws.numel(),
+                _lib.stream_ptr(dev))
+        _lib.check(st, "spt_edge_attn_bwd_f32")
+        if gea is not None and not (any(ctx.present[0::2])):
+            gea = None
+        return (gqkv.to(q_dtype), None, None if gea is None else gea.to(ea_dtype),
+                *gps, None, None, None, None)
+
+
+def edge_attention(qkv, edge_index, edge_attr=None, k_rpe=None, q_rpe=None, v_rpe=None,
+                   num_heads=1, qk_dim=8, scale_mode=0, scale_a=1.0):
+    """out[s] = sum_e softmax_e(<q_e, k_e>) v_e over the edges leaving s.
+
+    ``qkv`` [N, 2*H*D + C] is the output of the block's qkv Linear;
+    ``edge_index`` a [2,E] tensor or an :class:`EdgeCSR`; ``k_rpe`` etc. are
+    (weight, bias) pairs of the RPE Linears or None.  Returns [N, C]
+    (before out_proj)."""
+    ecsr = edge_csr_of(edge_index, qkv.shape[0])
+
+    def wb(p):
+        return (None, None) if p is None else (p[0], p[1])
+
+    Wk, bk = wb(k_rpe)
+    Wq, bq = wb(q_rpe)
+    Wv, bv = wb(v_rpe)
+    return _EdgeAttention.apply(qkv, ecsr, edge_attr, Wk, bk, Wq, bq, Wv, bv,
+                                int(num_heads), int(qk_dim), int(scale_mode), float(scale_a))

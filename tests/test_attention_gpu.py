@@ -1,0 +1,220 @@
+"""GPU parity: fused edge attention (fwd + bwd) and the Stage-level operator
+surface against fixtures produced by the REFERENCE's own modules
+(tests/golden/make_golden.py: SelfAttentionBlock / DownNFuseStage /
+UpNFuseStage of /root/reference run in float64) and against the float64
+oracle on random graphs.
+
+Stated tolerance (f32 kernel vs f64 reference): |err| <= 1e-5 + 1e-4 * |ref|
+for the block output and input gradients; parameter gradients (sums over all
+edges / nodes) are checked relative to the largest entry of the same tensor."""
+import pytest
+import torch
+
+from conftest import load_golden, t64, tl
+from oracle import spt_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL = 1e-4, 1e-5
+
+
+def _check(a, ref, name, rel_to_max=False):
+    a = a.detach().cpu().double()
+    ref = ref.detach().double()
+    assert a.shape == ref.shape, f"{name}: shape {tuple(a.shape)} vs {tuple(ref.shape)}"
+    if rel_to_max:
+        scale = ref.abs().max().clamp(min=1e-3)
+        err = ((a - ref).abs() / scale).max().item()
+        assert err <= 2e-5, f"{name}: max err / max|ref| = {err:.3e}"
+    else:
+        err = ((a - ref).abs() - RTOL * ref.abs()).max().item()
+        assert err <= ATOL, f"{name}: |err| - rtol|ref| = {err:.3e}"
+
+
+def _load_params(module, g, dev):
+    sd = {k[3:]: torch.from_numpy(v).float() for k, v in g.items() if k.startswith("p__")}
+    missing, unexpected = module.load_state_dict(sd, strict=True), None
+    return module.to(dev)
+
+
+@pytest.mark.parametrize("name,dim", [("attention_spt64.npz", 64), ("attention_spt128.npz", 128)])
+def test_self_attention_block_matches_reference_fixture(name, dim, dev):
+    from superpoint_transformer_amd import nn as N
+    g = load_golden(name)
+    blk = N.SelfAttentionBlock(dim, num_heads=int(g["num_heads"]), out_dim=dim,
+                               qk_dim=int(g["qk_dim"]), in_rpe_dim=g["edge_attr"].shape[1],
+                               k_rpe=True, q_rpe=True, v_rpe=True)
+    blk = _load_params(blk, g, dev)           # reference parameter names, strict
+    x = torch.from_numpy(g["x"]).float().to(dev).requires_grad_()
+    ea = torch.from_numpy(g["edge_attr"]).float().to(dev).requires_grad_()
+    ei = tl(g["edge_index"]).to(dev)
+    out = blk(x, ei, edge_attr=ea)
+    (out * torch.from_numpy(g["gw"]).float().to(dev)).sum().backward()
+    _check(out, t64(g["out"]), "out")
+    _check(x.grad, t64(g["g_x"]), "g_x")
+    _check(ea.grad, t64(g["g_edge_attr"]), "g_edge_attr")
+    for k, p in blk.named_parameters():
+        _check(p.grad, t64(g["g__" + k]), "g_" + k, rel_to_max=True)
+
+
+def _rand_graph(gen, n, deg):
+    m = int(n * deg / 2)
+    a = torch.randint(0, n, (m,), generator=gen)
+    b = torch.randint(0, n, (m,), generator=gen)
+    keep = a != b
+    a, b = a[keep], b[keep]
+    loops = torch.arange(n)
+    return torch.stack([torch.cat([a, b, loops]), torch.cat([b, a, loops])])
+
+
+CASES = [
+    # n, deg, H, D, Dv, F, which rpe, scale
+    (300, 10.0, 16, 4, 4, 32, "kqv", None),
+    (200, 25.0, 16, 4, 8, 32, "kqv", None),      # SPT-128: value dim 8
+    (150, 8.0, 32, 4, 4, 32, "kqv", "d+g"),      # scannet: 32 heads
+    (120, 6.0, 16, 2, 1, 18, "kqv", "d"),        # nano: qk_dim 2, dim 16, raw 18-D edge features
+    (100, 5.0, 16, 4, 4, 32, "k", "g"),
+    (100, 5.0, 16, 4, 4, 32, "v", 0.37),
+    (100, 5.0, 8, 8, 8, 32, "", None),           # no RPE at all
+    (50, 70.0, 16, 4, 4, 32, "kqv", None),       # degree > several tiles
+]
+
+
+@pytest.mark.parametrize("n,deg,H,D,Dv,F,rpe,scale", CASES)
+def test_edge_attention_vs_oracle(n, deg, H, D, Dv, F, rpe, scale, dev):
+    from superpoint_transformer_amd import nn as N
+    gen = torch.Generator().manual_seed(n * 7 + H + F)
+    dim = H * Dv
+    ei = _rand_graph(gen, n, deg)
+    # isolated node (no outgoing edge) + unsorted sources
+    ei = ei[:, ei[0] != 3]
+    ei = ei[:, torch.randperm(ei.shape[1], generator=gen)]
+    E = ei.shape[1]
+    blk = N.SelfAttentionBlock(dim, num_heads=H, out_dim=None, qk_dim=D, qk_scale=scale,
+                               in_rpe_dim=F, k_rpe="k" in rpe, q_rpe="q" in rpe,
+                               v_rpe="v" in rpe).to(dev)
+    x = torch.randn(n, dim, generator=gen)
+    ea = torch.randn(E, F, generator=gen) * 0.5
+    gw = torch.randn(n, dim, generator=gen)
+    xd = x.to(dev).requires_grad_()
+    ead = ea.to(dev).requires_grad_()
+    out = blk(xd, ei.to(dev), edge_attr=ead)
+    (out * gw.to(dev)).sum().backward()
+
+    p = {k: v.detach().cpu().double().requires_grad_() for k, v in blk.named_parameters()}
+    x64 = x.double().requires_grad_()
+    ea64 = ea.double().requires_grad_()
+
+    # oracle with the requested qk scaling
+    def scale_fn(s):
+        dd = (dim // H) ** -0.5
+        gg = (s.bincount(minlength=n).double() ** -0.5)[s].view(-1, 1, 1)
+        if scale is None:
+            return dd * gg
+        if scale == "d+g":
+            return dd + gg
+        if scale == "d":
+            return dd
+        if scale == "g":
+            return gg
+        return scale
+    old = O.qk_scale_dg
+    O.qk_scale_dg = lambda s, d_, h_: torch.as_tensor(scale_fn(s), dtype=torch.float64)
+    try:
+        ref = O.self_attention(x64, ei, ea64, p, H, D)
+    finally:
+        O.qk_scale_dg = old
+    (ref * gw.double()).sum().backward()
+    _check(out, ref, "out")
+    assert out[3].abs().sum().item() == 0          # node without edges -> zeros
+    _check(xd.grad, x64.grad, "g_x")
+    if rpe:
+        _check(ead.grad, ea64.grad, "g_edge_attr")
+    else:
+        assert ead.grad is None
+    for k, v in blk.named_parameters():
+        _check(v.grad, p[k].grad, "g_" + k, rel_to_max=True)
+
+
+def test_edge_attention_forward_is_deterministic_and_order_invariant(dev):
+    from superpoint_transformer_amd import ops
+    gen = torch.Generator().manual_seed(11)
+    n, H, D = 500, 16, 4
+    ei = _rand_graph(gen, n, 12.0)
+    E = ei.shape[1]
+    qkv = torch.randn(n, 192, generator=gen).to(dev)
+    ea = (torch.randn(E, 32, generator=gen) * 0.5).to(dev)
+    W = [(torch.randn(64, 32, generator=gen).to(dev) * 0.1, torch.randn(64, generator=gen).to(dev) * 0.1)
+         for _ in range(3)]
+    a = ops.edge_attention(qkv, ei.to(dev), ea, *W, num_heads=H, qk_dim=D, scale_a=0.5)
+    b = ops.edge_attention(qkv, ei.to(dev).clone(), ea, *W, num_heads=H, qk_dim=D, scale_a=0.5)
+    assert torch.equal(a, b)
+    perm = torch.randperm(E, generator=gen)
+    c = ops.edge_attention(qkv, ei[:, perm].to(dev), ea[perm.to(dev)], *W, num_heads=H,
+                           qk_dim=D, scale_a=0.5)
+    torch.testing.assert_close(a, c, rtol=1e-5, atol=1e-6)
+
+
+def test_edge_attention_rejects_unbuilt_shapes_loudly(dev):
+    from superpoint_transformer_amd import ops
+    qkv = torch.randn(10, 2 * 40 * 4 + 40 * 4, device=dev)      # H*D = 160 > 128
+    ei = torch.stack([torch.arange(10), torch.arange(10)]).to(dev)
+    with pytest.raises(RuntimeError, match="unsupported attention shape"):
+        ops.edge_attention(qkv, ei, None, num_heads=40, qk_dim=4)
+
+
+def _stage_case(g, stage, dev, kind):
+    f = lambda k: torch.from_numpy(g[k]).float().to(dev)
+    l = lambda k: tl(g[k]).to(dev)
+    stage = _load_params(stage, g, dev)
+    xc = f("x_child").requires_grad_()
+    if kind == "down":
+        out, diam = stage(f("x_parent"), xc, l("norm_index"), l("pool_index"), pos=f("pos"),
+                          node_size=l("node_size"), super_index=l("super_index"),
+                          edge_index=l("edge_index"), edge_attr=f("edge_attr"),
+                          num_super=int(g["num_super"]))
+        xp = None
+    else:
+        xp = f("x_parent").requires_grad_()
+        out, diam = stage(xc, xp, l("norm_index"), l("unpool_index"), pos=f("pos"),
+                          node_size=l("node_size"), super_index=l("super_index"),
+                          edge_index=l("edge_index"), edge_attr=f("edge_attr"))
+    (out * f("gw")).sum().backward()
+    # a whole stage chains 2-3 GraphNorms, MLPs and attention blocks: 5x the single-op bar
+    a = out.detach().cpu().double()
+    ref = t64(g["out"])
+    assert ((a - ref).abs() - 5e-4 * ref.abs()).max().item() <= 5e-5
+    _check(xc.grad, t64(g["g_x_child"]), "g_x_child", rel_to_max=True)
+    if xp is not None:
+        _check(xp.grad, t64(g["g_x_parent"]), "g_x_parent", rel_to_max=True)
+    for k, p in stage.named_parameters():
+        ref = t64(g["g__" + k])
+        scale = ref.abs().max().clamp(min=1e-3)
+        err = ((p.grad.detach().cpu().double() - ref).abs() / scale).max().item()
+        assert err <= 2e-4, f"g_{k}: {err:.3e}"
+    return diam
+
+
+def test_down_stage_matches_reference_fixture(dev):
+    from superpoint_transformer_amd import nn as N
+    g = load_golden("down_stage.npz")
+    dim = 64
+    stage = N.DownNFuseStage(
+        dim, num_blocks=2, num_heads=16, in_mlp=[4 + 3 + 128, dim, dim],
+        mlp_norm=N.GraphNorm, qk_dim=4, k_rpe=True, q_rpe=True, v_rpe=True, in_rpe_dim=32,
+        norm=N.GraphNorm, no_ffn=True, pool="max", fusion="cat", use_pos=True,
+        use_diameter_parent=False, version_holder=N.VersionHolder("3.0.0"))
+    diam = _stage_case(g, stage, dev, "down")
+    assert torch.equal(diam.cpu(), t64(g["diameter"]).float())
+
+
+def test_up_stage_matches_reference_fixture(dev):
+    from superpoint_transformer_amd import nn as N
+    g = load_golden("up_stage.npz")
+    dim = 64
+    stage = N.UpNFuseStage(
+        dim, num_blocks=1, num_heads=16, in_mlp=[dim + 3 + dim, dim, dim],
+        mlp_norm=N.GraphNorm, qk_dim=4, k_rpe=True, q_rpe=True, v_rpe=True, in_rpe_dim=32,
+        norm=N.GraphNorm, no_ffn=False, ffn_ratio=1, unpool="index", fusion="cat",
+        use_pos=True, version_holder=N.VersionHolder("3.0.0"))
+    _stage_case(g, stage, dev, "up")
