@@ -1,0 +1,155 @@
+"""CPU oracle of the WHOLE SPT forward -- TEST INFRASTRUCTURE ONLY.
+
+Re-executes a ``superpoint_transformer_amd.nn.SPT`` module's computation with
+the oracle ops of ``oracle/spt_oracle.py`` (plain torch-CPU, any dtype),
+following the reference's call graph:
+
+  SPT.forward                src/models/components/spt.py:760-879
+  Stage / Down / Up forward  src/nn/stage.py:215-286, 413-444, 545-571
+  TransformerBlock.forward   src/nn/transformer.py:195-256
+  SelfAttentionBlock.forward src/nn/attention.py:167-325
+  MLP.forward                src/nn/mlp.py:85-94
+
+The product module is used ONLY as a container of parameters and structure
+(which layers exist, in which order); none of its forward code or kernels run
+here.  Used by tests/ (model-level parity) and by bench.py's cpu_baseline leg.
+"""
+import torch
+from torch import nn
+
+from . import spt_oracle as O
+
+
+KEEP_GRAPH = False  # True: parameters stay attached (CPU module, autograd through the oracle)
+
+
+def _p(t, dtype):
+    if t is None:
+        return None
+    if KEEP_GRAPH:
+        return t.to(dtype)
+    return t.detach().cpu().to(dtype)
+
+
+def mlp(m, x, batch, dtype):
+    """src/nn/mlp.py:85-94."""
+    for layer in m.mlp:
+        if isinstance(layer, nn.Linear):
+            x = x @ _p(layer.weight, dtype).t()
+            if layer.bias is not None:
+                x = x + _p(layer.bias, dtype)
+        elif isinstance(layer, nn.LeakyReLU):
+            x = torch.nn.functional.leaky_relu(x, layer.negative_slope)
+        elif hasattr(layer, "mean_scale"):
+            x = graph_norm(layer, x, batch, dtype)
+        elif isinstance(layer, nn.Dropout):
+            pass
+        else:
+            raise TypeError(type(layer))
+    return x
+
+
+def graph_norm(m, x, batch, dtype):
+    return O.graph_norm(x, batch, _p(m.weight, dtype), _p(m.bias, dtype),
+                        _p(m.mean_scale, dtype), m.eps)
+
+
+def self_attention(sa, x, edge_index, edge_attr, dtype):
+    """src/nn/attention.py:167-325 for the encoders this block owns."""
+    p = {}
+    for name in ("qkv", "k_rpe", "q_rpe", "v_rpe", "out_proj"):
+        lin = getattr(sa, name, None)
+        if lin is not None:
+            p[name + ".weight"] = _p(lin.weight, dtype)
+            p[name + ".bias"] = _p(lin.bias, dtype)
+    return O.self_attention(x, edge_index, edge_attr, p, sa.num_heads, sa.qk_dim)
+
+
+def transformer_block(b, x, norm_index, edge_index, edge_attr, dtype):
+    """src/nn/transformer.py:195-256 (pre-norm, version >= 3 residuals)."""
+    shortcut = x
+    if not b.no_sa and edge_index is not None and edge_index.shape[1] > 0:
+        assert b.pre_norm
+        x = graph_norm(b.sa_norm, x, norm_index, dtype)
+        x = self_attention(b.sa, x, edge_index, edge_attr, dtype)
+        x = shortcut + x
+    shortcut = x
+    if not b.no_ffn:
+        x = graph_norm(b.ffn_norm, x, norm_index, dtype)
+        x = mlp(b.ffn, x, None, dtype)
+        x = shortcut + x
+    return x
+
+
+def stage(s, x, norm_index, pos, node_size, super_index, edge_index, edge_attr, dtype):
+    """src/nn/stage.py:215-286."""
+    n = pos.shape[0]
+    npos, diam_parent = O.unit_sphere_norm(pos, super_index, w=node_size)
+    if s.use_pos:
+        x = npos if x is None else torch.cat((npos, x), dim=1)
+    if s.use_diameter:
+        x = torch.cat((torch.zeros((n, 1), dtype=dtype), x), dim=1)
+    if s.use_diameter_parent:
+        d = diam_parent.repeat(n, 1) if super_index is None else diam_parent[super_index]
+        x = torch.cat((d, x), dim=1)
+    if s.in_mlp is not None:
+        x = mlp(s.in_mlp, x, norm_index, dtype)
+    if s.transformer_blocks is not None:
+        for b in s.transformer_blocks:
+            x = transformer_block(b, x, norm_index, edge_index, edge_attr, dtype)
+    if s.out_mlp is not None:
+        x = mlp(s.out_mlp, x, norm_index, dtype)
+    return x, diam_parent
+
+
+def spt_forward(model, levels, dtype=torch.float64, keep_graph=False):
+    """``levels``: list of dicts (pos, x, super_index, node_size, batch,
+    edge_index, edge_attr) of CPU tensors.  Returns what SPT.forward returns.
+    ``keep_graph=True`` (model must live on the CPU in ``dtype``) lets autograd
+    reach the module's parameters through the oracle ops."""
+    global KEEP_GRAPH
+    KEEP_GRAPH = keep_graph
+    def f(t):
+        return None if t is None else t.to(dtype)
+
+    nd = model.num_down_stages
+    lv0 = levels[0]
+    x, _ = stage(model.first_stage, f(lv0.get("x")) if model.use_node_hf else None,
+                 lv0.get("batch"), f(lv0["pos"]), lv0.get("node_size"),
+                 lv0.get("super_index"), None, None, dtype)
+    down, node_x, eattr = [], {}, {}
+    for i in range(nd):
+        lv = levels[i + 1]
+        st = model.down_stages[i]
+        ni = lv.get("batch")
+        xh = f(lv.get("x"))
+        if model.node_mlps[i] is not None and xh is not None:
+            xh = mlp(model.node_mlps[i], xh, ni, dtype)
+        ei, ea = lv.get("edge_index"), f(lv.get("edge_attr"))
+        if model.h_edge_mlps[i] is not None and ea is not None:
+            ea = mlp(model.h_edge_mlps[i], ea, None if ni is None else ni[ei[0]], dtype)
+        node_x[i + 1], eattr[i + 1] = xh, ea
+        pooled = O.scatter(x, levels[i]["super_index"], 0, None, lv["pos"].shape[0],
+                           st.down_pool_block.reduce)
+        xp = xh if model.use_node_hf else None
+        fused = pooled if xp is None else torch.cat((xp, pooled), dim=1)
+        last = i + 1 == len(levels) - 1 or i + 1 == nd and levels[i + 1].get("super_index") is None
+        x, _ = stage(st, fused, ni, f(lv["pos"]), lv.get("node_size"),
+                     None if (i + 1 == len(levels) - 1) else lv.get("super_index"), ei, ea, dtype)
+        down.append(x)
+    ups = []
+    for i in range(model.num_up_stages):
+        lvl = nd - i - 1
+        lv = levels[lvl]
+        skip = down[-(2 + i)]
+        xh = node_x.get(lvl) if model.use_node_hf else None
+        xc = skip if xh is None else torch.cat((skip, xh), dim=1)
+        unp = O.index_unpool(x, lv["super_index"])
+        fused = torch.cat((xc, unp), dim=1)
+        x, _ = stage(model.up_stages[i], fused, lv.get("batch"), f(lv["pos"]),
+                     lv.get("node_size"), lv.get("super_index"), lv.get("edge_index"),
+                     eattr.get(lvl), dtype)
+        ups.append(x)
+    if model.output_stage_wise:
+        return [x] + ups[::-1][1:] + [down[-1]]
+    return x

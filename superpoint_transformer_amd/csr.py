@@ -115,3 +115,15 @@ def edge_csr_of(edge_index, num_nodes):
             return ecsr
     memo[key] = ecsr
     return ecsr
+
+
+def forget(*tensors):
+    """Drop the memoised CSR views of these index tensors (a new batch would
+    carry new tensors; benchmarks reusing one batch call this every step so
+    that the per-batch sort stays inside the timed region)."""
+    for t in tensors:
+        if t is not None and hasattr(t, _ATTR):
+            try:
+                delattr(t, _ATTR)
+            except Exception:
+                pass

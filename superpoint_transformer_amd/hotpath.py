@@ -1,40 +1,125 @@
 """The benchmarked hot path: one step = one pass over one NAG batch.
 
-v0 (this file grows with the kernels): the hierarchical segment-CSR scatter
-chain of SPT-64 - per batch CSR build of every level's ``super_index``, max
-pool child->parent forward + backward (src/nn/stage.py:429-431), IndexUnpool
-parent->child forward + backward (src/nn/unpool.py:12-13).
+``SPTTrainStep`` (default): SPT-64 / spt-2 of the S3DIS experiment
+(configs/experiment/semantic/s3dis.yaml:6-9 -> configs/model/semantic/spt-2.yaml)
+forward + multi-level cross-entropy + backward + AdamW step on one synthetic
+NAG batch resident in HBM, including the per-batch CSR builds (device sorts of
+every ``super_index`` / ``edge_index[0]``).  N > 1: DistributedDataParallel over
+RCCL, one flat gradient bucket (~0.85 MB) per step.
+
+``ScatterChain``: only the hierarchical segment-CSR scatter kernels (max pool
+fwd/bwd L0->L1->L2 + unpool fwd/bwd), kept as a kernel-level benchmark.
 """
 import torch
+from torch import nn
 
+from . import csr as _csr
 from . import ops
-from .csr import build_csr
+from .nn import SPT, Classifier, GraphNorm
+
+NUM_CLASSES = 13  # S3DIS
 
 
-class _KernelTimer:
-    """HIP events around ONE kernel launch on torch's current stream (the
-    stream every launch of this library uses)."""
+def spt64_config(point_in=8, edge_in=18):
+    """Widths derived from the reference's config tree: point MLP
+    [12,32,64,128]; h_edge_mlp [18,32,32]; down in_mlps [132,64,64], [68,64,64];
+    up in_mlp [132,64,64]; 16 heads, qk_dim 4, 3 blocks down / 1 up, no FFN."""
+    inj = 3 + 1  # normalised position + parent diameter
+    return dict(
+        point_mlp=[point_in + inj, 32, 64, 128], down_dim=[64, 64], down_pool_dim=[128, 64],
+        down_in_mlp=[[inj + 128, 64, 64], [inj + 64, 64, 64]], down_num_heads=16,
+        down_num_blocks=3, down_ffn_ratio=1, up_dim=[64], up_in_mlp=[[inj + 64 + 64, 64, 64]],
+        up_num_heads=16, up_num_blocks=1, up_ffn_ratio=1, node_mlp=None,
+        h_edge_mlp=[edge_in, 32, 32], mlp_norm=GraphNorm, norm=GraphNorm, qk_dim=4,
+        in_rpe_dim=32, k_rpe=True, q_rpe=True, v_rpe=True, no_ffn=True, use_pos=True,
+        use_node_hf=True, use_diameter_parent=True, pool="max", unpool="index",
+        fusion="cat", output_stage_wise=True)
 
-    def __init__(self):
-        self.pairs = []
 
-    def time(self, fn):
-        a = torch.cuda.Event(enable_timing=True)
-        b = torch.cuda.Event(enable_timing=True)
-        a.record()
-        out = fn()
-        b.record()
-        self.pairs.append((a, b))
-        return out
+class SPTSegmenter(nn.Module):
+    """SPT backbone + one Classifier per output level (semantic.py:291-294)."""
 
-    def mean_ms(self):
-        if not self.pairs:
-            return None
-        torch.cuda.synchronize()
-        return sum(a.elapsed_time(b) for a, b in self.pairs) / len(self.pairs)
+    def __init__(self, **cfg):
+        super().__init__()
+        self.net = SPT(**cfg)
+        dims = self.net.out_dim if isinstance(self.net.out_dim, list) else [self.net.out_dim]
+        self.head = nn.ModuleList([Classifier(d, NUM_CLASSES) for d in dims])
 
-    def reset(self):
-        self.pairs = []
+    def forward(self, nag):
+        outs = self.net(nag)
+        outs = outs if isinstance(outs, list) else [outs]
+        return [h(x) for h, x in zip(self.head, outs)]
+
+
+class _NagView:
+    """What DDP forwards to the module: a plain object, not a tensor tree."""
+
+    def __init__(self, nag):
+        self.levels = nag.levels
+        self.num_clouds = nag.num_clouds
+
+    def __getitem__(self, i):
+        return self.levels[i]
+
+
+class SPTTrainStep:
+    name = "SPT-64 (spt-2, S3DIS cfg) fwd + CE loss + bwd + AdamW, incl. per-batch CSR builds"
+
+    def __init__(self, nag, dev, world=1, seed=0):
+        self.nag, self.dev, self.world = _NagView(nag), dev, world
+        self.n = nag.num_points
+        torch.manual_seed(seed)
+        self.model = SPTSegmenter(**spt64_config(nag[0]["x"].shape[1],
+                                                 nag[1]["edge_attr"].shape[1])).to(dev)
+        self.params = [p for p in self.model.parameters()]
+        self.module = self.model
+        if world > 1:
+            from torch.nn.parallel import DistributedDataParallel as DDP
+            # ~0.85 MB of gradients: ONE flat bucket, one all-reduce per step (latency bound)
+            self.module = DDP(self.model, device_ids=[dev.index], bucket_cap_mb=8,
+                              gradient_as_bucket_view=True, broadcast_buffers=False)
+        self.opt = torch.optim.AdamW(self.params, lr=1e-3, weight_decay=1e-4)
+        g = torch.Generator(device=dev).manual_seed(5)
+        self.labels = [torch.randint(0, NUM_CLASSES, (self.n[i],), device=dev, generator=g)
+                       for i in (1, 2)]
+        self.lambdas = [1.0, 50.0]               # configs/model/semantic/default.yaml:12
+        self.loss_fn = nn.CrossEntropyLoss()
+        n0, c = self.n[0], 128
+        self.tname = f"segcsr_reduce_fwd:3:{n0}x{c}"
+        ops.enable_timer(self.tname)
+        self.last_loss = None
+
+    def reset_kernel_timers(self):
+        ops.reset_timers()
+
+    def _forget_csr(self):
+        for lv in self.nag.levels:
+            _csr.forget(lv.get("super_index"), lv.get("edge_index"), lv.get("batch"))
+
+    def step(self):
+        self._forget_csr()
+        logits = self.module(self.nag)
+        loss = sum(l * self.loss_fn(lg, y) for l, lg, y in zip(self.lambdas, logits, self.labels))
+        self.opt.zero_grad(set_to_none=True)
+        loss.backward()
+        self.opt.step()
+        self.last_loss = loss
+        return loss
+
+    def roofline(self, peak_gbs):
+        n0, n1 = self.n[0], self.n[1]
+        c = 128
+        bytes_ = n0 * (4 * c + 4) + n1 * (8 * c + 4)
+        ms = ops.timer_mean_ms(self.tname)
+        ach = bytes_ / (ms * 1e-3) / 1e9 if ms else None
+        return {"bound": "hbm", "kernel": "segcsr_reduce_kernel<MAX,VEC4,ARG> L0->L1 C=128",
+                "achieved": round(ach, 1) if ach else None, "peak": peak_gbs,
+                "unit": "GB/s", "frac": round(ach / peak_gbs, 4) if ach else None,
+                "traffic": None, "bytes_per_launch": bytes_,
+                "ms_per_launch": round(ms, 4) if ms else None}
+
+    def describe(self, scene, sizes):
+        return f"{self.name}; synthetic NAG scene {scene} (N0,N1,N2,E1,E2,clouds)={sizes}"
 
 
 class ScatterChain:
@@ -49,43 +134,32 @@ class ScatterChain:
         self.x1 = torch.randn(n1, 64, device=dev, generator=g)
         self.g1 = torch.randn(n1, 128, device=dev, generator=g)
         self.g2 = torch.randn(n2, 64, device=dev, generator=g)
-        self.timer = _KernelTimer()
+        self.tname = f"segcsr_reduce_fwd:3:{n0}x128"
+        ops.enable_timer(self.tname)
 
     def reset_kernel_timers(self):
-        self.timer.reset()
+        ops.reset_timers()
 
     def step(self):
         nag = self.nag
         n0, n1, n2 = self.n
-        csr0 = build_csr(nag[0]["super_index"], n1)
-        csr1 = build_csr(nag[1]["super_index"], n2)
-        # forward
-        p1, a1 = self.timer.time(lambda: ops._seg_reduce_fwd(self.x0, csr0, 3, True))
+        csr0 = _csr.build_csr(nag[0]["super_index"], n1)
+        csr1 = _csr.build_csr(nag[1]["super_index"], n2)
+        p1, a1 = ops._seg_reduce_fwd(self.x0, csr0, 3, True)
         p2, a2 = ops._seg_reduce_fwd(self.x1, csr1, 3, True)
         u1 = ops._gather_fwd(p2, csr1.idx)
-        # backward
         gp2, _ = ops._seg_reduce_fwd(u1, csr1, 0, False)          # unpool bwd
         gx1 = ops._seg_reduce_bwd(self.g2, a2, csr1, 3, n1)
         gx0 = ops._seg_reduce_bwd(self.g1, a1, csr0, 3, n0)
         return gx0, gx1, gp2
 
-    def roofline(self, peak_gbs):
-        n0, n1, _ = self.n
-        c = 128
-        # algorithmic bytes of segment max fwd with arg, L0->L1:
-        # child row 4c + 4 (perm); parent row 4c (out) + 4c (arg) + 4 (rowptr)
-        bytes_ = n0 * (4 * c + 4) + n1 * (8 * c + 4)
-        ms = self.timer.mean_ms()
-        ach = bytes_ / (ms * 1e-3) / 1e9 if ms else None
-        return {"bound": "hbm", "kernel": "segcsr_reduce_kernel<MAX,VEC4,ARG> L0->L1 C=128",
-                "achieved": round(ach, 1) if ach else None, "peak": peak_gbs,
-                "unit": "GB/s", "frac": round(ach / peak_gbs, 4) if ach else None,
-                "traffic": None, "bytes_per_launch": bytes_,
-                "ms_per_launch": round(ms, 4) if ms else None}
+    roofline = SPTTrainStep.roofline
 
     def describe(self, scene, sizes):
         return f"{self.name}; scene {scene} {sizes}"
 
 
 def build(nag, dev, world=1, stages="all"):
-    return ScatterChain(nag, dev, world)
+    if stages == "scatter":
+        return ScatterChain(nag, dev, world)
+    return SPTTrainStep(nag, dev, world)

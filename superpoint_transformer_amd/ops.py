@@ -10,6 +10,43 @@ from .csr import EdgeCSR, SegmentCSR, csr_of, edge_csr_of
 
 _OPS = {"sum": 0, "add": 0, "mean": 1, "min": 2, "max": 3}
 
+# Optional per-kernel HIP-event timers (bench.py's roofline leg): name -> list
+# of (start, end) events recorded on the stream the kernel is launched on.
+_TIMERS = {}
+
+
+def enable_timer(name):
+    _TIMERS[name] = []
+
+
+def timer_mean_ms(name):
+    pairs = _TIMERS.get(name) or []
+    if not pairs:
+        return None
+    torch.cuda.synchronize()
+    return sum(a.elapsed_time(b) for a, b in pairs) / len(pairs)
+
+
+def reset_timers():
+    for k in _TIMERS:
+        _TIMERS[k] = []
+
+
+class _timed:
+    def __init__(self, name):
+        self.rec = _TIMERS.get(name)
+
+    def __enter__(self):
+        if self.rec is not None:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+
+    def __exit__(self, *exc):
+        if self.rec is not None:
+            b = torch.cuda.Event(enable_timing=True)
+            b.record()
+            self.rec.append((self.a, b))
+
 
 def _as_rows(x):
     """[n, ...] -> contiguous, 16B-aligned f32 [n, c] plus the trailing shape."""
@@ -29,7 +66,7 @@ def _seg_reduce_fwd(x2, csr, op, want_arg):
     arg = None
     if want_arg and op in (2, 3):
         arg = torch.empty((csr.num_seg, c), dtype=torch.int32, device=x2.device)
-    with torch.cuda.device(x2.device):
+    with torch.cuda.device(x2.device), _timed(f"segcsr_reduce_fwd:{op}:{n}x{c}"):
         st = _lib.lib.spt_segcsr_reduce_f32(
             op, _lib.ptr(x2), _lib.ptr(csr.perm), _lib.ptr(csr.rowptr), n,
             csr.num_seg, c, _lib.ptr(out), _lib.ptr(arg), _lib.stream_ptr(x2.device))
@@ -40,7 +77,7 @@ def _seg_reduce_fwd(x2, csr, op, want_arg):
 def _seg_reduce_bwd(gout, arg, csr, op, n):
     c = gout.shape[1]
     gx = torch.empty((n, c), dtype=torch.float32, device=gout.device)
-    with torch.cuda.device(gout.device):
+    with torch.cuda.device(gout.device), _timed(f"segcsr_reduce_bwd:{op}:{n}x{c}"):
         st = _lib.lib.spt_segcsr_reduce_bwd_f32(
             op, _lib.ptr(gout), _lib.ptr(arg), _lib.ptr(csr.idx),
             _lib.ptr(csr.perm), _lib.ptr(csr.rowptr), n, csr.num_seg, c, _lib.ptr(gx),

@@ -94,9 +94,10 @@ class SyntheticNAG:
 
 
 def make_nag(scene="S", seed=1234, device="cpu", sizes=None, point_dim=8,
-             edge_dim=18, scale=1.0):
+             edge_dim=18, scale=1.0, segment_dim=0):
     """Build a 3-level synthetic NAG. ``scale`` < 1 shrinks every size
-    proportionally (CPU-baseline samples)."""
+    proportionally (CPU-baseline samples).  ``segment_dim=0``: levels >= 1 carry
+    no handcrafted node features, like the S3DIS config (``segment_hf: []``)."""
     n0, n1, n2, e1, e2, b = sizes if sizes is not None else SCENES[scene]
     if scale != 1.0:
         n0, n1, n2 = (max(int(v * scale), 8) for v in (n0, n1, n2))
@@ -124,9 +125,9 @@ def make_nag(scene="S", seed=1234, device="cpu", sizes=None, point_dim=8,
     levels = [
         dict(pos=pos0, x=torch.rand(n0, point_dim, generator=gen, device=device),
              super_index=si0, batch=b0),
-        dict(pos=pos1, x=rnd(n1, 4), super_index=si1, batch=b1, node_size=ns1,
+        dict(pos=pos1, x=rnd(n1, segment_dim) if segment_dim else None, super_index=si1, batch=b1, node_size=ns1,
              edge_index=ei1, edge_attr=rnd(ei1.shape[1], edge_dim, s=0.3)),
-        dict(pos=pos2, x=rnd(n2, 4), super_index=None, batch=b2, node_size=ns2,
+        dict(pos=pos2, x=rnd(n2, segment_dim) if segment_dim else None, super_index=None, batch=b2, node_size=ns2,
              edge_index=ei2, edge_attr=rnd(ei2.shape[1], edge_dim, s=0.3)),
     ]
     return SyntheticNAG(levels, b)

