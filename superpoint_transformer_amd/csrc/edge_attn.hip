@@ -268,20 +268,26 @@ __global__ __launch_bounds__(EA_WAVES * 64, ea_min_waves(QPL, VPL, F)) void edge
 // reduce-scatter of the lane partials; the RPE weight gradients accumulate in
 // the owner lane's registers for the whole kernel and leave as per-wave partial
 // tables that a fixed-order kernel reduces.
+// Reduce-scatter of N per-lane partials across the 64 lanes of a wave: each
+// step halves the live values (compile-time indices only: a runtime index into
+// a register array would turn into a 32-way select chain).
+template <int HALF, int O, int N>
+__device__ __forceinline__ void rs_step(float (&p)[N], int lane) {
+  const bool upper = (lane & O) != 0;
+#pragma unroll
+  for (int i = 0; i < HALF; ++i) {
+    const float send = upper ? p[i] : p[i + HALF];
+    const float keep = upper ? p[i + HALF] : p[i];
+    p[i] = keep + __shfl_xor(send, O, 64);
+  }
+  if constexpr (HALF > 1) rs_step<HALF / 2, O / 2, N>(p, lane);
+}
+
 template <int N>
 __device__ __forceinline__ void wave_reduce_scatter(float (&p)[N], int lane) {
-  // after the call lane l holds the full sum of column (l * N / 64 ...) in p[0]
-  // for N = 32: columns are owned by lane pairs; see index math at the caller.
-#pragma unroll
-  for (int half = N / 2, o = 32; half >= 1; half >>= 1, o >>= 1) {
-    const bool upper = (lane & o) != 0;
-#pragma unroll
-    for (int i = 0; i < half; ++i) {
-      const float send = upper ? p[i] : p[i + half];
-      const float keep = upper ? p[i + half] : p[i];
-      p[i] = keep + __shfl_xor(send, o, 64);
-    }
-  }
+  // N = 32: after the call p[0] of lane l holds the sum over the 32 lanes that
+  // share bit 0 with l of column  b5*16 + b4*8 + b3*4 + b2*2 + b1  (bits of l).
+  rs_step<N / 2, 32, N>(p, lane);
 }
 
 template <int QPL, int VPL, int F>
