@@ -196,6 +196,49 @@ int spt_edge_attn_bwd_f32(const float* qkv, int64_t n, int H, int D, int Dv,
                           float* gbq, float* gWv, float* gbv, void* ws,
                           size_t ws_bytes, spt_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * Radius-bounded exact kNN on a uniform grid                        (a9)
+ * Replaces frnn.frnn_grid_points of the un-vendored FRNN CUDA extension
+ * (src/utils/neighbors.py:48 <- knn_1 :90, knn_2 :231): for each query the K
+ * nearest search points with squared distance < r^2 (<= when inclusive),
+ * ascending by (distance, index) - ties broken by ascending search index -,
+ * missing entries idx = -1 / dist = -1.  d2 = (dx*dx + dy*dy) + dz*dz in f32.
+ *   query [nq,3], search [ns,3] f32; K in [1,64]; idx [nq,K] int64,
+ *   dist [nq,K] f32 (squared when `squared`, FRNN's convention, else Euclidean);
+ *   cell_size/origin[3]/dims[3]: HOST description of the uniform grid that
+ *   covers the search points (any cell size gives the same result; ~K/4 points
+ *   per non-empty cell is fastest); dims[0]*dims[1]*dims[2] < 2^31;
+ *   order_queries_by_cell: when query == search, visit queries in cell order.
+ * ws: spt_grid_knn_workspace_bytes(ns, ncells).
+ * ---------------------------------------------------------------------- */
+size_t spt_grid_knn_workspace_bytes(int64_t ns, int64_t ncells);
+int spt_grid_knn_f32(const float* query, int64_t nq, const float* search, int64_t ns,
+                     int K, float r, float cell_size, const float* origin,
+                     const int32_t* dims, int order_queries_by_cell, int inclusive,
+                     int squared, int64_t* idx, float* dist, void* ws, size_t ws_bytes,
+                     spt_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Point geometric features                                          (a11-a14)
+ * Replaces pgeof.compute_features (src/utils/geometry.py:148-153) and the torch
+ * branch the reference takes on GPU (_geometric_features_torch :236-338 +
+ * scatter_pca, src/utils/scatter.py:41-125): per point the population
+ * covariance of {self} + valid neighbours, its 3x3 eigen-decomposition and
+ *   feats [n,11] = [linearity, planarity, scattering, verticality, nx, ny, nz,
+ *                   length, surface, volume, curvature]   (geometry.py:165-174)
+ * dense: nn [n,k] int64, negative = missing (FRNN padding); csr: nn_val / nn_ptr
+ * [n+1] int64 (pgeof layout).  add_self: count the point itself (geometry.py:95-96);
+ * features are zeroed where the neighbourhood has < k_min points; post != 0
+ * applies geometric_features' tail (verticality * 2, normal flipped to z >= 0,
+ * geometry.py:121,124).
+ * ---------------------------------------------------------------------- */
+int spt_point_geof_dense_f32(const float* xyz, int64_t n, const int64_t* nn, int k,
+                             int add_self, int k_min, int post, float* feats,
+                             spt_stream_t stream);
+int spt_point_geof_csr_f32(const float* xyz, int64_t n, const int64_t* nn_val,
+                           const int64_t* nn_ptr, int add_self, int k_min, int post,
+                           float* feats, spt_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

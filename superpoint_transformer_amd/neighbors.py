@@ -1,0 +1,165 @@
+"""Radius-bounded kNN and point geometric features on the HIP kernels: the
+preprocessing half of the hot path (src/utils/neighbors.py:24-123,186-242,
+668-684; src/utils/geometry.py:80-174)."""
+import ctypes
+
+import torch
+
+from . import _lib
+from .ops import _workspace
+
+__all__ = ["frnn_grid_points", "knn_1", "knn_2", "neighbors_dense_to_csr",
+           "geometric_features", "GEOF_COLUMNS"]
+
+GEOF_COLUMNS = ["linearity", "planarity", "scattering", "verticality", "normal_x",
+                "normal_y", "normal_z", "length", "surface", "volume", "curvature"]
+
+
+def _grid_for(search, r, K, cell_size=None):
+    """Host-side grid description (one sync: the bounding box).  The result
+    does not depend on the cell size, only the speed does: aim at ~K/4 points
+    per non-empty cell, estimated from one occupancy probe."""
+    lo = search.min(dim=0).values
+    hi = search.max(dim=0).values
+    lo_h, hi_h = lo.tolist(), hi.tolist()
+    ext = [max(h - l, 1e-6) for l, h in zip(lo_h, hi_h)]
+    n = search.shape[0]
+    if cell_size is None:
+        s = float(r) / 4
+        # occupancy probe at s: points per non-empty cell ~ s^2 on surfaces
+        probe_dims = [int(e / s) + 1 for e in ext]
+        if probe_dims[0] * probe_dims[1] * probe_dims[2] < (1 << 40) and n > 0:
+            c = ((search - lo) / s).floor().long()
+            lin = (c[:, 2] * probe_dims[1] + c[:, 1]) * probe_dims[0] + c[:, 0]
+            occ = n / max(int(torch.unique(lin).numel()), 1)
+            target = max(K / 4.0, 2.0)
+            s = s * (target / max(occ, 1e-3)) ** 0.5
+        s = min(max(s, float(r) / 64), float(r))
+    else:
+        s = float(cell_size)
+    while True:
+        dims = [int(e / s) + 1 for e in ext]
+        if dims[0] * dims[1] * dims[2] < (1 << 30):
+            break
+        s *= 1.26
+    return s, lo_h, dims
+
+
+def frnn_grid_points(query, search, K, r, squared=True, inclusive=False, cell_size=None):
+    """Same contract as ``frnn.frnn_grid_points`` on one cloud (the reference
+    always calls it with batch size 1, src/utils/neighbors.py:82-83):
+    returns ``(dists [nq,K], idxs [nq,K])``, ascending, -1 padded."""
+    _lib.require_cuda(query, search)
+    q = query.detach().float().contiguous()
+    s = q if search is query else search.detach().float().contiguous()
+    nq, ns = q.shape[0], s.shape[0]
+    K = int(K)
+    dev = q.device
+    idx = torch.empty((nq, K), dtype=torch.int64, device=dev)
+    dist = torch.empty((nq, K), dtype=torch.float32, device=dev)
+    if nq == 0:
+        return dist, idx
+    if ns == 0:
+        return dist.fill_(-1), idx.fill_(-1)
+    cs, origin, dims = _grid_for(s, r, K, cell_size)
+    ncells = dims[0] * dims[1] * dims[2]
+    nb = _lib.lib.spt_grid_knn_workspace_bytes(ns, ncells)
+    ws = _workspace(nb, dev)
+    o3 = (ctypes.c_float * 3)(*origin)
+    d3 = (ctypes.c_int32 * 3)(*dims)
+    with torch.cuda.device(dev):
+        st = _lib.lib.spt_grid_knn_f32(
+            _lib.ptr(q), nq, _lib.ptr(s), ns, K, float(r), cs,
+            ctypes.cast(o3, ctypes.c_void_p), ctypes.cast(d3, ctypes.c_void_p), 1,
+            int(inclusive), int(squared), _lib.ptr(idx), _lib.ptr(dist), _lib.ptr(ws),
+            ws.numel(), _lib.stream_ptr(dev))
+    _lib.check(st, "spt_grid_knn_f32")
+    return dist, idx
+
+
+def _batch_offset(xyz, batch, r_max):
+    """The reference separates batch items by shifting z (neighbors.py:75-78)."""
+    if batch is None:
+        return xyz
+    z = xyz[:, 2]
+    off = torch.zeros_like(xyz)
+    off[:, 2] = batch.to(xyz.dtype) * (z.max() - z.min() + r_max + 1)
+    return xyz + off
+
+
+def knn_1(xyz, k, r_max=1, batch=None, oversample=False, self_is_neighbor=False,
+          squared=True):
+    """k nearest OTHER points within r_max of every point (neighbors.py:51-123):
+    searches k+1 and drops the first column (the point itself).  Returns
+    (neighbors [N,k] int64 with -1 padding, distances [N,k])."""
+    if oversample:
+        raise NotImplementedError("oversample_partial_neighborhoods is not on the HIP path")
+    p = _batch_offset(xyz, batch, r_max)
+    ks = k if self_is_neighbor else k + 1
+    dist, idx = frnn_grid_points(p, p, ks, r_max, squared=squared)
+    if self_is_neighbor:
+        return idx, dist
+    return idx[:, 1:], dist[:, 1:]
+
+
+def knn_2(x_search, x_query, k, r_max=1, batch_search=None, batch_query=None, squared=True):
+    """k nearest search points of every query (neighbors.py:186-242)."""
+    if (batch_search is None) != (batch_query is None):
+        raise ValueError("pass both batch vectors or neither")
+    if batch_search is not None:
+        z = torch.cat((x_search[:, 2], x_query[:, 2]))
+        zoff = z.max() - z.min() + r_max + 1
+        x_search = x_search.clone()
+        x_query = x_query.clone()
+        x_search[:, 2] += batch_search.to(x_search.dtype) * zoff
+        x_query[:, 2] += batch_query.to(x_query.dtype) * zoff
+    dist, idx = frnn_grid_points(x_query, x_search, k, r_max, squared=squared)
+    if k == 1:
+        return idx[:, 0], dist[:, 0]
+    return idx, dist
+
+
+def neighbors_dense_to_csr(nn):
+    """[N,k] with negative = missing -> (ptr [N+1], val [M], sizes [N])
+    (neighbors.py:668-684)."""
+    mask = nn < 0
+    sizes = nn.shape[1] - mask.sum(dim=1)
+    ptr = torch.zeros(nn.shape[0] + 1, dtype=torch.long, device=nn.device)
+    ptr[1:] = sizes.cumsum(0)
+    return ptr, nn[~mask], sizes
+
+
+def geometric_features(xyz, nn, k_min=1, add_self_as_neighbor=True, raw=False):
+    """[N,11] features in pgeof's column order (``GEOF_COLUMNS``) from dense
+    neighbours ``nn`` [N,k] (-1 = missing).  ``raw=False`` includes the tail of
+    ``geometric_features`` (verticality * 2, normals flipped to z >= 0,
+    geometry.py:121,124)."""
+    _lib.require_cuda(xyz, nn)
+    p = xyz.detach().float().contiguous()
+    nn = nn.contiguous()
+    if nn.dtype != torch.int64:
+        nn = nn.long()
+    n, k = nn.shape
+    feats = torch.empty((n, 11), dtype=torch.float32, device=p.device)
+    with torch.cuda.device(p.device):
+        st = _lib.lib.spt_point_geof_dense_f32(
+            _lib.ptr(p), n, _lib.ptr(nn), k, int(add_self_as_neighbor), int(k_min),
+            0 if raw else 1, _lib.ptr(feats), _lib.stream_ptr(p.device))
+    _lib.check(st, "spt_point_geof_dense_f32")
+    return feats
+
+
+def geometric_features_csr(xyz, nn_val, nn_ptr, k_min=1, add_self=False, raw=True):
+    """pgeof.compute_features' layout: CSR neighbourhoods (the caller already
+    put the point itself in its list, geometry.py:95-96,142-153)."""
+    _lib.require_cuda(xyz, nn_val, nn_ptr)
+    p = xyz.detach().float().contiguous()
+    n = p.shape[0]
+    feats = torch.empty((n, 11), dtype=torch.float32, device=p.device)
+    with torch.cuda.device(p.device):
+        st = _lib.lib.spt_point_geof_csr_f32(
+            _lib.ptr(p), n, _lib.ptr(nn_val.long().contiguous()),
+            _lib.ptr(nn_ptr.long().contiguous()), int(add_self), int(k_min),
+            0 if raw else 1, _lib.ptr(feats), _lib.stream_ptr(p.device))
+    _lib.check(st, "spt_point_geof_csr_f32")
+    return feats
