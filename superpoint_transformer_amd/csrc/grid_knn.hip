@@ -176,14 +176,18 @@ __global__ __launch_bounds__(KNN_WAVES * 64) void knn_search_kernel(
     st.npend = 0;
 
     for (int rho = 0;; ++rho) {
-      if (rho > 0) {
-        // every point outside the finished rings is farther than (rho - 0.01) s
-        // (0.01 cell of slack covers the f32 rounding of the cell coordinates)
-        const float gr = ((float)rho - 0.01f) * g.s;
+      if (rho > 1) {
+        // Rings 0..rho-1 are done: an unexplored point sits in a cell at
+        // Chebyshev distance >= rho, i.e. more than (rho-1) whole cells away along
+        // one axis, so it is farther than (rho - 1 - 0.01) s  (0.01 cell of slack
+        // covers the f32 rounding of the cell coordinates).
+        const float gr = ((float)(rho - 1) - 0.01f) * g.s;
         const float g2 = gr * gr;
         if (g2 >= r2) break;                       // nothing within r is left
         knn_flush(st, pend, K, lane);              // exact K-th distance so far
         if (st.kth != KNN_EMPTY && __uint_as_float((uint32_t)(st.kth >> 32)) <= g2) break;
+      }
+      if (rho > 0) {
         const int in = rho - 1;                    // cube of finished rings covers the grid?
         if (cx - in <= 0 && cx + in >= g.dx - 1 && cy - in <= 0 && cy + in >= g.dy - 1 &&
             cz - in <= 0 && cz + in >= g.dz - 1)

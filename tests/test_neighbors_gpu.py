@@ -51,7 +51,7 @@ def test_grid_knn_two_sets_and_euclidean_and_inclusive(dev):
     rd, ri = O.frnn_grid_points(q, s, 20, 0.8)
     assert torch.equal(idx.cpu(), ri)
     ok = ri >= 0
-    assert torch.equal(dist.cpu()[ok], rd[ok].sqrt())
+    torch.testing.assert_close(dist.cpu()[ok], rd[ok].sqrt(), rtol=1e-6, atol=0)  # device sqrtf: 1 ulp
     assert (dist.cpu()[~ok] == -1).all()
     # inclusive radius on a lattice where many points sit exactly at r
     ax = torch.arange(8).float()
@@ -113,9 +113,11 @@ def test_geometric_features_match_reference_fixture(dev):
     f = NB.geometric_features(xyz.to(dev), nn.to(dev), k_min=int(g["k_min"])).cpu().double()
     ref = t64(g["feats"])
     good = _spectrum_ok(xyz, nn)
-    scal = [0, 1, 2, 3, 7, 8, 9, 10]
+    scal = [0, 1, 2, 7, 8, 9, 10]
     assert (f[:, scal] - ref[:, scal]).abs().max().item() <= 1e-4
-    assert (f[good][:, 4:7] - ref[good][:, 4:7]).abs().max().item() <= 1e-4
+    # verticality and the normal depend on eigenVECTORS: unique only away from
+    # repeated eigenvalues
+    assert (f[good][:, 3:7] - ref[good][:, 3:7]).abs().max().item() <= 1e-4
     assert good.float().mean() > 0.9
 
 
