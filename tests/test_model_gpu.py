@@ -3,10 +3,14 @@ demo-room-shaped NAG (and on the reference's real demo room hierarchy) against
 the float64 CPU oracle of oracle/spt_model.py.
 
 Tolerance: logits |err| <= 2e-4 + 1e-3 |ref| (13 chained GraphNorm / MLP /
-attention layers in f32); every parameter gradient within 5e-3 of the
-tensor's largest entry (a max-pool whose two best children differ by less than
-f32 rounding routes its gradient to the other child than the f64 oracle does:
-a discrete, legitimate difference that the first layers accumulate)."""
+attention layers in f32).  Parameter gradients: within 1e-3 of the tensor's
+largest entry, OR within 3x the deviation that a plain f32 evaluation of the
+same oracle shows against the f64 one.  The second clause matters only for the
+point-stage parameters below the max-pool: when a segment's two best children
+differ by less than f32 rounding, f32 arithmetic (the reference's dtype) routes
+the gradient to the other child than f64 does - a discrete, legitimate
+difference of ~5e-3 that any f32 implementation shows (measured:
+tools/diag_model_parity.py)."""
 import copy
 
 import numpy as np
@@ -39,6 +43,13 @@ def _run_case(nag_levels, num_clouds, dev):
     ref_loss = sum(l * loss_fn(lg, y) for l, lg, y in zip((1.0, 50.0), ref_logits, labels))
     ref_loss.backward()
 
+    # the same oracle in plain f32: the precision class of the reference itself
+    ref32 = copy.deepcopy(model).float()
+    outs32 = OM.spt_forward(ref32.net, nag_levels, dtype=torch.float32, keep_graph=True)
+    l32 = [h(x) for h, x in zip(ref32.head, outs32)]
+    sum(l * loss_fn(lg, y) for l, lg, y in zip((1.0, 50.0), l32, labels)).backward()
+    grads32 = dict(ref32.named_parameters())
+
     class View:
         def __init__(self, levels):
             self.levels, self.num_clouds = levels, num_clouds
@@ -63,7 +74,8 @@ def _run_case(nag_levels, num_clouds, dev):
         assert p.grad is not None and r is not None, k
         scale = r.abs().max().clamp(min=1e-2)
         err = ((p.grad.detach().cpu().double() - r).abs() / scale).max().item()
-        assert err <= 5e-3, f"{k}: {err:.3e}"
+        err32 = ((grads32[k].grad.double() - r).abs() / scale).max().item()
+        assert err <= max(1e-3, 3 * err32), f"{k}: hip {err:.3e} vs f32-oracle {err32:.3e}"
 
 
 def test_spt64_train_step_on_synthetic_room(dev):
