@@ -1,0 +1,106 @@
+"""The ``torch_geometric`` symbols the reference's hot path imports
+(src/nn/attention.py:4, pool.py:3-9, norm.py:5-7, utils/edge.py:1), on the HIP ops."""
+import torch
+from torch import nn
+
+from .. import ops
+from ..csr import csr_of
+from ..nn.norm import GraphNorm  # noqa: F401  (same parameters as PyG's: weight, bias, mean_scale)
+from . import scatter_shim
+
+
+def softmax(src, index=None, ptr=None, num_nodes=None, dim=0):
+    """torch_geometric.utils.softmax: per-group softmax along dim 0."""
+    if ptr is not None or dim != 0:
+        raise NotImplementedError("HIP shim: softmax(src, index, dim=0) only")
+    csr = csr_of(index, num_nodes)
+    mx = ops.segment_reduce(src.detach(), csr, None, "max")
+    e = (src - ops.gather_rows(mx, csr.idx)).exp()
+    z = ops.segment_reduce(e, csr, None, "sum") + 1e-16
+    return e / ops.gather_rows(z, csr.idx)
+
+
+def degree(index, num_nodes=None, dtype=None):
+    n = int(num_nodes) if num_nodes is not None else int(index.max()) + 1
+    return csr_of(index, n).counts().to(dtype or torch.float)
+
+
+def scatter(src, index, dim=0, dim_size=None, reduce="sum"):
+    return scatter_shim.scatter(src, index, dim, None, dim_size, reduce)
+
+
+class _Aggregation(nn.Module):
+    reduce = None
+
+    def forward(self, x, index=None, ptr=None, dim_size=None, dim=-2):
+        return scatter_shim.scatter(x, index, 0, None, dim_size, self.reduce)
+
+
+class SumAggregation(_Aggregation):
+    reduce = "sum"
+
+
+class MeanAggregation(_Aggregation):
+    reduce = "mean"
+
+
+class MaxAggregation(_Aggregation):
+    reduce = "max"
+
+
+class MinAggregation(_Aggregation):
+    reduce = "min"
+
+
+class StdAggregation(nn.Module):
+    def forward(self, x, index=None, ptr=None, dim_size=None, dim=-2):
+        mean = scatter_shim.scatter_mean(x, index, 0, None, dim_size)
+        mean2 = scatter_shim.scatter_mean(x * x, index, 0, None, dim_size)
+        return (mean2 - mean * mean).clamp(min=1e-5).sqrt()
+
+
+class _NotOnPath(nn.Module):
+    def __init__(self, *a, **k):
+        super().__init__()
+        raise NotImplementedError(
+            f"{type(self).__name__} is not used by any shipped SPT config "
+            "(all norms are GraphNorm, configs/model/semantic/spt.yaml:19-21)")
+
+
+class LayerNorm(_NotOnPath):
+    pass
+
+
+class InstanceNorm(_NotOnPath):
+    pass
+
+
+def ones(t):
+    if t is not None:
+        t.data.fill_(1.0)
+
+
+def zeros(t):
+    if t is not None:
+        t.data.fill_(0.0)
+
+
+def consecutive_cluster(src):
+    unique, inv = torch.unique(src, sorted=True, return_inverse=True)
+    perm = torch.arange(inv.size(0), dtype=inv.dtype, device=inv.device)
+    perm = inv.new_empty(unique.size(0)).scatter_(0, inv, perm)
+    return inv, perm
+
+
+def coalesce(edge_index, edge_attr=None, num_nodes=None, reduce="sum", **unused):
+    """torch_geometric.utils.coalesce: sort edges by (row, col) and merge
+    duplicates (imported by src/utils/scatter.py:6 and neighbors.py:7 for the
+    'next' rows; plain torch - not on the per-step path)."""
+    n = int(num_nodes) if num_nodes is not None else int(edge_index.max()) + 1 if edge_index.numel() else 0
+    key = edge_index[0] * max(n, 1) + edge_index[1]
+    uniq, inv = torch.unique(key, sorted=True, return_inverse=True)
+    ei = torch.stack([uniq // max(n, 1), uniq % max(n, 1)])
+    if edge_attr is None:
+        return ei
+    red = "sum" if reduce in ("add", "sum") else reduce
+    return ei, scatter_shim.scatter(edge_attr, inv, 0, None, uniq.numel(), red)
