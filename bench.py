@@ -112,10 +112,8 @@ def main():
         path.step()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    from superpoint_transformer_amd import parallel
+    dt = parallel.max_over_ranks(dt, dev)
 
     n0 = nag.num_points[0]
     value = world * n0 * args.steps / dt / 1e6

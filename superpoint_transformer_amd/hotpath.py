@@ -4,8 +4,9 @@
 (configs/experiment/semantic/s3dis.yaml:6-9 -> configs/model/semantic/spt-2.yaml)
 forward + multi-level cross-entropy + backward + AdamW step on one synthetic
 NAG batch resident in HBM, including the per-batch CSR builds (device sorts of
-every ``super_index`` / ``edge_index[0]``).  N > 1: DistributedDataParallel over
-RCCL, one flat gradient bucket (~0.85 MB) per step.
+every ``super_index`` / ``edge_index[0]``).  N > 1: every rank owns its own
+scene; the ~0.85 MB of gradients meet in ONE flat all-reduce per step over
+RCCL (``parallel.FlatGradAllReduce``).
 
 ``ScatterChain``: only the hierarchical segment-CSR scatter kernels (max pool
 fwd/bwd L0->L1->L2 + unpool fwd/bwd), kept as a kernel-level benchmark.
@@ -14,7 +15,7 @@ import torch
 from torch import nn
 
 from . import csr as _csr
-from . import ops
+from . import ops, parallel
 from .nn import SPT, Classifier, GraphNorm
 
 NUM_CLASSES = 13  # S3DIS
@@ -52,7 +53,7 @@ class SPTSegmenter(nn.Module):
 
 
 class _NagView:
-    """What DDP forwards to the module: a plain object, not a tensor tree."""
+    """Minimal NAG-like view: ``nag[i]`` -> level dict, ``nag.num_clouds``."""
 
     def __init__(self, nag):
         self.levels = nag.levels
@@ -72,12 +73,8 @@ class SPTTrainStep:
         self.model = SPTSegmenter(**spt64_config(nag[0]["x"].shape[1],
                                                  nag[1]["edge_attr"].shape[1])).to(dev)
         self.params = [p for p in self.model.parameters()]
-        self.module = self.model
-        if world > 1:
-            from torch.nn.parallel import DistributedDataParallel as DDP
-            # ~0.85 MB of gradients: ONE flat bucket, one all-reduce per step (latency bound)
-            self.module = DDP(self.model, device_ids=[dev.index], bucket_cap_mb=8,
-                              gradient_as_bucket_view=True, broadcast_buffers=False)
+        parallel.broadcast_parameters(self.params, src=0)
+        self.bucket = parallel.FlatGradAllReduce(self.params)
         self.opt = torch.optim.AdamW(self.params, lr=1e-3, weight_decay=1e-4)
         g = torch.Generator(device=dev).manual_seed(5)
         self.labels = [torch.randint(0, NUM_CLASSES, (self.n[i],), device=dev, generator=g)
@@ -98,10 +95,11 @@ class SPTTrainStep:
 
     def step(self):
         self._forget_csr()
-        logits = self.module(self.nag)
+        logits = self.model(self.nag)
         loss = sum(l * self.loss_fn(lg, y) for l, lg, y in zip(self.lambdas, logits, self.labels))
-        self.opt.zero_grad(set_to_none=True)
+        self.bucket.zero()
         loss.backward()
+        self.bucket.reduce()          # one RCCL all-reduce of the flat gradient (no-op at N=1)
         self.opt.step()
         self.last_loss = loss
         return loss

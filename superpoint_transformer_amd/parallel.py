@@ -1,0 +1,71 @@
+"""Data-parallel plumbing: scenes shard across ranks, gradients meet once per
+step.
+
+The reference trains with Lightning DDP (configs/trainer/ddp.yaml): each rank
+loads different clouds, one gradient all-reduce per step.  The whole SPT-64
+gradient is ~0.85 MB, so on an xGMI mesh the exchange is latency-bound: instead
+of DDP's bucketing / hook machinery, all parameter gradients live as VIEWS of
+one flat buffer and a single ``all_reduce`` (RCCL on GPUs - backend "nccl" -,
+gloo in the CPU tests) runs after backward."""
+import torch
+import torch.distributed as dist
+
+__all__ = ["FlatGradAllReduce", "shard_items", "broadcast_parameters", "max_over_ranks"]
+
+
+def shard_items(num_items, rank, world):
+    """Scene / tile indices owned by ``rank``: ``rank, rank+world, ...`` (the
+    DistributedSampler partition without padding)."""
+    return list(range(rank, num_items, world))
+
+
+def broadcast_parameters(params, src=0, group=None):
+    """Make every rank start from rank ``src``'s weights."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    for p in params:
+        dist.broadcast(p.data, src=src, group=group)
+
+
+def max_over_ranks(value, device, group=None):
+    """Slowest rank's time (the bench contract)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return float(t.item())
+
+
+class FlatGradAllReduce:
+    """All gradients of ``params`` as views into one flat f32 buffer; ``reduce()``
+    averages it over the ranks with ONE collective."""
+
+    def __init__(self, params, group=None):
+        self.params = [p for p in params if p.requires_grad]
+        self.group = group
+        total = sum(p.numel() for p in self.params)
+        dev = self.params[0].device if self.params else torch.device("cpu")
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        off = 0
+        for p in self.params:
+            if p.dtype != torch.float32:
+                raise TypeError("flat gradient bucket expects f32 parameters")
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+
+    def zero(self):
+        """Use instead of ``optimizer.zero_grad(set_to_none=True)``: the views stay."""
+        self.flat.zero_()
+
+    def reduce(self):
+        if self.world > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+            self.flat.div_(self.world)
+        return self.flat
+
+    def check_views(self):
+        """True when every ``p.grad`` still aliases the flat buffer."""
+        base = self.flat.untyped_storage().data_ptr()
+        return all(p.grad is not None and p.grad.untyped_storage().data_ptr() == base
+                   for p in self.params)
