@@ -88,6 +88,20 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(
   int cur = 0;
 #pragma unroll
   for (int k = 0; k < VEC; ++k) s1[k] = s2[k] = 0.0;
+  // per-(graph, channel) coefficients of the CURRENT graph live in registers:
+  // the graph id changes a handful of times per lane, the rows are millions
+  float t_am[VEC], t_sc[VEC], t_bs[VEC];
+  auto load_tables = [&](int b) {
+    if constexpr (BWD) {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        t_am[k] = cv ? am[b * d + c0 + k] : 0.f;
+        t_sc[k] = cv ? scale[b * d + c0 + k] : 0.f;
+        t_bs[k] = cv ? bias[c0 + k] : 0.f;
+      }
+    }
+  };
+  load_tables(0);
 
   auto flush = [&]() {
     if (cv) {
@@ -124,6 +138,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(
       if (b[u] != cur) {
         flush();
         cur = b[u];
+        load_tables(cur);
       }
       cnt += 1.0;
       if (!cv) continue;
@@ -134,11 +149,10 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(
           s1[k] += xv;
           s2[k] += xv * xv;
         } else {
-          const int t = cur * d + c0 + k;
-          const float o = v[u][k] - am[t];
+          const float o = v[u][k] - t_am[k];
           float gg = g[u][k];
           if (slope != 1.f) {
-            const float y = fmaf(o, scale[t], bias[c0 + k]);
+            const float y = fmaf(o, t_sc[k], t_bs[k]);
             gg = (y > 0.f) ? gg : gg * slope;
           }
           s1[k] += (double)gg;
@@ -225,9 +239,10 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_fwd_kernel(
   const int rsub = threadIdx.x >> lpr_log2;
   const int c0 = (threadIdx.x & (lpr - 1)) * VEC;
   if (c0 >= d) return;
-  float bs[VEC];
+  float bs[VEC], t_am[VEC], t_sc[VEC];
 #pragma unroll
   for (int k = 0; k < VEC; ++k) bs[k] = bias[c0 + k];
+  int cur = -1;
   const int64_t step = (int64_t)gridDim.x * rpb * GN_UNR;
   for (int64_t rb = (int64_t)blockIdx.x * rpb * GN_UNR; rb < R; rb += step) {
     float v[GN_UNR][VEC];
@@ -241,12 +256,19 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_fwd_kernel(
 #pragma unroll
     for (int u = 0; u < GN_UNR; ++u) {
       if (b[u] < 0) continue;
+      if (b[u] != cur) {  // coefficient rows of the current graph stay in registers
+        cur = b[u];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+          t_am[k] = am[cur * d + c0 + k];
+          t_sc[k] = scale[cur * d + c0 + k];
+        }
+      }
       const int64_t row = rb + (int64_t)u * rpb + rsub;
       float o[VEC];
 #pragma unroll
       for (int k = 0; k < VEC; ++k) {
-        const int t = b[u] * d + c0 + k;
-        float yy = fmaf(v[u][k] - am[t], scale[t], bs[k]);
+        float yy = fmaf(v[u][k] - t_am[k], t_sc[k], bs[k]);
         if (slope != 1.f) yy = (yy > 0.f) ? yy : yy * slope;
         o[k] = yy;
       }
@@ -301,9 +323,10 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_bwd_kernel(
   const int rsub = threadIdx.x >> lpr_log2;
   const int c0 = (threadIdx.x & (lpr - 1)) * VEC;
   if (c0 >= d) return;
-  float bs[VEC];
+  float bs[VEC], t_am[VEC], t_sc[VEC], t_c1[VEC], t_c2[VEC], t_c3[VEC];
 #pragma unroll
   for (int k = 0; k < VEC; ++k) bs[k] = bias[c0 + k];
+  int cur = -1;
   const int64_t step = (int64_t)gridDim.x * rpb * GN_UNR;
   for (int64_t rb = (int64_t)blockIdx.x * rpb * GN_UNR; rb < R; rb += step) {
     float v[GN_UNR][VEC], g[GN_UNR][VEC];
@@ -320,18 +343,26 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_bwd_kernel(
 #pragma unroll
     for (int u = 0; u < GN_UNR; ++u) {
       if (b[u] < 0) continue;
+      if (b[u] != cur) {
+        cur = b[u];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+          const int t = cur * d + c0 + k;
+          t_am[k] = am[t]; t_sc[k] = scale[t];
+          t_c1[k] = c1[t]; t_c2[k] = c2[t]; t_c3[k] = c3[t];
+        }
+      }
       const int64_t row = rb + (int64_t)u * rpb + rsub;
       float o[VEC];
 #pragma unroll
       for (int k = 0; k < VEC; ++k) {
-        const int t = b[u] * d + c0 + k;
-        const float oo = v[u][k] - am[t];
+        const float oo = v[u][k] - t_am[k];
         float gg = g[u][k];
         if (slope != 1.f) {
-          const float yy = fmaf(oo, scale[t], bs[k]);
+          const float yy = fmaf(oo, t_sc[k], bs[k]);
           gg = (yy > 0.f) ? gg : gg * slope;
         }
-        o[k] = fmaf(c1[t], gg, -fmaf(c2[t], oo, c3[t]));
+        o[k] = fmaf(t_c1[k], gg, -fmaf(t_c2[k], oo, t_c3[k]));
       }
       st<VEC>(gx + row * d + c0, o);
     }

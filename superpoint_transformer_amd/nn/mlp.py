@@ -2,6 +2,7 @@
 PyTorch; every ``GraphNorm -> LeakyReLU`` pair runs as ONE fused HIP pass."""
 from torch import nn
 
+from .. import ops
 from .norm import INDEX_BASED_NORMS, GraphNorm
 
 __all__ = ["MLP", "FFN", "Classifier"]
@@ -47,6 +48,8 @@ class MLP(nn.Module):
                 x = m(x, batch=batch, batch_size=batch_size)
             elif isinstance(m, INDEX_BASED_NORMS):
                 x = m(x, batch=batch)
+            elif isinstance(m, nn.Linear):
+                x = ops.linear(x, m.weight, m.bias)
             else:
                 x = m(x)
             i += 1

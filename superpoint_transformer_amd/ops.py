@@ -403,3 +403,52 @@ def edge_attention(qkv, edge_index, edge_attr=None, k_rpe=None, q_rpe=None, v_rp
     Wv, bv = wb(v_rpe)
     return _EdgeAttention.apply(qkv, ecsr, edge_attr, Wk, bk, Wq, bq, Wv, bv,
                                 int(num_heads), int(qk_dim), int(scale_mode), float(scale_a))
+
+
+# ---------------------------------------------------------------------------
+# Dense Linear on tall-skinny operands (plumbing over rocBLAS / hipBLASLt)
+# ---------------------------------------------------------------------------
+_DW_CHUNK = 32768
+
+
+class _TallLinear(torch.autograd.Function):
+    """y = x W^T (+ b) for [rows >> features] operands.  Forward and dX are plain
+    library GEMMs; dW = G^T X reduces over millions of rows into a <=128x132
+    output, a shape the library runs on a handful of workgroups - so it is
+    issued as a BATCHED GEMM over row chunks (thousands of workgroups) followed
+    by a small sum."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return torch.nn.functional.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        g = g.contiguous()
+        gx = g @ weight if ctx.needs_input_grad[0] else None
+        gw = gb = None
+        if ctx.needs_input_grad[1]:
+            n = x.shape[0]
+            nb = n // _DW_CHUNK
+            main = nb * _DW_CHUNK
+            gw = None
+            if nb > 0:
+                gm = g[:main].view(nb, _DW_CHUNK, g.shape[1])
+                xm = x[:main].view(nb, _DW_CHUNK, x.shape[1])
+                gw = torch.bmm(gm.transpose(1, 2), xm).sum(0)
+            if main < n:
+                tail = g[main:].t() @ x[main:]
+                gw = tail if gw is None else gw + tail
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = g.sum(0)
+        return gx, gw, gb
+
+
+def linear(x, weight, bias=None):
+    """``nn.Linear`` forward with a tall-skinny-aware backward (see _TallLinear)."""
+    if x.dim() != 2 or x.shape[0] < 4 * _DW_CHUNK or not x.is_contiguous():
+        return torch.nn.functional.linear(x, weight, bias)
+    return _TallLinear.apply(x, weight, bias)
