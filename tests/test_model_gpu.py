@@ -69,12 +69,19 @@ def _run_case(nag_levels, num_clouds, dev):
         assert ((a - r).abs() - 1e-3 * r.abs()).max().item() <= 2e-4
     assert abs(loss.item() - ref_loss.item()) <= 1e-4 * abs(ref_loss.item())
     ref_grads = dict(ref_model.named_parameters())
+
+    def rel(gr, r):
+        return ((gr.double() - r).abs() / r.abs().max().clamp(min=1e-2)).max().item()
+
+    # which point-stage tensor an arg-max flip lands on is random: bound that
+    # group by the WORST f32-oracle deviation inside the group
+    below_pool = max(rel(grads32[k].grad, ref_grads[k].grad)
+                     for k in ref_grads if k.startswith("net.first_stage."))
     for k, p in gm.named_parameters():
         r = ref_grads[k].grad
         assert p.grad is not None and r is not None, k
-        scale = r.abs().max().clamp(min=1e-2)
-        err = ((p.grad.detach().cpu().double() - r).abs() / scale).max().item()
-        err32 = ((grads32[k].grad.double() - r).abs() / scale).max().item()
+        err = rel(p.grad.detach().cpu(), r)
+        err32 = below_pool if k.startswith("net.first_stage.") else rel(grads32[k].grad, r)
         assert err <= max(1e-3, 3 * err32), f"{k}: hip {err:.3e} vs f32-oracle {err32:.3e}"
 
 
