@@ -22,7 +22,7 @@ FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
     "-ffp-contract=off",  # parity: no silent fma contraction vs the oracle
     "-Wno-unused-result",
-]
+] + os.environ.get("SPT_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def _sources():

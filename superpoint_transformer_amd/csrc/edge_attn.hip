@@ -124,9 +124,113 @@ __device__ __forceinline__ float qk_scale_of(int mode, float a, int deg) {
 }
 
 // waves per SIMD the register-resident weight block leaves room for
+#ifndef SPT_EA_FWD_MAXW
+#define SPT_EA_FWD_MAXW 3
+#endif
 constexpr int ea_min_waves(int qpl, int vpl, int f) {
   const int w = (2 * qpl + vpl) * f;
-  return w <= 96 ? 3 : (w <= 136 ? 2 : 1);
+  const int r = w <= 96 ? 3 : (w <= 136 ? 2 : 1);
+  return r < SPT_EA_FWD_MAXW ? r : SPT_EA_FWD_MAXW;
+}
+
+// ---- asynchronous tile pipeline (global -> LDS without a VGPR round trip) -------
+// A wave walks the flat sequence of 8-edge tiles of its nodes.  While it
+// computes tile i out of LDS buffer b, the edge_attr rows and the gathered k / v
+// rows of tile i+1 stream into buffer b^1 with `global_load_lds` (the data never
+// touches VGPRs, so the prefetch costs no registers), and the edge / target
+// indices of tile i+2 are already in flight.
+struct TileDesc {
+  int64_t s;        // source node
+  int start, end;   // CSR range of the node
+  int t0;           // first edge of this tile
+  bool valid;
+};
+
+__device__ __forceinline__ TileDesc tile_of_node(int64_t s, int64_t N,
+                                                 const int32_t* __restrict__ erowptr) {
+  TileDesc d;
+  d.s = s;
+  d.valid = s < N;
+  d.start = d.valid ? erowptr[s] : 0;
+  d.end = d.valid ? erowptr[s + 1] : 0;
+  d.t0 = d.start;
+  return d;
+}
+
+__device__ __forceinline__ TileDesc tile_advance(const TileDesc& c, int64_t N, int64_t nwaves,
+                                                 const int32_t* __restrict__ erowptr) {
+  if (c.valid && c.t0 + EA_TE < c.end) {
+    TileDesc d = c;
+    d.t0 += EA_TE;
+    return d;
+  }
+  return tile_of_node(c.s + nwaves, N, erowptr);
+}
+
+__device__ __forceinline__ int tile_count(const TileDesc& d) {
+  const int r = d.end - d.t0;
+  return r < EA_TE ? (r > 0 ? r : 0) : EA_TE;
+}
+
+__device__ __forceinline__ void wait_vmem_all() {
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), leave expcnt / lgkmcnt alone
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+#define SPT_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define SPT_GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+// issue the asynchronous loads of one tile into `buf` (layout: ea | k rows | v rows)
+template <int QPL, int VPL, int F>
+__device__ __forceinline__ void tile_issue(const float* __restrict__ qkv, int ld,
+                                           const AttnShape& sh, const float* __restrict__ ea,
+                                           bool has_rpe, int e_lane, int t_lane, int cnt,
+                                           float* buf, int lane, int j0, int c0, bool qv,
+                                           bool vv) {
+  constexpr int KROW = 64 * QPL, VROW = 64 * VPL;
+  float* kbuf = buf + EA_TE * F;
+  float* vbuf = kbuf + EA_TE * KROW;
+  if (has_rpe) {
+    if constexpr (F % 4 == 0) {
+      constexpr int CH = F / 4, TOT = EA_TE * CH;
+#pragma unroll
+      for (int p = 0; p < (TOT + 63) / 64; ++p) {
+        const int q = p * 64 + lane;
+        const int u = q / CH, ch = q - u * CH;
+        const int e = __shfl(e_lane, u < EA_TE ? u : 0, 64);
+        if (q < TOT && u < cnt)
+          __builtin_amdgcn_global_load_lds(SPT_GLB_PTR(ea + (size_t)e * F + ch * 4),
+                                           SPT_LDS_PTR(buf + p * 256), 16, 0, 0);
+      }
+    } else {
+      constexpr int TOT = EA_TE * F;
+#pragma unroll
+      for (int p = 0; p < (TOT + 63) / 64; ++p) {
+        const int q = p * 64 + lane;
+        const int u = q / F, f = q - u * F;
+        const int e = __shfl(e_lane, u < EA_TE ? u : 0, 64);
+        if (q < TOT && u < cnt)
+          __builtin_amdgcn_global_load_lds(SPT_GLB_PTR(ea + (size_t)e * F + f),
+                                           SPT_LDS_PTR(buf + p * 64), 4, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < EA_TE; ++u) {
+    const int64_t t = __shfl(t_lane, u, 64);
+    if (u < cnt) {
+#pragma unroll
+      for (int i = 0; i < QPL; ++i)
+        if (qv)
+          __builtin_amdgcn_global_load_lds(SPT_GLB_PTR(qkv + t * ld + sh.QK + j0 + i),
+                                           SPT_LDS_PTR(kbuf + u * KROW + i * 64), 4, 0, 0);
+#pragma unroll
+      for (int i = 0; i < VPL; ++i)
+        if (vv)
+          __builtin_amdgcn_global_load_lds(SPT_GLB_PTR(qkv + t * ld + 2 * sh.QK + c0 + i),
+                                           SPT_LDS_PTR(vbuf + u * VROW + i * 64), 4, 0, 0);
+    }
+  }
 }
 
 template <int QPL, int VPL, int F>
@@ -139,15 +243,12 @@ __global__ __launch_bounds__(EA_WAVES * 64, ea_min_waves(QPL, VPL, F)) void edge
     const float* __restrict__ Wv, const float* __restrict__ bv, int scale_mode,
     float scale_a, float* __restrict__ out, float* __restrict__ mbuf,
     float* __restrict__ zbuf) {
-  // per-wave LDS slab: edge_attr tile | gathered k rows | gathered v rows
+  // two per-wave LDS buffers: edge_attr tile | gathered k rows | gathered v rows
   constexpr int KROW = 64 * QPL, VROW = 64 * VPL;
   constexpr int SLAB = EA_TE * (F + KROW + VROW);
-  __shared__ __attribute__((aligned(16))) float slab_all[EA_WAVES][SLAB];
+  __shared__ __attribute__((aligned(16))) float slab_all[EA_WAVES][2][SLAB];
   const int lane = threadIdx.x & 63;
   const int wid = threadIdx.x >> 6;
-  float* slab = slab_all[wid];
-  float* kslab = slab + EA_TE * F;
-  float* vslab = kslab + EA_TE * KROW;
 
   const int j0 = lane * QPL, c0 = lane * VPL;
   const bool qv = j0 < sh.QK, vv = c0 < sh.C;
@@ -158,102 +259,117 @@ __global__ __launch_bounds__(EA_WAVES * 64, ea_min_waves(QPL, VPL, F)) void edge
   load_rows<VPL, F>(Wv, bv, c0, sh.C, wv, bbv);
 
   const int lph = 1 << sh.lph_log2;
-  // lane whose softmax state belongs to the head of this lane's value slots
+  const bool aligned = sh.lph_log2 == sh.lphv_log2;
   const int hv = vv ? c0 / sh.Dv : 0;
-  const int src_lane = (hv * sh.D) / QPL;
+  const int src_lane = (hv * sh.D) / QPL;   // qk lane holding my value head's softmax state
   const int my_head = qv ? j0 / sh.D : 0;
   const bool head_leader = qv && ((lane & (lph - 1)) == 0);
 
   const int64_t wave = (int64_t)blockIdx.x * EA_WAVES + wid;
   const int64_t nwaves = (int64_t)gridDim.x * EA_WAVES;
-  for (int64_t s = wave; s < N; s += nwaves) {
-    const int start = erowptr[s], end = erowptr[s + 1];
-    const int deg = end - start;
-    float qs[QPL];
-    const float scale = deg > 0 ? qk_scale_of(scale_mode, scale_a, deg) : 0.f;
-#pragma unroll
-    for (int i = 0; i < QPL; ++i) qs[i] = qv ? qkv[s * ld + j0 + i] * scale : 0.f;
-    float m = -INFINITY, z = 0.f;
-    float acc[VPL];
-#pragma unroll
-    for (int i = 0; i < VPL; ++i) acc[i] = 0.f;
 
-    for (int t0 = start; t0 < end; t0 += EA_TE) {
-      const int cnt = (end - t0 < EA_TE) ? end - t0 : EA_TE;
-      int e_lane = 0, t_lane = 0;
-      if (lane < cnt) {
-        e_lane = eperm ? eperm[t0 + lane] : t0 + lane;
-        t_lane = tgt[t0 + lane];
-      }
-      lds_fence();  // previous tile's LDS reads are done before we overwrite
-      {
-        float kt[EA_TE][QPL], vt[EA_TE][VPL];
+  auto load_idx = [&](const TileDesc& d, int& e_lane, int& t_lane) {
+    e_lane = 0;
+    t_lane = 0;
+    const int cnt = tile_count(d);
+    if (d.valid && lane < cnt) {
+      e_lane = eperm ? eperm[d.t0 + lane] : d.t0 + lane;
+      t_lane = tgt[d.t0 + lane];
+    }
+  };
+
+  for (int i = lane; i < 2 * SLAB; i += 64) (&slab_all[wid][0][0])[i] = 0.f;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  TileDesc cur = tile_of_node(wave, N, erowptr);
+  if (!cur.valid) return;
+  int e_cur, t_cur, e_nxt, t_nxt;
+  load_idx(cur, e_cur, t_cur);
+  int b = 0;
+  tile_issue<QPL, VPL, F>(qkv, ld, sh, ea, has_rpe, e_cur, t_cur, tile_count(cur),
+                          slab_all[wid][b], lane, j0, c0, qv, vv);
+  TileDesc nxt = tile_advance(cur, N, nwaves, erowptr);
+  load_idx(nxt, e_nxt, t_nxt);
+
+  float qs[QPL], acc[VPL];
+  float m = -INFINITY, z = 0.f;
+  while (cur.valid) {
+    wait_vmem_all();  // tile `cur` has landed in buffer b; the indices of `nxt` are here
+    if (nxt.valid)
+      tile_issue<QPL, VPL, F>(qkv, ld, sh, ea, has_rpe, e_nxt, t_nxt, tile_count(nxt),
+                              slab_all[wid][b ^ 1], lane, j0, c0, qv, vv);
+    const float* slab = slab_all[wid][b];
+    const float* kslab = slab + EA_TE * F;
+    const float* vslab = kslab + EA_TE * KROW;
+    const int cnt = tile_count(cur);
+    if (cur.t0 == cur.start) {  // first tile of the node: reset the state
+      const int deg = cur.end - cur.start;
+      const float scale = deg > 0 ? qk_scale_of(scale_mode, scale_a, deg) : 0.f;
 #pragma unroll
-        for (int u = 0; u < EA_TE; ++u) {
-          const int64_t t = __shfl(t_lane, u, 64);
+      for (int i = 0; i < QPL; ++i) qs[i] = qv ? qkv[cur.s * ld + j0 + i] * scale : 0.f;
 #pragma unroll
-          for (int i = 0; i < QPL; ++i)
-            kt[u][i] = (u < cnt && qv) ? qkv[t * ld + sh.QK + j0 + i] : 0.f;
-#pragma unroll
-          for (int i = 0; i < VPL; ++i)
-            vt[u][i] = (u < cnt && vv) ? qkv[t * ld + 2 * sh.QK + c0 + i] : 0.f;
-        }
-        if (has_rpe) stage_tile<F>(ea, e_lane, cnt, slab);
-#pragma unroll
-        for (int u = 0; u < EA_TE; ++u) {
-#pragma unroll
-          for (int i = 0; i < QPL; ++i) kslab[u * KROW + i * 64 + lane] = kt[u][i];
-#pragma unroll
-          for (int i = 0; i < VPL; ++i) vslab[u * VROW + i * 64 + lane] = vt[u][i];
-        }
-      }
-      lds_fence();
+      for (int i = 0; i < VPL; ++i) acc[i] = 0.f;
+      m = -INFINITY;
+      z = 0.f;
+    }
 #pragma unroll 1
-      for (int u = 0; u < cnt; ++u) {
-        float ke[QPL], qe[QPL], ve[VPL];
-        if (has_rpe) {
-          rpe<QPL, F>(wk, bbk, slab + u * F, ke);
-          rpe<QPL, F>(wq, bbq, slab + u * F, qe);
-          rpe<VPL, F>(wv, bbv, slab + u * F, ve);
-        } else {
+    for (int u = 0; u < cnt; ++u) {
+      float ke[QPL], qe[QPL], ve[VPL];
+      if (has_rpe) {
+        rpe<QPL, F>(wk, bbk, slab + u * F, ke);
+        rpe<QPL, F>(wq, bbq, slab + u * F, qe);
+        rpe<VPL, F>(wv, bbv, slab + u * F, ve);
+      } else {
 #pragma unroll
-          for (int i = 0; i < QPL; ++i) ke[i] = qe[i] = 0.f;
+        for (int i = 0; i < QPL; ++i) ke[i] = qe[i] = 0.f;
 #pragma unroll
-          for (int i = 0; i < VPL; ++i) ve[i] = 0.f;
-        }
-        float p = 0.f;
+        for (int i = 0; i < VPL; ++i) ve[i] = 0.f;
+      }
+      float p = 0.f;
 #pragma unroll
-        for (int i = 0; i < QPL; ++i) {
-          ke[i] += kslab[u * KROW + i * 64 + lane];
-          qe[i] += qs[i];
-          p = fmaf(qe[i], ke[i], p);
-        }
-        for (int o = 1; o < lph; o <<= 1) p += __shfl_xor(p, o, 64);
-        // online softmax per head (state replicated on the head's lanes)
-        const float mn = fmaxf(m, p);
-        const float corr = expf(m - mn);
-        const float pe = expf(p - mn);
-        z = fmaf(z, corr, pe);
-        m = mn;
-        float corr_v = corr, pe_v = pe;
-        if (sh.lph_log2 != sh.lphv_log2) {
-          corr_v = __shfl(corr, src_lane, 64);
-          pe_v = __shfl(pe, src_lane, 64);
-        }
+      for (int i = 0; i < QPL; ++i) {
+        ke[i] += kslab[u * KROW + i * 64 + lane];
+        qe[i] += qs[i];
+        p = fmaf(qe[i], ke[i], p);
+      }
+      for (int o = 1; o < lph; o <<= 1) p += __shfl_xor(p, o, 64);
+      // online softmax per head (state replicated on the head's lanes);
+      // v_exp_f32 path: relative error ~1e-6 at |x| <= 20, far inside the 1e-4 bar
+      const float mn = fmaxf(m, p);
+      const float corr = __expf(m - mn);
+      const float pe = __expf(p - mn);
+      z = fmaf(z, corr, pe);
+      m = mn;
+      float corr_v = corr, pe_v = pe;
+      if (!aligned) {
+        corr_v = __shfl(corr, src_lane, 64);
+        pe_v = __shfl(pe, src_lane, 64);
+      }
 #pragma unroll
-        for (int i = 0; i < VPL; ++i) acc[i] = fmaf(acc[i], corr_v, pe_v * (ve[i] + vslab[u * VROW + i * 64 + lane]));
+      for (int i = 0; i < VPL; ++i)
+        acc[i] = fmaf(acc[i], corr_v, pe_v * (ve[i] + vslab[u * VROW + i * 64 + lane]));
+    }
+    if (cur.t0 + EA_TE >= cur.end) {  // last tile of the node: write its row
+      float zz = z;
+      if (!aligned) zz = __shfl(z, src_lane, 64);
+      if (vv) {
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) out[cur.s * sh.C + c0 + i] = acc[i] / (zz + 1e-16f);
+      }
+      if (head_leader && mbuf) {
+        mbuf[cur.s * sh.H + my_head] = m;
+        zbuf[cur.s * sh.H + my_head] = z;
       }
     }
-    float zz = z;
-    if (sh.lph_log2 != sh.lphv_log2) zz = __shfl(z, src_lane, 64);
-    if (vv) {
-#pragma unroll
-      for (int i = 0; i < VPL; ++i) out[s * sh.C + c0 + i] = acc[i] / (zz + 1e-16f);
-    }
-    if (head_leader && mbuf) {
-      mbuf[s * sh.H + my_head] = m;
-      zbuf[s * sh.H + my_head] = z;
-    }
+    // rotate: the indices of the tile after `nxt` are requested now and land
+    // while `nxt` is being computed
+    cur = nxt;
+    e_cur = e_nxt;
+    t_cur = t_nxt;
+    nxt = tile_advance(cur, N, nwaves, erowptr);
+    load_idx(nxt, e_nxt, t_nxt);
+    b ^= 1;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   }
 }
 
@@ -303,12 +419,9 @@ __global__ __launch_bounds__(EA_WAVES * 64, 1) void edge_attn_bwd_kernel(
     float* __restrict__ gqkv, float* __restrict__ gea, float* __restrict__ partial) {
   constexpr int KROW = 64 * QPL, VROW = 64 * VPL;
   constexpr int SLAB = EA_TE * (F + KROW + VROW);
-  __shared__ __attribute__((aligned(16))) float slab_all[EA_WAVES][SLAB];
+  __shared__ __attribute__((aligned(16))) float slab_all[EA_WAVES][2][SLAB];
   const int lane = threadIdx.x & 63;
   const int wid = threadIdx.x >> 6;
-  float* slab = slab_all[wid];
-  float* kslab = slab + EA_TE * F;
-  float* vslab = kslab + EA_TE * KROW;
 
   const int j0 = lane * QPL, c0 = lane * VPL;
   const bool qv = j0 < sh.QK, vv = c0 < sh.C;
@@ -340,57 +453,58 @@ __global__ __launch_bounds__(EA_WAVES * 64, 1) void edge_attn_bwd_kernel(
 
   const int64_t wave = (int64_t)blockIdx.x * EA_WAVES + wid;
   const int64_t nwaves = (int64_t)gridDim.x * EA_WAVES;
-  for (int64_t s = wave; s < N; s += nwaves) {
-    const int start = erowptr[s], end = erowptr[s + 1];
-    const int deg = end - start;
-    const float scale = deg > 0 ? qk_scale_of(scale_mode, scale_a, deg) : 0.f;
-    float qs[QPL], dqa[QPL], g[VPL];
-#pragma unroll
-    for (int i = 0; i < QPL; ++i) {
-      qs[i] = qv ? qkv[s * ld + j0 + i] * scale : 0.f;
-      dqa[i] = 0.f;
+  auto load_idx = [&](const TileDesc& d, int& e_lane, int& t_lane) {
+    e_lane = 0;
+    t_lane = 0;
+    const int cnt = tile_count(d);
+    if (d.valid && lane < cnt) {
+      e_lane = eperm ? eperm[d.t0 + lane] : d.t0 + lane;
+      t_lane = tgt[d.t0 + lane];
     }
-    float dl = 0.f;
+  };
+  TileDesc cur = tile_of_node(wave, N, erowptr);
+  int e_lane = 0, t_lane = 0, e_nxt = 0, t_nxt = 0;
+  int bsel = 0;
+  TileDesc nxt = cur;
+  if (cur.valid) {
+    load_idx(cur, e_lane, t_lane);
+    tile_issue<QPL, VPL, F>(qkv, ld, sh, ea, has_rpe, e_lane, t_lane, tile_count(cur),
+                            slab_all[wid][bsel], lane, j0, c0, qv, vv);
+    nxt = tile_advance(cur, N, nwaves, erowptr);
+    load_idx(nxt, e_nxt, t_nxt);
+  }
+  float qs[QPL], dqa[QPL], g[VPL];
+  float scale = 0.f, delta = 0.f, m = 0.f, zi = 0.f;
+  while (cur.valid) {
+    wait_vmem_all();
+    if (nxt.valid)
+      tile_issue<QPL, VPL, F>(qkv, ld, sh, ea, has_rpe, e_nxt, t_nxt, tile_count(nxt),
+                              slab_all[wid][bsel ^ 1], lane, j0, c0, qv, vv);
+    const float* slab = slab_all[wid][bsel];
+    const float* kslab = slab + EA_TE * F;
+    const float* vslab = kslab + EA_TE * KROW;
+    const int64_t s = cur.s;
+    const int cnt = tile_count(cur);
+    if (cur.t0 == cur.start) {  // first tile of the node
+      const int deg = cur.end - cur.start;
+      scale = deg > 0 ? qk_scale_of(scale_mode, scale_a, deg) : 0.f;
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) {
-      g[i] = vv ? gout[s * sh.C + c0 + i] : 0.f;
-      dl = fmaf(g[i], vv ? out[s * sh.C + c0 + i] : 0.f, dl);
+      for (int i = 0; i < QPL; ++i) {
+        qs[i] = qv ? qkv[s * ld + j0 + i] * scale : 0.f;
+        dqa[i] = 0.f;
+      }
+      float dl = 0.f;
+#pragma unroll
+      for (int i = 0; i < VPL; ++i) {
+        g[i] = vv ? gout[s * sh.C + c0 + i] : 0.f;
+        dl = fmaf(g[i], vv ? out[s * sh.C + c0 + i] : 0.f, dl);
+      }
+      for (int o = 1; o < lphv; o <<= 1) dl += __shfl_xor(dl, o, 64);
+      delta = aligned ? dl : __shfl(dl, vsrc_lane, 64);
+      m = qv ? mbuf[s * sh.H + my_head] : 0.f;
+      zi = qv ? 1.0f / (zbuf[s * sh.H + my_head] + 1e-16f) : 0.f;
     }
-    for (int o = 1; o < lphv; o <<= 1) dl += __shfl_xor(dl, o, 64);
-    const float delta = aligned ? dl : __shfl(dl, vsrc_lane, 64);
-    const float m = qv ? mbuf[s * sh.H + my_head] : 0.f;
-    const float zi = qv ? 1.0f / (zbuf[s * sh.H + my_head] + 1e-16f) : 0.f;
-
-    for (int t0 = start; t0 < end; t0 += EA_TE) {
-      const int cnt = (end - t0 < EA_TE) ? end - t0 : EA_TE;
-      int e_lane = 0, t_lane = 0;
-      if (lane < cnt) {
-        e_lane = eperm ? eperm[t0 + lane] : t0 + lane;
-        t_lane = tgt[t0 + lane];
-      }
-      lds_fence();
-      {
-        float kt[EA_TE][QPL], vt[EA_TE][VPL];
-#pragma unroll
-        for (int u = 0; u < EA_TE; ++u) {
-          const int64_t t = __shfl(t_lane, u, 64);
-#pragma unroll
-          for (int i = 0; i < QPL; ++i)
-            kt[u][i] = (u < cnt && qv) ? qkv[t * ld + sh.QK + j0 + i] : 0.f;
-#pragma unroll
-          for (int i = 0; i < VPL; ++i)
-            vt[u][i] = (u < cnt && vv) ? qkv[t * ld + 2 * sh.QK + c0 + i] : 0.f;
-        }
-        if (has_rpe) stage_tile<F>(ea, e_lane, cnt, slab);
-#pragma unroll
-        for (int u = 0; u < EA_TE; ++u) {
-#pragma unroll
-          for (int i = 0; i < QPL; ++i) kslab[u * KROW + i * 64 + lane] = kt[u][i];
-#pragma unroll
-          for (int i = 0; i < VPL; ++i) vslab[u * VROW + i * 64 + lane] = vt[u][i];
-        }
-      }
-      lds_fence();
+    {
 #pragma unroll 1
       for (int u = 0; u < cnt; ++u) {
         const float* row = slab + u * F;
@@ -413,7 +527,7 @@ __global__ __launch_bounds__(EA_WAVES * 64, 1) void edge_attn_bwd_kernel(
           p = fmaf(qe[i], ke[i], p);
         }
         for (int o = 1; o < lph; o <<= 1) p += __shfl_xor(p, o, 64);
-        const float a = expf(p - m) * zi;                     // attention weight (qk lanes)
+        const float a = __expf(p - m) * zi;                   // attention weight (qk lanes)
         const float a_v = aligned ? a : __shfl(a, src_lane, 64);
         float dv[VPL], da = 0.f;
 #pragma unroll
@@ -514,10 +628,17 @@ __global__ __launch_bounds__(EA_WAVES * 64, 1) void edge_attn_bwd_kernel(
         }
       }
     }
-    if (qv) {
+    if (cur.t0 + EA_TE >= cur.end && qv) {  // last tile of the node
 #pragma unroll
       for (int i = 0; i < QPL; ++i) gqkv[s * ld + j0 + i] = dqa[i] * scale;
     }
+    cur = nxt;
+    e_lane = e_nxt;
+    t_lane = t_nxt;
+    nxt = tile_advance(cur, N, nwaves, erowptr);
+    load_idx(nxt, e_nxt, t_nxt);
+    bsel ^= 1;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   }
   // per-wave partial tables [rows = 2*QK + C][F + 1]
   if (has_rpe && partial) {

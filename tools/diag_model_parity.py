@@ -5,7 +5,7 @@ import sys
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from oracle import spt_model as OM
 from superpoint_transformer_amd import hotpath
 from superpoint_transformer_amd.synthetic import make_nag
