@@ -31,6 +31,7 @@ def parse():
     p.add_argument("--warmup", type=int, default=3)
     p.add_argument("--scene", default="S")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-preprocess", action="store_true")
     p.add_argument("--cpu-scale", type=float, default=None)
     p.add_argument("--stages", default="all")
     return p.parse_args()
@@ -78,6 +79,60 @@ def cpu_baseline(scene, scale):
                       f"of SPT-64 fwd+loss+bwd on torch-CPU f32 via oracle/spt_model.py"}
 
 
+PRE_CFG = {  # configs/datamodule/semantic/{s3dis,dales}.yaml: voxel, knn k, knn r
+    "S": (0.03, 45, 2.0), "T": (0.03, 45, 2.0), "R": (0.03, 45, 2.0), "D": (0.10, 25, 10.0)}
+
+
+def preprocess_leg(scene, n_points, dev, reps=3):
+    """Preprocessing half of the metric: KNN (utils/neighbors.py:51-123) +
+    PointFeatures' geometric features (utils/geometry.py:80-126) on a synthetic
+    voxelised cloud of the scene's size, inputs resident in HBM."""
+    from superpoint_transformer_amd import neighbors as NB
+    from superpoint_transformer_amd.synthetic import make_voxel_cloud
+    voxel, k, r = PRE_CFG.get(scene, PRE_CFG["S"])
+    pos = make_voxel_cloud(n_points, voxel=voxel, seed=4321, device=dev)
+
+    def step():
+        nb, _ = NB.knn_1(pos, k, r)
+        return NB.geometric_features(pos, nb, k_min=1)
+
+    step()
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    t_knn = t_geof = 0.0
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ev[0].record()
+        nb, _ = NB.knn_1(pos, k, r)
+        ev[1].record()
+        NB.geometric_features(pos, nb, k_min=1)
+        ev[2].record()
+        torch.cuda.synchronize()
+        t_knn += ev[0].elapsed_time(ev[1])
+        t_geof += ev[1].elapsed_time(ev[2])
+    dt = (time.perf_counter() - t0) / reps
+    return {"value": round(n_points / dt / 1e6, 3), "unit": "Mpoints/s",
+            "workload": f"knn_1(k={k}, r={r}) + geometric_features on {n_points} synthetic "
+                        f"voxelised-surface points ({voxel} m lattice)",
+            "ms_knn": round(t_knn / reps, 3), "ms_geof": round(t_geof / reps, 3),
+            "ms_total": round(dt * 1e3, 3)}
+
+
+def cpu_preprocess_baseline(scene, n_sample=6000):
+    """Same leg through the CPU oracle (exhaustive kNN + torch-CPU eigenfeatures)."""
+    from oracle import spt_oracle as O
+    from superpoint_transformer_amd.synthetic import make_voxel_cloud
+    voxel, k, r = PRE_CFG.get(scene, PRE_CFG["S"])
+    pos = make_voxel_cloud(n_sample, voxel=voxel, seed=4321, device="cpu", extent=(6.0, 6.0, 3.0))
+    t0 = time.perf_counter()
+    nb, _ = O.knn_1(pos, k, r)
+    O.geometric_features(pos.double(), nb, k_min=1)
+    dt = time.perf_counter() - t0
+    return {"value": round(n_sample / dt / 1e6, 5), "unit": "Mpoints/s",
+            "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n_sample} points, exhaustive kNN + eigenfeatures via oracle/spt_oracle.py"}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -118,10 +173,19 @@ def main():
     n0 = nag.num_points[0]
     value = world * n0 * args.steps / dt / 1e6
     roof = path.roofline(HBM_PEAK_GBS)
+    workload = path.describe(args.scene, SCENES.get(args.scene))
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args.scene, args.cpu_scale)
+    pre = None
+    if rank == 0 and world == 1:
+        del path
+        torch.cuda.empty_cache()
+        if not args.no_preprocess:
+            pre = preprocess_leg(args.scene, n0, dev)
+        if not args.no_cpu_baseline:
+            cpu = cpu_baseline(args.scene, args.cpu_scale)
+            if pre is not None:
+                pre["cpu_baseline"] = cpu_preprocess_baseline(args.scene)
 
     if rank == 0:
         line = {
@@ -138,13 +202,14 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": path.describe(args.scene, SCENES.get(args.scene)),
+                "workload": workload,
                 "scene": args.scene,
                 "points_per_gpu": n0,
                 "parallelism": f"dp{world}",
             },
             "roofline": roof,
             "cpu_baseline": cpu,
+            "preprocess": pre,
         }
         print(json.dumps(line))
     if world > 1:

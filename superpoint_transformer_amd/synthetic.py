@@ -131,3 +131,30 @@ def make_nag(scene="S", seed=1234, device="cpu", sizes=None, point_dim=8,
              edge_index=ei2, edge_attr=rnd(ei2.shape[1], edge_dim, s=0.3)),
     ]
     return SyntheticNAG(levels, b)
+
+
+def make_voxel_cloud(n, voxel=0.03, seed=1234, device="cpu", patch=3.0, extent=(50.0, 50.0, 5.0)):
+    """Voxelised-surface point cloud for the preprocessing leg (kNN + geometric
+    features): axis-aligned planar patches of ``patch`` metres sampled on a
+    ``voxel`` lattice (what GridSampling3D leaves of walls / floors / roofs),
+    placed at random in ``extent``, rows shuffled.  Returns [n,3] f32."""
+    device = torch.device(device)
+    gen = torch.Generator(device=device).manual_seed(seed)
+    side = max(int(patch / voxel), 2)
+    per = side * side
+    npatch = (n + per - 1) // per
+    centers = torch.rand(npatch, 3, generator=gen, device=device) * \
+        torch.tensor(extent, device=device)
+    centers = (centers / voxel).round() * voxel          # patches live on the voxel lattice
+    normal = torch.randint(0, 3, (npatch,), generator=gen, device=device)
+    ij = torch.arange(per, device=device)
+    i = (ij // side).float() * voxel
+    j = (ij % side).float() * voxel
+    # in-plane axes for each normal direction
+    u_axis = torch.tensor([1, 0, 0], device=device)[normal]   # axis index of u
+    v_axis = torch.tensor([2, 2, 1], device=device)[normal]   # axis index of v
+    pos = centers.view(npatch, 1, 3).repeat(1, per, 1)
+    pos.scatter_add_(2, u_axis.view(-1, 1, 1).expand(npatch, per, 1), i.view(1, per, 1).expand(npatch, per, 1))
+    pos.scatter_add_(2, v_axis.view(-1, 1, 1).expand(npatch, per, 1), j.view(1, per, 1).expand(npatch, per, 1))
+    pos = pos.view(-1, 3)[:n]
+    return pos[torch.randperm(pos.shape[0], generator=gen, device=device)].contiguous()
