@@ -15,6 +15,7 @@
 // through the CSR-by-source view (erowptr / eperm), so the result is
 // deterministic (no atomics in the forward).
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.hpp"
 
@@ -723,6 +724,21 @@ static inline int per_lane(int total) { return total <= 64 ? 1 : (total <= 128 ?
 
 }  // namespace spt
 
+namespace spt {
+// edge_attn_mfma.hip: matrix-pipe formulation for the SPT-64 head layout
+bool attn_mfma_shape_ok(int H, int D, int Dv, int F, const void* ea, const void* Wk,
+                        const void* Wq, const void* Wv);
+void attn_fwd_mfma_launch(const float* qkv, int64_t n, const int32_t* erowptr,
+                          const int32_t* eperm, const int32_t* tgt, const float* ea,
+                          const float* Wk, const float* bk, const float* Wq, const float* bq,
+                          const float* Wv, const float* bv, int scale_mode, float scale_a,
+                          float* out, float* m, float* z, hipStream_t stream);
+static bool use_mfma() {
+  static const bool on = getenv("SPT_ATTN_VALU_ONLY") == nullptr;  // A/B switch for profiling
+  return on;
+}
+}  // namespace spt
+
 using namespace spt;
 
 #define SPT_ATTN_DISPATCH(FN, ...)                                             \
@@ -752,6 +768,12 @@ extern "C" int spt_edge_attn_fwd_f32(const float* qkv, int64_t n, int H, int D, 
   if (n == 0) return 0;
   SPT_CHECK_ARG(qkv && erowptr && out && (tgt_sorted || e == 0), "null pointer");
   SPT_CHECK_ARG((m == nullptr) == (z == nullptr), "pass both m and z or neither");
+  if (use_mfma() && attn_mfma_shape_ok(H, D, Dv, F, edge_attr, Wk, Wq, Wv)) {
+    attn_fwd_mfma_launch(qkv, n, erowptr, eperm, tgt_sorted, edge_attr, Wk, bk, Wq, bq, Wv, bv,
+                         scale_mode, scale_a, out, m, z, stream);
+    SPT_CHECK_LAUNCH();
+    return 0;
+  }
   if (!edge_attr) F = 32;  // no RPE: any compiled F will do
   const int qpl = per_lane(H * D), vpl = per_lane(H * Dv);
   const int ld = 2 * H * D + H * Dv;

@@ -1,0 +1,376 @@
+// MFMA formulation of the fused edge attention for the SPT-64 head layout
+// (H = 16 heads, qk_dim = 4, value dim = 4, in_rpe_dim = 32; the S3DIS / DALES
+// configs).  Same math and same results as edge_attn.hip, different mapping:
+//
+//   * a wave owns one source node and walks its edges in tiles of 16;
+//   * the three RPE projections of a tile are ONE [16 edges x 32] x [32 x 192]
+//     product on the matrix pipe: 96 x v_mfma_f32_16x16x4_f32 (f32 in, f32
+//     accumulate - bitwise an fmaf chain, so the f32 parity bar is unchanged),
+//     with the [32 x 192] weight block resident in 96 VGPRs as B operands;
+//   * everything after the GEMM happens in the MFMA C layout - lane (g, c),
+//     register r  <->  edge 4g + r, output column 16b + c - where a head is one
+//     DPP quad, so the per-head dot product is two v_add_f32_dpp, and the
+//     softmax / value accumulation costs ~12 VALU instructions per edge
+//     instead of ~150 in the lane-per-output VALU kernel;
+//   * tiles stream global -> LDS asynchronously (global_load_lds), edge_attr
+//     rows XOR-swizzled so that the A-operand reads are <= 2-way bank conflicts.
+//
+// The backward runs three GEMMs per tile on the same pipe: the recompute, the
+// RPE weight gradients  dW[192x32] += D^T[192x16] EA[16x32]  (A operand = the
+// C-layout registers as they are) and  d edge_attr[16x32] = D[16x192] W[192x32]
+// (D transposed through LDS).
+#include <math.h>
+
+#include "common.hpp"
+
+namespace spt {
+namespace mfma {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TE = 16;            // edges per tile = MFMA M
+constexpr int F = 32;             // in_rpe_dim
+constexpr int NB = 4;             // 16-column blocks per 64-wide projection
+constexpr int WAVES = 4;
+constexpr int EA_FLOATS = TE * F;         // 512
+constexpr int ROW = 64;                   // k / v row length
+constexpr int SLAB = EA_FLOATS + 2 * TE * ROW;  // 2560 floats = 10 KB
+
+#define SPT_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define SPT_GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+__device__ __forceinline__ float quad_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));
+  return v;
+}
+__device__ __forceinline__ float xg_sum(float v) {  // sum over the 4 lane groups g
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+__device__ __forceinline__ float xg_max(float v) {
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  v = fmaxf(v, __shfl_xor(v, 32, 64));
+  return v;
+}
+
+__device__ __forceinline__ float qk_scale_of(int mode, float a, int deg) {
+  const float g = 1.0f / sqrtf((float)deg);
+  if (mode == 0) return a * g;
+  if (mode == 1) return a + g;
+  return a;
+}
+
+struct Tile {
+  int64_t s;
+  int start, end, t0;
+  bool valid;
+};
+__device__ __forceinline__ Tile tile_of_node(int64_t s, int64_t N, const int32_t* __restrict__ rp) {
+  Tile d;
+  d.s = s;
+  d.valid = s < N;
+  d.start = d.valid ? __builtin_amdgcn_readfirstlane(rp[s]) : 0;
+  d.end = d.valid ? __builtin_amdgcn_readfirstlane(rp[s + 1]) : 0;
+  d.t0 = d.start;
+  return d;
+}
+__device__ __forceinline__ Tile tile_advance(const Tile& c, int64_t N, int64_t nw,
+                                             const int32_t* __restrict__ rp) {
+  if (c.valid && c.t0 + TE < c.end) {
+    Tile d = c;
+    d.t0 += TE;
+    return d;
+  }
+  return tile_of_node(c.s + nw, N, rp);
+}
+__device__ __forceinline__ int tile_count(const Tile& d) {
+  const int r = d.end - d.t0;
+  return r < TE ? (r > 0 ? r : 0) : TE;
+}
+__device__ __forceinline__ void wait_vmem_all() {
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Asynchronous loads of one tile: edge_attr rows (16-B chunks XOR-swizzled by the
+// row index), gathered k rows and v rows of the edge targets (4 rows / instruction).
+__device__ __forceinline__ void tile_issue(const float* __restrict__ qkv, int ld,
+                                           const float* __restrict__ ea, int e_lane,
+                                           int t_lane, int cnt, float* buf, int lane) {
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int u = p * 8 + (lane >> 3), ch = lane & 7;
+    const int e = __shfl(e_lane, u, 64);
+    if (u < cnt)
+      __builtin_amdgcn_global_load_lds(SPT_GLB_PTR(ea + (size_t)e * F + ((ch ^ (u & 7)) << 2)),
+                                       SPT_LDS_PTR(buf + p * 256), 16, 0, 0);
+  }
+  float* kbuf = buf + EA_FLOATS;
+  float* vbuf = kbuf + TE * ROW;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int u = i * 4 + (lane >> 4), ch = lane & 15;
+    const int64_t t = __shfl(t_lane, u, 64);
+    if (u < cnt) {
+      __builtin_amdgcn_global_load_lds(SPT_GLB_PTR(qkv + t * ld + 64 + ch * 4),
+                                       SPT_LDS_PTR(kbuf + i * 256), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(SPT_GLB_PTR(qkv + t * ld + 128 + ch * 4),
+                                       SPT_LDS_PTR(vbuf + i * 256), 16, 0, 0);
+    }
+  }
+}
+
+// B operands of the RPE GEMM: lane (g, c) holds W[16 b + c][4 step + g]
+__device__ __forceinline__ void load_b(const float* __restrict__ W, int g, int c,
+                                       float (&B)[NB][8]) {
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int st = 0; st < 8; ++st) B[b][st] = W[(size_t)(16 * b + c) * F + 4 * st + g];
+}
+
+// A operands of a tile: lane (g, c) holds ea[edge c][4 step + g] (un-swizzle on read)
+__device__ __forceinline__ void load_a(const float* slab, int g, int c, float (&A)[8]) {
+#pragma unroll
+  for (int st = 0; st < 8; ++st) A[st] = slab[c * F + ((st ^ (c & 7)) << 2) + g];
+}
+
+// C[b][r] starts at init[b] (bias / node term folded into the accumulator for free)
+__device__ __forceinline__ void rpe_gemm(const float (&A)[8], const float (&B)[NB][8],
+                                         const float (&init)[NB], f32x4 (&C)[NB]) {
+#pragma unroll
+  for (int b = 0; b < NB; ++b) C[b] = (f32x4){init[b], init[b], init[b], init[b]};
+#pragma unroll
+  for (int st = 0; st < 8; ++st)
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+      C[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[st], B[b][st], C[b], 0, 0, 0);
+}
+
+// Three-deep software pipeline over the tiles of a wave's nodes (s, s+nw, ...):
+//   cur : being computed out of LDS buffer b
+//   nxt : its edge_attr / k / v rows are streaming into buffer b^1
+//   nn  : its edge ids / targets and the CSR range of the node after it are in
+//         flight in VGPRs
+// so no load is ever waited for in the iteration that issued it.  Node ranges
+// travel through VMEM (lanes 0/1) rather than SMEM: an outstanding s_load would
+// be waited for by every LDS lgkmcnt(0) in between.
+struct Pipe {
+  Tile cur, nxt, nn;
+  int e_nxt, t_nxt, e_nn, t_nn;       // edge id / target held by lane u < cnt
+  float q_nxt[NB];                    // raw q row (columns 16 b + c) of nxt's node
+  int rp_ahead;                       // lane 0/1: CSR range of node(nn)+nw (or beyond)
+  int64_t s_ahead;                    // the node rp_ahead describes
+  int bsel;
+  int64_t nw, N;
+  const int32_t *rp, *eperm, *tgt;
+  const float *qkv, *ea;
+  int ld;
+  float* base;
+
+  __device__ __forceinline__ float* buf_at(int b) const { return base + b * SLAB; }
+  __device__ __forceinline__ const float* cur_buf() const { return buf_at(bsel); }
+  __device__ __forceinline__ void load_q(const Tile& d, int lane) {
+    if (d.valid && d.t0 == d.start) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) q_nxt[b] = qkv[d.s * ld + 16 * b + (lane & 15)];
+    }
+  }
+
+  __device__ __forceinline__ void load_idx(const Tile& d, int& e_l, int& t_l, int lane) {
+    e_l = 0;
+    t_l = 0;
+    if (d.valid && lane < tile_count(d)) {
+      e_l = eperm ? eperm[d.t0 + lane] : d.t0 + lane;
+      t_l = tgt[d.t0 + lane];
+    }
+  }
+  __device__ __forceinline__ void load_range(int64_t s, int lane) {
+    s_ahead = s;
+    rp_ahead = (s < N && lane < 2) ? rp[s + lane] : 0;
+  }
+  // next tile after d; crossing into node d.s+nw uses the prefetched range
+  __device__ __forceinline__ Tile advance(const Tile& d) {
+    if (d.valid && d.t0 + TE < d.end) {
+      Tile t = d;
+      t.t0 += TE;
+      return t;
+    }
+    Tile t;
+    t.s = d.s + nw;
+    t.valid = d.valid && t.s < N;
+    // (s_ahead == t.s by construction)
+    t.start = __builtin_amdgcn_readlane(rp_ahead, 0);   // SGPRs: the tile walk is scalar code
+    t.end = __builtin_amdgcn_readlane(rp_ahead, 1);
+    t.t0 = t.start;
+    return t;
+  }
+
+  __device__ __forceinline__ void init(int64_t wave, int64_t nwaves, int64_t n,
+                                       const int32_t* erowptr, const int32_t* ep,
+                                       const int32_t* tg, const float* qkv_, int ld_,
+                                       const float* ea_, float* b0, float* b1, int lane) {
+    nw = nwaves; N = n; rp = erowptr; eperm = ep; tgt = tg; qkv = qkv_; ld = ld_; ea = ea_;
+    base = b0; (void)b1; bsel = 0;
+    cur = tile_of_node(wave, N, rp);
+    int e_cur, t_cur;
+    load_idx(cur, e_cur, t_cur, lane);
+    load_range(wave + nw, lane);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) q_nxt[b] = 0.f;
+    load_q(cur, lane);   // the kernel reads q_nxt for the very first node
+    tile_issue(qkv, ld, ea, e_cur, t_cur, tile_count(cur), buf_at(0), lane);
+    nxt = advance(cur);
+    load_idx(nxt, e_nxt, t_nxt, lane);
+    if (nxt.valid && nxt.t0 == nxt.start) load_range(nxt.s + nw, lane);
+    // nn is produced by the first top()
+    nn = nxt;
+    e_nn = t_nn = 0;
+  }
+
+  // called when `cur` is about to be computed
+  __device__ __forceinline__ void top(int lane) {
+    wait_vmem_all();
+    if (nxt.valid) tile_issue(qkv, ld, ea, e_nxt, t_nxt, tile_count(nxt), buf_at(bsel ^ 1), lane);
+    load_q(nxt, lane);
+    nn = advance(nxt);
+    load_idx(nn, e_nn, t_nn, lane);
+    if (nn.valid && nn.t0 == nn.start) load_range(nn.s + nw, lane);
+  }
+  __device__ __forceinline__ void rotate() {
+    cur = nxt;
+    nxt = nn;
+    e_nxt = e_nn;
+    t_nxt = t_nn;
+    bsel ^= 1;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  }
+};
+
+__global__ __launch_bounds__(WAVES * 64, 2) void attn_fwd_mfma_kernel(
+    const float* __restrict__ qkv, int ld, int64_t N, const int32_t* __restrict__ erowptr,
+    const int32_t* __restrict__ eperm, const int32_t* __restrict__ tgt,
+    const float* __restrict__ ea, const float* __restrict__ Wk, const float* __restrict__ bk,
+    const float* __restrict__ Wq, const float* __restrict__ bq, const float* __restrict__ Wv,
+    const float* __restrict__ bv, int scale_mode, float scale_a, float* __restrict__ out,
+    float* __restrict__ mbuf, float* __restrict__ zbuf) {
+  __shared__ __attribute__((aligned(16))) float slab_all[WAVES][2][SLAB];
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, c = lane & 15;
+  float Bk[NB][8], Bq[NB][8], Bv[NB][8], bk4[NB], bq4[NB], bv4[NB];
+  load_b(Wk, g, c, Bk);
+  load_b(Wq, g, c, Bq);
+  load_b(Wv, g, c, Bv);
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    bk4[b] = bk ? bk[16 * b + c] : 0.f;
+    bq4[b] = bq ? bq[16 * b + c] : 0.f;
+    bv4[b] = bv ? bv[16 * b + c] : 0.f;
+  }
+  for (int i = lane; i < 2 * SLAB; i += 64) (&slab_all[wid][0][0])[i] = 0.f;  // stale rows stay finite
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+
+  const int64_t wave = (int64_t)blockIdx.x * WAVES + wid;
+  const int64_t nwaves = (int64_t)gridDim.x * WAVES;
+  if (wave >= N) return;
+  Pipe P;
+  P.init(wave, nwaves, N, erowptr, eperm, tgt, qkv, ld, ea, slab_all[wid][0], slab_all[wid][1], lane);
+
+  float qs4[NB], m[NB], z[NB], acc[NB];
+  while (P.cur.valid) {
+    wait_vmem_all();  // tile `cur`, nxt's indices and cur's q row have landed
+    float qraw[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) qraw[b] = P.q_nxt[b];
+    P.top(lane);      // issues nxt's data, nn's indices, nxt's q row, range prefetch
+    const Tile cur = P.cur;
+    const float* slab = P.cur_buf();
+    const float* kslab = slab + EA_FLOATS;
+    const float* vslab = kslab + TE * ROW;
+    const int cnt = tile_count(cur);
+    if (cur.t0 == cur.start) {
+      const int deg = cur.end - cur.start;
+      const float scale = deg > 0 ? qk_scale_of(scale_mode, scale_a, deg) : 0.f;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        qs4[b] = fmaf(qraw[b], scale, bq4[b]);  // q_s*scale + bq
+        m[b] = -INFINITY;
+        z[b] = 0.f;
+        acc[b] = 0.f;
+      }
+    }
+    if (cnt > 0) {
+      float A[8];
+      load_a(slab, g, c, A);
+      f32x4 Ck[NB], Cq[NB], Cv[NB];
+      rpe_gemm(A, Bk, bk4, Ck);        // k_e - k_t   = Wk ea + bk
+      rpe_gemm(A, Bq, qs4, Cq);        // q_e         = Wq ea + bq + q_s scale
+      rpe_gemm(A, Bv, bv4, Cv);        // v_e - v_t   = Wv ea + bv
+      const bool partial = cnt < TE;   // wave-uniform
+      const float* kp = kslab + 4 * g * ROW + c;
+      const float* vp = vslab + 4 * g * ROW + c;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        float p[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p[r] = quad_sum(Cq[b][r] * (Ck[b][r] + kp[r * ROW + 16 * b]));
+        if (partial) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) p[r] = (4 * g + r < cnt) ? p[r] : -INFINITY;
+        }
+        const float mt = xg_max(fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3])));  // tile max of this head
+        const float mn = fmaxf(m[b], mt);
+        const float corr = __expf(m[b] - mn);  // m = -inf on the first tile -> 0
+        float zs = 0.f, as = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pe = __expf(p[r] - mn);  // rows beyond cnt: exp(-inf) = 0
+          zs += pe;
+          as = fmaf(pe, Cv[b][r] + vp[r * ROW + 16 * b], as);
+        }
+        // z / acc stay per-lane-group partial sums until the node ends
+        z[b] = fmaf(z[b], corr, zs);
+        acc[b] = fmaf(acc[b], corr, as);
+        m[b] = mn;
+      }
+    }
+    if (cur.t0 + TE >= cur.end) {  // last tile of the node
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const float zt = xg_sum(z[b]);
+        const float at = xg_sum(acc[b]);
+        if (g == 0) out[cur.s * 64 + 16 * b + c] = at / (zt + 1e-16f);
+        if (g == 0 && (c & 3) == 0 && mbuf) {
+          mbuf[cur.s * 16 + 4 * b + (c >> 2)] = m[b];
+          zbuf[cur.s * 16 + 4 * b + (c >> 2)] = zt;
+        }
+      }
+    }
+    P.rotate();
+  }
+}
+
+}  // namespace mfma
+
+// ---- launchers called from edge_attn.hip's C entry points --------------------
+bool attn_mfma_shape_ok(int H, int D, int Dv, int F, const void* ea, const void* Wk,
+                        const void* Wq, const void* Wv) {
+  return H == 16 && D == 4 && Dv == 4 && F == 32 && ea && Wk && Wq && Wv;
+}
+
+void attn_fwd_mfma_launch(const float* qkv, int64_t n, const int32_t* erowptr,
+                          const int32_t* eperm, const int32_t* tgt, const float* ea,
+                          const float* Wk, const float* bk, const float* Wq, const float* bq,
+                          const float* Wv, const float* bv, int scale_mode, float scale_a,
+                          float* out, float* m, float* z, hipStream_t stream) {
+  const int64_t blocks = ceil_div(n, mfma::WAVES);
+  const int grid = (int)(blocks < 256 * 2 * 4 ? blocks : 256 * 2 * 4);
+  mfma::attn_fwd_mfma_kernel<<<grid, mfma::WAVES * 64, 0, stream>>>(
+      qkv, 192, n, erowptr, eperm, tgt, ea, Wk, bk, Wq, bq, Wv, bv, scale_mode, scale_a, out, m, z);
+}
+
+}  // namespace spt
