@@ -733,6 +733,12 @@ void attn_fwd_mfma_launch(const float* qkv, int64_t n, const int32_t* erowptr,
                           const float* Wk, const float* bk, const float* Wq, const float* bq,
                           const float* Wv, const float* bv, int scale_mode, float scale_a,
                           float* out, float* m, float* z, hipStream_t stream);
+int attn_bwd_mfma_launch(const float* qkv, int64_t n, const int32_t* erowptr,
+                         const int32_t* eperm, const int32_t* tgt, const float* ea,
+                         const float* Wk, const float* bk, const float* Wq, const float* bq,
+                         const float* Wv, const float* bv, int scale_mode, float scale_a,
+                         const float* out, const float* m, const float* z, const float* gout,
+                         float* gqkv, float* gea, float* partial, hipStream_t stream);
 static bool use_mfma() {
   static const bool on = getenv("SPT_ATTN_VALU_ONLY") == nullptr;  // A/B switch for profiling
   return on;
@@ -829,6 +835,17 @@ extern "C" int spt_edge_attn_bwd_f32(const float* qkv, int64_t n, int H, int D, 
   const int grid = (int)(ceil_div(n, EA_WAVES) < EA_BWD_BLOCKS ? ceil_div(n, EA_WAVES) : EA_BWD_BLOCKS);
   // k / v columns of gqkv receive atomics: start from zero (q columns are overwritten)
   hipMemsetAsync(gqkv, 0, (size_t)n * ld * 4, stream);
+  if (use_mfma() && attn_mfma_shape_ok(H, D, Dv, F, edge_attr, Wk, Wq, Wv)) {
+    const int ntab = attn_bwd_mfma_launch(qkv, n, erowptr, eperm, tgt_sorted, edge_attr, Wk, bk,
+                                          Wq, bq, Wv, bv, scale_mode, scale_a, out, m, z, gout,
+                                          gqkv, gedge_attr, partial, stream);
+    attn_reduce_partials_kernel<<<(int)ceil_div((int64_t)len, 64), 256, 0, stream>>>(
+        partial, ntab, (int)len, total);
+    attn_unpack_grads_kernel<<<(int)ceil_div((int64_t)len, 256), 256, 0, stream>>>(
+        total, H * D, H * Dv, F, gWk, gbk, gWq, gbq, gWv, gbv);
+    SPT_CHECK_LAUNCH();
+    return 0;
+  }
 #define SPT_ATTN_CASE(FN, Q, V, FF, ...)                                        \
   if (!done__ && qpl == Q && vpl == V && F == FF) {                            \
     AttnShape sh;                                                              \

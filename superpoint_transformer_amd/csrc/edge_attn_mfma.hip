@@ -159,7 +159,7 @@ __device__ __forceinline__ void rpe_gemm(const float (&A)[8], const float (&B)[N
 // be waited for by every LDS lgkmcnt(0) in between.
 struct Pipe {
   Tile cur, nxt, nn;
-  int e_nxt, t_nxt, e_nn, t_nn;       // edge id / target held by lane u < cnt
+  int e_cur, t_cur, e_nxt, t_nxt, e_nn, t_nn;  // edge id / target held by lane u < cnt
   float q_nxt[NB];                    // raw q row (columns 16 b + c) of nxt's node
   int rp_ahead;                       // lane 0/1: CSR range of node(nn)+nw (or beyond)
   int64_t s_ahead;                    // the node rp_ahead describes
@@ -215,7 +215,6 @@ struct Pipe {
     nw = nwaves; N = n; rp = erowptr; eperm = ep; tgt = tg; qkv = qkv_; ld = ld_; ea = ea_;
     base = b0; (void)b1; bsel = 0;
     cur = tile_of_node(wave, N, rp);
-    int e_cur, t_cur;
     load_idx(cur, e_cur, t_cur, lane);
     load_range(wave + nw, lane);
 #pragma unroll
@@ -242,6 +241,8 @@ struct Pipe {
   __device__ __forceinline__ void rotate() {
     cur = nxt;
     nxt = nn;
+    e_cur = e_nxt;
+    t_cur = t_nxt;
     e_nxt = e_nn;
     t_nxt = t_nn;
     bsel ^= 1;
@@ -354,6 +355,210 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_fwd_mfma_kernel(
   }
 }
 
+// ---- backward ------------------------------------------------------------------
+constexpr int DT_STRIDE = 196;                 // transposed D tile: [16 edges][192 (+4 pad)]
+constexpr int DT_FLOATS = TE * DT_STRIDE;      // 3136 floats = 12.25 KB
+
+constexpr int W_FLOATS = 192 * F;   // [Wk; Wq; Wv] rows, shared by the 4 waves (B operands of D W)
+
+__global__ __launch_bounds__(WAVES * 64, 1) void attn_bwd_mfma_kernel(
+    const float* __restrict__ qkv, int ld, int64_t N, const int32_t* __restrict__ erowptr,
+    const int32_t* __restrict__ eperm, const int32_t* __restrict__ tgt,
+    const float* __restrict__ ea, const float* __restrict__ Wk, const float* __restrict__ bk,
+    const float* __restrict__ Wq, const float* __restrict__ bq, const float* __restrict__ Wv,
+    const float* __restrict__ bv, int scale_mode, float scale_a, const float* __restrict__ out,
+    const float* __restrict__ mbuf, const float* __restrict__ zbuf,
+    const float* __restrict__ gout, float* __restrict__ gqkv, float* __restrict__ gea,
+    float* __restrict__ partial) {
+  __shared__ __attribute__((aligned(16))) float slab_all[WAVES][2][SLAB];
+  __shared__ __attribute__((aligned(16))) float dt_all[WAVES][DT_FLOATS];
+  __shared__ __attribute__((aligned(16))) float w_lds[W_FLOATS];
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, c = lane & 15;
+  float* dt = dt_all[wid];
+  for (int i = threadIdx.x; i < 64 * F; i += WAVES * 64) {
+    w_lds[i] = Wk[i];
+    w_lds[64 * F + i] = Wq[i];
+    w_lds[128 * F + i] = Wv[i];
+  }
+  __syncthreads();
+
+  float Bk[NB][8], Bq[NB][8], Bv[NB][8], bk4[NB], bq4[NB], bv4[NB];
+  load_b(Wk, g, c, Bk);
+  load_b(Wq, g, c, Bq);
+  load_b(Wv, g, c, Bv);
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    bk4[b] = bk ? bk[16 * b + c] : 0.f;
+    bq4[b] = bq ? bq[16 * b + c] : 0.f;
+    bv4[b] = bv ? bv[16 * b + c] : 0.f;
+  }
+  // weight-gradient accumulators: C3[ob][fb][r] = dW[16 ob + 4 g + r][16 fb + c]
+  f32x4 C3[3 * NB][2];
+  float gb[3 * NB];   // bias gradients, per-lane-group partials for o = 16 ob + c
+#pragma unroll
+  for (int ob = 0; ob < 3 * NB; ++ob) {
+    C3[ob][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    C3[ob][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    gb[ob] = 0.f;
+  }
+  for (int i = lane; i < 2 * SLAB; i += 64) (&slab_all[wid][0][0])[i] = 0.f;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+
+  const int64_t wave = (int64_t)blockIdx.x * WAVES + wid;
+  const int64_t nwaves = (int64_t)gridDim.x * WAVES;
+  if (wave < N) {
+    Pipe P;
+    P.init(wave, nwaves, N, erowptr, eperm, tgt, qkv, ld, ea, slab_all[wid][0], slab_all[wid][1],
+           lane);
+    float qs4[NB], m[NB], zi[NB], delta[NB], g4[NB], dqa[NB];
+    float scale = 0.f;
+    while (P.cur.valid) {
+      wait_vmem_all();
+      float qraw[NB];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) qraw[b] = P.q_nxt[b];
+      const int e_cur = P.e_cur, t_cur = P.t_cur;
+      P.top(lane);
+      const Tile cur = P.cur;
+      const float* slab = P.cur_buf();
+      const float* kslab = slab + EA_FLOATS;
+      const float* vslab = kslab + TE * ROW;
+      const int cnt = tile_count(cur);
+      const int64_t s = cur.s;
+      if (cur.t0 == cur.start) {  // first tile of the node
+        const int deg = cur.end - cur.start;
+        scale = deg > 0 ? qk_scale_of(scale_mode, scale_a, deg) : 0.f;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          qs4[b] = fmaf(qraw[b], scale, bq4[b]);
+          dqa[b] = 0.f;
+          g4[b] = gout[s * 64 + 16 * b + c];
+          delta[b] = quad_sum(g4[b] * out[s * 64 + 16 * b + c]);   // <g, out> per head
+          m[b] = mbuf[s * 16 + 4 * b + (c >> 2)];
+          zi[b] = 1.0f / (zbuf[s * 16 + 4 * b + (c >> 2)] + 1e-16f);
+        }
+      }
+      if (cnt > 0) {
+        float A[8];
+        load_a(slab, g, c, A);
+        f32x4 Ck[NB], Cq[NB], Cv[NB];
+        rpe_gemm(A, Bk, bk4, Ck);
+        rpe_gemm(A, Bq, qs4, Cq);
+        rpe_gemm(A, Bv, bv4, Cv);
+        const float* kp = kslab + 4 * g * ROW + c;
+        const float* vp = vslab + 4 * g * ROW + c;
+        int64_t trow[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) trow[r] = (int64_t)__shfl(t_cur, 4 * g + r, 64) * ld;
+        // ---- per-edge gradients, in place: Ck <- dk, Cq <- dq, Cv <- dv ------------
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const bool valid = 4 * g + r < cnt;
+            const float k = Ck[b][r] + kp[r * ROW + 16 * b];
+            const float q = Cq[b][r];
+            const float v = Cv[b][r] + vp[r * ROW + 16 * b];
+            const float p = quad_sum(q * k);
+            const float a = valid ? __expf(p - m[b]) * zi[b] : 0.f;
+            const float da = quad_sum(g4[b] * v);
+            const float dc = a * (da - delta[b]);
+            const float dk = dc * q, dq = dc * k, dv = a * g4[b];
+            Ck[b][r] = dk;
+            Cq[b][r] = dq;
+            Cv[b][r] = dv;
+            dqa[b] += dq;
+            gb[b] += dk;
+            gb[NB + b] += dq;
+            gb[2 * NB + b] += dv;
+            if (valid) {
+              unsafeAtomicAdd(gqkv + trow[r] + 64 + 16 * b + c, dk);
+              unsafeAtomicAdd(gqkv + trow[r] + 128 + 16 * b + c, dv);
+            }
+          }
+        }
+        // ---- dW += D^T EA : A operand = the C-layout registers as they are ----------
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float eb[2];
+#pragma unroll
+          for (int fb = 0; fb < 2; ++fb) {
+            const int e = 4 * g + r, f = 16 * fb + c;
+            eb[fb] = slab[e * F + (((f >> 2) ^ (e & 7)) << 2) + (f & 3)];
+          }
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+#pragma unroll
+            for (int fb = 0; fb < 2; ++fb) {
+              C3[b][fb] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ck[b][r], eb[fb], C3[b][fb], 0, 0, 0);
+              C3[NB + b][fb] = __builtin_amdgcn_mfma_f32_16x16x4f32(Cq[b][r], eb[fb], C3[NB + b][fb], 0, 0, 0);
+              C3[2 * NB + b][fb] = __builtin_amdgcn_mfma_f32_16x16x4f32(Cv[b][r], eb[fb], C3[2 * NB + b][fb], 0, 0, 0);
+            }
+          }
+        }
+        // ---- d edge_attr = D W : D transposed through LDS ---------------------------
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float* row = dt + (4 * g + r) * DT_STRIDE + 16 * b + c;
+            row[0] = Ck[b][r];
+            row[64] = Cq[b][r];
+            row[128] = Cv[b][r];
+          }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        f32x4 C2[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+        const float* arow = dt + c * DT_STRIDE + g;       // A[i = edge c][k = 4 st + g]
+        const float* brow = w_lds + g * F + c;            // B[k = 4 st + g][j = 16 fb + c]
+#pragma unroll 8
+        for (int st = 0; st < 48; ++st) {
+          const float a = arow[4 * st];
+          const float b0 = brow[4 * st * F], b1 = brow[4 * st * F + 16];
+          C2[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0, C2[0], 0, 0, 0);
+          C2[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1, C2[1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t e = __shfl(e_cur, 4 * g + r, 64);
+          if (4 * g + r < cnt) {
+            gea[e * F + c] = C2[0][r];
+            gea[e * F + 16 + c] = C2[1][r];
+          }
+        }
+      }
+      if (cur.t0 + TE >= cur.end) {  // last tile of the node
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const float dq = xg_sum(dqa[b]);
+          if (g == 0) gqkv[s * ld + 16 * b + c] = dq * scale;
+        }
+      }
+      P.rotate();
+    }
+  }
+  // per-wave partial tables [192 rows][F + 1]: weight block + bias column
+  if (partial) {
+    float* pw = partial + (size_t)wave * 192 * (F + 1);
+#pragma unroll
+    for (int ob = 0; ob < 3 * NB; ++ob) {
+#pragma unroll
+      for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          pw[(size_t)(16 * ob + 4 * g + r) * (F + 1) + 16 * fb + c] = C3[ob][fb][r];
+      const float bsum = xg_sum(gb[ob]);
+      if (g == 0) pw[(size_t)(16 * ob + c) * (F + 1) + F] = bsum;
+    }
+  }
+}
+
 }  // namespace mfma
 
 // ---- launchers called from edge_attn.hip's C entry points --------------------
@@ -371,6 +576,22 @@ void attn_fwd_mfma_launch(const float* qkv, int64_t n, const int32_t* erowptr,
   const int grid = (int)(blocks < 256 * 2 * 4 ? blocks : 256 * 2 * 4);
   mfma::attn_fwd_mfma_kernel<<<grid, mfma::WAVES * 64, 0, stream>>>(
       qkv, 192, n, erowptr, eperm, tgt, ea, Wk, bk, Wq, bq, Wv, bv, scale_mode, scale_a, out, m, z);
+}
+
+constexpr int ATTN_BWD_MFMA_BLOCKS = 256;  // one 4-wave workgroup per CU (1 wave / SIMD)
+
+int attn_bwd_mfma_launch(const float* qkv, int64_t n, const int32_t* erowptr,
+                         const int32_t* eperm, const int32_t* tgt, const float* ea,
+                         const float* Wk, const float* bk, const float* Wq, const float* bq,
+                         const float* Wv, const float* bv, int scale_mode, float scale_a,
+                         const float* out, const float* m, const float* z, const float* gout,
+                         float* gqkv, float* gea, float* partial, hipStream_t stream) {
+  const int64_t blocks = ceil_div(n, mfma::WAVES);
+  const int grid = (int)(blocks < ATTN_BWD_MFMA_BLOCKS ? blocks : ATTN_BWD_MFMA_BLOCKS);
+  mfma::attn_bwd_mfma_kernel<<<grid, mfma::WAVES * 64, 0, stream>>>(
+      qkv, 192, n, erowptr, eperm, tgt, ea, Wk, bk, Wq, bq, Wv, bv, scale_mode, scale_a, out, m, z,
+      gout, gqkv, gea, partial);
+  return grid * mfma::WAVES;  // number of partial tables written
 }
 
 }  // namespace spt
