@@ -174,8 +174,26 @@ __device__ __forceinline__ int tile_count(const TileDesc& d) {
 }
 
 __device__ __forceinline__ void wait_vmem_all() {
-  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), leave expcnt / lgkmcnt alone
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// LDS-DMA through inline asm: the compiler's waitcnt pass puts a vmcnt(0) in front
+// of EVERY later LDS read once it has seen a global_load_lds builtin (it cannot
+// tell the two ping-pong buffers apart), which turns the prefetch synchronous.
+// Issued as asm, the DMA is invisible to that pass; this file waits explicitly
+// (wait_vmem_all) before the first read of a freshly filled buffer.
+__device__ __forceinline__ void lds_dma16(const float* g, float* lds) {
+  const unsigned a = __builtin_amdgcn_readfirstlane(
+      (unsigned)(size_t)((__attribute__((address_space(3))) void*)lds));
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+               :: "s"(a), "v"(g) : "memory");
+}
+__device__ __forceinline__ void lds_dma4(const float* g, float* lds) {
+  const unsigned a = __builtin_amdgcn_readfirstlane(
+      (unsigned)(size_t)((__attribute__((address_space(3))) void*)lds));
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off"
+               :: "s"(a), "v"(g) : "memory");
 }
 
 #define SPT_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
@@ -200,8 +218,7 @@ __device__ __forceinline__ void tile_issue(const float* __restrict__ qkv, int ld
         const int u = q / CH, ch = q - u * CH;
         const int e = __shfl(e_lane, u < EA_TE ? u : 0, 64);
         if (q < TOT && u < cnt)
-          __builtin_amdgcn_global_load_lds(SPT_GLB_PTR(ea + (size_t)e * F + ch * 4),
-                                           SPT_LDS_PTR(buf + p * 256), 16, 0, 0);
+          lds_dma16(ea + (size_t)e * F + ch * 4, buf + p * 256);
       }
     } else {
       constexpr int TOT = EA_TE * F;
@@ -211,8 +228,7 @@ __device__ __forceinline__ void tile_issue(const float* __restrict__ qkv, int ld
         const int u = q / F, f = q - u * F;
         const int e = __shfl(e_lane, u < EA_TE ? u : 0, 64);
         if (q < TOT && u < cnt)
-          __builtin_amdgcn_global_load_lds(SPT_GLB_PTR(ea + (size_t)e * F + f),
-                                           SPT_LDS_PTR(buf + p * 64), 4, 0, 0);
+          lds_dma4(ea + (size_t)e * F + f, buf + p * 64);
       }
     }
   }
@@ -223,13 +239,11 @@ __device__ __forceinline__ void tile_issue(const float* __restrict__ qkv, int ld
 #pragma unroll
       for (int i = 0; i < QPL; ++i)
         if (qv)
-          __builtin_amdgcn_global_load_lds(SPT_GLB_PTR(qkv + t * ld + sh.QK + j0 + i),
-                                           SPT_LDS_PTR(kbuf + u * KROW + i * 64), 4, 0, 0);
+          lds_dma4(qkv + t * ld + sh.QK + j0 + i, kbuf + u * KROW + i * 64);
 #pragma unroll
       for (int i = 0; i < VPL; ++i)
         if (vv)
-          __builtin_amdgcn_global_load_lds(SPT_GLB_PTR(qkv + t * ld + 2 * sh.QK + c0 + i),
-                                           SPT_LDS_PTR(vbuf + u * VROW + i * 64), 4, 0, 0);
+          lds_dma4(qkv + t * ld + 2 * sh.QK + c0 + i, vbuf + u * VROW + i * 64);
     }
   }
 }

@@ -90,8 +90,26 @@ __device__ __forceinline__ int tile_count(const Tile& d) {
   return r < TE ? (r > 0 ? r : 0) : TE;
 }
 __device__ __forceinline__ void wait_vmem_all() {
-  __builtin_amdgcn_s_waitcnt(0x0F70);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// LDS-DMA through inline asm: the compiler's waitcnt pass puts a vmcnt(0) in front
+// of EVERY later LDS read once it has seen a global_load_lds builtin (it cannot
+// tell the two ping-pong buffers apart), which turns the prefetch synchronous.
+// Issued as asm, the DMA is invisible to that pass; this file waits explicitly
+// (wait_vmem_all) before the first read of a freshly filled buffer.
+__device__ __forceinline__ void lds_dma16(const float* g, float* lds) {
+  const unsigned a = __builtin_amdgcn_readfirstlane(
+      (unsigned)(size_t)((__attribute__((address_space(3))) void*)lds));
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+               :: "s"(a), "v"(g) : "memory");
+}
+__device__ __forceinline__ void lds_dma4(const float* g, float* lds) {
+  const unsigned a = __builtin_amdgcn_readfirstlane(
+      (unsigned)(size_t)((__attribute__((address_space(3))) void*)lds));
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off"
+               :: "s"(a), "v"(g) : "memory");
 }
 
 // Asynchronous loads of one tile: edge_attr rows (16-B chunks XOR-swizzled by the
@@ -104,8 +122,7 @@ __device__ __forceinline__ void tile_issue(const float* __restrict__ qkv, int ld
     const int u = p * 8 + (lane >> 3), ch = lane & 7;
     const int e = __shfl(e_lane, u, 64);
     if (u < cnt)
-      __builtin_amdgcn_global_load_lds(SPT_GLB_PTR(ea + (size_t)e * F + ((ch ^ (u & 7)) << 2)),
-                                       SPT_LDS_PTR(buf + p * 256), 16, 0, 0);
+      lds_dma16(ea + (size_t)e * F + ((ch ^ (u & 7)) << 2), buf + p * 256);
   }
   float* kbuf = buf + EA_FLOATS;
   float* vbuf = kbuf + TE * ROW;
@@ -114,10 +131,8 @@ __device__ __forceinline__ void tile_issue(const float* __restrict__ qkv, int ld
     const int u = i * 4 + (lane >> 4), ch = lane & 15;
     const int64_t t = __shfl(t_lane, u, 64);
     if (u < cnt) {
-      __builtin_amdgcn_global_load_lds(SPT_GLB_PTR(qkv + t * ld + 64 + ch * 4),
-                                       SPT_LDS_PTR(kbuf + i * 256), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(SPT_GLB_PTR(qkv + t * ld + 128 + ch * 4),
-                                       SPT_LDS_PTR(vbuf + i * 256), 16, 0, 0);
+      lds_dma16(qkv + t * ld + 64 + ch * 4, kbuf + i * 256);
+      lds_dma16(qkv + t * ld + 128 + ch * 4, vbuf + i * 256);
     }
   }
 }
@@ -480,26 +495,8 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attn_bwd_mfma_kernel(
             }
           }
         }
-        // ---- dW += D^T EA : A operand = the C-layout registers as they are ----------
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float eb[2];
-#pragma unroll
-          for (int fb = 0; fb < 2; ++fb) {
-            const int e = 4 * g + r, f = 16 * fb + c;
-            eb[fb] = slab[e * F + (((f >> 2) ^ (e & 7)) << 2) + (f & 3)];
-          }
-#pragma unroll
-          for (int b = 0; b < NB; ++b) {
-#pragma unroll
-            for (int fb = 0; fb < 2; ++fb) {
-              C3[b][fb] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ck[b][r], eb[fb], C3[b][fb], 0, 0, 0);
-              C3[NB + b][fb] = __builtin_amdgcn_mfma_f32_16x16x4f32(Cq[b][r], eb[fb], C3[NB + b][fb], 0, 0, 0);
-              C3[2 * NB + b][fb] = __builtin_amdgcn_mfma_f32_16x16x4f32(Cv[b][r], eb[fb], C3[2 * NB + b][fb], 0, 0, 0);
-            }
-          }
-        }
-        // ---- d edge_attr = D W : D transposed through LDS ---------------------------
+        // ---- d edge_attr = D W : D transposed through LDS (before dW: its stores and the
+        //      atomics above then drain under the 96 MFMAs of the weight-gradient GEMM) ----
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -530,6 +527,25 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attn_bwd_mfma_kernel(
           if (4 * g + r < cnt) {
             gea[e * F + c] = C2[0][r];
             gea[e * F + 16 + c] = C2[1][r];
+          }
+        }
+        // ---- dW += D^T EA : A operand = the C-layout registers as they are ----------
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float eb[2];
+#pragma unroll
+          for (int fb = 0; fb < 2; ++fb) {
+            const int e = 4 * g + r, f = 16 * fb + c;
+            eb[fb] = slab[e * F + (((f >> 2) ^ (e & 7)) << 2) + (f & 3)];
+          }
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+#pragma unroll
+            for (int fb = 0; fb < 2; ++fb) {
+              C3[b][fb] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ck[b][r], eb[fb], C3[b][fb], 0, 0, 0);
+              C3[NB + b][fb] = __builtin_amdgcn_mfma_f32_16x16x4f32(Cq[b][r], eb[fb], C3[NB + b][fb], 0, 0, 0);
+              C3[2 * NB + b][fb] = __builtin_amdgcn_mfma_f32_16x16x4f32(Cv[b][r], eb[fb], C3[2 * NB + b][fb], 0, 0, 0);
+            }
           }
         }
       }
