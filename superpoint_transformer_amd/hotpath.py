@@ -37,6 +37,21 @@ def spt64_config(point_in=8, edge_in=18):
         fusion="cat", output_stage_wise=True)
 
 
+def _pmc_traffic(timer_name):
+    """HBM bytes per launch of the roofline kernel as measured with rocprofv3 PMC
+    counters on this exact shape (profiles/traffic.json; FETCH_SIZE doubled per
+    MI355X_MICROARCH.md's gfx950 correction).  None when no capture exists."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                        "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(timer_name, {}).get("bytes")
+    except (OSError, ValueError):
+        return None
+
+
 class SPTSegmenter(nn.Module):
     """SPT backbone + one Classifier per output level (semantic.py:291-294)."""
 
@@ -113,7 +128,7 @@ class SPTTrainStep:
         return {"bound": "hbm", "kernel": "segcsr_reduce_kernel<MAX,VEC4,ARG> L0->L1 C=128",
                 "achieved": round(ach, 1) if ach else None, "peak": peak_gbs,
                 "unit": "GB/s", "frac": round(ach / peak_gbs, 4) if ach else None,
-                "traffic": None, "bytes_per_launch": bytes_,
+                "traffic": _pmc_traffic(self.tname), "bytes_per_launch": bytes_,
                 "ms_per_launch": round(ms, 4) if ms else None}
 
     def describe(self, scene, sizes):

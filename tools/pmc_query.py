@@ -16,7 +16,7 @@ for f in files:
     if not (kname and cname and vname):
         print("counters_collection columns:", cols)
         continue
-    q = (f"select {kname}, {cname}, avg({vname}), count(*) from counters_collection "
+    q = (f"select {kname}, {cname}, avg({vname}), count(*), max({vname}) from counters_collection "
          f"where {kname} like ? group by substr({kname},1,60), {cname}")
     for r in c.execute(q, (pat,)):
-        print(f"{r[0][:48]:48s} {r[1]:28s} {r[2]:18.1f}  n={r[3]}")
+        print(f"{r[0][:48]:48s} {r[1]:28s} avg {r[2]:16.1f}  max {r[4]:16.1f}  n={r[3]}")
