@@ -239,6 +239,23 @@ int spt_point_geof_csr_f32(const float* xyz, int64_t n, const int64_t* nn_val,
                            const int64_t* nn_ptr, int add_self, int k_min, int post,
                            float* feats, spt_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * On-the-fly horizontal edge features + symmetrisation + self loops   (f1)
+ * Replaces _on_the_fly_horizontal_edge_features (src/transforms/graph.py:1135-1277,
+ * all default keys) followed by NAGAddSelfLoops (:1419-1452).
+ *   se [2,e] int64 trimmed edges (row-major: sources then targets);
+ *   edge_attr7 [e,7] f32 = [mean_off(3), std_off(3), mean_dist];
+ *   pos, normal [n,3]; log_length / log_surface / log_volume / log_size [n];
+ *   edge_index_out [2, 2e (+n)] int64 = [(s,t) | (t,s) | (i,i)];
+ *   edge_attr_out [2e (+n), 18] f32 in the reference's f_list column order;
+ *   self-loop rows are zero.
+ * ---------------------------------------------------------------------- */
+int spt_horizontal_edge_features_f32(
+    const int64_t* se, int64_t e, int64_t n, const float* edge_attr7, const float* pos,
+    const float* normal, const float* log_length, const float* log_surface,
+    const float* log_volume, const float* log_size, int add_self_loops,
+    int64_t* edge_index_out, float* edge_attr_out, spt_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

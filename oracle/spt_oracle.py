@@ -459,3 +459,53 @@ def geometric_features(xyz, nn, k_min=1, add_self_as_neighbor=True):
     flip = f[:, 6] < 0                                         # geometry.py:124
     f[flip, 4:7] *= -1
     return f
+
+
+# --------------------------------------------------------------------------
+# on-the-fly horizontal edge features + self loops
+# --------------------------------------------------------------------------
+
+
+def horizontal_edge_features(se, edge_attr7, pos, normal, log_length, log_surface,
+                             log_volume, log_size, add_self_loops=True):
+    """src/transforms/graph.py:1135-1277 (all default keys, in f_list order)
+    followed by NAGAddSelfLoops :1419-1452 (zero-feature loops appended)."""
+    ea = edge_attr7.to(pos.dtype)
+    s, t = se[0], se[1]
+    mean_off = ea[:, :3]
+    direction = mean_off / mean_off.norm(dim=1).view(-1, 1)           # graph.py:1203
+    direction = torch.where(direction.isnan(), torch.zeros_like(direction), direction)
+    direction = direction.clip(-1, 1)
+    cols_a, cols_b = [mean_off], [-mean_off]                           # graph.py:1210-1214
+
+    def both(f):
+        cols_a.append(f)
+        cols_b.append(f)
+
+    def anti(f):
+        cols_a.append(f)
+        cols_b.append(-f)
+
+    both(ea[:, 3:6])                                                   # std_off
+    both(ea[:, 6:7])                                                   # mean_dist
+    both((direction * normal[s]).sum(1).abs().view(-1, 1))             # angle_source
+    both((direction * normal[t]).sum(1).abs().view(-1, 1))             # angle_target
+    both((normal[s] * normal[t]).sum(1).abs().view(-1, 1))             # normal_angle
+    for a in (log_length, log_surface, log_volume, log_size):          # graph.py:1231-1245
+        a = a.view(-1)
+        anti((a[s] - a[t]).view(-1, 1))
+    cdir = pos[t] - pos[s]                                             # graph.py:1250-1257
+    cdist = cdir.norm(dim=1).view(-1, 1)
+    cdir = cdir / cdist
+    cdist = cdist.sqrt()
+    cdir = torch.where(cdir.isnan(), torch.zeros_like(cdir), cdir).clip(-1, 1)
+    anti(cdir)
+    both(cdist)
+    attr = torch.cat((torch.cat(cols_a, 1), torch.cat(cols_b, 1)), 0)
+    ei = torch.cat((se, se.flip(0)), dim=1)                            # graph.py:1268
+    if add_self_loops:                                                 # graph.py:1442-1446
+        n = pos.shape[0]
+        loops = torch.arange(n)
+        ei = torch.cat((ei, torch.stack((loops, loops))), dim=1)
+        attr = torch.cat((attr, torch.zeros((n, attr.shape[1]), dtype=attr.dtype)), 0)
+    return ei, attr

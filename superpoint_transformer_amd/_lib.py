@@ -46,6 +46,8 @@ SIGNATURES = {
                                 _p, _p, _p, _sz, _p]),
     "spt_point_geof_dense_f32": (_int, [_p, _i64, _p, _int, _int, _int, _int, _p, _p]),
     "spt_point_geof_csr_f32": (_int, [_p, _i64, _p, _p, _int, _int, _int, _p, _p]),
+    "spt_horizontal_edge_features_f32": (_int, [_p, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _int,
+                                                _p, _p, _p]),
     "spt_unit_sphere_norm_f32": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _p, _p, _p, _p]),
 }
 

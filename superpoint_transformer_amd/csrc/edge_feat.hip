@@ -1,0 +1,105 @@
+// On-the-fly horizontal edge features + symmetrisation + self loops, fused
+// (the step that runs on device every batch right before
+// the attention stages).  Replaces
+//   _on_the_fly_horizontal_edge_features   src/transforms/graph.py:1135-1277
+//   NAGAddSelfLoops._process               src/transforms/graph.py:1419-1452
+// From the E trimmed (i<j) edges with their 7 stored attributes
+// [mean_off(3), std_off(3), mean_dist] and the node attributes pos, normal,
+// log_length, log_surface, log_volume, log_size it writes the final
+//   edge_index [2, 2E (+N)] = [ (s,t) | (t,s) | (i,i) ]
+//   edge_attr  [2E (+N), 18] = [mean_off(3) std_off(3) mean_dist angle_source
+//        angle_target normal_angle log_length log_surface log_volume log_size
+//        centroid_dir(3) centroid_dist]          (f_list order, graph.py:1186-1275)
+// in one pass: the reference materialises ~14 [E, .] temporaries and two cats.
+#include <math.h>
+
+#include "common.hpp"
+
+namespace spt {
+
+__device__ __forceinline__ float clip1(float v) {
+  // graph.py:1206-1208: NaN -> 0 (0/0 directions), then clip to [-1, 1]
+  if (v != v) return 0.f;
+  return fminf(fmaxf(v, -1.f), 1.f);
+}
+
+__global__ __launch_bounds__(256) void edge_feat_kernel(
+    const int64_t* __restrict__ se, int64_t E, int64_t N, const float* __restrict__ ea7,
+    const float* __restrict__ pos, const float* __restrict__ normal,
+    const float* __restrict__ ll, const float* __restrict__ ls,
+    const float* __restrict__ lv, const float* __restrict__ lz, int self_loops,
+    int64_t* __restrict__ ei, float* __restrict__ out) {
+  const int64_t etot = 2 * E + (self_loops ? N : 0);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < E + (self_loops ? N : 0);
+       i += stride) {
+    if (i >= E) {  // self loop: zero features (add_self_loops(fill_value=0))
+      const int64_t n = i - E, row = 2 * E + n;
+      ei[row] = n;
+      ei[etot + row] = n;
+#pragma unroll
+      for (int k = 0; k < 18; ++k) out[row * 18 + k] = 0.f;
+      continue;
+    }
+    const int64_t s = se[i], t = se[E + i];
+    float f[18], fb[18];
+    const float mx = ea7[i * 7 + 0], my = ea7[i * 7 + 1], mz = ea7[i * 7 + 2];
+    const float nrm = sqrtf(mx * mx + my * my + mz * mz);
+    const float dx = clip1(mx / nrm), dy = clip1(my / nrm), dz = clip1(mz / nrm);
+    const float nsx = normal[s * 3], nsy = normal[s * 3 + 1], nsz = normal[s * 3 + 2];
+    const float ntx = normal[t * 3], nty = normal[t * 3 + 1], ntz = normal[t * 3 + 2];
+    f[0] = mx; f[1] = my; f[2] = mz;
+    f[3] = ea7[i * 7 + 3]; f[4] = ea7[i * 7 + 4]; f[5] = ea7[i * 7 + 5];
+    f[6] = ea7[i * 7 + 6];
+    f[7] = fabsf(dx * nsx + dy * nsy + dz * nsz);       // angle_source
+    f[8] = fabsf(dx * ntx + dy * nty + dz * ntz);       // angle_target
+    f[9] = fabsf(nsx * ntx + nsy * nty + nsz * ntz);    // normal_angle
+    f[10] = ll[s] - ll[t];
+    f[11] = ls[s] - ls[t];
+    f[12] = lv[s] - lv[t];
+    f[13] = lz[s] - lz[t];
+    const float cx = pos[t * 3] - pos[s * 3], cy = pos[t * 3 + 1] - pos[s * 3 + 1],
+                cz = pos[t * 3 + 2] - pos[s * 3 + 2];
+    const float cd = sqrtf(cx * cx + cy * cy + cz * cz);
+    f[14] = clip1(cx / cd); f[15] = clip1(cy / cd); f[16] = clip1(cz / cd);
+    f[17] = sqrtf(cd);                                   // graph.py:1251: sqrt of the distance
+    // the flipped edge (graph.py: torch.cat((f, +-f)))
+#pragma unroll
+    for (int k = 0; k < 18; ++k) fb[k] = f[k];
+    fb[0] = -f[0]; fb[1] = -f[1]; fb[2] = -f[2];
+    fb[10] = -f[10]; fb[11] = -f[11]; fb[12] = -f[12]; fb[13] = -f[13];
+    fb[14] = -f[14]; fb[15] = -f[15]; fb[16] = -f[16];
+    ei[i] = s;
+    ei[etot + i] = t;
+    ei[E + i] = t;
+    ei[etot + E + i] = s;
+#pragma unroll
+    for (int k = 0; k < 18; ++k) {
+      out[i * 18 + k] = f[k];
+      out[(E + i) * 18 + k] = fb[k];
+    }
+  }
+}
+
+}  // namespace spt
+
+using namespace spt;
+
+extern "C" int spt_horizontal_edge_features_f32(
+    const int64_t* se, int64_t e, int64_t n, const float* edge_attr7, const float* pos,
+    const float* normal, const float* log_length, const float* log_surface,
+    const float* log_volume, const float* log_size, int add_self_loops,
+    int64_t* edge_index_out, float* edge_attr_out, spt_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPT_CHECK_ARG(e >= 0 && n >= 0, "bad shape");
+  const int64_t work = e + (add_self_loops ? n : 0);
+  if (work == 0) return 0;
+  SPT_CHECK_ARG(edge_index_out && edge_attr_out, "null output");
+  SPT_CHECK_ARG(e == 0 || (se && edge_attr7 && pos && normal && log_length && log_surface &&
+                           log_volume && log_size), "null input");
+  edge_feat_kernel<<<stream_grid(work, 256), 256, 0, stream>>>(
+      se, e, n, edge_attr7, pos, normal, log_length, log_surface, log_volume, log_size,
+      add_self_loops, edge_index_out, edge_attr_out);
+  SPT_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,76 @@
+"""On-the-fly horizontal edge features + self loops.
+
+Golden vector: tests/golden/horizontal_edge_features.npz, produced by executing
+the REFERENCE's own `_on_the_fly_horizontal_edge_features` source on level 1 of
+its demo room (tests/golden/make_golden_edge_features.py).  CPU: the oracle
+matches it; GPU: the fused HIP kernel matches oracle and fixture."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import spt_oracle as O
+
+
+def _inputs(g):
+    t = lambda k: torch.from_numpy(g["in__" + k])
+    return (t("edge_index"), t("edge_attr"), t("pos"), t("normal"), t("log_length"),
+            t("log_surface"), t("log_volume"), t("log_size"))
+
+
+def test_oracle_matches_reference_function_output():
+    g = load_golden("horizontal_edge_features.npz")
+    ei, attr = O.horizontal_edge_features(*_inputs(g), add_self_loops=False)
+    assert torch.equal(ei, torch.from_numpy(g["edge_index"]))
+    torch.testing.assert_close(attr, torch.from_numpy(g["edge_attr"]), rtol=1e-6, atol=1e-7)
+    assert attr.shape[1] == 18
+
+
+def test_oracle_self_loops_are_zero_rows_at_the_end():
+    g = load_golden("horizontal_edge_features.npz")
+    ins = _inputs(g)
+    n, e = ins[2].shape[0], ins[0].shape[1]
+    ei, attr = O.horizontal_edge_features(*ins, add_self_loops=True)
+    assert ei.shape == (2, 2 * e + n) and attr.shape == (2 * e + n, 18)
+    assert torch.equal(ei[:, 2 * e:], torch.arange(n).repeat(2, 1))
+    assert attr[2 * e:].abs().sum() == 0
+
+
+@pytest.mark.gpu
+def test_fused_kernel_matches_reference_fixture_and_oracle(dev):
+    from superpoint_transformer_amd import transforms as T
+    g = load_golden("horizontal_edge_features.npz")
+    ins = _inputs(g)
+    e = ins[0].shape[1]
+    ei, attr = T.horizontal_edge_features(*[t.to(dev) for t in ins], add_self_loops=True)
+    rei, rattr = O.horizontal_edge_features(*ins, add_self_loops=True)
+    assert torch.equal(ei.cpu(), rei)                                   # indices bit-exact
+    torch.testing.assert_close(attr.cpu(), rattr, rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(attr.cpu()[:2 * e], torch.from_numpy(g["edge_attr"]),
+                               rtol=1e-6, atol=1e-7)                    # the reference's own output
+    ei2, attr2 = T.horizontal_edge_features(*[t.to(dev) for t in ins], add_self_loops=False)
+    assert torch.equal(ei2.cpu(), torch.from_numpy(g["edge_index"]))
+    assert torch.equal(attr2, attr[:2 * e])
+
+
+@pytest.mark.gpu
+def test_fused_kernel_degenerate_edges(dev):
+    """Zero offsets / coincident centroids: 0/0 directions become 0 like the
+    reference's NaN clean-up (graph.py:1206-1208, 1254-1256)."""
+    from superpoint_transformer_amd import transforms as T
+    n = 5
+    pos = torch.tensor([[0., 0, 0], [0, 0, 0], [1, 2, 3], [1, 2, 3], [4, 4, 4]])
+    normal = torch.nn.functional.normalize(torch.randn(n, 3, generator=torch.Generator().manual_seed(1)), dim=1)
+    se = torch.tensor([[0, 2, 0], [1, 3, 4]])
+    ea = torch.zeros(3, 7)
+    ea[2, :3] = torch.tensor([1.0, -2.0, 0.5])
+    ll = torch.arange(n).float().view(-1, 1)
+    args = (se, ea, pos, normal, ll, ll * 2, ll * 3, ll * 4)
+    ei, attr = T.horizontal_edge_features(*[t.to(dev) for t in args])
+    rei, rattr = O.horizontal_edge_features(*args)
+    assert torch.equal(ei.cpu(), rei)
+    assert not attr.isnan().any()
+    torch.testing.assert_close(attr.cpu(), rattr, rtol=1e-6, atol=1e-7)
+    # empty graph with self loops only
+    ei, attr = T.horizontal_edge_features(se[:, :0].to(dev), ea[:0].to(dev), *[t.to(dev) for t in args[2:]])
+    assert ei.shape == (2, n) and attr.abs().sum() == 0
