@@ -28,11 +28,26 @@ struct Vec<4> {
   float v[4];
 };
 
+// measured on scene S (profiles/r01q_segcsr_variants.txt): 8 rows in flight per lane slot
+// and non-temporal row loads (each child row is read exactly once) = +9 % over 4 / plain
+#ifndef SPT_SEG_UNR
+#define SPT_SEG_UNR 8
+#endif
+#ifndef SPT_SEG_NT
+#define SPT_SEG_NT 1
+#endif
+
 template <int VEC>
 __device__ __forceinline__ Vec<VEC> ldv(const float* __restrict__ p) {
   Vec<VEC> r;
   if constexpr (VEC == 4) {
+#if SPT_SEG_NT
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f t4 = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
+    const float4 t = make_float4(t4[0], t4[1], t4[2], t4[3]);
+#else
     const float4 t = *reinterpret_cast<const float4*>(p);
+#endif
     r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
   } else if constexpr (VEC == 2) {
     const float2 t = *reinterpret_cast<const float2*>(p);
@@ -121,7 +136,7 @@ __global__ __launch_bounds__(256) void segcsr_reduce_kernel(
     const int32_t* __restrict__ rowptr, int64_t n, int64_t num_seg, int c,
     int lpr_log2, int rpg_log2, float* __restrict__ out,
     int32_t* __restrict__ arg) {
-  constexpr int UNR = 4;
+  constexpr int UNR = SPT_SEG_UNR;
   const int lane = threadIdx.x & 63;
   const int g_log2 = lpr_log2 + rpg_log2;
   const int lpr = 1 << lpr_log2;
