@@ -140,11 +140,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback path exists)")
+    # test hook: SPT_BENCH_SHARE_GPU=1 runs every rank on cuda:0 over gloo, to exercise
+    # the N > 1 code path on a 1-GPU box (RCCL refuses two ranks on one device)
+    share = os.environ.get("SPT_BENCH_SHARE_GPU") == "1"
+    if share:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from superpoint_transformer_amd import hotpath
     from superpoint_transformer_amd.synthetic import SCENES, make_nag
@@ -158,7 +166,10 @@ def main():
 
     def barrier():
         if world > 1:
-            dist.barrier(device_ids=[local])
+            if share:
+                dist.barrier()
+            else:
+                dist.barrier(device_ids=[local])
         torch.cuda.synchronize()
 
     barrier()
