@@ -36,6 +36,16 @@ struct Vec<4> {
 #ifndef SPT_SEG_NT
 #define SPT_SEG_NT 1
 #endif
+#ifndef SPT_SEG_PREFETCH
+#define SPT_SEG_PREFETCH 0
+#endif
+// grid cap 256 CUs x 64 workgroups (measured: x16 per CU = 61 %, x64 = 69 %, x256 = 66 % of 8 TB/s)
+#ifndef SPT_SEG_GRIDCAP_MUL
+#define SPT_SEG_GRIDCAP_MUL 4
+#endif
+#ifndef SPT_SEG_RPG_BIAS
+#define SPT_SEG_RPG_BIAS 0
+#endif
 
 template <int VEC>
 __device__ __forceinline__ Vec<VEC> ldv(const float* __restrict__ p) {
@@ -150,11 +160,33 @@ __global__ __launch_bounds__(256) void segcsr_reduce_kernel(
   const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
   const int ctile = lpr * VEC;
 
+#if SPT_SEG_PREFETCH
+  int nstart = 0, nend = 0;
+  {
+    const int64_t s0 = wave * spw + slot;
+    if (s0 < num_seg) {
+      nstart = rowptr[s0];
+      nend = rowptr[s0 + 1];
+    }
+  }
+#endif
   for (int64_t sbase = wave * spw; sbase < num_seg; sbase += nwaves * spw) {
     const int64_t s = sbase + slot;
     const bool sv = s < num_seg;
+#if SPT_SEG_PREFETCH
+    const int start = nstart, end = nend;
+    {  // the next segment's range is requested a whole segment ahead
+      const int64_t sn = s + nwaves * spw;
+      nstart = nend = 0;
+      if (sn < num_seg) {
+        nstart = rowptr[sn];
+        nend = rowptr[sn + 1];
+      }
+    }
+#else
     const int start = sv ? rowptr[s] : 0;
     const int end = sv ? rowptr[s + 1] : 0;
+#endif
     for (int cb = 0; cb < c; cb += ctile) {
       const int c0 = cb + lr * VEC;
       const bool cv = c0 < c;
@@ -372,6 +404,8 @@ static int rows_in_flight_log2(int64_t n, int64_t num_seg, int lpr_log2) {
   const int64_t avg = (num_seg > 0) ? n / num_seg : 0;
   int rpg_log2 = log2_floor(avg / 4 > 1 ? avg / 4 : 1);
   if (rpg_log2 > 6 - lpr_log2) rpg_log2 = 6 - lpr_log2;
+  rpg_log2 -= SPT_SEG_RPG_BIAS;
+  if (rpg_log2 < 0) rpg_log2 = 0;
   return rpg_log2;
 }
 
@@ -393,7 +427,12 @@ static void launch_reduce(bool want_arg, const float* x, const int32_t* perm,
                           int lpr_log2, int rpg_log2, float* out, int32_t* arg,
                           hipStream_t stream) {
   const int spw = 64 >> (lpr_log2 + rpg_log2);
-  const int grid = stream_grid(ceil_div(num_seg, spw), 4);
+  int grid;
+  {
+    const int64_t want = ceil_div(ceil_div(num_seg, spw), 4);
+    const int64_t cap = (int64_t)256 * 16 * SPT_SEG_GRIDCAP_MUL;
+    grid = (int)(want < cap ? (want > 0 ? want : 1) : cap);
+  }
   if constexpr (OP == SPT_MIN || OP == SPT_MAX) {
     if (want_arg) {
       segcsr_reduce_kernel<OP, VEC, true><<<grid, 256, 0, stream>>>(
@@ -424,7 +463,12 @@ static void launch_bwd_csr(int vec, const float* gout, const int32_t* arg,
                            int64_t num_seg, int c, int lpr_log2, int rpg_log2,
                            float* gx, hipStream_t stream) {
   const int spw = 64 >> (lpr_log2 + rpg_log2);
-  const int grid = stream_grid(ceil_div(num_seg, spw), 4);
+  int grid;
+  {
+    const int64_t want = ceil_div(ceil_div(num_seg, spw), 4);
+    const int64_t cap = (int64_t)256 * 16 * SPT_SEG_GRIDCAP_MUL;
+    grid = (int)(want < cap ? (want > 0 ? want : 1) : cap);
+  }
   if (vec == 4)
     segcsr_bwd_kernel<MODE, 4><<<grid, 256, 0, stream>>>(gout, arg, perm, rowptr, num_seg, c, lpr_log2, rpg_log2, gx);
   else if (vec == 2)
