@@ -184,6 +184,11 @@ int spt_edge_attn_fwd_f32(const float* qkv, int64_t n, int H, int D, int Dv,
                           float scale_a, float* out, float* m, float* z,
                           spt_stream_t stream);
 size_t spt_edge_attn_bwd_workspace_bytes(int H, int D, int Dv, int F);
+/* Two independent formulations exist for the SPT-64 head layout (H=16, D=Dv=4,
+ * F=32): the matrix-pipe one (default) and the generic lane-per-output one.
+ * spt_attn_use_mfma(0|1) selects it process-wide and returns the previous
+ * setting; tests cross-check the two at full scene size. */
+int spt_attn_use_mfma(int on);
 int spt_edge_attn_bwd_f32(const float* qkv, int64_t n, int H, int D, int Dv,
                           const int32_t* erowptr, const int32_t* eperm,
                           const int32_t* tgt_sorted, int64_t e,

@@ -753,9 +753,10 @@ int attn_bwd_mfma_launch(const float* qkv, int64_t n, const int32_t* erowptr,
                          const float* Wv, const float* bv, int scale_mode, float scale_a,
                          const float* out, const float* m, const float* z, const float* gout,
                          float* gqkv, float* gea, float* partial, hipStream_t stream);
+static int g_attn_mfma = -1;  // -1: decide from the environment on first use
 static bool use_mfma() {
-  static const bool on = getenv("SPT_ATTN_VALU_ONLY") == nullptr;  // A/B switch for profiling
-  return on;
+  if (g_attn_mfma < 0) g_attn_mfma = getenv("SPT_ATTN_VALU_ONLY") == nullptr ? 1 : 0;
+  return g_attn_mfma != 0;
 }
 }  // namespace spt
 
@@ -774,6 +775,12 @@ using namespace spt;
       return ::spt::fail(-4, "%s: unsupported attention shape H=%d D=%d Dv=%d F=%d " \
                          "(built: H*D<=128, H*Dv<=128, F in {18,32})", __func__, H, D, Dv, F); \
   } while (0)
+
+extern "C" int spt_attn_use_mfma(int on) {
+  const int prev = use_mfma() ? 1 : 0;
+  g_attn_mfma = on ? 1 : 0;
+  return prev;
+}
 
 extern "C" int spt_edge_attn_fwd_f32(const float* qkv, int64_t n, int H, int D, int Dv,
                                      const int32_t* erowptr, const int32_t* eperm,

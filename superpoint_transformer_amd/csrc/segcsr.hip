@@ -79,6 +79,18 @@ __device__ __forceinline__ void stv(float* __restrict__ p, const Vec<VEC>& r) {
   }
 }
 
+// streaming store (rows written once, consumed by a later kernel)
+template <int VEC>
+__device__ __forceinline__ void stv_nt(float* __restrict__ p, const Vec<VEC>& r) {
+  if constexpr (VEC == 4) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    v4f t = {r.v[0], r.v[1], r.v[2], r.v[3]};
+    __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(p));
+  } else {
+    stv<VEC>(p, r);
+  }
+}
+
 template <int VEC>
 __device__ __forceinline__ void sti(int32_t* __restrict__ p, const int32_t (&a)[VEC]) {
   if constexpr (VEC == 4) {
@@ -362,7 +374,7 @@ __global__ __launch_bounds__(256) void segcsr_bwd_kernel(
 #pragma unroll
             for (int k = 0; k < VEC; ++k) o.v[k] = (a[k] == r[u]) ? g.v[k] : 0.f;
           }
-          stv<VEC>(gx + (int64_t)r[u] * c + c0, o);
+          stv_nt<VEC>(gx + (int64_t)r[u] * c + c0, o);
         }
       }
     }

@@ -1,0 +1,117 @@
+"""Parity at BASELINE.json's full sizes (scene S: 15 M points, 428 571 / 178 571
+superpoints, 7.03 M edges) through properties that do not need an O(N) CPU pass
+of the oracle - plus spot checks of random rows against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import spt_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def test_attention_two_formulations_agree_at_scene_scale(dev):
+    """The matrix-pipe kernels and the generic lane-per-output kernels are two
+    independent implementations of attention.py:202-315: at N = 428 571,
+    E = 7.03 M they must agree (f32 round-off), and random nodes must match the
+    float64 oracle evaluated on their edges only."""
+    from superpoint_transformer_amd import _lib, ops
+    n, e, H, D = 428_571, 7_030_000, 16, 4
+    g = torch.Generator(device=dev).manual_seed(0)
+    s = torch.randint(0, n, (e,), device=dev, generator=g)
+    t = torch.randint(0, n, (e,), device=dev, generator=g)
+    ei = torch.stack([s, t])
+    qkv = torch.randn(n, 192, device=dev, generator=g)
+    ea = torch.randn(e, 32, device=dev, generator=g) * 0.3
+    W = [(torch.randn(64, 32, device=dev, generator=g) * 0.1,
+          torch.randn(64, device=dev, generator=g) * 0.1) for _ in range(3)]
+    gw = torch.randn(n, 64, device=dev, generator=g)
+    res = {}
+    prev = _lib.lib.spt_attn_use_mfma(1)
+    try:
+        for mode in (1, 0):
+            _lib.lib.spt_attn_use_mfma(mode)
+            q = qkv.clone().requires_grad_()
+            a = ea.clone().requires_grad_()
+            ws = [(w.clone().requires_grad_(), b.clone().requires_grad_()) for w, b in W]
+            out = ops.edge_attention(q, ei, a, *ws, num_heads=H, qk_dim=D, scale_a=0.5)
+            out.backward(gw)
+            res[mode] = (out.detach(), q.grad, a.grad, [w.grad for w, _ in ws], [b.grad for _, b in ws])
+    finally:
+        _lib.lib.spt_attn_use_mfma(prev)
+    m, v = res[1], res[0]
+    torch.testing.assert_close(m[0], v[0], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(m[2], v[2], rtol=1e-3, atol=1e-5)               # d edge_attr
+    # dqkv: k/v columns are f32-atomic sums in both formulations
+    torch.testing.assert_close(m[1], v[1], rtol=1e-3, atol=2e-4)
+    for a_, b_ in zip(m[3] + m[4], v[3] + v[4]):                               # 7 M-term sums
+        assert ((a_ - b_).abs().max() / b_.abs().max().clamp(min=1e-3)).item() < 2e-4
+    # oracle spot check: 40 random nodes, their outgoing edges only
+    pick = torch.randperm(n, generator=torch.Generator().manual_seed(1))[:40].to(dev)
+    mask = torch.isin(s, pick)
+    sub_e = mask.nonzero().view(-1)
+    ss, tt = s[sub_e].cpu(), t[sub_e].cpu()
+    p = {"qkv.weight": torch.eye(192, dtype=torch.float64), "qkv.bias": None}
+    for nm, (w, b) in zip(("k_rpe", "q_rpe", "v_rpe"), W):
+        p[nm + ".weight"], p[nm + ".bias"] = w.cpu().double(), b.cpu().double()
+    # restrict to the picked nodes: keep global ids (the oracle only needs rows s and t)
+    old = O.qk_scale_dg
+    deg = torch.bincount(s, minlength=n).cpu()
+    O.qk_scale_dg = lambda s_, d_, h_: (0.5 * deg[s_].double() ** -0.5).view(-1, 1, 1)
+    try:
+        ref = O.self_attention(qkv.cpu().double(), torch.stack([ss, tt]), ea[sub_e].cpu().double(),
+                               p, H, D)
+    finally:
+        O.qk_scale_dg = old
+    got = m[0][pick].cpu().double()
+    assert ((got - ref[pick.cpu()]).abs() - 1e-4 * ref[pick.cpu()].abs()).max().item() <= 1e-5
+
+
+def test_knn_at_scene_scale_properties_and_oracle_spot_check(dev):
+    """15 M voxelised points, k = 45, r = 2 m (the S3DIS setting)."""
+    from superpoint_transformer_amd import neighbors as NB
+    from superpoint_transformer_amd.synthetic import make_voxel_cloud
+    n, k, r = 15_000_000, 45, 2.0
+    pos = make_voxel_cloud(n, voxel=0.03, seed=11, device=dev)
+    nb, d = NB.knn_1(pos, k, r)
+    ok = nb >= 0
+    assert bool((d[ok] < r * r).all()) and bool((d[~ok] == -1).all())
+    dd = torch.where(ok, d, torch.full_like(d, float("inf")))
+    assert bool((dd[:, 1:] >= dd[:, :-1]).all())                              # ascending rows
+    assert bool((nb != torch.arange(n, device=dev).view(-1, 1)).all())        # self excluded
+    assert bool((nb < n).all())
+    # the stored distance is the f32 distance to the stored index
+    rows = torch.randint(0, n, (100_000,), device=dev)
+    j = nb[rows]
+    diff = pos[rows].unsqueeze(1) - pos[j.clamp(min=0)]
+    d2 = (diff[..., 0] * diff[..., 0] + diff[..., 1] * diff[..., 1]) + diff[..., 2] * diff[..., 2]
+    assert bool((d2[j >= 0] == d[rows][j >= 0]).all())
+    # exhaustive oracle on a few queries against ALL 15 M points
+    q = torch.randint(0, n, (24,), generator=torch.Generator().manual_seed(3))
+    rd, ri = O.frnn_grid_points(pos[q.to(dev)].cpu(), pos.cpu(), k + 1, r)
+    assert torch.equal(nb[q.to(dev)].cpu(), ri[:, 1:])
+    assert torch.equal(d[q.to(dev)].cpu(), rd[:, 1:])
+
+
+def test_graph_norm_and_usn_at_scene_scale(dev):
+    from superpoint_transformer_amd import ops
+    n, c, ns = 15_000_000, 128, 428_571
+    g = torch.Generator(device=dev).manual_seed(2)
+    x = torch.randn(n, c, device=dev, generator=g) * 3 + 1
+    ones, zeros = torch.ones(c, device=dev), torch.zeros(c, device=dev)
+    y = ops.graph_norm(x, None, ones, zeros, ones, num_graphs=1)
+    mu = y.double().mean(0)
+    var = y.double().var(0, unbiased=False)
+    assert mu.abs().max().item() < 1e-5 and (var - 1).abs().max().item() < 1e-4  # normalised
+    idx = torch.randint(0, ns, (n,), device=dev, generator=g)
+    pos = torch.randn(n, 3, device=dev, generator=g) * 10
+    pn, diam = ops.unit_sphere_norm(pos, idx, None, ns)
+    assert bool((pn.abs() <= 1.0 + 1e-6).all())                               # inside the unit box
+    rows = torch.randint(0, ns, (50,), generator=torch.Generator().manual_seed(4))
+    for s_ in rows.tolist():                                                   # oracle on whole segments
+        mem = (idx == s_).nonzero().view(-1)
+        if mem.numel() == 0:
+            continue
+        ro, rd = O.unit_sphere_norm(pos[mem].cpu().double(), torch.zeros(mem.numel(), dtype=torch.long))
+        assert diam[s_].item() == rd.float().item()
+        assert (pn[mem].cpu().double() - ro).abs().max().item() < 1e-5
