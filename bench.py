@@ -91,6 +91,7 @@ def preprocess_leg(scene, n_points, dev, reps=3):
     from superpoint_transformer_amd.synthetic import make_voxel_cloud
     voxel, k, r = PRE_CFG.get(scene, PRE_CFG["S"])
     pos = make_voxel_cloud(n_points, voxel=voxel, seed=4321, device=dev)
+    n_points = pos.shape[0]          # one point per voxel: slightly fewer than requested
 
     def step():
         nb, _ = NB.knn_1(pos, k, r)
@@ -124,6 +125,7 @@ def cpu_preprocess_baseline(scene, n_sample=6000):
     from superpoint_transformer_amd.synthetic import make_voxel_cloud
     voxel, k, r = PRE_CFG.get(scene, PRE_CFG["S"])
     pos = make_voxel_cloud(n_sample, voxel=voxel, seed=4321, device="cpu", extent=(6.0, 6.0, 3.0))
+    n_sample = pos.shape[0]
     t0 = time.perf_counter()
     nb, _ = O.knn_1(pos, k, r)
     O.geometric_features(pos.double(), nb, k_min=1)

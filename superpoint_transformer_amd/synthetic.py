@@ -137,7 +137,8 @@ def make_voxel_cloud(n, voxel=0.03, seed=1234, device="cpu", patch=3.0, extent=(
     """Voxelised-surface point cloud for the preprocessing leg (kNN + geometric
     features): axis-aligned planar patches of ``patch`` metres sampled on a
     ``voxel`` lattice (what GridSampling3D leaves of walls / floors / roofs),
-    placed at random in ``extent``, rows shuffled.  Returns [n,3] f32."""
+    placed at random in ``extent``, de-duplicated per voxel, rows shuffled.
+    Returns [<= n, 3] f32 (a few percent fewer than ``n`` where patches cross)."""
     device = torch.device(device)
     gen = torch.Generator(device=device).manual_seed(seed)
     side = max(int(patch / voxel), 2)
@@ -157,4 +158,13 @@ def make_voxel_cloud(n, voxel=0.03, seed=1234, device="cpu", patch=3.0, extent=(
     pos.scatter_add_(2, u_axis.view(-1, 1, 1).expand(npatch, per, 1), i.view(1, per, 1).expand(npatch, per, 1))
     pos.scatter_add_(2, v_axis.view(-1, 1, 1).expand(npatch, per, 1), j.view(1, per, 1).expand(npatch, per, 1))
     pos = pos.view(-1, 3)[:n]
+    # one point per voxel, like GridSampling3D's output (patches may overlap)
+    q = (pos / voxel).round().long()
+    q = q - q.min(dim=0).values
+    key = q[:, 0] + (q[:, 1] << 21) + (q[:, 2] << 42)
+    order = key.argsort()
+    ks = key[order]
+    first = torch.ones_like(ks, dtype=torch.bool)
+    first[1:] = ks[1:] != ks[:-1]
+    pos = pos[order[first]]
     return pos[torch.randperm(pos.shape[0], generator=gen, device=device)].contiguous()

@@ -73,6 +73,8 @@ def test_knn_at_scene_scale_properties_and_oracle_spot_check(dev):
     from superpoint_transformer_amd.synthetic import make_voxel_cloud
     n, k, r = 15_000_000, 45, 2.0
     pos = make_voxel_cloud(n, voxel=0.03, seed=11, device=dev)
+    n = pos.shape[0]
+    assert n > 14_000_000
     nb, d = NB.knn_1(pos, k, r)
     ok = nb >= 0
     assert bool((d[ok] < r * r).all()) and bool((d[~ok] == -1).all())
