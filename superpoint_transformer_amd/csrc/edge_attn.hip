@@ -684,22 +684,27 @@ __global__ __launch_bounds__(EA_WAVES * 64, 1) void edge_attn_bwd_kernel(
   }
 }
 
-// fixed-order sum of the per-wave partial tables: 64 columns x 4 slices per block
+// fixed-order sum of the per-wave partial tables: 16 columns x 16 slices per block
 __global__ __launch_bounds__(256) void attn_reduce_partials_kernel(
     const float* __restrict__ partial, int nwaves, int len, float* __restrict__ total) {
-  __shared__ float sl[4][64];
-  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int slice = threadIdx.x >> 6;
+  __shared__ float sl[16][17];
+  const int cl = threadIdx.x & 15;
+  const int col = blockIdx.x * 16 + cl;
+  const int slice = threadIdx.x >> 4;
   float acc = 0.f;
   if (col < len) {
-    const int per = (nwaves + 3) / 4;
+    const int per = (nwaves + 15) / 16;
     const int lo = slice * per, hi = (lo + per < nwaves) ? lo + per : nwaves;
     for (int k = lo; k < hi; ++k) acc += partial[(size_t)k * len + col];
   }
-  sl[slice][threadIdx.x & 63] = acc;
+  sl[slice][cl] = acc;
   __syncthreads();
-  if (slice == 0 && col < len)
-    total[col] = ((sl[0][threadIdx.x] + sl[1][threadIdx.x]) + sl[2][threadIdx.x]) + sl[3][threadIdx.x];
+  if (slice == 0 && col < len) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += sl[k][cl];
+    total[col] = t;
+  }
 }
 
 // split the reduced [rows][F+1] table into the six gradient tensors
@@ -860,7 +865,7 @@ extern "C" int spt_edge_attn_bwd_f32(const float* qkv, int64_t n, int H, int D, 
     const int ntab = attn_bwd_mfma_launch(qkv, n, erowptr, eperm, tgt_sorted, edge_attr, Wk, bk,
                                           Wq, bq, Wv, bv, scale_mode, scale_a, out, m, z, gout,
                                           gqkv, gedge_attr, partial, stream);
-    attn_reduce_partials_kernel<<<(int)ceil_div((int64_t)len, 64), 256, 0, stream>>>(
+    attn_reduce_partials_kernel<<<(int)ceil_div((int64_t)len, 16), 256, 0, stream>>>(
         partial, ntab, (int)len, total);
     attn_unpack_grads_kernel<<<(int)ceil_div((int64_t)len, 256), 256, 0, stream>>>(
         total, H * D, H * Dv, F, gWk, gbk, gWq, gbq, gWv, gbv);
@@ -880,7 +885,7 @@ extern "C" int spt_edge_attn_bwd_f32(const float* qkv, int64_t n, int H, int D, 
                     gout, gqkv, gedge_attr, partial);
 #undef SPT_ATTN_CASE
   if (has_rpe) {
-    attn_reduce_partials_kernel<<<(int)ceil_div((int64_t)len, 64), 256, 0, stream>>>(
+    attn_reduce_partials_kernel<<<(int)ceil_div((int64_t)len, 16), 256, 0, stream>>>(
         partial, grid * EA_WAVES, (int)len, total);
     attn_unpack_grads_kernel<<<(int)ceil_div((int64_t)len, 256), 256, 0, stream>>>(
         total, H * D, H * Dv, F, gWk, gbk, gWq, gbq, gWv, gbv);

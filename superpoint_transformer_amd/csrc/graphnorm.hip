@@ -168,24 +168,31 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(
 }
 
 // ---- finalize: fixed-order reduction of the per-block partial tables --------
-// grid = (B, ceil(row_len / 64)); 256 threads = 64 columns x 4 slices.
+// grid = (B, ceil(row_len / 16)); 256 threads = 16 columns x 16 slices: each thread
+// sums <= 64 partials (the 64-column x 4-slice shape took 73 us per call, 40 calls
+// per train step, purely on load latency).
 __global__ __launch_bounds__(256) void gn_reduce_partials_kernel(
     const double* __restrict__ partial, int nblocks, int B, int row_len,
     double* __restrict__ total) {
-  __shared__ double sl[4][64];
+  __shared__ double sl[16][17];
   const int b = blockIdx.x;
-  const int col = blockIdx.y * 64 + (threadIdx.x & 63);
-  const int slice = threadIdx.x >> 6;
+  const int cl = threadIdx.x & 15;
+  const int col = blockIdx.y * 16 + cl;
+  const int slice = threadIdx.x >> 4;
   double acc = 0.0;
   if (col < row_len) {
-    const int per = (nblocks + 3) / 4;
+    const int per = (nblocks + 15) / 16;
     const int lo = slice * per, hi = (lo + per < nblocks) ? lo + per : nblocks;
     for (int k = lo; k < hi; ++k) acc += partial[((size_t)k * B + b) * row_len + col];
   }
-  sl[slice][threadIdx.x & 63] = acc;
+  sl[slice][cl] = acc;
   __syncthreads();
-  if (slice == 0 && col < row_len)
-    total[(size_t)b * row_len + col] = ((sl[0][threadIdx.x] + sl[1][threadIdx.x]) + sl[2][threadIdx.x]) + sl[3][threadIdx.x];
+  if (slice == 0 && col < row_len) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += sl[k][cl];   // fixed order: deterministic
+    total[(size_t)b * row_len + col] = t;
+  }
 }
 
 // forward tables from the totals
@@ -443,7 +450,7 @@ extern "C" int spt_graphnorm_fwd_f32(const float* x, const int64_t* batch, int64
   float* am = (float*)(base + p.off_am);
   float* scale = (float*)(base + p.off_scale);
   launch_stats<false>(p, x, nullptr, batch, r, d, B, nullptr, nullptr, nullptr, 1.f, partial, stream);
-  gn_reduce_partials_kernel<<<dim3(B, (p.row_len + 63) / 64), 256, 0, stream>>>(partial, p.nblocks, B, p.row_len, total);
+  gn_reduce_partials_kernel<<<dim3(B, (p.row_len + 15) / 16), 256, 0, stream>>>(partial, p.nblocks, B, p.row_len, total);
   gn_fwd_tables_kernel<<<(B * d + 255) / 256, 256, 0, stream>>>(total, B, d, weight, mean_scale, eps, mean, rstd, am, scale);
   if (r > 0) {
     if (p.sh.vec == 4)
@@ -485,7 +492,7 @@ extern "C" int spt_graphnorm_bwd_f32(const float* x, const float* gy,
   // rebuild (alpha*mu, weight*rstd) from the saved statistics
   gn_rebuild_tables_kernel<<<(B * d + 255) / 256, 256, 0, stream>>>(mean, rstd, weight, mean_scale, B, d, am, scale);
   launch_stats<true>(p, x, gy, batch, r, d, B, am, scale, bias, act_slope, partial, stream);
-  gn_reduce_partials_kernel<<<dim3(B, (p.row_len + 63) / 64), 256, 0, stream>>>(partial, p.nblocks, B, p.row_len, total);
+  gn_reduce_partials_kernel<<<dim3(B, (p.row_len + 15) / 16), 256, 0, stream>>>(partial, p.nblocks, B, p.row_len, total);
   gn_bwd_tables_kernel<<<(d + 127) / 128, 128, 0, stream>>>(total, B, d, weight, mean_scale, mean, rstd, c1, c2, c3, gweight, gbias, gmean_scale);
   if (r > 0) {
     if (p.sh.vec == 4)
