@@ -261,6 +261,51 @@ int spt_horizontal_edge_features_f32(
     const float* log_volume, const float* log_size, int add_self_loops,
     int64_t* edge_index_out, float* edge_attr_out, spt_stream_t stream);
 
+/* Pieces of the GraphNorm two-pass scheme for callers that produce / consume the
+ * per-graph totals themselves (the fused MLP layers below).  totals layout:
+ * [num_graphs][2d+1] f64 = (column sums, column sums of the second quantity, row count). */
+int spt_graphnorm_tables_f32(const double* total, int num_graphs, int d, const float* weight,
+                             const float* mean_scale, float eps, float* mean, float* rstd,
+                             float* am, float* scale, spt_stream_t stream);
+int spt_graphnorm_apply_f32(const float* x, const int64_t* batch, int64_t r, int d,
+                            int num_graphs, const float* am, const float* scale,
+                            const float* bias, float act_slope, float* y, spt_stream_t stream);
+int spt_graphnorm_bwd_stats_f32(const float* x, const float* gy, const int64_t* batch, int64_t r,
+                                int d, int num_graphs, const float* am, const float* scale,
+                                const float* bias, float act_slope, double* total, void* ws,
+                                size_t ws_bytes, spt_stream_t stream);
+int spt_graphnorm_bwd_tables_f32(const double* total, int num_graphs, int d, const float* weight,
+                                 const float* mean_scale, const float* mean, const float* rstd,
+                                 float* c1, float* c2, float* c3, float* gweight, float* gbias,
+                                 float* gmean_scale, spt_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Fused MLP layer: bias-free Linear whose input is the previous layer's RAW output
+ * (GraphNorm-apply + LeakyReLU happen while the tile is staged) and whose epilogue
+ * yields the statistics of its own GraphNorm.  Replaces, per layer of
+ * src/nn/mlp.py:8-94, one library GEMM + GraphNorm statistics pass + GraphNorm apply
+ * pass (forward), and GraphNorm backward apply + the dX / dW GEMMs (backward).
+ * One call covers the rows [r0, r1) of ONE graph of the batch.
+ *   x / xprev [rows, K] raw, W [N, K], h [rows, N] raw output; pre_* = (am, scale
+ *   [K], bias [K], slope) of the previous GraphNorm or NULL (layer input used as is);
+ *   total [2N+1] f64 out; backward: gy, h [rows, N], this layer's (am, scale, bias,
+ *   slope) and backward rows (c1, c2, c3); gx [rows, K] or NULL; gW [N, K] (+= when
+ *   accumulate); prev_total [2K+1] = statistics for the previous GraphNorm's backward.
+ * ---------------------------------------------------------------------- */
+int spt_fused_linear_supported(int K, int N);
+size_t spt_fused_linear_workspace_bytes(int K, int N);
+int spt_fused_linear_fwd_f32(const float* x, int64_t r0, int64_t r1, int K, const float* W,
+                             int N, const float* pre_am, const float* pre_scale,
+                             const float* pre_bias, float pre_slope, float* h, double* total,
+                             void* ws, size_t ws_bytes, spt_stream_t stream);
+int spt_fused_linear_bwd_f32(const float* gy, const float* h, int64_t r0, int64_t r1, int N,
+                             const float* am, const float* scale, const float* bias,
+                             float slope, const float* c1, const float* c2, const float* c3,
+                             const float* xprev, int K, const float* pre_am,
+                             const float* pre_scale, const float* pre_bias, float pre_slope,
+                             const float* W, float* gx, float* gW, int accumulate,
+                             double* prev_total, void* ws, size_t ws_bytes, spt_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -49,6 +49,19 @@ SIGNATURES = {
     "spt_point_geof_csr_f32": (_int, [_p, _i64, _p, _p, _int, _int, _int, _p, _p]),
     "spt_horizontal_edge_features_f32": (_int, [_p, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _int,
                                                 _p, _p, _p]),
+    "spt_graphnorm_tables_f32": (_int, [_p, _int, _int, _p, _p, _f32, _p, _p, _p, _p, _p]),
+    "spt_graphnorm_apply_f32": (_int, [_p, _p, _i64, _int, _int, _p, _p, _p, _f32, _p, _p]),
+    "spt_graphnorm_bwd_stats_f32": (_int, [_p, _p, _p, _i64, _int, _int, _p, _p, _p, _f32, _p,
+                                           _p, _sz, _p]),
+    "spt_graphnorm_bwd_tables_f32": (_int, [_p, _int, _int, _p, _p, _p, _p, _p, _p, _p, _p, _p,
+                                            _p, _p]),
+    "spt_fused_linear_supported": (_int, [_int, _int]),
+    "spt_fused_linear_workspace_bytes": (_sz, [_int, _int]),
+    "spt_fused_linear_fwd_f32": (_int, [_p, _i64, _i64, _int, _p, _int, _p, _p, _p, _f32, _p, _p,
+                                        _p, _sz, _p]),
+    "spt_fused_linear_bwd_f32": (_int, [_p, _p, _i64, _i64, _int, _p, _p, _p, _f32, _p, _p, _p,
+                                        _p, _int, _p, _p, _p, _f32, _p, _p, _p, _int, _p, _p,
+                                        _sz, _p]),
     "spt_unit_sphere_norm_f32": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _p, _p, _p, _p]),
 }
 

@@ -1,0 +1,432 @@
+// Fused layers of the point / node / edge MLPs (src/nn/mlp.py:8-94: bias-free
+// nn.Linear -> GraphNorm -> LeakyReLU stacks; GraphNorm = PyG 2.3.0).
+//
+// Unfused, one layer over [rows, C] (rows up to 15 M) costs
+//   fwd : GEMM (w h) | GraphNorm stats (r h) | GraphNorm apply (r h, w y) | next GEMM (r y)
+//   bwd : GN stats (r h, r gy) | GN apply (r h, r gy, w gh) | dX GEMM (r gh, w gx) | dW GEMM (r gh, r y_prev)
+// Here a layer is ONE kernel per direction:
+//   fwd : y_prev = leaky(gn(h_prev)) is formed while the A tile is staged (h_prev
+//         is read raw), the product runs as f32 MFMA 16x16x4 with the weight block in
+//         B-operand registers, and the statistics of THIS layer's GraphNorm (column
+//         sums / sums of squares, f64) come out of the epilogue;
+//   bwd : gh = GraphNorm-backward(gy, h) and y_prev are formed while the tiles are
+//         staged; gx = gh W and gW += gh^T y_prev are two MFMA GEMMs over the tile; the
+//         statistics the PREVIOUS layer's GraphNorm backward needs (sum g', sum g' o')
+//         come out of the gx epilogue.
+// One launch covers the rows of one graph (statistics are per graph; a batch of B
+// clouds = B launches over contiguous row ranges, described by a host `gptr`).
+#include <math.h>
+
+#include "common.hpp"
+
+namespace spt {
+namespace fmlp {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int WAVES = 4;
+constexpr int TR = 16;          // rows per MFMA tile
+constexpr int MAX_BLOCKS = 1024;
+
+__device__ __forceinline__ double xg_sum_d(double v) {
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+__device__ __forceinline__ void wave_sync_lds() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Stage a [cnt x K] tile of row-major x into LDS (row stride LD), optionally applying
+// v <- leaky((v - am[k]) * sc[k] + bs[k]).  Rows >= cnt and columns >= K become 0.
+template <int KP, int LD>
+__device__ __forceinline__ void stage_tile(const float* __restrict__ x, int64_t row0, int cnt,
+                                           int K, bool pre, const float* __restrict__ am,
+                                           const float* __restrict__ sc,
+                                           const float* __restrict__ bs, float slope,
+                                           float* lds, int lane) {
+  for (int q = lane; q < TR * KP; q += 64) {
+    const int rr = q / KP, k = q - rr * KP;
+    float v = 0.f;
+    if (rr < cnt && k < K) {
+      v = x[(row0 + rr) * K + k];
+      if (pre) {
+        v = fmaf(v - am[k], sc[k], bs[k]);
+        v = (v > 0.f) ? v : v * slope;
+      }
+    }
+    lds[rr * LD + k] = v;
+  }
+}
+
+// ---- forward -------------------------------------------------------------------
+// K4 = ceil(K/4) k-steps, NBK = N/16 column blocks.
+template <int K4, int NBK>
+__global__ __launch_bounds__(WAVES * 64, 2) void fwd_kernel(
+    const float* __restrict__ x, int64_t r0, int64_t r1, int K, const float* __restrict__ W,
+    const float* __restrict__ am, const float* __restrict__ sc, const float* __restrict__ bs,
+    float slope, float* __restrict__ h, double* __restrict__ partial) {
+  constexpr int KP = K4 * 4, LDA = KP + 4, N = NBK * 16;
+  __shared__ __attribute__((aligned(16))) float a_lds[WAVES][TR * LDA];
+  __shared__ double red[WAVES][2 * N];
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, c = lane & 15;
+  float* al = a_lds[wid];
+  const bool pre = am != nullptr;
+
+  float B[NBK][K4];   // lane (g, c): W[16 nb + c][4 st + g]
+#pragma unroll
+  for (int nb = 0; nb < NBK; ++nb)
+#pragma unroll
+    for (int st = 0; st < K4; ++st) {
+      const int k = 4 * st + g;
+      B[nb][st] = (k < K) ? W[(size_t)(16 * nb + c) * K + k] : 0.f;
+    }
+  double s1[NBK], s2[NBK];
+#pragma unroll
+  for (int nb = 0; nb < NBK; ++nb) s1[nb] = s2[nb] = 0.0;
+
+  const int64_t ntiles = (r1 - r0 + TR - 1) / TR;
+  const int64_t wave = (int64_t)blockIdx.x * WAVES + wid;
+  const int64_t nwaves = (int64_t)gridDim.x * WAVES;
+  for (int64_t t = wave; t < ntiles; t += nwaves) {
+    const int64_t row0 = r0 + t * TR;
+    const int cnt = (int)((r1 - row0) < TR ? (r1 - row0) : TR);
+    wave_sync_lds();
+    stage_tile<KP, LDA>(x, row0, cnt, K, pre, am, sc, bs, slope, al, lane);
+    wave_sync_lds();
+    float A[K4];
+#pragma unroll
+    for (int st = 0; st < K4; ++st) A[st] = al[c * LDA + 4 * st + g];
+    f32x4 C[NBK];
+#pragma unroll
+    for (int nb = 0; nb < NBK; ++nb) C[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int st = 0; st < K4; ++st)
+#pragma unroll
+      for (int nb = 0; nb < NBK; ++nb)
+        C[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[st], B[nb][st], C[nb], 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int rr = 4 * g + r;
+      if (rr < cnt) {
+        float* hr = h + (row0 + rr) * N + c;
+#pragma unroll
+        for (int nb = 0; nb < NBK; ++nb) {
+          const float v = C[nb][r];
+          hr[16 * nb] = v;
+          s1[nb] += (double)v;
+          s2[nb] += (double)v * (double)v;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int nb = 0; nb < NBK; ++nb) {
+    const double a = xg_sum_d(s1[nb]), b = xg_sum_d(s2[nb]);
+    if (g == 0) {
+      red[wid][nb * 16 + c] = a;
+      red[wid][N + nb * 16 + c] = b;
+    }
+  }
+  __syncthreads();
+  double* out = partial + (size_t)blockIdx.x * (2 * N + 1);
+  for (int i = threadIdx.x; i < 2 * N; i += WAVES * 64)
+    out[i] = ((red[0][i] + red[1][i]) + red[2][i]) + red[3][i];
+  if (threadIdx.x == 0) out[2 * N] = (blockIdx.x == 0) ? (double)(r1 - r0) : 0.0;  // row count once
+}
+
+// ---- backward ------------------------------------------------------------------
+// gh[r, n] = c1[n] g - c2[n] o - c3[n],  g = gy * leaky'(y),  o = h - am,  y = o sc + bs
+// gx = gh W  (optional), gW += gh^T y_prev, previous-layer statistics from gx.
+template <int K4, int NBK, bool NEED_GX>
+__global__ __launch_bounds__(WAVES * 64, 1) void bwd_kernel(
+    const float* __restrict__ gy, const float* __restrict__ h, int64_t r0, int64_t r1,
+    const float* __restrict__ am, const float* __restrict__ sc, const float* __restrict__ bs,
+    float slope, const float* __restrict__ c1, const float* __restrict__ c2,
+    const float* __restrict__ c3, const float* __restrict__ xprev, int K,
+    const float* __restrict__ pam, const float* __restrict__ psc, const float* __restrict__ pbs,
+    float pslope, const float* __restrict__ W, float* __restrict__ gx,
+    float* __restrict__ gw_partial, double* __restrict__ pstat_partial) {
+  constexpr int KP = K4 * 4, KB = (KP + 15) / 16, KPP = KB * 16, N = NBK * 16;
+  constexpr int LDG = N + 4, LDX = KPP + 4;
+  __shared__ __attribute__((aligned(16))) float g_lds[WAVES][TR * LDG];   // gh tile
+  __shared__ __attribute__((aligned(16))) float x_lds[WAVES][TR * LDX];   // y_prev tile
+  __shared__ __attribute__((aligned(16))) float r_lds[WAVES][TR * LDX];   // raw h_prev tile
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, c = lane & 15;
+  float* gl = g_lds[wid];
+  float* xl = x_lds[wid];
+  float* rl = r_lds[wid];
+  const bool pre = pam != nullptr;
+
+  // weight-gradient accumulators: C3[nb][kb][r] = gW[16 nb + 4 g + r][16 kb + c]
+  f32x4 C3[NBK][KB];
+#pragma unroll
+  for (int nb = 0; nb < NBK; ++nb)
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) C3[nb][kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // B operands of gx = gh W: lane (g, c) holds W[4 st + g][16 kb + c], st < N/4
+  float BW[NEED_GX ? N / 4 : 1][NEED_GX ? KB : 1];
+  if constexpr (NEED_GX) {
+#pragma unroll
+    for (int st = 0; st < N / 4; ++st)
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        const int k = 16 * kb + c;
+        BW[st][kb] = (k < K) ? W[(size_t)(4 * st + g) * K + k] : 0.f;
+      }
+  }
+  double p1[KB], p2[KB];   // previous layer: sum g', sum g' o'   (columns 16 kb + c)
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) p1[kb] = p2[kb] = 0.0;
+
+  const int64_t ntiles = (r1 - r0 + TR - 1) / TR;
+  const int64_t wave = (int64_t)blockIdx.x * WAVES + wid;
+  const int64_t nwaves = (int64_t)gridDim.x * WAVES;
+  for (int64_t t = wave; t < ntiles; t += nwaves) {
+    const int64_t row0 = r0 + t * TR;
+    const int cnt = (int)((r1 - row0) < TR ? (r1 - row0) : TR);
+    wave_sync_lds();
+    // gh tile (coalesced reads of gy and h)
+    for (int q = lane; q < TR * N; q += 64) {
+      const int rr = q / N, n = q - rr * N;
+      float v = 0.f;
+      if (rr < cnt) {
+        const float o = h[(row0 + rr) * N + n] - am[n];
+        float gg = gy[(row0 + rr) * N + n];
+        if (slope != 1.f) {
+          const float y = fmaf(o, sc[n], bs[n]);
+          gg = (y > 0.f) ? gg : gg * slope;
+        }
+        v = fmaf(c1[n], gg, -fmaf(c2[n], o, c3[n]));
+      }
+      gl[rr * LDG + n] = v;
+    }
+    // y_prev tile and raw h_prev tile
+    for (int q = lane; q < TR * KPP; q += 64) {
+      const int rr = q / KPP, k = q - rr * KPP;
+      float raw = 0.f, v = 0.f;
+      if (rr < cnt && k < K) {
+        raw = xprev[(row0 + rr) * K + k];
+        v = raw;
+        if (pre) {
+          v = fmaf(raw - pam[k], psc[k], pbs[k]);
+          v = (v > 0.f) ? v : v * pslope;
+        }
+      }
+      xl[rr * LDX + k] = v;
+      rl[rr * LDX + k] = raw;
+    }
+    wave_sync_lds();
+    // ---- gW += gh^T y_prev : contraction index = row = 4 g + r  (k-slot = lane group)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float xb[KB];
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) xb[kb] = xl[(4 * g + r) * LDX + 16 * kb + c];
+#pragma unroll
+      for (int nb = 0; nb < NBK; ++nb) {
+        const float ga = gl[(4 * g + r) * LDG + 16 * nb + c];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+          C3[nb][kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga, xb[kb], C3[nb][kb], 0, 0, 0);
+      }
+    }
+    // ---- gx = gh W (+ statistics for the previous GraphNorm's backward) ------------
+    if constexpr (NEED_GX) {
+      f32x4 CX[KB];
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) CX[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int st = 0; st < N / 4; ++st) {
+        const float a = gl[c * LDG + 4 * st + g];       // A[i = row c][k = 4 st + g]
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+          CX[kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, BW[st][kb], CX[kb], 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rr = 4 * g + r;
+        if (rr < cnt) {
+#pragma unroll
+          for (int kb = 0; kb < KB; ++kb) {
+            const int k = 16 * kb + c;
+            if (k < K) {
+              const float v = CX[kb][r];
+              gx[(row0 + rr) * K + k] = v;
+              if (pre) {
+                const float o = rl[rr * LDX + k] - pam[k];
+                float gg = v;
+                if (pslope != 1.f) gg = (xl[rr * LDX + k] > 0.f) ? gg : gg * pslope;  // sign(y_prev)
+                p1[kb] += (double)gg;
+                p2[kb] += (double)gg * (double)o;
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+  // per-wave partial weight gradients [N][K] and previous-layer statistics
+  float* gwp = gw_partial + (size_t)wave * N * K;
+#pragma unroll
+  for (int nb = 0; nb < NBK; ++nb)
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k = 16 * kb + c;
+        if (k < K) gwp[(size_t)(16 * nb + 4 * g + r) * K + k] = C3[nb][kb][r];
+      }
+  if (pstat_partial) {
+    double* pp = pstat_partial + (size_t)wave * (2 * K + 1);
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      const double a = xg_sum_d(p1[kb]), b = xg_sum_d(p2[kb]);
+      const int k = 16 * kb + c;
+      if (g == 0 && k < K) {
+        pp[k] = a;
+        pp[K + k] = b;
+      }
+    }
+    if (lane == 0) pp[2 * K] = (wave == 0) ? (double)(r1 - r0) : 0.0;
+  }
+}
+
+// sums of per-wave tables, fixed order: 16 columns x 16 slices per block
+template <typename T>
+__global__ __launch_bounds__(256) void reduce_tables_kernel(const T* __restrict__ partial,
+                                                            int ntab, int len,
+                                                            T* __restrict__ total, int accumulate) {
+  __shared__ T sl[16][17];
+  const int cl = threadIdx.x & 15;
+  const int col = blockIdx.x * 16 + cl;
+  const int slice = threadIdx.x >> 4;
+  T acc = 0;
+  if (col < len) {
+    const int per = (ntab + 15) / 16;
+    const int lo = slice * per, hi = (lo + per < ntab) ? lo + per : ntab;
+    for (int k = lo; k < hi; ++k) acc += partial[(size_t)k * len + col];
+  }
+  sl[slice][cl] = acc;
+  __syncthreads();
+  if (slice == 0 && col < len) {
+    T t = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += sl[k][cl];
+    total[col] = accumulate ? total[col] + t : t;
+  }
+}
+
+static int grid_for(int64_t rows, int per_cu) {
+  const int64_t tiles = (rows + TR - 1) / TR;
+  int64_t blocks = (tiles + WAVES - 1) / WAVES;
+  const int64_t cap = 256 * per_cu;
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  return (int)blocks;
+}
+
+}  // namespace fmlp
+}  // namespace spt
+
+using namespace spt;
+using namespace spt::fmlp;
+
+// shapes built: (K, N) of the SPT MLPs; K <= 64 (K4 <= 16), N in {32, 64, 128}
+#define SPT_FMLP_SHAPES(X) X(3, 2) X(5, 2) X(8, 2) X(8, 4) X(16, 4) X(16, 8) X(17, 4) X(33, 4)
+
+extern "C" int spt_fused_linear_supported(int K, int N) {
+  const int k4 = (K + 3) / 4, nbk = N / 16;
+  if (N % 16) return 0;
+#define X(a, b) if (k4 == a && nbk == b) return 1;
+  SPT_FMLP_SHAPES(X)
+#undef X
+  return 0;
+}
+
+extern "C" size_t spt_fused_linear_workspace_bytes(int K, int N) {
+  // fwd: MAX_BLOCKS x (2N+1) doubles; bwd: 1024 waves x (N*K floats + (2K+1) doubles)
+  const size_t fwd = (size_t)MAX_BLOCKS * (2 * N + 1) * 8;
+  const size_t bwd = (size_t)256 * WAVES * ((size_t)N * K * 4 + (2 * K + 1) * 8);
+  return align_up(fwd > bwd ? fwd : bwd, 256) + 4096;
+}
+
+// h[r0:r1, :N] = act(gn_prev(x))[r0:r1, :K] W^T ; total[2N+1] = column sums, sums of
+// squares and the row count of h over [r0, r1)  (one graph).
+extern "C" int spt_fused_linear_fwd_f32(const float* x, int64_t r0, int64_t r1, int K,
+                                        const float* W, int N, const float* pre_am,
+                                        const float* pre_scale, const float* pre_bias,
+                                        float pre_slope, float* h, double* total, void* ws,
+                                        size_t ws_bytes, spt_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPT_CHECK_ARG(r1 >= r0 && K >= 1 && N >= 16, "bad shape");
+  SPT_CHECK_ARG(spt_fused_linear_supported(K, N), "(K, N) not built");
+  SPT_CHECK_ARG(x && W && h && total && ws, "null pointer");
+  SPT_CHECK_ARG(ws_bytes >= spt_fused_linear_workspace_bytes(K, N), "workspace too small");
+  SPT_CHECK_ARG(!pre_am || (pre_scale && pre_bias), "incomplete pre-normalisation tables");
+  const int k4 = (K + 3) / 4, nbk = N / 16;
+  const int grid = grid_for(r1 - r0, 2) < MAX_BLOCKS ? grid_for(r1 - r0, 2) : MAX_BLOCKS;
+  double* partial = (double*)ws;
+#define X(a, b)                                                                        \
+  if (k4 == a && nbk == b)                                                             \
+    fwd_kernel<a, b><<<grid, WAVES * 64, 0, stream>>>(x, r0, r1, K, W, pre_am, pre_scale, \
+                                                      pre_bias, pre_slope, h, partial);
+  SPT_FMLP_SHAPES(X)
+#undef X
+  reduce_tables_kernel<double><<<(2 * N + 1 + 15) / 16, 256, 0, stream>>>(partial, grid, 2 * N + 1,
+                                                                           total, 0);
+  SPT_CHECK_LAUNCH();
+  return 0;
+}
+
+// Backward of one layer over the rows [r0, r1) of one graph.
+//   gy, h [rows, N]; (am, scale, bias, slope): this layer's GraphNorm forward tables;
+//   (c1, c2, c3): its backward coefficient rows; xprev [rows, K] raw input of the layer
+//   with its own (pre_*) tables or NULL; gx [rows, K] or NULL; gW [N, K] is ACCUMULATED
+//   into when `accumulate` (further graphs of the batch); prev_total [2K+1] or NULL.
+extern "C" int spt_fused_linear_bwd_f32(const float* gy, const float* h, int64_t r0, int64_t r1,
+                                        int N, const float* am, const float* scale,
+                                        const float* bias, float slope, const float* c1,
+                                        const float* c2, const float* c3, const float* xprev,
+                                        int K, const float* pre_am, const float* pre_scale,
+                                        const float* pre_bias, float pre_slope, const float* W,
+                                        float* gx, float* gW, int accumulate,
+                                        double* prev_total, void* ws, size_t ws_bytes,
+                                        spt_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPT_CHECK_ARG(r1 >= r0 && K >= 1 && N >= 16, "bad shape");
+  SPT_CHECK_ARG(spt_fused_linear_supported(K, N), "(K, N) not built");
+  SPT_CHECK_ARG(gy && h && am && scale && bias && c1 && c2 && c3 && xprev && W && gW && ws,
+                "null pointer");
+  SPT_CHECK_ARG(ws_bytes >= spt_fused_linear_workspace_bytes(K, N), "workspace too small");
+  SPT_CHECK_ARG(!prev_total || (gx && pre_am), "previous-layer statistics need gx and its tables");
+  const int k4 = (K + 3) / 4, nbk = N / 16;
+  const int grid = grid_for(r1 - r0, 1);
+  const int nw = grid * WAVES;
+  float* gwp = (float*)ws;
+  double* pst = (double*)((char*)ws + align_up((size_t)256 * WAVES * N * K * 4, 256));
+#define X(a, b)                                                                                  \
+  if (k4 == a && nbk == b) {                                                                     \
+    if (gx)                                                                                      \
+      bwd_kernel<a, b, true><<<grid, WAVES * 64, 0, stream>>>(                                   \
+          gy, h, r0, r1, am, scale, bias, slope, c1, c2, c3, xprev, K, pre_am, pre_scale,        \
+          pre_bias, pre_slope, W, gx, gwp, prev_total ? pst : nullptr);                          \
+    else                                                                                         \
+      bwd_kernel<a, b, false><<<grid, WAVES * 64, 0, stream>>>(                                  \
+          gy, h, r0, r1, am, scale, bias, slope, c1, c2, c3, xprev, K, pre_am, pre_scale,        \
+          pre_bias, pre_slope, W, nullptr, gwp, nullptr);                                        \
+  }
+  SPT_FMLP_SHAPES(X)
+#undef X
+  reduce_tables_kernel<float><<<(N * K + 15) / 16, 256, 0, stream>>>(gwp, nw, N * K, gW, accumulate);
+  if (prev_total)
+    reduce_tables_kernel<double><<<(2 * K + 1 + 15) / 16, 256, 0, stream>>>(pst, nw, 2 * K + 1,
+                                                                            prev_total, 0);
+  SPT_CHECK_LAUNCH();
+  return 0;
+}

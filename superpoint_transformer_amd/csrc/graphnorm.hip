@@ -505,3 +505,78 @@ extern "C" int spt_graphnorm_bwd_f32(const float* x, const float* gy,
   SPT_CHECK_LAUNCH();
   return 0;
 }
+
+// ---- pieces of the two-pass scheme, exposed for the fused MLP layers (fused_mlp.hip),
+//      which produce / consume the per-graph totals themselves -------------------------
+
+// totals [B][2d+1] (sum x, sum x^2, row count) -> mean, rstd, am = alpha*mean, scale = w*rstd
+extern "C" int spt_graphnorm_tables_f32(const double* total, int num_graphs, int d,
+                                        const float* weight, const float* mean_scale,
+                                        float eps, float* mean, float* rstd, float* am,
+                                        float* scale, spt_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPT_CHECK_ARG(num_graphs >= 1 && d >= 1, "bad shape");
+  SPT_CHECK_ARG(total && weight && mean_scale && mean && rstd && am && scale, "null pointer");
+  gn_fwd_tables_kernel<<<(num_graphs * d + 255) / 256, 256, 0, stream>>>(
+      total, num_graphs, d, weight, mean_scale, eps, mean, rstd, am, scale);
+  SPT_CHECK_LAUNCH();
+  return 0;
+}
+
+// y = leaky((x - am[batch]) * scale[batch] + bias)
+extern "C" int spt_graphnorm_apply_f32(const float* x, const int64_t* batch, int64_t r, int d,
+                                       int num_graphs, const float* am, const float* scale,
+                                       const float* bias, float act_slope, float* y,
+                                       spt_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPT_CHECK_ARG(r >= 0 && d >= 1 && num_graphs >= 1, "bad shape");
+  GnPlan p;
+  SPT_CHECK_ARG(gn_plan(r, d, num_graphs, &p), "dim > 1024 unsupported");
+  if (r == 0) return 0;
+  SPT_CHECK_ARG(x && y && am && scale && bias, "null pointer");
+  if (p.sh.vec == 4)
+    gn_apply_fwd_kernel<4><<<p.nblocks * 2, GN_THREADS, 0, stream>>>(x, batch, r, d, p.sh.lpr_log2, am, scale, bias, act_slope, y);
+  else if (p.sh.vec == 2)
+    gn_apply_fwd_kernel<2><<<p.nblocks * 2, GN_THREADS, 0, stream>>>(x, batch, r, d, p.sh.lpr_log2, am, scale, bias, act_slope, y);
+  else
+    gn_apply_fwd_kernel<1><<<p.nblocks * 2, GN_THREADS, 0, stream>>>(x, batch, r, d, p.sh.lpr_log2, am, scale, bias, act_slope, y);
+  SPT_CHECK_LAUNCH();
+  return 0;
+}
+
+// totals [B][2d+1] = (sum g, sum g*o, row count), g = gy * leaky'(y), o = x - am
+extern "C" int spt_graphnorm_bwd_stats_f32(const float* x, const float* gy, const int64_t* batch,
+                                           int64_t r, int d, int num_graphs, const float* am,
+                                           const float* scale, const float* bias,
+                                           float act_slope, double* total, void* ws,
+                                           size_t ws_bytes, spt_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int B = num_graphs;
+  SPT_CHECK_ARG(r >= 0 && d >= 1 && B >= 1, "bad shape");
+  GnPlan p;
+  SPT_CHECK_ARG(gn_plan(r, d, B, &p), "dim > 1024 unsupported");
+  if (int e = gn_check(r, d, B, p, ws, ws_bytes)) return e;
+  SPT_CHECK_ARG(total && am && scale && bias && (r == 0 || (x && gy)), "null pointer");
+  double* partial = (double*)((char*)ws + p.off_partial);
+  launch_stats<true>(p, x, gy, batch, r, d, B, am, scale, bias, act_slope, partial, stream);
+  gn_reduce_partials_kernel<<<dim3(B, (p.row_len + 15) / 16), 256, 0, stream>>>(partial, p.nblocks, B, p.row_len, total);
+  SPT_CHECK_LAUNCH();
+  return 0;
+}
+
+// backward coefficient rows (gx = c1*g - c2*o - c3) and the three parameter gradients
+extern "C" int spt_graphnorm_bwd_tables_f32(const double* total, int num_graphs, int d,
+                                            const float* weight, const float* mean_scale,
+                                            const float* mean, const float* rstd, float* c1,
+                                            float* c2, float* c3, float* gweight, float* gbias,
+                                            float* gmean_scale, spt_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPT_CHECK_ARG(num_graphs >= 1 && d >= 1, "bad shape");
+  SPT_CHECK_ARG(total && weight && mean_scale && mean && rstd && c1 && c2 && c3 && gweight &&
+                gbias && gmean_scale, "null pointer");
+  gn_bwd_tables_kernel<<<(d + 127) / 128, 128, 0, stream>>>(total, num_graphs, d, weight, mean_scale,
+                                                            mean, rstd, c1, c2, c3, gweight, gbias,
+                                                            gmean_scale);
+  SPT_CHECK_LAUNCH();
+  return 0;
+}

@@ -33,7 +33,34 @@ class MLP(nn.Module):
         self.mlp = _mlp(dims, activation, last_activation, norm, last_norm, drop)
         self.out_dim = dims[-1]
 
+    def _fused_layers(self):
+        """[(W, gn_weight, gn_bias, gn_mean_scale, eps, slope)] when the stack is
+        exactly [bias-free Linear -> GraphNorm (-> LeakyReLU)] x L, else None."""
+        mods = list(self.mlp)
+        out, i = [], 0
+        while i < len(mods):
+            lin = mods[i]
+            gn = mods[i + 1] if i + 1 < len(mods) else None
+            if not (isinstance(lin, nn.Linear) and lin.bias is None and isinstance(gn, GraphNorm)):
+                return None
+            act = mods[i + 2] if i + 2 < len(mods) else None
+            if isinstance(act, nn.LeakyReLU):
+                out.append((lin.weight, gn.weight, gn.bias, gn.mean_scale, gn.eps, act.negative_slope))
+                i += 3
+            else:
+                out.append((lin.weight, gn.weight, gn.bias, gn.mean_scale, gn.eps, 1.0))
+                i += 2
+        return out or None
+
+    FUSE_MIN_ROWS = 16384
+
     def forward(self, x, batch=None, batch_size=None):
+        if x.is_cuda and x.shape[0] >= self.FUSE_MIN_ROWS and (batch is None or batch_size is not None):
+            layers = self._fused_layers()
+            if layers is not None:
+                y = ops.fused_mlp(x, batch, batch_size, layers)
+                if y is not None:
+                    return y
         mods = list(self.mlp)
         i = 0
         while i < len(mods):
