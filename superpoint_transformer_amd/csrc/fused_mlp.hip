@@ -38,26 +38,52 @@ __device__ __forceinline__ void wave_sync_lds() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Stage a [cnt x K] tile of row-major x into LDS (row stride LD), optionally applying
-// v <- leaky((v - am[k]) * sc[k] + bs[k]).  Rows >= cnt and columns >= K become 0.
-template <int KP, int LD>
+// Stage a [cnt x K] tile of row-major x into LDS (row stride LD) with the widest
+// aligned vector loads, optionally applying v <- leaky((v - am[k]) * sc[k] + bs[k])
+// with the per-column tables read from LDS (tab = am | sc | bs, KT floats each).
+// Rows >= cnt and columns >= K become 0.  RAW != nullptr also keeps the raw values.
+template <int KP, int LD, int KT>
 __device__ __forceinline__ void stage_tile(const float* __restrict__ x, int64_t row0, int cnt,
-                                           int K, bool pre, const float* __restrict__ am,
-                                           const float* __restrict__ sc,
-                                           const float* __restrict__ bs, float slope,
-                                           float* lds, int lane) {
-  for (int q = lane; q < TR * KP; q += 64) {
-    const int rr = q / KP, k = q - rr * KP;
-    float v = 0.f;
-    if (rr < cnt && k < K) {
-      v = x[(row0 + rr) * K + k];
-      if (pre) {
-        v = fmaf(v - am[k], sc[k], bs[k]);
+                                           int K, bool pre, const float* tab, float slope,
+                                           float* lds, float* raw, int lane) {
+  if ((K & 3) == 0) {
+    const int CH = K >> 2;
+    for (int q = lane; q < TR * CH; q += 64) {
+      const int rr = q / CH, k = (q - rr * CH) << 2;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (rr < cnt) v = *reinterpret_cast<const float4*>(x + (row0 + rr) * K + k);
+      if (raw) *reinterpret_cast<float4*>(raw + rr * LD + k) = v;
+      if (pre && rr < cnt) {
+        const float4 a = *reinterpret_cast<const float4*>(tab + k);
+        const float4 s = *reinterpret_cast<const float4*>(tab + KT + k);
+        const float4 b = *reinterpret_cast<const float4*>(tab + 2 * KT + k);
+        v.x = fmaf(v.x - a.x, s.x, b.x); v.y = fmaf(v.y - a.y, s.y, b.y);
+        v.z = fmaf(v.z - a.z, s.z, b.z); v.w = fmaf(v.w - a.w, s.w, b.w);
+        v.x = v.x > 0.f ? v.x : v.x * slope; v.y = v.y > 0.f ? v.y : v.y * slope;
+        v.z = v.z > 0.f ? v.z : v.z * slope; v.w = v.w > 0.f ? v.w : v.w * slope;
+      }
+      *reinterpret_cast<float4*>(lds + rr * LD + k) = v;
+    }
+    // zero the padding columns [K, KP) once per tile (K % 4 == 0 => KP == K: nothing)
+  } else {
+    for (int q = lane; q < TR * KP; q += 64) {
+      const int rr = q / KP, k = q - rr * KP;
+      float v = 0.f;
+      if (rr < cnt && k < K) v = x[(row0 + rr) * K + k];
+      if (raw) raw[rr * LD + k] = v;
+      if (pre && rr < cnt && k < K) {
+        v = fmaf(v - tab[k], tab[KT + k], tab[2 * KT + k]);
         v = (v > 0.f) ? v : v * slope;
       }
+      lds[rr * LD + k] = v;
     }
-    lds[rr * LD + k] = v;
   }
+}
+
+// copy n floats (or zeros when src is null) into LDS, whole workgroup
+__device__ __forceinline__ void load_table(float* dst, const float* __restrict__ src, int n,
+                                           int cap) {
+  for (int i = threadIdx.x; i < cap; i += WAVES * 64) dst[i] = (src && i < n) ? src[i] : 0.f;
 }
 
 // ---- forward -------------------------------------------------------------------
@@ -69,12 +95,19 @@ __global__ __launch_bounds__(WAVES * 64, 2) void fwd_kernel(
     float slope, float* __restrict__ h, double* __restrict__ partial) {
   constexpr int KP = K4 * 4, LDA = KP + 4, N = NBK * 16;
   __shared__ __attribute__((aligned(16))) float a_lds[WAVES][TR * LDA];
+  __shared__ __attribute__((aligned(16))) float tab[3 * KP];   // am | sc | bs of the previous norm
   __shared__ double red[WAVES][2 * N];
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, c = lane & 15;
   float* al = a_lds[wid];
   const bool pre = am != nullptr;
+  load_table(tab, am, K, KP);
+  load_table(tab + KP, sc, K, KP);
+  load_table(tab + 2 * KP, bs, K, KP);
+  // padding columns of the A tile stay zero for the whole kernel
+  for (int i = lane; i < TR * LDA; i += 64) al[i] = 0.f;
+  __syncthreads();
 
   float B[NBK][K4];   // lane (g, c): W[16 nb + c][4 st + g]
 #pragma unroll
@@ -95,7 +128,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void fwd_kernel(
     const int64_t row0 = r0 + t * TR;
     const int cnt = (int)((r1 - row0) < TR ? (r1 - row0) : TR);
     wave_sync_lds();
-    stage_tile<KP, LDA>(x, row0, cnt, K, pre, am, sc, bs, slope, al, lane);
+    stage_tile<KP, LDA, KP>(x, row0, cnt, K, pre, tab, slope, al, nullptr, lane);
     wave_sync_lds();
     float A[K4];
 #pragma unroll
@@ -158,10 +191,23 @@ __global__ __launch_bounds__(WAVES * 64, 1) void bwd_kernel(
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, c = lane & 15;
+  __shared__ __attribute__((aligned(16))) float gt[6 * N];      // am | sc | bs | c1 | c2 | c3
+  __shared__ __attribute__((aligned(16))) float pt[3 * KPP];    // previous norm: am | sc | bs
   float* gl = g_lds[wid];
   float* xl = x_lds[wid];
   float* rl = r_lds[wid];
   const bool pre = pam != nullptr;
+  load_table(gt, am, N, N);
+  load_table(gt + N, sc, N, N);
+  load_table(gt + 2 * N, bs, N, N);
+  load_table(gt + 3 * N, c1, N, N);
+  load_table(gt + 4 * N, c2, N, N);
+  load_table(gt + 5 * N, c3, N, N);
+  load_table(pt, pam, K, KPP);
+  load_table(pt + KPP, psc, K, KPP);
+  load_table(pt + 2 * KPP, pbs, K, KPP);
+  for (int i = lane; i < TR * LDX; i += 64) xl[i] = rl[i] = 0.f;
+  __syncthreads();
 
   // weight-gradient accumulators: C3[nb][kb][r] = gW[16 nb + 4 g + r][16 kb + c]
   f32x4 C3[NBK][KB];
@@ -191,36 +237,43 @@ __global__ __launch_bounds__(WAVES * 64, 1) void bwd_kernel(
     const int64_t row0 = r0 + t * TR;
     const int cnt = (int)((r1 - row0) < TR ? (r1 - row0) : TR);
     wave_sync_lds();
-    // gh tile (coalesced reads of gy and h)
-    for (int q = lane; q < TR * N; q += 64) {
-      const int rr = q / N, n = q - rr * N;
-      float v = 0.f;
-      if (rr < cnt) {
-        const float o = h[(row0 + rr) * N + n] - am[n];
-        float gg = gy[(row0 + rr) * N + n];
-        if (slope != 1.f) {
-          const float y = fmaf(o, sc[n], bs[n]);
-          gg = (y > 0.f) ? gg : gg * slope;
+    // gh tile: each lane owns one 4-column group, 16-byte loads of gy and h
+    {
+      constexpr int CH = N / 4;
+      for (int q = lane; q < TR * CH; q += 64) {
+        const int rr = q / CH, n = (q - rr * CH) << 2;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rr < cnt) {
+          const float4 hv = *reinterpret_cast<const float4*>(h + (row0 + rr) * N + n);
+          const float4 gv = *reinterpret_cast<const float4*>(gy + (row0 + rr) * N + n);
+          const float4 a = *reinterpret_cast<const float4*>(gt + n);
+          const float4 sc4 = *reinterpret_cast<const float4*>(gt + N + n);
+          const float4 b4 = *reinterpret_cast<const float4*>(gt + 2 * N + n);
+          const float4 k1 = *reinterpret_cast<const float4*>(gt + 3 * N + n);
+          const float4 k2 = *reinterpret_cast<const float4*>(gt + 4 * N + n);
+          const float4 k3 = *reinterpret_cast<const float4*>(gt + 5 * N + n);
+          const float hh[4] = {hv.x, hv.y, hv.z, hv.w}, gg4[4] = {gv.x, gv.y, gv.z, gv.w};
+          const float aa[4] = {a.x, a.y, a.z, a.w}, ss[4] = {sc4.x, sc4.y, sc4.z, sc4.w};
+          const float bb[4] = {b4.x, b4.y, b4.z, b4.w}, q1[4] = {k1.x, k1.y, k1.z, k1.w};
+          const float q2[4] = {k2.x, k2.y, k2.z, k2.w}, q3[4] = {k3.x, k3.y, k3.z, k3.w};
+          float o4[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float o = hh[e] - aa[e];
+            float gg = gg4[e];
+            if (slope != 1.f) {
+              const float y = fmaf(o, ss[e], bb[e]);
+              gg = (y > 0.f) ? gg : gg * slope;
+            }
+            o4[e] = fmaf(q1[e], gg, -fmaf(q2[e], o, q3[e]));
+          }
+          v = make_float4(o4[0], o4[1], o4[2], o4[3]);
         }
-        v = fmaf(c1[n], gg, -fmaf(c2[n], o, c3[n]));
+        *reinterpret_cast<float4*>(gl + rr * LDG + n) = v;
       }
-      gl[rr * LDG + n] = v;
     }
-    // y_prev tile and raw h_prev tile
-    for (int q = lane; q < TR * KPP; q += 64) {
-      const int rr = q / KPP, k = q - rr * KPP;
-      float raw = 0.f, v = 0.f;
-      if (rr < cnt && k < K) {
-        raw = xprev[(row0 + rr) * K + k];
-        v = raw;
-        if (pre) {
-          v = fmaf(raw - pam[k], psc[k], pbs[k]);
-          v = (v > 0.f) ? v : v * pslope;
-        }
-      }
-      xl[rr * LDX + k] = v;
-      rl[rr * LDX + k] = raw;
-    }
+    // y_prev tile (normalised + activated on the way) and raw h_prev tile
+    stage_tile<KPP, LDX, KPP>(xprev, row0, cnt, K, pre, pt, pslope, xl, rl, lane);
     wave_sync_lds();
     // ---- gW += gh^T y_prev : contraction index = row = 4 g + r  (k-slot = lane group)
 #pragma unroll
@@ -259,7 +312,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void bwd_kernel(
               const float v = CX[kb][r];
               gx[(row0 + rr) * K + k] = v;
               if (pre) {
-                const float o = rl[rr * LDX + k] - pam[k];
+                const float o = rl[rr * LDX + k] - pt[k];
                 float gg = v;
                 if (pslope != 1.f) gg = (xl[rr * LDX + k] > 0.f) ? gg : gg * pslope;  // sign(y_prev)
                 p1[kb] += (double)gg;
