@@ -174,8 +174,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void fwd_kernel(
 // ---- backward ------------------------------------------------------------------
 // gh[r, n] = c1[n] g - c2[n] o - c3[n],  g = gy * leaky'(y),  o = h - am,  y = o sc + bs
 // gx = gh W  (optional), gW += gh^T y_prev, previous-layer statistics from gx.
-template <int K4, int NBK, bool NEED_GX>
-__global__ __launch_bounds__(WAVES * 64, 1) void bwd_kernel(
+// NW waves per workgroup share the LDS copies of the tables and (when the weight
+// block is too big for B-operand registers next to the gW accumulators) of W itself:
+// the 64 -> 128 layer then runs 2 waves per SIMD instead of 1.
+template <int K4, int NBK, bool NEED_GX, int NW, bool W_IN_LDS>
+__global__ __launch_bounds__(NW * 64, NW / 4) void bwd_kernel(
     const float* __restrict__ gy, const float* __restrict__ h, int64_t r0, int64_t r1,
     const float* __restrict__ am, const float* __restrict__ sc, const float* __restrict__ bs,
     float slope, const float* __restrict__ c1, const float* __restrict__ c2,
@@ -185,9 +188,9 @@ __global__ __launch_bounds__(WAVES * 64, 1) void bwd_kernel(
     float* __restrict__ gw_partial, double* __restrict__ pstat_partial) {
   constexpr int KP = K4 * 4, KB = (KP + 15) / 16, KPP = KB * 16, N = NBK * 16;
   constexpr int LDG = N + 4, LDX = KPP + 4;
-  __shared__ __attribute__((aligned(16))) float g_lds[WAVES][TR * LDG];   // gh tile
-  __shared__ __attribute__((aligned(16))) float x_lds[WAVES][TR * LDX];   // y_prev tile
-  __shared__ __attribute__((aligned(16))) float r_lds[WAVES][TR * LDX];   // raw h_prev tile
+  __shared__ __attribute__((aligned(16))) float g_lds[NW][TR * LDG];   // gh tile
+  __shared__ __attribute__((aligned(16))) float x_lds[NW][TR * LDX];   // RAW h_prev tile
+  __shared__ __attribute__((aligned(16))) float w_lds[(NEED_GX && W_IN_LDS) ? N * KPP : 4];
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, c = lane & 15;
@@ -195,8 +198,13 @@ __global__ __launch_bounds__(WAVES * 64, 1) void bwd_kernel(
   __shared__ __attribute__((aligned(16))) float pt[3 * KPP];    // previous norm: am | sc | bs
   float* gl = g_lds[wid];
   float* xl = x_lds[wid];
-  float* rl = r_lds[wid];
   const bool pre = pam != nullptr;
+  if constexpr (NEED_GX && W_IN_LDS) {
+    for (int i = threadIdx.x; i < N * KPP; i += NW * 64) {
+      const int n = i / KPP, k = i - n * KPP;
+      w_lds[i] = (k < K) ? W[(size_t)n * K + k] : 0.f;
+    }
+  }
   load_table(gt, am, N, N);
   load_table(gt + N, sc, N, N);
   load_table(gt + 2 * N, bs, N, N);
@@ -206,7 +214,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void bwd_kernel(
   load_table(pt, pam, K, KPP);
   load_table(pt + KPP, psc, K, KPP);
   load_table(pt + 2 * KPP, pbs, K, KPP);
-  for (int i = lane; i < TR * LDX; i += 64) xl[i] = rl[i] = 0.f;
+  for (int i = lane; i < TR * LDX; i += 64) xl[i] = 0.f;
   __syncthreads();
 
   // weight-gradient accumulators: C3[nb][kb][r] = gW[16 nb + 4 g + r][16 kb + c]
@@ -216,8 +224,8 @@ __global__ __launch_bounds__(WAVES * 64, 1) void bwd_kernel(
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) C3[nb][kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
   // B operands of gx = gh W: lane (g, c) holds W[4 st + g][16 kb + c], st < N/4
-  float BW[NEED_GX ? N / 4 : 1][NEED_GX ? KB : 1];
-  if constexpr (NEED_GX) {
+  float BW[(NEED_GX && !W_IN_LDS) ? N / 4 : 1][(NEED_GX && !W_IN_LDS) ? KB : 1];
+  if constexpr (NEED_GX && !W_IN_LDS) {
 #pragma unroll
     for (int st = 0; st < N / 4; ++st)
 #pragma unroll
@@ -231,8 +239,8 @@ __global__ __launch_bounds__(WAVES * 64, 1) void bwd_kernel(
   for (int kb = 0; kb < KB; ++kb) p1[kb] = p2[kb] = 0.0;
 
   const int64_t ntiles = (r1 - r0 + TR - 1) / TR;
-  const int64_t wave = (int64_t)blockIdx.x * WAVES + wid;
-  const int64_t nwaves = (int64_t)gridDim.x * WAVES;
+  const int64_t wave = (int64_t)blockIdx.x * NW + wid;
+  const int64_t nwaves = (int64_t)gridDim.x * NW;
   for (int64_t t = wave; t < ntiles; t += nwaves) {
     const int64_t row0 = r0 + t * TR;
     const int cnt = (int)((r1 - row0) < TR ? (r1 - row0) : TR);
@@ -272,15 +280,24 @@ __global__ __launch_bounds__(WAVES * 64, 1) void bwd_kernel(
         *reinterpret_cast<float4*>(gl + rr * LDG + n) = v;
       }
     }
-    // y_prev tile (normalised + activated on the way) and raw h_prev tile
-    stage_tile<KPP, LDX, KPP>(xprev, row0, cnt, K, pre, pt, pslope, xl, rl, lane);
+    // RAW h_prev tile; y_prev = leaky(gn(raw)) is formed where it is consumed
+    stage_tile<KPP, LDX, KPP>(xprev, row0, cnt, K, false, pt, pslope, xl, nullptr, lane);
     wave_sync_lds();
     // ---- gW += gh^T y_prev : contraction index = row = 4 g + r  (k-slot = lane group)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float xb[KB];
 #pragma unroll
-      for (int kb = 0; kb < KB; ++kb) xb[kb] = xl[(4 * g + r) * LDX + 16 * kb + c];
+      for (int kb = 0; kb < KB; ++kb) {
+        const int k = 16 * kb + c;
+        float v = xl[(4 * g + r) * LDX + k];
+        if (pre) {
+          v = fmaf(v - pt[k], pt[KPP + k], pt[2 * KPP + k]);
+          v = (v > 0.f) ? v : v * pslope;
+          v = (4 * g + r < cnt && k < K) ? v : 0.f;   // padding rows / columns contribute nothing
+        }
+        xb[kb] = v;
+      }
 #pragma unroll
       for (int nb = 0; nb < NBK; ++nb) {
         const float ga = gl[(4 * g + r) * LDG + 16 * nb + c];
@@ -298,8 +315,12 @@ __global__ __launch_bounds__(WAVES * 64, 1) void bwd_kernel(
       for (int st = 0; st < N / 4; ++st) {
         const float a = gl[c * LDG + 4 * st + g];       // A[i = row c][k = 4 st + g]
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb)
-          CX[kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, BW[st][kb], CX[kb], 0, 0, 0);
+        for (int kb = 0; kb < KB; ++kb) {
+          float b;
+          if constexpr (W_IN_LDS) b = w_lds[(4 * st + g) * KPP + 16 * kb + c];
+          else b = BW[st][kb];
+          CX[kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, CX[kb], 0, 0, 0);
+        }
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -312,9 +333,12 @@ __global__ __launch_bounds__(WAVES * 64, 1) void bwd_kernel(
               const float v = CX[kb][r];
               gx[(row0 + rr) * K + k] = v;
               if (pre) {
-                const float o = rl[rr * LDX + k] - pt[k];
+                const float o = xl[rr * LDX + k] - pt[k];
                 float gg = v;
-                if (pslope != 1.f) gg = (xl[rr * LDX + k] > 0.f) ? gg : gg * pslope;  // sign(y_prev)
+                if (pslope != 1.f) {
+                  const float y = fmaf(o, pt[KPP + k], pt[2 * KPP + k]);
+                  gg = (y > 0.f) ? gg : gg * pslope;
+                }
                 p1[kb] += (double)gg;
                 p2[kb] += (double)gg * (double)o;
               }
@@ -375,6 +399,15 @@ __global__ __launch_bounds__(256) void reduce_tables_kernel(const T* __restrict_
   }
 }
 
+static int grid_for_nw(int64_t rows, int per_cu, int nwv) {
+  const int64_t tiles = (rows + TR - 1) / TR;
+  int64_t blocks = (tiles + nwv - 1) / nwv;
+  const int64_t cap = 256 * per_cu;
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  return (int)blocks;
+}
+
 static int grid_for(int64_t rows, int per_cu) {
   const int64_t tiles = (rows + TR - 1) / TR;
   int64_t blocks = (tiles + WAVES - 1) / WAVES;
@@ -405,7 +438,7 @@ extern "C" int spt_fused_linear_supported(int K, int N) {
 extern "C" size_t spt_fused_linear_workspace_bytes(int K, int N) {
   // fwd: MAX_BLOCKS x (2N+1) doubles; bwd: 1024 waves x (N*K floats + (2K+1) doubles)
   const size_t fwd = (size_t)MAX_BLOCKS * (2 * N + 1) * 8;
-  const size_t bwd = (size_t)256 * WAVES * ((size_t)N * K * 4 + (2 * K + 1) * 8);
+  const size_t bwd = (size_t)256 * 8 * ((size_t)N * K * 4 + (2 * K + 1) * 8);
   return align_up(fwd > bwd ? fwd : bwd, 256) + 4096;
 }
 
@@ -459,18 +492,21 @@ extern "C" int spt_fused_linear_bwd_f32(const float* gy, const float* h, int64_t
   SPT_CHECK_ARG(ws_bytes >= spt_fused_linear_workspace_bytes(K, N), "workspace too small");
   SPT_CHECK_ARG(!prev_total || (gx && pre_am), "previous-layer statistics need gx and its tables");
   const int k4 = (K + 3) / 4, nbk = N / 16;
-  const int grid = grid_for(r1 - r0, 1);
-  const int nw = grid * WAVES;
+  int grid = 1, nw = 1;
   float* gwp = (float*)ws;
-  double* pst = (double*)((char*)ws + align_up((size_t)256 * WAVES * N * K * 4, 256));
+  double* pst = (double*)((char*)ws + align_up((size_t)256 * 8 * N * K * 4, 256));
 #define X(a, b)                                                                                  \
   if (k4 == a && nbk == b) {                                                                     \
+    constexpr bool big = (a * b >= 96);   /* (N/4)*(K/16) B-operand registers would not fit */  \
+    constexpr int NWV = big ? 8 : 4;                                                             \
+    grid = grid_for_nw(r1 - r0, 1, NWV);                                                         \
+    nw = grid * NWV;                                                                             \
     if (gx)                                                                                      \
-      bwd_kernel<a, b, true><<<grid, WAVES * 64, 0, stream>>>(                                   \
+      bwd_kernel<a, b, true, NWV, big><<<grid, NWV * 64, 0, stream>>>(                           \
           gy, h, r0, r1, am, scale, bias, slope, c1, c2, c3, xprev, K, pre_am, pre_scale,        \
           pre_bias, pre_slope, W, gx, gwp, prev_total ? pst : nullptr);                          \
     else                                                                                         \
-      bwd_kernel<a, b, false><<<grid, WAVES * 64, 0, stream>>>(                                  \
+      bwd_kernel<a, b, false, NWV, big><<<grid, NWV * 64, 0, stream>>>(                          \
           gy, h, r0, r1, am, scale, bias, slope, c1, c2, c3, xprev, K, pre_am, pre_scale,        \
           pre_bias, pre_slope, W, nullptr, gwp, nullptr);                                        \
   }
