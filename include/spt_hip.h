@@ -245,6 +245,37 @@ int spt_point_geof_csr_f32(const float* xyz, int64_t n, const int64_t* nn_val,
                            float* feats, spt_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * Per-segment random sampling without replacement                      (f2/f3)
+ * Replaces sparse_sample (src/utils/sparse.py:142-243) behind NAG.get_sampling
+ * (src/data/nag.py:672-711): shuffle + stable sort by segment + take the first
+ * n_samples[s] of every segment, with
+ *   n_samples = clamp(floor(n_max * tanh(size / n_max)), n_min, size)   (n_max > 0)
+ *             = clamp(round(sqrt(size)), n_min, size)                   (n_max <= 0)
+ * mask (nullable, 1 = keep): heuristic on the unmasked sizes, then clamped to the
+ * number of kept elements (sparse.py:180-205).  seed: counter-based RNG, same seed
+ * => same draw.  out_ptr [num_seg+1] int64 (out_ptr[num_seg] = number of samples,
+ * never more than n), out_idx [n] int64 (only the first out_ptr[num_seg] are written).
+ * ---------------------------------------------------------------------- */
+size_t spt_sparse_sample_workspace_bytes(int64_t n, int64_t num_seg);
+int spt_sparse_sample(const int64_t* idx, int64_t n, int64_t num_seg, const uint8_t* mask,
+                      int n_max, int n_min, uint64_t seed, int64_t* out_ptr,
+                      int64_t* out_idx, void* ws, size_t ws_bytes, spt_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Segment statistics of SegmentFeatures                                   (f2)
+ * spt_segment_std_f32: torch_scatter.scatter_std(x, idx, dim=0) (unbiased, denominator
+ *   max(cnt-1, 1) + 1e-6) as called at src/transforms/graph.py:285; x [n,c], out [num_seg,c].
+ * spt_segment_mean_orientation_f32: scatter_mean_orientation
+ *   (src/utils/scatter.py:249-300); orientation [n,3] -> out [num_seg,3] (unit, z >= 0).
+ * Rows are visited through the CSR view (perm nullable = already grouped).
+ * ---------------------------------------------------------------------- */
+int spt_segment_std_f32(const float* x, const int32_t* perm, const int32_t* rowptr,
+                        int64_t num_seg, int c, float* out, spt_stream_t stream);
+int spt_segment_mean_orientation_f32(const float* orientation, const int32_t* perm,
+                                     const int32_t* rowptr, int64_t num_seg, float* out,
+                                     spt_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * On-the-fly horizontal edge features + symmetrisation + self loops   (f1)
  * Replaces _on_the_fly_horizontal_edge_features (src/transforms/graph.py:1135-1277,
  * all default keys) followed by NAGAddSelfLoops (:1419-1452).

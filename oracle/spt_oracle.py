@@ -432,7 +432,7 @@ def geometric_features(xyz, nn, k_min=1, add_self_as_neighbor=True):
     [lin, plan, scat, vert, nx, ny, nz, length, surface, volume, curvature]
     AFTER the post-processing of geometry.py:121,124 (verticality*2, normal
     flipped to z>=0)."""
-    N = xyz.shape[0]
+    N = nn.shape[0]      # one feature row per neighbourhood (== xyz rows when add_self)
     if add_self_as_neighbor:                                   # geometry.py:95-96
         nn = torch.cat((torch.arange(N).view(-1, 1), nn), dim=1)
     ptr, val, sizes = neighbors_dense_to_csr(nn)               # geometry.py:347
@@ -509,3 +509,99 @@ def horizontal_edge_features(se, edge_attr7, pos, normal, log_length, log_surfac
         ei = torch.cat((ei, torch.stack((loops, loops))), dim=1)
         attr = torch.cat((attr, torch.zeros((n, attr.shape[1]), dtype=attr.dtype)), 0)
     return ei, attr
+
+
+# --------------------------------------------------------------------------
+# segment-level preprocessing
+# --------------------------------------------------------------------------
+
+
+def sparse_sample_counts(idx, n_max=32, n_min=1, mask=None):
+    """The deterministic part of sparse_sample (src/utils/sparse.py:168-205,
+    237-243): how many elements each segment contributes and the resulting
+    pointers.  (Which elements are drawn is random: randperm + stable sort,
+    sparse.py:217-231.)"""
+    assert 0 <= n_min <= n_max
+    size = idx.bincount()
+    num_segments = int(idx.max()) + 1
+    if n_max > 0:
+        n_samples = (n_max * torch.tanh(size / n_max)).floor().long()
+    else:
+        n_samples = size.sqrt().round().long()
+    n_samples = n_samples.clamp(min=n_min).clamp(max=size)
+    if mask is not None:
+        size = idx[mask].bincount(minlength=num_segments)
+        n_samples = n_samples.clamp(max=size)
+    ptr = torch.cat((torch.zeros(1, dtype=torch.long), n_samples)).cumsum(0)
+    return n_samples, ptr
+
+
+def check_sparse_sample(idx, samples, ptr, n_max, n_min, mask=None):
+    """Contract of sparse_sample's output, as a list of violated clauses (empty =
+    ok): pointers as above, every sample a member of its segment, no duplicate,
+    none masked out."""
+    bad = []
+    n_samples, ptr_ref = sparse_sample_counts(idx, n_max, n_min, mask)
+    if not torch.equal(ptr, ptr_ref):
+        bad.append("pointers")
+    if samples.numel() != int(ptr_ref[-1]):
+        bad.append("total")
+        return bad
+    seg = torch.repeat_interleave(torch.arange(n_samples.numel()), n_samples)
+    if not torch.equal(idx[samples], seg):
+        bad.append("membership")
+    if torch.unique(samples).numel() != samples.numel():
+        bad.append("duplicates")
+    if mask is not None and not bool(mask[samples].all()):
+        bad.append("mask")
+    return bad
+
+
+def scatter_mean_orientation(orientation, idx, num_groups=None):
+    """src/utils/scatter.py:249-300."""
+    n = _dim_size(idx, num_groups)
+    eps = 1e-4
+    x = orientation.clone()
+    x = x / (x.norm(dim=1).view(-1, 1) + eps)
+    x = x.clamp(min=-1, max=1)
+    phi = x[:, 2].arcsin()
+    phi_mean = scatter_mean(phi, idx, 0, None, n)
+    is_horizontal = (phi_mean < math.pi / 4)[idx]
+    _, argmin = scatter_min(phi, idx, 0, None, n)
+    is_opposing = (x * x[argmin[idx]]).sum(dim=1) < 0
+    flip = is_horizontal & is_opposing
+    x = torch.where(flip.view(-1, 1), -x, x)
+    x_mean = scatter_mean(x, idx, 0, None, n)
+    x_mean = x_mean / (x_mean.norm(dim=1).view(-1, 1) + eps)
+    x_mean = x_mean.clamp(min=-1, max=1)
+    neg = x_mean[:, -1] < 0
+    return torch.where(neg.view(-1, 1), -x_mean, x_mean)
+
+
+def segment_features(pos, super_index, num_segments, samples, ptr, sub_size=None,
+                     point_attrs=None):
+    """_compute_cluster_features (src/transforms/graph.py:193-321) for given
+    samples: geometric features of the sampled points of each segment (k_min = 5,
+    the default of geometric_features, no self), log_ variants, log_size, mean_ /
+    std_ of the point attributes (mean_normal = scatter_mean_orientation)."""
+    width = ptr[1:] - ptr[:-1]
+    kmax = int(width.max()) if width.numel() else 0
+    nn = torch.full((num_segments, max(kmax, 1)), -1, dtype=torch.long)
+    rows = torch.repeat_interleave(torch.arange(num_segments), width)
+    cols = torch.arange(samples.numel()) - ptr[:-1][rows]
+    nn[rows, cols] = samples                                    # csr_to_dense, graph.py:239-242
+    f = geometric_features(pos, nn, k_min=5, add_self_as_neighbor=False)
+    out = dict(linearity=f[:, 0:1], planarity=f[:, 1:2], scattering=f[:, 2:3],
+               verticality=f[:, 3:4], normal=f[:, 4:7], curvature=f[:, 10:11],
+               log_length=torch.log(f[:, 7:8] + 1), log_surface=torch.log(f[:, 8:9] + 1),
+               log_volume=torch.log(f[:, 9:10] + 1))
+    if sub_size is None:
+        sub_size = torch.bincount(super_index, minlength=num_segments)
+    out["log_size"] = (torch.log(sub_size + 1).view(-1, 1) - np.log(2)) / 10
+    for key, a in (point_attrs or {}).items():
+        if key == "normal":
+            out[f"mean_{key}"] = scatter_mean_orientation(a, super_index, num_segments)
+        else:
+            out[f"mean_{key}"] = scatter_mean(a, super_index, 0, None, num_segments)
+        out[f"std_{key}"] = scatter_std(a, super_index, 0, None, num_segments)
+    return out

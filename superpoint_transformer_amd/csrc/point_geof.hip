@@ -77,12 +77,21 @@ __global__ __launch_bounds__(256) void point_geof_kernel(
     float* __restrict__ feats) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const double px = xyz[i * 3], py = xyz[i * 3 + 1], pz = xyz[i * 3 + 2];
-    // sums of d = x_j - p_i: the self contributes d = 0
-    double s1[3] = {0, 0, 0}, s2[6] = {0, 0, 0, 0, 0, 0};
-    int cnt = add_self ? 1 : 0;
     const int64_t lo = CSR ? ptr[i] : i * k;
     const int64_t hi = CSR ? ptr[i + 1] : lo + k;
+    // origin of the moment sums: the point itself when it is part of its own
+    // neighbourhood, else the first valid neighbour (row i of nn then describes a
+    // GROUP of points, e.g. the samples of segment i - src/transforms/graph.py:239-242)
+    int64_t o = i;
+    if (!add_self) {
+      o = -1;
+      for (int64_t j = lo; j < hi && o < 0; ++j) o = nn[j] < 0 ? -1 : nn[j];
+    }
+    const double px = o < 0 ? 0.0 : (double)xyz[o * 3], py = o < 0 ? 0.0 : (double)xyz[o * 3 + 1],
+                 pz = o < 0 ? 0.0 : (double)xyz[o * 3 + 2];
+    // sums of d = x_j - origin: the self contributes d = 0
+    double s1[3] = {0, 0, 0}, s2[6] = {0, 0, 0, 0, 0, 0};
+    int cnt = add_self ? 1 : 0;
     for (int64_t j = lo; j < hi; ++j) {
       const int64_t t = nn[j];
       if (t < 0) continue;

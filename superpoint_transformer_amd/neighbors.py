@@ -153,10 +153,12 @@ def geometric_features(xyz, nn, k_min=1, add_self_as_neighbor=True, raw=False):
 
 def geometric_features_csr(xyz, nn_val, nn_ptr, k_min=1, add_self=False, raw=True):
     """pgeof.compute_features' layout: CSR neighbourhoods (the caller already
-    put the point itself in its list, geometry.py:95-96,142-153)."""
+    put the point itself in its list, geometry.py:95-96,142-153).  One feature
+    row per neighbourhood: ``nn_ptr`` may describe fewer groups than ``xyz`` has
+    rows (the sampled points of each segment, transforms/graph.py:234-242)."""
     _lib.require_cuda(xyz, nn_val, nn_ptr)
     p = xyz.detach().float().contiguous()
-    n = p.shape[0]
+    n = nn_ptr.numel() - 1
     feats = torch.empty((n, 11), dtype=torch.float32, device=p.device)
     with torch.cuda.device(p.device):
         st = _lib.lib.spt_point_geof_csr_f32(
