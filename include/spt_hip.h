@@ -276,6 +276,36 @@ int spt_segment_mean_orientation_f32(const float* orientation, const int32_t* pe
                                      spt_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * Radius graph between point clusters                                     (f2)
+ * The two device-heavy stages of cluster_radius_nn_graph
+ * (src/utils/neighbors.py:491-665).
+ *
+ * spt_cluster_graph_edges (:563-613): neighbours [S,k] int64 (-1 = missing) and
+ *   distances [S,k] f32 of the cluster centres (knn_1's output), r_cluster [S] = diam/2;
+ *   keeps `dist <= r_s + r_t + 1.732 * gap`, then to_trimmed (trim != 0: s < t,
+ *   src/utils/graph.py:466-502) or coalesce, both with reduce = 'min', no self loops.
+ *   edges [2, S*k] int64 (row stride S*k), edge_dist [S*k]: the first *count columns are
+ *   written, sorted by (s, t); count: device int64.
+ *
+ * spt_cluster_pair_anchors_f32: scatter_nearest_neighbor (src/utils/scatter.py:128-238)
+ *   + anchor distance (neighbors.py:631-632) for every edge (s, t): `cycles` rounds of
+ *   "closest point of t to s's candidate, closest point of s to t's candidate" starting
+ *   from the cluster centroids [S,3]; clusters are walked through the CSR view
+ *   (perm, rowptr) of the point -> cluster index; ties -> first point in CSR order.
+ *   edges: row 0 at edges[0..E), row 1 at edges[edge_stride..]; anchors [2,E] int64 point
+ *   indices, d_nn [E].  group_lanes in {8,16,64}: lanes cooperating on one edge.
+ * ---------------------------------------------------------------------- */
+size_t spt_cluster_graph_edges_workspace_bytes(int64_t num_clusters, int k);
+int spt_cluster_graph_edges(const int64_t* neighbors, const float* distances,
+                            const float* r_cluster, int64_t num_clusters, int k, float gap,
+                            int trim, int64_t* edges, float* edge_dist, int64_t* count,
+                            void* ws, size_t ws_bytes, spt_stream_t stream);
+int spt_cluster_pair_anchors_f32(const float* points, const int32_t* perm, const int32_t* rowptr,
+                                 const float* centroid, const int64_t* edges, int64_t num_edges,
+                                 int64_t edge_stride, int cycles, int group_lanes,
+                                 int64_t* anchors, float* d_nn, spt_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * On-the-fly horizontal edge features + symmetrisation + self loops   (f1)
  * Replaces _on_the_fly_horizontal_edge_features (src/transforms/graph.py:1135-1277,
  * all default keys) followed by NAGAddSelfLoops (:1419-1452).

@@ -67,6 +67,9 @@ SIGNATURES = {
     "spt_sparse_sample": (_int, [_p, _i64, _i64, _p, _int, _int, _c.c_uint64, _p, _p, _p, _sz, _p]),
     "spt_segment_std_f32": (_int, [_p, _p, _p, _i64, _int, _p, _p]),
     "spt_segment_mean_orientation_f32": (_int, [_p, _p, _p, _i64, _p, _p]),
+    "spt_cluster_graph_edges_workspace_bytes": (_sz, [_i64, _int]),
+    "spt_cluster_graph_edges": (_int, [_p, _p, _p, _i64, _int, _f32, _int, _p, _p, _p, _p, _sz, _p]),
+    "spt_cluster_pair_anchors_f32": (_int, [_p, _p, _p, _p, _p, _i64, _i64, _int, _int, _p, _p, _p]),
 }
 
 

@@ -9,7 +9,8 @@ from . import _lib
 from .ops import _workspace
 
 __all__ = ["frnn_grid_points", "knn_1", "knn_2", "neighbors_dense_to_csr",
-           "geometric_features", "GEOF_COLUMNS"]
+           "geometric_features", "GEOF_COLUMNS", "cluster_radius_nn_graph",
+           "scatter_nearest_neighbor"]
 
 GEOF_COLUMNS = ["linearity", "planarity", "scattering", "verticality", "normal_x",
                 "normal_y", "normal_z", "length", "surface", "volume", "curvature"]
@@ -167,3 +168,92 @@ def geometric_features_csr(xyz, nn_val, nn_ptr, k_min=1, add_self=False, raw=Tru
             0 if raw else 1, _lib.ptr(feats), _lib.stream_ptr(p.device))
     _lib.check(st, "spt_point_geof_csr_f32")
     return feats
+
+
+def scatter_nearest_neighbor(points, index, edge_index, cycles=3, chunk_size=None,
+                             num_clusters=None):
+    """For each pair of clusters of ``edge_index`` the (approximately) two closest
+    points between them (src/utils/scatter.py:128-238).  Returns
+    ``(candidate [2E,3], candidate_idx [2,E])`` like the reference; ``chunk_size`` is
+    accepted and ignored (nothing edge-wise is materialised here)."""
+    anchors, _ = _pair_anchors(points, index, edge_index, cycles, num_clusters)
+    p = points.detach().float()
+    return torch.vstack((p[anchors[0]], p[anchors[1]])), anchors
+
+
+def _pair_anchors(points, index, edge_index, cycles, num_clusters=None, edge_stride=None,
+                  num_edges=None):
+    from .csr import csr_of
+    from .ops import segment_reduce
+    _lib.require_cuda(points, index, edge_index)
+    p = points.detach().float().contiguous()
+    csr = csr_of(index, num_clusters)
+    centroid = segment_reduce(p, index, csr.num_seg, "mean").contiguous()
+    if edge_stride is None:
+        edge_index = edge_index.long().contiguous()
+        edge_stride = num_edges = edge_index.shape[1]
+    dev = p.device
+    anchors = torch.empty((2, num_edges), dtype=torch.int64, device=dev)
+    d_nn = torch.empty(num_edges, dtype=torch.float32, device=dev)
+    mean_size = csr.n / max(csr.num_seg, 1)
+    lanes = 8 if mean_size <= 12 else 16 if mean_size <= 48 else 64
+    with torch.cuda.device(dev):
+        st = _lib.lib.spt_cluster_pair_anchors_f32(
+            _lib.ptr(p), _lib.ptr(csr.perm), _lib.ptr(csr.rowptr), _lib.ptr(centroid),
+            _lib.ptr(edge_index), num_edges, edge_stride, int(cycles), lanes, _lib.ptr(anchors),
+            _lib.ptr(d_nn), _lib.stream_ptr(dev))
+    _lib.check(st, "spt_cluster_pair_anchors_f32")
+    return anchors, d_nn
+
+
+def cluster_radius_nn_graph(x_points, idx, k_max=100, gap=0, batch=None, trim=True, cycles=3,
+                            chunk_size=None, verbose=False, squared=True, num_clusters=None,
+                            return_intermediate=False):
+    """Radius neighbours of clusters: two clusters are neighbours if two of their
+    points are ``gap`` or less apart (src/utils/neighbors.py:491-665; same steps:
+    bounding-box centres -> knn_1 within max diameter + gap -> radius-sum filter ->
+    to_trimmed / coalesce -> anchor points -> ``d_nn <= gap``).  Returns
+    ``(edge_index [2,E], distances [E])``.
+
+    ``squared``: whether the centre distances compared with the radius sum are the
+    squared ones FRNN returns (neighbors.py:591-593 compares them as they come)."""
+    from .csr import csr_of
+    from .ops import segment_reduce
+    _lib.require_cuda(x_points, idx)
+    if k_max + 1 > 64:
+        raise NotImplementedError("the grid kNN kernel holds up to 64 neighbours (k_max <= 63; "
+                                  "the reference's configs use 30)")
+    x = x_points.detach().float().contiguous()
+    dev = x.device
+    csr = csr_of(idx, num_clusters)
+    S = csr.num_seg
+    lo = segment_reduce(x, idx, S, "min")
+    hi = segment_reduce(x, idx, S, "max")
+    diam = (hi - lo).max(dim=1).values
+    center = (hi + lo) / 2
+    r_search = float(diam.max() + gap)                         # host sync, as in the reference
+    nb, dist = knn_1(center, k_max, r_max=r_search, batch=batch, squared=squared)
+    r_seg = (diam / 2).contiguous()
+    m = S * k_max
+    edges = torch.empty((2, max(m, 1)), dtype=torch.int64, device=dev)
+    edge_dist = torch.empty(max(m, 1), dtype=torch.float32, device=dev)
+    count = torch.zeros(1, dtype=torch.int64, device=dev)
+    nbytes = _lib.lib.spt_cluster_graph_edges_workspace_bytes(S, k_max)
+    ws = _workspace(nbytes, dev)
+    nb = nb.contiguous()
+    dist = dist.contiguous()
+    with torch.cuda.device(dev):
+        st = _lib.lib.spt_cluster_graph_edges(
+            _lib.ptr(nb), _lib.ptr(dist), _lib.ptr(r_seg), S, int(k_max), float(gap), int(trim),
+            _lib.ptr(edges), _lib.ptr(edge_dist), _lib.ptr(count), _lib.ptr(ws), nbytes,
+            _lib.stream_ptr(dev))
+    _lib.check(st, "spt_cluster_graph_edges")
+    E = int(count)
+    anchors, d_nn = _pair_anchors(x, idx, edges, cycles, S, edge_stride=edges.shape[1],
+                                  num_edges=E)
+    keep = d_nn <= gap
+    edge_index = edges[:, :E][:, keep]
+    if return_intermediate:
+        return edge_index, d_nn[keep], dict(trimmed=edges[:, :E], anchors=anchors, d_nn=d_nn,
+                                            center_dist=edge_dist[:E])
+    return edge_index, d_nn[keep]
