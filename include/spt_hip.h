@@ -306,6 +306,43 @@ int spt_cluster_pair_anchors_f32(const float* points, const int32_t* perm, const
                                  int64_t* anchors, float* d_nn, spt_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * NAG selection / re-indexing                                             (f3)
+ * The integer work of NAG.select (src/data/nag.py:306-399), Data.select
+ * (src/data/data.py:286-470) and Cluster.select (src/data/cluster.py:79-140).  All ids
+ * are bounded by a level size, so every consecutive_cluster (torch.unique) of the
+ * reference is a presence bitmap + scan here.  Counts are device int64 scalars.
+ *
+ * spt_index_inverse: inv [n] = -1 except inv[idx[j]] = j          (data.py:365-368)
+ * spt_select_edges: edges whose two ends survive, relabelled through inv, original
+ *   order kept; idx_edge = their positions (data.py:369-373).  edge_index rows at
+ *   [0..E) and [edge_stride..); out rows at [0..) and [out_stride..).
+ * spt_cluster_select: clusters idx [k] (no duplicates) of the CSR (pointers [S+1],
+ *   points [num_points], point ids < n_sub) -> new_pointers [k+1], new_points (dense
+ *   new ids, first new_pointers[k] entries), idx_sub (ascending surviving point ids,
+ *   first *count_sub entries) and sub_super (new cluster of each surviving point)
+ *   (src/data/csr.py:328-408, cluster.py:127-138).
+ * spt_relabel_consecutive: consecutive_cluster of values[gather[i]] (gather nullable)
+ *   for labels in [0, n_range): new_values [k] dense labels in sorted order, uniques =
+ *   the labels present, ascending (data.py:404-406: new super_index / idx_super).
+ * ---------------------------------------------------------------------- */
+int spt_index_inverse(const int64_t* idx, int64_t k, int64_t n, int64_t* inv,
+                      spt_stream_t stream);
+size_t spt_select_edges_workspace_bytes(int64_t num_edges);
+int spt_select_edges(const int64_t* edge_index, int64_t num_edges, int64_t edge_stride,
+                     const int64_t* inv, int64_t n, int64_t* out_edges, int64_t out_stride,
+                     int64_t* idx_edge, int64_t* count, void* ws, size_t ws_bytes,
+                     spt_stream_t stream);
+size_t spt_cluster_select_workspace_bytes(int64_t k, int64_t num_points, int64_t n_sub);
+int spt_cluster_select(const int64_t* pointers, const int64_t* points, int64_t num_points,
+                       const int64_t* idx, int64_t k, int64_t n_sub, int64_t* new_pointers,
+                       int64_t* new_points, int64_t* idx_sub, int64_t* sub_super,
+                       int64_t* count_sub, void* ws, size_t ws_bytes, spt_stream_t stream);
+size_t spt_relabel_consecutive_workspace_bytes(int64_t n_range);
+int spt_relabel_consecutive(const int64_t* values, const int64_t* gather, int64_t k,
+                            int64_t n_range, int64_t* new_values, int64_t* uniques,
+                            int64_t* count, void* ws, size_t ws_bytes, spt_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * On-the-fly horizontal edge features + symmetrisation + self loops   (f1)
  * Replaces _on_the_fly_horizontal_edge_features (src/transforms/graph.py:1135-1277,
  * all default keys) followed by NAGAddSelfLoops (:1419-1452).

@@ -713,3 +713,86 @@ def cluster_radius_nn_graph(x_points, idx, k_max=100, gap=0, batch=None, trim=Tr
     d_nn = (x_points[anchors[0]] - x_points[anchors[1]]).norm(dim=1)
     keep = d_nn <= gap
     return edge_index[:, keep], d_nn[keep], dict(trimmed=edge_index, anchors=anchors, d_nn=d_nn)
+
+
+# --------------------------------------------------------------------------
+# NAG selection / re-indexing
+# levels: list of dicts of tensors; 'sub' -> (pointers, points)
+# --------------------------------------------------------------------------
+
+
+def cluster_from_index(index, values):
+    """Cluster(index, values, dense=True): CSRData.__init__ / indices_to_pointers
+    (src/data/csr.py:85-88, src/utils/sparse.py:23-42), stable order."""
+    n = int(index.max()) + 1 if index.numel() else 0
+    order = torch.argsort(index, stable=True)
+    ptr = torch.cat((torch.zeros(1, dtype=torch.long), torch.bincount(index, minlength=n))).cumsum(0)
+    return ptr, values[order]
+
+
+def cluster_select(pointers, points, idx, update_sub=True):
+    """CSRData.select (src/data/csr.py:328-408) + Cluster.select
+    (src/data/cluster.py:79-140)."""
+    sizes = (pointers[1:] - pointers[:-1])[idx]
+    new_ptr = torch.cat((torch.zeros(1, dtype=torch.long), sizes)).cumsum(0)
+    start = pointers[:-1][idx]
+    val_idx = torch.arange(int(new_ptr[-1])) + (start - new_ptr[:-1]).repeat_interleave(sizes)
+    new_points = points[val_idx]
+    if not update_sub:
+        return (new_ptr, new_points), (None, None)
+    inv, perm = consecutive_cluster(new_points)                  # cluster.py:130
+    idx_sub = new_points[perm]
+    sub_super = torch.empty(inv.numel(), dtype=torch.long)       # to_super_index, cluster.py:67-77
+    sub_super[inv] = torch.arange(idx.numel()).repeat_interleave(sizes)
+    return (new_ptr, inv), (idx_sub, sub_super)
+
+
+def data_select(d, idx, update_sub=True, update_super=True):
+    """Data.select (src/data/data.py:286-470) on a dict level."""
+    n = next(d[k] for k in ("pos", "x", "super_index") if k in d).shape[0]
+    out = {}
+    idx_edge = None
+    if "edge_index" in d:                                         # data.py:360-373
+        reindex = torch.full((n,), -1, dtype=torch.long)
+        reindex[idx] = torch.arange(idx.numel())
+        ei = reindex[d["edge_index"]]
+        idx_edge = torch.where((ei != -1).all(dim=0))[0]
+        out["edge_index"] = ei[:, idx_edge]
+    out_sub = (None, None)
+    if "sub" in d:
+        out["sub"], out_sub = cluster_select(d["sub"][0], d["sub"][1], idx, update_sub)
+    out_super = (None, None)
+    if "super_index" in d:
+        out["super_index"] = d["super_index"][idx]
+        if update_super:                                          # data.py:399-416
+            inv, perm = consecutive_cluster(out["super_index"])
+            idx_super = out["super_index"][perm]
+            out["super_index"] = inv
+            out_super = (idx_super, cluster_from_index(inv, torch.arange(idx.numel())))
+    ne = d["edge_index"].shape[1] if "edge_index" in d else -1
+    for k, v in d.items():
+        if k in ("edge_index", "sub", "super_index"):
+            continue
+        if k.startswith("v_edge_"):
+            out[k] = v[idx]
+        elif k.startswith("edge_") and v.shape[0] == ne:
+            out[k] = v[idx_edge]
+        else:
+            out[k] = v[idx]
+    return out, out_sub, out_super
+
+
+def nag_select(levels, i_level, idx):
+    """NAG.select (src/data/nag.py:306-399)."""
+    L = len(levels)
+    out = [None] * L
+    out[i_level], out_sub, out_super = data_select(levels[i_level], idx)
+    for i in range(i_level - 1, -1, -1):
+        idx_sub, sub_super = out_sub
+        out[i], out_sub, _ = data_select(levels[i], idx_sub, True, False)
+        out[i]["super_index"] = sub_super
+    for i in range(i_level + 1, L):
+        idx_super, super_sub = out_super
+        out[i], _, out_super = data_select(levels[i], idx_super, False, True)
+        out[i]["sub"] = super_sub
+    return out

@@ -195,7 +195,7 @@ extern "C" int spt_cluster_graph_edges(const int64_t* neighbors, const float* di
   SPT_CHECK_ARG(S >= 0 && k >= 1 && m < ((int64_t)1 << 31) - SORT_TILE - 1, "shape out of range");
   SPT_CHECK_ARG(count != nullptr, "count is null");
   if (m == 0) {
-    hipMemsetAsync(count, 0, 8, stream);
+    (void)hipMemsetAsync(count, 0, 8, stream);
     return 0;
   }
   SPT_CHECK_ARG(neighbors && distances && r_cluster && edges && edge_dist, "null pointer");

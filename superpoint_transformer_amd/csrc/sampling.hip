@@ -156,7 +156,7 @@ extern "C" int spt_sparse_sample(const int64_t* idx, int64_t n, int64_t num_seg,
     random_keys_kernel<<<stream_grid(n, 256), 256, 0, stream>>>(seed, n, keys);
     radix_sort_pairs<2>(nullptr, keys, nullptr, n, 32, s, nullptr, &ks, &vs, stream);
     // 2. stable sort of the shuffled elements by segment (masked-out -> bucket num_seg)
-    if (size_all) hipMemsetAsync(size_all, 0, (size_t)(num_seg + 1) * 4, stream);
+    if (size_all) (void)hipMemsetAsync(size_all, 0, (size_t)(num_seg + 1) * 4, stream);
     segment_keys_kernel<<<stream_grid(n, 256), 256, 0, stream>>>(idx, mask, vs, n, num_seg,
                                                                 keys, size_all);
     // the shuffled values sit in one of the scratch value buffers; sorting with
