@@ -357,6 +357,53 @@ class NAG:
                              return_pointers=return_pointers, seed=seed,
                              num_segments=self[high].num_nodes)
 
+    @classmethod
+    def from_nag_list(cls, nag_list):
+        """One NAG out of several (NAGBatch.from_nag_list, nag.py:878-898 +
+        Batch.from_data_list): per level, attributes concatenated, ``super_index`` /
+        ``edge_index`` / ``sub`` shifted by the node counts of the preceding items, and a
+        ``batch`` vector telling which item each node came from."""
+        L = nag_list[0].num_levels
+        dev = nag_list[0].device
+        counts = [[n[l].num_nodes for n in nag_list] for l in range(L)]
+        out = []
+        for l in range(L):
+            items = [n[l] for n in nag_list]
+            off = [0]
+            for c in counts[l]:
+                off.append(off[-1] + c)
+            d = Data()
+            for key in items[0].keys:
+                vals = [it[key] for it in items]
+                if key == "super_index":
+                    up = [0]
+                    for c in counts[l + 1]:
+                        up.append(up[-1] + c)
+                    d[key] = torch.cat([v + up[j] for j, v in enumerate(vals)])
+                elif key == "edge_index":
+                    d[key] = torch.cat([v + off[j] for j, v in enumerate(vals)], dim=1)
+                elif key == "sub":
+                    lo = [0]
+                    for c in counts[l - 1]:
+                        lo.append(lo[-1] + c)
+                    ptr = [vals[0].pointers]
+                    base = int(vals[0].pointers[-1])
+                    for v in vals[1:]:
+                        ptr.append(v.pointers[1:] + base)
+                        base += int(v.pointers[-1])
+                    d[key] = Cluster(torch.cat(ptr),
+                                     torch.cat([v.points + lo[j] for j, v in enumerate(vals)]))
+                elif torch.is_tensor(vals[0]):
+                    d[key] = torch.cat(vals, dim=0)
+                else:
+                    d[key] = copy.deepcopy(vals[0])
+            d.batch = torch.repeat_interleave(
+                torch.arange(len(nag_list), device=dev),
+                torch.tensor(counts[l], device=dev))
+            d.num_nodes = off[-1]
+            out.append(d)
+        return cls(out)
+
     def select(self, i_level, idx):
         """New NAG keeping the nodes ``idx`` (no duplicates) of level ``i_level``, their
         descendants and their ancestors, every level re-indexed consistently

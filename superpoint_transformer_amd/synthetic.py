@@ -168,3 +168,51 @@ def make_voxel_cloud(n, voxel=0.03, seed=1234, device="cpu", patch=3.0, extent=(
     first[1:] = ks[1:] != ks[:-1]
     pos = pos[order[first]]
     return pos[torch.randperm(pos.shape[0], generator=gen, device=device)].contiguous()
+
+
+def make_raw_nag(scene="R", seed=1234, device="cpu", sizes=None, point_dim=8):
+    """A NAG as it sits on disk BEFORE the per-batch on-device transforms
+    (configs/datamodule/semantic/default.yaml:206-290): trimmed (i < j) horizontal edges
+    with the 7 stored edge attributes, segment attributes (normal, log_length,
+    log_surface, log_volume, log_size), the cluster CSR of every level, no node_size.
+    Returns a ``superpoint_transformer_amd.data.NAG``."""
+    from .data import NAG, Data, Cluster
+    n0, n1, n2, e1, e2, b = sizes if sizes is not None else SCENES[scene]
+    device = torch.device(device)
+    gen = torch.Generator(device=device).manual_seed(seed)
+    si0 = _super_index(gen, n0, n1, "lognormal", device, shuffle=True)
+    si1 = _super_index(gen, n1, n2, "geometric", device, shuffle=True)
+
+    def rnd(*shape, s=1.0):
+        return torch.randn(*shape, generator=gen, device=device) * s
+
+    pos2 = torch.rand(n2, 3, generator=gen, device=device) * 40.0
+    pos1 = pos2[si1] + rnd(n1, 3, s=1.5)
+    pos0 = pos1[si0] + rnd(n0, 3, s=0.3)
+
+    def trimmed(n, e_target):
+        m = max((e_target - n) // 2, 1)
+        a = torch.randint(0, n, (m,), generator=gen, device=device)
+        c = torch.randint(0, n, (m,), generator=gen, device=device)
+        lo, hi = torch.minimum(a, c), torch.maximum(a, c)
+        key = torch.unique(lo[lo != hi] * n + hi[lo != hi])
+        return torch.stack([key // n, key % n])
+
+    def segment_level(n, pos, si, sub_index, sub_n, e_target):
+        ei = trimmed(n, e_target)
+        nrm = torch.nn.functional.normalize(rnd(n, 3), dim=1)
+        nrm = nrm * torch.where(nrm[:, 2:3] < 0, -1.0, 1.0)
+        d = Data(pos=pos, normal=nrm, log_length=torch.rand(n, 1, generator=gen, device=device),
+                 log_surface=torch.rand(n, 1, generator=gen, device=device),
+                 log_volume=torch.rand(n, 1, generator=gen, device=device),
+                 log_size=torch.rand(n, 1, generator=gen, device=device),
+                 sub=Cluster(sub_index, torch.arange(sub_n, device=device), dense=True),
+                 edge_index=ei, edge_attr=rnd(ei.shape[1], 7, s=0.3))
+        if si is not None:
+            d.super_index = si
+        return d
+
+    return NAG([
+        Data(pos=pos0, x=torch.rand(n0, point_dim, generator=gen, device=device), super_index=si0),
+        segment_level(n1, pos1, si1, si0, n0, e1),
+        segment_level(n2, pos2, None, si1, n1, e2)])

@@ -5,7 +5,8 @@ import torch
 
 from . import _lib
 
-__all__ = ["horizontal_edge_features", "EDGE_FEATURE_COLUMNS"]
+__all__ = ["horizontal_edge_features", "EDGE_FEATURE_COLUMNS", "NodeSize", "SampleSubNodes",
+           "SampleSegments", "SampleEdges", "OnTheFlyHorizontalEdgeFeatures"]
 
 EDGE_FEATURE_COLUMNS = [
     "mean_off_x", "mean_off_y", "mean_off_z", "std_off_x", "std_off_y", "std_off_z",
@@ -45,3 +46,104 @@ def horizontal_edge_features(edge_index, edge_attr, pos, normal, log_length, log
             int(add_self_loops), _lib.ptr(ei_out), _lib.ptr(ea_out), _lib.stream_ptr(dev))
     _lib.check(st, "spt_horizontal_edge_features_f32")
     return ei_out, ea_out
+
+
+# ---------------------------------------------------------------------------
+# Per-batch on-device transforms of the training pipeline
+# (configs/datamodule/semantic/default.yaml:206-290), on the NAG mirror of data.py
+# ---------------------------------------------------------------------------
+
+
+class NodeSize:
+    """``node_size`` of every level above ``low`` = number of ``low``-level nodes it
+    holds (src/transforms/graph.py:1475-1498)."""
+
+    def __init__(self, low=0):
+        self.low = low
+
+    def __call__(self, nag):
+        for i in range(self.low + 1, nag.num_levels):
+            nag[i].node_size = nag.get_sub_size(i, low=self.low)
+        return nag
+
+
+class SampleSubNodes:
+    """Keep ``n_min``..``n_max`` random ``low``-level nodes of every ``high``-level
+    segment (src/transforms/sampling.py:656-715)."""
+
+    def __init__(self, high=1, low=0, n_max=32, n_min=16, mask=None, seed=None):
+        self.high, self.low, self.n_max, self.n_min, self.mask, self.seed = \
+            high, low, n_max, n_min, mask, seed
+
+    def __call__(self, nag):
+        if self.low == self.high:
+            return nag
+        idx = nag.get_sampling(high=self.high, low=self.low, n_max=self.n_max, n_min=self.n_min,
+                               mask=self.mask, return_pointers=False, seed=self.seed)
+        return nag.select(self.low, idx)
+
+
+class SampleSegments:
+    """Drop a ``ratio`` of the segments of every level >= 1, from the top level down
+    (src/transforms/sampling.py:718-807; ``by_class`` is not mirrored)."""
+
+    def __init__(self, ratio=0.2, by_size=False):
+        self.ratio, self.by_size = ratio, by_size
+
+    def __call__(self, nag):
+        L = nag.num_levels
+        ratio = self.ratio if isinstance(self.ratio, list) else [self.ratio] * (L - 1)
+        for i in range(L - 1, 0, -1):
+            if ratio[i - 1] <= 0:
+                continue
+            n = nag[i].num_nodes
+            keep = n - int(n * ratio[i - 1])
+            w = torch.ones(n, device=nag.device)
+            if self.by_size:
+                sw = nag.get_sub_size(i, low=0).float() ** 0.333
+                w = w + sw / sw.sum()
+            idx = torch.multinomial(w / w.sum(), keep, replacement=False)
+            nag = nag.select(i, idx)
+        return nag
+
+
+class SampleEdges:
+    """Keep ``n_min``..``n_max`` random outgoing edges per source node
+    (src/transforms/sampling.py:1234-1312) on the levels ``levels``."""
+
+    def __init__(self, levels=(1, 2), n_min=16, n_max=32, seed=None):
+        self.levels, self.n_min, self.n_max, self.seed = tuple(levels), n_min, n_max, seed
+
+    def __call__(self, nag):
+        from .segment import sparse_sample
+        for i in self.levels:
+            d = nag[i]
+            if i >= nag.num_levels or not d.has_edges or self.n_min < 0 or self.n_max < 0:
+                continue
+            idx = sparse_sample(d.edge_index[0], n_max=self.n_max, n_min=self.n_min,
+                                seed=self.seed, num_segments=d.num_nodes)
+            d.edge_index = d.edge_index[:, idx]
+            for key in ["edge_attr"] + d.edge_keys:
+                if key in d:
+                    d[key] = d[key][idx]
+        return nag
+
+
+class OnTheFlyHorizontalEdgeFeatures:
+    """18-D edge features from the stored 7-D ones + node attributes, edges doubled, and
+    (``add_self_loops``) ``NAGAddSelfLoops`` fused (src/transforms/graph.py:1063-1277,
+    1419-1452)."""
+
+    def __init__(self, add_self_loops=True, use_mean_normal=False):
+        self.add_self_loops = add_self_loops
+        self.normal_key = "mean_normal" if use_mean_normal else "normal"
+
+    def __call__(self, nag):
+        for i in range(1, nag.num_levels):
+            d = nag[i]
+            if not d.has_edges:
+                continue
+            d.edge_index, d.edge_attr = horizontal_edge_features(
+                d.edge_index, d.edge_attr, d.pos, d[self.normal_key], d.log_length, d.log_surface,
+                d.log_volume, d.log_size, add_self_loops=self.add_self_loops)
+        return nag
