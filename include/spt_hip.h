@@ -359,6 +359,16 @@ int spt_horizontal_edge_features_f32(
     const float* log_volume, const float* log_size, int add_self_loops,
     int64_t* edge_index_out, float* edge_attr_out, spt_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * Tall-skinny Linear: y [rows, N] = x [rows, K] W[N, K]^T (+ bias [N] or NULL), f32 in /
+ * f32 accumulate.  The qkv / out_proj nn.Linear of SelfAttentionBlock
+ * (src/nn/attention.py:202-215, 311-313) and, on (gy, W^T), their input gradients.
+ * K in {32, 64, 128, 192}, N a multiple of 64; x, W, y contiguous.
+ * ---------------------------------------------------------------------- */
+int spt_skinny_linear_supported(int K, int N);
+int spt_skinny_linear_f32(const float* x, int64_t rows, int K, const float* W, const float* bias,
+                          int N, float* y, spt_stream_t stream);
+
 /* Pieces of the GraphNorm two-pass scheme for callers that produce / consume the
  * per-graph totals themselves (the fused MLP layers below).  totals layout:
  * [num_graphs][2d+1] f64 = (column sums, column sums of the second quantity, row count). */

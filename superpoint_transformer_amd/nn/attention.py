@@ -100,8 +100,8 @@ class SelfAttentionBlock(nn.Module):
         """x [N, Cx]; edge_index [2, E] (row 0 = querying source, row 1 = key
         target; any order) or an ``EdgeCSR``; edge_attr [E, in_rpe_dim]."""
         if self.in_proj is not None:
-            x = self.in_proj(x)
-        qkv = self.qkv(x)
+            x = ops.linear(x, self.in_proj.weight, self.in_proj.bias)
+        qkv = ops.linear(x, self.qkv.weight, self.qkv.bias)
         k_rpe = q_rpe = v_rpe = None
         if edge_attr is not None:
             k_rpe = self._expand(self.k_rpe)
@@ -115,7 +115,7 @@ class SelfAttentionBlock(nn.Module):
             k_rpe=k_rpe, q_rpe=q_rpe, v_rpe=v_rpe, num_heads=self.num_heads,
             qk_dim=self.qk_dim, scale_mode=self.scale_mode, scale_a=self.scale_a)
         if self.out_proj is not None:
-            x = self.out_proj(x)
+            x = ops.linear(x, self.out_proj.weight, self.out_proj.bias)
         if self.out_drop is not None:
             x = self.out_drop(x)
         return x

@@ -409,47 +409,82 @@ def edge_attention(qkv, edge_index, edge_attr=None, k_rpe=None, q_rpe=None, v_rp
 # Dense Linear on tall-skinny operands (plumbing over rocBLAS / hipBLASLt)
 # ---------------------------------------------------------------------------
 _DW_CHUNK = 32768
+_SKINNY_MIN_ROWS = 4096
+
+
+def _skinny_ok(x, weight):
+    return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32
+            and x.dim() == 2 and x.shape[0] >= _SKINNY_MIN_ROWS
+            and _lib.lib.spt_skinny_linear_supported(weight.shape[1], weight.shape[0]))
+
+
+def _skinny_launch(x, weight, bias):
+    """y = x W^T + b on the MFMA skinny-GEMM kernel (csrc/skinny_linear.hip)."""
+    x = x.contiguous()
+    weight = weight.contiguous()
+    rows, k = x.shape
+    n = weight.shape[0]
+    y = torch.empty((rows, n), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        st = _lib.lib.spt_skinny_linear_f32(
+            _lib.ptr(x), rows, k, _lib.ptr(weight), _lib.ptr(bias), n, _lib.ptr(y),
+            _lib.stream_ptr(x.device))
+    _lib.check(st, "spt_skinny_linear_f32")
+    return y
+
+
+def _dw_batched(g, x):
+    """dW = G^T X reduces over millions of rows into a <=192x192 output, a shape the
+    library runs on a handful of workgroups - so it is issued as a BATCHED GEMM over row
+    chunks (thousands of workgroups) followed by a small sum."""
+    n = x.shape[0]
+    nb = n // _DW_CHUNK
+    main = nb * _DW_CHUNK
+    gw = None
+    if nb > 0:
+        gm = g[:main].view(nb, _DW_CHUNK, g.shape[1])
+        xm = x[:main].view(nb, _DW_CHUNK, x.shape[1])
+        gw = torch.bmm(gm.transpose(1, 2), xm).sum(0)
+    if main < n:
+        tail = g[main:].t() @ x[main:]
+        gw = tail if gw is None else gw + tail
+    return gw
 
 
 class _TallLinear(torch.autograd.Function):
-    """y = x W^T (+ b) for [rows >> features] operands.  Forward and dX are plain
-    library GEMMs; dW = G^T X reduces over millions of rows into a <=128x132
-    output, a shape the library runs on a handful of workgroups - so it is
-    issued as a BATCHED GEMM over row chunks (thousands of workgroups) followed
-    by a small sum."""
+    """y = x W^T (+ b) for [rows >> features] operands.  Forward and dX run on the
+    hand-written skinny-GEMM kernel when the shape is built (K in {32,64,128,192},
+    N % 64 == 0 - the attention block's qkv / out_proj), else on the library; dW is a
+    batched library GEMM over row chunks."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        if _skinny_ok(x, weight):
+            return _skinny_launch(x.detach(), weight.detach(), None if bias is None else bias.detach())
         return torch.nn.functional.linear(x, weight, bias)
 
     @staticmethod
     def backward(ctx, g):
         x, weight = ctx.saved_tensors
         g = g.contiguous()
-        gx = g @ weight if ctx.needs_input_grad[0] else None
+        gx = None
+        if ctx.needs_input_grad[0]:
+            wt = weight.detach().t().contiguous()           # [K, N]: dX = G (W^T)^T
+            gx = _skinny_launch(g, wt, None) if _skinny_ok(g, wt) else g @ weight
         gw = gb = None
         if ctx.needs_input_grad[1]:
-            n = x.shape[0]
-            nb = n // _DW_CHUNK
-            main = nb * _DW_CHUNK
-            gw = None
-            if nb > 0:
-                gm = g[:main].view(nb, _DW_CHUNK, g.shape[1])
-                xm = x[:main].view(nb, _DW_CHUNK, x.shape[1])
-                gw = torch.bmm(gm.transpose(1, 2), xm).sum(0)
-            if main < n:
-                tail = g[main:].t() @ x[main:]
-                gw = tail if gw is None else gw + tail
+            gw = _dw_batched(g, x) if x.shape[0] >= 4 * _DW_CHUNK else g.t() @ x
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = g.sum(0)
         return gx, gw, gb
 
 
 def linear(x, weight, bias=None):
-    """``nn.Linear`` forward with a tall-skinny-aware backward (see _TallLinear)."""
-    if x.dim() != 2 or x.shape[0] < 4 * _DW_CHUNK or not x.is_contiguous():
+    """``nn.Linear`` forward for tall-skinny operands (see _TallLinear); small or
+    unsupported inputs go straight to the library."""
+    if x.dim() != 2 or not x.is_cuda or x.shape[0] < _SKINNY_MIN_ROWS:
         return torch.nn.functional.linear(x, weight, bias)
     return _TallLinear.apply(x, weight, bias)
 

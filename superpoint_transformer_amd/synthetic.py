@@ -108,6 +108,14 @@ def make_nag(scene="S", seed=1234, device="cpu", sizes=None, point_dim=8,
     si1 = _super_index(gen, n1, n2, "geometric", device, shuffle=True)
     # cloud (batch) ids: contiguous blocks of level-2 nodes, pushed down
     b2 = (torch.arange(n2, device=device) * b // n2).long()
+    if b > 1:
+        # a batch is a concatenation of clouds (NAGBatch.from_nag_list, nag.py:878-898):
+        # the nodes of one cloud are contiguous at EVERY level, shuffled inside the block
+        o1 = torch.argsort(b2[si1], stable=True)
+        inv1 = torch.empty_like(o1)
+        inv1[o1] = torch.arange(n1, device=device)
+        si1, si0 = si1[o1], inv1[si0]
+        si0 = si0[torch.argsort(b2[si1][si0], stable=True)]
     b1 = b2[si1]
     b0 = b1[si0]
 

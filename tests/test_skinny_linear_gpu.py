@@ -1,0 +1,50 @@
+"""GPU parity of the tall-skinny Linear kernel (qkv / out_proj of the attention
+block and their input gradients) against torch in float64.  f32 in / f32 accumulate:
+the error is that of an fmaf chain over K terms - bar 2e-6 * K * max|x| * max|w|."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("rows", [1, 15, 16, 17, 4099, 70001])
+@pytest.mark.parametrize("K,N", [(64, 192), (64, 64), (192, 64), (32, 64), (128, 128), (192, 192)])
+@pytest.mark.parametrize("bias", [True, False])
+def test_forward_matches_float64(rows, K, N, bias, dev):
+    from superpoint_transformer_amd import ops
+    g = torch.Generator().manual_seed(rows + K + N)
+    x = torch.randn(rows, K, generator=g)
+    w = torch.randn(N, K, generator=g) * 0.2
+    b = torch.randn(N, generator=g) if bias else None
+    y = ops._skinny_launch(x.to(dev), w.to(dev), None if b is None else b.to(dev)).cpu().double()
+    ref = torch.nn.functional.linear(x.double(), w.double(), None if b is None else b.double())
+    tol = 2e-6 * K * float(x.abs().max()) * float(w.abs().max())
+    assert (y - ref).abs().max() < tol
+
+
+def test_linear_autograd_matches_torch(dev):
+    from superpoint_transformer_amd import ops
+    g = torch.Generator().manual_seed(0)
+    for rows, K, N in ((5000, 64, 192), (140000, 64, 64), (9000, 48, 64)):   # last: library path
+        x = torch.randn(rows, K, generator=g).to(dev).requires_grad_()
+        w = (torch.randn(N, K, generator=g) * 0.2).to(dev).requires_grad_()
+        b = torch.randn(N, generator=g).to(dev).requires_grad_()
+        go = torch.randn(rows, N, generator=g).to(dev)
+        y = ops.linear(x, w, b)
+        gx, gw, gb = torch.autograd.grad(y, (x, w, b), go)
+        xd, wd, bd = (t.detach().double().requires_grad_() for t in (x, w, b))
+        yr = torch.nn.functional.linear(xd, wd, bd)
+        rx, rw, rb = torch.autograd.grad(yr, (xd, wd, bd), go.double())
+        for a, r in ((y, yr), (gx, rx), (gw, rw), (gb, rb)):
+            assert (a.double() - r).abs().max() <= 1e-5 * max(1.0, float(r.abs().max())) * (K + N) ** 0.5
+
+
+def test_unsupported_shapes_and_small_inputs_use_the_library(dev):
+    from superpoint_transformer_amd import ops, _lib
+    assert not _lib.lib.spt_skinny_linear_supported(48, 64)
+    assert not _lib.lib.spt_skinny_linear_supported(64, 13)
+    x = torch.randn(100, 64, device=dev)
+    w = torch.randn(192, 64, device=dev)
+    assert torch.equal(ops.linear(x, w), torch.nn.functional.linear(x, w))
+    with pytest.raises(RuntimeError):
+        ops._skinny_launch(torch.randn(5000, 48, device=dev), torch.randn(64, 48, device=dev), None)
