@@ -497,7 +497,7 @@ extern "C" int spt_fused_linear_bwd_f32(const float* gy, const float* h, int64_t
   double* pst = (double*)((char*)ws + align_up((size_t)256 * 8 * N * K * 4, 256));
 #define X(a, b)                                                                                  \
   if (k4 == a && nbk == b) {                                                                     \
-    constexpr bool big = (a * b >= 96);   /* (N/4)*(K/16) B-operand registers would not fit */  \
+    constexpr bool big = (a * b >= 32);   /* W as LDS B operands, 8-wave blocks */              \
     constexpr int NWV = big ? 8 : 4;                                                             \
     grid = grid_for_nw(r1 - r0, 1, NWV);                                                         \
     nw = grid * NWV;                                                                             \

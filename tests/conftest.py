@@ -28,6 +28,14 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+@pytest.fixture(autouse=True)
+def _seed_global_rng():
+    """Module constructors draw their initial weights from torch's GLOBAL generator:
+    seed it per test so that every run (and every box) sees the same parameters."""
+    torch.manual_seed(20240607)
+    yield
+
+
 def load_golden(name):
     d = np.load(os.path.join(GOLDEN, name))
     return {k: d[k] for k in d.files}

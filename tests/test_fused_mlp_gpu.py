@@ -35,10 +35,30 @@ def test_fused_mlp_matches_oracle_and_unfused_path(dims, rows, B, dev):
     ref = copy.deepcopy(mlp).double()
     OM.KEEP_GRAPH = True
     x64 = x.double().requires_grad_()
-    yr = OM.mlp(ref, x64, batch, torch.float64)
-    pre_last = yr.detach()
-    # elements within f32 rounding of the last LeakyReLU kink may take the other slope
-    gw = gw * (pre_last.abs() > 1e-3).float()
+    # the oracle layer by layer (same calls as OM.mlp), keeping every pre-activation
+    pre_acts, h = [], x64
+    for layer in ref.mlp:
+        if isinstance(layer, torch.nn.Linear):
+            h = h @ layer.weight.t()
+        elif isinstance(layer, torch.nn.LeakyReLU):
+            pre_acts.append(h.detach())
+            h = torch.nn.functional.leaky_relu(h, layer.negative_slope)
+        else:
+            h = OM.graph_norm(layer, h, batch, torch.float64)
+    yr = h
+    assert torch.equal(yr.detach(), OM.mlp(copy.deepcopy(mlp).double(), x.double(), batch,
+                                           torch.float64).detach())
+    # LeakyReLU kinks: a pre-activation within f32 rounding of 0 takes one slope or the
+    # other depending on the summation order (MFMA vs library vs f64) and moves the
+    # gradients by that row's whole contribution (about 1/sqrt(rows) of the total; at
+    # these sizes ~1 such element per run is EXPECTED: 4.5 M hidden values, density 0.4
+    # per unit, f32 error 3e-7).  Rows holding any pre-activation closer than 1e-4 to a
+    # kink (about 0.5 % of them) get a zero upstream gradient, so the comparison judges
+    # the arithmetic and not the coin flips.
+    safe = torch.ones(rows, dtype=torch.bool)
+    for pa in pre_acts:
+        safe &= (pa.abs() > 1e-4).all(dim=1)
+    gw = gw * safe.view(-1, 1).float()
     (yr * gw.double()).sum().backward()
     OM.KEEP_GRAPH = False
 
@@ -59,10 +79,8 @@ def test_fused_mlp_matches_oracle_and_unfused_path(dims, rows, B, dev):
         bad = int((err > tol).sum())
         assert bad <= outliers, f"{name}: {bad} elements above {tol}, max {err.max().item():.3e}"
 
-    # A hidden pre-activation within f32 rounding of a LeakyReLU kink takes one slope
-    # or the other depending on the GEMM's summation order (MFMA vs library, f32 vs
-    # f64): the rows of gx fed by such an element legitimately differ.  Expect a
-    # handful among rows * hidden elements, never a pattern.
+    # kink rows carry no upstream gradient; what reaches them through the GraphNorm
+    # statistics is O(1/rows) - a handful of gx elements may still sit above the bar
     few = 8 * dims[0]
 
     close(yf, yr.detach(), 2e-5, "y")
