@@ -26,6 +26,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int WAVES = 4;
 constexpr int TR = 16;          // rows per MFMA tile
 constexpr int MAX_BLOCKS = 1024;
+constexpr int MAX_BWD_WAVES = 4096;   // per-wave partial tables of the backward
 
 __device__ __forceinline__ double xg_sum_d(double v) {
   v += __shfl_xor(v, 16, 64);
@@ -190,7 +191,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_kernel(
   constexpr int LDG = N + 4, LDX = KPP + 4;
   __shared__ __attribute__((aligned(16))) float g_lds[NW][TR * LDG];   // gh tile
   __shared__ __attribute__((aligned(16))) float x_lds[NW][TR * LDX];   // RAW h_prev tile
-  __shared__ __attribute__((aligned(16))) float w_lds[(NEED_GX && W_IN_LDS) ? N * KPP : 4];
+  // row stride KPP + 16: lane groups g = 0..3 read rows 4 st + g, whose 16-float column
+  // windows then fall on alternating halves of the 32 LDS banks (2 lanes per bank = the
+  // natural wave64 rate) instead of all four on the same 16 banks
+  constexpr int LDW = KPP + 16;
+  __shared__ __attribute__((aligned(16))) float w_lds[(NEED_GX && W_IN_LDS) ? N * LDW : 4];
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, c = lane & 15;
@@ -202,7 +207,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_kernel(
   if constexpr (NEED_GX && W_IN_LDS) {
     for (int i = threadIdx.x; i < N * KPP; i += NW * 64) {
       const int n = i / KPP, k = i - n * KPP;
-      w_lds[i] = (k < K) ? W[(size_t)n * K + k] : 0.f;
+      w_lds[n * LDW + k] = (k < K) ? W[(size_t)n * K + k] : 0.f;
     }
   }
   load_table(gt, am, N, N);
@@ -317,7 +322,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_kernel(
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
           float b;
-          if constexpr (W_IN_LDS) b = w_lds[(4 * st + g) * KPP + 16 * kb + c];
+          if constexpr (W_IN_LDS) b = w_lds[(4 * st + g) * LDW + 16 * kb + c];
           else b = BW[st][kb];
           CX[kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, CX[kb], 0, 0, 0);
         }
@@ -438,7 +443,7 @@ extern "C" int spt_fused_linear_supported(int K, int N) {
 extern "C" size_t spt_fused_linear_workspace_bytes(int K, int N) {
   // fwd: MAX_BLOCKS x (2N+1) doubles; bwd: 1024 waves x (N*K floats + (2K+1) doubles)
   const size_t fwd = (size_t)MAX_BLOCKS * (2 * N + 1) * 8;
-  const size_t bwd = (size_t)256 * 8 * ((size_t)N * K * 4 + (2 * K + 1) * 8);
+  const size_t bwd = (size_t)MAX_BWD_WAVES * ((size_t)N * K * 4 + (2 * K + 1) * 8);
   return align_up(fwd > bwd ? fwd : bwd, 256) + 4096;
 }
 
@@ -456,7 +461,10 @@ extern "C" int spt_fused_linear_fwd_f32(const float* x, int64_t r0, int64_t r1, 
   SPT_CHECK_ARG(ws_bytes >= spt_fused_linear_workspace_bytes(K, N), "workspace too small");
   SPT_CHECK_ARG(!pre_am || (pre_scale && pre_bias), "incomplete pre-normalisation tables");
   const int k4 = (K + 3) / 4, nbk = N / 16;
-  const int grid = grid_for(r1 - r0, 2) < MAX_BLOCKS ? grid_for(r1 - r0, 2) : MAX_BLOCKS;
+  // small layers are latency-bound: give every SIMD 4 waves to overlap tiles (the
+  // 64 -> 128 layer holds W in 128 B-operand registers and fits 2)
+  const int per_cu = (k4 * nbk <= 32) ? 4 : 2;
+  const int grid = grid_for(r1 - r0, per_cu) < MAX_BLOCKS ? grid_for(r1 - r0, per_cu) : MAX_BLOCKS;
   double* partial = (double*)ws;
 #define X(a, b)                                                                        \
   if (k4 == a && nbk == b)                                                             \
@@ -494,12 +502,14 @@ extern "C" int spt_fused_linear_bwd_f32(const float* gy, const float* h, int64_t
   const int k4 = (K + 3) / 4, nbk = N / 16;
   int grid = 1, nw = 1;
   float* gwp = (float*)ws;
-  double* pst = (double*)((char*)ws + align_up((size_t)256 * 8 * N * K * 4, 256));
+  double* pst = (double*)((char*)ws + align_up((size_t)MAX_BWD_WAVES * N * K * 4, 256));
 #define X(a, b)                                                                                  \
   if (k4 == a && nbk == b) {                                                                     \
     constexpr bool big = (a * b >= 32);   /* W as LDS B operands, 8-wave blocks */              \
     constexpr int NWV = big ? 8 : 4;                                                             \
-    grid = grid_for_nw(r1 - r0, 1, NWV);                                                         \
+    /* workgroups per CU the registers / LDS allow: 4 x 4 waves for the small layers, */         \
+    /* 2 x 8 waves while the LDS tiles stay under 80 KB, else 1 x 8 */                            \
+    grid = grid_for_nw(r1 - r0, big ? ((a * b <= 32) ? 2 : 1) : 4, NWV);                         \
     nw = grid * NWV;                                                                             \
     if (gx)                                                                                      \
       bwd_kernel<a, b, true, NWV, big><<<grid, NWV * 64, 0, stream>>>(                           \
