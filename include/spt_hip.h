@@ -324,6 +324,10 @@ int spt_cluster_pair_anchors_f32(const float* points, const int32_t* perm, const
  * spt_relabel_consecutive: consecutive_cluster of values[gather[i]] (gather nullable)
  *   for labels in [0, n_range): new_values [k] dense labels in sorted order, uniques =
  *   the labels present, ascending (data.py:404-406: new super_index / idx_super).
+ * spt_radius_ball_f32: ascending indices of the nodes within r of `center` (HOST float[3];
+ *   z ignored when cylindrical) and of batch item `batch_id` (batch nullable) - the seed
+ *   neighbourhood of SampleRadiusSubgraphs (src/transforms/sampling.py:1196-1230, via
+ *   knn_brute_force, src/utils/neighbors.py:245-295: Euclidean norm, d <= r kept).
  * ---------------------------------------------------------------------- */
 int spt_index_inverse(const int64_t* idx, int64_t k, int64_t n, int64_t* inv,
                       spt_stream_t stream);
@@ -337,6 +341,11 @@ int spt_cluster_select(const int64_t* pointers, const int64_t* points, int64_t n
                        const int64_t* idx, int64_t k, int64_t n_sub, int64_t* new_pointers,
                        int64_t* new_points, int64_t* idx_sub, int64_t* sub_super,
                        int64_t* count_sub, void* ws, size_t ws_bytes, spt_stream_t stream);
+size_t spt_radius_ball_workspace_bytes(int64_t n);
+int spt_radius_ball_f32(const float* pos, int64_t n, const float* center, float r,
+                        int cylindrical, const int64_t* batch, int64_t batch_id,
+                        int64_t* out_idx, int64_t* count, void* ws, size_t ws_bytes,
+                        spt_stream_t stream);
 size_t spt_relabel_consecutive_workspace_bytes(int64_t n_range);
 int spt_relabel_consecutive(const int64_t* values, const int64_t* gather, int64_t k,
                             int64_t n_range, int64_t* new_values, int64_t* uniques,

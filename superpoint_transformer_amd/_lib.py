@@ -78,6 +78,8 @@ SIGNATURES = {
     "spt_cluster_select": (_int, [_p, _p, _i64, _p, _i64, _i64, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "spt_relabel_consecutive_workspace_bytes": (_sz, [_i64]),
     "spt_relabel_consecutive": (_int, [_p, _p, _i64, _i64, _p, _p, _p, _p, _sz, _p]),
+    "spt_radius_ball_workspace_bytes": (_sz, [_i64]),
+    "spt_radius_ball_f32": (_int, [_p, _i64, _p, _f32, _int, _p, _i64, _p, _p, _p, _sz, _p]),
     "spt_cluster_pair_anchors_f32": (_int, [_p, _p, _p, _p, _p, _i64, _i64, _int, _int, _p, _p, _p]),
 }
 

@@ -152,6 +152,20 @@ __global__ void relabel_kernel(const int64_t* __restrict__ values,
   }
 }
 
+// ---- radius ball around a seed (SampleRadiusSubgraphs) -------------------------------
+__global__ void ball_flags_kernel(const float* __restrict__ pos, int64_t n, float cx, float cy,
+                                  float cz, float wz, float r, const int64_t* __restrict__ batch,
+                                  int64_t batch_id, uint32_t* __restrict__ flag) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += stride) {
+    if (i == n) { flag[i] = 0; continue; }
+    const float dx = pos[i * 3] - cx, dy = pos[i * 3 + 1] - cy, dz = (pos[i * 3 + 2] - cz) * wz;
+    const float d = sqrtf(dx * dx + dy * dy + dz * dz);      // (xyz_search - xyz_query).norm()
+    const bool same = !batch || batch[i] == batch_id;
+    flag[i] = (same && d <= r) ? 1u : 0u;                    // neighbors.py:283-285 keeps d <= r
+  }
+}
+
 static size_t scan_part_bytes(int64_t m) {
   return align_up((size_t)ceil_div(m > 0 ? m : 1, SCAN_TILE) * 4, 256);
 }
@@ -304,6 +318,30 @@ extern "C" int spt_relabel_consecutive(const int64_t* values, const int64_t* gat
                                                             new_values);
   compact_present_kernel<<<stream_grid(n_range + 1, 256), 256, 0, stream>>>(present, n_range,
                                                                           uniques, count);
+  SPT_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" size_t spt_radius_ball_workspace_bytes(int64_t n) {
+  if (n < 0) return 0;
+  return align_up((size_t)(n + 1) * 4, 256) + scan_part_bytes(n + 1);
+}
+
+extern "C" int spt_radius_ball_f32(const float* pos, int64_t n, const float* center, float r,
+                                   int cylindrical, const int64_t* batch, int64_t batch_id,
+                                   int64_t* out_idx, int64_t* count, void* ws, size_t ws_bytes,
+                                   spt_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPT_CHECK_ARG(n >= 0 && n < ((int64_t)1 << 32) - 2 && r >= 0.f, "bad shape");
+  SPT_CHECK_ARG(count && center, "null pointer");
+  SPT_CHECK_ARG(ws && ws_bytes >= spt_radius_ball_workspace_bytes(n), "workspace too small");
+  SPT_CHECK_ARG(n == 0 || (pos && out_idx), "null pointer");
+  uint32_t* flag = (uint32_t*)ws;
+  uint32_t* part = (uint32_t*)((char*)ws + align_up((size_t)(n + 1) * 4, 256));
+  ball_flags_kernel<<<stream_grid(n + 1, 256), 256, 0, stream>>>(
+      pos, n, center[0], center[1], center[2], cylindrical ? 0.f : 1.f, r, batch, batch_id, flag);
+  device_exclusive_scan(flag, n + 1, part, stream);
+  compact_present_kernel<<<stream_grid(n + 1, 256), 256, 0, stream>>>(flag, n, out_idx, count);
   SPT_CHECK_LAUNCH();
   return 0;
 }

@@ -1,12 +1,15 @@
 """Per-batch on-device graph transforms of the hot path's "next" rows
 (SURVEY.md 8f): on-the-fly horizontal edge features fused with the edge
 symmetrisation and the self loops."""
+import ctypes
+
 import torch
 
 from . import _lib
 
 __all__ = ["horizontal_edge_features", "EDGE_FEATURE_COLUMNS", "NodeSize", "SampleSubNodes",
-           "SampleSegments", "SampleEdges", "OnTheFlyHorizontalEdgeFeatures"]
+           "SampleSegments", "SampleEdges", "OnTheFlyHorizontalEdgeFeatures",
+           "SampleRadiusSubgraphs"]
 
 EDGE_FEATURE_COLUMNS = [
     "mean_off_x", "mean_off_y", "mean_off_z", "std_off_x", "std_off_y", "std_off_z",
@@ -147,3 +150,77 @@ class OnTheFlyHorizontalEdgeFeatures:
                 d.edge_index, d.edge_attr, d.pos, d[self.normal_key], d.log_length, d.log_surface,
                 d.log_volume, d.log_size, add_self_loops=self.add_self_loops)
         return nag
+
+
+class SampleRadiusSubgraphs:
+    """Keep the level-``i_level`` nodes within ``r`` of ``k`` random seed nodes (at most
+    the ``k_max`` nearest per seed), each neighbourhood as its own batch item when
+    ``disjoint`` (src/transforms/sampling.py:810-1000, 1094-1230).  Seeds are drawn like
+    the reference (uniform ``torch.multinomial``, spread over the batch items when the
+    level carries a ``batch``; ``by_size`` / ``by_class`` are not mirrored); ``idx_seed``
+    overrides the draw."""
+
+    def __init__(self, r=2, k_max=10000, i_level=1, k=1, use_batch=True, disjoint=False,
+                 cylindrical=False, idx_seed=None):
+        self.r, self.k_max, self.i_level, self.k = r, k_max, i_level, k
+        self.use_batch, self.disjoint, self.cylindrical, self.idx_seed = \
+            use_batch, disjoint, cylindrical, idx_seed
+
+    def _seeds(self, data, k):
+        n = data.num_nodes
+        dev = data.device
+        w = torch.ones(n, device=dev)
+        batch = data.batch if "batch" in data else None
+        if batch is None or not self.use_batch:
+            return torch.multinomial(w, k, replacement=False)
+        ids = batch.unique()
+        ids = ids[torch.randperm(ids.numel())]
+        kb = max(k // ids.numel(), 1)
+        out, done = [], 0
+        for step, b in enumerate(ids):
+            if step >= ids.numel() - 1:
+                kb = k - done
+            m = torch.where(batch == b)[0]
+            out.append(m[torch.multinomial(w[m], kb, replacement=False)])
+            done += kb
+            if done >= k:
+                break
+        return torch.cat(out)
+
+    def _ball(self, data, seed):
+        from .ops import _workspace
+        dev = data.device
+        pos = data.pos.detach().float().contiguous()
+        n = pos.shape[0]
+        batch = data.batch.long().contiguous() if "batch" in data else None
+        c = pos[seed].cpu()
+        center = (ctypes.c_float * 3)(float(c[0]), float(c[1]), float(c[2]))
+        out = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
+        count = torch.zeros(1, dtype=torch.int64, device=dev)
+        nbytes = _lib.lib.spt_radius_ball_workspace_bytes(n)
+        ws = _workspace(nbytes, dev)
+        with torch.cuda.device(dev):
+            st = _lib.lib.spt_radius_ball_f32(
+                _lib.ptr(pos), n, ctypes.cast(center, ctypes.c_void_p), float(self.r),
+                int(self.cylindrical), _lib.ptr(batch), int(batch[seed]) if batch is not None else 0,
+                _lib.ptr(out), _lib.ptr(count), _lib.ptr(ws), nbytes, _lib.stream_ptr(dev))
+        _lib.check(st, "spt_radius_ball_f32")
+        idx = out[:int(count)]
+        if idx.numel() > self.k_max:                      # keep the k_max nearest (rare)
+            w = torch.tensor([1.0, 1.0, 0.0 if self.cylindrical else 1.0], device=dev)
+            d = ((pos[idx] - pos[seed]) * w).norm(dim=1)
+            idx = idx[torch.topk(d, self.k_max, largest=False).indices].sort().values
+        return idx
+
+    def __call__(self, nag):
+        from .data import NAG
+        if self.i_level is None or self.k <= 0 or self.r is None or self.r <= 0:
+            return nag
+        i_level = nag.num_levels - 1 if self.i_level == -1 else self.i_level
+        data = nag[i_level]
+        k = self.k if self.k < data.num_nodes else 1
+        seeds = self.idx_seed if self.idx_seed is not None else self._seeds(data, k)
+        balls = [self._ball(data, int(s)) for s in seeds]
+        if self.disjoint:
+            return NAG.from_nag_list([nag.select(i_level, idx) for idx in balls])
+        return nag.select(i_level, torch.unique(torch.cat(balls)))

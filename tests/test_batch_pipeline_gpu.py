@@ -126,3 +126,45 @@ def test_batch_preparation_at_train_batch_scale(dev):
     print(f"on-device batch preparation, scene T: {ev[0].elapsed_time(ev[1]):.1f} ms "
           f"{nag0.num_points} -> {nag.num_points}")
     check_hierarchy(nag)
+
+
+def test_radius_subgraphs_match_the_brute_force_neighbourhoods(dev):
+    from superpoint_transformer_amd.synthetic import make_raw_nag
+    from superpoint_transformer_amd import transforms as T
+    nag = make_raw_nag("R", device=dev)
+    pos1 = nag[1].pos.cpu()
+    seeds = torch.tensor([5, 700, 311])
+    for cyl in (False, True):
+        t = T.SampleRadiusSubgraphs(r=6.0, k_max=10000, i_level=1, k=3, disjoint=False,
+                                    cylindrical=cyl, idx_seed=seeds)
+        out = t(nag)
+        w = torch.tensor([[1.0, 1.0, 0.0 if cyl else 1.0]])
+        nb, _ = O.knn_brute_force(pos1 * w, pos1[seeds] * w, pos1.shape[0], r_max=6.0)
+        expect = nb[nb >= 0].unique()                       # sampling.py:1228
+        assert out.num_points[1] == expect.numel() and expect.numel() > 20
+        assert torch.equal(out[1].pos.cpu(), pos1[expect])
+        check_hierarchy(out)
+    # k_max caps every ball at its nearest nodes
+    t = T.SampleRadiusSubgraphs(r=6.0, k_max=15, i_level=1, k=1, idx_seed=seeds[:1])
+    out = t(nag)
+    nb, _ = O.knn_brute_force(pos1, pos1[seeds[:1]], 15, r_max=6.0)
+    assert torch.equal(out[1].pos.cpu(), pos1[nb[nb >= 0].unique()])
+
+
+def test_disjoint_radius_subgraphs_become_batch_items(dev):
+    from superpoint_transformer_amd.hotpath import SPTSegmenter, spt64_config
+    from superpoint_transformer_amd.synthetic import make_raw_nag
+    from superpoint_transformer_amd import transforms as T
+    torch.manual_seed(3)
+    nag = T.NodeSize(0)(make_raw_nag("R", device=dev))
+    out = T.SampleRadiusSubgraphs(r=7.0, k_max=10000, i_level=1, k=4, disjoint=True)(nag)
+    check_hierarchy(out)
+    for i in range(3):
+        b = out[i].batch
+        assert int(b.max()) == 3 and bool((b[1:] >= b[:-1]).all())    # 4 contiguous items
+    assert torch.equal(out[1].batch[out[0].super_index], out[0].batch)
+    out = T.OnTheFlyHorizontalEdgeFeatures()(out)
+    out.num_clouds = 4
+    model = SPTSegmenter(**spt64_config(out[0].x.shape[1], 18)).to(dev)
+    logits = model(out)
+    assert logits[0].shape[0] == out.num_points[1] and torch.isfinite(logits[0]).all()
