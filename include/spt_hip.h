@@ -235,11 +235,19 @@ int spt_grid_knn_f32(const float* query, int64_t nq, const float* search, int64_
  * [n+1] int64 (pgeof layout).  add_self: count the point itself (geometry.py:95-96);
  * features are zeroed where the neighbourhood has < k_min points; post != 0
  * applies geometric_features' tail (verticality * 2, normal flipped to z >= 0,
- * geometry.py:121,124).
+ * geometry.py:121,124).  order (nullable): a permutation of the points, e.g.
+ * spt_spatial_order's; points are visited in that order so that the neighbourhoods a
+ * wave gathers overlap (results do not depend on it).
+ * spt_spatial_order: order[j] = j-th point when grouped by the cells of a uniform grid
+ * (HOST cell_size / origin[3] / dims[3] as for spt_grid_knn_f32).
  * ---------------------------------------------------------------------- */
+size_t spt_spatial_order_workspace_bytes(int64_t n, int64_t ncells);
+int spt_spatial_order(const float* xyz, int64_t n, float cell_size, const float* origin,
+                      const int32_t* dims, int32_t* order, void* ws, size_t ws_bytes,
+                      spt_stream_t stream);
 int spt_point_geof_dense_f32(const float* xyz, int64_t n, const int64_t* nn, int k,
-                             int add_self, int k_min, int post, float* feats,
-                             spt_stream_t stream);
+                             int add_self, int k_min, int post, const int32_t* order,
+                             float* feats, spt_stream_t stream);
 int spt_point_geof_csr_f32(const float* xyz, int64_t n, const int64_t* nn_val,
                            const int64_t* nn_ptr, int add_self, int k_min, int post,
                            float* feats, spt_stream_t stream);

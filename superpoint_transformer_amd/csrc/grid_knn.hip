@@ -273,6 +273,40 @@ static KnnPlan knn_plan(int64_t ns, int64_t ncells) {
   return p;
 }
 
+// ---- spatial (cell) order of a cloud -----------------------------------------------------
+// order[j] = index of the j-th point when points are grouped by grid cell (z, y, x major):
+// consumers that gather neighbourhoods (point_geof.hip) visit points in this order so that
+// the rows one wave touches overlap and stay in L2.
+extern "C" size_t spt_spatial_order_workspace_bytes(int64_t n, int64_t ncells) {
+  if (n < 0 || ncells < 1) return 0;
+  return align_up((size_t)(n > 0 ? n : 1) * 8, 256) + align_up((size_t)(ncells + 1) * 4, 256) +
+         align_up(spt_csr_build_workspace_bytes(n, ncells), 256);
+}
+
+extern "C" int spt_spatial_order(const float* xyz, int64_t n, float cell_size, const float* origin,
+                                 const int32_t* dims, int32_t* order, void* ws, size_t ws_bytes,
+                                 spt_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPT_CHECK_ARG(n >= 0 && cell_size > 0.f && origin && dims, "bad arguments");
+  SPT_CHECK_ARG(dims[0] >= 1 && dims[1] >= 1 && dims[2] >= 1, "bad grid dims");
+  const int64_t ncells = (int64_t)dims[0] * dims[1] * dims[2];
+  SPT_CHECK_ARG(ncells < ((int64_t)1 << 31), "grid has more than 2^31 cells: enlarge cell_size");
+  if (n == 0) return 0;
+  SPT_CHECK_ARG(xyz && order, "null pointer");
+  SPT_CHECK_ARG(ws && ws_bytes >= spt_spatial_order_workspace_bytes(n, ncells), "workspace too small");
+  Grid g;
+  g.ox = origin[0]; g.oy = origin[1]; g.oz = origin[2];
+  g.s = cell_size; g.inv_s = 1.0f / cell_size;
+  g.dx = dims[0]; g.dy = dims[1]; g.dz = dims[2];
+  char* base = (char*)ws;
+  int64_t* cell = (int64_t*)base;
+  int32_t* rowptr = (int32_t*)(base + align_up((size_t)n * 8, 256));
+  char* sortws = (char*)rowptr + align_up((size_t)(ncells + 1) * 4, 256);
+  knn_cell_ids_kernel<<<stream_grid(n, 256), 256, 0, stream>>>(xyz, n, g, cell);
+  return spt_csr_build(cell, n, ncells, order, rowptr, sortws,
+                       spt_csr_build_workspace_bytes(n, ncells), stream_);
+}
+
 extern "C" size_t spt_grid_knn_workspace_bytes(int64_t ns, int64_t ncells) {
   if (ns < 0 || ncells < 1) return 0;
   return knn_plan(ns, ncells).total;

@@ -68,17 +68,72 @@ __device__ __forceinline__ void eigh3(double (&a)[3][3], double (&w)[3], double 
 #undef SPT_SWAP
 }
 
-// neighbours of point i: dense rows nn[i*k .. i*k+k) with negative = missing, or
-// CSR val[ptr[i] .. ptr[i+1]).
-template <bool CSR>
-__global__ __launch_bounds__(256) void point_geof_kernel(
-    const float* __restrict__ xyz, int64_t n, const int64_t* __restrict__ nn, int k,
+// moments (sums of d and d d^T about an origin, count) -> the 11 features of one point
+__device__ __forceinline__ void finish_features(const double s1[3], const double s2[6], int cnt,
+                                                int k_min, int post, float* __restrict__ out) {
+  double w[3] = {1.0, 1.0, 1.0};
+  double v[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  if (cnt > 0) {                       // cnt == 0: scatter.py:113-118 -> (1,1,1) / I
+    const double inv = 1.0 / (double)cnt;
+    const double mx = s1[0] * inv, my = s1[1] * inv, mz = s1[2] * inv;
+    double a[3][3];
+    a[0][0] = s2[0] * inv - mx * mx;
+    a[0][1] = a[1][0] = s2[1] * inv - mx * my;
+    a[0][2] = a[2][0] = s2[2] * inv - mx * mz;
+    a[1][1] = s2[3] * inv - my * my;
+    a[1][2] = a[2][1] = s2[4] * inv - my * mz;
+    a[2][2] = s2[5] * inv - mz * mz;
+    eigh3(a, w, v);
+  }
+#pragma unroll
+  for (int q = 0; q < 3; ++q) w[q] = w[q] > 0.0 ? w[q] : 0.0;     // scatter.py:123
+  // geometry.py:292-315
+  const double l1 = sqrt(w[2]), l2 = sqrt(w[1]), l3 = sqrt(w[0]);
+  double f[11];
+  f[0] = (l1 - l2) / (l1 + 1e-3);
+  f[1] = (l2 - l3) / (l1 + 1e-3);
+  f[2] = l3 / (l1 + 1e-3);
+  double un[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+    un[r] = fabs(v[r][0]) * w[0] + fabs(v[r][1]) * w[1] + fabs(v[r][2]) * w[2];
+  f[3] = un[2] / (sqrt(un[0] * un[0] + un[1] * un[1] + un[2] * un[2]) + 1e-8);
+  f[4] = v[0][0]; f[5] = v[1][0]; f[6] = v[2][0];                 // normal = smallest eigvec
+  f[7] = l1;
+  f[8] = sqrt(l1 * l2 + 1e-6);
+  f[9] = cbrt(l1 * l2 * l3 + 1e-9);
+  f[10] = l3 / (l1 + l2 + l3 + 1e-3);
+  if (cnt < k_min) {                                              // geometry.py:318-327
+#pragma unroll
+    for (int q = 0; q < 11; ++q) f[q] = 0.0;
+  }
+  if (post) {                                                     // geometry.py:121,124
+    f[3] *= 2.0;
+    if (f[6] < 0.0) { f[4] = -f[4]; f[5] = -f[5]; f[6] = -f[6]; }
+  }
+#pragma unroll
+  for (int q = 0; q < 11; ++q) out[q] = (float)f[q];
+}
+
+__device__ __forceinline__ void accumulate(const float* __restrict__ xyz, int64_t t, double px,
+                                           double py, double pz, double s1[3], double s2[6],
+                                           int& cnt) {
+  const double dx = (double)xyz[t * 3] - px, dy = (double)xyz[t * 3 + 1] - py,
+               dz = (double)xyz[t * 3 + 2] - pz;
+  s1[0] += dx; s1[1] += dy; s1[2] += dz;
+  s2[0] += dx * dx; s2[1] += dx * dy; s2[2] += dx * dz;
+  s2[3] += dy * dy; s2[4] += dy * dz; s2[5] += dz * dz;
+  ++cnt;
+}
+
+// CSR neighbourhoods val[ptr[i] .. ptr[i+1]): one lane per group
+__global__ __launch_bounds__(256) void point_geof_csr_kernel(
+    const float* __restrict__ xyz, int64_t n, const int64_t* __restrict__ nn,
     const int64_t* __restrict__ ptr, int add_self, int k_min, int post,
     float* __restrict__ feats) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const int64_t lo = CSR ? ptr[i] : i * k;
-    const int64_t hi = CSR ? ptr[i + 1] : lo + k;
+    const int64_t lo = ptr[i], hi = ptr[i + 1];
     // origin of the moment sums: the point itself when it is part of its own
     // neighbourhood, else the first valid neighbour (row i of nn then describes a
     // GROUP of points, e.g. the samples of segment i - src/transforms/graph.py:239-242)
@@ -89,61 +144,79 @@ __global__ __launch_bounds__(256) void point_geof_kernel(
     }
     const double px = o < 0 ? 0.0 : (double)xyz[o * 3], py = o < 0 ? 0.0 : (double)xyz[o * 3 + 1],
                  pz = o < 0 ? 0.0 : (double)xyz[o * 3 + 2];
-    // sums of d = x_j - origin: the self contributes d = 0
     double s1[3] = {0, 0, 0}, s2[6] = {0, 0, 0, 0, 0, 0};
-    int cnt = add_self ? 1 : 0;
+    int cnt = add_self ? 1 : 0;          // the self contributes d = 0
     for (int64_t j = lo; j < hi; ++j) {
       const int64_t t = nn[j];
-      if (t < 0) continue;
-      const double dx = (double)xyz[t * 3] - px, dy = (double)xyz[t * 3 + 1] - py,
-                   dz = (double)xyz[t * 3 + 2] - pz;
-      s1[0] += dx; s1[1] += dy; s1[2] += dz;
-      s2[0] += dx * dx; s2[1] += dx * dy; s2[2] += dx * dz;
-      s2[3] += dy * dy; s2[4] += dy * dz; s2[5] += dz * dz;
-      ++cnt;
+      if (t >= 0) accumulate(xyz, t, px, py, pz, s1, s2, cnt);
     }
-    double w[3] = {1.0, 1.0, 1.0};
-    double v[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
-    if (cnt > 0) {                       // cnt == 0: scatter.py:113-118 -> (1,1,1) / I
-      const double inv = 1.0 / (double)cnt;
-      const double mx = s1[0] * inv, my = s1[1] * inv, mz = s1[2] * inv;
-      double a[3][3];
-      a[0][0] = s2[0] * inv - mx * mx;
-      a[0][1] = a[1][0] = s2[1] * inv - mx * my;
-      a[0][2] = a[2][0] = s2[2] * inv - mx * mz;
-      a[1][1] = s2[3] * inv - my * my;
-      a[1][2] = a[2][1] = s2[4] * inv - my * mz;
-      a[2][2] = s2[5] * inv - mz * mz;
-      eigh3(a, w, v);
+    finish_features(s1, s2, cnt, k_min, post, feats + i * 11);
+  }
+}
+
+// Dense neighbourhoods nn[i*k .. i*k+k), negative = missing: one lane per point, one wave
+// per 64 points.  Half of the naive kernel's time was the index stream: lanes reading their
+// own 8 k-byte rows touch 64 different cache lines per load and come back to each line 16
+// times.  Here the wave loads the index columns [c0, c0+8) of its 64 rows cooperatively
+// (8 lanes x 8 B = one 64-byte run per row) into LDS and each lane then reads its row back;
+// the 8 position gathers of a chunk are independent and in flight together.
+constexpr int GEOF_CH = 8;              // index columns per chunk
+constexpr int GEOF_LD = GEOF_CH + 1;    // padded LDS row (int64 units)
+
+__global__ __launch_bounds__(256) void point_geof_dense_kernel(
+    const float* __restrict__ xyz, int64_t n, const int64_t* __restrict__ nn, int k,
+    int add_self, int k_min, int post, const int32_t* __restrict__ order,
+    float* __restrict__ feats) {
+  __shared__ int64_t idx_lds[4][64 * GEOF_LD];
+  const int lane = threadIdx.x & 63;
+  const int wid = threadIdx.x >> 6;
+  int64_t* il = idx_lds[wid];
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int sub = lane >> 3, cc = lane & 7;
+  for (int64_t base = wave * 64; base < n; base += nwaves * 64) {
+    const int64_t ii = base + lane;
+    // visiting order: spatially sorted when given, so that the neighbourhoods gathered by
+    // the lanes of a wave overlap and stay in cache
+    const int64_t i = (ii < n) ? (order ? (int64_t)order[ii] : ii) : -1;
+    double px = 0.0, py = 0.0, pz = 0.0;
+    bool have_origin = false;
+    if (i >= 0 && add_self) {
+      px = xyz[i * 3]; py = xyz[i * 3 + 1]; pz = xyz[i * 3 + 2];
+      have_origin = true;
     }
+    double s1[3] = {0, 0, 0}, s2[6] = {0, 0, 0, 0, 0, 0};
+    int cnt = (i >= 0 && add_self) ? 1 : 0;
+    for (int c0 = 0; c0 < k; c0 += GEOF_CH) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int q = 0; q < 3; ++q) w[q] = w[q] > 0.0 ? w[q] : 0.0;     // scatter.py:123
-    // geometry.py:292-315
-    const double l1 = sqrt(w[2]), l2 = sqrt(w[1]), l3 = sqrt(w[0]);
-    double f[11];
-    f[0] = (l1 - l2) / (l1 + 1e-3);
-    f[1] = (l2 - l3) / (l1 + 1e-3);
-    f[2] = l3 / (l1 + 1e-3);
-    double un[3];
+      for (int p = 0; p < 8; ++p) {
+        const int row = 8 * p + sub;
+        const int64_t ri = __shfl(i, row, 64);
+        const int col = c0 + cc;
+        il[row * GEOF_LD + cc] = (ri >= 0 && col < k) ? nn[ri * k + col] : -1;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      int64_t t[GEOF_CH];
 #pragma unroll
-    for (int r = 0; r < 3; ++r)
-      un[r] = fabs(v[r][0]) * w[0] + fabs(v[r][1]) * w[1] + fabs(v[r][2]) * w[2];
-    f[3] = un[2] / (sqrt(un[0] * un[0] + un[1] * un[1] + un[2] * un[2]) + 1e-8);
-    f[4] = v[0][0]; f[5] = v[1][0]; f[6] = v[2][0];                 // normal = smallest eigvec
-    f[7] = l1;
-    f[8] = sqrt(l1 * l2 + 1e-6);
-    f[9] = cbrt(l1 * l2 * l3 + 1e-9);
-    f[10] = l3 / (l1 + l2 + l3 + 1e-3);
-    if (cnt < k_min) {                                              // geometry.py:318-327
+      for (int q = 0; q < GEOF_CH; ++q) t[q] = il[lane * GEOF_LD + q];
+      if (!have_origin) {
+        // no self: the first valid neighbour is the origin (see point_geof_csr_kernel)
 #pragma unroll
-      for (int q = 0; q < 11; ++q) f[q] = 0.0;
+        for (int q = 0; q < GEOF_CH; ++q)
+          if (!have_origin && t[q] >= 0) {
+            px = xyz[t[q] * 3]; py = xyz[t[q] * 3 + 1]; pz = xyz[t[q] * 3 + 2];
+            have_origin = true;
+          }
+      }
+#pragma unroll
+      for (int q = 0; q < GEOF_CH; ++q)
+        if (t[q] >= 0) accumulate(xyz, t[q], px, py, pz, s1, s2, cnt);
     }
-    if (post) {                                                     // geometry.py:121,124
-      f[3] *= 2.0;
-      if (f[6] < 0.0) { f[4] = -f[4]; f[5] = -f[5]; f[6] = -f[6]; }
-    }
-#pragma unroll
-    for (int q = 0; q < 11; ++q) feats[i * 11 + q] = (float)f[q];
+    if (i >= 0) finish_features(s1, s2, cnt, k_min, post, feats + i * 11);
   }
 }
 
@@ -153,13 +226,14 @@ using namespace spt;
 
 extern "C" int spt_point_geof_dense_f32(const float* xyz, int64_t n, const int64_t* nn,
                                         int k, int add_self, int k_min, int post,
-                                        float* feats, spt_stream_t stream_) {
+                                        const int32_t* order, float* feats,
+                                        spt_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SPT_CHECK_ARG(n >= 0 && k >= 0, "bad shape");
   if (n == 0) return 0;
   SPT_CHECK_ARG(xyz && feats && (nn || k == 0), "null pointer");
-  point_geof_kernel<false><<<stream_grid(n, 256), 256, 0, stream>>>(
-      xyz, n, nn, k, nullptr, add_self, k_min, post, feats);
+  point_geof_dense_kernel<<<stream_grid(n, 256), 256, 0, stream>>>(
+      xyz, n, nn, k, add_self, k_min, post, order, feats);
   SPT_CHECK_LAUNCH();
   return 0;
 }
@@ -171,8 +245,8 @@ extern "C" int spt_point_geof_csr_f32(const float* xyz, int64_t n, const int64_t
   SPT_CHECK_ARG(n >= 0, "bad shape");
   if (n == 0) return 0;
   SPT_CHECK_ARG(xyz && feats && nn_ptr, "null pointer");
-  point_geof_kernel<true><<<stream_grid(n, 256), 256, 0, stream>>>(
-      xyz, n, nn_val, 0, nn_ptr, add_self, k_min, post, feats);
+  point_geof_csr_kernel<<<stream_grid(n, 256), 256, 0, stream>>>(
+      xyz, n, nn_val, nn_ptr, add_self, k_min, post, feats);
   SPT_CHECK_LAUNCH();
   return 0;
 }

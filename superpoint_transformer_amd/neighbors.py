@@ -132,22 +132,50 @@ def neighbors_dense_to_csr(nn):
     return ptr, nn[~mask], sizes
 
 
-def geometric_features(xyz, nn, k_min=1, add_self_as_neighbor=True, raw=False):
+def spatial_order(xyz, points_per_cell=32):
+    """int32 permutation grouping the points by the cells of a uniform grid holding
+    about ``points_per_cell`` points each (one host sync for the bounding box)."""
+    _lib.require_cuda(xyz)
+    p = xyz.detach().float().contiguous()
+    n = p.shape[0]
+    ext = float((p.max(dim=0).values - p.min(dim=0).values).max())
+    s, lo_h, dims = _grid_for(p, max(ext, 1e-3) / 64, points_per_cell / 1.5)
+    ncells = dims[0] * dims[1] * dims[2]
+    order = torch.empty(max(n, 1), dtype=torch.int32, device=p.device)
+    nbytes = _lib.lib.spt_spatial_order_workspace_bytes(n, ncells)
+    ws = _workspace(nbytes, p.device)
+    o3 = (ctypes.c_float * 3)(*lo_h)
+    d3 = (ctypes.c_int32 * 3)(*dims)
+    with torch.cuda.device(p.device):
+        st = _lib.lib.spt_spatial_order(
+            _lib.ptr(p), n, float(s), ctypes.cast(o3, ctypes.c_void_p),
+            ctypes.cast(d3, ctypes.c_void_p), _lib.ptr(order), _lib.ptr(ws), nbytes,
+            _lib.stream_ptr(p.device))
+    _lib.check(st, "spt_spatial_order")
+    return order[:n]
+
+
+def geometric_features(xyz, nn, k_min=1, add_self_as_neighbor=True, raw=False, order=None):
     """[N,11] features in pgeof's column order (``GEOF_COLUMNS``) from dense
     neighbours ``nn`` [N,k] (-1 = missing).  ``raw=False`` includes the tail of
     ``geometric_features`` (verticality * 2, normals flipped to z >= 0,
-    geometry.py:121,124)."""
+    geometry.py:121,124).  ``order``: optional visiting order of the points (e.g.
+    ``spatial_order(xyz)``: neighbourhoods gathered by one wave then overlap - 13 vs 17 ms
+    at 15 M shuffled points, but the sort itself costs more than that unless it is
+    reused); the result does not depend on it."""
     _lib.require_cuda(xyz, nn)
     p = xyz.detach().float().contiguous()
     nn = nn.contiguous()
     if nn.dtype != torch.int64:
         nn = nn.long()
     n, k = nn.shape
+    if order is not None:
+        order = order.to(torch.int32).contiguous()
     feats = torch.empty((n, 11), dtype=torch.float32, device=p.device)
     with torch.cuda.device(p.device):
         st = _lib.lib.spt_point_geof_dense_f32(
             _lib.ptr(p), n, _lib.ptr(nn), k, int(add_self_as_neighbor), int(k_min),
-            0 if raw else 1, _lib.ptr(feats), _lib.stream_ptr(p.device))
+            0 if raw else 1, _lib.ptr(order), _lib.ptr(feats), _lib.stream_ptr(p.device))
     _lib.check(st, "spt_point_geof_dense_f32")
     return feats
 

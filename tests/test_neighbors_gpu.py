@@ -165,3 +165,18 @@ def test_preprocess_pipeline_on_demo_room_regresses_to_stored_features(dev):
         # the stored room was voxelised/sub-sampled after feature computation, so
         # neighbourhoods differ slightly: compare distributions, not points
         assert err.median().item() < 0.05, (key, err.median().item())
+
+
+def test_visiting_order_does_not_change_the_features(dev):
+    """geometric_features can visit the points in a spatial order (cache locality of the
+    gathers); the features are bit-identical whatever the visiting order."""
+    from superpoint_transformer_amd import neighbors as NB
+    from superpoint_transformer_amd.synthetic import make_voxel_cloud
+    pos = make_voxel_cloud(260_000, voxel=0.03, seed=5, device=dev, extent=(12.0, 12.0, 4.0))
+    nb, _ = NB.knn_1(pos, 20, 0.5)
+    order = NB.spatial_order(pos)
+    assert order.dtype == torch.int32
+    assert torch.equal(torch.sort(order.long()).values, torch.arange(pos.shape[0], device=dev))
+    a = NB.geometric_features(pos, nb, k_min=1, order=None)
+    b = NB.geometric_features(pos, nb, k_min=1, order=order)
+    assert torch.equal(a, b)
