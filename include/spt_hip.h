@@ -217,6 +217,10 @@ int spt_edge_attn_bwd_f32(const float* qkv, int64_t n, int H, int D, int Dv,
  * ws: spt_grid_knn_workspace_bytes(ns, ncells).
  * ---------------------------------------------------------------------- */
 size_t spt_grid_knn_workspace_bytes(int64_t ns, int64_t ncells);
+/* Bounding box of a cloud, the input of the host-side grid description above
+ * (src/utils/neighbors.py has no counterpart: FRNN derives its grid internally).
+ * lo_hi: DEVICE float[12]; [0..3) = min, [3..6) = max, [6..12) scratch. */
+int spt_bbox_f32(const float* xyz, int64_t n, float* lo_hi, spt_stream_t stream);
 int spt_grid_knn_f32(const float* query, int64_t nq, const float* search, int64_t ns,
                      int K, float r, float cell_size, const float* origin,
                      const int32_t* dims, int order_queries_by_cell, int inclusive,

@@ -273,10 +273,67 @@ static KnnPlan knn_plan(int64_t ns, int64_t ncells) {
   return p;
 }
 
+// ---- bounding box --------------------------------------------------------------------
+// torch's column reductions of a tall [n, 3] tensor take ~8 ms each at 15 M points; the
+// grid description needs min and max before anything else can start.
+__device__ __forceinline__ uint32_t bbox_key(float f) {      // order-preserving f32 -> u32
+  const uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ __launch_bounds__(256) void bbox_init_kernel(uint32_t* __restrict__ keys) {
+  if (threadIdx.x < 3) keys[threadIdx.x] = 0xffffffffu;        // running minima
+  else if (threadIdx.x < 6) keys[threadIdx.x] = 0u;            // running maxima
+}
+
+__global__ __launch_bounds__(256) void bbox_kernel(const float* __restrict__ xyz, int64_t n,
+                                                   uint32_t* __restrict__ keys) {
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const float v = xyz[i * 3 + q];
+      lo[q] = fminf(lo[q], v);
+      hi[q] = fmaxf(hi[q], v);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    lo[q] = wave_reduce_min(lo[q]);
+    hi[q] = wave_reduce_max(hi[q]);
+  }
+  if ((threadIdx.x & 63) == 0) {                               // integer atomics: order-free
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      atomicMin(&keys[q], bbox_key(lo[q]));
+      atomicMax(&keys[3 + q], bbox_key(hi[q]));
+    }
+  }
+}
+
+__global__ void bbox_decode_kernel(const uint32_t* __restrict__ keys, float* __restrict__ out) {
+  if (threadIdx.x < 6) {
+    const uint32_t k = keys[threadIdx.x];
+    out[threadIdx.x] = __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+  }
+}
+
 // ---- spatial (cell) order of a cloud -----------------------------------------------------
 // order[j] = index of the j-th point when points are grouped by grid cell (z, y, x major):
 // consumers that gather neighbourhoods (point_geof.hip) visit points in this order so that
 // the rows one wave touches overlap and stay in L2.
+extern "C" int spt_bbox_f32(const float* xyz, int64_t n, float* lo_hi, spt_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPT_CHECK_ARG(n >= 1 && xyz && lo_hi, "bad arguments");
+  uint32_t* keys = (uint32_t*)(lo_hi + 6);                     // caller provides 12 floats
+  bbox_init_kernel<<<1, 256, 0, stream>>>(keys);
+  bbox_kernel<<<stream_grid(n, 256 * 8), 256, 0, stream>>>(xyz, n, keys);
+  bbox_decode_kernel<<<1, 64, 0, stream>>>(keys, lo_hi);
+  SPT_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" size_t spt_spatial_order_workspace_bytes(int64_t n, int64_t ncells) {
   if (n < 0 || ncells < 1) return 0;
   return align_up((size_t)(n > 0 ? n : 1) * 8, 256) + align_up((size_t)(ncells + 1) * 4, 256) +

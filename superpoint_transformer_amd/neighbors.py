@@ -16,14 +16,23 @@ GEOF_COLUMNS = ["linearity", "planarity", "scattering", "verticality", "normal_x
                 "normal_y", "normal_z", "length", "surface", "volume", "curvature"]
 
 
+def _bbox(xyz):
+    """(min [3], max [3]) of a contiguous f32 cloud on the device."""
+    buf = torch.empty(12, dtype=torch.float32, device=xyz.device)
+    with torch.cuda.device(xyz.device):
+        st = _lib.lib.spt_bbox_f32(_lib.ptr(xyz), xyz.shape[0], _lib.ptr(buf),
+                                   _lib.stream_ptr(xyz.device))
+    _lib.check(st, "spt_bbox_f32")
+    return buf[0:3], buf[3:6]
+
+
 def _grid_for(search, r, K, cell_size=None):
     """Host-side grid description (one sync: the bounding box).  The result
     does not depend on the cell size, only the speed does: ~1.5 K points per
     non-empty cell measured fastest (few rings, few row ranges per ring).  The
     occupancy is estimated on a <=200 k-point subsample at a coarse probe size
     and scaled as s^2 (points lie on surfaces)."""
-    lo = search.min(dim=0).values
-    hi = search.max(dim=0).values
+    lo, hi = _bbox(search)
     lo_h, hi_h = lo.tolist(), hi.tolist()
     ext = [max(h - l, 1e-6) for l, h in zip(lo_h, hi_h)]
     n = search.shape[0]
@@ -138,7 +147,8 @@ def spatial_order(xyz, points_per_cell=32):
     _lib.require_cuda(xyz)
     p = xyz.detach().float().contiguous()
     n = p.shape[0]
-    ext = float((p.max(dim=0).values - p.min(dim=0).values).max())
+    lo, hi = _bbox(p)
+    ext = float((hi - lo).max())
     s, lo_h, dims = _grid_for(p, max(ext, 1e-3) / 64, points_per_cell / 1.5)
     ncells = dims[0] * dims[1] * dims[2]
     order = torch.empty(max(n, 1), dtype=torch.int32, device=p.device)
