@@ -48,6 +48,9 @@ def scatter_max(src, index, dim=-1, out=None, dim_size=None):
 def scatter_std(src, index, dim=-1, out=None, dim_size=None, unbiased=True):
     _check(src, index, dim, out)
     from ..csr import csr_of
+    if unbiased and not src.requires_grad and src.dim() <= 2:
+        from ..segment import scatter_std as segment_std      # one kernel, two passes in-cache
+        return segment_std(src, index, dim_size).to(src.dtype)
     csr = csr_of(index, dim_size)
     cnt = csr.counts().to(src.dtype).view((-1,) + (1,) * (src.dim() - 1))
     mean = ops.segment_reduce(src, csr, None, "sum") / cnt.clamp(min=1)
