@@ -164,6 +164,22 @@ __device__ __forceinline__ void rpe_gemm(const float (&A)[8], const float (&B)[N
       C[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[st], B[b][st], C[b], 0, 0, 0);
 }
 
+// Same product with the B operands read from the padded LDS copy of [Wk; Wq; Wv]
+// (row n = output column, stride W_LD): lane (g, c) reads w[(row0 + 16 b + c) W_LD + 4 st + g],
+// bank = c + g (+ const) - conflict-free up to the natural 2 lanes per bank.
+constexpr int W_LD = F + 1;
+__device__ __forceinline__ void rpe_gemm_lds(const float (&A)[8], const float* w, int row0, int g,
+                                             int c, const float (&init)[NB], f32x4 (&C)[NB]) {
+#pragma unroll
+  for (int b = 0; b < NB; ++b) C[b] = (f32x4){init[b], init[b], init[b], init[b]};
+  const float* wr = w + (row0 + c) * W_LD + g;
+#pragma unroll
+  for (int st = 0; st < 8; ++st)
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+      C[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[st], wr[16 * b * W_LD + 4 * st], C[b], 0, 0, 0);
+}
+
 // Three-deep software pipeline over the tiles of a wave's nodes (s, s+nw, ...):
 //   cur : being computed out of LDS buffer b
 //   nxt : its edge_attr / k / v rows are streaming into buffer b^1
@@ -374,7 +390,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_fwd_mfma_kernel(
 constexpr int DT_STRIDE = 196;                 // transposed D tile: [16 edges][192 (+4 pad)]
 constexpr int DT_FLOATS = TE * DT_STRIDE;      // 3136 floats = 12.25 KB
 
-constexpr int W_FLOATS = 192 * F;   // [Wk; Wq; Wv] rows, shared by the 4 waves (B operands of D W)
+constexpr int W_FLOATS = 192 * (F + 1);   // [Wk; Wq; Wv] rows (padded), shared by the 4 waves:
+                                          // B operands of the recompute GEMM and of D W
 
 __global__ __launch_bounds__(WAVES * 64, 1) void attn_bwd_mfma_kernel(
     const float* __restrict__ qkv, int ld, int64_t N, const int32_t* __restrict__ erowptr,
@@ -393,16 +410,14 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attn_bwd_mfma_kernel(
   const int g = lane >> 4, c = lane & 15;
   float* dt = dt_all[wid];
   for (int i = threadIdx.x; i < 64 * F; i += WAVES * 64) {
-    w_lds[i] = Wk[i];
-    w_lds[64 * F + i] = Wq[i];
-    w_lds[128 * F + i] = Wv[i];
+    const int n = i / F, f = i - n * F;
+    w_lds[n * W_LD + f] = Wk[i];
+    w_lds[(64 + n) * W_LD + f] = Wq[i];
+    w_lds[(128 + n) * W_LD + f] = Wv[i];
   }
   __syncthreads();
 
-  float Bk[NB][8], Bq[NB][8], Bv[NB][8], bk4[NB], bq4[NB], bv4[NB];
-  load_b(Wk, g, c, Bk);
-  load_b(Wq, g, c, Bq);
-  load_b(Wv, g, c, Bv);
+  float bk4[NB], bq4[NB], bv4[NB];
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     bk4[b] = bk ? bk[16 * b + c] : 0.f;
@@ -429,6 +444,19 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attn_bwd_mfma_kernel(
     P.init(wave, nwaves, N, erowptr, eperm, tgt, qkv, ld, ea, slab_all[wid][0], slab_all[wid][1],
            lane);
     float qs4[NB], m[NB], zi[NB], delta[NB], g4[NB], dqa[NB];
+    // rows of the NEXT node (gout, out, m, z), fetched one tile ahead: read at the node's
+    // first tile they cost a full memory latency per node with nothing to hide it behind
+    float g4n[NB], on[NB], mn[NB], zn[NB];
+    auto fetch_node_rows = [&](int64_t sn) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        g4n[b] = gout[sn * 64 + 16 * b + c];
+        on[b] = out[sn * 64 + 16 * b + c];
+        mn[b] = mbuf[sn * 16 + 4 * b + (c >> 2)];
+        zn[b] = zbuf[sn * 16 + 4 * b + (c >> 2)];
+      }
+    };
+    fetch_node_rows(wave);
     float scale = 0.f;
     while (P.cur.valid) {
       wait_vmem_all();
@@ -450,19 +478,20 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attn_bwd_mfma_kernel(
         for (int b = 0; b < NB; ++b) {
           qs4[b] = fmaf(qraw[b], scale, bq4[b]);
           dqa[b] = 0.f;
-          g4[b] = gout[s * 64 + 16 * b + c];
-          delta[b] = quad_sum(g4[b] * out[s * 64 + 16 * b + c]);   // <g, out> per head
-          m[b] = mbuf[s * 16 + 4 * b + (c >> 2)];
-          zi[b] = 1.0f / (zbuf[s * 16 + 4 * b + (c >> 2)] + 1e-16f);
+          g4[b] = g4n[b];
+          delta[b] = quad_sum(g4[b] * on[b]);                       // <g, out> per head
+          m[b] = mn[b];
+          zi[b] = 1.0f / (zn[b] + 1e-16f);
         }
       }
+      if (P.nxt.valid && P.nxt.t0 == P.nxt.start) fetch_node_rows(P.nxt.s);
       if (cnt > 0) {
         float A[8];
         load_a(slab, g, c, A);
         f32x4 Ck[NB], Cq[NB], Cv[NB];
-        rpe_gemm(A, Bk, bk4, Ck);
-        rpe_gemm(A, Bq, qs4, Cq);
-        rpe_gemm(A, Bv, bv4, Cv);
+        rpe_gemm_lds(A, w_lds, 0, g, c, bk4, Ck);
+        rpe_gemm_lds(A, w_lds, 64, g, c, qs4, Cq);
+        rpe_gemm_lds(A, w_lds, 128, g, c, bv4, Cv);
         const float* kp = kslab + 4 * g * ROW + c;
         const float* vp = vslab + 4 * g * ROW + c;
         int64_t trow[4];
@@ -513,11 +542,11 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attn_bwd_mfma_kernel(
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         f32x4 C2[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
         const float* arow = dt + c * DT_STRIDE + g;       // A[i = edge c][k = 4 st + g]
-        const float* brow = w_lds + g * F + c;            // B[k = 4 st + g][j = 16 fb + c]
+        const float* brow = w_lds + g * W_LD + c;         // B[k = 4 st + g][j = 16 fb + c]
 #pragma unroll 8
         for (int st = 0; st < 48; ++st) {
           const float a = arow[4 * st];
-          const float b0 = brow[4 * st * F], b1 = brow[4 * st * F + 16];
+          const float b0 = brow[4 * st * W_LD], b1 = brow[4 * st * W_LD + 16];
           C2[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0, C2[0], 0, 0, 0);
           C2[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1, C2[1], 0, 0, 0);
         }
