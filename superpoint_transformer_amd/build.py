@@ -25,6 +25,15 @@ FLAGS = [
 ] + os.environ.get("SPT_EXTRA_HIPCC_FLAGS", "").split()
 
 
+# per-file code generation options
+#   edge_attn_mfma.hip: keep MFMA accumulators / results in the VGPR file.  With the default
+#   (AGPR form) the attention backward moved ~300 values per tile between AGPRs and VGPRs
+#   (v_accvgpr_read / write), because its MFMA results feed VALU code.
+PER_FILE_FLAGS = {
+    "edge_attn_mfma.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+}
+
+
 def _sources():
     return sorted(
         os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
@@ -46,7 +55,7 @@ def _stale(target, deps):
 def _compile(src):
     obj = os.path.join(OBJDIR, os.path.basename(src)[:-4] + ".o")
     if _stale(obj, [src] + _headers()):
-        cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [HIPCC] + FLAGS + PER_FILE_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(

@@ -164,20 +164,50 @@ __device__ __forceinline__ void rpe_gemm(const float (&A)[8], const float (&B)[N
       C[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[st], B[b][st], C[b], 0, 0, 0);
 }
 
-// Same product with the B operands read from the padded LDS copy of [Wk; Wq; Wv]
-// (row n = output column, stride W_LD): lane (g, c) reads w[(row0 + 16 b + c) W_LD + 4 st + g],
-// bank = c + g (+ const) - conflict-free up to the natural 2 lanes per bank.
+// The three RPE products of a tile with the B operands read from the padded LDS copy of
+// [Wk; Wq; Wv] (row n = output column, stride W_LD): lane (g, c) reads
+// w[(64 p + 16 b + c) W_LD + 4 st + g], bank = c + g (+ const) - conflict-free up to the
+// natural 2 lanes per bank.  Software-pipelined by hand: the 12 operands of k-step st + 1
+// are in flight while the 12 MFMAs of step st run, so only 24 of them are ever live (left
+// to itself the scheduler hoists all 96 loads and spills into AGPRs).
 constexpr int W_LD = F + 1;
-__device__ __forceinline__ void rpe_gemm_lds(const float (&A)[8], const float* w, int row0, int g,
-                                             int c, const float (&init)[NB], f32x4 (&C)[NB]) {
+__device__ __forceinline__ void rpe_gemm3_lds(const float (&A)[8], const float* w, int g, int c,
+                                              const float (&ik)[NB], const float (&iq)[NB],
+                                              const float (&iv)[NB], f32x4 (&Ck)[NB],
+                                              f32x4 (&Cq)[NB], f32x4 (&Cv)[NB]) {
 #pragma unroll
-  for (int b = 0; b < NB; ++b) C[b] = (f32x4){init[b], init[b], init[b], init[b]};
-  const float* wr = w + (row0 + c) * W_LD + g;
+  for (int b = 0; b < NB; ++b) {
+    Ck[b] = (f32x4){ik[b], ik[b], ik[b], ik[b]};
+    Cq[b] = (f32x4){iq[b], iq[b], iq[b], iq[b]};
+    Cv[b] = (f32x4){iv[b], iv[b], iv[b], iv[b]};
+  }
+  const float* wr = w + c * W_LD + g;
+  float cur[3][NB], nxt[3][NB];
 #pragma unroll
-  for (int st = 0; st < 8; ++st)
+  for (int p = 0; p < 3; ++p)
 #pragma unroll
-    for (int b = 0; b < NB; ++b)
-      C[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[st], wr[16 * b * W_LD + 4 * st], C[b], 0, 0, 0);
+    for (int b = 0; b < NB; ++b) cur[p][b] = wr[(64 * p + 16 * b) * W_LD];
+#pragma unroll
+  for (int st = 0; st < 8; ++st) {
+    if (st < 7) {
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) nxt[p][b] = wr[(64 * p + 16 * b) * W_LD + 4 * (st + 1)];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      Ck[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[st], cur[0][b], Ck[b], 0, 0, 0);
+      Cq[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[st], cur[1][b], Cq[b], 0, 0, 0);
+      Cv[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[st], cur[2][b], Cv[b], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int b = 0; b < NB; ++b) cur[p][b] = nxt[p][b];
+  }
 }
 
 // Three-deep software pipeline over the tiles of a wave's nodes (s, s+nw, ...):
@@ -489,9 +519,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attn_bwd_mfma_kernel(
         float A[8];
         load_a(slab, g, c, A);
         f32x4 Ck[NB], Cq[NB], Cv[NB];
-        rpe_gemm_lds(A, w_lds, 0, g, c, bk4, Ck);
-        rpe_gemm_lds(A, w_lds, 64, g, c, qs4, Cq);
-        rpe_gemm_lds(A, w_lds, 128, g, c, bv4, Cv);
+        rpe_gemm3_lds(A, w_lds, g, c, bk4, qs4, bv4, Ck, Cq, Cv);
         const float* kp = kslab + 4 * g * ROW + c;
         const float* vp = vslab + 4 * g * ROW + c;
         int64_t trow[4];
