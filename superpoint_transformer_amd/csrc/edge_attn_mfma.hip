@@ -546,9 +546,19 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attn_bwd_mfma_kernel(
             gb[b] += dk;
             gb[NB + b] += dq;
             gb[2 * NB + b] += dv;
-            if (valid) {
-              unsafeAtomicAdd(gqkv + trow[r] + 64 + 16 * b + c, dk);
-              unsafeAtomicAdd(gqkv + trow[r] + 128 + 16 * b + c, dv);
+          }
+        }
+        // dk / dv go to the target rows.  One branch per edge row r (validity depends on
+        // (g, r) only) instead of one per (b, r): the 16 iterations above stay one basic
+        // block the scheduler can interleave.
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (4 * g + r < cnt) {
+            float* row = gqkv + trow[r] + c;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+              unsafeAtomicAdd(row + 64 + 16 * b, Ck[b][r]);
+              unsafeAtomicAdd(row + 128 + 16 * b, Cv[b][r]);
             }
           }
         }
