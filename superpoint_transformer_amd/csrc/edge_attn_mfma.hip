@@ -581,12 +581,36 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attn_bwd_mfma_kernel(
         f32x4 C2[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
         const float* arow = dt + c * DT_STRIDE + g;       // A[i = edge c][k = 4 st + g]
         const float* brow = w_lds + g * W_LD + c;         // B[k = 4 st + g][j = 16 fb + c]
-#pragma unroll 8
-        for (int st = 0; st < 48; ++st) {
-          const float a = arow[4 * st];
-          const float b0 = brow[4 * st * W_LD], b1 = brow[4 * st * W_LD + 16];
-          C2[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0, C2[0], 0, 0, 0);
-          C2[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1, C2[1], 0, 0, 0);
+        // operands of the next 4 k-steps in flight under the 8 MFMAs of the current 4
+        {
+          float ac[4], b0c[4], b1c[4], an[4], b0n[4], b1n[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            ac[u] = arow[4 * u];
+            b0c[u] = brow[4 * u * W_LD];
+            b1c[u] = brow[4 * u * W_LD + 16];
+          }
+#pragma unroll
+          for (int grp = 0; grp < 12; ++grp) {
+            if (grp < 11) {
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                const int st = 4 * (grp + 1) + u;
+                an[u] = arow[4 * st];
+                b0n[u] = brow[4 * st * W_LD];
+                b1n[u] = brow[4 * st * W_LD + 16];
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              C2[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[u], b0c[u], C2[0], 0, 0, 0);
+              C2[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[u], b1c[u], C2[1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { ac[u] = an[u]; b0c[u] = b0n[u]; b1c[u] = b1n[u]; }
+          }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
