@@ -316,15 +316,49 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_kernel(
       f32x4 CX[KB];
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb) CX[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if constexpr (W_IN_LDS) {
+        // operands of k-steps st+1, st+2 in flight under the MFMAs of st, st-1 (the
+        // scheduler, left alone, waits for every LDS read right before its MFMA)
+        constexpr int G = (KB > 4) ? 1 : 2;              // k-steps per group
+        float ac[G], bc[G][KB], an[G], bn[G][KB];
 #pragma unroll
-      for (int st = 0; st < N / 4; ++st) {
-        const float a = gl[c * LDG + 4 * st + g];       // A[i = row c][k = 4 st + g]
+        for (int u = 0; u < G; ++u) {
+          ac[u] = gl[c * LDG + 4 * u + g];               // A[i = row c][k = 4 st + g]
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {
-          float b;
-          if constexpr (W_IN_LDS) b = w_lds[(4 * st + g) * LDW + 16 * kb + c];
-          else b = BW[st][kb];
-          CX[kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, CX[kb], 0, 0, 0);
+          for (int kb = 0; kb < KB; ++kb) bc[u][kb] = w_lds[(4 * u + g) * LDW + 16 * kb + c];
+        }
+#pragma unroll
+        for (int grp = 0; grp < N / 4 / G; ++grp) {
+          if (grp + 1 < N / 4 / G) {
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+              const int st = G * (grp + 1) + u;
+              an[u] = gl[c * LDG + 4 * st + g];
+#pragma unroll
+              for (int kb = 0; kb < KB; ++kb) bn[u][kb] = w_lds[(4 * st + g) * LDW + 16 * kb + c];
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int u = 0; u < G; ++u)
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb)
+              CX[kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[u], bc[u][kb], CX[kb], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int u = 0; u < G; ++u) {
+            ac[u] = an[u];
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) bc[u][kb] = bn[u][kb];
+          }
+        }
+      } else {
+#pragma unroll
+        for (int st = 0; st < N / 4; ++st) {
+          const float a = gl[c * LDG + 4 * st + g];     // A[i = row c][k = 4 st + g]
+#pragma unroll
+          for (int kb = 0; kb < KB; ++kb)
+            CX[kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, BW[st][kb], CX[kb], 0, 0, 0);
         }
       }
 #pragma unroll
