@@ -99,17 +99,20 @@ class Stage(nn.Module):
         else:
             n, dtype, device = ref.shape[0], ref.dtype, ref.device
 
+        # position / diameter injection (stage.py:249-271): every fusion prepends its
+        # columns, so [diameter_parent | diameter | normalized_pos | x] is built by ONE
+        # concatenation instead of up to three passes over the level's rows
+        parts = [x]
         if pos is not None:                                   # stage.py:249-254
             normalized_pos, diameter_parent = self.pos_norm(
                 pos, super_index, w=node_size, num_super=num_super)
             if self.use_pos:
-                x = self.feature_fusion(normalized_pos, x)
+                parts.insert(0, normalized_pos)
         else:
             diameter_parent = None
         if self.use_diameter:                                 # stage.py:257-261
-            diam = diameter if diameter is not None else \
-                torch.zeros((n, 1), dtype=dtype, device=device)
-            x = self.feature_fusion(diam, x)
+            parts.insert(0, diameter if diameter is not None else
+                         torch.zeros((n, 1), dtype=dtype, device=device))
         if self.use_diameter_parent:                          # stage.py:263-271
             if diameter_parent is None:
                 diam = torch.zeros((n, 1), dtype=dtype, device=device)
@@ -117,7 +120,12 @@ class Stage(nn.Module):
                 diam = diameter_parent.repeat(n, 1)
             else:
                 diam = diameter_parent[super_index]
-            x = self.feature_fusion(diam, x)
+            parts.insert(0, diam)
+        parts = [p for p in parts if p is not None]
+        if len(parts) == 1:
+            x = parts[0]
+        elif parts:
+            x = torch.cat(parts, dim=1)
 
         if self.in_mlp is not None:
             x = self.in_mlp(x, batch=norm_index, batch_size=num_graphs)
