@@ -110,3 +110,16 @@ def test_graph_at_scene_scale(dev):
     assert torch.equal(idx[a[0]], tr[0]) and torch.equal(idx[a[1]], tr[1])
     dn = (pos[a[0]] - pos[a[1]]).norm(dim=1)
     assert torch.allclose(dn, mid["d_nn"], rtol=1e-5, atol=1e-7)
+
+
+def test_graph_degenerate_inputs(dev):
+    from superpoint_transformer_amd.neighbors import cluster_radius_nn_graph
+    # two far-apart clusters: no edge survives
+    pos = torch.cat([torch.rand(50, 3), torch.rand(40, 3) + 100.0]).to(dev)
+    idx = torch.cat([torch.zeros(50), torch.ones(40)]).long().to(dev)
+    ei, d = cluster_radius_nn_graph(pos, idx, k_max=5, gap=0.5)
+    assert ei.shape == (2, 0) and d.numel() == 0
+    # two touching clusters: exactly the edge (0, 1)
+    pos = torch.cat([torch.rand(50, 3), torch.rand(40, 3) + torch.tensor([1.0, 0.0, 0.0])]).to(dev)
+    ei, d = cluster_radius_nn_graph(pos, idx, k_max=5, gap=0.5)
+    assert ei.tolist() == [[0], [1]] and float(d[0]) <= 0.5

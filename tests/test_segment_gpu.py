@@ -203,3 +203,20 @@ def test_sampler_at_scene_scale(dev):
     seg = torch.repeat_interleave(torch.arange(s, device=dev), got)
     assert torch.equal(idx[smp], seg)
     assert torch.unique(smp).numel() == smp.numel()
+
+
+def test_sampler_and_statistics_on_degenerate_inputs(dev):
+    from superpoint_transformer_amd.segment import (sparse_sample, scatter_std,
+                                                    scatter_mean_orientation)
+    empty = torch.zeros(0, dtype=torch.long, device=dev)
+    s, p = sparse_sample(empty, 8, 1, return_pointers=True, num_segments=3)
+    assert s.numel() == 0 and p.tolist() == [0, 0, 0, 0]
+    x = torch.rand(5, 2, device=dev)
+    idx = torch.tensor([2, 2, 2, 0, 2], device=dev)
+    std = scatter_std(x, idx, 4)
+    assert std.shape == (4, 2) and bool((std[[0, 1, 3]] == 0).all())     # singletons / empties
+    ref = O.scatter_std(x.cpu().double(), idx.cpu(), 0, None, 4)
+    assert torch.allclose(std.cpu().double(), ref, atol=1e-6)
+    o = scatter_mean_orientation(torch.tensor([[0.0, 0.0, -2.0]], device=dev),
+                                 torch.zeros(1, dtype=torch.long, device=dev), 1)
+    assert torch.allclose(o.cpu(), torch.tensor([[0.0, 0.0, 1.0]]), atol=1e-4)   # flipped to z+

@@ -180,3 +180,32 @@ def test_select_at_scene_scale(dev):
     ok = keep0[e[0]] & keep0[e[1]]
     assert torch.equal(sel[1].edge_index, inv[e[:, ok]])
     assert torch.equal(sel[1].edge_attr, nag[1].edge_attr[ok])
+
+
+def test_select_edge_cases(dev):
+    from superpoint_transformer_amd.data import NAG, Data, Cluster
+    nag = to_nag(levels_of("in"), dev)
+    n = nag.num_points
+    # a permutation of everything at level 1: nothing disappears, every level is re-ordered
+    perm = torch.randperm(n[1], generator=torch.Generator().manual_seed(1))
+    sel = nag.select(1, perm.to(dev))
+    assert sel.num_points == n
+    ref = O.nag_select(levels_of("in"), 1, perm)
+    for data, r in zip(sel, ref):
+        check_level(data, r)
+    # a single node
+    one = nag.select(2, 3)
+    assert one.num_points[2] == 1 and one.num_points[1] == int((levels_of("in")[1]["super_index"] == 3).sum())
+    assert torch.equal(one[1].sub.to_super_index(), one[0].super_index)
+    # boolean mask
+    mask = torch.zeros(n[1], dtype=torch.bool)
+    mask[::3] = True
+    a = nag.select(1, mask.to(dev))
+    b = nag.select(1, torch.where(mask)[0].to(dev))
+    for x, y in zip(a, b):
+        assert torch.equal(x.pos, y.pos)
+    # a level without edges / an empty selection of edges
+    d = Data(pos=torch.rand(10, 3, device=dev), edge_index=torch.zeros((2, 0), dtype=torch.long, device=dev),
+             edge_attr=torch.zeros((0, 7), device=dev))
+    out, _, _ = d.select(torch.tensor([4, 2], device=dev))
+    assert out.num_nodes == 2 and out.edge_index.shape == (2, 0) and out.edge_attr.shape == (0, 7)
