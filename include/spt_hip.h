@@ -82,6 +82,16 @@ int spt_segcsr_reduce_f32(int op, const float* x, const int32_t* perm,
  *   MEAN: gx[i,:] = gout[idx[i],:] / max(count[idx[i]],1)
  *   MIN/MAX: gx[i,c] = gout[idx[i],c] if arg[idx[i],c]==i else 0
  * (torch_scatter routes the gradient to the single arg element.)           */
+/* Max-pool of y = leaky(scale[g] (x - am[g]) + bias) computed on the fly from the RAW x:
+ * the GraphNorm-apply + LeakyReLU that ends the point MLP (src/nn/mlp.py:46-50) folded into
+ * the L0 -> L1 pool read (src/nn/pool.py:61-82).  am / scale [B, c] per graph, bias [c],
+ * seg_graph [num_seg] int64 graph of each segment (NULL = one graph); out / arg as above.
+ * Same values and arg as applying the norm first, without writing the normalised rows. */
+int spt_segcsr_max_affine_f32(const float* x, const int32_t* perm, const int32_t* rowptr,
+                              int64_t n, int64_t num_seg, int c, const float* am,
+                              const float* scale, const float* bias, float act_slope,
+                              const int64_t* seg_graph, float* out, int32_t* arg,
+                              spt_stream_t stream);
 int spt_segcsr_reduce_bwd_f32(int op, const float* gout, const int32_t* arg,
                               const int64_t* idx, const int32_t* perm,
                               const int32_t* rowptr, int64_t n, int64_t num_seg,

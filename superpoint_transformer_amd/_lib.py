@@ -27,6 +27,7 @@ SIGNATURES = {
     "spt_csr_build_workspace_bytes": (_sz, [_i64, _i64]),
     "spt_csr_build": (_int, [_p, _i64, _i64, _p, _p, _p, _sz, _p]),
     "spt_segcsr_reduce_f32": (_int, [_int, _p, _p, _p, _i64, _i64, _int, _p, _p, _p]),
+    "spt_segcsr_max_affine_f32": (_int, [_p, _p, _p, _i64, _i64, _int, _p, _p, _p, _f32, _p, _p, _p, _p]),
     "spt_segcsr_reduce_bwd_f32": (_int, [_int, _p, _p, _p, _p, _p, _i64, _i64, _int, _p, _p]),
     "spt_segcsr_sum_i64": (_int, [_p, _p, _p, _i64, _i64, _int, _p, _p]),
     "spt_gather_rows_f32": (_int, [_p, _p, _i64, _i64, _int, _p, _p]),

@@ -150,14 +150,26 @@ __device__ __forceinline__ void combine(A& acc, int32_t& accr, A v, int32_t r) {
   }
 }
 
+// Optional per-element map applied to every loaded value BEFORE the reduction:
+// y = leaky(sc[g][c] (x - am[g][c]) + bs[c]), g = graph of the segment.  This is the
+// GraphNorm-apply + LeakyReLU that ends the point MLP: pooling its RAW output this way
+// removes the [15 M, 128] apply pass (read + write of 7.7 GB each) in front of the pool.
+struct Affine {
+  const float* am;           // [B, c] alpha * mean
+  const float* sc;           // [B, c] weight * rstd
+  const float* bs;           // [c]
+  const int64_t* seg_graph;  // [num_seg] graph of each segment, or null (one graph)
+  float slope;
+};
+
 // One lane group of G = LPR*RPG lanes per segment: LPR lanes span the channels
 // of a row (VEC floats each), RPG rows are in flight side by side, UNR deep.
-template <int OP, int VEC, bool ARG>
+template <int OP, int VEC, bool ARG, bool AFF = false>
 __global__ __launch_bounds__(256) void segcsr_reduce_kernel(
     const float* __restrict__ x, const int32_t* __restrict__ perm,
     const int32_t* __restrict__ rowptr, int64_t n, int64_t num_seg, int c,
     int lpr_log2, int rpg_log2, float* __restrict__ out,
-    int32_t* __restrict__ arg) {
+    int32_t* __restrict__ arg, Affine af = Affine{}) {
   constexpr int UNR = SPT_SEG_UNR;
   const int lane = threadIdx.x & 63;
   const int g_log2 = lpr_log2 + rpg_log2;
@@ -210,6 +222,17 @@ __global__ __launch_bounds__(256) void segcsr_reduce_kernel(
         acc[k] = op_identity<OP>();
         accr[k] = 0x7fffffff;
       }
+      float t_am[VEC], t_sc[VEC], t_bs[VEC];
+      const bool leaky01 = AFF && af.slope >= 0.f && af.slope <= 1.f;
+      if constexpr (AFF) {
+        const int64_t gph = (sv && af.seg_graph) ? af.seg_graph[s] : 0;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+          t_am[k] = cv ? af.am[gph * c + c0 + k] : 0.f;
+          t_sc[k] = cv ? af.sc[gph * c + c0 + k] : 0.f;
+          t_bs[k] = cv ? af.bs[c0 + k] : 0.f;
+        }
+      }
       for (int j = start + rsub; j < end; j += rpg * UNR) {
         int32_t r[UNR];
         Vec<VEC> v[UNR];
@@ -225,7 +248,15 @@ __global__ __launch_bounds__(256) void segcsr_reduce_kernel(
         for (int u = 0; u < UNR; ++u)
           if (r[u] >= 0 && cv) {
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) combine<OP, ARG, A>(acc[k], accr[k], (A)v[u].v[k], r[u]);
+            for (int k = 0; k < VEC; ++k) {
+              float val = v[u].v[k];
+              if constexpr (AFF) {
+                val = fmaf(val - t_am[k], t_sc[k], t_bs[k]);     // same expression as gn_apply
+                // leaky(y) == max(y, slope y) for 0 <= slope <= 1 (bitwise, incl. -0 / NaN)
+                val = leaky01 ? fmaxf(val, val * af.slope) : (val > 0.f ? val : val * af.slope);
+              }
+              combine<OP, ARG, A>(acc[k], accr[k], (A)val, r[u]);
+            }
           }
       }
       // tree across the RPG row slots of the group
@@ -533,6 +564,31 @@ extern "C" int spt_segcsr_reduce_f32(int op, const float* x, const int32_t* perm
       launch_reduce_vec<SPT_MAX>(rs.vec, want_arg, x, perm, rowptr, n, num_seg, c, rs.lpr_log2, rpg_log2, out, arg, stream);
       break;
   }
+  SPT_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int spt_segcsr_max_affine_f32(const float* x, const int32_t* perm,
+                                         const int32_t* rowptr, int64_t n, int64_t num_seg,
+                                         int c, const float* am, const float* scale,
+                                         const float* bias, float act_slope,
+                                         const int64_t* seg_graph, float* out, int32_t* arg,
+                                         spt_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPT_CHECK_ARG(n >= 0 && num_seg >= 0 && c >= 4 && (c & 3) == 0, "c must be a multiple of 4");
+  SPT_CHECK_ARG(rowptr && out && arg && am && scale && bias && (x || n == 0), "null pointer");
+  if (num_seg == 0) return 0;
+  const RowShape rs = row_shape(c);
+  SPT_CHECK_ARG(rs.vec == 4, "unsupported row shape");
+  const int rpg_log2 = rows_in_flight_log2(n, num_seg, rs.lpr_log2);
+  const int spw = 64 >> (rs.lpr_log2 + rpg_log2);
+  const int64_t want = ceil_div(ceil_div(num_seg, spw), 4);
+  const int64_t cap = (int64_t)256 * 16 * SPT_SEG_GRIDCAP_MUL;
+  const int grid = (int)(want < cap ? (want > 0 ? want : 1) : cap);
+  Affine af;
+  af.am = am; af.sc = scale; af.bs = bias; af.seg_graph = seg_graph; af.slope = act_slope;
+  segcsr_reduce_kernel<SPT_MAX, 4, true, true><<<grid, 256, 0, stream>>>(
+      x, perm, rowptr, n, num_seg, c, rs.lpr_log2, rpg_log2, out, arg, af);
   SPT_CHECK_LAUNCH();
   return 0;
 }

@@ -128,7 +128,8 @@ class SPTTrainStep:
         bytes_ = n0 * (4 * c + 4) + n1 * (8 * c + 4)
         ms = ops.timer_mean_ms(self.tname)
         ach = bytes_ / (ms * 1e-3) / 1e9 if ms else None
-        return {"bound": "hbm", "kernel": "segcsr_reduce_kernel<MAX,VEC4,ARG> L0->L1 C=128",
+        return {"bound": "hbm", "kernel": "segcsr_reduce_kernel<MAX,VEC4,ARG> L0->L1 C=128 (in the train step: with the "
+                          "point MLP's last GraphNorm + LeakyReLU applied on the fly)",
                 "achieved": round(ach, 1) if ach else None, "peak": peak_gbs,
                 "unit": "GB/s", "frac": round(ach / peak_gbs, 4) if ach else None,
                 "traffic": _pmc_traffic(self.tname), "bytes_per_launch": bytes_,

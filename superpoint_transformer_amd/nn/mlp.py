@@ -54,6 +54,19 @@ class MLP(nn.Module):
 
     FUSE_MIN_ROWS = 16384
 
+    def forward_max_pooled(self, x, index, num_pool, batch=None, batch_size=None,
+                           seg_graph=None):
+        """``max-pool(self(x), index)`` with the last norm + activation folded into the pool's
+        read of the raw activations (ops.fused_mlp_maxpool), or None when that route does not
+        apply (the caller then runs ``self(x)`` and the pool separately)."""
+        if not (x.is_cuda and x.shape[0] >= self.FUSE_MIN_ROWS and
+                (batch is None or batch_size is not None)):
+            return None
+        layers = self._fused_layers()
+        if layers is None:
+            return None
+        return ops.fused_mlp_maxpool(x, batch, batch_size, layers, index, num_pool, seg_graph)
+
     def forward(self, x, batch=None, batch_size=None):
         if x.is_cuda and x.shape[0] >= self.FUSE_MIN_ROWS and (batch is None or batch_size is not None):
             layers = self._fused_layers()

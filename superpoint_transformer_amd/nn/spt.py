@@ -12,7 +12,7 @@ from torch import nn
 from .fusion import CatFusion
 from .mlp import MLP
 from .norm import GraphNorm
-from .pool import pool_factory
+from .pool import MaxPool, pool_factory
 from .stage import DownNFuseStage, PointStage, UpNFuseStage
 from .transformer import VersionHolder
 
@@ -187,11 +187,16 @@ class SPT(nn.Module):
             return _get(lv, "batch")
 
         d0 = levels[0]
+        # the point features feed nothing but the max-pool of the first down stage: let the
+        # first stage hand over pooled features (its last norm then runs inside the pool)
+        fuse_pool = (self.num_down_stages > 0 and
+                     isinstance(getattr(self.down_stages[0], "down_pool_block", None), MaxPool))
         x, diameter = self.first_stage(                       # spt.py:894-913
             _get(d0, "x") if self.use_node_hf else None, norm_index(d0),
             pos=_get(d0, "pos"), node_size=_get(d0, "node_size"),
             super_index=_get(d0, "super_index"), num_super=sizes[1] if len(sizes) > 1 else None,
-            num_graphs=B)
+            num_graphs=B,
+            pool_to_parent=(norm_index(levels[1]),) if fuse_pool else None)
 
         down_outputs, node_x, edge_attrs = [], {}, {}
         for i_stage in range(self.num_down_stages):

@@ -90,7 +90,11 @@ class Stage(nn.Module):
 
     def forward(self, x, norm_index, pos=None, diameter=None, node_size=None,
                 super_index=None, edge_index=None, edge_attr=None, num_super=None,
-                num_graphs=None):
+                num_graphs=None, pool_to_parent=None):
+        """``pool_to_parent`` = (parent batch vector or None): when the stage is only an
+        in_mlp (PointStage) whose output feeds nothing but the max-pool to the parents, the
+        pooled features are returned instead (``PooledToParent``) and the MLP's last
+        norm + activation run inside the pool's read."""
         ref = x if x is not None else pos if pos is not None else diameter
         if ref is None:
             if super_index is None:
@@ -127,6 +131,13 @@ class Stage(nn.Module):
         elif parts:
             x = torch.cat(parts, dim=1)
 
+        if (pool_to_parent is not None and self.in_mlp is not None and super_index is not None
+                and self.transformer_blocks is None and self.out_mlp is None):
+            pooled = self.in_mlp.forward_max_pooled(
+                x, super_index, num_super, batch=norm_index, batch_size=num_graphs,
+                seg_graph=pool_to_parent[0])
+            if pooled is not None:
+                return PooledToParent(pooled), diameter_parent
         if self.in_mlp is not None:
             x = self.in_mlp(x, batch=norm_index, batch_size=num_graphs)
         if self.transformer_blocks is not None:
@@ -142,6 +153,15 @@ class Stage(nn.Module):
         return x, diameter_parent
 
 
+class PooledToParent:
+    """Child features already max-pooled to the parent level (see Stage.forward)."""
+
+    __slots__ = ("x",)
+
+    def __init__(self, x):
+        self.x = x
+
+
 class DownNFuseStage(Stage):
     """pool child features to the parents, fuse with the parents' own
     features, then a Stage (stage.py:321-444)."""
@@ -154,8 +174,11 @@ class DownNFuseStage(Stage):
     def forward(self, x_parent, x_child, norm_index, pool_index, pos=None, diameter=None,
                 node_size=None, super_index=None, edge_index=None, edge_attr=None,
                 v_edge_attr=None, num_super=None, num_graphs=None, num_super_parent=None):
-        x_pooled = self.down_pool_block(x_child, x_parent, pool_index,
-                                        edge_attr=v_edge_attr, num_pool=num_super)
+        if isinstance(x_child, PooledToParent):
+            x_pooled = x_child.x
+        else:
+            x_pooled = self.down_pool_block(x_child, x_parent, pool_index,
+                                            edge_attr=v_edge_attr, num_pool=num_super)
         x_fused = self.fusion(x_parent, x_pooled)
         return super().forward(x_fused, norm_index, pos=pos, node_size=node_size,
                                super_index=super_index, edge_index=edge_index,
@@ -204,7 +227,7 @@ class PointStage(Stage):
 
     def forward(self, x, norm_index, pos=None, diameter=None, node_size=None,
                 super_index=None, edge_index=None, edge_attr=None, coords=None, batch=None,
-                x_mlp=None, num_super=None, num_graphs=None):
+                x_mlp=None, num_super=None, num_graphs=None, pool_to_parent=None):
         return super().forward(x, norm_index, pos, diameter, node_size, super_index,
                                edge_index, edge_attr, num_super=num_super,
-                               num_graphs=num_graphs)
+                               num_graphs=num_graphs, pool_to_parent=pool_to_parent)

@@ -524,53 +524,52 @@ def fused_mlp_supported(dims):
                for k, n in zip(dims[:-1], dims[1:]))
 
 
-class _FusedMLP(torch.autograd.Function):
-    """All layers of one MLP in one autograd node: raw layer outputs h_l are the
-    only [rows, C] tensors kept; normalised activations are never materialised
-    except the final output."""
-
-    @staticmethod
-    def forward(ctx, x, batch, ranges, eps_list, slope_list, *params):
-        L = len(eps_list)
-        Ws = [params[4 * i].detach().float().contiguous() for i in range(L)]
-        gnw = [params[4 * i + 1].detach().float().contiguous() for i in range(L)]
-        gnb = [params[4 * i + 2].detach().float().contiguous() for i in range(L)]
-        gms = [params[4 * i + 3].detach().float().contiguous() for i in range(L)]
-        x2 = x.detach().contiguous()
-        if x2.dtype != torch.float32:
-            x2 = x2.float()
-        R = x2.shape[0]
-        dev = x2.device
-        B = len(ranges) - 1
-        sp = _lib.stream_ptr(dev)
-        hs, tabs = [], []
-        cur, pre = x2, None
-        with torch.cuda.device(dev):
-            for l in range(L):
-                N, K = Ws[l].shape
-                h = torch.empty((R, N), dtype=torch.float32, device=dev)
-                total = torch.empty((B, 2 * N + 1), dtype=torch.float64, device=dev)
-                nb = _lib.lib.spt_fused_linear_workspace_bytes(K, N)
-                ws = _workspace(nb, dev)
-                for g in range(B):
-                    pa = ps = pb = None
-                    if pre is not None:
-                        pa, ps, pb = pre[0][g], pre[1][g], pre[2]
-                    st = _lib.lib.spt_fused_linear_fwd_f32(
-                        _lib.ptr(cur), ranges[g], ranges[g + 1], K, _lib.ptr(Ws[l]), N,
-                        _lib.ptr(pa), _lib.ptr(ps), _lib.ptr(pb),
-                        float(slope_list[l - 1]) if l else 1.0, _lib.ptr(h),
-                        _lib.ptr(total[g]), _lib.ptr(ws), ws.numel(), sp)
-                    _lib.check(st, "spt_fused_linear_fwd_f32")
-                mean = torch.empty((B, N), dtype=torch.float32, device=dev)
-                rstd, am, sc = (torch.empty_like(mean) for _ in range(3))
-                st = _lib.lib.spt_graphnorm_tables_f32(
-                    _lib.ptr(total), B, N, _lib.ptr(gnw[l]), _lib.ptr(gms[l]), float(eps_list[l]),
-                    _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(am), _lib.ptr(sc), sp)
-                _lib.check(st, "spt_graphnorm_tables_f32")
-                hs.append(h)
-                tabs.append((mean, rstd, am, sc))
-                cur, pre = h, (am, sc, gnb[l])
+def _fmlp_forward(x, batch, ranges, eps_list, slope_list, params, apply_last=True):
+    """Forward of the fused layer chain.  Returns (y or None, saved tensors, hs[-1], tables of
+    the last GraphNorm): with ``apply_last=False`` the last norm + activation are left to the
+    consumer (the fused max-pool)."""
+    L = len(eps_list)
+    Ws = [params[4 * i].detach().float().contiguous() for i in range(L)]
+    gnw = [params[4 * i + 1].detach().float().contiguous() for i in range(L)]
+    gnb = [params[4 * i + 2].detach().float().contiguous() for i in range(L)]
+    gms = [params[4 * i + 3].detach().float().contiguous() for i in range(L)]
+    x2 = x.detach().contiguous()
+    if x2.dtype != torch.float32:
+        x2 = x2.float()
+    R = x2.shape[0]
+    dev = x2.device
+    B = len(ranges) - 1
+    sp = _lib.stream_ptr(dev)
+    hs, tabs = [], []
+    cur, pre = x2, None
+    y = None
+    with torch.cuda.device(dev):
+        for l in range(L):
+            N, K = Ws[l].shape
+            h = torch.empty((R, N), dtype=torch.float32, device=dev)
+            total = torch.empty((B, 2 * N + 1), dtype=torch.float64, device=dev)
+            nb = _lib.lib.spt_fused_linear_workspace_bytes(K, N)
+            ws = _workspace(nb, dev)
+            for g in range(B):
+                pa = ps = pb = None
+                if pre is not None:
+                    pa, ps, pb = pre[0][g], pre[1][g], pre[2]
+                st = _lib.lib.spt_fused_linear_fwd_f32(
+                    _lib.ptr(cur), ranges[g], ranges[g + 1], K, _lib.ptr(Ws[l]), N,
+                    _lib.ptr(pa), _lib.ptr(ps), _lib.ptr(pb),
+                    float(slope_list[l - 1]) if l else 1.0, _lib.ptr(h),
+                    _lib.ptr(total[g]), _lib.ptr(ws), ws.numel(), sp)
+                _lib.check(st, "spt_fused_linear_fwd_f32")
+            mean = torch.empty((B, N), dtype=torch.float32, device=dev)
+            rstd, am, sc = (torch.empty_like(mean) for _ in range(3))
+            st = _lib.lib.spt_graphnorm_tables_f32(
+                _lib.ptr(total), B, N, _lib.ptr(gnw[l]), _lib.ptr(gms[l]), float(eps_list[l]),
+                _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(am), _lib.ptr(sc), sp)
+            _lib.check(st, "spt_graphnorm_tables_f32")
+            hs.append(h)
+            tabs.append((mean, rstd, am, sc))
+            cur, pre = h, (am, sc, gnb[l])
+        if apply_last:
             N = Ws[-1].shape[0]
             y = torch.empty((R, N), dtype=torch.float32, device=dev)
             st = _lib.lib.spt_graphnorm_apply_f32(
@@ -578,73 +577,126 @@ class _FusedMLP(torch.autograd.Function):
                 _lib.ptr(tabs[-1][2]), _lib.ptr(tabs[-1][3]), _lib.ptr(gnb[-1]),
                 float(slope_list[-1]), _lib.ptr(y), sp)
             _lib.check(st, "spt_graphnorm_apply_f32")
-        ctx.save_for_backward(x2, batch, *hs, *[t for tab in tabs for t in tab], *Ws, *gnw, *gnb, *gms)
-        ctx.meta = (L, ranges, list(slope_list), x.dtype, x.requires_grad)
+    saved = (x2, batch, *hs, *[t for tab in tabs for t in tab], *Ws, *gnw, *gnb, *gms)
+    return y, saved, hs[-1], (tabs[-1][2], tabs[-1][3], gnb[-1])
+
+
+def _fmlp_backward(saved, meta, gy):
+    """Backward of the fused layer chain from the gradient of its (normalised) output."""
+    L, ranges, slopes, in_dtype, need_gx0 = meta
+    sv = list(saved)
+    x2, batch = sv[0], sv[1]
+    hs = sv[2:2 + L]
+    tabs = [tuple(sv[2 + L + 4 * i: 2 + L + 4 * i + 4]) for i in range(L)]
+    o = 2 + 5 * L
+    Ws, gnw, gnb, gms = sv[o:o + L], sv[o + L:o + 2 * L], sv[o + 2 * L:o + 3 * L], sv[o + 3 * L:o + 4 * L]
+    R = x2.shape[0]
+    dev = x2.device
+    B = len(ranges) - 1
+    sp = _lib.stream_ptr(dev)
+    g_cur = gy.contiguous().float()
+    grads = [None] * (4 * L)
+    gx0 = None
+    with torch.cuda.device(dev):
+        # statistics of the top GraphNorm's backward need their own pass over (h_L, gy)
+        N = Ws[-1].shape[0]
+        mean, rstd, am, sc = tabs[-1]
+        total = torch.empty((B, 2 * N + 1), dtype=torch.float64, device=dev)
+        ws = _workspace(_lib.lib.spt_graphnorm_workspace_bytes(R, N, B), dev)
+        st = _lib.lib.spt_graphnorm_bwd_stats_f32(
+            _lib.ptr(hs[-1]), _lib.ptr(g_cur), _lib.ptr(batch) if B > 1 else None, R, N, B,
+            _lib.ptr(am), _lib.ptr(sc), _lib.ptr(gnb[-1]), float(slopes[-1]), _lib.ptr(total),
+            _lib.ptr(ws), ws.numel(), sp)
+        _lib.check(st, "spt_graphnorm_bwd_stats_f32")
+        for l in range(L - 1, -1, -1):
+            N, K = Ws[l].shape
+            mean, rstd, am, sc = tabs[l]
+            c1, c2, c3 = (torch.empty((B, N), dtype=torch.float32, device=dev) for _ in range(3))
+            gw_n, gb_n, ga_n = (torch.empty(N, dtype=torch.float32, device=dev) for _ in range(3))
+            st = _lib.lib.spt_graphnorm_bwd_tables_f32(
+                _lib.ptr(total), B, N, _lib.ptr(gnw[l]), _lib.ptr(gms[l]), _lib.ptr(mean),
+                _lib.ptr(rstd), _lib.ptr(c1), _lib.ptr(c2), _lib.ptr(c3), _lib.ptr(gw_n),
+                _lib.ptr(gb_n), _lib.ptr(ga_n), sp)
+            _lib.check(st, "spt_graphnorm_bwd_tables_f32")
+            xprev = hs[l - 1] if l else x2
+            pre = tabs[l - 1] if l else None
+            want_gx = l > 0 or need_gx0
+            gx = torch.empty((R, K), dtype=torch.float32, device=dev) if want_gx else None
+            gW = torch.empty((N, K), dtype=torch.float32, device=dev)
+            ptot = torch.empty((B, 2 * K + 1), dtype=torch.float64, device=dev) if l else None
+            ws = _workspace(_lib.lib.spt_fused_linear_workspace_bytes(K, N), dev)
+            for g in range(B):
+                pa = ps = pb = None
+                if pre is not None:
+                    pa, ps, pb = pre[2][g], pre[3][g], gnb[l - 1]
+                st = _lib.lib.spt_fused_linear_bwd_f32(
+                    _lib.ptr(g_cur), _lib.ptr(hs[l]), ranges[g], ranges[g + 1], N,
+                    _lib.ptr(am[g]), _lib.ptr(sc[g]), _lib.ptr(gnb[l]), float(slopes[l]),
+                    _lib.ptr(c1[g]), _lib.ptr(c2[g]), _lib.ptr(c3[g]), _lib.ptr(xprev), K,
+                    _lib.ptr(pa), _lib.ptr(ps), _lib.ptr(pb),
+                    float(slopes[l - 1]) if l else 1.0, _lib.ptr(Ws[l]), _lib.ptr(gx),
+                    _lib.ptr(gW), 1 if g else 0, _lib.ptr(ptot[g]) if l else None,
+                    _lib.ptr(ws), ws.numel(), sp)
+                _lib.check(st, "spt_fused_linear_bwd_f32")
+            grads[4 * l], grads[4 * l + 1], grads[4 * l + 2], grads[4 * l + 3] = gW, gw_n, gb_n, ga_n
+            if l:
+                g_cur, total = gx, ptot
+            else:
+                gx0 = gx
+    return (None if gx0 is None else gx0.to(in_dtype)), grads
+
+
+class _FusedMLP(torch.autograd.Function):
+    """All layers of one MLP in one autograd node: raw layer outputs h_l are the
+    only [rows, C] tensors kept; normalised activations are never materialised
+    except the final output."""
+
+    @staticmethod
+    def forward(ctx, x, batch, ranges, eps_list, slope_list, *params):
+        y, saved, _, _ = _fmlp_forward(x, batch, ranges, eps_list, slope_list, params)
+        ctx.save_for_backward(*saved)
+        ctx.meta = (len(eps_list), ranges, list(slope_list), x.dtype, x.requires_grad)
         return y.to(x.dtype)
 
     @staticmethod
     def backward(ctx, gy):
-        L, ranges, slopes, in_dtype, need_gx0 = ctx.meta
-        sv = list(ctx.saved_tensors)
-        x2, batch = sv[0], sv[1]
-        hs = sv[2:2 + L]
-        tabs = [tuple(sv[2 + L + 4 * i: 2 + L + 4 * i + 4]) for i in range(L)]
-        o = 2 + 5 * L
-        Ws, gnw, gnb, gms = sv[o:o + L], sv[o + L:o + 2 * L], sv[o + 2 * L:o + 3 * L], sv[o + 3 * L:o + 4 * L]
-        R = x2.shape[0]
-        dev = x2.device
-        B = len(ranges) - 1
-        sp = _lib.stream_ptr(dev)
-        g_cur = gy.contiguous().float()
-        grads = [None] * (4 * L)
-        gx0 = None
-        with torch.cuda.device(dev):
-            # statistics of the top GraphNorm's backward need their own pass over (h_L, gy)
-            N = Ws[-1].shape[0]
-            mean, rstd, am, sc = tabs[-1]
-            total = torch.empty((B, 2 * N + 1), dtype=torch.float64, device=dev)
-            ws = _workspace(_lib.lib.spt_graphnorm_workspace_bytes(R, N, B), dev)
-            st = _lib.lib.spt_graphnorm_bwd_stats_f32(
-                _lib.ptr(hs[-1]), _lib.ptr(g_cur), _lib.ptr(batch) if B > 1 else None, R, N, B,
-                _lib.ptr(am), _lib.ptr(sc), _lib.ptr(gnb[-1]), float(slopes[-1]), _lib.ptr(total),
-                _lib.ptr(ws), ws.numel(), sp)
-            _lib.check(st, "spt_graphnorm_bwd_stats_f32")
-            for l in range(L - 1, -1, -1):
-                N, K = Ws[l].shape
-                mean, rstd, am, sc = tabs[l]
-                c1, c2, c3 = (torch.empty((B, N), dtype=torch.float32, device=dev) for _ in range(3))
-                gw_n, gb_n, ga_n = (torch.empty(N, dtype=torch.float32, device=dev) for _ in range(3))
-                st = _lib.lib.spt_graphnorm_bwd_tables_f32(
-                    _lib.ptr(total), B, N, _lib.ptr(gnw[l]), _lib.ptr(gms[l]), _lib.ptr(mean),
-                    _lib.ptr(rstd), _lib.ptr(c1), _lib.ptr(c2), _lib.ptr(c3), _lib.ptr(gw_n),
-                    _lib.ptr(gb_n), _lib.ptr(ga_n), sp)
-                _lib.check(st, "spt_graphnorm_bwd_tables_f32")
-                xprev = hs[l - 1] if l else x2
-                pre = tabs[l - 1] if l else None
-                want_gx = l > 0 or need_gx0
-                gx = torch.empty((R, K), dtype=torch.float32, device=dev) if want_gx else None
-                gW = torch.empty((N, K), dtype=torch.float32, device=dev)
-                ptot = torch.empty((B, 2 * K + 1), dtype=torch.float64, device=dev) if l else None
-                ws = _workspace(_lib.lib.spt_fused_linear_workspace_bytes(K, N), dev)
-                for g in range(B):
-                    pa = ps = pb = None
-                    if pre is not None:
-                        pa, ps, pb = pre[2][g], pre[3][g], gnb[l - 1]
-                    st = _lib.lib.spt_fused_linear_bwd_f32(
-                        _lib.ptr(g_cur), _lib.ptr(hs[l]), ranges[g], ranges[g + 1], N,
-                        _lib.ptr(am[g]), _lib.ptr(sc[g]), _lib.ptr(gnb[l]), float(slopes[l]),
-                        _lib.ptr(c1[g]), _lib.ptr(c2[g]), _lib.ptr(c3[g]), _lib.ptr(xprev), K,
-                        _lib.ptr(pa), _lib.ptr(ps), _lib.ptr(pb),
-                        float(slopes[l - 1]) if l else 1.0, _lib.ptr(Ws[l]), _lib.ptr(gx),
-                        _lib.ptr(gW), 1 if g else 0, _lib.ptr(ptot[g]) if l else None,
-                        _lib.ptr(ws), ws.numel(), sp)
-                    _lib.check(st, "spt_fused_linear_bwd_f32")
-                grads[4 * l], grads[4 * l + 1], grads[4 * l + 2], grads[4 * l + 3] = gW, gw_n, gb_n, ga_n
-                if l:
-                    g_cur, total = gx, ptot
-                else:
-                    gx0 = gx
-        return (None if gx0 is None else gx0.to(in_dtype), None, None, None, None, *grads)
+        gx0, grads = _fmlp_backward(ctx.saved_tensors, ctx.meta, gy)
+        return (gx0, None, None, None, None, *grads)
+
+
+class _FusedMLPMaxPool(torch.autograd.Function):
+    """The fused MLP followed by a max-pool over segments, as ONE node: the last
+    GraphNorm-apply + LeakyReLU run inside the pool's read of the raw h_L (the normalised
+    [rows, C] tensor is never written).  Backward = the pool's scatter of the incoming
+    gradient to the arg rows, then the MLP backward."""
+
+    @staticmethod
+    def forward(ctx, x, batch, ranges, eps_list, slope_list, csr, seg_graph, *params):
+        _, saved, h_last, (am, sc, bs) = _fmlp_forward(x, batch, ranges, eps_list, slope_list,
+                                                        params, apply_last=False)
+        R, N = h_last.shape
+        dev = h_last.device
+        out = torch.empty((csr.num_seg, N), dtype=torch.float32, device=dev)
+        arg = torch.empty((csr.num_seg, N), dtype=torch.int32, device=dev)
+        # same timer key as the plain segment-max: this IS the L0 -> L1 pool launch
+        with torch.cuda.device(dev), _timed(f"segcsr_reduce_fwd:3:{R}x{N}"):
+            st = _lib.lib.spt_segcsr_max_affine_f32(
+                _lib.ptr(h_last), _lib.ptr(csr.perm), _lib.ptr(csr.rowptr), R, csr.num_seg, N,
+                _lib.ptr(am), _lib.ptr(sc), _lib.ptr(bs), float(slope_list[-1]),
+                _lib.ptr(seg_graph), _lib.ptr(out), _lib.ptr(arg), _lib.stream_ptr(dev))
+        _lib.check(st, "spt_segcsr_max_affine_f32")
+        ctx.save_for_backward(arg, *saved)
+        ctx.csr = csr
+        ctx.meta = (len(eps_list), ranges, list(slope_list), x.dtype, x.requires_grad)
+        return out.to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, gout):
+        arg, saved = ctx.saved_tensors[0], ctx.saved_tensors[1:]
+        R = saved[0].shape[0]
+        gy = _seg_reduce_bwd(gout.contiguous().float(), arg, ctx.csr, 3, R)
+        gx0, grads = _fmlp_backward(saved, ctx.meta, gy)
+        return (gx0, None, None, None, None, None, None, *grads)
 
 
 def fused_mlp(x, batch, num_graphs, layers):
@@ -662,3 +714,23 @@ def fused_mlp(x, batch, num_graphs, layers):
         return None
     params = [t for l in layers for t in l[:4]]
     return _FusedMLP.apply(x, batch, ranges, [l[4] for l in layers], [l[5] for l in layers], *params)
+
+
+def fused_mlp_maxpool(x, batch, num_graphs, layers, index, num_seg, seg_graph=None):
+    """``max-pool(MLP(x), index)`` with the MLP's last GraphNorm + activation applied inside
+    the pool's read (``_FusedMLPMaxPool``).  ``seg_graph`` [num_seg]: graph of every segment
+    (needed when the batch holds several graphs).  Returns None when the fused path does not
+    apply; the caller then runs MLP and pool separately."""
+    if x.dim() != 2 or not x.is_cuda:
+        return None
+    dims = [layers[0][0].shape[1]] + [l[0].shape[0] for l in layers]
+    if not fused_mlp_supported(dims) or dims[-1] % 4 != 0:
+        return None
+    ranges = graph_ranges(batch, num_graphs if batch is not None else 1, x.shape[0])
+    if ranges is None or (len(ranges) > 2 and seg_graph is None):
+        return None
+    csr = index if isinstance(index, SegmentCSR) else csr_of(index, num_seg)
+    sg = None if len(ranges) <= 2 else seg_graph.long().contiguous()
+    params = [t for l in layers for t in l[:4]]
+    return _FusedMLPMaxPool.apply(x, batch, ranges, [l[4] for l in layers],
+                                  [l[5] for l in layers], csr, sg, *params)

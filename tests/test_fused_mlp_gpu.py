@@ -104,3 +104,45 @@ def test_fused_mlp_falls_back_on_unsorted_batch(dev):
     assert ops.graph_ranges(batch, 3, 20000) is None
     y = mlp(x, batch=batch, batch_size=3)            # layer-by-layer HIP path
     assert y.shape == (20000, 64) and bool(torch.isfinite(y).all())
+
+
+@pytest.mark.parametrize("rows,nseg,B", [(50_000, 1500, 1), (40_001, 900, 3)])
+def test_mlp_folded_into_the_max_pool_equals_mlp_then_pool(rows, nseg, B, dev):
+    """MLP.forward_max_pooled (last GraphNorm + LeakyReLU applied inside the pool's read of
+    the raw activations) against the same MLP followed by the segment max-pool: pooled
+    values and arg rows bit-identical (same expression per element), gradients equal."""
+    from superpoint_transformer_amd import nn as N, ops
+    g = torch.Generator().manual_seed(rows)
+    mlp = N.MLP([12, 32, 64, 128], norm=N.GraphNorm).to(dev)
+    with torch.no_grad():
+        for p in mlp.parameters():
+            p.add_(0.1 * torch.randn(p.shape, generator=g).to(dev))
+    x = (torch.randn(rows, 12, generator=g) * 2 + 0.5).to(dev)
+    batch = (torch.arange(rows) * B // rows).to(dev) if B > 1 else None
+    # segments never straddle two graphs; unsorted membership inside a graph
+    seg_graph = (torch.arange(nseg) * B // nseg).to(dev)
+    idx = torch.empty(rows, dtype=torch.long, device=dev)
+    for b in range(B):
+        rows_b = torch.where(batch == b)[0] if B > 1 else torch.arange(rows, device=dev)
+        segs_b = torch.where(seg_graph == b)[0]
+        idx[rows_b] = segs_b[torch.randint(0, segs_b.numel(), (rows_b.numel(),), generator=g).to(dev)]
+    gout = torch.randn(nseg, 128, generator=g).to(dev)
+
+    def run(fused):
+        m = copy.deepcopy(mlp)
+        xd = x.clone().requires_grad_()
+        if fused:
+            out = m.forward_max_pooled(xd, idx, nseg, batch=batch, batch_size=B,
+                                       seg_graph=seg_graph if B > 1 else None)
+            assert out is not None
+        else:
+            out = ops.segment_reduce(m(xd, batch=batch, batch_size=B), idx, nseg, "max")
+        (out * gout).sum().backward()
+        return out.detach(), xd.grad, [p.grad for p in m.parameters()]
+
+    of, gxf, gpf = run(True)
+    ou, gxu, gpu_ = run(False)
+    assert torch.equal(of, ou)
+    assert torch.equal(gxf, gxu)
+    for a, b in zip(gpf, gpu_):
+        assert torch.equal(a, b)
