@@ -413,6 +413,17 @@ int spt_graphnorm_bwd_stats_f32(const float* x, const float* gy, const int64_t* 
                                 int d, int num_graphs, const float* am, const float* scale,
                                 const float* bias, float act_slope, double* total, void* ws,
                                 size_t ws_bytes, spt_stream_t stream);
+/* The totals of spt_graphnorm_bwd_stats_f32 when gy is the backward of a segment max-pool
+ * (one non-zero per (segment, channel): gy[arg[s,c], c] = gout[s,c]), computed from
+ * (gout, arg [num_seg, d], the raw rows x gathered at arg) without a pass over [r, d] tensors.
+ * seg_graph [num_seg] (NULL = one graph), graph_rows [B] int64 = rows of every graph. */
+size_t spt_graphnorm_bwd_stats_sparse_workspace_bytes(int64_t num_seg, int d, int num_graphs);
+int spt_graphnorm_bwd_stats_sparse_f32(const float* x, const float* gout, const int32_t* arg,
+                                       const int64_t* seg_graph, const int64_t* graph_rows,
+                                       int64_t num_seg, int64_t n, int d, int num_graphs,
+                                       const float* am, const float* scale, const float* bias,
+                                       float act_slope, double* total, void* ws,
+                                       size_t ws_bytes, spt_stream_t stream);
 int spt_graphnorm_bwd_tables_f32(const double* total, int num_graphs, int d, const float* weight,
                                  const float* mean_scale, const float* mean, const float* rstd,
                                  float* c1, float* c2, float* c3, float* gweight, float* gbias,

@@ -57,6 +57,9 @@ SIGNATURES = {
     "spt_graphnorm_apply_f32": (_int, [_p, _p, _i64, _int, _int, _p, _p, _p, _f32, _p, _p]),
     "spt_graphnorm_bwd_stats_f32": (_int, [_p, _p, _p, _i64, _int, _int, _p, _p, _p, _f32, _p,
                                            _p, _sz, _p]),
+    "spt_graphnorm_bwd_stats_sparse_workspace_bytes": (_sz, [_i64, _int, _int]),
+    "spt_graphnorm_bwd_stats_sparse_f32": (_int, [_p, _p, _p, _p, _p, _i64, _i64, _int, _int, _p, _p,
+                                                   _p, _f32, _p, _p, _sz, _p]),
     "spt_graphnorm_bwd_tables_f32": (_int, [_p, _int, _int, _p, _p, _p, _p, _p, _p, _p, _p, _p,
                                             _p, _p]),
     "spt_fused_linear_supported": (_int, [_int, _int]),

@@ -564,6 +564,96 @@ extern "C" int spt_graphnorm_bwd_stats_f32(const float* x, const float* gy, cons
   return 0;
 }
 
+// ---- the same totals when gy is the backward of a segment max-pool -------------------------
+// gy then has ONE non-zero per (segment, channel): gy[arg[s,c], c] = gout[s,c].  The sums
+// sum g' and sum g' o over the rows of a graph only see those entries, so they are computed
+// from (gout, arg) and a gather of the raw rows - num_seg*d elements instead of a pass over
+// the [r, d] tensors (15.4 GB at scene S).  Layout and meaning of `total` as above; the row
+// count of graph b is graph_rows[b].
+__global__ __launch_bounds__(256) void gn_bwd_stats_sparse_kernel(
+    const float* __restrict__ x, const float* __restrict__ gout,
+    const int32_t* __restrict__ arg, const int64_t* __restrict__ seg_graph, int64_t num_seg,
+    int64_t n, int d, int B, const float* __restrict__ am, const float* __restrict__ scale,
+    const float* __restrict__ bias, float slope, double* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) double tab[];
+  const int row_len = 2 * d + 1;
+  for (int i = threadIdx.x; i < B * row_len; i += 256) tab[i] = 0.0;
+  __syncthreads();
+  const int spb = 256 / d;                 // segments per block iteration (d divides 256)
+  const int c = threadIdx.x % d, sub = threadIdx.x / d;
+  double s1 = 0.0, s2 = 0.0;
+  int cur = 0;
+  float t_am = am[c], t_sc = scale[c];
+  const float t_bs = bias[c];
+  auto flush = [&]() {
+    if (s1 != 0.0) atomicAdd(&tab[(size_t)cur * row_len + c], s1);
+    if (s2 != 0.0) atomicAdd(&tab[(size_t)cur * row_len + d + c], s2);
+    s1 = s2 = 0.0;
+  };
+  for (int64_t s = (int64_t)blockIdx.x * spb + sub; s < num_seg; s += (int64_t)gridDim.x * spb) {
+    const int b = seg_graph ? (int)seg_graph[s] : 0;
+    if (b != cur) {
+      flush();
+      cur = b;
+      t_am = am[(size_t)b * d + c];
+      t_sc = scale[(size_t)b * d + c];
+    }
+    const int64_t i = arg[s * d + c];
+    if (i < 0 || i >= n) continue;         // empty segment: sentinel n
+    const float o = x[i * d + c] - t_am;
+    float g = gout[s * d + c];
+    if (slope != 1.f) {
+      const float y = fmaf(o, t_sc, t_bs);
+      g = (y > 0.f) ? g : g * slope;
+    }
+    s1 += (double)g;
+    s2 += (double)g * (double)o;
+  }
+  flush();
+  __syncthreads();
+  double* out = partial + (size_t)blockIdx.x * B * row_len;
+  for (int i = threadIdx.x; i < B * row_len; i += 256) out[i] = tab[i];
+}
+
+__global__ void gn_set_row_counts_kernel(double* __restrict__ total, int B, int row_len,
+                                         const int64_t* __restrict__ graph_rows) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) total[(size_t)b * row_len + row_len - 1] = (double)graph_rows[b];
+}
+
+extern "C" size_t spt_graphnorm_bwd_stats_sparse_workspace_bytes(int64_t num_seg, int d,
+                                                                 int num_graphs) {
+  if (num_seg < 0 || d < 1 || num_graphs < 1) return 0;
+  return (size_t)1024 * num_graphs * (2 * d + 1) * 8;
+}
+
+extern "C" int spt_graphnorm_bwd_stats_sparse_f32(
+    const float* x, const float* gout, const int32_t* arg, const int64_t* seg_graph,
+    const int64_t* graph_rows, int64_t num_seg, int64_t n, int d, int num_graphs,
+    const float* am, const float* scale, const float* bias, float act_slope, double* total,
+    void* ws, size_t ws_bytes, spt_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int B = num_graphs;
+  SPT_CHECK_ARG(num_seg >= 0 && n >= 0 && B >= 1, "bad shape");
+  SPT_CHECK_ARG(d >= 1 && d <= 256 && 256 % d == 0, "dim must divide 256");
+  SPT_CHECK_ARG(total && am && scale && bias && graph_rows && x && gout && arg, "null pointer");
+  const int row_len = 2 * d + 1;
+  SPT_CHECK_ARG((size_t)B * row_len * 8 <= 64 * 1024, "num_graphs * dim too large for the LDS table");
+  SPT_CHECK_ARG(ws && ws_bytes >= spt_graphnorm_bwd_stats_sparse_workspace_bytes(num_seg, d, B),
+                "workspace too small");
+  const int spb = 256 / d;
+  int64_t nb = ceil_div(num_seg > 0 ? num_seg : 1, (int64_t)spb * 8);
+  if (nb > 1024) nb = 1024;
+  double* partial = (double*)ws;
+  gn_bwd_stats_sparse_kernel<<<(int)nb, 256, (size_t)B * row_len * 8, stream>>>(
+      x, gout, arg, seg_graph, num_seg, n, d, B, am, scale, bias, act_slope, partial);
+  gn_reduce_partials_kernel<<<dim3(B, (row_len + 15) / 16), 256, 0, stream>>>(partial, (int)nb, B,
+                                                                           row_len, total);
+  gn_set_row_counts_kernel<<<(B + 63) / 64, 64, 0, stream>>>(total, B, row_len, graph_rows);
+  SPT_CHECK_LAUNCH();
+  return 0;
+}
+
 // backward coefficient rows (gx = c1*g - c2*o - c3) and the three parameter gradients
 extern "C" int spt_graphnorm_bwd_tables_f32(const double* total, int num_graphs, int d,
                                             const float* weight, const float* mean_scale,

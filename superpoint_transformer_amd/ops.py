@@ -581,8 +581,10 @@ def _fmlp_forward(x, batch, ranges, eps_list, slope_list, params, apply_last=Tru
     return y, saved, hs[-1], (tabs[-1][2], tabs[-1][3], gnb[-1])
 
 
-def _fmlp_backward(saved, meta, gy):
-    """Backward of the fused layer chain from the gradient of its (normalised) output."""
+def _fmlp_backward(saved, meta, gy, top_total=None):
+    """Backward of the fused layer chain from the gradient of its (normalised) output.
+    ``top_total``: statistics of the top GraphNorm's backward when the caller already has
+    them (the max-pool route computes them from the pool's sparse gradient)."""
     L, ranges, slopes, in_dtype, need_gx0 = meta
     sv = list(saved)
     x2, batch = sv[0], sv[1]
@@ -601,13 +603,16 @@ def _fmlp_backward(saved, meta, gy):
         # statistics of the top GraphNorm's backward need their own pass over (h_L, gy)
         N = Ws[-1].shape[0]
         mean, rstd, am, sc = tabs[-1]
-        total = torch.empty((B, 2 * N + 1), dtype=torch.float64, device=dev)
-        ws = _workspace(_lib.lib.spt_graphnorm_workspace_bytes(R, N, B), dev)
-        st = _lib.lib.spt_graphnorm_bwd_stats_f32(
-            _lib.ptr(hs[-1]), _lib.ptr(g_cur), _lib.ptr(batch) if B > 1 else None, R, N, B,
-            _lib.ptr(am), _lib.ptr(sc), _lib.ptr(gnb[-1]), float(slopes[-1]), _lib.ptr(total),
-            _lib.ptr(ws), ws.numel(), sp)
-        _lib.check(st, "spt_graphnorm_bwd_stats_f32")
+        if top_total is not None:
+            total = top_total
+        else:
+            total = torch.empty((B, 2 * N + 1), dtype=torch.float64, device=dev)
+            ws = _workspace(_lib.lib.spt_graphnorm_workspace_bytes(R, N, B), dev)
+            st = _lib.lib.spt_graphnorm_bwd_stats_f32(
+                _lib.ptr(hs[-1]), _lib.ptr(g_cur), _lib.ptr(batch) if B > 1 else None, R, N, B,
+                _lib.ptr(am), _lib.ptr(sc), _lib.ptr(gnb[-1]), float(slopes[-1]), _lib.ptr(total),
+                _lib.ptr(ws), ws.numel(), sp)
+            _lib.check(st, "spt_graphnorm_bwd_stats_f32")
         for l in range(L - 1, -1, -1):
             N, K = Ws[l].shape
             mean, rstd, am, sc = tabs[l]
@@ -687,15 +692,39 @@ class _FusedMLPMaxPool(torch.autograd.Function):
         _lib.check(st, "spt_segcsr_max_affine_f32")
         ctx.save_for_backward(arg, *saved)
         ctx.csr = csr
+        ctx.seg_graph = seg_graph
         ctx.meta = (len(eps_list), ranges, list(slope_list), x.dtype, x.requires_grad)
         return out.to(x.dtype)
 
     @staticmethod
     def backward(ctx, gout):
         arg, saved = ctx.saved_tensors[0], ctx.saved_tensors[1:]
-        R = saved[0].shape[0]
-        gy = _seg_reduce_bwd(gout.contiguous().float(), arg, ctx.csr, 3, R)
-        gx0, grads = _fmlp_backward(saved, ctx.meta, gy)
+        L, ranges, slopes = ctx.meta[0], ctx.meta[1], ctx.meta[2]
+        h_last = saved[2 + L - 1]
+        am, sc = saved[2 + L + 4 * (L - 1) + 2], saved[2 + L + 4 * (L - 1) + 3]
+        gnb_last = saved[2 + 5 * L + 2 * L + (L - 1)]
+        R, N = h_last.shape
+        dev = h_last.device
+        B = len(ranges) - 1
+        gout = gout.contiguous().float()
+        # statistics of the top GraphNorm's backward from the pool's SPARSE gradient (one
+        # non-zero per (segment, channel)) instead of a pass over the dense [R, N] tensors
+        total = None
+        if N <= 256 and 256 % N == 0:
+            total = torch.empty((B, 2 * N + 1), dtype=torch.float64, device=dev)
+            rows = torch.tensor([ranges[g + 1] - ranges[g] for g in range(B)], dtype=torch.int64,
+                                device=dev)
+            nb = _lib.lib.spt_graphnorm_bwd_stats_sparse_workspace_bytes(ctx.csr.num_seg, N, B)
+            ws = _workspace(nb, dev)
+            with torch.cuda.device(dev):
+                st = _lib.lib.spt_graphnorm_bwd_stats_sparse_f32(
+                    _lib.ptr(h_last), _lib.ptr(gout), _lib.ptr(arg), _lib.ptr(ctx.seg_graph),
+                    _lib.ptr(rows), ctx.csr.num_seg, R, N, B, _lib.ptr(am), _lib.ptr(sc),
+                    _lib.ptr(gnb_last), float(slopes[-1]), _lib.ptr(total), _lib.ptr(ws), nb,
+                    _lib.stream_ptr(dev))
+            _lib.check(st, "spt_graphnorm_bwd_stats_sparse_f32")
+        gy = _seg_reduce_bwd(gout, arg, ctx.csr, 3, R)
+        gx0, grads = _fmlp_backward(saved, ctx.meta, gy, top_total=total)
         return (gx0, None, None, None, None, None, None, *grads)
 
 

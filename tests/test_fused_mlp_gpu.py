@@ -110,7 +110,9 @@ def test_fused_mlp_falls_back_on_unsorted_batch(dev):
 def test_mlp_folded_into_the_max_pool_equals_mlp_then_pool(rows, nseg, B, dev):
     """MLP.forward_max_pooled (last GraphNorm + LeakyReLU applied inside the pool's read of
     the raw activations) against the same MLP followed by the segment max-pool: pooled
-    values and arg rows bit-identical (same expression per element), gradients equal."""
+    values bit-identical (same expression per element, hence the same arg rows); gradients
+    equal up to the f64 summation order of the top GraphNorm's backward statistics (computed
+    from the pool's sparse gradient on the folded route)."""
     from superpoint_transformer_amd import nn as N, ops
     g = torch.Generator().manual_seed(rows)
     mlp = N.MLP([12, 32, 64, 128], norm=N.GraphNorm).to(dev)
@@ -143,6 +145,6 @@ def test_mlp_folded_into_the_max_pool_equals_mlp_then_pool(rows, nseg, B, dev):
     of, gxf, gpf = run(True)
     ou, gxu, gpu_ = run(False)
     assert torch.equal(of, ou)
-    assert torch.equal(gxf, gxu)
+    assert torch.allclose(gxf, gxu, rtol=1e-5, atol=1e-6 * float(gxu.abs().max()))
     for a, b in zip(gpf, gpu_):
-        assert torch.equal(a, b)
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6 * float(b.abs().max()))
