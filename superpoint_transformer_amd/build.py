@@ -56,8 +56,13 @@ def _stale(target, deps):
 def _compile(src):
     obj = os.path.join(OBJDIR, os.path.basename(src)[:-4] + ".o")
     if _stale(obj, [src] + _headers()):
-        cmd = [HIPCC] + FLAGS + PER_FILE_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
+        extra = PER_FILE_FLAGS.get(os.path.basename(src), [])
+        cmd = [HIPCC] + FLAGS + extra + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0 and extra and "Unknown command line argument" in r.stderr:
+            # a toolchain without the code-generation option: same code, default MFMA form
+            cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+            r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(
                 f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
