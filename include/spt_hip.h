@@ -224,6 +224,8 @@ int spt_edge_attn_bwd_f32(const float* qkv, int64_t n, int H, int D, int Dv,
  *   covers the search points (any cell size gives the same result; ~K/4 points
  *   per non-empty cell is fastest); dims[0]*dims[1]*dims[2] < 2^31;
  *   order_queries_by_cell: when query == search, visit queries in cell order.
+ *   cell_order (nullable) [ns] int32: receives the search points' cell order (the
+ *   permutation spt_spatial_order computes), a by-product of the grid build.
  * ws: spt_grid_knn_workspace_bytes(ns, ncells).
  * ---------------------------------------------------------------------- */
 size_t spt_grid_knn_workspace_bytes(int64_t ns, int64_t ncells);
@@ -234,8 +236,8 @@ int spt_bbox_f32(const float* xyz, int64_t n, float* lo_hi, spt_stream_t stream)
 int spt_grid_knn_f32(const float* query, int64_t nq, const float* search, int64_t ns,
                      int K, float r, float cell_size, const float* origin,
                      const int32_t* dims, int order_queries_by_cell, int inclusive,
-                     int squared, int64_t* idx, float* dist, void* ws, size_t ws_bytes,
-                     spt_stream_t stream);
+                     int squared, int64_t* idx, float* dist, int32_t* cell_order, void* ws,
+                     size_t ws_bytes, spt_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Point geometric features                                          (a11-a14)

@@ -373,8 +373,8 @@ extern "C" int spt_grid_knn_f32(const float* query, int64_t nq, const float* sea
                                 int64_t ns, int K, float r, float cell_size,
                                 const float* origin, const int32_t* dims,
                                 int order_queries_by_cell, int inclusive, int squared,
-                                int64_t* idx, float* dist, void* ws, size_t ws_bytes,
-                                spt_stream_t stream_) {
+                                int64_t* idx, float* dist, int32_t* cell_order, void* ws,
+                                size_t ws_bytes, spt_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SPT_CHECK_ARG(nq >= 0 && ns >= 0, "bad shape");
   SPT_CHECK_ARG(K >= 1 && K <= 64, "K must be in [1, 64]");
@@ -404,6 +404,9 @@ extern "C" int spt_grid_knn_f32(const float* query, int64_t nq, const float* sea
     knn_gather_sorted_kernel<<<stream_grid(ns, 256), 256, 0, stream>>>(search, perm, ns, sorted);
   // self-search: visiting queries in cell order keeps candidate cells L2-resident
   const int32_t* qorder = (order_queries_by_cell && query == search && nq == ns) ? perm : nullptr;
+  // the cell order of the search points is a by-product other gather kernels can reuse
+  if (cell_order && ns > 0)
+    (void)hipMemcpyAsync(cell_order, perm, (size_t)ns * 4, hipMemcpyDeviceToDevice, stream);
   const int grid = (int)(ceil_div(nq, KNN_WAVES) < 256 * 8 ? ceil_div(nq, KNN_WAVES) : 256 * 8);
   knn_search_kernel<<<grid, KNN_WAVES * 64, 0, stream>>>(query, nq, qorder, sorted, rowptr, g, K, r,
                                                          inclusive, squared, idx, dist);

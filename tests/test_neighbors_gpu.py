@@ -177,6 +177,10 @@ def test_visiting_order_does_not_change_the_features(dev):
     order = NB.spatial_order(pos)
     assert order.dtype == torch.int32
     assert torch.equal(torch.sort(order.long()).values, torch.arange(pos.shape[0], device=dev))
-    a = NB.geometric_features(pos, nb, k_min=1, order=None)
-    b = NB.geometric_features(pos, nb, k_min=1, order=order)
-    assert torch.equal(a, b)
+    assert NB._recall_order(pos) is not None                    # left behind by knn_1 (>= 200 k points)
+    a = NB.geometric_features(pos, nb, k_min=1, order=False)    # as stored
+    b = NB.geometric_features(pos, nb, k_min=1, order=order)    # explicit permutation
+    c = NB.geometric_features(pos, nb, k_min=1)                 # the kNN grid's cell order
+    assert torch.equal(a, b) and torch.equal(a, c)
+    pos2 = pos.clone()
+    assert NB._recall_order(pos2) is None                       # the memo belongs to that tensor
