@@ -60,47 +60,79 @@ __global__ void knn_gather_sorted_kernel(const float* __restrict__ pos,
   }
 }
 
-__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int o) {
-  const uint32_t lo = __shfl_xor((uint32_t)v, o, 64);
-  const uint32_t hi = __shfl_xor((uint32_t)(v >> 32), o, 64);
+// lane ^ J exchange without the LDS crossbar: DPP row operations inside a 16-lane row,
+// gfx950's v_permlane16_swap / v_permlane32_swap across rows.
+template <int J>
+__device__ __forceinline__ uint32_t xor_lane_u32(uint32_t v) {
+  const int x = (int)v;
+  if constexpr (J == 1) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, false);      // quad [1,0,3,2]
+  } else if constexpr (J == 2) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, false);      // quad [2,3,0,1]
+  } else if constexpr (J == 4) {                                                     // ^3 then ^7
+    const int t = __builtin_amdgcn_update_dpp(0, x, 0x1B, 0xF, 0xF, false);         // quad [3,2,1,0]
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, t, 0x141, 0xF, 0xF, false);     // row_half_mirror
+  } else if constexpr (J == 8) {                                                     // ^7 then ^15
+    const int t = __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, false);        // row_half_mirror
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, t, 0x140, 0xF, 0xF, false);     // row_mirror
+  } else if constexpr (J == 16) {
+    const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);   // {[v0 v0 v2 v2], [v1 v1 v3 v3]}
+    return (threadIdx.x & 16) ? r[0] : r[1];
+  } else {
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);   // {[lo lo], [hi hi]}
+    return (threadIdx.x & 32) ? r[0] : r[1];
+  }
+}
+template <int J>
+__device__ __forceinline__ uint64_t xor_lane_u64(uint64_t v) {
+  return ((uint64_t)xor_lane_u32<J>((uint32_t)(v >> 32)) << 32) | xor_lane_u32<J>((uint32_t)v);
+}
+
+__device__ __forceinline__ uint64_t row_mirror_u64(uint64_t v) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, 0x140, 0xF, 0xF, false);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), 0x140, 0xF, 0xF, false);
   return ((uint64_t)hi << 32) | lo;
 }
-__device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src) {
-  const uint32_t lo = __shfl((uint32_t)v, src, 64);
-  const uint32_t hi = __shfl((uint32_t)(v >> 32), src, 64);
+// value of a wave-uniform lane index (v_readlane, no LDS permute)
+__device__ __forceinline__ uint64_t read_lane_u64(uint64_t v, int src) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src);
   return ((uint64_t)hi << 32) | lo;
+}
+
+template <int K, int J>
+__device__ __forceinline__ uint64_t bitonic_step(uint64_t key, int lane) {
+  const uint64_t other = xor_lane_u64<J>(key);
+  const bool asc = (lane & K) == 0;
+  const bool lower = (lane & J) == 0;
+  const uint64_t mn = key < other ? key : other;
+  const uint64_t mx = key < other ? other : key;
+  return (lower == asc) ? mn : mx;
+}
+template <int K, int J>
+__device__ __forceinline__ uint64_t bitonic_merge_steps(uint64_t key, int lane) {
+  key = bitonic_step<K, J>(key, lane);
+  if constexpr (J > 1) key = bitonic_merge_steps<K, J / 2>(key, lane);
+  return key;
 }
 
 // ascending bitonic sort of one key per lane
 __device__ __forceinline__ uint64_t wave_sort(uint64_t key, int lane) {
-#pragma unroll
-  for (int k = 2; k <= 64; k <<= 1) {
-#pragma unroll
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      const uint64_t other = shfl_xor_u64(key, j);
-      const bool asc = (lane & k) == 0;
-      const bool lower = (lane & j) == 0;
-      const uint64_t mn = key < other ? key : other;
-      const uint64_t mx = key < other ? other : key;
-      key = (lower == asc) ? mn : mx;
-    }
-  }
+  key = bitonic_merge_steps<2, 1>(key, lane);
+  key = bitonic_merge_steps<4, 2>(key, lane);
+  key = bitonic_merge_steps<8, 4>(key, lane);
+  key = bitonic_merge_steps<16, 8>(key, lane);
+  key = bitonic_merge_steps<32, 16>(key, lane);
+  key = bitonic_merge_steps<64, 32>(key, lane);   // lane & 64 == 0: ascending everywhere
   return key;
 }
 
 // merge two ascending 64-lists, keep the 64 smallest, ascending
 __device__ __forceinline__ uint64_t wave_merge(uint64_t best, uint64_t cand_sorted, int lane) {
-  const uint64_t rev = shfl_u64(cand_sorted, 63 - lane);
-  uint64_t key = best < rev ? best : rev;  // bitonic
-#pragma unroll
-  for (int j = 32; j > 0; j >>= 1) {
-    const uint64_t other = shfl_xor_u64(key, j);
-    const bool lower = (lane & j) == 0;
-    const uint64_t mn = key < other ? key : other;
-    const uint64_t mx = key < other ? other : key;
-    key = lower ? mn : mx;
-  }
-  return key;
+  // lane 63 - l = l ^ 63: mirror inside the rows (^15), then swap rows (^16) and halves (^32)
+  const uint64_t rev = xor_lane_u64<32>(xor_lane_u64<16>(row_mirror_u64(cand_sorted)));
+  const uint64_t key = best < rev ? best : rev;  // bitonic
+  return bitonic_merge_steps<64, 32>(key, lane);
 }
 
 struct KnnState {
@@ -117,7 +149,7 @@ __device__ __forceinline__ void knn_flush(KnnState& st, uint64_t* pend, int K, i
   uint64_t c = lane < st.npend ? pend[lane] : KNN_EMPTY;
   c = wave_sort(c, lane);
   st.best = wave_merge(st.best, c, lane);
-  st.kth = shfl_u64(st.best, K - 1);
+  st.kth = read_lane_u64(st.best, K - 1);
   st.npend = 0;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
