@@ -44,14 +44,25 @@ __device__ __forceinline__ float quad_sum(float v) {
   v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));
   return v;
 }
+// lane ^ 16 / lane ^ 32 through gfx950's row / half swaps (VALU, no LDS permute)
+__device__ __forceinline__ float xor16(float v) {
+  const unsigned u = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);   // {[r0 r0 r2 r2], [r1 r1 r3 r3]}
+  return __uint_as_float((threadIdx.x & 16) ? r[0] : r[1]);
+}
+__device__ __forceinline__ float xor32(float v) {
+  const unsigned u = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);   // {[lo lo], [hi hi]}
+  return __uint_as_float((threadIdx.x & 32) ? r[0] : r[1]);
+}
 __device__ __forceinline__ float xg_sum(float v) {  // sum over the 4 lane groups g
-  v += __shfl_xor(v, 16, 64);
-  v += __shfl_xor(v, 32, 64);
+  v += xor16(v);
+  v += xor32(v);
   return v;
 }
 __device__ __forceinline__ float xg_max(float v) {
-  v = fmaxf(v, __shfl_xor(v, 16, 64));
-  v = fmaxf(v, __shfl_xor(v, 32, 64));
+  v = fmaxf(v, xor16(v));
+  v = fmaxf(v, xor32(v));
   return v;
 }
 
