@@ -132,7 +132,10 @@ class SPTTrainStep:
                           "point MLP's last GraphNorm + LeakyReLU applied on the fly)",
                 "achieved": round(ach, 1) if ach else None, "peak": peak_gbs,
                 "unit": "GB/s", "frac": round(ach / peak_gbs, 4) if ach else None,
-                "traffic": _pmc_traffic(self.tname), "bytes_per_launch": bytes_,
+                "traffic": _pmc_traffic(self.tname),
+                "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an "
+                                  "earlier visit on this shape; a committed constant, not a live counter)",
+                "bytes_per_launch": bytes_,
                 "ms_per_launch": round(ms, 4) if ms else None}
 
     def describe(self, scene, sizes):

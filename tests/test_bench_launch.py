@@ -1,0 +1,42 @@
+"""bench.py's launch contract: `python bench.py --gpus N` starts N ranks itself
+(one process per device, configs/trainer/ddp.yaml:8-13) and rank 0 prints ONE
+JSON line carrying n_gpus == N."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def test_world_size_mismatch_is_refused():
+    """A launcher that started a different number of ranks than --gpus must not
+    silently measure something else (round-1 defect: --gpus was ignored)."""
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
+@pytest.mark.gpu
+def test_gpus_2_spawns_two_ranks_share_gpu():
+    """1-GPU box: SPT_BENCH_SHARE_GPU=1 puts both ranks on cuda:0 over gloo, so the
+    N > 1 code path (spawn, scene sharding, flat gradient all-reduce, barrier,
+    max-over-ranks) is executed end to end from the bare `--gpus 2` command."""
+    env = dict(os.environ, SPT_BENCH_SHARE_GPU="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--scene", "R", "--no-cpu-baseline", "--no-preprocess"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2
+    assert out["config"]["parallelism"] == "dp2"
+    assert out["value"] > 0
