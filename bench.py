@@ -47,6 +47,8 @@ def cpu_baseline(scene, scale):
     from superpoint_transformer_amd import hotpath
     from superpoint_transformer_amd.synthetic import SCENES, make_nag
     n0_full = SCENES[scene][0]
+    # 128 threads on sub-millisecond torch-CPU ops is slower than 32 (round-1 figure: 0.012 Mpts/s)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
     if scale is None:
         scale = min(1.0, max(0.05 * n0_full, 150_000) / n0_full)   # >= 5 % of the workload
     nag = make_nag(scene, seed=1234, device="cpu", scale=scale)

@@ -55,7 +55,10 @@ def build_csr(idx, num_seg):
             _lib.ptr(idx), n, num_seg, _lib.ptr(perm), _lib.ptr(rowptr),
             _lib.ptr(ws), ws_bytes, _lib.stream_ptr(dev))
     _lib.check(st, "spt_csr_build")
-    return SegmentCSR(idx, perm[:n], rowptr, n, num_seg)
+    # keep an ALIAS of the index (same storage, new tensor object): the memo dict hangs on the
+    # caller's tensor object, so holding that object here would close a reference cycle
+    # (tensor -> memo -> csr -> tensor) and leave every batch's views to the cyclic GC
+    return SegmentCSR(idx.detach(), perm[:n], rowptr, n, num_seg)
 
 
 def csr_of(idx, num_seg=None):

@@ -70,10 +70,11 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(
     const float* __restrict__ am,     // [B,d] alpha*mu          (BWD)
     const float* __restrict__ scale,  // [B,d] weight*rstd       (BWD, act mask)
     const float* __restrict__ bias,   // [d]                     (BWD, act mask)
-    float slope, double* __restrict__ partial) {
+    float slope, double* __restrict__ partial,
+    int b_lo, int Bc) {               // this launch owns graphs [b_lo, b_lo + Bc): its LDS table
   extern __shared__ __attribute__((aligned(16))) double tab[];
   const int row_len = 2 * d + 1;
-  for (int i = threadIdx.x; i < B * row_len; i += GN_THREADS) tab[i] = 0.0;
+  for (int i = threadIdx.x; i < Bc * row_len; i += GN_THREADS) tab[i] = 0.0;
   __syncthreads();
 
   const int lpr = 1 << lpr_log2;
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(
 
   double s1[VEC], s2[VEC];
   double cnt = 0.0;
-  int cur = 0;
+  int cur = b_lo;
 #pragma unroll
   for (int k = 0; k < VEC; ++k) s1[k] = s2[k] = 0.0;
   // per-(graph, channel) coefficients of the CURRENT graph live in registers:
@@ -101,11 +102,11 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(
       }
     }
   };
-  load_tables(0);
+  load_tables(b_lo);
 
   auto flush = [&]() {
     if (cv) {
-      double* t = tab + (size_t)cur * row_len;
+      double* t = tab + (size_t)(cur - b_lo) * row_len;
 #pragma unroll
       for (int k = 0; k < VEC; ++k) {
         if (s1[k] != 0.0) atomicAdd(&t[c0 + k], s1[k]);
@@ -127,7 +128,8 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(
       row[u] = rb + (int64_t)u * rpb + rsub;
       const bool ok = row[u] < R;
       b[u] = ok ? (batch ? (int)batch[row[u]] : 0) : -1;
-      if (ok && cv) {
+      if (b[u] < b_lo || b[u] >= b_lo + Bc) b[u] = -1;   // another launch's graph
+      if (b[u] >= 0 && cv) {
         ld<VEC>(x + row[u] * d + c0, v[u]);
         if constexpr (BWD) ld<VEC>(gy + row[u] * d + c0, g[u]);
       }
@@ -163,8 +165,8 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(
   }
   flush();
   __syncthreads();
-  double* out = partial + (size_t)blockIdx.x * B * row_len;
-  for (int i = threadIdx.x; i < B * row_len; i += GN_THREADS) out[i] = tab[i];
+  double* out = partial + ((size_t)blockIdx.x * B + b_lo) * row_len;
+  for (int i = threadIdx.x; i < Bc * row_len; i += GN_THREADS) out[i] = tab[i];
 }
 
 // ---- finalize: fixed-order reduction of the per-block partial tables --------
@@ -401,18 +403,30 @@ static bool gn_plan(int64_t R, int d, int B, GnPlan* p) {
   return true;
 }
 
+static int gn_graphs_per_launch(int row_len) {
+  int cap = (int)((64 * 1024) / ((size_t)row_len * 8));
+  return cap < 1 ? 1 : cap;          // d <= 1024: one graph row is at most 16 392 B
+}
+
 template <bool BWD>
 static void launch_stats(const GnPlan& p, const float* x, const float* gy,
                          const int64_t* batch, int64_t R, int d, int B,
                          const float* am, const float* scale, const float* bias,
                          float slope, double* partial, hipStream_t stream) {
-  const size_t lds = (size_t)B * p.row_len * 8;
-  if (p.sh.vec == 4)
-    gn_stats_kernel<4, BWD><<<p.nblocks, GN_THREADS, lds, stream>>>(x, gy, batch, R, d, B, p.sh.lpr_log2, am, scale, bias, slope, partial);
-  else if (p.sh.vec == 2)
-    gn_stats_kernel<2, BWD><<<p.nblocks, GN_THREADS, lds, stream>>>(x, gy, batch, R, d, B, p.sh.lpr_log2, am, scale, bias, slope, partial);
-  else
-    gn_stats_kernel<1, BWD><<<p.nblocks, GN_THREADS, lds, stream>>>(x, gy, batch, R, d, B, p.sh.lpr_log2, am, scale, bias, slope, partial);
+  // The per-graph table lives in LDS (64 KiB without opting into more).  More graphs than
+  // fit (num_graphs > 31 at d = 128) are covered by several launches, each owning a window
+  // of graph ids and skipping the other rows; the usual 1..8 graphs take one launch.
+  const int cap = gn_graphs_per_launch(p.row_len);
+  for (int b_lo = 0; b_lo < B; b_lo += cap) {
+    const int Bc = (B - b_lo < cap) ? B - b_lo : cap;
+    const size_t lds = (size_t)Bc * p.row_len * 8;
+    if (p.sh.vec == 4)
+      gn_stats_kernel<4, BWD><<<p.nblocks, GN_THREADS, lds, stream>>>(x, gy, batch, R, d, B, p.sh.lpr_log2, am, scale, bias, slope, partial, b_lo, Bc);
+    else if (p.sh.vec == 2)
+      gn_stats_kernel<2, BWD><<<p.nblocks, GN_THREADS, lds, stream>>>(x, gy, batch, R, d, B, p.sh.lpr_log2, am, scale, bias, slope, partial, b_lo, Bc);
+    else
+      gn_stats_kernel<1, BWD><<<p.nblocks, GN_THREADS, lds, stream>>>(x, gy, batch, R, d, B, p.sh.lpr_log2, am, scale, bias, slope, partial, b_lo, Bc);
+  }
 }
 
 }  // namespace spt
@@ -427,7 +441,6 @@ extern "C" size_t spt_graphnorm_workspace_bytes(int64_t r, int d, int num_graphs
 
 static int gn_check(int64_t r, int d, int B, const GnPlan& p, const void* ws, size_t ws_bytes) {
   SPT_CHECK_ARG(ws && ws_bytes >= p.total, "workspace too small");
-  SPT_CHECK_ARG((size_t)B * p.row_len * 8 <= 64 * 1024, "num_graphs * dim too large for the LDS table");
   return 0;
 }
 
@@ -574,24 +587,26 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_sparse_kernel(
     const float* __restrict__ x, const float* __restrict__ gout,
     const int32_t* __restrict__ arg, const int64_t* __restrict__ seg_graph, int64_t num_seg,
     int64_t n, int d, int B, const float* __restrict__ am, const float* __restrict__ scale,
-    const float* __restrict__ bias, float slope, double* __restrict__ partial) {
+    const float* __restrict__ bias, float slope, double* __restrict__ partial,
+    int b_lo, int Bc) {
   extern __shared__ __attribute__((aligned(16))) double tab[];
   const int row_len = 2 * d + 1;
-  for (int i = threadIdx.x; i < B * row_len; i += 256) tab[i] = 0.0;
+  for (int i = threadIdx.x; i < Bc * row_len; i += 256) tab[i] = 0.0;
   __syncthreads();
   const int spb = 256 / d;                 // segments per block iteration (d divides 256)
   const int c = threadIdx.x % d, sub = threadIdx.x / d;
   double s1 = 0.0, s2 = 0.0;
-  int cur = 0;
-  float t_am = am[c], t_sc = scale[c];
+  int cur = b_lo;
+  float t_am = am[(size_t)b_lo * d + c], t_sc = scale[(size_t)b_lo * d + c];
   const float t_bs = bias[c];
   auto flush = [&]() {
-    if (s1 != 0.0) atomicAdd(&tab[(size_t)cur * row_len + c], s1);
-    if (s2 != 0.0) atomicAdd(&tab[(size_t)cur * row_len + d + c], s2);
+    if (s1 != 0.0) atomicAdd(&tab[(size_t)(cur - b_lo) * row_len + c], s1);
+    if (s2 != 0.0) atomicAdd(&tab[(size_t)(cur - b_lo) * row_len + d + c], s2);
     s1 = s2 = 0.0;
   };
   for (int64_t s = (int64_t)blockIdx.x * spb + sub; s < num_seg; s += (int64_t)gridDim.x * spb) {
     const int b = seg_graph ? (int)seg_graph[s] : 0;
+    if (b < b_lo || b >= b_lo + Bc) continue;   // another launch's graph
     if (b != cur) {
       flush();
       cur = b;
@@ -611,8 +626,8 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_sparse_kernel(
   }
   flush();
   __syncthreads();
-  double* out = partial + (size_t)blockIdx.x * B * row_len;
-  for (int i = threadIdx.x; i < B * row_len; i += 256) out[i] = tab[i];
+  double* out = partial + ((size_t)blockIdx.x * B + b_lo) * row_len;
+  for (int i = threadIdx.x; i < Bc * row_len; i += 256) out[i] = tab[i];
 }
 
 __global__ void gn_set_row_counts_kernel(double* __restrict__ total, int B, int row_len,
@@ -638,15 +653,18 @@ extern "C" int spt_graphnorm_bwd_stats_sparse_f32(
   SPT_CHECK_ARG(d >= 1 && d <= 256 && 256 % d == 0, "dim must divide 256");
   SPT_CHECK_ARG(total && am && scale && bias && graph_rows && x && gout && arg, "null pointer");
   const int row_len = 2 * d + 1;
-  SPT_CHECK_ARG((size_t)B * row_len * 8 <= 64 * 1024, "num_graphs * dim too large for the LDS table");
   SPT_CHECK_ARG(ws && ws_bytes >= spt_graphnorm_bwd_stats_sparse_workspace_bytes(num_seg, d, B),
                 "workspace too small");
   const int spb = 256 / d;
   int64_t nb = ceil_div(num_seg > 0 ? num_seg : 1, (int64_t)spb * 8);
   if (nb > 1024) nb = 1024;
   double* partial = (double*)ws;
-  gn_bwd_stats_sparse_kernel<<<(int)nb, 256, (size_t)B * row_len * 8, stream>>>(
-      x, gout, arg, seg_graph, num_seg, n, d, B, am, scale, bias, act_slope, partial);
+  const int cap = gn_graphs_per_launch(row_len);
+  for (int b_lo = 0; b_lo < B; b_lo += cap) {
+    const int Bc = (B - b_lo < cap) ? B - b_lo : cap;
+    gn_bwd_stats_sparse_kernel<<<(int)nb, 256, (size_t)Bc * row_len * 8, stream>>>(
+        x, gout, arg, seg_graph, num_seg, n, d, B, am, scale, bias, act_slope, partial, b_lo, Bc);
+  }
   gn_reduce_partials_kernel<<<dim3(B, (row_len + 15) / 16), 256, 0, stream>>>(partial, (int)nb, B,
                                                                            row_len, total);
   gn_set_row_counts_kernel<<<(B + 63) / 64, 64, 0, stream>>>(total, B, row_len, graph_rows);

@@ -229,10 +229,11 @@ def geometric_features_csr(xyz, nn_val, nn_ptr, k_min=1, add_self=False, raw=Tru
     p = xyz.detach().float().contiguous()
     n = nn_ptr.numel() - 1
     feats = torch.empty((n, 11), dtype=torch.float32, device=p.device)
+    val64 = nn_val.long().contiguous()       # named: a converted copy must outlive the launch
+    ptr64 = nn_ptr.long().contiguous()
     with torch.cuda.device(p.device):
         st = _lib.lib.spt_point_geof_csr_f32(
-            _lib.ptr(p), n, _lib.ptr(nn_val.long().contiguous()),
-            _lib.ptr(nn_ptr.long().contiguous()), int(add_self), int(k_min),
+            _lib.ptr(p), n, _lib.ptr(val64), _lib.ptr(ptr64), int(add_self), int(k_min),
             0 if raw else 1, _lib.ptr(feats), _lib.stream_ptr(p.device))
     _lib.check(st, "spt_point_geof_csr_f32")
     return feats

@@ -56,7 +56,8 @@ class StdAggregation(nn.Module):
     def forward(self, x, index=None, ptr=None, dim_size=None, dim=-2):
         mean = scatter_shim.scatter_mean(x, index, 0, None, dim_size)
         mean2 = scatter_shim.scatter_mean(x * x, index, 0, None, dim_size)
-        return (mean2 - mean * mean).clamp(min=1e-5).sqrt()
+        out = (mean2 - mean * mean).clamp(min=1e-5).sqrt()
+        return out.masked_fill(out <= 1e-5 ** 0.5, 0.0)     # PyG: a clamped variance reads as 0
 
 
 class _NotOnPath(nn.Module):
@@ -92,7 +93,10 @@ def consecutive_cluster(src):
     return inv, perm
 
 
-def coalesce(edge_index, edge_attr=None, num_nodes=None, reduce="sum", **unused):
+_MISSING = "???"   # PyG's sentinel: "edge_attr not passed" differs from "edge_attr=None"
+
+
+def coalesce(edge_index, edge_attr=_MISSING, num_nodes=None, reduce="sum", **unused):
     """torch_geometric.utils.coalesce: sort edges by (row, col) and merge
     duplicates (imported by src/utils/scatter.py:6 and neighbors.py:7 for the
     'next' rows; plain torch - not on the per-step path)."""
@@ -100,7 +104,9 @@ def coalesce(edge_index, edge_attr=None, num_nodes=None, reduce="sum", **unused)
     key = edge_index[0] * max(n, 1) + edge_index[1]
     uniq, inv = torch.unique(key, sorted=True, return_inverse=True)
     ei = torch.stack([uniq // max(n, 1), uniq % max(n, 1)])
-    if edge_attr is None:
+    if isinstance(edge_attr, str) and edge_attr == _MISSING:
         return ei
+    if edge_attr is None:
+        return ei, None
     red = "sum" if reduce in ("add", "sum") else reduce
     return ei, scatter_shim.scatter(edge_attr, inv, 0, None, uniq.numel(), red)

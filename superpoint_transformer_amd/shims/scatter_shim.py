@@ -18,11 +18,27 @@ def _check(src, index, dim, out):
             "reference's hot path does)")
 
 
+def _float_src(src, what):
+    """The segment kernels compute in f32: f16 / bf16 sources widen exactly, f64 would
+    silently lose precision -> refused (no call site of the hot path passes f64)."""
+    if src.dtype == torch.float64:
+        raise NotImplementedError(f"HIP shim: {what} of a float64 source (the kernels are f32)")
+    return src
+
+
+def _int_as_f32(src, what):
+    """Integer min / max through the f32 kernel is exact only below 2^24."""
+    if src.numel() and int(src.abs().max()) >= (1 << 24):
+        raise NotImplementedError(f"HIP shim: {what} of integers >= 2^24 (f32 kernel)")
+    return src.float()
+
+
 def scatter_sum(src, index, dim=-1, out=None, dim_size=None):
     _check(src, index, dim, out)
     if not src.is_floating_point():
-        return ops.segment_sum_i64(src, index, dim_size)        # bit-exact (nag.py:97,108)
-    return ops.segment_reduce(src, index, dim_size, "sum")
+        o = ops.segment_sum_i64(src, index, dim_size)            # bit-exact (nag.py:97,108)
+        return o if src.dtype == torch.bool else o.to(src.dtype)
+    return ops.segment_reduce(_float_src(src, "scatter_sum"), index, dim_size, "sum").to(src.dtype)
 
 
 scatter_add = scatter_sum
@@ -30,19 +46,33 @@ scatter_add = scatter_sum
 
 def scatter_mean(src, index, dim=-1, out=None, dim_size=None):
     _check(src, index, dim, out)
-    return ops.segment_reduce(src, index, dim_size, "mean")
+    if not src.is_floating_point():
+        # torch_scatter: integer sum, then floor division by the clamped count
+        from ..csr import csr_of
+        csr = csr_of(index, dim_size)
+        tot = ops.segment_sum_i64(src, csr, None)
+        cnt = csr.counts().long().clamp(min=1).view((-1,) + (1,) * (src.dim() - 1))
+        return torch.div(tot, cnt, rounding_mode="floor").to(src.dtype)
+    return ops.segment_reduce(_float_src(src, "scatter_mean"), index, dim_size, "mean").to(src.dtype)
+
+
+def _minmax(src, index, dim_size, op):
+    if not src.is_floating_point():
+        o, a = ops.segment_reduce(_int_as_f32(src, f"scatter_{op}"), index, dim_size, op,
+                                  return_arg=True)
+        return o.to(src.dtype), a.long()
+    o, a = ops.segment_reduce(_float_src(src, f"scatter_{op}"), index, dim_size, op, return_arg=True)
+    return o.to(src.dtype), a.long()
 
 
 def scatter_min(src, index, dim=-1, out=None, dim_size=None):
     _check(src, index, dim, out)
-    o, a = ops.segment_reduce(src, index, dim_size, "min", return_arg=True)
-    return o, a.long()
+    return _minmax(src, index, dim_size, "min")
 
 
 def scatter_max(src, index, dim=-1, out=None, dim_size=None):
     _check(src, index, dim, out)
-    o, a = ops.segment_reduce(src, index, dim_size, "max", return_arg=True)
-    return o, a.long()
+    return _minmax(src, index, dim_size, "max")
 
 
 def scatter_std(src, index, dim=-1, out=None, dim_size=None, unbiased=True):

@@ -120,8 +120,10 @@ class SampleEdges:
     def __call__(self, nag):
         from .segment import sparse_sample
         for i in self.levels:
+            if i >= nag.num_levels or self.n_min < 0 or self.n_max < 0:
+                continue
             d = nag[i]
-            if i >= nag.num_levels or not d.has_edges or self.n_min < 0 or self.n_max < 0:
+            if not d.has_edges:
                 continue
             idx = sparse_sample(d.edge_index[0], n_max=self.n_max, n_min=self.n_min,
                                 seed=self.seed, num_segments=d.num_nodes)

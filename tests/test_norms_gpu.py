@@ -49,7 +49,10 @@ def test_unit_sphere_norm_random(n, nseg, weighted, dev):
 
 @pytest.mark.parametrize("r,d,B,slope", [(1000, 64, 1, 1.0), (5000, 32, 3, 0.01), (40000, 128, 4, 0.01),
                                          (777, 18, 2, 1.0), (3, 64, 2, 0.2), (20000, 132, 1, 0.01),
-                                         (9000, 7, 5, 1.0)])
+                                         (9000, 7, 5, 1.0),
+                                         # more graphs than one 64 KiB LDS table holds (31 at d=128,
+                                         # 15 at d=256): several graph windows, one launch each
+                                         (60000, 128, 40, 0.01), (50000, 256, 70, 1.0)])
 @pytest.mark.parametrize("sorted_batch", [True, False])
 def test_graph_norm_forward_backward(r, d, B, slope, sorted_batch, dev):
     from superpoint_transformer_amd import ops
