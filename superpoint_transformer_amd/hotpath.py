@@ -37,6 +37,18 @@ def spt64_config(point_in=8, edge_in=18):
         fusion="cat", output_stage_wise=True)
 
 
+def spt128_config(point_in=8, edge_in=18):
+    """SPT-128 of configs/experiment/semantic/kitti360.yaml:22-27: the same spt-2 tree
+    (2 down stages, 1 up) with `_down_dim` / `_up_dim` 128 (value dim 8 per head),
+    `no_ffn: False`, `down_ffn_ratio: 1`."""
+    cfg = spt64_config(point_in, edge_in)
+    inj = 3 + 1
+    cfg.update(down_dim=[128, 128], down_pool_dim=[128, 128],
+               down_in_mlp=[[inj + 128, 128, 128], [inj + 128, 128, 128]],
+               up_dim=[128], up_in_mlp=[[inj + 128 + 128, 128, 128]], no_ffn=False)
+    return cfg
+
+
 def _pmc_traffic(timer_name):
     """HBM bytes per launch of the roofline kernel as measured with rocprofv3 PMC
     counters on this exact shape (profiles/traffic.json; FETCH_SIZE doubled per
