@@ -229,6 +229,12 @@ int spt_edge_attn_bwd_f32(const float* qkv, int64_t n, int H, int D, int Dv,
  * ws: spt_grid_knn_workspace_bytes(ns, ncells).
  * ---------------------------------------------------------------------- */
 size_t spt_grid_knn_workspace_bytes(int64_t ns, int64_t ncells);
+/* A self-search visited in cell order (query == search, order_queries_by_cell) has two
+ * equivalent implementations: waves that own 64 consecutive cell-sorted points and share
+ * one candidate stream (default), and one wave per query (also the path of every other
+ * call).  spt_knn_use_cell_path(0|1) selects process-wide and returns the previous
+ * setting; tests cross-check the two bit for bit. */
+int spt_knn_use_cell_path(int on);
 /* Bounding box of a cloud, the input of the host-side grid description above
  * (src/utils/neighbors.py has no counterpart: FRNN derives its grid internally).
  * lo_hi: DEVICE float[12]; [0..3) = min, [3..6) = max, [6..12) scratch. */

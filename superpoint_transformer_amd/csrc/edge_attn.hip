@@ -751,18 +751,21 @@ void attn_fwd_mfma_launch(const float* qkv, int64_t n, const int32_t* erowptr,
                           const int32_t* eperm, const int32_t* tgt, const float* ea,
                           const float* Wk, const float* bk, const float* Wq, const float* bq,
                           const float* Wv, const float* bv, int scale_mode, float scale_a,
-                          float* out, float* m, float* z, hipStream_t stream);
+                          float* out, float* m, float* z, int split_bf16, hipStream_t stream);
 int attn_bwd_mfma_launch(const float* qkv, int64_t n, const int32_t* erowptr,
                          const int32_t* eperm, const int32_t* tgt, const float* ea,
                          const float* Wk, const float* bk, const float* Wq, const float* bq,
                          const float* Wv, const float* bv, int scale_mode, float scale_a,
                          const float* out, const float* m, const float* z, const float* gout,
                          float* gqkv, float* gea, float* partial, hipStream_t stream);
+// 0: lane-per-output VALU kernels, 1: f32 matrix pipe (bitwise an fmaf chain), 2 (default):
+// split-bf16 on the bf16 matrix pipe (3 products per f32 product, ~10 ulp of f32)
 static int g_attn_mfma = -1;  // -1: decide from the environment on first use
-static bool use_mfma() {
-  if (g_attn_mfma < 0) g_attn_mfma = getenv("SPT_ATTN_VALU_ONLY") == nullptr ? 1 : 0;
-  return g_attn_mfma != 0;
+static int mfma_mode() {
+  if (g_attn_mfma < 0) g_attn_mfma = getenv("SPT_ATTN_VALU_ONLY") == nullptr ? 2 : 0;
+  return g_attn_mfma;
 }
+static bool use_mfma() { return mfma_mode() != 0; }
 }  // namespace spt
 
 using namespace spt;
@@ -781,9 +784,9 @@ using namespace spt;
                          "(built: H*D<=128, H*Dv<=128, F in {18,32})", __func__, H, D, Dv, F); \
   } while (0)
 
-extern "C" int spt_attn_use_mfma(int on) {
-  const int prev = use_mfma() ? 1 : 0;
-  g_attn_mfma = on ? 1 : 0;
+extern "C" int spt_attn_use_mfma(int mode) {
+  const int prev = mfma_mode();
+  g_attn_mfma = mode < 0 ? 0 : (mode > 2 ? 2 : mode);
   return prev;
 }
 
@@ -802,7 +805,7 @@ extern "C" int spt_edge_attn_fwd_f32(const float* qkv, int64_t n, int H, int D, 
   SPT_CHECK_ARG((m == nullptr) == (z == nullptr), "pass both m and z or neither");
   if (use_mfma() && attn_mfma_shape_ok(H, D, Dv, F, edge_attr, Wk, Wq, Wv)) {
     attn_fwd_mfma_launch(qkv, n, erowptr, eperm, tgt_sorted, edge_attr, Wk, bk, Wq, bq, Wv, bv,
-                         scale_mode, scale_a, out, m, z, stream);
+                         scale_mode, scale_a, out, m, z, mfma_mode() == 2, stream);
     SPT_CHECK_LAUNCH();
     return 0;
   }

@@ -163,6 +163,59 @@ __device__ __forceinline__ void load_a(const float* slab, int g, int c, float (&
   for (int st = 0; st < 8; ++st) A[st] = slab[c * F + ((st ^ (c & 7)) << 2) + g];
 }
 
+// ---- split-bf16 operands: x = hi + lo (+ 2^-18 |x|), both bf16 (RNE).  A product of two
+// f32 numbers is taken as hi*hi + lo*hi + hi*lo on the bf16 matrix pipe (16x the f32 pipe's
+// rate, exact bf16 x bf16 products, f32 accumulate): relative error <= ~3 * 2^-18 per product,
+// i.e. ~10 ulp of f32 - inside the attention parity bar (1e-5 + 1e-4 |ref|).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+template <int NV, typename V>
+__device__ __forceinline__ void split_bf16(const float (&x)[NV], V& hi, V& lo) {
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const __bf16 h = (__bf16)x[i];
+    hi[i] = h;
+    lo[i] = (__bf16)(x[i] - (float)h);
+  }
+}
+
+// B operands of the RPE GEMM on the bf16 pipe (16x16x32): lane (g, c) holds
+// W[16 b + c][8 g .. 8 g + 7], split
+__device__ __forceinline__ void load_b_bf(const float* __restrict__ W, int g, int c,
+                                          bf16x8 (&Bh)[NB], bf16x8 (&Bl)[NB]) {
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    float w[8];
+    const float4 w0 = *reinterpret_cast<const float4*>(W + (size_t)(16 * b + c) * F + 8 * g);
+    const float4 w1 = *reinterpret_cast<const float4*>(W + (size_t)(16 * b + c) * F + 8 * g + 4);
+    w[0] = w0.x; w[1] = w0.y; w[2] = w0.z; w[3] = w0.w;
+    w[4] = w1.x; w[5] = w1.y; w[6] = w1.z; w[7] = w1.w;
+    split_bf16<8>(w, Bh[b], Bl[b]);
+  }
+}
+
+// A operands of a tile on the bf16 pipe: lane (g, c) holds ea[edge c][8 g .. 8 g + 7]
+// (two 16-byte chunks, un-swizzled on read), split
+__device__ __forceinline__ void load_a_bf(const float* slab, int g, int c, bf16x8& Ah, bf16x8& Al) {
+  const float4 a0 = *reinterpret_cast<const float4*>(slab + c * F + (((2 * g) ^ (c & 7)) << 2));
+  const float4 a1 = *reinterpret_cast<const float4*>(slab + c * F + (((2 * g + 1) ^ (c & 7)) << 2));
+  const float a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+  split_bf16<8>(a, Ah, Al);
+}
+
+__device__ __forceinline__ void rpe_gemm_bf(const bf16x8& Ah, const bf16x8& Al,
+                                            const bf16x8 (&Bh)[NB], const bf16x8 (&Bl)[NB],
+                                            const float (&init)[NB], f32x4 (&C)[NB]) {
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    C[b] = (f32x4){init[b], init[b], init[b], init[b]};
+    C[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, Bh[b], C[b], 0, 0, 0);
+    C[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bl[b], C[b], 0, 0, 0);
+    C[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bh[b], C[b], 0, 0, 0);
+  }
+}
+
 // C[b][r] starts at init[b] (bias / node term folded into the accumulator for free)
 __device__ __forceinline__ void rpe_gemm(const float (&A)[8], const float (&B)[NB][8],
                                          const float (&init)[NB], f32x4 (&C)[NB]) {
@@ -322,6 +375,7 @@ struct Pipe {
   }
 };
 
+template <bool BF3>
 __global__ __launch_bounds__(WAVES * 64, 2) void attn_fwd_mfma_kernel(
     const float* __restrict__ qkv, int ld, int64_t N, const int32_t* __restrict__ erowptr,
     const int32_t* __restrict__ eperm, const int32_t* __restrict__ tgt,
@@ -333,10 +387,17 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_fwd_mfma_kernel(
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, c = lane & 15;
-  float Bk[NB][8], Bq[NB][8], Bv[NB][8], bk4[NB], bq4[NB], bv4[NB];
-  load_b(Wk, g, c, Bk);
-  load_b(Wq, g, c, Bq);
-  load_b(Wv, g, c, Bv);
+  float Bk[BF3 ? 1 : NB][8], Bq[BF3 ? 1 : NB][8], Bv[BF3 ? 1 : NB][8], bk4[NB], bq4[NB], bv4[NB];
+  bf16x8 Bkh[NB], Bkl[NB], Bqh[NB], Bql[NB], Bvh[NB], Bvl[NB];
+  if constexpr (BF3) {
+    load_b_bf(Wk, g, c, Bkh, Bkl);
+    load_b_bf(Wq, g, c, Bqh, Bql);
+    load_b_bf(Wv, g, c, Bvh, Bvl);
+  } else {
+    load_b(Wk, g, c, Bk);
+    load_b(Wq, g, c, Bq);
+    load_b(Wv, g, c, Bv);
+  }
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     bk4[b] = bk ? bk[16 * b + c] : 0.f;
@@ -377,12 +438,20 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_fwd_mfma_kernel(
       }
     }
     if (cnt > 0) {
-      float A[8];
-      load_a(slab, g, c, A);
       f32x4 Ck[NB], Cq[NB], Cv[NB];
-      rpe_gemm(A, Bk, bk4, Ck);        // k_e - k_t   = Wk ea + bk
-      rpe_gemm(A, Bq, qs4, Cq);        // q_e         = Wq ea + bq + q_s scale
-      rpe_gemm(A, Bv, bv4, Cv);        // v_e - v_t   = Wv ea + bv
+      if constexpr (BF3) {
+        bf16x8 Ah, Al;
+        load_a_bf(slab, g, c, Ah, Al);
+        rpe_gemm_bf(Ah, Al, Bkh, Bkl, bk4, Ck);
+        rpe_gemm_bf(Ah, Al, Bqh, Bql, qs4, Cq);
+        rpe_gemm_bf(Ah, Al, Bvh, Bvl, bv4, Cv);
+      } else {
+        float A[8];
+        load_a(slab, g, c, A);
+        rpe_gemm(A, Bk, bk4, Ck);        // k_e - k_t   = Wk ea + bk
+        rpe_gemm(A, Bq, qs4, Cq);        // q_e         = Wq ea + bq + q_s scale
+        rpe_gemm(A, Bv, bv4, Cv);        // v_e - v_t   = Wv ea + bv
+      }
       const bool partial = cnt < TE;   // wave-uniform
       const float* kp = kslab + 4 * g * ROW + c;
       const float* vp = vslab + 4 * g * ROW + c;
@@ -689,11 +758,15 @@ void attn_fwd_mfma_launch(const float* qkv, int64_t n, const int32_t* erowptr,
                           const int32_t* eperm, const int32_t* tgt, const float* ea,
                           const float* Wk, const float* bk, const float* Wq, const float* bq,
                           const float* Wv, const float* bv, int scale_mode, float scale_a,
-                          float* out, float* m, float* z, hipStream_t stream) {
+                          float* out, float* m, float* z, int split_bf16, hipStream_t stream) {
   const int64_t blocks = ceil_div(n, mfma::WAVES);
   const int grid = (int)(blocks < 256 * 2 * 4 ? blocks : 256 * 2 * 4);
-  mfma::attn_fwd_mfma_kernel<<<grid, mfma::WAVES * 64, 0, stream>>>(
-      qkv, 192, n, erowptr, eperm, tgt, ea, Wk, bk, Wq, bq, Wv, bv, scale_mode, scale_a, out, m, z);
+  if (split_bf16)
+    mfma::attn_fwd_mfma_kernel<true><<<grid, mfma::WAVES * 64, 0, stream>>>(
+        qkv, 192, n, erowptr, eperm, tgt, ea, Wk, bk, Wq, bq, Wv, bv, scale_mode, scale_a, out, m, z);
+  else
+    mfma::attn_fwd_mfma_kernel<false><<<grid, mfma::WAVES * 64, 0, stream>>>(
+        qkv, 192, n, erowptr, eperm, tgt, ea, Wk, bk, Wq, bq, Wv, bv, scale_mode, scale_a, out, m, z);
 }
 
 constexpr int ATTN_BWD_MFMA_BLOCKS = 256;  // one 4-wave workgroup per CU (1 wave / SIMD)

@@ -187,8 +187,9 @@ __global__ __launch_bounds__(KNN_WAVES * 64) void knn_search_kernel(
     const float* __restrict__ query, int64_t nq, const int32_t* __restrict__ qorder,
     const float4* __restrict__ sorted, const int32_t* __restrict__ rowptr, Grid g, int K,
     float r, int inclusive, int squared, int64_t* __restrict__ out_idx,
-    float* __restrict__ out_dist) {
+    float* __restrict__ out_dist, const int32_t* __restrict__ nq_dev) {
   __shared__ uint64_t pend_all[KNN_WAVES][64];
+  if (nq_dev) nq = *nq_dev;          // leftovers of knn_cell_kernel: the count lives on the device
   const int lane = threadIdx.x & 63;
   const int wid = threadIdx.x >> 6;
   uint64_t* pend = pend_all[wid];
@@ -284,8 +285,247 @@ __global__ __launch_bounds__(KNN_WAVES * 64) void knn_search_kernel(
   }
 }
 
+// ---- self-search, cell-centric fast path ---------------------------------------------------
+// The wave-per-query kernel above spends ~2 000 instructions per query: every query walks the
+// same 27 cells as its cell mates, and every ~64 accepted candidates cost a 64-lane sort +
+// merge.  For the preprocessing call (every point of a cloud searches the cloud itself,
+// src/utils/neighbors.py:51-123) the queries ARE the cell-sorted search points, so here a wave
+// owns 64 consecutive sorted points = 1-3 neighbouring cells of one grid row and shares the
+// candidate stream among its lanes:
+//   round : leader = first unfinished lane; group = lanes of the leader's row with cell x in
+//           [lx, lx + KC_W); candidates = the 9 rows (dz, dy in -1..1), x in [lx-1, lx+KC_W]
+//           - one contiguous range of `sorted` per row - staged 64 at a time through LDS and
+//           read back as broadcasts: every lane evaluates ITS distance to the same candidate;
+//   pass A: per-lane histogram (KC_NBINS bins of d2 over [0, B2], B2 = min(guaranteed radius^2
+//           of ring 1, r^2)) -> smallest bin edge holding >= K candidates;
+//   pass B: candidates at or below that bin are appended to the lane's list (<= 64 entries);
+//   sort  : per query one 64-lane bitonic sort of its list, K results written.
+// A lane whose ring-1 neighbourhood does not guarantee its K-th neighbour (fewer than K
+// candidates within B2 while r reaches further; a bin so dense that the list would overflow)
+// is appended to `todo` and finished by knn_search_kernel afterwards: same exact contract.
+constexpr int KC_WAVES = 4;
+constexpr int KC_NBINS = 16;
+constexpr int KC_CAP = 64;
+constexpr int KC_W = 3;
+
+struct KcLds {
+  uint32_t hist[KC_NBINS][64];
+  uint16_t list[KC_CAP + 1][64];   // + 1: the branch-free append always stores, then maybe advances
+  float4 stage[64];
+};
+
+__device__ __forceinline__ void kc_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ int kc_clamped_cell(float p, float o, float inv_s, int d) {
+  int c = cell_coord(p, o, inv_s);
+  return c < 0 ? 0 : (c >= d ? d - 1 : c);
+}
+
+__device__ __forceinline__ float kc_d2(const float4& q, const float4& p) {
+  const float ddx = q.x - p.x, ddy = q.y - p.y, ddz = q.z - p.z;
+  return (ddx * ddx + ddy * ddy) + ddz * ddz;       // the contract's rounding order
+}
+
+// 64 candidates of one range into the wave's staging tile; slots beyond m hold a point
+// that is out of every radius, so the consumers run whole groups of 4 without a tail
+__device__ __forceinline__ void kc_stage(KcLds& L, const float4* __restrict__ sorted, int first,
+                                         int m, int lane) {
+  kc_wave_sync();
+  L.stage[lane] = lane < m ? sorted[first + lane] : make_float4(1e30f, 1e30f, 1e30f, 0.f);
+  kc_wave_sync();
+}
+
+__global__ __launch_bounds__(KC_WAVES * 64) void knn_cell_kernel(
+    const float4* __restrict__ sorted, int64_t ns, const int32_t* __restrict__ rowptr, Grid g,
+    int K, float r, int inclusive, int squared, int64_t* __restrict__ out_idx,
+    float* __restrict__ out_dist, int32_t* __restrict__ todo, int32_t* __restrict__ todo_count) {
+  __shared__ KcLds lds_all[KC_WAVES];
+  const int lane = threadIdx.x & 63;
+  const int wid = threadIdx.x >> 6;
+  KcLds& L = lds_all[wid];
+  const float r2 = r * r;
+  const float gr = (1.0f - 0.01f) * g.s;   // ring 1 done: unexplored points are farther than this
+  const float g2 = gr * gr;
+  const bool ring_covers_r = g2 >= r2;
+  const float B2 = ring_covers_r ? r2 : g2;
+  // one comparison per candidate: d2 <= lim  <=>  d2 <= g2 and (d2 < r2, or <= when inclusive)
+  const float lim = (ring_covers_r && !inclusive) ? __uint_as_float(__float_as_uint(r2) - 1u) : B2;
+  const float bin_scale = (float)KC_NBINS / B2;
+  const int64_t nunits = (ns + 63) / 64;
+
+  for (int64_t unit = (int64_t)blockIdx.x * KC_WAVES + wid; unit < nunits;
+       unit += (int64_t)gridDim.x * KC_WAVES) {
+    const int64_t j = unit * 64 + lane;
+    const bool have = j < ns;
+    const float4 q = have ? sorted[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int cx = kc_clamped_cell(q.x, g.ox, g.inv_s, g.dx);
+    const int cy = kc_clamped_cell(q.y, g.oy, g.inv_s, g.dy);
+    const int cz = kc_clamped_cell(q.z, g.oz, g.inv_s, g.dz);
+    uint64_t pending = __ballot(have);
+    while (pending) {
+      const int leader = __ffsll((unsigned long long)pending) - 1;
+      const int lx = __builtin_amdgcn_readlane(cx, leader), ly = __builtin_amdgcn_readlane(cy, leader),
+                lz = __builtin_amdgcn_readlane(cz, leader);
+      const bool mine = ((pending >> lane) & 1) && cy == ly && cz == lz && cx >= lx &&
+                        cx < lx + KC_W;
+      pending &= ~__ballot(mine);
+      // the 9 candidate ranges (lanes 0..8), their prefix bases and the total
+      int rs = 0, rl = 0;
+      if (lane < 9) {
+        const int z = lz + lane / 3 - 1, y = ly + lane % 3 - 1;
+        if (z >= 0 && z < g.dz && y >= 0 && y < g.dy) {
+          const int x0 = lx - 1 < 0 ? 0 : lx - 1;
+          const int x1 = lx + KC_W >= g.dx ? g.dx - 1 : lx + KC_W;
+          const int64_t rb = ((int64_t)z * g.dy + y) * g.dx;
+          rs = rowptr[rb + x0];
+          rl = rowptr[rb + x1 + 1] - rs;
+        }
+      }
+      const int rbase = (int)wave_inclusive_scan((uint32_t)rl) - rl;   // exclusive prefix
+      int rs_u[9], rl_u[9], rb_u[9];                                   // wave-uniform copies
+#pragma unroll
+      for (int ri = 0; ri < 9; ++ri) {
+        rs_u[ri] = __builtin_amdgcn_readlane(rs, ri);
+        rl_u[ri] = __builtin_amdgcn_readlane(rl, ri);
+        rb_u[ri] = __builtin_amdgcn_readlane(rbase, ri);
+      }
+      const int ncand = rb_u[8] + rl_u[8];
+      bool ok = false;
+      int bK = KC_NBINS - 1, len = 0;
+      if (ncand <= 65535) {
+        // ---- pass A: per-lane histogram of d2 (lanes outside the group count too: their
+        //      columns are simply not read) --------------------------------------------------
+#pragma unroll
+        for (int b = 0; b < KC_NBINS; ++b) L.hist[b][lane] = 0u;
+#pragma unroll
+        for (int ri = 0; ri < 9; ++ri) {
+          for (int b0 = 0; b0 < rl_u[ri]; b0 += 64) {
+            const int m = rl_u[ri] - b0 < 64 ? rl_u[ri] - b0 : 64;
+            kc_stage(L, sorted, rs_u[ri] + b0, m, lane);
+            for (int t = 0; t < m; t += 4) {
+              float4 p[4];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) p[u] = L.stage[t + u];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                const float d2 = kc_d2(q, p[u]);
+                int bin = (int)(d2 * bin_scale);
+                bin = bin > KC_NBINS - 1 ? KC_NBINS - 1 : bin;
+                __hip_atomic_fetch_add(&L.hist[bin][lane], d2 <= lim ? 1u : 0u, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WAVEFRONT);
+              }
+            }
+          }
+        }
+        kc_wave_sync();
+        int cum = 0, found = -1;
+#pragma unroll
+        for (int b = 0; b < KC_NBINS; ++b) {
+          cum += (int)L.hist[b][lane];
+          if (found < 0 && cum >= K) {
+            found = b;
+            len = cum;
+          }
+        }
+        if (found >= 0) {
+          bK = found;
+          ok = len <= KC_CAP;
+        } else {                     // fewer than K within B2: final only if B2 is the radius
+          len = cum;
+          ok = ring_covers_r;
+        }
+      }
+      ok = ok && mine;
+      // ---- lanes the fast path cannot finish ----------------------------------------------
+      const uint64_t fb = __ballot(mine && !ok);
+      if (fb) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(todo_count, __popcll(fb));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (mine && !ok) todo[base + __popcll(fb & lanemask_lt())] = __float_as_int(q.w);
+      }
+      uint64_t todo_sort = __ballot(ok);
+      if (todo_sort == 0) continue;
+      // ---- pass B: the candidates at or below the lane's bin, as positions in the round's
+      //      candidate enumeration (branch-free append: store, then advance if taken) --------
+      const int bKe = ok ? bK : -1;
+      int nl = 0;
+#pragma unroll
+      for (int ri = 0; ri < 9; ++ri) {
+        for (int b0 = 0; b0 < rl_u[ri]; b0 += 64) {
+          const int m = rl_u[ri] - b0 < 64 ? rl_u[ri] - b0 : 64;
+          kc_stage(L, sorted, rs_u[ri] + b0, m, lane);
+          const int pb = rb_u[ri] + b0;
+          for (int t = 0; t < m; t += 4) {
+            float4 p[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) p[u] = L.stage[t + u];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const float d2 = kc_d2(q, p[u]);
+              int bin = (int)(d2 * bin_scale);
+              bin = bin > KC_NBINS - 1 ? KC_NBINS - 1 : bin;
+              const bool take = d2 <= lim && bin <= bKe;
+              L.list[nl][lane] = (uint16_t)(pb + t + u);
+              nl += take ? 1 : 0;
+            }
+          }
+        }
+      }
+      kc_wave_sync();
+      // ---- per query: 64-lane sort of its list, K results; the candidate rows of the next
+      //      query are in flight while the current one sorts ---------------------------------
+      auto fetch = [&](int ql) -> float4 {
+        float4 pc = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int n = __builtin_amdgcn_readlane(len, ql);
+        if (lane < n) {
+          const int pos = (int)L.list[lane][ql];
+          int gi = 0;
+#pragma unroll
+          for (int ri = 0; ri < 9; ++ri) gi = pos >= rb_u[ri] ? rs_u[ri] + (pos - rb_u[ri]) : gi;
+          pc = sorted[gi];
+        }
+        return pc;
+      };
+      int ql = __ffsll((unsigned long long)todo_sort) - 1;
+      todo_sort &= todo_sort - 1;
+      float4 pc = fetch(ql);
+      while (true) {
+        const int qn = todo_sort ? __ffsll((unsigned long long)todo_sort) - 1 : -1;
+        todo_sort &= todo_sort - 1;
+        float4 pn = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (qn >= 0) pn = fetch(qn);
+        const int n = __builtin_amdgcn_readlane(len, ql);
+        float4 qq;
+        qq.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.x), ql));
+        qq.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.y), ql));
+        qq.z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.z), ql));
+        const int64_t qi = (int64_t)(uint32_t)__builtin_amdgcn_readlane(__float_as_int(q.w), ql);
+        uint64_t key = KNN_EMPTY;
+        if (lane < n)
+          key = ((uint64_t)__float_as_uint(kc_d2(qq, pc)) << 32) | (uint32_t)__float_as_int(pc.w);
+        key = wave_sort(key, lane);
+        if (lane < K) {
+          const bool okk = key != KNN_EMPTY;
+          float d = __uint_as_float((uint32_t)(key >> 32));
+          if (!squared) d = sqrtf(d);
+          out_idx[qi * K + lane] = okk ? (int64_t)(uint32_t)(key & 0xffffffffu) : -1;
+          out_dist[qi * K + lane] = okk ? d : -1.0f;
+        }
+        if (qn < 0) break;
+        ql = qn;
+        pc = pn;
+      }
+    }
+  }
+}
+
 struct KnnPlan {
-  size_t off_cell, off_perm, off_rowptr, off_sorted, off_sortws, sortws, total;
+  size_t off_cell, off_perm, off_rowptr, off_sorted, off_sortws, off_todo, off_count, sortws, total;
 };
 
 }  // namespace spt
@@ -301,6 +541,8 @@ static KnnPlan knn_plan(int64_t ns, int64_t ncells) {
   p.off_sorted = o; o += align_up((size_t)(ns > 0 ? ns : 1) * 16, 256);
   p.sortws = spt_csr_build_workspace_bytes(ns, ncells);
   p.off_sortws = o; o += align_up(p.sortws, 256);
+  p.off_todo = o;   o += align_up((size_t)(ns > 0 ? ns : 1) * 4, 256);   // queries left to the slow path
+  p.off_count = o;  o += 256;
   p.total = o;
   return p;
 }
@@ -396,6 +638,16 @@ extern "C" int spt_spatial_order(const float* xyz, int64_t n, float cell_size, c
                        spt_csr_build_workspace_bytes(n, ncells), stream_);
 }
 
+// process-wide switch between the two self-search kernels (tests cross-check them; 1 = shared
+// candidate streams, 0 = wave per query); returns the previous setting
+static int g_knn_cell_path = 1;
+static bool knn_cell_path_enabled() { return g_knn_cell_path != 0; }
+extern "C" int spt_knn_use_cell_path(int on) {
+  const int prev = g_knn_cell_path;
+  g_knn_cell_path = on ? 1 : 0;
+  return prev;
+}
+
 extern "C" size_t spt_grid_knn_workspace_bytes(int64_t ns, int64_t ncells) {
   if (ns < 0 || ncells < 1) return 0;
   return knn_plan(ns, ncells).total;
@@ -440,8 +692,22 @@ extern "C" int spt_grid_knn_f32(const float* query, int64_t nq, const float* sea
   if (cell_order && ns > 0)
     (void)hipMemcpyAsync(cell_order, perm, (size_t)ns * 4, hipMemcpyDeviceToDevice, stream);
   const int grid = (int)(ceil_div(nq, KNN_WAVES) < 256 * 8 ? ceil_div(nq, KNN_WAVES) : 256 * 8);
-  knn_search_kernel<<<grid, KNN_WAVES * 64, 0, stream>>>(query, nq, qorder, sorted, rowptr, g, K, r,
-                                                         inclusive, squared, idx, dist);
+  if (qorder && knn_cell_path_enabled()) {
+    // self-search in cell order: shared candidate streams (knn_cell_kernel), leftovers through
+    // the wave-per-query kernel with their count read on the device
+    int32_t* todo = (int32_t*)(base + p.off_todo);
+    int32_t* count = (int32_t*)(base + p.off_count);
+    (void)hipMemsetAsync(count, 0, 4, stream);
+    const int64_t units = ceil_div(ns, 64);
+    const int cgrid = (int)(ceil_div(units, KC_WAVES) < 256 * 8 ? ceil_div(units, KC_WAVES) : 256 * 8);
+    knn_cell_kernel<<<cgrid, KC_WAVES * 64, 0, stream>>>(sorted, ns, rowptr, g, K, r, inclusive,
+                                                         squared, idx, dist, todo, count);
+    knn_search_kernel<<<grid, KNN_WAVES * 64, 0, stream>>>(query, nq, todo, sorted, rowptr, g, K, r,
+                                                           inclusive, squared, idx, dist, count);
+  } else {
+    knn_search_kernel<<<grid, KNN_WAVES * 64, 0, stream>>>(query, nq, qorder, sorted, rowptr, g, K,
+                                                           r, inclusive, squared, idx, dist, nullptr);
+  }
   SPT_CHECK_LAUNCH();
   return 0;
 }

@@ -26,7 +26,7 @@ def _bbox(xyz):
     return buf[0:3], buf[3:6]
 
 
-def _grid_for(search, r, K, cell_size=None):
+def _grid_for(search, r, K, cell_size=None, self_search=False):
     """Host-side grid description (one sync: the bounding box).  The result
     does not depend on the cell size, only the speed does: ~1.5 K points per
     non-empty cell measured fastest (few rings, few row ranges per ring).  The
@@ -44,7 +44,11 @@ def _grid_for(search, r, K, cell_size=None):
         c = ((sub - lo) / s1).floor().long()
         lin = (c[:, 2] * d1[1] + c[:, 1]) * d1[0] + c[:, 0]
         occ = (m / max(int(torch.unique(lin).numel()), 1)) * (n / m)   # points per cell at s1
-        target = max(1.5 * K, 8.0)
+        # self-search (shared candidate streams): the wave scans 5 x 9 cells per 64 queries, so
+        # fewer points per cell than the wave-per-query kernel likes (SPT_KNN_OCC: tuning knob)
+        import os
+        occ_k = float(os.environ.get("SPT_KNN_OCC", "0.75" if self_search else "1.5"))
+        target = max(occ_k * K, 8.0)
         s = s1 * (target / max(occ, 1e-3)) ** 0.5
         s = min(max(s, float(r) / 64), float(r))
     else:
@@ -73,7 +77,7 @@ def frnn_grid_points(query, search, K, r, squared=True, inclusive=False, cell_si
         return dist, idx
     if ns == 0:
         return dist.fill_(-1), idx.fill_(-1)
-    cs, origin, dims = _grid_for(s, r, K, cell_size)
+    cs, origin, dims = _grid_for(s, r, K, cell_size, self_search=search is query)
     # self-search of a large cloud: keep the grid's cell order of the points, the kernels
     # that gather neighbourhoods afterwards (geometric_features) visit points in that order
     order = torch.empty(ns, dtype=torch.int32, device=dev) \

@@ -42,6 +42,48 @@ def test_grid_knn_is_bit_exact(name, K, r, cell, dev):
     assert torch.equal(dist.cpu(), rd)          # same f32 expression: exact
 
 
+@pytest.mark.parametrize("name,K,r", [("mixed", 46, 2.0), ("mixed", 11, 0.3), ("mixed", 64, 50.0),
+                                      ("lattice", 26, 0.6), ("lattice", 46, 10.0), ("lattice", 7, 0.25),
+                                      ("tiny", 8, 1.0), ("tiny", 1, 0.01)])
+@pytest.mark.parametrize("cell", [None, 0.11, 0.6, 3.7])
+@pytest.mark.parametrize("inclusive", [False, True])
+def test_self_search_cell_path_is_bit_exact(name, K, r, cell, inclusive, dev):
+    """Self-search (query IS search: the preprocessing call) runs the shared-candidate-stream
+    kernel + the wave-per-query kernel for its leftovers; both must reproduce the oracle, at
+    any cell size (cells far too fine / far too coarse push queries to the leftover path)."""
+    from superpoint_transformer_amd import _lib
+    from superpoint_transformer_amd import neighbors as NB
+    xyz = _clouds()[name]
+    p = xyz.to(dev)
+    rd, ri = O.frnn_grid_points(xyz, xyz, K, r, strict=not inclusive)
+    for path in (1, 0):
+        prev = _lib.lib.spt_knn_use_cell_path(path)
+        try:
+            dist, idx = NB.frnn_grid_points(p, p, K, r, cell_size=cell, inclusive=inclusive)
+        finally:
+            _lib.lib.spt_knn_use_cell_path(prev)
+        assert torch.equal(idx.cpu(), ri), f"path {path}"
+        assert torch.equal(dist.cpu(), rd), f"path {path}"
+
+
+def test_self_search_paths_agree_on_a_voxel_cloud(dev):
+    """2 M-point voxelised surfaces at the S3DIS settings: the two self-search kernels
+    agree bit for bit (indices and squared distances) on every row."""
+    from superpoint_transformer_amd import _lib
+    from superpoint_transformer_amd import neighbors as NB
+    from superpoint_transformer_amd.synthetic import make_voxel_cloud
+    pos = make_voxel_cloud(2_000_000, voxel=0.03, seed=11, device=dev)
+    out = []
+    for path in (1, 0):
+        prev = _lib.lib.spt_knn_use_cell_path(path)
+        try:
+            out.append(NB.frnn_grid_points(pos, pos, 46, 2.0))
+        finally:
+            _lib.lib.spt_knn_use_cell_path(prev)
+    assert torch.equal(out[0][1], out[1][1])
+    assert torch.equal(out[0][0], out[1][0])
+
+
 def test_grid_knn_two_sets_and_euclidean_and_inclusive(dev):
     from superpoint_transformer_amd import neighbors as NB
     g = torch.Generator().manual_seed(5)
