@@ -86,6 +86,9 @@ def cpu_baseline(scene, scale):
 
 PRE_CFG = {  # configs/datamodule/semantic/{s3dis,dales}.yaml: voxel, knn k, knn r
     "S": (0.03, 45, 2.0), "T": (0.03, 45, 2.0), "R": (0.03, 45, 2.0), "D": (0.10, 25, 10.0)}
+# synthetic cloud geometry: indoor rooms (3 m patches in a 50 x 50 x 5 m block) vs an aerial
+# tile (20 m patches of ground / roofs / facades over 350 x 350 x 30 m: ~12 M voxels of 10 cm)
+PRE_GEOM = {"D": dict(patch=20.0, extent=(350.0, 350.0, 30.0))}
 
 
 def preprocess_leg(scene, n_points, dev, reps=5):
@@ -95,7 +98,7 @@ def preprocess_leg(scene, n_points, dev, reps=5):
     from superpoint_transformer_amd import neighbors as NB
     from superpoint_transformer_amd.synthetic import make_voxel_cloud
     voxel, k, r = PRE_CFG.get(scene, PRE_CFG["S"])
-    pos = make_voxel_cloud(n_points, voxel=voxel, seed=4321, device=dev)
+    pos = make_voxel_cloud(n_points, voxel=voxel, seed=4321, device=dev, **PRE_GEOM.get(scene, {}))
     n_points = pos.shape[0]          # one point per voxel: slightly fewer than requested
 
     def step():

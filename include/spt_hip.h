@@ -194,11 +194,15 @@ int spt_edge_attn_fwd_f32(const float* qkv, int64_t n, int H, int D, int Dv,
                           float scale_a, float* out, float* m, float* z,
                           spt_stream_t stream);
 size_t spt_edge_attn_bwd_workspace_bytes(int H, int D, int Dv, int F);
-/* Two independent formulations exist for the SPT-64 head layout (H=16, D=Dv=4,
- * F=32): the matrix-pipe one (default) and the generic lane-per-output one.
- * spt_attn_use_mfma(0|1) selects it process-wide and returns the previous
- * setting; tests cross-check the two at full scene size. */
-int spt_attn_use_mfma(int on);
+/* Three formulations exist for the SPT-64 head layout (H=16, D=Dv=4, F=32):
+ *   2 (default)  matrix pipe, split-bf16: every f32 product of the three RPE GEMMs (and of
+ *                the two gradient GEMMs) is hi*hi + lo*hi + hi*lo of bf16 halves on the bf16
+ *                MFMA (16x the f32 pipe's rate), f32 accumulate: ~10 ulp of f32 per product;
+ *   1            matrix pipe, f32 in / f32 accumulate (bitwise an fmaf chain);
+ *   0            generic lane-per-output VALU kernels (every other shape uses these).
+ * spt_attn_use_mfma(mode) selects process-wide and returns the previous mode; tests
+ * cross-check all three at full scene size. */
+int spt_attn_use_mfma(int mode);
 int spt_edge_attn_bwd_f32(const float* qkv, int64_t n, int H, int D, int Dv,
                           const int32_t* erowptr, const int32_t* eperm,
                           const int32_t* tgt_sorted, int64_t e,
@@ -273,6 +277,20 @@ int spt_point_geof_dense_f32(const float* xyz, int64_t n, const int64_t* nn, int
 int spt_point_geof_csr_f32(const float* xyz, int64_t n, const int64_t* nn_val,
                            const int64_t* nn_ptr, int add_self, int k_min, int post,
                            float* feats, spt_stream_t stream);
+/* scatter_pca (src/utils/scatter.py:41-125, algorithm='eigh') as an entry of its own (a12):
+ * for every group of the CSR view (perm nullable = rows already grouped) the population
+ * covariance of x [rows, 3], its eigenvalues ascending and clamped at 0 -> eigenval [S,3],
+ * eigenvectors in the COLUMNS of eigenvec [S,3,3] (torch.linalg.eigh's layout; the sign of a
+ * column is arbitrary there as here); an empty group yields (1,1,1) / identity
+ * (scatter.py:113-118). */
+int spt_scatter_pca_f32(const float* x, const int32_t* perm, const int32_t* rowptr,
+                        int64_t num_seg, float* eigenval, float* eigenvec, spt_stream_t stream);
+/* neighbors_dense_to_csr (src/utils/neighbors.py:668-684)                       (a10)
+ * nn [n,k] int64 with negative = missing -> ptr [n+1], val [capacity n*k, first ptr[n]
+ * entries valid, row order kept], sizes [n] (all int64). */
+size_t spt_neighbors_dense_to_csr_workspace_bytes(int64_t n);
+int spt_neighbors_dense_to_csr(const int64_t* nn, int64_t n, int k, int64_t* ptr, int64_t* val,
+                               int64_t* sizes, void* ws, size_t ws_bytes, spt_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Per-segment random sampling without replacement                      (f2/f3)

@@ -757,7 +757,8 @@ int attn_bwd_mfma_launch(const float* qkv, int64_t n, const int32_t* erowptr,
                          const float* Wk, const float* bk, const float* Wq, const float* bq,
                          const float* Wv, const float* bv, int scale_mode, float scale_a,
                          const float* out, const float* m, const float* z, const float* gout,
-                         float* gqkv, float* gea, float* partial, hipStream_t stream);
+                         float* gqkv, float* gea, float* partial, int split_bf16,
+                         hipStream_t stream);
 // 0: lane-per-output VALU kernels, 1: f32 matrix pipe (bitwise an fmaf chain), 2 (default):
 // split-bf16 on the bf16 matrix pipe (3 products per f32 product, ~10 ulp of f32)
 static int g_attn_mfma = -1;  // -1: decide from the environment on first use
@@ -867,7 +868,7 @@ extern "C" int spt_edge_attn_bwd_f32(const float* qkv, int64_t n, int H, int D, 
   if (use_mfma() && attn_mfma_shape_ok(H, D, Dv, F, edge_attr, Wk, Wq, Wv)) {
     const int ntab = attn_bwd_mfma_launch(qkv, n, erowptr, eperm, tgt_sorted, edge_attr, Wk, bk,
                                           Wq, bq, Wv, bv, scale_mode, scale_a, out, m, z, gout,
-                                          gqkv, gedge_attr, partial, stream);
+                                          gqkv, gedge_attr, partial, mfma_mode() == 2, stream);
     attn_reduce_partials_kernel<<<(int)ceil_div((int64_t)len, 16), 256, 0, stream>>>(
         partial, ntab, (int)len, total);
     attn_unpack_grads_kernel<<<(int)ceil_div((int64_t)len, 256), 256, 0, stream>>>(

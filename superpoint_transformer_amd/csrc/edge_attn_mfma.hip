@@ -503,6 +503,13 @@ constexpr int DT_FLOATS = TE * DT_STRIDE;      // 3136 floats = 12.25 KB
 constexpr int W_FLOATS = 192 * (F + 1);   // [Wk; Wq; Wv] rows (padded), shared by the 4 waves:
                                           // B operands of the recompute GEMM and of D W
 
+// split-bf16 variant: padded bf16 copies of [Wk; Wq; Wv] (row n = output column, 32 + 8 bf16
+// per row: 80-byte rows put the 16 lanes of a group on 16 distinct 4-bank windows)
+constexpr int WB_LD = F + 8;
+constexpr int WB_ELEMS = 192 * WB_LD;
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+template <bool BF3>
 __global__ __launch_bounds__(WAVES * 64, 1) void attn_bwd_mfma_kernel(
     const float* __restrict__ qkv, int ld, int64_t N, const int32_t* __restrict__ erowptr,
     const int32_t* __restrict__ eperm, const int32_t* __restrict__ tgt,
@@ -514,18 +521,48 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attn_bwd_mfma_kernel(
     float* __restrict__ partial) {
   __shared__ __attribute__((aligned(16))) float slab_all[WAVES][2][SLAB];
   __shared__ __attribute__((aligned(16))) float dt_all[WAVES][DT_FLOATS];
-  __shared__ __attribute__((aligned(16))) float w_lds[W_FLOATS];
+  __shared__ __attribute__((aligned(16))) float w_lds[BF3 ? 4 : W_FLOATS];
+  __shared__ __attribute__((aligned(16))) __bf16 wb_hi[BF3 ? WB_ELEMS : 8];
+  __shared__ __attribute__((aligned(16))) __bf16 wb_lo[BF3 ? WB_ELEMS : 8];
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, c = lane & 15;
   float* dt = dt_all[wid];
   for (int i = threadIdx.x; i < 64 * F; i += WAVES * 64) {
     const int n = i / F, f = i - n * F;
-    w_lds[n * W_LD + f] = Wk[i];
-    w_lds[(64 + n) * W_LD + f] = Wq[i];
-    w_lds[(128 + n) * W_LD + f] = Wv[i];
+    if constexpr (BF3) {
+      const float w3[3] = {Wk[i], Wq[i], Wv[i]};
+#pragma unroll
+      for (int p3 = 0; p3 < 3; ++p3) {
+        const __bf16 h = (__bf16)w3[p3];
+        wb_hi[(64 * p3 + n) * WB_LD + f] = h;
+        wb_lo[(64 * p3 + n) * WB_LD + f] = (__bf16)(w3[p3] - (float)h);
+      }
+    } else {
+      w_lds[n * W_LD + f] = Wk[i];
+      w_lds[(64 + n) * W_LD + f] = Wq[i];
+      w_lds[(128 + n) * W_LD + f] = Wv[i];
+    }
   }
   __syncthreads();
+  // split-bf16: B operands of d edge_attr = D W live in registers for the whole launch:
+  // lane (g, c) holds W[o = 32 s + 8 g .. + 7][f = 16 fb + c]  (o runs over [Wk; Wq; Wv] rows)
+  bf16x8 W2h[BF3 ? 6 : 1][2], W2l[BF3 ? 6 : 1][2];
+  if constexpr (BF3) {
+#pragma unroll
+    for (int sg = 0; sg < 6; ++sg)
+#pragma unroll
+      for (int fb = 0; fb < 2; ++fb) {
+        float w[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int o = 32 * sg + 8 * g + i;
+          const float* Wp = o < 64 ? Wk : (o < 128 ? Wq : Wv);
+          w[i] = Wp[(size_t)(o & 63) * F + 16 * fb + c];
+        }
+        split_bf16<8>(w, W2h[sg][fb], W2l[sg][fb]);
+      }
+  }
 
   float bk4[NB], bq4[NB], bv4[NB];
 #pragma unroll
@@ -568,6 +605,24 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attn_bwd_mfma_kernel(
     };
     fetch_node_rows(wave);
     float scale = 0.f;
+#if defined(SPT_BWD_DEFER_ATOMICS)
+    float pend_dk[NB][4], pend_dv[NB][4];
+    int64_t pend_row[4] = {-1, -1, -1, -1};
+    auto flush_pending = [&]() {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (pend_row[r] >= 0) {
+          float* row = gqkv + pend_row[r] + c;
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+            unsafeAtomicAdd(row + 64 + 16 * b, pend_dk[b][r]);
+            unsafeAtomicAdd(row + 128 + 16 * b, pend_dv[b][r]);
+          }
+          pend_row[r] = -1;
+        }
+      }
+    };
+#endif
     while (P.cur.valid) {
       wait_vmem_all();
       float qraw[NB];
@@ -575,6 +630,9 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attn_bwd_mfma_kernel(
       for (int b = 0; b < NB; ++b) qraw[b] = P.q_nxt[b];
       const int e_cur = P.e_cur, t_cur = P.t_cur;
       P.top(lane);
+#if defined(SPT_BWD_DEFER_ATOMICS)
+      flush_pending();
+#endif
       const Tile cur = P.cur;
       const float* slab = P.cur_buf();
       const float* kslab = slab + EA_FLOATS;
@@ -596,10 +654,41 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attn_bwd_mfma_kernel(
       }
       if (P.nxt.valid && P.nxt.t0 == P.nxt.start) fetch_node_rows(P.nxt.s);
       if (cnt > 0) {
-        float A[8];
-        load_a(slab, g, c, A);
         f32x4 Ck[NB], Cq[NB], Cv[NB];
-        rpe_gemm3_lds(A, w_lds, g, c, bk4, qs4, bv4, Ck, Cq, Cv);
+        if constexpr (BF3) {
+          bf16x8 Ah, Al;
+          load_a_bf(slab, g, c, Ah, Al);
+          const __bf16* wh = wb_hi + c * WB_LD + 8 * g;
+          const __bf16* wl = wb_lo + c * WB_LD + 8 * g;
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+            Ck[b] = (f32x4){bk4[b], bk4[b], bk4[b], bk4[b]};
+            Cq[b] = (f32x4){qs4[b], qs4[b], qs4[b], qs4[b]};
+            Cv[b] = (f32x4){bv4[b], bv4[b], bv4[b], bv4[b]};
+          }
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+            const bf16x8 kh = *reinterpret_cast<const bf16x8*>(wh + (16 * b) * WB_LD);
+            const bf16x8 kl = *reinterpret_cast<const bf16x8*>(wl + (16 * b) * WB_LD);
+            const bf16x8 qh = *reinterpret_cast<const bf16x8*>(wh + (64 + 16 * b) * WB_LD);
+            const bf16x8 ql = *reinterpret_cast<const bf16x8*>(wl + (64 + 16 * b) * WB_LD);
+            const bf16x8 vh = *reinterpret_cast<const bf16x8*>(wh + (128 + 16 * b) * WB_LD);
+            const bf16x8 vl = *reinterpret_cast<const bf16x8*>(wl + (128 + 16 * b) * WB_LD);
+            Ck[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, kh, Ck[b], 0, 0, 0);
+            Cq[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, qh, Cq[b], 0, 0, 0);
+            Cv[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, vh, Cv[b], 0, 0, 0);
+            Ck[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, kl, Ck[b], 0, 0, 0);
+            Cq[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, ql, Cq[b], 0, 0, 0);
+            Cv[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, vl, Cv[b], 0, 0, 0);
+            Ck[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, kh, Ck[b], 0, 0, 0);
+            Cq[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, qh, Cq[b], 0, 0, 0);
+            Cv[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, vh, Cv[b], 0, 0, 0);
+          }
+        } else {
+          float A[8];
+          load_a(slab, g, c, A);
+          rpe_gemm3_lds(A, w_lds, g, c, bk4, qs4, bv4, Ck, Cq, Cv);
+        }
         const float* kp = kslab + 4 * g * ROW + c;
         const float* vp = vslab + 4 * g * ROW + c;
         int64_t trow[4];
@@ -631,6 +720,20 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attn_bwd_mfma_kernel(
         // dk / dv go to the target rows.  One branch per edge row r (validity depends on
         // (g, r) only) instead of one per (b, r): the 16 iterations above stay one basic
         // block the scheduler can interleave.
+#if defined(SPT_BWD_DEFER_ATOMICS)
+        // hold this tile's dk / dv: their atomics are issued at the top of the NEXT iteration,
+        // right after that tile's loads, so that they drain under a whole tile of compute
+        // instead of being waited for by the next wait_vmem_all()
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          pend_row[r] = (4 * g + r < cnt) ? trow[r] : -1;
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+            pend_dk[b][r] = Ck[b][r];
+            pend_dv[b][r] = Cv[b][r];
+          }
+        }
+#elif !defined(SPT_BWD_NO_ATOMICS)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           if (4 * g + r < cnt) {
@@ -642,6 +745,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attn_bwd_mfma_kernel(
             }
           }
         }
+#endif
         // ---- d edge_attr = D W : D transposed through LDS (before dW: its stores and the
         //      atomics above then drain under the 96 MFMAs of the weight-gradient GEMM) ----
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -659,6 +763,24 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attn_bwd_mfma_kernel(
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         f32x4 C2[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+        if constexpr (BF3) {
+          // A[i = edge c][k = o = 32 s + 8 g .. + 7] out of the transposed tile, split on the fly
+          const float* arow = dt + c * DT_STRIDE + 8 * g;
+#pragma unroll
+          for (int sg = 0; sg < 6; ++sg) {
+            const float4 d0 = *reinterpret_cast<const float4*>(arow + 32 * sg);
+            const float4 d1 = *reinterpret_cast<const float4*>(arow + 32 * sg + 4);
+            const float dd[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+            bf16x8 dh, dl;
+            split_bf16<8>(dd, dh, dl);
+#pragma unroll
+            for (int fb = 0; fb < 2; ++fb) {
+              C2[fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dl, W2h[sg][fb], C2[fb], 0, 0, 0);
+              C2[fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dh, W2l[sg][fb], C2[fb], 0, 0, 0);
+              C2[fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dh, W2h[sg][fb], C2[fb], 0, 0, 0);
+            }
+          }
+        } else {
         const float* arow = dt + c * DT_STRIDE + g;       // A[i = edge c][k = 4 st + g]
         const float* brow = w_lds + g * W_LD + c;         // B[k = 4 st + g][j = 16 fb + c]
         // operands of the next 4 k-steps in flight under the 8 MFMAs of the current 4
@@ -692,15 +814,50 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attn_bwd_mfma_kernel(
             for (int u = 0; u < 4; ++u) { ac[u] = an[u]; b0c[u] = b0n[u]; b1c[u] = b1n[u]; }
           }
         }
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int64_t e = __shfl(e_cur, 4 * g + r, 64);
+#if !defined(SPT_BWD_NO_GEA_STORE)
           if (4 * g + r < cnt) {
             gea[e * F + c] = C2[0][r];
             gea[e * F + 16 + c] = C2[1][r];
           }
+#endif
         }
         // ---- dW += D^T EA : A operand = the C-layout registers as they are ----------
+        if constexpr (BF3) {
+          // contraction index = edge 4 g + r: the 4 registers of a block, packed, are the A
+          // operand of a 16x16x16 bf16 product; B = ea[edge 4 g + r][16 fb + c]
+          s16x4 Eh[2], El[2];
+#pragma unroll
+          for (int fb = 0; fb < 2; ++fb) {
+            float ev[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int e = 4 * g + r, f = 16 * fb + c;
+              ev[r] = slab[e * F + (((f >> 2) ^ (e & 7)) << 2) + (f & 3)];
+            }
+            bf16x4 eh, el;
+            split_bf16<4>(ev, eh, el);
+            Eh[fb] = __builtin_bit_cast(s16x4, eh);
+            El[fb] = __builtin_bit_cast(s16x4, el);
+          }
+#pragma unroll
+          for (int ob = 0; ob < 3 * NB; ++ob) {
+            const f32x4& Dsrc = ob < NB ? Ck[ob % NB] : (ob < 2 * NB ? Cq[ob % NB] : Cv[ob % NB]);
+            const float dv4[4] = {Dsrc[0], Dsrc[1], Dsrc[2], Dsrc[3]};
+            bf16x4 dh, dl;
+            split_bf16<4>(dv4, dh, dl);
+            const s16x4 Dh = __builtin_bit_cast(s16x4, dh), Dl = __builtin_bit_cast(s16x4, dl);
+#pragma unroll
+            for (int fb = 0; fb < 2; ++fb) {
+              C3[ob][fb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(Dl, Eh[fb], C3[ob][fb], 0, 0, 0);
+              C3[ob][fb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(Dh, El[fb], C3[ob][fb], 0, 0, 0);
+              C3[ob][fb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(Dh, Eh[fb], C3[ob][fb], 0, 0, 0);
+            }
+          }
+        } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float eb[2];
@@ -719,6 +876,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attn_bwd_mfma_kernel(
             }
           }
         }
+        }
       }
       if (cur.t0 + TE >= cur.end) {  // last tile of the node
 #pragma unroll
@@ -729,6 +887,9 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attn_bwd_mfma_kernel(
       }
       P.rotate();
     }
+#if defined(SPT_BWD_DEFER_ATOMICS)
+    flush_pending();
+#endif
   }
   // per-wave partial tables [192 rows][F + 1]: weight block + bias column
   if (partial) {
@@ -776,12 +937,18 @@ int attn_bwd_mfma_launch(const float* qkv, int64_t n, const int32_t* erowptr,
                          const float* Wk, const float* bk, const float* Wq, const float* bq,
                          const float* Wv, const float* bv, int scale_mode, float scale_a,
                          const float* out, const float* m, const float* z, const float* gout,
-                         float* gqkv, float* gea, float* partial, hipStream_t stream) {
+                         float* gqkv, float* gea, float* partial, int split_bf16,
+                         hipStream_t stream) {
   const int64_t blocks = ceil_div(n, mfma::WAVES);
   const int grid = (int)(blocks < ATTN_BWD_MFMA_BLOCKS ? blocks : ATTN_BWD_MFMA_BLOCKS);
-  mfma::attn_bwd_mfma_kernel<<<grid, mfma::WAVES * 64, 0, stream>>>(
-      qkv, 192, n, erowptr, eperm, tgt, ea, Wk, bk, Wq, bq, Wv, bv, scale_mode, scale_a, out, m, z,
-      gout, gqkv, gea, partial);
+  if (split_bf16)
+    mfma::attn_bwd_mfma_kernel<true><<<grid, mfma::WAVES * 64, 0, stream>>>(
+        qkv, 192, n, erowptr, eperm, tgt, ea, Wk, bk, Wq, bq, Wv, bv, scale_mode, scale_a, out, m,
+        z, gout, gqkv, gea, partial);
+  else
+    mfma::attn_bwd_mfma_kernel<false><<<grid, mfma::WAVES * 64, 0, stream>>>(
+        qkv, 192, n, erowptr, eperm, tgt, ea, Wk, bk, Wq, bq, Wv, bv, scale_mode, scale_a, out, m,
+        z, gout, gqkv, gea, partial);
   return grid * mfma::WAVES;  // number of partial tables written
 }
 

@@ -238,6 +238,59 @@ extern "C" int spt_point_geof_dense_f32(const float* xyz, int64_t n, const int64
   return 0;
 }
 
+// ---- scatter_pca (src/utils/scatter.py:41-125) as an entry of its own ----------------------
+// One lane per group of the CSR view (perm, rowptr): population covariance about the group's
+// first row (f64 moments, no cancellation), cyclic Jacobi, eigenvalues ascending and clamped at
+// 0 (scatter.py:123), eigenvectors in the columns of a row-major [3,3] block (the layout of
+// torch.linalg.eigh), an empty group -> (1,1,1) / identity (scatter.py:113-118: 0/0 = NaN).
+__global__ __launch_bounds__(256) void scatter_pca_kernel(
+    const float* __restrict__ x, const int32_t* __restrict__ perm,
+    const int32_t* __restrict__ rowptr, int64_t num_seg, float* __restrict__ eigenval,
+    float* __restrict__ eigenvec) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < num_seg; s += stride) {
+    const int lo = rowptr[s], hi = rowptr[s + 1];
+    double w[3] = {1.0, 1.0, 1.0};
+    double v[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    if (hi > lo) {
+      const int64_t o = perm ? perm[lo] : lo;
+      const double px = x[o * 3], py = x[o * 3 + 1], pz = x[o * 3 + 2];
+      double s1[3] = {0, 0, 0}, s2[6] = {0, 0, 0, 0, 0, 0};
+      int cnt = 0;
+      for (int j = lo; j < hi; ++j) accumulate(x, perm ? perm[j] : j, px, py, pz, s1, s2, cnt);
+      const double inv = 1.0 / (double)cnt;
+      const double mx = s1[0] * inv, my = s1[1] * inv, mz = s1[2] * inv;
+      double a[3][3];
+      a[0][0] = s2[0] * inv - mx * mx;
+      a[0][1] = a[1][0] = s2[1] * inv - mx * my;
+      a[0][2] = a[2][0] = s2[2] * inv - mx * mz;
+      a[1][1] = s2[3] * inv - my * my;
+      a[1][2] = a[2][1] = s2[4] * inv - my * mz;
+      a[2][2] = s2[5] * inv - mz * mz;
+      eigh3(a, w, v);
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) eigenval[s * 3 + q] = (float)(w[q] > 0.0 ? w[q] : 0.0);
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) eigenvec[s * 9 + r * 3 + q] = (float)v[r][q];
+  }
+}
+
+extern "C" int spt_scatter_pca_f32(const float* x, const int32_t* perm, const int32_t* rowptr,
+                                   int64_t num_seg, float* eigenval, float* eigenvec,
+                                   spt_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPT_CHECK_ARG(num_seg >= 0, "bad shape");
+  if (num_seg == 0) return 0;
+  SPT_CHECK_ARG(x && rowptr && eigenval && eigenvec, "null pointer");
+  scatter_pca_kernel<<<stream_grid(num_seg, 256), 256, 0, stream>>>(x, perm, rowptr, num_seg,
+                                                                   eigenval, eigenvec);
+  SPT_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int spt_point_geof_csr_f32(const float* xyz, int64_t n, const int64_t* nn_val,
                                       const int64_t* nn_ptr, int add_self, int k_min,
                                       int post, float* feats, spt_stream_t stream_) {

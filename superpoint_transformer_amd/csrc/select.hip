@@ -218,6 +218,64 @@ extern "C" int spt_select_edges(const int64_t* edge_index, int64_t num_edges, in
   return 0;
 }
 
+// ---- neighbors_dense_to_csr (src/utils/neighbors.py:668-684) ------------------------------
+// [n, k] neighbour table with negative = missing -> (ptr [n+1], val [nnz], sizes [n]):
+// per-row counts, one device scan, one emit pass that keeps each row's order.  The reference
+// does this with a boolean-mask gather (`nn[~mask]`: a scan + host sync inside torch).
+namespace {
+__global__ __launch_bounds__(256) void dense_count_kernel(const int64_t* __restrict__ nn, int64_t n,
+                                                          int k, uint32_t* __restrict__ cnt,
+                                                          int64_t* __restrict__ sizes) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += stride) {
+    uint32_t c = 0;
+    if (i < n) {
+      for (int j = 0; j < k; ++j) c += nn[i * k + j] >= 0 ? 1u : 0u;
+      sizes[i] = (int64_t)c;
+    }
+    cnt[i] = c;                                     // cnt[n] = 0: the scan leaves the total there
+  }
+}
+__global__ __launch_bounds__(256) void dense_emit_kernel(const int64_t* __restrict__ nn, int64_t n,
+                                                         int k, const uint32_t* __restrict__ off,
+                                                         int64_t* __restrict__ ptr,
+                                                         int64_t* __restrict__ val) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += stride) {
+    int64_t o = (int64_t)off[i];
+    ptr[i] = o;
+    if (i < n)
+      for (int j = 0; j < k; ++j) {
+        const int64_t v = nn[i * k + j];
+        if (v >= 0) val[o++] = v;
+      }
+  }
+}
+}  // namespace
+
+extern "C" size_t spt_neighbors_dense_to_csr_workspace_bytes(int64_t n) {
+  if (n < 0) return 0;
+  return align_up((size_t)(n + 1) * 4, 256) + scan_part_bytes(n + 1);
+}
+
+extern "C" int spt_neighbors_dense_to_csr(const int64_t* nn, int64_t n, int k, int64_t* ptr,
+                                          int64_t* val, int64_t* sizes, void* ws,
+                                          size_t ws_bytes, spt_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPT_CHECK_ARG(n >= 0 && k >= 0, "bad shape");
+  SPT_CHECK_ARG((int64_t)n * k < ((int64_t)1 << 32) - 2, "more than 2^32 entries");
+  SPT_CHECK_ARG(ptr && ws && ws_bytes >= spt_neighbors_dense_to_csr_workspace_bytes(n),
+                "null pointer / workspace too small");
+  SPT_CHECK_ARG(n == 0 || (sizes && (k == 0 || (nn && val))), "null pointer");
+  uint32_t* cnt = (uint32_t*)ws;
+  uint32_t* part = (uint32_t*)((char*)ws + align_up((size_t)(n + 1) * 4, 256));
+  dense_count_kernel<<<stream_grid(n + 1, 256), 256, 0, stream>>>(nn, n, k, cnt, sizes);
+  device_exclusive_scan(cnt, n + 1, part, stream);
+  dense_emit_kernel<<<stream_grid(n + 1, 256), 256, 0, stream>>>(nn, n, k, cnt, ptr, val);
+  SPT_CHECK_LAUNCH();
+  return 0;
+}
+
 namespace {
 struct ClusterPlan {
   size_t off_sizes, off_owner, off_present, off_tmp, off_part, total;

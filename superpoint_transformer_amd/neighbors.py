@@ -37,19 +37,28 @@ def _grid_for(search, r, K, cell_size=None, self_search=False):
     ext = [max(h - l, 1e-6) for l, h in zip(lo_h, hi_h)]
     n = search.shape[0]
     if cell_size is None:
+        # occupancy of the non-empty cells at two probe sizes (s1, s1/2) on a subsample gives the
+        # local dimension d of the cloud (2 = surfaces, 3 = volumetric scans, vegetation): the
+        # points per cell scale as s^d
+        import math
+        import os
         s1 = float(r) / 4
         m = min(n, 200_000)
         sub = search if m == n else search[torch.randint(0, n, (m,), device=search.device)]
-        d1 = [int(e / s1) + 1 for e in ext]
-        c = ((sub - lo) / s1).floor().long()
-        lin = (c[:, 2] * d1[1] + c[:, 1]) * d1[0] + c[:, 0]
-        occ = (m / max(int(torch.unique(lin).numel()), 1)) * (n / m)   # points per cell at s1
+
+        def occupancy(sz):
+            d1 = [int(e / sz) + 1 for e in ext]
+            c = ((sub - lo) / sz).floor().long()
+            lin = (c[:, 2] * d1[1] + c[:, 1]) * d1[0] + c[:, 0]
+            return (m / max(int(torch.unique(lin).numel()), 1)) * (n / m)
+
+        occ1, occ2 = occupancy(s1), occupancy(s1 / 2)
+        dim = min(max(math.log2(max(occ1 / max(occ2, 1e-9), 1.0 + 1e-6)), 1.0), 3.0)
         # self-search (shared candidate streams): the wave scans 5 x 9 cells per 64 queries, so
         # fewer points per cell than the wave-per-query kernel likes (SPT_KNN_OCC: tuning knob)
-        import os
         occ_k = float(os.environ.get("SPT_KNN_OCC", "0.75" if self_search else "1.5"))
         target = max(occ_k * K, 8.0)
-        s = s1 * (target / max(occ, 1e-3)) ** 0.5
+        s = s1 * (target / max(occ1, 1e-3)) ** (1.0 / dim)
         s = min(max(s, float(r) / 64), float(r))
     else:
         s = float(cell_size)
@@ -143,12 +152,25 @@ def knn_2(x_search, x_query, k, r_max=1, batch_search=None, batch_query=None, sq
 
 def neighbors_dense_to_csr(nn):
     """[N,k] with negative = missing -> (ptr [N+1], val [M], sizes [N])
-    (neighbors.py:668-684)."""
-    mask = nn < 0
-    sizes = nn.shape[1] - mask.sum(dim=1)
-    ptr = torch.zeros(nn.shape[0] + 1, dtype=torch.long, device=nn.device)
-    ptr[1:] = sizes.cumsum(0)
-    return ptr, nn[~mask], sizes
+    (neighbors.py:668-684): per-row counts, device scan, ordered emit (one kernel each).  The
+    one host sync reads M to size ``val`` - the reference's ``nn[~mask]`` syncs the same way."""
+    _lib.require_cuda(nn)
+    if nn.dim() != 2:
+        raise ValueError("nn must be [N, k]")
+    t = nn.long().contiguous()
+    n, k = t.shape
+    dev = t.device
+    ptr = torch.empty(n + 1, dtype=torch.long, device=dev)
+    val = torch.empty(max(n * k, 1), dtype=torch.long, device=dev)
+    sizes = torch.empty(n, dtype=torch.long, device=dev)
+    nb = _lib.lib.spt_neighbors_dense_to_csr_workspace_bytes(n)
+    ws = _workspace(nb, dev)
+    with torch.cuda.device(dev):
+        st = _lib.lib.spt_neighbors_dense_to_csr(_lib.ptr(t), n, k, _lib.ptr(ptr), _lib.ptr(val),
+                                                 _lib.ptr(sizes), _lib.ptr(ws), ws.numel(),
+                                                 _lib.stream_ptr(dev))
+    _lib.check(st, "spt_neighbors_dense_to_csr")
+    return ptr, val[:int(ptr[-1])], sizes
 
 
 _ORDER_MIN_POINTS = 200_000

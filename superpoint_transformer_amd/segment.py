@@ -90,6 +90,26 @@ def scatter_std(x, idx, num_segments=None):
     return out.view(-1) if squeeze else out
 
 
+def scatter_pca(x, idx, num_segments=None):
+    """Eigen-decomposition of every group's population covariance
+    (src/utils/scatter.py:41-125): returns ``(eigenval [S,3] ascending, clamped at 0,
+    eigenvec [S,3,3] with eigenvectors in columns)``; a group without rows gets (1,1,1) and
+    the identity like the reference's NaN rule.  ``x`` [N,3]; ``idx`` [N] int64 (unsorted)."""
+    _lib.require_cuda(x, idx)
+    if x.dim() != 2 or x.shape[1] != 3:
+        raise NotImplementedError("scatter_pca is built for 3-D points (the only use in the reference)")
+    csr = csr_of(idx, num_segments)
+    p = x.detach().float().contiguous()
+    val = torch.empty((csr.num_seg, 3), dtype=torch.float32, device=p.device)
+    vec = torch.empty((csr.num_seg, 3, 3), dtype=torch.float32, device=p.device)
+    with torch.cuda.device(p.device):
+        st = _lib.lib.spt_scatter_pca_f32(_lib.ptr(p), _lib.ptr(csr.perm), _lib.ptr(csr.rowptr),
+                                          csr.num_seg, _lib.ptr(val), _lib.ptr(vec),
+                                          _lib.stream_ptr(p.device))
+    _lib.check(st, "spt_scatter_pca_f32")
+    return val, vec
+
+
 def scatter_mean_orientation(orientation, idx, num_segments=None):
     """Mean orientation of the vectors of each segment, up to sign, expressed in the
     z+ half-space (scatter.py:249-300)."""

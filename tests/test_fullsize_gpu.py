@@ -27,9 +27,9 @@ def test_attention_two_formulations_agree_at_scene_scale(dev):
           torch.randn(64, device=dev, generator=g) * 0.1) for _ in range(3)]
     gw = torch.randn(n, 64, device=dev, generator=g)
     res = {}
-    prev = _lib.lib.spt_attn_use_mfma(1)
+    prev = _lib.lib.spt_attn_use_mfma(2)
     try:
-        for mode in (1, 0):
+        for mode in (2, 1, 0):   # split-bf16 matrix pipe (default), f32 matrix pipe, VALU
             _lib.lib.spt_attn_use_mfma(mode)
             q = qkv.clone().requires_grad_()
             a = ea.clone().requires_grad_()
@@ -39,13 +39,18 @@ def test_attention_two_formulations_agree_at_scene_scale(dev):
             res[mode] = (out.detach(), q.grad, a.grad, [w.grad for w, _ in ws], [b.grad for _, b in ws])
     finally:
         _lib.lib.spt_attn_use_mfma(prev)
-    m, v = res[1], res[0]
-    torch.testing.assert_close(m[0], v[0], rtol=1e-4, atol=1e-5)
-    torch.testing.assert_close(m[2], v[2], rtol=1e-3, atol=1e-5)               # d edge_attr
-    # dqkv: k/v columns are f32-atomic sums in both formulations
-    torch.testing.assert_close(m[1], v[1], rtol=1e-3, atol=2e-4)
-    for a_, b_ in zip(m[3] + m[4], v[3] + v[4]):                               # 7 M-term sums
-        assert ((a_ - b_).abs().max() / b_.abs().max().clamp(min=1e-3)).item() < 2e-4
+    v = res[0]
+    for mode in (2, 1):
+        m = res[mode]
+        torch.testing.assert_close(m[0], v[0], rtol=1e-4, atol=1e-5)
+        # d edge_attr = D W: the split-bf16 error is relative to sum |d||w| (~6e-6 of it), not
+        # to the (possibly cancelled) result: one entry in 225 M sits at 1.8e-5 absolute
+        torch.testing.assert_close(m[2], v[2], rtol=1e-3, atol=1e-5 if mode == 1 else 4e-5)
+        # dqkv: k/v columns are f32-atomic sums in every formulation
+        torch.testing.assert_close(m[1], v[1], rtol=1e-3, atol=2e-4)
+        for a_, b_ in zip(m[3] + m[4], v[3] + v[4]):                           # 7 M-term sums
+            assert ((a_ - b_).abs().max() / b_.abs().max().clamp(min=1e-3)).item() < 2e-4
+    m = res[2]
     # oracle spot check: 40 random nodes, their outgoing edges only
     pick = torch.randperm(n, generator=torch.Generator().manual_seed(1))[:40].to(dev)
     mask = torch.isin(s, pick)

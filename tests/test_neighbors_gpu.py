@@ -226,3 +226,55 @@ def test_visiting_order_does_not_change_the_features(dev):
     assert torch.equal(a, b) and torch.equal(a, c)
     pos2 = pos.clone()
     assert NB._recall_order(pos2) is None                       # the memo belongs to that tensor
+
+
+def test_neighbors_dense_to_csr_kernel_matches_reference_rule(dev):
+    """a10 (src/utils/neighbors.py:668-684): the product function (count / scan / emit
+    kernels) against the oracle restatement and the reference's own fixture."""
+    from superpoint_transformer_amd import neighbors as NB
+    g = torch.Generator().manual_seed(3)
+    nn = torch.randint(0, 5000, (3000, 17), generator=g)
+    nn[torch.rand(nn.shape, generator=g) < 0.35] = -1          # holes anywhere in a row
+    nn[7] = -1                                                 # an empty row
+    nn[11] = torch.arange(17)                                  # a full row
+    ptr, val, sizes = NB.neighbors_dense_to_csr(nn.to(dev))
+    rp, rv, rs = O.neighbors_dense_to_csr(nn)
+    assert torch.equal(ptr.cpu(), rp) and torch.equal(val.cpu(), rv) and torch.equal(sizes.cpu(), rs)
+    gold = load_golden("geometric_features.npz")               # written by the reference itself
+    full = torch.cat((torch.arange(gold["nn"].shape[0]).view(-1, 1), tl(gold["nn"])), dim=1)
+    ptr, val, sizes = NB.neighbors_dense_to_csr(full.to(dev))
+    assert torch.equal(ptr.cpu(), tl(gold["nn_ptr"]))
+    assert torch.equal(val.cpu(), tl(gold["nn_val"]))
+    assert torch.equal(sizes.cpu(), tl(gold["sizes"]))
+    e_ptr, e_val, e_sizes = NB.neighbors_dense_to_csr(torch.empty((0, 5), dtype=torch.long, device=dev))
+    assert e_ptr.tolist() == [0] and e_val.numel() == 0 and e_sizes.numel() == 0
+
+
+def test_scatter_pca_entry_matches_reference_fixture(dev):
+    """a12 (src/utils/scatter.py:41-125): eigenvalues against the reference's own
+    scatter_pca output (ascending, clamped at 0), eigenvectors against the f64 oracle up to
+    the sign of each column (eigh's sign is arbitrary), away from repeated eigenvalues; an
+    empty group yields (1,1,1) / identity."""
+    from superpoint_transformer_amd import segment as SG
+    gold = load_golden("geometric_features.npz")
+    xyz = torch.from_numpy(gold["xyz"]).float()
+    ptr, val = tl(gold["nn_ptr"]), tl(gold["nn_val"])
+    n = ptr.numel() - 1
+    gidx = torch.repeat_interleave(torch.arange(n), ptr[1:] - ptr[:-1])
+    pts = xyz[val]
+    # unsorted group index + two trailing empty groups
+    perm = torch.randperm(pts.shape[0], generator=torch.Generator().manual_seed(1))
+    ev, evec = SG.scatter_pca(pts[perm].to(dev), gidx[perm].to(dev), n + 2)
+    ev, evec = ev.cpu().double(), evec.cpu().double()
+    ref_ev = t64(gold["eigenval"])
+    assert ((ev[:n] - ref_ev).abs() / ref_ev.abs().max(dim=1, keepdim=True).values.clamp(min=1e-6)).max() < 1e-5
+    assert (ev[:n, 1:] >= ev[:n, :-1]).all() and (ev >= 0).all()
+    assert torch.equal(ev[n:], torch.ones(2, 3, dtype=torch.float64))
+    assert torch.equal(evec[n:], torch.eye(3, dtype=torch.float64).expand(2, 3, 3))
+    rv, rvec = O.scatter_pca(pts.double(), gidx, n)
+    gap_ok = ((rv[:, 1] - rv[:, 0]) > 1e-3 * rv[:, 2]) & ((rv[:, 2] - rv[:, 1]) > 1e-3 * rv[:, 2])
+    dots = (evec[:n] * rvec).sum(dim=1).abs()                  # |<column_i, ref column_i>|
+    assert (dots[gap_ok] > 1 - 1e-4).all()
+    # orthonormal columns everywhere
+    eye = torch.eye(3, dtype=torch.float64)
+    assert ((evec.transpose(1, 2) @ evec) - eye).abs().max() < 1e-5

@@ -11,13 +11,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from superpoint_transformer_amd import neighbors as NB
 from superpoint_transformer_amd.synthetic import SCENES, make_voxel_cloud
 
-CFG = {"S": (0.03, 45, 2.0), "D": (0.10, 25, 10.0)}
+CFG = {"S": (0.03, 45, 2.0), "D": (0.10, 25, 10.0), "V": (0.10, 25, 10.0)}   # V: dense volume
+GEOM = {"D": dict(patch=20.0, extent=(350.0, 350.0, 30.0))}
 scene = sys.argv[1] if len(sys.argv) > 1 else "S"
-n = int(sys.argv[2]) if len(sys.argv) > 2 and int(sys.argv[2]) > 0 else SCENES[scene][0]
+n = int(sys.argv[2]) if len(sys.argv) > 2 and int(sys.argv[2]) > 0 else SCENES["D" if scene == "V" else scene][0]
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 voxel, k, r = CFG[scene]
 dev = torch.device("cuda:0")
-pos = make_voxel_cloud(n, voxel=voxel, seed=4321, device=dev)
+pos = make_voxel_cloud(n, voxel=voxel, seed=4321, device=dev, **GEOM.get(scene, {}))
 for rep in range(reps + 1):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
