@@ -34,6 +34,11 @@ def parse():
     p.add_argument("--no-preprocess", action="store_true")
     p.add_argument("--cpu-scale", type=float, default=None)
     p.add_argument("--stages", default="all")
+    p.add_argument("--mode", default="train", choices=["train", "infer", "panoptic"],
+                   help="train: fwd+loss+bwd+AdamW (default, BASELINE cfg #2); infer: forward only "
+                        "(cfg #3, use --scene D); panoptic: + edge-affinity head and loss (cfg #5)")
+    p.add_argument("--model", default="spt64", choices=["spt64", "spt128"],
+                   help="spt128 = the KITTI-360 width (cfg #4)")
     return p.parse_args()
 
 
@@ -201,7 +206,7 @@ def main():
     from superpoint_transformer_amd.synthetic import SCENES, make_nag
 
     nag = make_nag(args.scene, seed=1234 + rank, device=dev)
-    path = hotpath.build(nag, dev, world=world, stages=args.stages)
+    path = hotpath.build(nag, dev, world=world, stages=args.stages, mode=args.mode, model=args.model)
 
     for _ in range(args.warmup):
         path.step()
@@ -231,7 +236,10 @@ def main():
 
     cpu = None
     pre = None
-    if rank == 0 and world == 1:
+    headline = args.mode == "train" and args.model == "spt64" and args.stages == "all"
+    if rank == 0 and world == 1 and not headline:
+        del path                      # other BASELINE configs: the GPU line only
+    elif rank == 0 and world == 1:
         del path
         torch.cuda.empty_cache()
         if not args.no_preprocess:
@@ -243,7 +251,8 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "Mpoints/s SPT fwd+bwd on S3DIS-scale NAG",
+            "metric": "Mpoints/s SPT fwd+bwd on S3DIS-scale NAG" if args.mode != "infer"
+            else "Mpoints/s SPT forward (inference) on a DALES-scale NAG",
             "value": round(value, 3),
             "unit": "Mpoints/s",
             "n_gpus": world,
@@ -260,6 +269,8 @@ def main():
                 "scene": args.scene,
                 "points_per_gpu": n0,
                 "parallelism": f"dp{world}",
+                "mode": args.mode,
+                "net": args.model,
             },
             "roofline": roof,
             "cpu_baseline": cpu,

@@ -415,6 +415,16 @@ int spt_horizontal_edge_features_f32(
     const float* normal, const float* log_length, const float* log_surface,
     const float* log_volume, const float* log_size, int add_self_loops,
     int64_t* edge_index_out, float* edge_attr_out, spt_stream_t stream);
+/* Symmetric edge features of the panoptic edge-affinity head (src/models/panoptic.py:477-480):
+ *   out[e] = cat(|x[a_e] - x[b_e]|, (x[a_e] + x[b_e]) / 2)   x [n,C], C % 4 == 0, out [e,2C].
+ * Backward: gend [2e, C], row e = gradient reaching x[a_e] through edge e, row e + E the one
+ * reaching x[b_e]; the caller sums them per node with spt_segcsr_reduce_f32 over cat(a, b). */
+int spt_edge_affinity_features_f32(const float* x, int64_t n, int C, const int64_t* edge_a,
+                                   const int64_t* edge_b, int64_t e, float* out,
+                                   spt_stream_t stream);
+int spt_edge_affinity_features_bwd_f32(const float* x, const float* gout, int64_t n, int C,
+                                       const int64_t* edge_a, const int64_t* edge_b, int64_t e,
+                                       float* gend, spt_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Tall-skinny Linear: y [rows, N] = x [rows, K] W[N, K]^T (+ bias [N] or NULL), f32 in /

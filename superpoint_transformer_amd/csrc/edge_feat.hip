@@ -81,9 +81,84 @@ __global__ __launch_bounds__(256) void edge_feat_kernel(
   }
 }
 
+// ---- symmetric edge features of the panoptic edge-affinity head ---------------------------
+// src/models/panoptic.py:477-480:  x_edge = x[obj_edge_index];
+//   out[e] = cat(|x[a_e] - x[b_e]|, (x[a_e] + x[b_e]) / 2)          [E, 2C]
+// One kernel instead of a [2, E, C] gather + sub / abs / add / mul / cat (5 passes over
+// [E, C]).  A lane group of C/4 lanes owns an edge: two 16-byte row reads, two row writes.
+__global__ __launch_bounds__(256) void edge_affinity_fwd_kernel(
+    const float* __restrict__ x, const int64_t* __restrict__ ea, const int64_t* __restrict__ eb,
+    int64_t E, int C, float* __restrict__ out) {
+  const int lpr = C >> 2;                       // lanes per edge
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < E * lpr; t += stride) {
+    const int64_t e = t / lpr;
+    const int k = (int)(t - e * lpr) << 2;
+    const float4 a = *reinterpret_cast<const float4*>(x + ea[e] * C + k);
+    const float4 b = *reinterpret_cast<const float4*>(x + eb[e] * C + k);
+    float* o = out + e * 2 * C + k;
+    *reinterpret_cast<float4*>(o) =
+        make_float4(fabsf(a.x - b.x), fabsf(a.y - b.y), fabsf(a.z - b.z), fabsf(a.w - b.w));
+    *reinterpret_cast<float4*>(o + C) = make_float4((a.x + b.x) / 2.f, (a.y + b.y) / 2.f,
+                                                    (a.z + b.z) / 2.f, (a.w + b.w) / 2.f);
+  }
+}
+
+// gend[e] = d loss / d x[a_e] through edge e, gend[E + e] = the same for x[b_e]:
+//   sign(x_a - x_b) * g_abs + g_mean / 2   and   -sign(x_a - x_b) * g_abs + g_mean / 2
+// (torch's abs backward: sign(0) = 0).  The per-node sums are a segment reduce over
+// cat(a, b) on the CSR kernels - deterministic, no atomics.
+__global__ __launch_bounds__(256) void edge_affinity_bwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ gout, const int64_t* __restrict__ ea,
+    const int64_t* __restrict__ eb, int64_t E, int C, float* __restrict__ gend) {
+  const int lpr = C >> 2;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < E * lpr; t += stride) {
+    const int64_t e = t / lpr;
+    const int k = (int)(t - e * lpr) << 2;
+    const float4 a = *reinterpret_cast<const float4*>(x + ea[e] * C + k);
+    const float4 b = *reinterpret_cast<const float4*>(x + eb[e] * C + k);
+    const float4 g1 = *reinterpret_cast<const float4*>(gout + e * 2 * C + k);
+    const float4 g2 = *reinterpret_cast<const float4*>(gout + e * 2 * C + C + k);
+    auto sgn = [](float d) { return d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f); };
+    const float4 s = make_float4(sgn(a.x - b.x), sgn(a.y - b.y), sgn(a.z - b.z), sgn(a.w - b.w));
+    *reinterpret_cast<float4*>(gend + e * C + k) = make_float4(
+        s.x * g1.x + g2.x / 2.f, s.y * g1.y + g2.y / 2.f, s.z * g1.z + g2.z / 2.f, s.w * g1.w + g2.w / 2.f);
+    *reinterpret_cast<float4*>(gend + (E + e) * C + k) = make_float4(
+        -s.x * g1.x + g2.x / 2.f, -s.y * g1.y + g2.y / 2.f, -s.z * g1.z + g2.z / 2.f, -s.w * g1.w + g2.w / 2.f);
+  }
+}
+
 }  // namespace spt
 
 using namespace spt;
+
+extern "C" int spt_edge_affinity_features_f32(const float* x, int64_t n, int C,
+                                              const int64_t* edge_a, const int64_t* edge_b,
+                                              int64_t e, float* out, spt_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPT_CHECK_ARG(n >= 0 && e >= 0 && C >= 4 && C % 4 == 0, "bad shape (C must be a multiple of 4)");
+  if (e == 0) return 0;
+  SPT_CHECK_ARG(x && edge_a && edge_b && out, "null pointer");
+  edge_affinity_fwd_kernel<<<stream_grid(e * (C / 4), 256), 256, 0, stream>>>(x, edge_a, edge_b, e,
+                                                                             C, out);
+  SPT_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int spt_edge_affinity_features_bwd_f32(const float* x, const float* gout, int64_t n,
+                                                  int C, const int64_t* edge_a,
+                                                  const int64_t* edge_b, int64_t e, float* gend,
+                                                  spt_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPT_CHECK_ARG(n >= 0 && e >= 0 && C >= 4 && C % 4 == 0, "bad shape (C must be a multiple of 4)");
+  if (e == 0) return 0;
+  SPT_CHECK_ARG(x && gout && edge_a && edge_b && gend, "null pointer");
+  edge_affinity_bwd_kernel<<<stream_grid(e * (C / 4), 256), 256, 0, stream>>>(x, gout, edge_a, edge_b,
+                                                                             e, C, gend);
+  SPT_CHECK_LAUNCH();
+  return 0;
+}
 
 extern "C" int spt_horizontal_edge_features_f32(
     const int64_t* se, int64_t e, int64_t n, const float* edge_attr7, const float* pos,

@@ -79,6 +79,44 @@ class SPTSegmenter(nn.Module):
         return [h(x) for h, x in zip(self.head, outs)]
 
 
+class SPTPanoptic(nn.Module):
+    """PanopticSegmentationModule.forward up to the partitioner (src/models/panoptic.py:443-492):
+    SPT backbone, one Classifier per output level, and the edge-affinity head
+    ``MLP([2 * up_dim, 32, 16, 1], norm=None, last_activation=False)`` of
+    configs/model/panoptic/_instance.yaml:21-28 on the symmetric edge features of
+    ``obj_edge_index``.  The point encoder is the panoptic configs' smaller one
+    (``_point_mlp: [32, 64, 64]``, _instance.yaml:16)."""
+
+    def __init__(self, **cfg):
+        super().__init__()
+        from .nn import MLP
+        self.net = SPT(**cfg)
+        dims = self.net.out_dim if isinstance(self.net.out_dim, list) else [self.net.out_dim]
+        self.head = nn.ModuleList([Classifier(d, NUM_CLASSES) for d in dims])
+        self.edge_affinity_head = MLP([2 * dims[0], 32, 16, 1], activation=nn.LeakyReLU(),
+                                      norm=None, last_norm=False, last_activation=False)
+
+    def forward(self, nag):
+        outs = self.net(nag)
+        outs = outs if isinstance(outs, list) else [outs]
+        logits = [h(x) for h, x in zip(self.head, outs)]
+        x_edge = ops.edge_affinity_features(outs[0], nag[1]["obj_edge_index"])   # panoptic.py:477-480
+        return logits, self.edge_affinity_head(x_edge).squeeze(-1)              # :481-483
+
+
+def panoptic_config(point_in=8, edge_in=18):
+    """spt-2 of configs/model/panoptic/spt-2.yaml: the semantic tree with the point encoder
+    of _instance.yaml:16 ([32, 64, 64]: pooled width 64)."""
+    cfg = spt64_config(point_in, edge_in)
+    inj = 3 + 1
+    cfg.update(point_mlp=[point_in + inj, 32, 64, 64], down_pool_dim=[64, 64],
+               down_in_mlp=[[inj + 64, 64, 64], [inj + 64, 64, 64]])
+    return cfg
+
+
+MODEL_CONFIGS = {"spt64": spt64_config, "spt128": spt128_config}
+
+
 class _NagView:
     """Minimal NAG-like view: ``nag[i]`` -> level dict, ``nag.num_clouds``."""
 
@@ -93,12 +131,15 @@ class _NagView:
 class SPTTrainStep:
     name = "SPT-64 (spt-2, S3DIS cfg) fwd + CE loss + bwd + AdamW, incl. per-batch CSR builds"
 
-    def __init__(self, nag, dev, world=1, seed=0):
+    def __init__(self, nag, dev, world=1, seed=0, model="spt64"):
         self.nag, self.dev, self.world = _NagView(nag), dev, world
         self.n = nag.num_points
         torch.manual_seed(seed)
-        self.model = SPTSegmenter(**spt64_config(nag[0]["x"].shape[1],
-                                                 nag[1]["edge_attr"].shape[1])).to(dev)
+        if model != "spt64":
+            self.name = self.name.replace("SPT-64 (spt-2, S3DIS cfg)",
+                                          "SPT-128 (spt-2 tree, KITTI-360 cfg: dim 128, FFN on)")
+        self.model = SPTSegmenter(**MODEL_CONFIGS[model](nag[0]["x"].shape[1],
+                                                         nag[1]["edge_attr"].shape[1])).to(dev)
         self.params = [p for p in self.model.parameters()]
         parallel.broadcast_parameters(self.params, src=0)
         self.bucket = parallel.FlatGradAllReduce(self.params)
@@ -136,11 +177,11 @@ class SPTTrainStep:
 
     def roofline(self, peak_gbs):
         n0, n1 = self.n[0], self.n[1]
-        c = 128
+        c = getattr(self, "pool_c", 128)
         bytes_ = n0 * (4 * c + 4) + n1 * (8 * c + 4)
         ms = ops.timer_mean_ms(self.tname)
         ach = bytes_ / (ms * 1e-3) / 1e9 if ms else None
-        return {"bound": "hbm", "kernel": "segcsr_reduce_kernel<MAX,VEC4,ARG> L0->L1 C=128 (in the train step: with the "
+        return {"bound": "hbm", "kernel": f"segcsr_reduce_kernel<MAX,VEC4,ARG> L0->L1 C={c} (in the train step: with the "
                           "point MLP's last GraphNorm + LeakyReLU applied on the fly)",
                 "achieved": round(ach, 1) if ach else None, "peak": peak_gbs,
                 "unit": "GB/s", "frac": round(ach / peak_gbs, 4) if ach else None,
@@ -153,6 +194,71 @@ class SPTTrainStep:
     def describe(self, scene, sizes):
         return f"{self.name}; synthetic NAG scene {scene} (N0,N1,N2,E1,E2,clouds)={sizes}"
 
+
+class SPTInferStep(SPTTrainStep):
+    """Config #3 (DALES tile inference): the forward pass alone under ``no_grad``, model in
+    eval mode, per-batch CSR builds included (src/models/semantic.py forward at test time)."""
+    name = "SPT-64 (spt-2) forward only (eval, no_grad), incl. per-batch CSR builds"
+
+    def __init__(self, nag, dev, world=1, seed=0, model="spt64"):
+        super().__init__(nag, dev, world, seed, model)
+        self.name = SPTInferStep.name if model == "spt64" else SPTInferStep.name.replace("SPT-64", "SPT-128")
+        self.model.eval()
+
+    def step(self):
+        self._forget_csr()
+        with torch.no_grad():
+            logits = self.model(self.nag)
+        self.last_loss = logits[0]
+        return logits
+
+
+class SPTPanopticStep(SPTTrainStep):
+    """Config #5 (SuperCluster panoptic training): backbone + semantic heads + edge-affinity
+    head; loss = multi-stage CE + BCE-with-logits on the affinities of ``obj_edge_index``
+    (src/models/panoptic.py:443-492, 1100-1160; the graph-cluster partitioner runs at
+    validation time only: partition_every_n_epoch, _instance.yaml:33-36)."""
+    name = ("SuperCluster panoptic (spt-2 + edge-affinity head) fwd + CE/BCE loss + bwd + AdamW, "
+            "incl. per-batch CSR builds")
+
+    def __init__(self, nag, dev, world=1, seed=0, model="spt64"):
+        self.nag, self.dev, self.world = _NagView(nag), dev, world
+        self.n = nag.num_points
+        torch.manual_seed(seed)
+        self.model = SPTPanoptic(**panoptic_config(nag[0]["x"].shape[1],
+                                                   nag[1]["edge_attr"].shape[1])).to(dev)
+        # obj_edge_index = the trimmed (i < j) level-1 graph (src/transforms/instance.py:164,199)
+        ei = nag[1]["edge_index"]
+        self.nag.levels[1]["obj_edge_index"] = ei[:, ei[0] < ei[1]].contiguous()
+        self.params = [p for p in self.model.parameters()]
+        parallel.broadcast_parameters(self.params, src=0)
+        self.bucket = parallel.FlatGradAllReduce(self.params)
+        self.opt = torch.optim.AdamW(self.params, lr=1e-3, weight_decay=1e-4,
+                                     fused=dev.type == "cuda")
+        g = torch.Generator(device=dev).manual_seed(5)
+        self.labels = [torch.randint(0, NUM_CLASSES, (self.n[i],), device=dev, generator=g)
+                       for i in (1, 2)]
+        ne = self.nag.levels[1]["obj_edge_index"].shape[1]
+        self.affinity = (torch.rand(ne, device=dev, generator=g) < 0.5).float()
+        self.lambdas = [1.0, 50.0]
+        self.loss_fn = nn.CrossEntropyLoss()
+        self.bce = nn.BCEWithLogitsLoss()
+        self.pool_c = 64
+        self.tname = f"segcsr_reduce_fwd:3:{self.n[0]}x64"
+        ops.enable_timer(self.tname)
+        self.last_loss = None
+
+    def step(self):
+        self._forget_csr()
+        logits, aff = self.model(self.nag)
+        loss = sum(l * self.loss_fn(lg, y) for l, lg, y in zip(self.lambdas, logits, self.labels))
+        loss = loss + self.bce(aff, self.affinity)          # edge_affinity_loss_lambda: 1
+        self.bucket.zero()
+        loss.backward()
+        self.bucket.reduce()
+        self.opt.step()
+        self.last_loss = loss
+        return loss
 
 class ScatterChain:
     name = "segment-CSR scatter chain (CSR build + max-pool fwd/bwd over L0->L1->L2 + unpool fwd/bwd)"
@@ -191,7 +297,11 @@ class ScatterChain:
         return f"{self.name}; scene {scene} {sizes}"
 
 
-def build(nag, dev, world=1, stages="all"):
+def build(nag, dev, world=1, stages="all", mode="train", model="spt64"):
     if stages == "scatter":
         return ScatterChain(nag, dev, world)
-    return SPTTrainStep(nag, dev, world)
+    if mode == "infer":
+        return SPTInferStep(nag, dev, world, model=model)
+    if mode == "panoptic":
+        return SPTPanopticStep(nag, dev, world, model=model)
+    return SPTTrainStep(nag, dev, world, model=model)

@@ -42,18 +42,33 @@ def _grid_for(search, r, K, cell_size=None, self_search=False):
         # points per cell scale as s^d
         import math
         import os
-        s1 = float(r) / 4
-        m = min(n, 200_000)
-        sub = search if m == n else search[torch.randint(0, n, (m,), device=search.device)]
+        # probe on a SPATIALLY COHERENT subsample (whole coarse cells of size r, ~2 M points):
+        # the counts per fine cell are then exact, which a random subsample cannot give at the
+        # scale of the target cell (a few dozen points)
+        if n > 2_000_000:
+            cc = ((search - lo) / float(r)).floor().long()
+            key0 = (cc[:, 0] * 73856093) ^ (cc[:, 1] * 19349663) ^ (cc[:, 2] * 83492791)
+            keep = (key0 & 0xFFFF) < int(65536 * 2_000_000 / n)
+            sub = search[keep]
+            if sub.shape[0] < 1000:
+                sub = search
+        else:
+            sub = search
+        m = sub.shape[0]
 
-        def occupancy(sz):
+        def per_cell(sz):
             d1 = [int(e / sz) + 1 for e in ext]
             c = ((sub - lo) / sz).floor().long()
             lin = (c[:, 2] * d1[1] + c[:, 1]) * d1[0] + c[:, 0]
-            return (m / max(int(torch.unique(lin).numel()), 1)) * (n / m)
+            return m / max(int(torch.unique(lin).numel()), 1)
 
-        occ1, occ2 = occupancy(s1), occupancy(s1 / 2)
-        dim = min(max(math.log2(max(occ1 / max(occ2, 1e-9), 1.0 + 1e-6)), 1.0), 3.0)
+        # first guess from a coarse probe assuming surfaces, then the local dimension and the
+        # occupancy measured AT that guess (stacked surfaces look volumetric from afar)
+        s0 = float(r) / 4
+        s1 = min(max(s0 * (max(K, 8.0) / max(per_cell(s0), 1e-3)) ** 0.5, float(r) / 64), float(r))
+        o1, o2 = per_cell(s1), per_cell(2 * s1)
+        occ1 = o1
+        dim = min(max(math.log2(max(o2 / max(o1, 1e-9), 1.0 + 1e-6)), 1.0), 3.0)
         # self-search (shared candidate streams): the wave scans 5 x 9 cells per 64 queries, so
         # fewer points per cell than the wave-per-query kernel likes (SPT_KNN_OCC: tuning knob)
         occ_k = float(os.environ.get("SPT_KNN_OCC", "0.75" if self_search else "1.5"))

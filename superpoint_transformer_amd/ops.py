@@ -167,6 +167,48 @@ def gather_rows(x, idx):
     return _GatherRows.apply(x, idx, idx)
 
 
+class _EdgeAffinityFeatures(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, edge_index):
+        _lib.require_cuda(x, edge_index)
+        xc = x.detach().float().contiguous()
+        ei = edge_index.long().contiguous()
+        n, c = xc.shape
+        e = ei.shape[1]
+        out = torch.empty((e, 2 * c), dtype=torch.float32, device=xc.device)
+        with torch.cuda.device(xc.device):
+            st = _lib.lib.spt_edge_affinity_features_f32(
+                _lib.ptr(xc), n, c, _lib.ptr(ei[0]), _lib.ptr(ei[1]), e, _lib.ptr(out),
+                _lib.stream_ptr(xc.device))
+        _lib.check(st, "spt_edge_affinity_features_f32")
+        ctx.save_for_backward(xc, ei)
+        ctx.in_dtype = x.dtype
+        return out.to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, gout):
+        xc, ei = ctx.saved_tensors
+        n, c = xc.shape
+        e = ei.shape[1]
+        g = gout.float().contiguous()
+        gend = torch.empty((2 * e, c), dtype=torch.float32, device=xc.device)
+        with torch.cuda.device(xc.device):
+            st = _lib.lib.spt_edge_affinity_features_bwd_f32(
+                _lib.ptr(xc), _lib.ptr(g), n, c, _lib.ptr(ei[0]), _lib.ptr(ei[1]), e,
+                _lib.ptr(gend), _lib.stream_ptr(xc.device))
+        _lib.check(st, "spt_edge_affinity_features_bwd_f32")
+        # per-node sums over both endpoint lists: one CSR segment reduce (memoised on the
+        # edge_index tensor's flattened view for the lifetime of the batch)
+        gx, _ = _seg_reduce_fwd(gend, csr_of(ei.reshape(-1), n), 0, False)
+        return gx.to(ctx.in_dtype), None
+
+
+def edge_affinity_features(x, edge_index):
+    """``cat(|x[a] - x[b]|, (x[a] + x[b]) / 2)`` for the edges ``(a, b) = edge_index``
+    (src/models/panoptic.py:477-480), one fused pass each way."""
+    return _EdgeAffinityFeatures.apply(x, edge_index)
+
+
 def segment_sum_i64(x, index, num_seg=None):
     """Bit-exact int64 segment sum (NAG.get_sub_size chain)."""
     _lib.require_cuda(x)

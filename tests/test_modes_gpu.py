@@ -1,0 +1,123 @@
+"""The other BASELINE configs' paths: panoptic edge-affinity head (cfg #5,
+src/models/panoptic.py:477-483) and forward-only inference (cfg #3), model level.
+
+Edge features: |a - b| and (a + b) / 2 are single f32 operations - bit-exact against
+torch on the same device values; gradients (signs, halves, per-node sums) within f32
+summation error of the f64 evaluation.  Panoptic model: same bars as
+tests/test_model_gpu.py against the f64 oracle of the backbone + plain torch f64 for the head."""
+import copy
+
+import pytest
+import torch
+
+from oracle import spt_model as OM
+
+pytestmark = pytest.mark.gpu
+
+
+def test_edge_affinity_features_forward_backward(dev):
+    from superpoint_transformer_amd import ops
+    g = torch.Generator().manual_seed(2)
+    n, c, e = 700, 64, 5000
+    x = torch.randn(n, c, generator=g)
+    x[5] = x[9]                                        # exact ties: sign(0) = 0 in the backward
+    ei = torch.randint(0, n, (2, e), generator=g)
+    ei[:, 0] = torch.tensor([5, 9])
+    gw = torch.randn(e, 2 * c, generator=g)
+    xd = x.to(dev).requires_grad_()
+    out = ops.edge_affinity_features(xd, ei.to(dev))
+    (out * gw.to(dev)).sum().backward()
+    x64 = x.double().requires_grad_()
+    xe = x64[ei]
+    ref = torch.cat(((xe[0] - xe[1]).abs(), (xe[0] + xe[1]) / 2), dim=1)
+    (ref * gw.double()).sum().backward()
+    assert torch.equal(out.detach().cpu(), ref.detach().float())      # one rounding each
+    err = (xd.grad.cpu().double() - x64.grad).abs().max() / x64.grad.abs().max()
+    assert err < 1e-6
+    empty = ops.edge_affinity_features(xd, torch.empty((2, 0), dtype=torch.long, device=dev))
+    assert empty.shape == (0, 2 * c)
+
+
+def _panoptic_case(dev):
+    from superpoint_transformer_amd import hotpath
+    from superpoint_transformer_amd.synthetic import make_nag
+    nag = make_nag("R", seed=31, device="cpu", sizes=(20000, 600, 250, 9000, 7000, 2))
+    levels = nag.levels
+    ei = levels[1]["edge_index"]
+    levels[1]["obj_edge_index"] = ei[:, ei[0] < ei[1]].contiguous()
+    torch.manual_seed(4)
+    model = hotpath.SPTPanoptic(**hotpath.panoptic_config(levels[0]["x"].shape[1],
+                                                          levels[1]["edge_attr"].shape[1]))
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    return model, levels
+
+
+def test_panoptic_model_matches_oracle(dev):
+    model, levels = _panoptic_case(dev)
+    n = [lv["pos"].shape[0] for lv in levels]
+    g = torch.Generator().manual_seed(1)
+    labels = [torch.randint(0, 13, (n[i],), generator=g) for i in (1, 2)]
+    oe = levels[1]["obj_edge_index"]
+    aff = (torch.rand(oe.shape[1], generator=g) < 0.5).float()
+    ce, bce = torch.nn.CrossEntropyLoss(), torch.nn.BCEWithLogitsLoss()
+
+    ref = copy.deepcopy(model).double()
+    outs = OM.spt_forward(ref.net, levels, dtype=torch.float64, keep_graph=True)
+    rl = [h(x) for h, x in zip(ref.head, outs)]
+    xe = outs[0][oe]
+    xedge = torch.cat(((xe[0] - xe[1]).abs(), (xe[0] + xe[1]) / 2), dim=1)
+    h = xedge
+    for layer in ref.edge_affinity_head.mlp:            # Linear / LeakyReLU stack, norm=None
+        h = layer(h)
+    raff = h.squeeze(-1)
+    rloss = sum(l * ce(lg, y) for l, lg, y in zip((1.0, 50.0), rl, labels)) + bce(raff, aff.double())
+    rloss.backward()
+
+    class View:
+        num_clouds = 2
+
+        def __init__(self, lv):
+            self.levels = lv
+
+        def __getitem__(self, i):
+            return self.levels[i]
+
+    dl = [{k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in lv.items()} for lv in levels]
+    gm = model.to(dev)
+    logits, gaff = gm(View(dl))
+    loss = sum(l * ce(lg, y.to(dev)) for l, lg, y in zip((1.0, 50.0), logits, labels)) + \
+        bce(gaff, aff.to(dev))
+    loss.backward()
+    for a, r in zip(logits + [gaff], rl + [raff]):
+        a, r = a.detach().cpu().double(), r.detach()
+        assert ((a - r).abs() - 1e-3 * r.abs()).max().item() <= 2e-4
+    assert abs(loss.item() - rloss.item()) <= 1e-4 * abs(rloss.item())
+    rg = dict(ref.named_parameters())
+    for k, p in gm.named_parameters():
+        if k.startswith("net.first_stage."):
+            continue                                   # arg-max flips: covered in test_model_gpu
+        r = rg[k].grad
+        err = ((p.grad.detach().cpu().double() - r).abs().max() / r.abs().max().clamp(min=1e-2)).item()
+        assert err <= 2e-3, f"{k}: {err:.3e}"
+
+
+def test_inference_step_reproduces_the_training_forward(dev):
+    """cfg #3: eval + no_grad forward = the logits of the training-mode forward, bit for bit
+    (same kernels, nothing saved for a backward), on a 2-cloud batch."""
+    from superpoint_transformer_amd import hotpath
+    from superpoint_transformer_amd.synthetic import make_nag
+    nag = make_nag("R", seed=8, device=dev, sizes=(30000, 900, 350, 14000, 10000, 2))
+    step = hotpath.build(nag, dev, mode="infer")
+    logits = step.step()
+    train_logits = step.model.train()(step.nag)
+    for a, b in zip(logits, train_logits):
+        assert not a.requires_grad and b.requires_grad
+        assert torch.equal(a, b.detach())
+    # and the panoptic / SPT-128 steps run end to end
+    for kw in (dict(mode="panoptic"), dict(mode="train", model="spt128")):
+        st = hotpath.build(nag, dev, **kw)
+        l0 = float(st.step())
+        l1 = float(st.step())
+        assert l0 == l0 and l1 == l1 and l1 != l0       # finite, parameters moved
