@@ -479,6 +479,12 @@ int spt_graphnorm_bwd_tables_f32(const double* total, int num_graphs, int d, con
  *   accumulate); prev_total [2K+1] = statistics for the previous GraphNorm's backward.
  * ---------------------------------------------------------------------- */
 int spt_fused_linear_supported(int K, int N);
+/* Matrix pipe of the fused layers' GEMMs.  0: f32 in / f32 accumulate everywhere (bitwise an
+ * fmaf chain).  1 (default): the backward GEMMs (gW, gx) on the bf16 pipe with split operands
+ * (each f32 product = hi*hi + lo*hi + hi*lo of bf16 halves, f32 accumulate, ~10 ulp of f32 -
+ * a tenth of the gradients' parity bar); the forward stays exact f32 (its outputs feed
+ * GraphNorm statistics, bar 2e-5).  2: forward too.  Returns the previous setting. */
+int spt_fused_linear_use_split_bf16(int mode);
 size_t spt_fused_linear_workspace_bytes(int K, int N);
 int spt_fused_linear_fwd_f32(const float* x, int64_t r0, int64_t r1, int K, const float* W,
                              int N, const float* pre_am, const float* pre_scale,

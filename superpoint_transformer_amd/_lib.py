@@ -69,6 +69,7 @@ SIGNATURES = {
     "spt_graphnorm_bwd_tables_f32": (_int, [_p, _int, _int, _p, _p, _p, _p, _p, _p, _p, _p, _p,
                                             _p, _p]),
     "spt_fused_linear_supported": (_int, [_int, _int]),
+    "spt_fused_linear_use_split_bf16": (_int, [_int]),
     "spt_fused_linear_workspace_bytes": (_sz, [_int, _int]),
     "spt_fused_linear_fwd_f32": (_int, [_p, _i64, _i64, _int, _p, _int, _p, _p, _p, _f32, _p, _p,
                                         _p, _sz, _p]),

@@ -413,6 +413,334 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_kernel(
   }
 }
 
+// =====================================================================================
+// Split-bf16 variants.  x = hi + lo with hi = bf16(x), lo = bf16(x - hi)  (|x - hi - lo| <=
+// 2^-18 |x|); an f32 product a*b is taken as a_hi b_hi + a_lo b_hi + a_hi b_lo on the bf16
+// matrix pipe (16x the f32 pipe's rate; bf16 x bf16 is exact in f32, f32 accumulate), a
+// relative error of <= ~3 * 2^-18 per product - the same class as a different summation
+// order of an f32 GEMM (tests/test_fused_mlp_gpu.py bars unchanged).  The layers are
+// HBM-bound once the matrix pipe time is gone; what remains per tile is the staging.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+template <int NV, typename V>
+__device__ __forceinline__ void split_bf16(const float (&x)[NV], V& hi, V& lo) {
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const __bf16 h = (__bf16)x[i];
+    hi[i] = h;
+    lo[i] = (__bf16)(x[i] - (float)h);
+  }
+}
+__device__ __forceinline__ f32x4 mfma3_32(const bf16x8& ah, const bf16x8& al, const bf16x8& bh,
+                                          const bf16x8& bl, f32x4 c) {
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma3_16(const bf16x4& ah, const bf16x4& al, const bf16x4& bh,
+                                          const bf16x4& bl, f32x4 c) {
+  const s16x4 AH = __builtin_bit_cast(s16x4, ah), AL = __builtin_bit_cast(s16x4, al);
+  const s16x4 BH = __builtin_bit_cast(s16x4, bh), BL = __builtin_bit_cast(s16x4, bl);
+  c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(AL, BH, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(AH, BL, c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(AH, BH, c, 0, 0, 0);
+}
+
+// ---- forward: K padded to KS steps of 32, the weight block W[n][k] as split bf16 B operands
+// (lane (g, c): W[16 nb + c][32 ks + 8 g .. + 7]) resident for the whole launch -----------
+template <int K4, int NBK>
+__global__ __launch_bounds__(WAVES * 64, 2) void fwd_kernel_bf(
+    const float* __restrict__ x, int64_t r0, int64_t r1, int K, const float* __restrict__ W,
+    const float* __restrict__ am, const float* __restrict__ sc, const float* __restrict__ bs,
+    float slope, float* __restrict__ h, double* __restrict__ partial) {
+  constexpr int KP = K4 * 4, KS = (KP + 31) / 32, KP32 = KS * 32, LDA = KP32 + 4, N = NBK * 16;
+  __shared__ __attribute__((aligned(16))) float a_lds[WAVES][TR * LDA];
+  __shared__ __attribute__((aligned(16))) float tab[3 * KP32];
+  __shared__ double red[WAVES][2 * N];
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, c = lane & 15;
+  float* al = a_lds[wid];
+  const bool pre = am != nullptr;
+  load_table(tab, am, K, KP32);
+  load_table(tab + KP32, sc, K, KP32);
+  load_table(tab + 2 * KP32, bs, K, KP32);
+  for (int i = lane; i < TR * LDA; i += 64) al[i] = 0.f;   // padding columns stay zero
+  __syncthreads();
+
+  bf16x8 Bh[NBK][KS], Bl[NBK][KS];
+#pragma unroll
+  for (int nb = 0; nb < NBK; ++nb)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      float w[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int k = 32 * ks + 8 * g + i;
+        w[i] = (k < K) ? W[(size_t)(16 * nb + c) * K + k] : 0.f;
+      }
+      split_bf16<8>(w, Bh[nb][ks], Bl[nb][ks]);
+    }
+  double s1[NBK], s2[NBK];
+#pragma unroll
+  for (int nb = 0; nb < NBK; ++nb) s1[nb] = s2[nb] = 0.0;
+
+  const int64_t ntiles = (r1 - r0 + TR - 1) / TR;
+  const int64_t wave = (int64_t)blockIdx.x * WAVES + wid;
+  const int64_t nwaves = (int64_t)gridDim.x * WAVES;
+  for (int64_t t = wave; t < ntiles; t += nwaves) {
+    const int64_t row0 = r0 + t * TR;
+    const int cnt = (int)((r1 - row0) < TR ? (r1 - row0) : TR);
+    wave_sync_lds();
+    stage_tile<KP32, LDA, KP32>(x, row0, cnt, K, pre, tab, slope, al, nullptr, lane);
+    wave_sync_lds();
+    f32x4 C[NBK];
+#pragma unroll
+    for (int nb = 0; nb < NBK; ++nb) C[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const float4 a0 = *reinterpret_cast<const float4*>(al + c * LDA + 32 * ks + 8 * g);
+      const float4 a1 = *reinterpret_cast<const float4*>(al + c * LDA + 32 * ks + 8 * g + 4);
+      const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+      bf16x8 ah, alo;
+      split_bf16<8>(av, ah, alo);
+#pragma unroll
+      for (int nb = 0; nb < NBK; ++nb) C[nb] = mfma3_32(ah, alo, Bh[nb][ks], Bl[nb][ks], C[nb]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int rr = 4 * g + r;
+      if (rr < cnt) {
+        float* hr = h + (row0 + rr) * N + c;
+#pragma unroll
+        for (int nb = 0; nb < NBK; ++nb) {
+          const float v = C[nb][r];
+          hr[16 * nb] = v;
+          s1[nb] += (double)v;
+          s2[nb] += (double)v * (double)v;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int nb = 0; nb < NBK; ++nb) {
+    const double a = xg_sum_d(s1[nb]), b = xg_sum_d(s2[nb]);
+    if (g == 0) {
+      red[wid][nb * 16 + c] = a;
+      red[wid][N + nb * 16 + c] = b;
+    }
+  }
+  __syncthreads();
+  double* out = partial + (size_t)blockIdx.x * (2 * N + 1);
+  for (int i = threadIdx.x; i < 2 * N; i += WAVES * 64)
+    out[i] = ((red[0][i] + red[1][i]) + red[2][i]) + red[3][i];
+  if (threadIdx.x == 0) out[2 * N] = (blockIdx.x == 0) ? (double)(r1 - r0) : 0.0;
+}
+
+// ---- backward: gW += gh^T y_prev as 16x16x16 products (contraction = the 16 rows of the
+// tile: the 4 rows a lane group holds are one packed operand), gx = gh W as 16x16x32
+// products with W^T as split bf16 rows in LDS (wt[k][n], n contiguous: lane (g, c) reads the 8
+// values W[32 s + 8 g .. + 7][16 kb + c] with one 16-byte read each for hi and lo) ---------
+template <int K4, int NBK, bool NEED_GX, int NW>
+__global__ __launch_bounds__(NW * 64, NW / 4) void bwd_kernel_bf(
+    const float* __restrict__ gy, const float* __restrict__ h, int64_t r0, int64_t r1,
+    const float* __restrict__ am, const float* __restrict__ sc, const float* __restrict__ bs,
+    float slope, const float* __restrict__ c1, const float* __restrict__ c2,
+    const float* __restrict__ c3, const float* __restrict__ xprev, int K,
+    const float* __restrict__ pam, const float* __restrict__ psc, const float* __restrict__ pbs,
+    float pslope, const float* __restrict__ W, float* __restrict__ gx,
+    float* __restrict__ gw_partial, double* __restrict__ pstat_partial) {
+  constexpr int KP = K4 * 4, KB = (KP + 15) / 16, KPP = KB * 16, N = NBK * 16;
+  constexpr int NS = (N + 31) / 32, NP32 = NS * 32;
+  constexpr int LDG = NP32 + 4, LDX = KPP + 4, LDT = NP32 + 8;
+  __shared__ __attribute__((aligned(16))) float g_lds[NW][TR * LDG];   // gh tile
+  __shared__ __attribute__((aligned(16))) float x_lds[NW][TR * LDX];   // RAW h_prev tile
+  __shared__ __attribute__((aligned(16))) __bf16 wt_hi[NEED_GX ? KPP * LDT : 8];
+  __shared__ __attribute__((aligned(16))) __bf16 wt_lo[NEED_GX ? KPP * LDT : 8];
+  __shared__ __attribute__((aligned(16))) float gt[6 * N];      // am | sc | bs | c1 | c2 | c3
+  __shared__ __attribute__((aligned(16))) float pt[3 * KPP];    // previous norm: am | sc | bs
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, c = lane & 15;
+  float* gl = g_lds[wid];
+  float* xl = x_lds[wid];
+  const bool pre = pam != nullptr;
+  if constexpr (NEED_GX) {
+    for (int i = threadIdx.x; i < KPP * NP32; i += NW * 64) {
+      const int k = i / NP32, n = i - k * NP32;
+      const float w = (k < K && n < N) ? W[(size_t)n * K + k] : 0.f;
+      const __bf16 hh = (__bf16)w;
+      wt_hi[k * LDT + n] = hh;
+      wt_lo[k * LDT + n] = (__bf16)(w - (float)hh);
+    }
+  }
+  load_table(gt, am, N, N);
+  load_table(gt + N, sc, N, N);
+  load_table(gt + 2 * N, bs, N, N);
+  load_table(gt + 3 * N, c1, N, N);
+  load_table(gt + 4 * N, c2, N, N);
+  load_table(gt + 5 * N, c3, N, N);
+  load_table(pt, pam, K, KPP);
+  load_table(pt + KPP, psc, K, KPP);
+  load_table(pt + 2 * KPP, pbs, K, KPP);
+  for (int i = lane; i < TR * LDX; i += 64) xl[i] = 0.f;
+  for (int i = lane; i < TR * LDG; i += 64) gl[i] = 0.f;     // columns [N, NP32) stay zero
+  __syncthreads();
+
+  f32x4 C3[NBK][KB];       // C3[nb][kb][r] = gW[16 nb + 4 g + r][16 kb + c]
+#pragma unroll
+  for (int nb = 0; nb < NBK; ++nb)
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) C3[nb][kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  double p1[KB], p2[KB];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) p1[kb] = p2[kb] = 0.0;
+
+  const int64_t ntiles = (r1 - r0 + TR - 1) / TR;
+  const int64_t wave = (int64_t)blockIdx.x * NW + wid;
+  const int64_t nwaves = (int64_t)gridDim.x * NW;
+  for (int64_t t = wave; t < ntiles; t += nwaves) {
+    const int64_t row0 = r0 + t * TR;
+    const int cnt = (int)((r1 - row0) < TR ? (r1 - row0) : TR);
+    wave_sync_lds();
+    {
+      constexpr int CH = N / 4;
+      for (int q = lane; q < TR * CH; q += 64) {
+        const int rr = q / CH, n = (q - rr * CH) << 2;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rr < cnt) {
+          const float4 hv = *reinterpret_cast<const float4*>(h + (row0 + rr) * N + n);
+          const float4 gv = *reinterpret_cast<const float4*>(gy + (row0 + rr) * N + n);
+          const float4 a = *reinterpret_cast<const float4*>(gt + n);
+          const float4 sc4 = *reinterpret_cast<const float4*>(gt + N + n);
+          const float4 b4 = *reinterpret_cast<const float4*>(gt + 2 * N + n);
+          const float4 k1 = *reinterpret_cast<const float4*>(gt + 3 * N + n);
+          const float4 k2 = *reinterpret_cast<const float4*>(gt + 4 * N + n);
+          const float4 k3 = *reinterpret_cast<const float4*>(gt + 5 * N + n);
+          const float hh[4] = {hv.x, hv.y, hv.z, hv.w}, gg4[4] = {gv.x, gv.y, gv.z, gv.w};
+          const float aa[4] = {a.x, a.y, a.z, a.w}, ss[4] = {sc4.x, sc4.y, sc4.z, sc4.w};
+          const float bb[4] = {b4.x, b4.y, b4.z, b4.w}, q1[4] = {k1.x, k1.y, k1.z, k1.w};
+          const float q2[4] = {k2.x, k2.y, k2.z, k2.w}, q3[4] = {k3.x, k3.y, k3.z, k3.w};
+          float o4[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float o = hh[e] - aa[e];
+            float gg = gg4[e];
+            if (slope != 1.f) {
+              const float y = fmaf(o, ss[e], bb[e]);
+              gg = (y > 0.f) ? gg : gg * slope;
+            }
+            o4[e] = fmaf(q1[e], gg, -fmaf(q2[e], o, q3[e]));
+          }
+          v = make_float4(o4[0], o4[1], o4[2], o4[3]);
+        }
+        *reinterpret_cast<float4*>(gl + rr * LDG + n) = v;
+      }
+    }
+    stage_tile<KPP, LDX, KPP>(xprev, row0, cnt, K, false, pt, pslope, xl, nullptr, lane);
+    wave_sync_lds();
+    // ---- gW += gh^T y_prev ------------------------------------------------------------
+    {
+      bf16x4 Xh[KB], Xl[KB];
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        const int k = 16 * kb + c;
+        float xv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = xl[(4 * g + r) * LDX + k];
+          if (pre) {
+            v = fmaf(v - pt[k], pt[KPP + k], pt[2 * KPP + k]);
+            v = (v > 0.f) ? v : v * pslope;
+            v = (4 * g + r < cnt && k < K) ? v : 0.f;
+          }
+          xv[r] = v;
+        }
+        split_bf16<4>(xv, Xh[kb], Xl[kb]);
+      }
+#pragma unroll
+      for (int nb = 0; nb < NBK; ++nb) {
+        float gv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gv[r] = gl[(4 * g + r) * LDG + 16 * nb + c];
+        bf16x4 gh4, gl4;
+        split_bf16<4>(gv, gh4, gl4);
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) C3[nb][kb] = mfma3_16(gh4, gl4, Xh[kb], Xl[kb], C3[nb][kb]);
+      }
+    }
+    // ---- gx = gh W (+ statistics for the previous GraphNorm's backward) ------------------
+    if constexpr (NEED_GX) {
+      f32x4 CX[KB];
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) CX[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int sg = 0; sg < NS; ++sg) {
+        const float4 a0 = *reinterpret_cast<const float4*>(gl + c * LDG + 32 * sg + 8 * g);
+        const float4 a1 = *reinterpret_cast<const float4*>(gl + c * LDG + 32 * sg + 8 * g + 4);
+        const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        bf16x8 ah, alo;
+        split_bf16<8>(av, ah, alo);
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+          const bf16x8 bh = *reinterpret_cast<const bf16x8*>(wt_hi + (16 * kb + c) * LDT + 32 * sg + 8 * g);
+          const bf16x8 bl = *reinterpret_cast<const bf16x8*>(wt_lo + (16 * kb + c) * LDT + 32 * sg + 8 * g);
+          CX[kb] = mfma3_32(ah, alo, bh, bl, CX[kb]);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rr = 4 * g + r;
+        if (rr < cnt) {
+#pragma unroll
+          for (int kb = 0; kb < KB; ++kb) {
+            const int k = 16 * kb + c;
+            if (k < K) {
+              const float v = CX[kb][r];
+              gx[(row0 + rr) * K + k] = v;
+              if (pre) {
+                const float o = xl[rr * LDX + k] - pt[k];
+                float gg = v;
+                if (pslope != 1.f) {
+                  const float y = fmaf(o, pt[KPP + k], pt[2 * KPP + k]);
+                  gg = (y > 0.f) ? gg : gg * pslope;
+                }
+                p1[kb] += (double)gg;
+                p2[kb] += (double)gg * (double)o;
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+  float* gwp = gw_partial + (size_t)wave * N * K;
+#pragma unroll
+  for (int nb = 0; nb < NBK; ++nb)
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k = 16 * kb + c;
+        if (k < K) gwp[(size_t)(16 * nb + 4 * g + r) * K + k] = C3[nb][kb][r];
+      }
+  if (pstat_partial) {
+    double* pp = pstat_partial + (size_t)wave * (2 * K + 1);
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      const double a = xg_sum_d(p1[kb]), b = xg_sum_d(p2[kb]);
+      const int k = 16 * kb + c;
+      if (g == 0 && k < K) {
+        pp[k] = a;
+        pp[K + k] = b;
+      }
+    }
+    if (lane == 0) pp[2 * K] = (wave == 0) ? (double)(r1 - r0) : 0.0;
+  }
+}
+
 // sums of per-wave tables, fixed order: 16 columns x 16 slices per block
 template <typename T>
 __global__ __launch_bounds__(256) void reduce_tables_kernel(const T* __restrict__ partial,
@@ -465,6 +793,20 @@ using namespace spt::fmlp;
 // shapes built: (K, N) of the SPT MLPs; K <= 64 (K4 <= 16), N in {32, 64, 128}
 #define SPT_FMLP_SHAPES(X) X(3, 2) X(5, 2) X(8, 2) X(8, 4) X(16, 4) X(16, 8) X(17, 4) X(33, 4)
 
+// 0: f32-in / f32-accumulate MFMA everywhere (bitwise an fmaf chain);
+// 1 (default): the BACKWARD GEMMs (gW, gx) on the bf16 matrix pipe with split operands - the
+//    gradients' parity bars are 1e-4 of the tensor's scale, ten times the split's error; the
+//    forward stays exact f32 because its outputs feed GraphNorm statistics and are held to
+//    2e-5 (measured with the split forward: 1e-4 after three normalised layers);
+// 2: forward too.  Process-wide, returns the previous setting.
+static int g_fmlp_mode = 1;
+#define g_fmlp_split_bf16 (g_fmlp_mode >= 1)
+extern "C" int spt_fused_linear_use_split_bf16(int mode) {
+  const int prev = g_fmlp_mode;
+  g_fmlp_mode = mode < 0 ? 0 : (mode > 2 ? 2 : mode);
+  return prev;
+}
+
 extern "C" int spt_fused_linear_supported(int K, int N) {
   const int k4 = (K + 3) / 4, nbk = N / 16;
   if (N % 16) return 0;
@@ -501,9 +843,14 @@ extern "C" int spt_fused_linear_fwd_f32(const float* x, int64_t r0, int64_t r1, 
   const int grid = grid_for(r1 - r0, per_cu) < MAX_BLOCKS ? grid_for(r1 - r0, per_cu) : MAX_BLOCKS;
   double* partial = (double*)ws;
 #define X(a, b)                                                                        \
-  if (k4 == a && nbk == b)                                                             \
-    fwd_kernel<a, b><<<grid, WAVES * 64, 0, stream>>>(x, r0, r1, K, W, pre_am, pre_scale, \
-                                                      pre_bias, pre_slope, h, partial);
+  if (k4 == a && nbk == b) {                                                           \
+    if (g_fmlp_mode >= 2)                                                              \
+      fwd_kernel_bf<a, b><<<grid, WAVES * 64, 0, stream>>>(x, r0, r1, K, W, pre_am, pre_scale, \
+                                                           pre_bias, pre_slope, h, partial);   \
+    else                                                                               \
+      fwd_kernel<a, b><<<grid, WAVES * 64, 0, stream>>>(x, r0, r1, K, W, pre_am, pre_scale, \
+                                                        pre_bias, pre_slope, h, partial);  \
+  }
   SPT_FMLP_SHAPES(X)
 #undef X
   reduce_tables_kernel<double><<<(2 * N + 1 + 15) / 16, 256, 0, stream>>>(partial, grid, 2 * N + 1,
@@ -545,7 +892,22 @@ extern "C" int spt_fused_linear_bwd_f32(const float* gy, const float* h, int64_t
     /* 2 x 8 waves while the LDS tiles stay under 80 KB, else 1 x 8 */                            \
     grid = grid_for_nw(r1 - r0, big ? ((a * b <= 32) ? 2 : 1) : 4, NWV);                         \
     nw = grid * NWV;                                                                             \
-    if (gx)                                                                                      \
+    /* split-bf16: the K = 132 layer keeps W^T, its accumulators and both split operands live: */ \
+    /* 4-wave workgroups (1 wave per SIMD, 512 registers) instead of spilling at 256           */ \
+    constexpr int NWB = (a * b > 128) ? 4 : NWV;                                                 \
+    if (g_fmlp_split_bf16) {                                                                     \
+      grid = grid_for_nw(r1 - r0, (a * b > 128) ? 1 : (big ? ((a * b <= 32) ? 2 : 1) : 4), NWB); \
+      nw = grid * NWB;                                                                           \
+    }                                                                                            \
+    if (g_fmlp_split_bf16 && gx)                                                                 \
+      bwd_kernel_bf<a, b, true, NWB><<<grid, NWB * 64, 0, stream>>>(                             \
+          gy, h, r0, r1, am, scale, bias, slope, c1, c2, c3, xprev, K, pre_am, pre_scale,        \
+          pre_bias, pre_slope, W, gx, gwp, prev_total ? pst : nullptr);                          \
+    else if (g_fmlp_split_bf16)                                                                  \
+      bwd_kernel_bf<a, b, false, NWB><<<grid, NWB * 64, 0, stream>>>(                            \
+          gy, h, r0, r1, am, scale, bias, slope, c1, c2, c3, xprev, K, pre_am, pre_scale,        \
+          pre_bias, pre_slope, W, nullptr, gwp, nullptr);                                        \
+    else if (gx)                                                                                 \
       bwd_kernel<a, b, true, NWV, big><<<grid, NWV * 64, 0, stream>>>(                           \
           gy, h, r0, r1, am, scale, bias, slope, c1, c2, c3, xprev, K, pre_am, pre_scale,        \
           pre_bias, pre_slope, W, gx, gwp, prev_total ? pst : nullptr);                          \

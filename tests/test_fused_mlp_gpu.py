@@ -20,8 +20,18 @@ CASES = [
 ]
 
 
+@pytest.fixture(params=[1, 0, 2], ids=["bwd-split-bf16", "f32-pipe", "all-split-bf16"])
+def gemm_mode(request):
+    """1 = default (backward GEMMs on the bf16 pipe with split operands, forward exact f32),
+    0 = f32 matrix pipe everywhere, 2 = forward split too (y then meets 2e-4, not 2e-5)."""
+    from superpoint_transformer_amd import _lib
+    prev = _lib.lib.spt_fused_linear_use_split_bf16(request.param)
+    yield request.param
+    _lib.lib.spt_fused_linear_use_split_bf16(prev)
+
+
 @pytest.mark.parametrize("dims,rows,B", CASES)
-def test_fused_mlp_matches_oracle_and_unfused_path(dims, rows, B, dev):
+def test_fused_mlp_matches_oracle_and_unfused_path(dims, rows, B, gemm_mode, dev):
     from superpoint_transformer_amd import nn as N
     g = torch.Generator().manual_seed(rows + B)
     mlp = N.MLP(dims, norm=N.GraphNorm)
@@ -83,7 +93,8 @@ def test_fused_mlp_matches_oracle_and_unfused_path(dims, rows, B, dev):
     # statistics is O(1/rows) - a handful of gx elements may still sit above the bar
     few = 8 * dims[0]
 
-    close(yf, yr.detach(), 2e-5, "y")
+    ytol = 2e-5 if gemm_mode < 2 else 2e-4
+    close(yf, yr.detach(), ytol, "y")
     close(gxf, x64.grad, 1e-4, "gx", outliers=few)
     for k in gpf:
         r = refp[k].grad
@@ -92,7 +103,7 @@ def test_fused_mlp_matches_oracle_and_unfused_path(dims, rows, B, dev):
         erru = ((gpu_[k].double() - r).abs() / scale).max().item()
         assert err <= max(2e-4, 3 * erru), f"{k}: fused {err:.3e} unfused {erru:.3e}"
     # fused and unfused HIP paths agree with each other
-    close(yf, yu.double(), 2e-5, "y fused vs unfused")
+    close(yf, yu.double(), ytol, "y fused vs unfused")
     close(gxf, gxu.double(), 1e-4, "gx fused vs unfused", outliers=few)
 
 
