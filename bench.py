@@ -37,6 +37,9 @@ def parse():
     p.add_argument("--mode", default="train", choices=["train", "infer", "panoptic"],
                    help="train: fwd+loss+bwd+AdamW (default, BASELINE cfg #2); infer: forward only "
                         "(cfg #3, use --scene D); panoptic: + edge-affinity head and loss (cfg #5)")
+    p.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f32-exact"],
+                   help="matrix-pipe precision (superpoint_transformer_amd.precision); f32 = the "
+                        "reference's shipped `precision: 32`, bf16 = its bf16 option (cfg #2)")
     p.add_argument("--model", default="spt64", choices=["spt64", "spt128"],
                    help="spt128 = the KITTI-360 width (cfg #4)")
     return p.parse_args()
@@ -205,6 +208,8 @@ def main():
     from superpoint_transformer_amd import hotpath
     from superpoint_transformer_amd.synthetic import SCENES, make_nag
 
+    from superpoint_transformer_amd import precision
+    precision.set_matrix_precision(args.dtype)
     nag = make_nag(args.scene, seed=1234 + rank, device=dev)
     path = hotpath.build(nag, dev, world=world, stages=args.stages, mode=args.mode, model=args.model)
 
@@ -236,7 +241,8 @@ def main():
 
     cpu = None
     pre = None
-    headline = args.mode == "train" and args.model == "spt64" and args.stages == "all"
+    headline = (args.mode == "train" and args.model == "spt64" and args.stages == "all"
+                and args.dtype == "f32")
     if rank == 0 and world == 1 and not headline:
         del path                      # other BASELINE configs: the GPU line only
     elif rank == 0 and world == 1:
@@ -262,7 +268,8 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": {"f32": "f32", "f32-exact": "f32",
+                      "bf16": "bf16 (matrix operands; f32 accumulate, storage and statistics)"}[args.dtype],
             "data": "synthetic",
             "config": {
                 "workload": workload,

@@ -415,6 +415,17 @@ int spt_horizontal_edge_features_f32(
     const float* normal, const float* log_length, const float* log_surface,
     const float* log_volume, const float* log_size, int add_self_loops,
     int64_t* edge_index_out, float* edge_attr_out, spt_stream_t stream);
+/* On-the-fly VERTICAL edge features (src/transforms/graph.py:1335-1416, all default keys), one
+ * row per child node with parent p = super_index[i]:
+ *   [centroid_dir (3, 0/0 -> 0, clipped to [-1,1]), sqrt(centroid_dist), |<n_i, n_p>|,
+ *    log_length_p - log_length_i, log_surface.., log_volume.., log_size..]      out [n, 9]. */
+int spt_vertical_edge_features_f32(
+    const int64_t* super_index, int64_t n, const float* child_pos, const float* child_normal,
+    const float* child_log_length, const float* child_log_surface, const float* child_log_volume,
+    const float* child_log_size, const float* parent_pos, const float* parent_normal,
+    const float* parent_log_length, const float* parent_log_surface,
+    const float* parent_log_volume, const float* parent_log_size, float* v_edge_attr,
+    spt_stream_t stream);
 /* Symmetric edge features of the panoptic edge-affinity head (src/models/panoptic.py:477-480):
  *   out[e] = cat(|x[a_e] - x[b_e]|, (x[a_e] + x[b_e]) / 2)   x [n,C], C % 4 == 0, out [e,2C].
  * Backward: gend [2e, C], row e = gradient reaching x[a_e] through edge e, row e + E the one

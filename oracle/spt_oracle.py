@@ -796,3 +796,21 @@ def nag_select(levels, i_level, idx):
         out[i], _, out_super = data_select(levels[i], idx_super, False, True)
         out[i]["sub"] = super_sub
     return out
+
+
+def vertical_edge_features(child_pos, child_normal, child_logs, parent_pos, parent_normal,
+                           parent_logs, super_index):
+    """src/transforms/graph.py:1335-1416 with all default keys: per child node
+    [centroid_dir (3), sqrt(centroid_dist), |<n_child, n_parent>|, parent - child of
+    log_length / log_surface / log_volume / log_size]; a 0/0 direction becomes 0, directions are
+    clipped to [-1, 1].  ``*_logs`` = (log_length, log_surface, log_volume, log_size)."""
+    idx = super_index
+    d = parent_pos[idx] - child_pos
+    dist = d.norm(dim=1)
+    d = d / dist.view(-1, 1)
+    d = torch.where(d.isnan(), torch.zeros_like(d), d).clip(-1, 1)
+    cols = [d, dist.sqrt().view(-1, 1),
+            (child_normal * parent_normal[idx]).sum(dim=1).abs().view(-1, 1)]
+    for pc, cc in zip(parent_logs, child_logs):
+        cols.append((pc.view(-1)[idx] - cc.view(-1)).view(-1, 1))
+    return torch.cat(cols, dim=1)

@@ -52,6 +52,7 @@ SIGNATURES = {
     "spt_spatial_order_workspace_bytes": (_sz, [_i64, _i64]),
     "spt_spatial_order": (_int, [_p, _i64, _f32, _p, _p, _p, _p, _sz, _p]),
     "spt_point_geof_csr_f32": (_int, [_p, _i64, _p, _p, _int, _int, _int, _p, _p]),
+    "spt_vertical_edge_features_f32": (_int, [_p, _i64] + [_p] * 13 + [_p]),
     "spt_edge_affinity_features_f32": (_int, [_p, _i64, _int, _p, _p, _i64, _p, _p]),
     "spt_edge_affinity_features_bwd_f32": (_int, [_p, _p, _i64, _int, _p, _p, _i64, _p, _p]),
     "spt_scatter_pca_f32": (_int, [_p, _p, _p, _i64, _p, _p, _p]),

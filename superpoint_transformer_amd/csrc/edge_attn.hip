@@ -760,7 +760,8 @@ int attn_bwd_mfma_launch(const float* qkv, int64_t n, const int32_t* erowptr,
                          float* gqkv, float* gea, float* partial, int split_bf16,
                          hipStream_t stream);
 // 0: lane-per-output VALU kernels, 1: f32 matrix pipe (bitwise an fmaf chain), 2 (default):
-// split-bf16 on the bf16 matrix pipe (3 products per f32 product, ~10 ulp of f32)
+// split-bf16 on the bf16 matrix pipe (3 products per f32 product, ~10 ulp of f32), 3: plain
+// bf16 operands, f32 accumulate (the bf16 precision mode)
 static int g_attn_mfma = -1;  // -1: decide from the environment on first use
 static int mfma_mode() {
   if (g_attn_mfma < 0) g_attn_mfma = getenv("SPT_ATTN_VALU_ONLY") == nullptr ? 2 : 0;
@@ -787,7 +788,7 @@ using namespace spt;
 
 extern "C" int spt_attn_use_mfma(int mode) {
   const int prev = mfma_mode();
-  g_attn_mfma = mode < 0 ? 0 : (mode > 2 ? 2 : mode);
+  g_attn_mfma = mode < 0 ? 0 : (mode > 3 ? 3 : mode);
   return prev;
 }
 
@@ -806,7 +807,8 @@ extern "C" int spt_edge_attn_fwd_f32(const float* qkv, int64_t n, int H, int D, 
   SPT_CHECK_ARG((m == nullptr) == (z == nullptr), "pass both m and z or neither");
   if (use_mfma() && attn_mfma_shape_ok(H, D, Dv, F, edge_attr, Wk, Wq, Wv)) {
     attn_fwd_mfma_launch(qkv, n, erowptr, eperm, tgt_sorted, edge_attr, Wk, bk, Wq, bq, Wv, bv,
-                         scale_mode, scale_a, out, m, z, mfma_mode() == 2, stream);
+                         scale_mode, scale_a, out, m, z,
+                         mfma_mode() == 2 ? 3 : (mfma_mode() == 3 ? 1 : 0), stream);
     SPT_CHECK_LAUNCH();
     return 0;
   }
@@ -868,7 +870,8 @@ extern "C" int spt_edge_attn_bwd_f32(const float* qkv, int64_t n, int H, int D, 
   if (use_mfma() && attn_mfma_shape_ok(H, D, Dv, F, edge_attr, Wk, Wq, Wv)) {
     const int ntab = attn_bwd_mfma_launch(qkv, n, erowptr, eperm, tgt_sorted, edge_attr, Wk, bk,
                                           Wq, bq, Wv, bv, scale_mode, scale_a, out, m, z, gout,
-                                          gqkv, gedge_attr, partial, mfma_mode() == 2, stream);
+                                          gqkv, gedge_attr, partial,
+                                          mfma_mode() == 2 ? 3 : (mfma_mode() == 3 ? 1 : 0), stream);
     attn_reduce_partials_kernel<<<(int)ceil_div((int64_t)len, 16), 256, 0, stream>>>(
         partial, ntab, (int)len, total);
     attn_unpack_grads_kernel<<<(int)ceil_div((int64_t)len, 256), 256, 0, stream>>>(

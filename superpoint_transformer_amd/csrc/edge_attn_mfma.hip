@@ -204,14 +204,18 @@ __device__ __forceinline__ void load_a_bf(const float* slab, int g, int c, bf16x
   split_bf16<8>(a, Ah, Al);
 }
 
+// LO = false: plain bf16 operands (the hi halves only) - the "bf16 matrix" precision mode
+template <bool LO>
 __device__ __forceinline__ void rpe_gemm_bf(const bf16x8& Ah, const bf16x8& Al,
                                             const bf16x8 (&Bh)[NB], const bf16x8 (&Bl)[NB],
                                             const float (&init)[NB], f32x4 (&C)[NB]) {
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     C[b] = (f32x4){init[b], init[b], init[b], init[b]};
-    C[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, Bh[b], C[b], 0, 0, 0);
-    C[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bl[b], C[b], 0, 0, 0);
+    if constexpr (LO) {
+      C[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, Bh[b], C[b], 0, 0, 0);
+      C[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bl[b], C[b], 0, 0, 0);
+    }
     C[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bh[b], C[b], 0, 0, 0);
   }
 }
@@ -375,7 +379,8 @@ struct Pipe {
   }
 };
 
-template <bool BF3>
+// PREC: 0 = f32 matrix pipe, 3 = split-bf16 (3 products), 1 = plain bf16 operands
+template <int PREC>
 __global__ __launch_bounds__(WAVES * 64, 2) void attn_fwd_mfma_kernel(
     const float* __restrict__ qkv, int ld, int64_t N, const int32_t* __restrict__ erowptr,
     const int32_t* __restrict__ eperm, const int32_t* __restrict__ tgt,
@@ -383,6 +388,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_fwd_mfma_kernel(
     const float* __restrict__ Wq, const float* __restrict__ bq, const float* __restrict__ Wv,
     const float* __restrict__ bv, int scale_mode, float scale_a, float* __restrict__ out,
     float* __restrict__ mbuf, float* __restrict__ zbuf) {
+  constexpr bool BF3 = PREC != 0, LO = PREC == 3;
   __shared__ __attribute__((aligned(16))) float slab_all[WAVES][2][SLAB];
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -442,9 +448,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_fwd_mfma_kernel(
       if constexpr (BF3) {
         bf16x8 Ah, Al;
         load_a_bf(slab, g, c, Ah, Al);
-        rpe_gemm_bf(Ah, Al, Bkh, Bkl, bk4, Ck);
-        rpe_gemm_bf(Ah, Al, Bqh, Bql, qs4, Cq);
-        rpe_gemm_bf(Ah, Al, Bvh, Bvl, bv4, Cv);
+        rpe_gemm_bf<LO>(Ah, Al, Bkh, Bkl, bk4, Ck);
+        rpe_gemm_bf<LO>(Ah, Al, Bqh, Bql, qs4, Cq);
+        rpe_gemm_bf<LO>(Ah, Al, Bvh, Bvl, bv4, Cv);
       } else {
         float A[8];
         load_a(slab, g, c, A);
@@ -509,7 +515,7 @@ constexpr int WB_LD = F + 8;
 constexpr int WB_ELEMS = 192 * WB_LD;
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-template <bool BF3>
+template <int PREC>
 __global__ __launch_bounds__(WAVES * 64, 1) void attn_bwd_mfma_kernel(
     const float* __restrict__ qkv, int ld, int64_t N, const int32_t* __restrict__ erowptr,
     const int32_t* __restrict__ eperm, const int32_t* __restrict__ tgt,
@@ -519,6 +525,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attn_bwd_mfma_kernel(
     const float* __restrict__ mbuf, const float* __restrict__ zbuf,
     const float* __restrict__ gout, float* __restrict__ gqkv, float* __restrict__ gea,
     float* __restrict__ partial) {
+  constexpr bool BF3 = PREC != 0, LO = PREC == 3;
   __shared__ __attribute__((aligned(16))) float slab_all[WAVES][2][SLAB];
   __shared__ __attribute__((aligned(16))) float dt_all[WAVES][DT_FLOATS];
   __shared__ __attribute__((aligned(16))) float w_lds[BF3 ? 4 : W_FLOATS];
@@ -674,12 +681,14 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attn_bwd_mfma_kernel(
             const bf16x8 ql = *reinterpret_cast<const bf16x8*>(wl + (64 + 16 * b) * WB_LD);
             const bf16x8 vh = *reinterpret_cast<const bf16x8*>(wh + (128 + 16 * b) * WB_LD);
             const bf16x8 vl = *reinterpret_cast<const bf16x8*>(wl + (128 + 16 * b) * WB_LD);
-            Ck[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, kh, Ck[b], 0, 0, 0);
-            Cq[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, qh, Cq[b], 0, 0, 0);
-            Cv[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, vh, Cv[b], 0, 0, 0);
-            Ck[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, kl, Ck[b], 0, 0, 0);
-            Cq[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, ql, Cq[b], 0, 0, 0);
-            Cv[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, vl, Cv[b], 0, 0, 0);
+            if constexpr (LO) {
+              Ck[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, kh, Ck[b], 0, 0, 0);
+              Cq[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, qh, Cq[b], 0, 0, 0);
+              Cv[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, vh, Cv[b], 0, 0, 0);
+              Ck[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, kl, Ck[b], 0, 0, 0);
+              Cq[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, ql, Cq[b], 0, 0, 0);
+              Cv[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, vl, Cv[b], 0, 0, 0);
+            }
             Ck[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, kh, Ck[b], 0, 0, 0);
             Cq[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, qh, Cq[b], 0, 0, 0);
             Cv[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, vh, Cv[b], 0, 0, 0);
@@ -775,8 +784,10 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attn_bwd_mfma_kernel(
             split_bf16<8>(dd, dh, dl);
 #pragma unroll
             for (int fb = 0; fb < 2; ++fb) {
-              C2[fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dl, W2h[sg][fb], C2[fb], 0, 0, 0);
-              C2[fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dh, W2l[sg][fb], C2[fb], 0, 0, 0);
+              if constexpr (LO) {
+                C2[fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dl, W2h[sg][fb], C2[fb], 0, 0, 0);
+                C2[fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dh, W2l[sg][fb], C2[fb], 0, 0, 0);
+              }
               C2[fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dh, W2h[sg][fb], C2[fb], 0, 0, 0);
             }
           }
@@ -852,8 +863,10 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attn_bwd_mfma_kernel(
             const s16x4 Dh = __builtin_bit_cast(s16x4, dh), Dl = __builtin_bit_cast(s16x4, dl);
 #pragma unroll
             for (int fb = 0; fb < 2; ++fb) {
-              C3[ob][fb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(Dl, Eh[fb], C3[ob][fb], 0, 0, 0);
-              C3[ob][fb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(Dh, El[fb], C3[ob][fb], 0, 0, 0);
+              if constexpr (LO) {
+                C3[ob][fb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(Dl, Eh[fb], C3[ob][fb], 0, 0, 0);
+                C3[ob][fb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(Dh, El[fb], C3[ob][fb], 0, 0, 0);
+              }
               C3[ob][fb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(Dh, Eh[fb], C3[ob][fb], 0, 0, 0);
             }
           }
@@ -922,11 +935,14 @@ void attn_fwd_mfma_launch(const float* qkv, int64_t n, const int32_t* erowptr,
                           float* out, float* m, float* z, int split_bf16, hipStream_t stream) {
   const int64_t blocks = ceil_div(n, mfma::WAVES);
   const int grid = (int)(blocks < 256 * 2 * 4 ? blocks : 256 * 2 * 4);
-  if (split_bf16)
-    mfma::attn_fwd_mfma_kernel<true><<<grid, mfma::WAVES * 64, 0, stream>>>(
+  if (split_bf16 == 3)
+    mfma::attn_fwd_mfma_kernel<3><<<grid, mfma::WAVES * 64, 0, stream>>>(
+        qkv, 192, n, erowptr, eperm, tgt, ea, Wk, bk, Wq, bq, Wv, bv, scale_mode, scale_a, out, m, z);
+  else if (split_bf16 == 1)
+    mfma::attn_fwd_mfma_kernel<1><<<grid, mfma::WAVES * 64, 0, stream>>>(
         qkv, 192, n, erowptr, eperm, tgt, ea, Wk, bk, Wq, bq, Wv, bv, scale_mode, scale_a, out, m, z);
   else
-    mfma::attn_fwd_mfma_kernel<false><<<grid, mfma::WAVES * 64, 0, stream>>>(
+    mfma::attn_fwd_mfma_kernel<0><<<grid, mfma::WAVES * 64, 0, stream>>>(
         qkv, 192, n, erowptr, eperm, tgt, ea, Wk, bk, Wq, bq, Wv, bv, scale_mode, scale_a, out, m, z);
 }
 
@@ -941,12 +957,16 @@ int attn_bwd_mfma_launch(const float* qkv, int64_t n, const int32_t* erowptr,
                          hipStream_t stream) {
   const int64_t blocks = ceil_div(n, mfma::WAVES);
   const int grid = (int)(blocks < ATTN_BWD_MFMA_BLOCKS ? blocks : ATTN_BWD_MFMA_BLOCKS);
-  if (split_bf16)
-    mfma::attn_bwd_mfma_kernel<true><<<grid, mfma::WAVES * 64, 0, stream>>>(
+  if (split_bf16 == 3)
+    mfma::attn_bwd_mfma_kernel<3><<<grid, mfma::WAVES * 64, 0, stream>>>(
+        qkv, 192, n, erowptr, eperm, tgt, ea, Wk, bk, Wq, bq, Wv, bv, scale_mode, scale_a, out, m,
+        z, gout, gqkv, gea, partial);
+  else if (split_bf16 == 1)
+    mfma::attn_bwd_mfma_kernel<1><<<grid, mfma::WAVES * 64, 0, stream>>>(
         qkv, 192, n, erowptr, eperm, tgt, ea, Wk, bk, Wq, bq, Wv, bv, scale_mode, scale_a, out, m,
         z, gout, gqkv, gea, partial);
   else
-    mfma::attn_bwd_mfma_kernel<false><<<grid, mfma::WAVES * 64, 0, stream>>>(
+    mfma::attn_bwd_mfma_kernel<0><<<grid, mfma::WAVES * 64, 0, stream>>>(
         qkv, 192, n, erowptr, eperm, tgt, ea, Wk, bk, Wq, bq, Wv, bv, scale_mode, scale_a, out, m,
         z, gout, gqkv, gea, partial);
   return grid * mfma::WAVES;  // number of partial tables written

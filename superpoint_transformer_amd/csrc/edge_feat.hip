@@ -81,6 +81,33 @@ __global__ __launch_bounds__(256) void edge_feat_kernel(
   }
 }
 
+// ---- vertical (child -> parent) edge features, src/transforms/graph.py:1335-1416 -------------
+// out[i] = [dir(3), sqrt(dist), |<n_i, n_p>|, log_length_p - log_length_i, ... surface, volume,
+// size] with p = super_index[i]; 0/0 directions -> 0, directions clipped to [-1, 1].
+__global__ __launch_bounds__(256) void vertical_edge_feat_kernel(
+    const int64_t* __restrict__ sup, int64_t n, const float* __restrict__ cpos,
+    const float* __restrict__ cnrm, const float* __restrict__ cll, const float* __restrict__ cls,
+    const float* __restrict__ clv, const float* __restrict__ clz, const float* __restrict__ ppos,
+    const float* __restrict__ pnrm, const float* __restrict__ pll, const float* __restrict__ pls,
+    const float* __restrict__ plv, const float* __restrict__ plz, float* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int64_t p = sup[i];
+    const float dx = ppos[p * 3] - cpos[i * 3], dy = ppos[p * 3 + 1] - cpos[i * 3 + 1],
+                dz = ppos[p * 3 + 2] - cpos[i * 3 + 2];
+    const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
+    float* o = out + i * 9;
+    o[0] = clip1(dx / dist); o[1] = clip1(dy / dist); o[2] = clip1(dz / dist);
+    o[3] = sqrtf(dist);
+    o[4] = fabsf(cnrm[i * 3] * pnrm[p * 3] + cnrm[i * 3 + 1] * pnrm[p * 3 + 1] +
+                 cnrm[i * 3 + 2] * pnrm[p * 3 + 2]);
+    o[5] = pll[p] - cll[i];
+    o[6] = pls[p] - cls[i];
+    o[7] = plv[p] - clv[i];
+    o[8] = plz[p] - clz[i];
+  }
+}
+
 // ---- symmetric edge features of the panoptic edge-affinity head ---------------------------
 // src/models/panoptic.py:477-480:  x_edge = x[obj_edge_index];
 //   out[e] = cat(|x[a_e] - x[b_e]|, (x[a_e] + x[b_e]) / 2)          [E, 2C]
@@ -132,6 +159,28 @@ __global__ __launch_bounds__(256) void edge_affinity_bwd_kernel(
 }  // namespace spt
 
 using namespace spt;
+
+extern "C" int spt_vertical_edge_features_f32(
+    const int64_t* super_index, int64_t n, const float* child_pos, const float* child_normal,
+    const float* child_log_length, const float* child_log_surface, const float* child_log_volume,
+    const float* child_log_size, const float* parent_pos, const float* parent_normal,
+    const float* parent_log_length, const float* parent_log_surface,
+    const float* parent_log_volume, const float* parent_log_size, float* v_edge_attr,
+    spt_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPT_CHECK_ARG(n >= 0, "bad shape");
+  if (n == 0) return 0;
+  SPT_CHECK_ARG(super_index && child_pos && child_normal && child_log_length && child_log_surface &&
+                child_log_volume && child_log_size && parent_pos && parent_normal &&
+                parent_log_length && parent_log_surface && parent_log_volume && parent_log_size &&
+                v_edge_attr, "null pointer");
+  vertical_edge_feat_kernel<<<stream_grid(n, 256), 256, 0, stream>>>(
+      super_index, n, child_pos, child_normal, child_log_length, child_log_surface,
+      child_log_volume, child_log_size, parent_pos, parent_normal, parent_log_length,
+      parent_log_surface, parent_log_volume, parent_log_size, v_edge_attr);
+  SPT_CHECK_LAUNCH();
+  return 0;
+}
 
 extern "C" int spt_edge_affinity_features_f32(const float* x, int64_t n, int C,
                                               const int64_t* edge_a, const int64_t* edge_b,

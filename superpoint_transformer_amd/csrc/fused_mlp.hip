@@ -433,24 +433,31 @@ __device__ __forceinline__ void split_bf16(const float (&x)[NV], V& hi, V& lo) {
     lo[i] = (__bf16)(x[i] - (float)h);
   }
 }
+// LO = false: plain bf16 operands (hi halves only): the bf16 precision mode
+template <bool LO>
 __device__ __forceinline__ f32x4 mfma3_32(const bf16x8& ah, const bf16x8& al, const bf16x8& bh,
                                           const bf16x8& bl, f32x4 c) {
-  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
+  if constexpr (LO) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
+  }
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
 }
+template <bool LO>
 __device__ __forceinline__ f32x4 mfma3_16(const bf16x4& ah, const bf16x4& al, const bf16x4& bh,
                                           const bf16x4& bl, f32x4 c) {
   const s16x4 AH = __builtin_bit_cast(s16x4, ah), AL = __builtin_bit_cast(s16x4, al);
   const s16x4 BH = __builtin_bit_cast(s16x4, bh), BL = __builtin_bit_cast(s16x4, bl);
-  c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(AL, BH, c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(AH, BL, c, 0, 0, 0);
+  if constexpr (LO) {
+    c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(AL, BH, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(AH, BL, c, 0, 0, 0);
+  }
   return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(AH, BH, c, 0, 0, 0);
 }
 
 // ---- forward: K padded to KS steps of 32, the weight block W[n][k] as split bf16 B operands
 // (lane (g, c): W[16 nb + c][32 ks + 8 g .. + 7]) resident for the whole launch -----------
-template <int K4, int NBK>
+template <int K4, int NBK, bool LO>
 __global__ __launch_bounds__(WAVES * 64, 2) void fwd_kernel_bf(
     const float* __restrict__ x, int64_t r0, int64_t r1, int K, const float* __restrict__ W,
     const float* __restrict__ am, const float* __restrict__ sc, const float* __restrict__ bs,
@@ -507,7 +514,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void fwd_kernel_bf(
       bf16x8 ah, alo;
       split_bf16<8>(av, ah, alo);
 #pragma unroll
-      for (int nb = 0; nb < NBK; ++nb) C[nb] = mfma3_32(ah, alo, Bh[nb][ks], Bl[nb][ks], C[nb]);
+      for (int nb = 0; nb < NBK; ++nb) C[nb] = mfma3_32<LO>(ah, alo, Bh[nb][ks], Bl[nb][ks], C[nb]);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -543,7 +550,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void fwd_kernel_bf(
 // tile: the 4 rows a lane group holds are one packed operand), gx = gh W as 16x16x32
 // products with W^T as split bf16 rows in LDS (wt[k][n], n contiguous: lane (g, c) reads the 8
 // values W[32 s + 8 g .. + 7][16 kb + c] with one 16-byte read each for hi and lo) ---------
-template <int K4, int NBK, bool NEED_GX, int NW>
+template <int K4, int NBK, bool NEED_GX, int NW, bool LO>
 __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_kernel_bf(
     const float* __restrict__ gy, const float* __restrict__ h, int64_t r0, int64_t r1,
     const float* __restrict__ am, const float* __restrict__ sc, const float* __restrict__ bs,
@@ -668,7 +675,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_kernel_bf(
         bf16x4 gh4, gl4;
         split_bf16<4>(gv, gh4, gl4);
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) C3[nb][kb] = mfma3_16(gh4, gl4, Xh[kb], Xl[kb], C3[nb][kb]);
+        for (int kb = 0; kb < KB; ++kb) C3[nb][kb] = mfma3_16<LO>(gh4, gl4, Xh[kb], Xl[kb], C3[nb][kb]);
       }
     }
     // ---- gx = gh W (+ statistics for the previous GraphNorm's backward) ------------------
@@ -687,7 +694,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_kernel_bf(
         for (int kb = 0; kb < KB; ++kb) {
           const bf16x8 bh = *reinterpret_cast<const bf16x8*>(wt_hi + (16 * kb + c) * LDT + 32 * sg + 8 * g);
           const bf16x8 bl = *reinterpret_cast<const bf16x8*>(wt_lo + (16 * kb + c) * LDT + 32 * sg + 8 * g);
-          CX[kb] = mfma3_32(ah, alo, bh, bl, CX[kb]);
+          CX[kb] = mfma3_32<LO>(ah, alo, bh, bl, CX[kb]);
         }
       }
 #pragma unroll
@@ -798,12 +805,13 @@ using namespace spt::fmlp;
 //    gradients' parity bars are 1e-4 of the tensor's scale, ten times the split's error; the
 //    forward stays exact f32 because its outputs feed GraphNorm statistics and are held to
 //    2e-5 (measured with the split forward: 1e-4 after three normalised layers);
-// 2: forward too.  Process-wide, returns the previous setting.
+// 2: forward too;  3: plain bf16 operands (hi halves only) in both directions - the bf16
+//    precision mode.  Process-wide, returns the previous setting.
 static int g_fmlp_mode = 1;
 #define g_fmlp_split_bf16 (g_fmlp_mode >= 1)
 extern "C" int spt_fused_linear_use_split_bf16(int mode) {
   const int prev = g_fmlp_mode;
-  g_fmlp_mode = mode < 0 ? 0 : (mode > 2 ? 2 : mode);
+  g_fmlp_mode = mode < 0 ? 0 : (mode > 3 ? 3 : mode);
   return prev;
 }
 
@@ -844,9 +852,12 @@ extern "C" int spt_fused_linear_fwd_f32(const float* x, int64_t r0, int64_t r1, 
   double* partial = (double*)ws;
 #define X(a, b)                                                                        \
   if (k4 == a && nbk == b) {                                                           \
-    if (g_fmlp_mode >= 2)                                                              \
-      fwd_kernel_bf<a, b><<<grid, WAVES * 64, 0, stream>>>(x, r0, r1, K, W, pre_am, pre_scale, \
-                                                           pre_bias, pre_slope, h, partial);   \
+    if (g_fmlp_mode == 3)                                                              \
+      fwd_kernel_bf<a, b, false><<<grid, WAVES * 64, 0, stream>>>(x, r0, r1, K, W, pre_am, pre_scale, \
+                                                                  pre_bias, pre_slope, h, partial); \
+    else if (g_fmlp_mode == 2)                                                         \
+      fwd_kernel_bf<a, b, true><<<grid, WAVES * 64, 0, stream>>>(x, r0, r1, K, W, pre_am, pre_scale, \
+                                                                 pre_bias, pre_slope, h, partial);  \
     else                                                                               \
       fwd_kernel<a, b><<<grid, WAVES * 64, 0, stream>>>(x, r0, r1, K, W, pre_am, pre_scale, \
                                                         pre_bias, pre_slope, h, partial);  \
@@ -899,12 +910,20 @@ extern "C" int spt_fused_linear_bwd_f32(const float* gy, const float* h, int64_t
       grid = grid_for_nw(r1 - r0, (a * b > 128) ? 1 : (big ? ((a * b <= 32) ? 2 : 1) : 4), NWB); \
       nw = grid * NWB;                                                                           \
     }                                                                                            \
-    if (g_fmlp_split_bf16 && gx)                                                                 \
-      bwd_kernel_bf<a, b, true, NWB><<<grid, NWB * 64, 0, stream>>>(                             \
+    if (g_fmlp_mode == 3 && gx)                                                                  \
+      bwd_kernel_bf<a, b, true, NWB, false><<<grid, NWB * 64, 0, stream>>>(                      \
+          gy, h, r0, r1, am, scale, bias, slope, c1, c2, c3, xprev, K, pre_am, pre_scale,        \
+          pre_bias, pre_slope, W, gx, gwp, prev_total ? pst : nullptr);                          \
+    else if (g_fmlp_mode == 3)                                                                   \
+      bwd_kernel_bf<a, b, false, NWB, false><<<grid, NWB * 64, 0, stream>>>(                     \
+          gy, h, r0, r1, am, scale, bias, slope, c1, c2, c3, xprev, K, pre_am, pre_scale,        \
+          pre_bias, pre_slope, W, nullptr, gwp, nullptr);                                        \
+    else if (g_fmlp_split_bf16 && gx)                                                            \
+      bwd_kernel_bf<a, b, true, NWB, true><<<grid, NWB * 64, 0, stream>>>(                       \
           gy, h, r0, r1, am, scale, bias, slope, c1, c2, c3, xprev, K, pre_am, pre_scale,        \
           pre_bias, pre_slope, W, gx, gwp, prev_total ? pst : nullptr);                          \
     else if (g_fmlp_split_bf16)                                                                  \
-      bwd_kernel_bf<a, b, false, NWB><<<grid, NWB * 64, 0, stream>>>(                            \
+      bwd_kernel_bf<a, b, false, NWB, true><<<grid, NWB * 64, 0, stream>>>(                      \
           gy, h, r0, r1, am, scale, bias, slope, c1, c2, c3, xprev, K, pre_am, pre_scale,        \
           pre_bias, pre_slope, W, nullptr, gwp, nullptr);                                        \
     else if (gx)                                                                                 \

@@ -51,6 +51,30 @@ def horizontal_edge_features(edge_index, edge_attr, pos, normal, log_length, log
     return ei_out, ea_out
 
 
+def vertical_edge_features(child, parent):
+    """``_on_the_fly_vertical_edge_features`` with all default keys
+    (src/transforms/graph.py:1335-1416): ``child`` / ``parent`` are level objects (Data or
+    dicts) holding pos, normal, log_length, log_surface, log_volume, log_size, and
+    ``child.super_index``.  Returns ``v_edge_attr`` [num_child, 9] (one kernel)."""
+    def get(d, k):
+        v = d[k] if isinstance(d, dict) else getattr(d, k)
+        return v
+    sup = get(child, "super_index").long().contiguous()
+    _lib.require_cuda(sup)
+    n = sup.numel()
+    dev = sup.device
+    keys = ("pos", "normal", "log_length", "log_surface", "log_volume", "log_size")
+    cargs = [get(child, k).detach().float().contiguous() for k in keys]
+    pargs = [get(parent, k).detach().float().contiguous() for k in keys]
+    out = torch.empty((n, 9), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        st = _lib.lib.spt_vertical_edge_features_f32(
+            _lib.ptr(sup), n, *[_lib.ptr(a) for a in cargs], *[_lib.ptr(a) for a in pargs],
+            _lib.ptr(out), _lib.stream_ptr(dev))
+    _lib.check(st, "spt_vertical_edge_features_f32")
+    return out
+
+
 # ---------------------------------------------------------------------------
 # Per-batch on-device transforms of the training pipeline
 # (configs/datamodule/semantic/default.yaml:206-290), on the NAG mirror of data.py

@@ -121,3 +121,41 @@ def test_inference_step_reproduces_the_training_forward(dev):
         l0 = float(st.step())
         l1 = float(st.step())
         assert l0 == l0 and l1 == l1 and l1 != l0       # finite, parameters moved
+
+
+def test_bf16_matrix_precision_mode(dev):
+    """cfg #2's `precision: bf16`: GEMM operands rounded to bf16 (f32 accumulate, everything
+    else f32).  Attention block against the reference fixture and a fused MLP against the f64
+    oracle at rtol 2e-2 of the tensor scale; the default mode is restored."""
+    from conftest import load_golden, t64, tl
+    from superpoint_transformer_amd import nn as N, precision
+    g = load_golden("attention_spt64.npz")
+    assert precision.get_matrix_precision() == "f32"
+    with precision.matrix_precision("bf16"):
+        blk = N.SelfAttentionBlock(64, num_heads=16, out_dim=64, qk_dim=4, in_rpe_dim=32,
+                                   k_rpe=True, q_rpe=True, v_rpe=True)
+        blk.load_state_dict({k[3:]: torch.from_numpy(v).float() for k, v in g.items()
+                             if k.startswith("p__")}, strict=True)
+        blk = blk.to(dev)
+        x = torch.from_numpy(g["x"]).float().to(dev).requires_grad_()
+        ea = torch.from_numpy(g["edge_attr"]).float().to(dev).requires_grad_()
+        out = blk(x, tl(g["edge_index"]).to(dev), edge_attr=ea)
+        (out * torch.from_numpy(g["gw"]).float().to(dev)).sum().backward()
+
+        def rel(a, r):
+            return ((a.detach().cpu().double() - r).abs().max() / r.abs().max()).item()
+        errs = {"out": rel(out, t64(g["out"])), "g_x": rel(x.grad, t64(g["g_x"])),
+                "g_ea": rel(ea.grad, t64(g["g_edge_attr"]))}
+        for k, p in blk.named_parameters():
+            if k.endswith("weight"):
+                errs[k] = rel(p.grad, t64(g["g__" + k]))
+        assert max(errs.values()) < 2e-2, errs
+        assert errs["out"] > 1e-5           # the mode really is bf16: well above f32 round-off
+
+        torch.manual_seed(0)
+        mlp = N.MLP([12, 32, 64, 128], norm=N.GraphNorm).to(dev)
+        xin = torch.randn(40000, 12, device=dev)
+        y = mlp(xin)
+        ref = OM.mlp(copy.deepcopy(mlp).double().cpu(), xin.cpu().double(), None, torch.float64)
+        assert ((y.detach().cpu().double() - ref).abs().max() / ref.abs().max()).item() < 2e-2
+    assert precision.get_matrix_precision() == "f32"

@@ -74,3 +74,32 @@ def test_fused_kernel_degenerate_edges(dev):
     # empty graph with self loops only
     ei, attr = T.horizontal_edge_features(se[:, :0].to(dev), ea[:0].to(dev), *[t.to(dev) for t in args[2:]])
     assert ei.shape == (2, n) and attr.abs().sum() == 0
+
+
+def _vertical_inputs(g):
+    def lv(pre):
+        return {k[len(pre):]: torch.from_numpy(v) for k, v in g.items() if k.startswith(pre)}
+    return lv("child__"), lv("parent__")
+
+
+def test_oracle_vertical_features_match_reference_function_output():
+    """graph.py:1335-1416 executed from the reference's source on levels 1 -> 2 of the demo room
+    (one child moved onto its parent's centroid: the 0/0 direction)."""
+    g = load_golden("vertical_edge_features.npz")
+    c, p = _vertical_inputs(g)
+    logs = ("log_length", "log_surface", "log_volume", "log_size")
+    out = O.vertical_edge_features(c["pos"], c["normal"], [c[k] for k in logs], p["pos"],
+                                   p["normal"], [p[k] for k in logs], c["super_index"])
+    torch.testing.assert_close(out, torch.from_numpy(g["v_edge_attr"]), rtol=1e-6, atol=1e-7)
+    assert out.shape[1] == 9 and not out.isnan().any()
+
+
+@pytest.mark.gpu
+def test_vertical_edge_feature_kernel_matches_reference_fixture(dev):
+    from superpoint_transformer_amd import transforms as T
+    g = load_golden("vertical_edge_features.npz")
+    c, p = _vertical_inputs(g)
+    out = T.vertical_edge_features({k: v.to(dev) for k, v in c.items()},
+                                   {k: v.to(dev) for k, v in p.items()})
+    torch.testing.assert_close(out.cpu(), torch.from_numpy(g["v_edge_attr"]), rtol=1e-6, atol=1e-7)
+    assert float(out[3, :3].abs().sum()) == 0.0          # the degenerate child: direction 0
