@@ -46,6 +46,10 @@ struct Vec<4> {
 #ifndef SPT_SEG_RPG_BIAS
 #define SPT_SEG_RPG_BIAS 0
 #endif
+// row ids of the next chunk in flight under the rows of the current one (see the kernel)
+#ifndef SPT_SEG_PIPE
+#define SPT_SEG_PIPE 0
+#endif
 
 template <int VEC>
 __device__ __forceinline__ Vec<VEC> ldv(const float* __restrict__ p) {
@@ -233,6 +237,46 @@ __global__ __launch_bounds__(256) void segcsr_reduce_kernel(
           t_bs[k] = cv ? af.bs[c0 + k] : 0.f;
         }
       }
+#if SPT_SEG_PIPE
+      // Row ids of the NEXT chunk are requested before the rows of the current one are waited
+      // for: the perm -> row dependency (two memory latencies per chunk of rpg * UNR rows) is
+      // taken off the critical path inside a segment.
+      {
+        int32_t rc[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          const int jj = start + rsub + u * rpg;
+          rc[u] = (jj < end) ? (perm ? perm[jj] : jj) : -1;
+        }
+        for (int j = start + rsub; j < end; j += rpg * UNR) {
+          Vec<VEC> v[UNR];
+#pragma unroll
+          for (int u = 0; u < UNR; ++u)
+            if (rc[u] >= 0 && cv) v[u] = ldv<VEC>(x + (int64_t)rc[u] * c + c0);
+          int32_t rn[UNR];
+#pragma unroll
+          for (int u = 0; u < UNR; ++u) {
+            const int jj = j + rpg * UNR + u * rpg;
+            rn[u] = (jj < end) ? (perm ? perm[jj] : jj) : -1;
+          }
+#pragma unroll
+          for (int u = 0; u < UNR; ++u)
+            if (rc[u] >= 0 && cv) {
+#pragma unroll
+              for (int k = 0; k < VEC; ++k) {
+                float val = v[u].v[k];
+                if constexpr (AFF) {
+                  val = fmaf(val - t_am[k], t_sc[k], t_bs[k]);
+                  val = leaky01 ? fmaxf(val, val * af.slope) : (val > 0.f ? val : val * af.slope);
+                }
+                combine<OP, ARG, A>(acc[k], accr[k], (A)val, rc[u]);
+              }
+            }
+#pragma unroll
+          for (int u = 0; u < UNR; ++u) rc[u] = rn[u];
+        }
+      }
+#else
       for (int j = start + rsub; j < end; j += rpg * UNR) {
         int32_t r[UNR];
         Vec<VEC> v[UNR];
@@ -259,6 +303,7 @@ __global__ __launch_bounds__(256) void segcsr_reduce_kernel(
             }
           }
       }
+#endif
       // tree across the RPG row slots of the group
       for (int o = lpr; o < (1 << g_log2); o <<= 1) {
 #pragma unroll
