@@ -814,3 +814,81 @@ def vertical_edge_features(child_pos, child_normal, child_logs, parent_pos, pare
     for pc, cc in zip(parent_logs, child_logs):
         cols.append((pc.view(-1)[idx] - cc.view(-1)).view(-1, 1))
     return torch.cat(cols, dim=1)
+
+
+# --------------------------------------------------------------------------
+# subedges: src/utils/graph.py:99-463
+# --------------------------------------------------------------------------
+
+
+def base_vectors_3d(x):
+    """src/utils/geometry.py:42-78."""
+    a = x.clone()
+    a[a.norm(dim=1) == 0] = torch.tensor([1.0, 0.0, 0.0], dtype=x.dtype)
+    a = a / a.norm(dim=1).view(-1, 1)
+    b = torch.stack((a[:, 1] - a[:, 2], a[:, 2] - a[:, 0], a[:, 0] - a[:, 1]), dim=1)
+    b[b.norm(dim=1) == 0] = torch.tensor([2.0, 1.0, -1.0], dtype=x.dtype)
+    b = b / b.norm(dim=1).view(-1, 1)
+    return torch.stack((a, b, torch.linalg.cross(a, b)), dim=1)
+
+
+def subedges(points, index, edge_index, ratio=0.2, k_min=20, cycles=3, margin=0.2,
+             halfspace_filter=True, bbox_filter=True, target_pc_flip=True):
+    """src/utils/graph.py:99-463 restated EDGE BY EDGE (the reference works on the edge-wise
+    expansion of all points; per edge the steps are: anchors -> local frame -> half-space filter
+    -> bounding-box filter (each never emptying a side) -> closest-to-anchor first -> top
+    max(ratio * size, k_min) on both sides, equal count -> first principal component of each
+    side -> target direction flipped against the source's -> both sides ordered along their
+    component and paired rank by rank).  Returns (edge_index, ST_pairs, ST_uid).
+
+    Not pinned by construction: the SIGN of the eigenvectors torch.linalg.eigh returns is
+    arbitrary, and graph.py:442 decides the target flip from it - so the pairing order of an
+    edge may legitimately differ between LAPACK builds; the selected point SETS do not."""
+    edge_index = to_trimmed(edge_index)
+    E = edge_index.shape[1]
+    anchors = scatter_nearest_neighbor(points, index, edge_index, cycles)
+    base = base_vectors_3d(points[anchors[1]] - points[anchors[0]])
+    order = torch.argsort(index, stable=True)
+    n = int(index.max()) + 1
+    ptr = torch.cat((torch.zeros(1, dtype=torch.long), torch.bincount(index, minlength=n))).cumsum(0)
+    S_out, T_out, U_out = [], [], []
+    for e in range(E):
+        s, t = int(edge_index[0, e]), int(edge_index[1, e])
+        sid, tid = order[ptr[s]:ptr[s + 1]], order[ptr[t]:ptr[t + 1]]
+        S = (points[sid] - points[anchors[0, e]]) @ base[e].t()
+        T = (points[tid] - points[anchors[1, e]]) @ base[e].t()
+
+        def keep(mask, P, I):
+            if not bool(mask.any()):
+                return P, I                                   # idx_preserving_mask
+            return P[mask], I[mask]
+        if halfspace_filter:
+            S, sid = keep(S[:, 0] <= margin, S, sid)
+            T, tid = keep(T[:, 0] >= -margin, T, tid)
+        if bbox_filter:
+            lo = torch.max(S[:, 1:].min(0).values, T[:, 1:].min(0).values).clamp(max=-margin)
+            hi = torch.min(S[:, 1:].max(0).values, T[:, 1:].max(0).values).clamp(min=margin)
+            S, sid = keep(((S[:, 1:] >= lo) & (S[:, 1:] <= hi)).all(1), S, sid)
+            T, tid = keep(((T[:, 1:] >= lo) & (T[:, 1:] <= hi)).all(1), T, tid)
+        ps = torch.argsort(S[:, 0], descending=True, stable=True)
+        pt = torch.argsort(T[:, 0], descending=False, stable=True)
+        S, sid, T, tid = S[ps], sid[ps], T[pt], tid[pt]
+        ks = min(max(int(S.shape[0] * ratio), k_min), S.shape[0])
+        kt = min(max(int(T.shape[0] * ratio), k_min), T.shape[0])
+        k = min(ks, kt)
+        S, sid, T, tid = S[:k], sid[:k], T[:k], tid[:k]
+        zeros = torch.zeros(k, dtype=torch.long)
+        s_v = scatter_pca(S, zeros, 1)[1][0, :, -1]
+        t_v = scatter_pca(T, zeros, 1)[1][0, :, -1]
+        if target_pc_flip:
+            t_min = T[(T @ t_v).argmin()]
+            st_u = t_min - S.mean(0)
+            st_u = st_u / st_u.norm()
+            if float(s_v @ t_v) <= float(s_v @ st_u):
+                t_v = -t_v
+        qs = torch.argsort((S - S.mean(0)) @ s_v, stable=True)
+        qt = torch.argsort((T - T.mean(0)) @ t_v, stable=True)
+        S_out.append(sid[qs])
+        T_out.append(tid[qt])
+        U_out.append(torch.full((k,), e, dtype=torch.long))
+    return edge_index, torch.vstack((torch.cat(S_out), torch.cat(T_out))), torch.cat(U_out)
