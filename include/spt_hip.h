@@ -203,6 +203,11 @@ size_t spt_edge_attn_bwd_workspace_bytes(int H, int D, int Dv, int F);
  * spt_attn_use_mfma(mode) selects process-wide and returns the previous mode; tests
  * cross-check all three at full scene size. */
 int spt_attn_use_mfma(int mode);
+/* Backward tiling of the bf16-pipe modes (2, 3): 1 (default) = 16-edge tiles over the edge
+ * stream, at most two consecutive source nodes per pass, tiles 100 % full (dq by atomicAdd: a
+ * node may be cut between two waves); 0 = one tile set per source node (62-69 % full at mean
+ * degree 16).  Same results up to f32 summation order.  Returns the previous setting. */
+int spt_attn_bwd_packed(int on);
 int spt_edge_attn_bwd_f32(const float* qkv, int64_t n, int H, int D, int Dv,
                           const int32_t* erowptr, const int32_t* eperm,
                           const int32_t* tgt_sorted, int64_t e,
@@ -508,6 +513,21 @@ int spt_fused_linear_bwd_f32(const float* gy, const float* h, int64_t r0, int64_
                              const float* pre_scale, const float* pre_bias, float pre_slope,
                              const float* W, float* gx, float* gW, int accumulate,
                              double* prev_total, void* ws, size_t ws_bytes, spt_stream_t stream);
+/* Backward of the TOP layer of a fused MLP whose output went through a segment max-pool
+ * (MaxPool(MLP(x)), nn/stage.py:429-431): the pool's gradient (gout [S,N], arg [S,N]) is consumed
+ * directly - rows are visited in the pool's CSR order (positions [p0, p1) of perm; pos_seg[j] =
+ * segment of position j), h / xprev rows gathered, gx rows scattered - so the dense [rows, N]
+ * gradient the pool's backward would write (and this layer read back) never exists.  Other
+ * arguments as spt_fused_linear_bwd_f32.  spt_fused_linear_pooled_supported: built shapes, under
+ * the current matrix mode (split-bf16 kernels only). */
+int spt_fused_linear_pooled_supported(int K, int N);
+int spt_fused_linear_bwd_pooled_f32(
+    const float* gout, const int32_t* arg, const int32_t* perm, const int32_t* pos_seg,
+    const float* h, int64_t p0, int64_t p1, int N, const float* am, const float* scale,
+    const float* bias, float slope, const float* c1, const float* c2, const float* c3,
+    const float* xprev, int K, const float* pre_am, const float* pre_scale, const float* pre_bias,
+    float pre_slope, const float* W, float* gx, float* gW, int accumulate, double* prev_total,
+    void* ws, size_t ws_bytes, spt_stream_t stream);
 
 #ifdef __cplusplus
 }

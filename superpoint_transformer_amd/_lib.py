@@ -40,6 +40,7 @@ SIGNATURES = {
                                      _p, _p, _p, _p, _p, _p, _int, _f32, _p, _p, _p, _p]),
     "spt_edge_attn_bwd_workspace_bytes": (_sz, [_int, _int, _int, _int]),
     "spt_attn_use_mfma": (_int, [_int]),
+    "spt_attn_bwd_packed": (_int, [_int]),
     "spt_edge_attn_bwd_f32": (_int, [_p, _i64, _int, _int, _int, _p, _p, _p, _i64, _p, _int,
                                      _p, _p, _p, _p, _p, _p, _int, _f32, _p, _p, _p, _p,
                                      _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
@@ -71,6 +72,10 @@ SIGNATURES = {
                                             _p, _p]),
     "spt_fused_linear_supported": (_int, [_int, _int]),
     "spt_fused_linear_use_split_bf16": (_int, [_int]),
+    "spt_fused_linear_pooled_supported": (_int, [_int, _int]),
+    "spt_fused_linear_bwd_pooled_f32": (_int, [_p, _p, _p, _p, _p, _i64, _i64, _int, _p, _p, _p, _f32,
+                                               _p, _p, _p, _p, _int, _p, _p, _p, _f32, _p, _p, _p,
+                                               _int, _p, _p, _sz, _p]),
     "spt_fused_linear_workspace_bytes": (_sz, [_int, _int]),
     "spt_fused_linear_fwd_f32": (_int, [_p, _i64, _i64, _int, _p, _int, _p, _p, _p, _f32, _p, _p,
                                         _p, _sz, _p]),

@@ -20,7 +20,7 @@ class SegmentCSR:
     """(perm, rowptr) view of ``idx``: rows of segment ``s`` are
     ``perm[rowptr[s]:rowptr[s+1]]`` in ascending original order."""
 
-    __slots__ = ("idx", "perm", "rowptr", "n", "num_seg")
+    __slots__ = ("idx", "perm", "rowptr", "n", "num_seg", "_pos_seg")
 
     def __init__(self, idx, perm, rowptr, n, num_seg):
         self.idx = idx
@@ -28,6 +28,13 @@ class SegmentCSR:
         self.rowptr = rowptr
         self.n = n
         self.num_seg = num_seg
+        self._pos_seg = None
+
+    def pos_seg(self):
+        """int32 [n]: segment of every CSR position (``idx[perm]``), built on first use."""
+        if self._pos_seg is None:
+            self._pos_seg = self.idx.index_select(0, self.perm.long()).to(torch.int32)
+        return self._pos_seg
 
     def counts(self):
         return (self.rowptr[1:] - self.rowptr[:-1])

@@ -758,7 +758,7 @@ int attn_bwd_mfma_launch(const float* qkv, int64_t n, const int32_t* erowptr,
                          const float* Wv, const float* bv, int scale_mode, float scale_a,
                          const float* out, const float* m, const float* z, const float* gout,
                          float* gqkv, float* gea, float* partial, int split_bf16,
-                         hipStream_t stream);
+                         int64_t e, int packed, hipStream_t stream);
 // 0: lane-per-output VALU kernels, 1: f32 matrix pipe (bitwise an fmaf chain), 2 (default):
 // split-bf16 on the bf16 matrix pipe (3 products per f32 product, ~10 ulp of f32), 3: plain
 // bf16 operands, f32 accumulate (the bf16 precision mode)
@@ -768,6 +768,8 @@ static int mfma_mode() {
   return g_attn_mfma;
 }
 static bool use_mfma() { return mfma_mode() != 0; }
+// backward tiles over the edge stream (1, default, bf16-pipe modes) or per node (0)
+static int g_attn_bwd_packed = 1;
 }  // namespace spt
 
 using namespace spt;
@@ -785,6 +787,12 @@ using namespace spt;
       return ::spt::fail(-4, "%s: unsupported attention shape H=%d D=%d Dv=%d F=%d " \
                          "(built: H*D<=128, H*Dv<=128, F in {18,32})", __func__, H, D, Dv, F); \
   } while (0)
+
+extern "C" int spt_attn_bwd_packed(int on) {
+  const int prev = g_attn_bwd_packed;
+  g_attn_bwd_packed = on ? 1 : 0;
+  return prev;
+}
 
 extern "C" int spt_attn_use_mfma(int mode) {
   const int prev = mfma_mode();
@@ -871,7 +879,8 @@ extern "C" int spt_edge_attn_bwd_f32(const float* qkv, int64_t n, int H, int D, 
     const int ntab = attn_bwd_mfma_launch(qkv, n, erowptr, eperm, tgt_sorted, edge_attr, Wk, bk,
                                           Wq, bq, Wv, bv, scale_mode, scale_a, out, m, z, gout,
                                           gqkv, gedge_attr, partial,
-                                          mfma_mode() == 2 ? 3 : (mfma_mode() == 3 ? 1 : 0), stream);
+                                          mfma_mode() == 2 ? 3 : (mfma_mode() == 3 ? 1 : 0), e,
+                                          g_attn_bwd_packed, stream);
     attn_reduce_partials_kernel<<<(int)ceil_div((int64_t)len, 16), 256, 0, stream>>>(
         partial, ntab, (int)len, total);
     attn_unpack_grads_kernel<<<(int)ceil_div((int64_t)len, 256), 256, 0, stream>>>(

@@ -612,24 +612,6 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attn_bwd_mfma_kernel(
     };
     fetch_node_rows(wave);
     float scale = 0.f;
-#if defined(SPT_BWD_DEFER_ATOMICS)
-    float pend_dk[NB][4], pend_dv[NB][4];
-    int64_t pend_row[4] = {-1, -1, -1, -1};
-    auto flush_pending = [&]() {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (pend_row[r] >= 0) {
-          float* row = gqkv + pend_row[r] + c;
-#pragma unroll
-          for (int b = 0; b < NB; ++b) {
-            unsafeAtomicAdd(row + 64 + 16 * b, pend_dk[b][r]);
-            unsafeAtomicAdd(row + 128 + 16 * b, pend_dv[b][r]);
-          }
-          pend_row[r] = -1;
-        }
-      }
-    };
-#endif
     while (P.cur.valid) {
       wait_vmem_all();
       float qraw[NB];
@@ -637,9 +619,6 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attn_bwd_mfma_kernel(
       for (int b = 0; b < NB; ++b) qraw[b] = P.q_nxt[b];
       const int e_cur = P.e_cur, t_cur = P.t_cur;
       P.top(lane);
-#if defined(SPT_BWD_DEFER_ATOMICS)
-      flush_pending();
-#endif
       const Tile cur = P.cur;
       const float* slab = P.cur_buf();
       const float* kslab = slab + EA_FLOATS;
@@ -729,20 +708,6 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attn_bwd_mfma_kernel(
         // dk / dv go to the target rows.  One branch per edge row r (validity depends on
         // (g, r) only) instead of one per (b, r): the 16 iterations above stay one basic
         // block the scheduler can interleave.
-#if defined(SPT_BWD_DEFER_ATOMICS)
-        // hold this tile's dk / dv: their atomics are issued at the top of the NEXT iteration,
-        // right after that tile's loads, so that they drain under a whole tile of compute
-        // instead of being waited for by the next wait_vmem_all()
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          pend_row[r] = (4 * g + r < cnt) ? trow[r] : -1;
-#pragma unroll
-          for (int b = 0; b < NB; ++b) {
-            pend_dk[b][r] = Ck[b][r];
-            pend_dv[b][r] = Cv[b][r];
-          }
-        }
-#elif !defined(SPT_BWD_NO_ATOMICS)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           if (4 * g + r < cnt) {
@@ -754,7 +719,6 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attn_bwd_mfma_kernel(
             }
           }
         }
-#endif
         // ---- d edge_attr = D W : D transposed through LDS (before dW: its stores and the
         //      atomics above then drain under the 96 MFMAs of the weight-gradient GEMM) ----
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -829,12 +793,10 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attn_bwd_mfma_kernel(
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int64_t e = __shfl(e_cur, 4 * g + r, 64);
-#if !defined(SPT_BWD_NO_GEA_STORE)
           if (4 * g + r < cnt) {
             gea[e * F + c] = C2[0][r];
             gea[e * F + 16 + c] = C2[1][r];
           }
-#endif
         }
         // ---- dW += D^T EA : A operand = the C-layout registers as they are ----------
         if constexpr (BF3) {
@@ -900,11 +862,434 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attn_bwd_mfma_kernel(
       }
       P.rotate();
     }
-#if defined(SPT_BWD_DEFER_ATOMICS)
-    flush_pending();
-#endif
   }
   // per-wave partial tables [192 rows][F + 1]: weight block + bias column
+  if (partial) {
+    float* pw = partial + (size_t)wave * 192 * (F + 1);
+#pragma unroll
+    for (int ob = 0; ob < 3 * NB; ++ob) {
+#pragma unroll
+      for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          pw[(size_t)(16 * ob + 4 * g + r) * (F + 1) + 16 * fb + c] = C3[ob][fb][r];
+      const float bsum = xg_sum(gb[ob]);
+      if (g == 0) pw[(size_t)(16 * ob + c) * (F + 1) + F] = bsum;
+    }
+  }
+}
+
+
+// =====================================================================================
+// Packed backward: 16-edge tiles over the EDGE stream, not per node.
+//
+// The kernels above give every source node its own tiles: at a mean degree of 16.4 a tile is
+// 62-69 % full (a node of degree 17 costs two tiles), and since the backward became VALU bound
+// (split-bf16) the empty rows are pure loss.  The backward does not need the running softmax
+// state of the forward - m and z of every node are saved - so nothing ties a tile to one node:
+// here tile t holds edges [16 t, 16 t + 16) of the CSR-by-source order, whatever nodes they
+// belong to.  A tile is processed in passes over at most TWO consecutive node contexts
+// (A = rows below `split`, B = rows from `split` on; per-row select of the node quantities);
+// tiles holding more than two nodes (rare: both of degree < 16 and a third one starting) run
+// another pass with the rows of the finished nodes masked.  A wave owns a contiguous range of
+// tiles: a node cut by a range boundary gets its dq from two waves, hence dq by atomicAdd
+// (gqkv is zero-filled by the entry point); dk / dv were atomic already.  The node owning a
+// wave's first edge comes from one binary search of the CSR pointers at the wave's start; from
+// there the nodes are walked in order.
+struct NodeCtx {
+  // ml = m + log(z + 1e-16): the softmax weight of an edge is exp(p - ml) (one value and one
+  // select per head instead of m and 1/z)
+  float qs[NB], g4[NB], delta[NB], ml[NB], dqa[NB];
+  float scale;
+  int64_t node;
+  int end;                                 // rp[node + 1]
+};
+
+template <int PREC>
+__global__ __launch_bounds__(WAVES * 64, 1) void attn_bwd_packed_kernel(
+    const float* __restrict__ qkv, int ld, int64_t N, int64_t E,
+    const int32_t* __restrict__ erowptr, const int32_t* __restrict__ eperm,
+    const int32_t* __restrict__ tgt, int64_t ntiles, const float* __restrict__ ea, const float* __restrict__ Wk, const float* __restrict__ bk,
+    const float* __restrict__ Wq, const float* __restrict__ bq, const float* __restrict__ Wv,
+    const float* __restrict__ bv, int scale_mode, float scale_a, const float* __restrict__ out,
+    const float* __restrict__ mbuf, const float* __restrict__ zbuf,
+    const float* __restrict__ gout, float* __restrict__ gqkv, float* __restrict__ gea,
+    float* __restrict__ partial) {
+  static_assert(PREC == 1 || PREC == 3, "bf16 matrix pipe only");
+  constexpr bool LO = PREC == 3;
+  __shared__ __attribute__((aligned(16))) float slab_all[WAVES][2][SLAB];
+  __shared__ __attribute__((aligned(16))) float dt_all[WAVES][DT_FLOATS];
+  __shared__ __attribute__((aligned(16))) __bf16 wb_hi[WB_ELEMS];
+  __shared__ __attribute__((aligned(16))) __bf16 wb_lo[WB_ELEMS];
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, c = lane & 15;
+  float* dt = dt_all[wid];
+  for (int i = threadIdx.x; i < 64 * F; i += WAVES * 64) {
+    const int n = i / F, f = i - n * F;
+    const float w3[3] = {Wk[i], Wq[i], Wv[i]};
+#pragma unroll
+    for (int p3 = 0; p3 < 3; ++p3) {
+      const __bf16 h = (__bf16)w3[p3];
+      wb_hi[(64 * p3 + n) * WB_LD + f] = h;
+      wb_lo[(64 * p3 + n) * WB_LD + f] = (__bf16)(w3[p3] - (float)h);
+    }
+  }
+  __syncthreads();
+  bf16x8 W2h[6][2], W2l[6][2];
+#pragma unroll
+  for (int sg = 0; sg < 6; ++sg)
+#pragma unroll
+    for (int fb = 0; fb < 2; ++fb) {
+      float w[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int o = 32 * sg + 8 * g + i;
+        const float* Wp = o < 64 ? Wk : (o < 128 ? Wq : Wv);
+        w[i] = Wp[(size_t)(o & 63) * F + 16 * fb + c];
+      }
+      split_bf16<8>(w, W2h[sg][fb], W2l[sg][fb]);
+    }
+  float bk4[NB], bq4[NB], bv4[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    bk4[b] = bk ? bk[16 * b + c] : 0.f;
+    bq4[b] = bq ? bq[16 * b + c] : 0.f;
+    bv4[b] = bv ? bv[16 * b + c] : 0.f;
+  }
+  f32x4 C3[3 * NB][2];
+  float gb[3 * NB];
+#pragma unroll
+  for (int ob = 0; ob < 3 * NB; ++ob) {
+    C3[ob][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    C3[ob][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    gb[ob] = 0.f;
+  }
+  for (int i = lane; i < 2 * SLAB; i += 64) (&slab_all[wid][0][0])[i] = 0.f;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+
+  const int64_t wave = (int64_t)blockIdx.x * WAVES + wid;
+  const int64_t nwaves = (int64_t)gridDim.x * WAVES;
+  const int64_t tpw = (ntiles + nwaves - 1) / nwaves;
+  const int64_t t_begin = wave * tpw;
+  const int64_t t_end = (t_begin + tpw < ntiles) ? t_begin + tpw : ntiles;
+  if (t_begin < t_end) {
+    // ---- node contexts ------------------------------------------------------------------
+    // A = the node owning the next unprocessed row (ready).  B = the node after it: its rows
+    // are requested as soon as A is known and land IN B's own fields (qs <- raw q, delta <- out
+    // row, ml <- m, dqa <- z), converted in place once they are there.  Converting right after
+    // the top-of-iteration wait is free; anywhere else the compiler's own vmcnt for those loads
+    // also waits for the tile DMA issued in between (it cannot see the asm loads): a stall, paid
+    // only when a tile holds a second node boundary.
+    NodeCtx A, B;
+    int b_rp0 = 0;                                      // rowptr[B.node] while B is raw
+    int b_state = 0;                                    // 0 none, 1 requested this iteration,
+                                                        // 2 requested earlier (landed), 3 ready
+    bool a_ready = false;
+    auto fetch_b = [&](int64_t nd) {
+      B.node = nd;
+      B.end = 0;
+      b_rp0 = 0;
+      if (nd < N) {
+        b_rp0 = erowptr[nd];
+        B.end = erowptr[nd + 1];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          B.qs[b] = qkv[nd * ld + 16 * b + c];
+          B.g4[b] = gout[nd * 64 + 16 * b + c];
+          B.delta[b] = out[nd * 64 + 16 * b + c];
+          B.ml[b] = mbuf[nd * 16 + 4 * b + (c >> 2)];
+          B.dqa[b] = zbuf[nd * 16 + 4 * b + (c >> 2)];
+        }
+      }
+      b_state = 1;
+    };
+    auto convert_b = [&]() {                            // raw rows -> context, in place
+      int s0 = __builtin_amdgcn_readfirstlane(b_rp0), s1 = __builtin_amdgcn_readfirstlane(B.end);
+      while (B.node < N && s1 == s0) {                  // nodes without edges own no row: skip
+        fetch_b(B.node + 1);
+        wait_vmem_all();
+        s0 = __builtin_amdgcn_readfirstlane(b_rp0);
+        s1 = __builtin_amdgcn_readfirstlane(B.end);
+      }
+      B.end = s1;
+      const int deg = s1 - s0;
+      B.scale = deg > 0 ? qk_scale_of(scale_mode, scale_a, deg) : 0.f;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        B.qs[b] = fmaf(B.qs[b], B.scale, bq4[b]);
+        B.delta[b] = quad_sum(B.g4[b] * B.delta[b]);
+        B.ml[b] = B.ml[b] + __logf(B.dqa[b] + 1e-16f);
+        B.dqa[b] = 0.f;
+      }
+      b_state = 3;
+    };
+    auto finish_node = [&](NodeCtx& X) {                // dq of a node whose last row is done
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const float dq = xg_sum(X.dqa[b]);
+        if (g == 0) unsafeAtomicAdd(gqkv + X.node * ld + 16 * b + c, dq * X.scale);
+      }
+    };
+    auto pop_node = [&]() {                              // A is finished: B takes over
+      if (b_state != 3) convert_b();
+      A = B;                                             // carries B's partial dq when it started
+      fetch_b(A.node + 1);
+    };
+    {
+      // node owning the wave's first edge: largest a with rowptr[a] <= e (then rowptr[a+1] > e)
+      const int e_first = (int)(t_begin * TE);
+      int64_t blo = 0, bhi = N;
+      while (bhi - blo > 1) {
+        const int64_t mid = (blo + bhi) >> 1;
+        if (__builtin_amdgcn_readfirstlane(erowptr[mid]) <= e_first) blo = mid; else bhi = mid;
+      }
+      fetch_b(blo);
+    }
+    // ---- tile pipeline: cur in LDS buffer bsel, nxt streaming into bsel ^ 1, indices of the
+    //      tile after that in VGPRs -----------------------------------------------------------
+    int bsel = 0;
+    int e_cur = 0, t_cur = 0, e_nxt = 0, t_nxt = 0, e_nn = 0, t_nn = 0;
+    auto cnt_of = [&](int64_t t) {
+      const int64_t r = E - t * TE;
+      return (int)(t < t_end ? (r < TE ? r : TE) : 0);
+    };
+    auto load_idx = [&](int64_t t, int& e_l, int& t_l) {
+      e_l = 0;
+      t_l = 0;
+      if (lane < cnt_of(t)) {
+        e_l = eperm ? eperm[t * TE + lane] : (int)(t * TE + lane);
+        t_l = tgt[t * TE + lane];
+      }
+    };
+    float* base = slab_all[wid][0];
+    load_idx(t_begin, e_cur, t_cur);
+    wait_vmem_all();
+    tile_issue(qkv, ld, ea, e_cur, t_cur, cnt_of(t_begin), base, lane);
+    load_idx(t_begin + 1, e_nxt, t_nxt);
+
+    for (int64_t t = t_begin; t < t_end; ++t) {
+      wait_vmem_all();                                   // tile t landed, indices of t + 1 too
+      if (!a_ready) {                                    // first iteration: the wave's first node
+        pop_node();
+        a_ready = true;
+      } else if (b_state == 1 || b_state == 2) {
+        convert_b();                                     // requested before this wait: landed
+      }
+      if (t + 1 < t_end)
+        tile_issue(qkv, ld, ea, e_nxt, t_nxt, cnt_of(t + 1), base + (bsel ^ 1) * SLAB, lane);
+      load_idx(t + 2, e_nn, t_nn);
+      const float* slab = base + bsel * SLAB;
+      const float* kslab = slab + EA_FLOATS;
+      const float* vslab = kslab + TE * ROW;
+      const int cnt = cnt_of(t);
+      const int e0 = (int)(t * TE);
+
+      // ---- recompute GEMM (context independent: q's node term is added per row below) ------
+      f32x4 Ck[NB], Cq[NB], Cv[NB];
+      {
+        bf16x8 Ah, Al;
+        load_a_bf(slab, g, c, Ah, Al);
+        const __bf16* wh = wb_hi + c * WB_LD + 8 * g;
+        const __bf16* wl = wb_lo + c * WB_LD + 8 * g;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          Ck[b] = (f32x4){bk4[b], bk4[b], bk4[b], bk4[b]};
+          Cq[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          Cv[b] = (f32x4){bv4[b], bv4[b], bv4[b], bv4[b]};
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const bf16x8 kh = *reinterpret_cast<const bf16x8*>(wh + (16 * b) * WB_LD);
+          const bf16x8 kl = *reinterpret_cast<const bf16x8*>(wl + (16 * b) * WB_LD);
+          const bf16x8 qh = *reinterpret_cast<const bf16x8*>(wh + (64 + 16 * b) * WB_LD);
+          const bf16x8 ql = *reinterpret_cast<const bf16x8*>(wl + (64 + 16 * b) * WB_LD);
+          const bf16x8 vh = *reinterpret_cast<const bf16x8*>(wh + (128 + 16 * b) * WB_LD);
+          const bf16x8 vl = *reinterpret_cast<const bf16x8*>(wl + (128 + 16 * b) * WB_LD);
+          if constexpr (LO) {
+            Ck[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, kh, Ck[b], 0, 0, 0);
+            Cq[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, qh, Cq[b], 0, 0, 0);
+            Cv[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, vh, Cv[b], 0, 0, 0);
+            Ck[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, kl, Ck[b], 0, 0, 0);
+            Cq[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, ql, Cq[b], 0, 0, 0);
+            Cv[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, vl, Cv[b], 0, 0, 0);
+          }
+          Ck[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, kh, Ck[b], 0, 0, 0);
+          Cq[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, qh, Cq[b], 0, 0, 0);
+          Cv[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, vh, Cv[b], 0, 0, 0);
+        }
+      }
+      // ---- per-edge gradients: rows below `split` belong to A, the rest (up to `hi`) to B;
+      //      more than two nodes in the tile -> further passes over the remaining rows ---------
+      const float* kp = kslab + 4 * g * ROW + c;
+      const float* vp = vslab + 4 * g * ROW + c;
+      // gradients replace (k, q, v) in place, row by row as the passes reach them: Ck <- dk,
+      // Cq <- dq, Cv <- dv (rows of a later pass keep their k / q / v until then)
+      int lo = 0;
+      while (lo < cnt) {
+        // A owns the row `lo`; B is needed when A ends inside the tile
+        int split = A.end - e0;                            // first row after A
+        split = split > cnt ? cnt : split;
+        int hi = cnt;
+        if (split < cnt) {
+          if (b_state != 3) convert_b();
+          hi = B.node < N ? B.end - e0 : cnt;              // first row after B
+          hi = hi > cnt ? cnt : hi;
+        }
+        if (hi <= lo) hi = cnt;                            // cannot happen: guarantees progress
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 4 * g + r;
+            const bool valid = row >= lo && row < hi;
+            const bool isB = row >= split;
+            const float qsr = isB ? B.qs[b] : A.qs[b];
+            const float mr = isB ? B.ml[b] : A.ml[b];
+            const float gr = isB ? B.g4[b] : A.g4[b];
+            const float dr = isB ? B.delta[b] : A.delta[b];
+            const float k = Ck[b][r] + kp[r * ROW + 16 * b];
+            const float q = Cq[b][r] + qsr;
+            const float v = Cv[b][r] + vp[r * ROW + 16 * b];
+            const float p = quad_sum(q * k);
+            const float a = valid ? __expf(p - mr) : 0.f;
+            const float da = quad_sum(gr * v);
+            const float dc = a * (da - dr);
+            const float dk = dc * q, dq = dc * k, dv = a * gr;
+            Ck[b][r] = valid ? dk : Ck[b][r];
+            Cq[b][r] = valid ? dq : Cq[b][r];
+            Cv[b][r] = valid ? dv : Cv[b][r];
+            A.dqa[b] += isB ? 0.f : dq;                    // a == 0 outside [lo, hi): adds 0
+            B.dqa[b] += isB ? dq : 0.f;
+          }
+        }
+        // node bookkeeping (wave-uniform)
+        if (A.end - e0 <= hi) {                            // A's last row is inside this pass
+          const bool b_started = hi > split;
+          finish_node(A);
+          pop_node();
+          if (b_started && A.end - e0 <= hi) {             // the next node ended in the pass too
+            finish_node(A);
+            pop_node();
+          }
+        }
+        lo = hi;
+      }
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (4 * g + r >= cnt) {                          // rows beyond the edge list (last tile)
+            Ck[b][r] = 0.f;
+            Cq[b][r] = 0.f;
+            Cv[b][r] = 0.f;
+          }
+          gb[b] += Ck[b][r];
+          gb[NB + b] += Cq[b][r];
+          gb[2 * NB + b] += Cv[b][r];
+        }
+      // dk / dv to the target rows
+      int64_t trow[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) trow[r] = (int64_t)__shfl(t_cur, 4 * g + r, 64) * ld;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (4 * g + r < cnt) {
+          float* row = gqkv + trow[r] + c;
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+            unsafeAtomicAdd(row + 64 + 16 * b, Ck[b][r]);
+            unsafeAtomicAdd(row + 128 + 16 * b, Cv[b][r]);
+          }
+        }
+      }
+      // ---- d edge_attr = D W ---------------------------------------------------------------
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float* row = dt + (4 * g + r) * DT_STRIDE + 16 * b + c;
+          row[0] = Ck[b][r];
+          row[64] = Cq[b][r];
+          row[128] = Cv[b][r];
+        }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      f32x4 C2[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+      {
+        const float* arow = dt + c * DT_STRIDE + 8 * g;
+#pragma unroll
+        for (int sg = 0; sg < 6; ++sg) {
+          const float4 d0 = *reinterpret_cast<const float4*>(arow + 32 * sg);
+          const float4 d1 = *reinterpret_cast<const float4*>(arow + 32 * sg + 4);
+          const float dd[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+          bf16x8 dh, dl;
+          split_bf16<8>(dd, dh, dl);
+#pragma unroll
+          for (int fb = 0; fb < 2; ++fb) {
+            if constexpr (LO) {
+              C2[fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dl, W2h[sg][fb], C2[fb], 0, 0, 0);
+              C2[fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dh, W2l[sg][fb], C2[fb], 0, 0, 0);
+            }
+            C2[fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dh, W2h[sg][fb], C2[fb], 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t e = __shfl(e_cur, 4 * g + r, 64);
+        if (4 * g + r < cnt) {
+          gea[e * F + c] = C2[0][r];
+          gea[e * F + 16 + c] = C2[1][r];
+        }
+      }
+      // ---- dW += D^T EA ------------------------------------------------------------------------
+      {
+        s16x4 Eh[2], El[2];
+#pragma unroll
+        for (int fb = 0; fb < 2; ++fb) {
+          float ev[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int e = 4 * g + r, f = 16 * fb + c;
+            ev[r] = slab[e * F + (((f >> 2) ^ (e & 7)) << 2) + (f & 3)];
+          }
+          bf16x4 eh, el;
+          split_bf16<4>(ev, eh, el);
+          Eh[fb] = __builtin_bit_cast(s16x4, eh);
+          El[fb] = __builtin_bit_cast(s16x4, el);
+        }
+#pragma unroll
+        for (int ob = 0; ob < 3 * NB; ++ob) {
+          const f32x4& Dsrc = ob < NB ? Ck[ob % NB] : (ob < 2 * NB ? Cq[ob % NB] : Cv[ob % NB]);
+          const float dv4[4] = {Dsrc[0], Dsrc[1], Dsrc[2], Dsrc[3]};
+          bf16x4 dh, dl;
+          split_bf16<4>(dv4, dh, dl);
+          const s16x4 Dh = __builtin_bit_cast(s16x4, dh), Dl = __builtin_bit_cast(s16x4, dl);
+#pragma unroll
+          for (int fb = 0; fb < 2; ++fb) {
+            if constexpr (LO) {
+              C3[ob][fb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(Dl, Eh[fb], C3[ob][fb], 0, 0, 0);
+              C3[ob][fb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(Dh, El[fb], C3[ob][fb], 0, 0, 0);
+            }
+            C3[ob][fb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(Dh, Eh[fb], C3[ob][fb], 0, 0, 0);
+          }
+        }
+      }
+      // rotate the pipeline
+      e_cur = e_nxt; t_cur = t_nxt;
+      e_nxt = e_nn; t_nxt = t_nn;
+      bsel ^= 1;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    }
+    // nodes left open at the end of the wave's range: their remaining rows belong to the next
+    // wave; what this wave accumulated goes out now
+    if (a_ready && A.node < N) finish_node(A);
+  }
   if (partial) {
     float* pw = partial + (size_t)wave * 192 * (F + 1);
 #pragma unroll
@@ -954,9 +1339,24 @@ int attn_bwd_mfma_launch(const float* qkv, int64_t n, const int32_t* erowptr,
                          const float* Wv, const float* bv, int scale_mode, float scale_a,
                          const float* out, const float* m, const float* z, const float* gout,
                          float* gqkv, float* gea, float* partial, int split_bf16,
-                         hipStream_t stream) {
+                         int64_t e, int packed, hipStream_t stream) {
   const int64_t blocks = ceil_div(n, mfma::WAVES);
   const int grid = (int)(blocks < ATTN_BWD_MFMA_BLOCKS ? blocks : ATTN_BWD_MFMA_BLOCKS);
+  if (packed && split_bf16 != 0 && e > 0) {
+    // tiles over the edge stream: every wave owns a contiguous range of 16-edge tiles
+    const int64_t ntiles = ceil_div(e, (int64_t)mfma::TE);
+    const int64_t pb = ceil_div(ntiles, mfma::WAVES);
+    const int pgrid = (int)(pb < ATTN_BWD_MFMA_BLOCKS ? pb : ATTN_BWD_MFMA_BLOCKS);
+    if (split_bf16 == 3)
+      mfma::attn_bwd_packed_kernel<3><<<pgrid, mfma::WAVES * 64, 0, stream>>>(
+          qkv, 192, n, e, erowptr, eperm, tgt, ntiles, ea, Wk, bk, Wq, bq, Wv, bv, scale_mode,
+          scale_a, out, m, z, gout, gqkv, gea, partial);
+    else
+      mfma::attn_bwd_packed_kernel<1><<<pgrid, mfma::WAVES * 64, 0, stream>>>(
+          qkv, 192, n, e, erowptr, eperm, tgt, ntiles, ea, Wk, bk, Wq, bq, Wv, bv, scale_mode,
+          scale_a, out, m, z, gout, gqkv, gea, partial);
+    return pgrid * mfma::WAVES;
+  }
   if (split_bf16 == 3)
     mfma::attn_bwd_mfma_kernel<3><<<grid, mfma::WAVES * 64, 0, stream>>>(
         qkv, 192, n, erowptr, eperm, tgt, ea, Wk, bk, Wq, bq, Wv, bv, scale_mode, scale_a, out, m,

@@ -43,16 +43,18 @@ __device__ __forceinline__ void wave_sync_lds() {
 // aligned vector loads, optionally applying v <- leaky((v - am[k]) * sc[k] + bs[k])
 // with the per-column tables read from LDS (tab = am | sc | bs, KT floats each).
 // Rows >= cnt and columns >= K become 0.  RAW != nullptr also keeps the raw values.
-template <int KP, int LD, int KT>
+// IND: the tile's rows are x[rid] with rid held by lane rr of `rid_l` (a gathered tile).
+template <int KP, int LD, int KT, bool IND = false>
 __device__ __forceinline__ void stage_tile(const float* __restrict__ x, int64_t row0, int cnt,
                                            int K, bool pre, const float* tab, float slope,
-                                           float* lds, float* raw, int lane) {
+                                           float* lds, float* raw, int lane, int rid_l = 0) {
   if ((K & 3) == 0) {
     const int CH = K >> 2;
     for (int q = lane; q < TR * CH; q += 64) {
       const int rr = q / CH, k = (q - rr * CH) << 2;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (rr < cnt) v = *reinterpret_cast<const float4*>(x + (row0 + rr) * K + k);
+      const int64_t xr = IND ? (int64_t)__shfl(rid_l, rr, 64) : row0 + rr;
+      if (rr < cnt) v = *reinterpret_cast<const float4*>(x + xr * K + k);
       if (raw) *reinterpret_cast<float4*>(raw + rr * LD + k) = v;
       if (pre && rr < cnt) {
         const float4 a = *reinterpret_cast<const float4*>(tab + k);
@@ -70,7 +72,8 @@ __device__ __forceinline__ void stage_tile(const float* __restrict__ x, int64_t 
     for (int q = lane; q < TR * KP; q += 64) {
       const int rr = q / KP, k = q - rr * KP;
       float v = 0.f;
-      if (rr < cnt && k < K) v = x[(row0 + rr) * K + k];
+      const int64_t xr = IND ? (int64_t)__shfl(rid_l, rr, 64) : row0 + rr;
+      if (rr < cnt && k < K) v = x[xr * K + k];
       if (raw) raw[rr * LD + k] = v;
       if (pre && rr < cnt && k < K) {
         v = fmaf(v - tab[k], tab[KT + k], tab[2 * KT + k]);
@@ -550,7 +553,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void fwd_kernel_bf(
 // tile: the 4 rows a lane group holds are one packed operand), gx = gh W as 16x16x32
 // products with W^T as split bf16 rows in LDS (wt[k][n], n contiguous: lane (g, c) reads the 8
 // values W[32 s + 8 g .. + 7][16 kb + c] with one 16-byte read each for hi and lo) ---------
-template <int K4, int NBK, bool NEED_GX, int NW, bool LO>
+// POOLED: gy is never materialised.  The layer's output went through a segment max-pool; its
+// gradient is gy[i, c] = gout[s, c] if arg[s, c] == i else 0 with s the segment of row i.  The
+// tiles then walk the rows in the CSR order of the pool (positions [r0, r1) of `perm`, segment
+// of a position in `pos_seg`): h / x_prev rows are gathered, gx rows scattered (whole rows), and
+// the (gout, arg) rows of a segment are read once per ~35 consecutive rows out of L1 / L2 -
+// instead of the pool's backward writing a dense [rows, N] tensor that this kernel reads back.
+template <int K4, int NBK, bool NEED_GX, int NW, bool LO, bool POOLED = false>
 __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_kernel_bf(
     const float* __restrict__ gy, const float* __restrict__ h, int64_t r0, int64_t r1,
     const float* __restrict__ am, const float* __restrict__ sc, const float* __restrict__ bs,
@@ -558,7 +567,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_kernel_bf(
     const float* __restrict__ c3, const float* __restrict__ xprev, int K,
     const float* __restrict__ pam, const float* __restrict__ psc, const float* __restrict__ pbs,
     float pslope, const float* __restrict__ W, float* __restrict__ gx,
-    float* __restrict__ gw_partial, double* __restrict__ pstat_partial) {
+    float* __restrict__ gw_partial, double* __restrict__ pstat_partial,
+    const int32_t* __restrict__ perm = nullptr, const int32_t* __restrict__ pos_seg = nullptr,
+    const float* __restrict__ gout = nullptr, const int32_t* __restrict__ arg = nullptr) {
   constexpr int KP = K4 * 4, KB = (KP + 15) / 16, KPP = KB * 16, N = NBK * 16;
   constexpr int NS = (N + 31) / 32, NP32 = NS * 32;
   constexpr int LDG = NP32 + 4, LDX = KPP + 4, LDT = NP32 + 8;
@@ -608,18 +619,50 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_kernel_bf(
   const int64_t ntiles = (r1 - r0 + TR - 1) / TR;
   const int64_t wave = (int64_t)blockIdx.x * NW + wid;
   const int64_t nwaves = (int64_t)gridDim.x * NW;
+  int rid_n = 0, seg_n = 0;
+  if constexpr (POOLED) {
+    const int64_t rowf = r0 + wave * TR;
+    if (rowf + lane < r1 && lane < TR) {
+      rid_n = perm[rowf + lane];
+      seg_n = pos_seg[rowf + lane];
+    }
+  }
   for (int64_t t = wave; t < ntiles; t += nwaves) {
     const int64_t row0 = r0 + t * TR;
     const int cnt = (int)((r1 - row0) < TR ? (r1 - row0) : TR);
     wave_sync_lds();
+    // POOLED: lane rr holds row id / segment of tile row rr; those of the wave's NEXT tile are
+    // requested now, so that the perm -> row dependency costs one memory latency per tile, not two
+    int rid_l = 0, seg_l = 0;
+    if constexpr (POOLED) {
+      rid_l = rid_n;
+      seg_l = seg_n;
+      const int64_t rown = row0 + nwaves * TR;
+      rid_n = seg_n = 0;
+      if (rown + lane < r1 && lane < TR) {
+        rid_n = perm[rown + lane];
+        seg_n = pos_seg[rown + lane];
+      }
+    }
     {
       constexpr int CH = N / 4;
       for (int q = lane; q < TR * CH; q += 64) {
         const int rr = q / CH, n = (q - rr * CH) << 2;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int rid = POOLED ? __shfl(rid_l, rr, 64) : 0;
+        const int64_t sg = POOLED ? (int64_t)__shfl(seg_l, rr, 64) : 0;
         if (rr < cnt) {
-          const float4 hv = *reinterpret_cast<const float4*>(h + (row0 + rr) * N + n);
-          const float4 gv = *reinterpret_cast<const float4*>(gy + (row0 + rr) * N + n);
+          const int64_t hr = POOLED ? (int64_t)rid : row0 + rr;
+          const float4 hv = *reinterpret_cast<const float4*>(h + hr * N + n);
+          float4 gv;
+          if constexpr (POOLED) {
+            const int4 a4 = *reinterpret_cast<const int4*>(arg + sg * N + n);
+            const float4 g4 = *reinterpret_cast<const float4*>(gout + sg * N + n);
+            gv = make_float4(a4.x == rid ? g4.x : 0.f, a4.y == rid ? g4.y : 0.f,
+                             a4.z == rid ? g4.z : 0.f, a4.w == rid ? g4.w : 0.f);
+          } else {
+            gv = *reinterpret_cast<const float4*>(gy + (row0 + rr) * N + n);
+          }
           const float4 a = *reinterpret_cast<const float4*>(gt + n);
           const float4 sc4 = *reinterpret_cast<const float4*>(gt + N + n);
           const float4 b4 = *reinterpret_cast<const float4*>(gt + 2 * N + n);
@@ -646,7 +689,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_kernel_bf(
         *reinterpret_cast<float4*>(gl + rr * LDG + n) = v;
       }
     }
-    stage_tile<KPP, LDX, KPP>(xprev, row0, cnt, K, false, pt, pslope, xl, nullptr, lane);
+    stage_tile<KPP, LDX, KPP, POOLED>(xprev, row0, cnt, K, false, pt, pslope, xl, nullptr, lane, rid_l);
     wave_sync_lds();
     // ---- gW += gh^T y_prev ------------------------------------------------------------
     {
@@ -700,13 +743,14 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_kernel_bf(
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int rr = 4 * g + r;
+        const int64_t orow = POOLED ? (int64_t)__shfl(rid_l, rr, 64) : row0 + rr;
         if (rr < cnt) {
 #pragma unroll
           for (int kb = 0; kb < KB; ++kb) {
             const int k = 16 * kb + c;
             if (k < K) {
               const float v = CX[kb][r];
-              gx[(row0 + rr) * K + k] = v;
+              gx[orow * K + k] = v;
               if (pre) {
                 const float o = xl[rr * LDX + k] - pt[k];
                 float gg = v;
@@ -748,27 +792,35 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_kernel_bf(
   }
 }
 
-// sums of per-wave tables, fixed order: 16 columns x 16 slices per block
+// sums of per-wave tables, fixed order: 16 columns x 64 slices per 1024-thread block (each
+// thread sums <= ntab / 64 partials, 4-way unrolled: the loop is pure load latency; the
+// 16-slice shape took 35-60 us per call, ~70 calls per train step at batch size)
 template <typename T>
-__global__ __launch_bounds__(256) void reduce_tables_kernel(const T* __restrict__ partial,
-                                                            int ntab, int len,
-                                                            T* __restrict__ total, int accumulate) {
-  __shared__ T sl[16][17];
+__global__ __launch_bounds__(1024) void reduce_tables_kernel(const T* __restrict__ partial,
+                                                             int ntab, int len,
+                                                             T* __restrict__ total, int accumulate) {
+  __shared__ T sl[64][17];
   const int cl = threadIdx.x & 15;
   const int col = blockIdx.x * 16 + cl;
   const int slice = threadIdx.x >> 4;
   T acc = 0;
   if (col < len) {
-    const int per = (ntab + 15) / 16;
+    const int per = (ntab + 63) / 64;
     const int lo = slice * per, hi = (lo + per < ntab) ? lo + per : ntab;
-    for (int k = lo; k < hi; ++k) acc += partial[(size_t)k * len + col];
+    int k = lo;
+    for (; k + 4 <= hi; k += 4) {
+      const T a0 = partial[(size_t)k * len + col], a1 = partial[(size_t)(k + 1) * len + col];
+      const T a2 = partial[(size_t)(k + 2) * len + col], a3 = partial[(size_t)(k + 3) * len + col];
+      acc += a0; acc += a1; acc += a2; acc += a3;           // same order as the plain loop
+    }
+    for (; k < hi; ++k) acc += partial[(size_t)k * len + col];
   }
   sl[slice][cl] = acc;
   __syncthreads();
   if (slice == 0 && col < len) {
     T t = 0;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) t += sl[k][cl];
+    for (int k = 0; k < 64; ++k) t += sl[k][cl];             // fixed order: deterministic
     total[col] = accumulate ? total[col] + t : t;
   }
 }
@@ -813,6 +865,18 @@ extern "C" int spt_fused_linear_use_split_bf16(int mode) {
   const int prev = g_fmlp_mode;
   g_fmlp_mode = mode < 0 ? 0 : (mode > 3 ? 3 : mode);
   return prev;
+}
+
+// top layers that exist in front of a max-pool: the point MLP's last layer (64 -> 128 semantic,
+// 64 -> 64 panoptic, 32 -> 64 for small MLPs)
+#define SPT_FMLP_POOLED_SHAPES(X) X(16, 8) X(16, 4) X(8, 4)
+extern "C" int spt_fused_linear_pooled_supported(int K, int N) {
+  const int k4 = (K + 3) / 4, nbk = N / 16;
+  if (N % 16 || g_fmlp_mode < 1) return 0;
+#define X(a, b) if (k4 == a && nbk == b) return 1;
+  SPT_FMLP_POOLED_SHAPES(X)
+#undef X
+  return 0;
 }
 
 extern "C" int spt_fused_linear_supported(int K, int N) {
@@ -864,8 +928,54 @@ extern "C" int spt_fused_linear_fwd_f32(const float* x, int64_t r0, int64_t r1, 
   }
   SPT_FMLP_SHAPES(X)
 #undef X
-  reduce_tables_kernel<double><<<(2 * N + 1 + 15) / 16, 256, 0, stream>>>(partial, grid, 2 * N + 1,
+  reduce_tables_kernel<double><<<(2 * N + 1 + 15) / 16, 1024, 0, stream>>>(partial, grid, 2 * N + 1,
                                                                            total, 0);
+  SPT_CHECK_LAUNCH();
+  return 0;
+}
+
+// Backward of the TOP layer when its output went through a segment max-pool (see POOLED above):
+// positions [p0, p1) of the pool's CSR order instead of a row range, (gout, arg) instead of gy.
+// Split-bf16 kernels only (mode >= 1); gx is required.
+extern "C" int spt_fused_linear_bwd_pooled_f32(
+    const float* gout, const int32_t* arg, const int32_t* perm, const int32_t* pos_seg,
+    const float* h, int64_t p0, int64_t p1, int N, const float* am, const float* scale,
+    const float* bias, float slope, const float* c1, const float* c2, const float* c3,
+    const float* xprev, int K, const float* pre_am, const float* pre_scale, const float* pre_bias,
+    float pre_slope, const float* W, float* gx, float* gW, int accumulate, double* prev_total,
+    void* ws, size_t ws_bytes, spt_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPT_CHECK_ARG(p1 >= p0 && K >= 1 && N >= 16, "bad shape");
+  SPT_CHECK_ARG(spt_fused_linear_pooled_supported(K, N), "(K, N) has no pooled kernel in this matrix mode");
+  SPT_CHECK_ARG(gout && arg && perm && pos_seg && h && am && scale && bias && c1 && c2 && c3 &&
+                xprev && W && gW && gx && ws, "null pointer");
+  SPT_CHECK_ARG(ws_bytes >= spt_fused_linear_workspace_bytes(K, N), "workspace too small");
+  SPT_CHECK_ARG(!prev_total || pre_am, "previous-layer statistics need its tables");
+  const int k4 = (K + 3) / 4, nbk = N / 16;
+  int grid = 1, nw = 1;
+  float* gwp = (float*)ws;
+  double* pst = (double*)((char*)ws + align_up((size_t)MAX_BWD_WAVES * N * K * 4, 256));
+#define X(a, b)                                                                                  \
+  if (k4 == a && nbk == b) {                                                                     \
+    constexpr bool big = (a * b >= 32);                                                          \
+    constexpr int NWB = (a * b > 128) ? 4 : (big ? 8 : 4);                                       \
+    grid = grid_for_nw(p1 - p0, (a * b > 128) ? 1 : (big ? ((a * b <= 32) ? 2 : 1) : 4), NWB);   \
+    nw = grid * NWB;                                                                             \
+    if (g_fmlp_mode == 3)                                                                        \
+      bwd_kernel_bf<a, b, true, NWB, false, true><<<grid, NWB * 64, 0, stream>>>(                \
+          nullptr, h, p0, p1, am, scale, bias, slope, c1, c2, c3, xprev, K, pre_am, pre_scale,   \
+          pre_bias, pre_slope, W, gx, gwp, prev_total ? pst : nullptr, perm, pos_seg, gout, arg); \
+    else                                                                                         \
+      bwd_kernel_bf<a, b, true, NWB, true, true><<<grid, NWB * 64, 0, stream>>>(                 \
+          nullptr, h, p0, p1, am, scale, bias, slope, c1, c2, c3, xprev, K, pre_am, pre_scale,   \
+          pre_bias, pre_slope, W, gx, gwp, prev_total ? pst : nullptr, perm, pos_seg, gout, arg); \
+  }
+  SPT_FMLP_POOLED_SHAPES(X)
+#undef X
+  reduce_tables_kernel<float><<<(N * K + 15) / 16, 1024, 0, stream>>>(gwp, nw, N * K, gW, accumulate);
+  if (prev_total)
+    reduce_tables_kernel<double><<<(2 * K + 1 + 15) / 16, 1024, 0, stream>>>(pst, nw, 2 * K + 1,
+                                                                            prev_total, 0);
   SPT_CHECK_LAUNCH();
   return 0;
 }
@@ -937,9 +1047,9 @@ extern "C" int spt_fused_linear_bwd_f32(const float* gy, const float* h, int64_t
   }
   SPT_FMLP_SHAPES(X)
 #undef X
-  reduce_tables_kernel<float><<<(N * K + 15) / 16, 256, 0, stream>>>(gwp, nw, N * K, gW, accumulate);
+  reduce_tables_kernel<float><<<(N * K + 15) / 16, 1024, 0, stream>>>(gwp, nw, N * K, gW, accumulate);
   if (prev_total)
-    reduce_tables_kernel<double><<<(2 * K + 1 + 15) / 16, 256, 0, stream>>>(pst, nw, 2 * K + 1,
+    reduce_tables_kernel<double><<<(2 * K + 1 + 15) / 16, 1024, 0, stream>>>(pst, nw, 2 * K + 1,
                                                                             prev_total, 0);
   SPT_CHECK_LAUNCH();
   return 0;

@@ -623,10 +623,12 @@ def _fmlp_forward(x, batch, ranges, eps_list, slope_list, params, apply_last=Tru
     return y, saved, hs[-1], (tabs[-1][2], tabs[-1][3], gnb[-1])
 
 
-def _fmlp_backward(saved, meta, gy, top_total=None):
+def _fmlp_backward(saved, meta, gy, top_total=None, pooled=None):
     """Backward of the fused layer chain from the gradient of its (normalised) output.
     ``top_total``: statistics of the top GraphNorm's backward when the caller already has
-    them (the max-pool route computes them from the pool's sparse gradient)."""
+    them (the max-pool route computes them from the pool's sparse gradient).
+    ``pooled = (gout, arg, csr)``: the top layer consumes the pool's gradient directly
+    (``spt_fused_linear_bwd_pooled_f32``), ``gy`` is then None."""
     L, ranges, slopes, in_dtype, need_gx0 = meta
     sv = list(saved)
     x2, batch = sv[0], sv[1]
@@ -638,7 +640,7 @@ def _fmlp_backward(saved, meta, gy, top_total=None):
     dev = x2.device
     B = len(ranges) - 1
     sp = _lib.stream_ptr(dev)
-    g_cur = gy.contiguous().float()
+    g_cur = gy.contiguous().float() if gy is not None else None
     grads = [None] * (4 * L)
     gx0 = None
     with torch.cuda.device(dev):
@@ -676,6 +678,19 @@ def _fmlp_backward(saved, meta, gy, top_total=None):
                 pa = ps = pb = None
                 if pre is not None:
                     pa, ps, pb = pre[2][g], pre[3][g], gnb[l - 1]
+                if pooled is not None and l == L - 1:
+                    p_gout, p_arg, p_csr = pooled
+                    st = _lib.lib.spt_fused_linear_bwd_pooled_f32(
+                        _lib.ptr(p_gout), _lib.ptr(p_arg), _lib.ptr(p_csr.perm),
+                        _lib.ptr(p_csr.pos_seg()), _lib.ptr(hs[l]), ranges[g], ranges[g + 1], N,
+                        _lib.ptr(am[g]), _lib.ptr(sc[g]), _lib.ptr(gnb[l]), float(slopes[l]),
+                        _lib.ptr(c1[g]), _lib.ptr(c2[g]), _lib.ptr(c3[g]), _lib.ptr(xprev), K,
+                        _lib.ptr(pa), _lib.ptr(ps), _lib.ptr(pb),
+                        float(slopes[l - 1]) if l else 1.0, _lib.ptr(Ws[l]), _lib.ptr(gx),
+                        _lib.ptr(gW), 1 if g else 0, _lib.ptr(ptot[g]) if l else None,
+                        _lib.ptr(ws), ws.numel(), sp)
+                    _lib.check(st, "spt_fused_linear_bwd_pooled_f32")
+                    continue
                 st = _lib.lib.spt_fused_linear_bwd_f32(
                     _lib.ptr(g_cur), _lib.ptr(hs[l]), ranges[g], ranges[g + 1], N,
                     _lib.ptr(am[g]), _lib.ptr(sc[g]), _lib.ptr(gnb[l]), float(slopes[l]),
@@ -765,8 +780,21 @@ class _FusedMLPMaxPool(torch.autograd.Function):
                     _lib.ptr(gnb_last), float(slopes[-1]), _lib.ptr(total), _lib.ptr(ws), nb,
                     _lib.stream_ptr(dev))
             _lib.check(st, "spt_graphnorm_bwd_stats_sparse_f32")
-        gy = _seg_reduce_bwd(gout, arg, ctx.csr, 3, R)
-        gx0, grads = _fmlp_backward(saved, ctx.meta, gy, top_total=total)
+        # The pool's gradient has one non-zero per (segment, channel): the top layer's backward
+        # reads (gout, arg) through the pool's CSR order instead of a dense [R, N] tensor.  Needs
+        # the top GraphNorm's statistics from the sparse route above, an input gradient (L > 1),
+        # a built shape, and - with several graphs - graph-contiguous CSR positions (segments
+        # numbered graph by graph, as NAG batches are).
+        K_top = saved[2 + 5 * L + (L - 1)].shape[1]
+        pooled_ok = (total is not None and L > 1
+                     and _lib.lib.spt_fused_linear_pooled_supported(int(K_top), int(N)) == 1
+                     and (B == 1 or graph_ranges(ctx.seg_graph, B, ctx.csr.num_seg) is not None))
+        if pooled_ok:
+            gx0, grads = _fmlp_backward(saved, ctx.meta, None, top_total=total,
+                                        pooled=(gout, arg, ctx.csr))
+        else:
+            gy = _seg_reduce_bwd(gout, arg, ctx.csr, 3, R)
+            gx0, grads = _fmlp_backward(saved, ctx.meta, gy, top_total=total)
         return (gx0, None, None, None, None, None, None, *grads)
 
 

@@ -220,3 +220,59 @@ def test_up_stage_matches_reference_fixture(dev):
         norm=N.GraphNorm, no_ffn=False, ffn_ratio=1, unpool="index", fusion="cat",
         use_pos=True, version_holder=N.VersionHolder("3.0.0"))
     _stage_case(g, stage, dev, "up")
+
+
+def _degree_graph(gen, degrees):
+    """Directed edges with prescribed out-degrees (targets random), shuffled."""
+    n = len(degrees)
+    src = torch.repeat_interleave(torch.arange(n), torch.tensor(degrees))
+    tgt = torch.randint(0, n, (src.numel(),), generator=gen)
+    p = torch.randperm(src.numel(), generator=gen)
+    return torch.stack([src[p], tgt[p]])
+
+
+@pytest.mark.parametrize("degrees", [
+    [1] * 40 + [2] * 30 + [3] * 20,                       # up to 16 nodes in one 16-edge tile
+    [0, 5, 0, 0, 7, 16, 0, 17, 1, 0, 31, 32, 33, 0, 2],   # edge-less nodes between the others
+    [16] * 12,                                            # every tile exactly one node
+    [15, 17] * 8 + [1, 100, 1, 3],                        # boundaries drifting through the tiles
+    [0] * 5 + [9] + [0] * 5,                              # a single node with edges
+])
+@pytest.mark.parametrize("packed", [1, 0])
+def test_attention_backward_tilings_match_oracle(degrees, packed, dev):
+    """The packed backward (16-edge tiles over the edge stream, two node contexts per pass,
+    extra passes when a tile holds more nodes) and the per-node tiling, against the f64
+    oracle on graphs built to hit the tile / node boundary cases."""
+    from superpoint_transformer_amd import _lib, nn as N
+    gen = torch.Generator().manual_seed(sum(degrees) + len(degrees))
+    n, H, D, dim, F = len(degrees), 16, 4, 64, 32
+    ei = _degree_graph(gen, degrees)
+    E = ei.shape[1]
+    blk = N.SelfAttentionBlock(dim, num_heads=H, out_dim=None, qk_dim=D, in_rpe_dim=F,
+                               k_rpe=True, q_rpe=True, v_rpe=True).to(dev)
+    x = torch.randn(n, dim, generator=gen)
+    ea = torch.randn(E, F, generator=gen) * 0.5
+    gw = torch.randn(n, dim, generator=gen)
+    prev = _lib.lib.spt_attn_bwd_packed(packed)
+    try:
+        xd = x.to(dev).requires_grad_()
+        ead = ea.to(dev).requires_grad_()
+        out = blk(xd, ei.to(dev), edge_attr=ead)
+        (out * gw.to(dev)).sum().backward()
+    finally:
+        _lib.lib.spt_attn_bwd_packed(prev)
+    p = {k: v.detach().cpu().double().requires_grad_() for k, v in blk.named_parameters()}
+    x64, ea64 = x.double().requires_grad_(), ea.double().requires_grad_()
+    deg = torch.tensor(degrees).double().clamp(min=1)
+    old = O.qk_scale_dg
+    O.qk_scale_dg = lambda s, d_, h_: ((dim // H) ** -0.5 * deg[s] ** -0.5).view(-1, 1, 1)
+    try:
+        ref = O.self_attention(x64, ei, ea64, p, H, D)
+    finally:
+        O.qk_scale_dg = old
+    (ref * gw.double()).sum().backward()
+    _check(out, ref, "out")
+    _check(xd.grad, x64.grad, "g_x")
+    _check(ead.grad, ea64.grad, "g_edge_attr")
+    for k, v in blk.named_parameters():
+        _check(v.grad, p[k].grad, "g_" + k, rel_to_max=True)

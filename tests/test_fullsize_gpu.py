@@ -29,18 +29,23 @@ def test_attention_two_formulations_agree_at_scene_scale(dev):
     res = {}
     prev = _lib.lib.spt_attn_use_mfma(2)
     try:
-        for mode in (2, 1, 0):   # split-bf16 matrix pipe (default), f32 matrix pipe, VALU
-            _lib.lib.spt_attn_use_mfma(mode)
+        # 2 = split-bf16 matrix pipe with the packed backward (default), 12 = the same with the
+        # per-node backward tiling, 1 = f32 matrix pipe, 0 = VALU
+        for mode in (2, 12, 1, 0):
+            packed_prev = _lib.lib.spt_attn_bwd_packed(0 if mode == 12 else 1)
+            mode_set = 2 if mode == 12 else mode
+            _lib.lib.spt_attn_use_mfma(mode_set)
             q = qkv.clone().requires_grad_()
             a = ea.clone().requires_grad_()
             ws = [(w.clone().requires_grad_(), b.clone().requires_grad_()) for w, b in W]
             out = ops.edge_attention(q, ei, a, *ws, num_heads=H, qk_dim=D, scale_a=0.5)
             out.backward(gw)
             res[mode] = (out.detach(), q.grad, a.grad, [w.grad for w, _ in ws], [b.grad for _, b in ws])
+            _lib.lib.spt_attn_bwd_packed(packed_prev)
     finally:
         _lib.lib.spt_attn_use_mfma(prev)
     v = res[0]
-    for mode in (2, 1):
+    for mode in (2, 12, 1):
         m = res[mode]
         torch.testing.assert_close(m[0], v[0], rtol=1e-4, atol=1e-5)
         # d edge_attr = D W: the split-bf16 error is relative to sum |d||w| (~6e-6 of it), not

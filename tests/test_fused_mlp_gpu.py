@@ -157,5 +157,8 @@ def test_mlp_folded_into_the_max_pool_equals_mlp_then_pool(rows, nseg, B, dev):
     ou, gxu, gpu_ = run(False)
     assert torch.equal(of, ou)
     assert torch.allclose(gxf, gxu, rtol=1e-5, atol=1e-6 * float(gxu.abs().max()))
+    # the folded route's top layer walks the rows in the pool's CSR order (the pool's gradient
+    # is consumed directly): its weight gradient is the same f32 sum over 4e4-5e4 rows in another
+    # order
     for a, b in zip(gpf, gpu_):
-        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6 * float(b.abs().max()))
+        assert torch.allclose(a, b, rtol=1e-4, atol=2e-5 * float(b.abs().max()))
