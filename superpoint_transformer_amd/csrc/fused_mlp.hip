@@ -559,7 +559,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void fwd_kernel_bf(
 // of a position in `pos_seg`): h / x_prev rows are gathered, gx rows scattered (whole rows), and
 // the (gout, arg) rows of a segment are read once per ~35 consecutive rows out of L1 / L2 -
 // instead of the pool's backward writing a dense [rows, N] tensor that this kernel reads back.
-template <int K4, int NBK, bool NEED_GX, int NW, bool LO, bool POOLED = false>
+// PIPE: the raw rows of the wave's NEXT tile (h, gy or gout/arg, x_prev) are requested into
+// registers right after the current tile has been staged into LDS, so that they travel while
+// the tile's GEMMs run; without it the 8-12 loads a lane issues per tile are consumed one
+// round trip after the other (the staging loop is load -> transform -> ds_write) and the kernel
+// is bound by memory LATENCY (937 k tiles x ~14 us / 2 048 waves = 6.4 ms at 64 -> 128), not by
+// bandwidth.  Needs K % 4 == 0 (16-byte row chunks) and one wave per SIMD (the prefetch
+// registers do not fit twice into 256).
+template <int K4, int NBK, bool NEED_GX, int NW, bool LO, bool POOLED = false, bool PIPE = false>
 __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_kernel_bf(
     const float* __restrict__ gy, const float* __restrict__ h, int64_t r0, int64_t r1,
     const float* __restrict__ am, const float* __restrict__ sc, const float* __restrict__ bs,
@@ -619,33 +626,106 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_kernel_bf(
   const int64_t ntiles = (r1 - r0 + TR - 1) / TR;
   const int64_t wave = (int64_t)blockIdx.x * NW + wid;
   const int64_t nwaves = (int64_t)gridDim.x * NW;
-  int rid_n = 0, seg_n = 0;
-  if constexpr (POOLED) {
-    const int64_t rowf = r0 + wave * TR;
-    if (rowf + lane < r1 && lane < TR) {
-      rid_n = perm[rowf + lane];
-      seg_n = pos_seg[rowf + lane];
+  // gh[rr][n..n+3] from (h, g) of one 16-byte chunk; g = gy, or the pool's gradient routed to
+  // the arg row
+  auto gh_of = [&](const float4& hv, const float4& gv, int n) {
+    const float4 a = *reinterpret_cast<const float4*>(gt + n);
+    const float4 sc4 = *reinterpret_cast<const float4*>(gt + N + n);
+    const float4 b4 = *reinterpret_cast<const float4*>(gt + 2 * N + n);
+    const float4 k1 = *reinterpret_cast<const float4*>(gt + 3 * N + n);
+    const float4 k2 = *reinterpret_cast<const float4*>(gt + 4 * N + n);
+    const float4 k3 = *reinterpret_cast<const float4*>(gt + 5 * N + n);
+    const float hh[4] = {hv.x, hv.y, hv.z, hv.w}, gg4[4] = {gv.x, gv.y, gv.z, gv.w};
+    const float aa[4] = {a.x, a.y, a.z, a.w}, ss[4] = {sc4.x, sc4.y, sc4.z, sc4.w};
+    const float bb[4] = {b4.x, b4.y, b4.z, b4.w}, q1[4] = {k1.x, k1.y, k1.z, k1.w};
+    const float q2[4] = {k2.x, k2.y, k2.z, k2.w}, q3[4] = {k3.x, k3.y, k3.z, k3.w};
+    float o4[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float o = hh[e] - aa[e];
+      float gg = gg4[e];
+      if (slope != 1.f) {
+        const float y = fmaf(o, ss[e], bb[e]);
+        gg = (y > 0.f) ? gg : gg * slope;
+      }
+      o4[e] = fmaf(q1[e], gg, -fmaf(q2[e], o, q3[e]));
     }
+    return make_float4(o4[0], o4[1], o4[2], o4[3]);
+  };
+  constexpr int CH = N / 4, CHX = KPP / 4;
+  constexpr int HN = PIPE ? TR * CH / 64 : 1, XN = PIPE ? TR * CHX / 64 : 1;
+  float4 p_h[HN], p_g[HN], p_x[XN];          // PIPE: raw chunks of the tile about to be staged
+  int4 p_a[(PIPE && POOLED) ? HN : 1];
+  int rid_n = 0, seg_n = 0;                   // POOLED: row id / segment of the NEXT tile's rows
+  auto load_ids = [&](int64_t t) {
+    rid_n = seg_n = 0;
+    if constexpr (POOLED) {
+      const int64_t rowf = r0 + t * TR;
+      if (t < ntiles && rowf + lane < r1 && lane < TR) {
+        rid_n = perm[rowf + lane];
+        seg_n = pos_seg[rowf + lane];
+      }
+    }
+  };
+  auto load_raw = [&](int64_t t, int rid_l, int seg_l) {   // PIPE only
+    const int64_t row0 = r0 + t * TR;
+    const int cnt = (t < ntiles) ? (int)((r1 - row0) < TR ? (r1 - row0) : TR) : 0;
+#pragma unroll
+    for (int i = 0; i < HN; ++i) {
+      const int q = lane + 64 * i, rr = q / CH, n = (q - rr * CH) << 2;
+      const int rid = POOLED ? __shfl(rid_l, rr, 64) : 0;
+      const int64_t sg = POOLED ? (int64_t)__shfl(seg_l, rr, 64) : 0;
+      p_h[i] = p_g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (rr < cnt) {
+        const int64_t hr = POOLED ? (int64_t)rid : row0 + rr;
+        p_h[i] = *reinterpret_cast<const float4*>(h + hr * N + n);
+        if constexpr (POOLED) {
+          p_a[i] = *reinterpret_cast<const int4*>(arg + sg * N + n);
+          p_g[i] = *reinterpret_cast<const float4*>(gout + sg * N + n);
+        } else {
+          p_g[i] = *reinterpret_cast<const float4*>(gy + (row0 + rr) * N + n);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < XN; ++i) {
+      const int q = lane + 64 * i, rr = q / CHX, k = (q - rr * CHX) << 2;
+      const int64_t xr = POOLED ? (int64_t)__shfl(rid_l, rr, 64) : row0 + rr;
+      p_x[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (rr < cnt && k < K) p_x[i] = *reinterpret_cast<const float4*>(xprev + xr * K + k);
+    }
+  };
+  load_ids(wave);
+  if constexpr (PIPE) {
+    load_raw(wave, rid_n, seg_n);
   }
+  int rid_l = rid_n, seg_l = seg_n;
+  load_ids(wave + nwaves);
   for (int64_t t = wave; t < ntiles; t += nwaves) {
     const int64_t row0 = r0 + t * TR;
     const int cnt = (int)((r1 - row0) < TR ? (r1 - row0) : TR);
     wave_sync_lds();
-    // POOLED: lane rr holds row id / segment of tile row rr; those of the wave's NEXT tile are
-    // requested now, so that the perm -> row dependency costs one memory latency per tile, not two
-    int rid_l = 0, seg_l = 0;
-    if constexpr (POOLED) {
-      rid_l = rid_n;
-      seg_l = seg_n;
-      const int64_t rown = row0 + nwaves * TR;
-      rid_n = seg_n = 0;
-      if (rown + lane < r1 && lane < TR) {
-        rid_n = perm[rown + lane];
-        seg_n = pos_seg[rown + lane];
+    if constexpr (PIPE) {
+      // stage the prefetched chunks, then request the next tile's while this one computes
+#pragma unroll
+      for (int i = 0; i < HN; ++i) {
+        const int q = lane + 64 * i, rr = q / CH, n = (q - rr * CH) << 2;
+        float4 gv = p_g[i];
+        if constexpr (POOLED) {
+          const int rid = __shfl(rid_l, rr, 64);
+          gv = make_float4(p_a[i].x == rid ? gv.x : 0.f, p_a[i].y == rid ? gv.y : 0.f,
+                           p_a[i].z == rid ? gv.z : 0.f, p_a[i].w == rid ? gv.w : 0.f);
+        }
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rr < cnt) v = gh_of(p_h[i], gv, n);
+        *reinterpret_cast<float4*>(gl + rr * LDG + n) = v;
       }
-    }
-    {
-      constexpr int CH = N / 4;
+#pragma unroll
+      for (int i = 0; i < XN; ++i) {
+        const int q = lane + 64 * i, rr = q / CHX, k = (q - rr * CHX) << 2;
+        *reinterpret_cast<float4*>(xl + rr * LDX + k) = p_x[i];
+      }
+    } else {
       for (int q = lane; q < TR * CH; q += 64) {
         const int rr = q / CH, n = (q - rr * CH) << 2;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -663,33 +743,17 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_kernel_bf(
           } else {
             gv = *reinterpret_cast<const float4*>(gy + (row0 + rr) * N + n);
           }
-          const float4 a = *reinterpret_cast<const float4*>(gt + n);
-          const float4 sc4 = *reinterpret_cast<const float4*>(gt + N + n);
-          const float4 b4 = *reinterpret_cast<const float4*>(gt + 2 * N + n);
-          const float4 k1 = *reinterpret_cast<const float4*>(gt + 3 * N + n);
-          const float4 k2 = *reinterpret_cast<const float4*>(gt + 4 * N + n);
-          const float4 k3 = *reinterpret_cast<const float4*>(gt + 5 * N + n);
-          const float hh[4] = {hv.x, hv.y, hv.z, hv.w}, gg4[4] = {gv.x, gv.y, gv.z, gv.w};
-          const float aa[4] = {a.x, a.y, a.z, a.w}, ss[4] = {sc4.x, sc4.y, sc4.z, sc4.w};
-          const float bb[4] = {b4.x, b4.y, b4.z, b4.w}, q1[4] = {k1.x, k1.y, k1.z, k1.w};
-          const float q2[4] = {k2.x, k2.y, k2.z, k2.w}, q3[4] = {k3.x, k3.y, k3.z, k3.w};
-          float o4[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float o = hh[e] - aa[e];
-            float gg = gg4[e];
-            if (slope != 1.f) {
-              const float y = fmaf(o, ss[e], bb[e]);
-              gg = (y > 0.f) ? gg : gg * slope;
-            }
-            o4[e] = fmaf(q1[e], gg, -fmaf(q2[e], o, q3[e]));
-          }
-          v = make_float4(o4[0], o4[1], o4[2], o4[3]);
+          v = gh_of(hv, gv, n);
         }
         *reinterpret_cast<float4*>(gl + rr * LDG + n) = v;
       }
+      stage_tile<KPP, LDX, KPP, POOLED>(xprev, row0, cnt, K, false, pt, pslope, xl, nullptr, lane, rid_l);
     }
-    stage_tile<KPP, LDX, KPP, POOLED>(xprev, row0, cnt, K, false, pt, pslope, xl, nullptr, lane, rid_l);
+    const int rid_cur = rid_l;                 // the gx scatter below needs this tile's row ids
+    if constexpr (PIPE) load_raw(t + nwaves, rid_n, seg_n);
+    rid_l = rid_n;
+    seg_l = seg_n;
+    load_ids(t + 2 * nwaves);
     wave_sync_lds();
     // ---- gW += gh^T y_prev ------------------------------------------------------------
     {
@@ -743,7 +807,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_kernel_bf(
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int rr = 4 * g + r;
-        const int64_t orow = POOLED ? (int64_t)__shfl(rid_l, rr, 64) : row0 + rr;
+        const int64_t orow = POOLED ? (int64_t)__shfl(rid_cur, rr, 64) : row0 + rr;
         if (rr < cnt) {
 #pragma unroll
           for (int kb = 0; kb < KB; ++kb) {
@@ -957,6 +1021,8 @@ extern "C" int spt_fused_linear_bwd_pooled_f32(
   double* pst = (double*)((char*)ws + align_up((size_t)MAX_BWD_WAVES * N * K * 4, 256));
 #define X(a, b)                                                                                  \
   if (k4 == a && nbk == b) {                                                                     \
+    /* (the register-prefetch variant PIPE = true measured slower: 7.3 vs 6.7 ms at 64 -> 128; */ \
+    /* at one wave per SIMD nothing overlaps the ~1 450 VALU instructions per tile)            */ \
     constexpr bool big = (a * b >= 32);                                                          \
     constexpr int NWB = (a * b > 128) ? 4 : (big ? 8 : 4);                                       \
     grid = grid_for_nw(p1 - p0, (a * b > 128) ? 1 : (big ? ((a * b <= 32) ? 2 : 1) : 4), NWB);   \
