@@ -253,6 +253,16 @@ int spt_grid_knn_f32(const float* query, int64_t nq, const float* search, int64_
                      const int32_t* dims, int order_queries_by_cell, int inclusive,
                      int squared, int64_t* idx, float* dist, int32_t* cell_order, void* ws,
                      size_t ws_bytes, spt_stream_t stream);
+/* Continuation of a search: for every query the K search points ranked strictly AFTER
+ * (after_d2[q], after_idx[q]) in the contract's (squared distance, index) order - chained after a
+ * K = 64 call it returns neighbours 65..128, which lifts the 64-per-call limit of the kernels
+ * (cluster_radius_nn_graph's k_max = 100, src/utils/neighbors.py:491).  after_idx[q] < 0 = the
+ * previous list was not full: nothing left (all -1).  after_d2 is SQUARED whatever `squared`. */
+int spt_grid_knn_after_f32(const float* query, int64_t nq, const float* search, int64_t ns, int K,
+                           float r, float cell_size, const float* origin, const int32_t* dims,
+                           int inclusive, int squared, const int64_t* after_idx,
+                           const float* after_d2, int64_t* idx, float* dist, void* ws,
+                           size_t ws_bytes, spt_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Point geometric features                                          (a11-a14)

@@ -159,7 +159,8 @@ __device__ __forceinline__ void knn_flush(KnnState& st, uint64_t* pend, int K, i
 __device__ __forceinline__ void knn_scan(KnnState& st, uint64_t* pend,
                                          const float4* __restrict__ sorted, int start,
                                          int len, float qx, float qy, float qz, float r2,
-                                         bool inclusive, int K, int lane) {
+                                         bool inclusive, int K, int lane, uint64_t lb = 0,
+                                         bool has_lb = false) {
   for (int b = 0; b < len; b += 64) {
     const int j = b + lane;
     uint64_t key = KNN_EMPTY;
@@ -169,6 +170,8 @@ __device__ __forceinline__ void knn_scan(KnnState& st, uint64_t* pend,
       const float d2 = (ddx * ddx + ddy * ddy) + ddz * ddz;  // -ffp-contract=off: no fma
       const bool in = inclusive ? (d2 <= r2) : (d2 < r2);
       if (in) key = ((uint64_t)__float_as_uint(d2) << 32) | (uint32_t)__float_as_int(p.w);
+      // continuation search: only neighbours strictly after (d2, index) = lb
+      if (has_lb && key <= lb) key = KNN_EMPTY;
     }
     const bool acc = key < st.kth;
     const uint64_t m = __ballot(acc);
@@ -187,7 +190,9 @@ __global__ __launch_bounds__(KNN_WAVES * 64) void knn_search_kernel(
     const float* __restrict__ query, int64_t nq, const int32_t* __restrict__ qorder,
     const float4* __restrict__ sorted, const int32_t* __restrict__ rowptr, Grid g, int K,
     float r, int inclusive, int squared, int64_t* __restrict__ out_idx,
-    float* __restrict__ out_dist, const int32_t* __restrict__ nq_dev) {
+    float* __restrict__ out_dist, const int32_t* __restrict__ nq_dev,
+    const int64_t* __restrict__ after_idx = nullptr,
+    const float* __restrict__ after_d2 = nullptr) {
   __shared__ uint64_t pend_all[KNN_WAVES][64];
   if (nq_dev) nq = *nq_dev;          // leftovers of knn_cell_kernel: the count lives on the device
   const int lane = threadIdx.x & 63;
@@ -207,6 +212,15 @@ __global__ __launch_bounds__(KNN_WAVES * 64) void knn_search_kernel(
     st.best = KNN_EMPTY;
     st.kth = KNN_EMPTY;
     st.npend = 0;
+    // continuation (spt_grid_knn_after_f32): neighbours ranked strictly after the given one;
+    // a query whose previous list was not full (index -1) has nothing left
+    const bool has_lb = after_idx != nullptr;
+    uint64_t lb = 0;
+    if (has_lb) {
+      const int64_t ai = after_idx[qi];
+      lb = ai < 0 ? KNN_EMPTY - 1
+                  : (((uint64_t)__float_as_uint(after_d2[qi]) << 32) | (uint32_t)ai);
+    }
 
     for (int rho = 0;; ++rho) {
       if (rho > 1) {
@@ -263,14 +277,14 @@ __global__ __launch_bounds__(KNN_WAVES * 64) void knn_search_kernel(
           const int l = __ffsll((unsigned long long)mA) - 1;
           mA &= mA - 1;
           knn_scan(st, pend, sorted, __shfl(sA, l, 64), __shfl(lA, l, 64), qx, qy, qz, r2,
-                   inclusive != 0, K, lane);
+                   inclusive != 0, K, lane, lb, has_lb);
         }
         uint64_t mB = __ballot(lB > 0);
         while (mB) {
           const int l = __ffsll((unsigned long long)mB) - 1;
           mB &= mB - 1;
           knn_scan(st, pend, sorted, __shfl(sB, l, 64), __shfl(lB, l, 64), qx, qy, qz, r2,
-                   inclusive != 0, K, lane);
+                   inclusive != 0, K, lane, lb, has_lb);
         }
       }
     }
@@ -653,12 +667,45 @@ extern "C" size_t spt_grid_knn_workspace_bytes(int64_t ns, int64_t ncells) {
   return knn_plan(ns, ncells).total;
 }
 
+static int grid_knn_impl(const float* query, int64_t nq, const float* search, int64_t ns, int K,
+                         float r, float cell_size, const float* origin, const int32_t* dims,
+                         int order_queries_by_cell, int inclusive, int squared,
+                         const int64_t* after_idx, const float* after_d2, int64_t* idx,
+                         float* dist, int32_t* cell_order, void* ws, size_t ws_bytes,
+                         spt_stream_t stream_);
+
 extern "C" int spt_grid_knn_f32(const float* query, int64_t nq, const float* search,
                                 int64_t ns, int K, float r, float cell_size,
                                 const float* origin, const int32_t* dims,
                                 int order_queries_by_cell, int inclusive, int squared,
                                 int64_t* idx, float* dist, int32_t* cell_order, void* ws,
                                 size_t ws_bytes, spt_stream_t stream_) {
+  return grid_knn_impl(query, nq, search, ns, K, r, cell_size, origin, dims,
+                       order_queries_by_cell, inclusive, squared, nullptr, nullptr, idx, dist,
+                       cell_order, ws, ws_bytes, stream_);
+}
+
+// The K neighbours ranked strictly AFTER (after_d2[q], after_idx[q]) in the (squared distance,
+// index) order of the contract: chained after a K = 64 search it yields neighbours 65..128
+// (k_max = 100 of cluster_radius_nn_graph, src/utils/neighbors.py:491).  after_idx[q] < 0 (the
+// previous list was not full) -> nothing left for that query.
+extern "C" int spt_grid_knn_after_f32(const float* query, int64_t nq, const float* search,
+                                      int64_t ns, int K, float r, float cell_size,
+                                      const float* origin, const int32_t* dims, int inclusive,
+                                      int squared, const int64_t* after_idx,
+                                      const float* after_d2, int64_t* idx, float* dist, void* ws,
+                                      size_t ws_bytes, spt_stream_t stream_) {
+  if (!after_idx || !after_d2) return ::spt::fail(-1, "%s: null continuation keys", __func__);
+  return grid_knn_impl(query, nq, search, ns, K, r, cell_size, origin, dims, 1, inclusive,
+                       squared, after_idx, after_d2, idx, dist, nullptr, ws, ws_bytes, stream_);
+}
+
+static int grid_knn_impl(const float* query, int64_t nq, const float* search, int64_t ns, int K,
+                         float r, float cell_size, const float* origin, const int32_t* dims,
+                         int order_queries_by_cell, int inclusive, int squared,
+                         const int64_t* after_idx, const float* after_d2, int64_t* idx,
+                         float* dist, int32_t* cell_order, void* ws, size_t ws_bytes,
+                         spt_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SPT_CHECK_ARG(nq >= 0 && ns >= 0, "bad shape");
   SPT_CHECK_ARG(K >= 1 && K <= 64, "K must be in [1, 64]");
@@ -692,7 +739,7 @@ extern "C" int spt_grid_knn_f32(const float* query, int64_t nq, const float* sea
   if (cell_order && ns > 0)
     (void)hipMemcpyAsync(cell_order, perm, (size_t)ns * 4, hipMemcpyDeviceToDevice, stream);
   const int grid = (int)(ceil_div(nq, KNN_WAVES) < 256 * 8 ? ceil_div(nq, KNN_WAVES) : 256 * 8);
-  if (qorder && knn_cell_path_enabled()) {
+  if (qorder && knn_cell_path_enabled() && !after_idx) {
     // self-search in cell order: shared candidate streams (knn_cell_kernel), leftovers through
     // the wave-per-query kernel with their count read on the device
     int32_t* todo = (int32_t*)(base + p.off_todo);
@@ -706,7 +753,8 @@ extern "C" int spt_grid_knn_f32(const float* query, int64_t nq, const float* sea
                                                            inclusive, squared, idx, dist, count);
   } else {
     knn_search_kernel<<<grid, KNN_WAVES * 64, 0, stream>>>(query, nq, qorder, sorted, rowptr, g, K,
-                                                           r, inclusive, squared, idx, dist, nullptr);
+                                                           r, inclusive, squared, idx, dist, nullptr,
+                                                           after_idx, after_d2);
   }
   SPT_CHECK_LAUNCH();
   return 0;

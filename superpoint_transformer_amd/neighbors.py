@@ -88,7 +88,9 @@ def _grid_for(search, r, K, cell_size=None, self_search=False):
 def frnn_grid_points(query, search, K, r, squared=True, inclusive=False, cell_size=None):
     """Same contract as ``frnn.frnn_grid_points`` on one cloud (the reference
     always calls it with batch size 1, src/utils/neighbors.py:82-83):
-    returns ``(dists [nq,K], idxs [nq,K])``, ascending, -1 padded."""
+    returns ``(dists [nq,K], idxs [nq,K])``, ascending, -1 padded.  ``K > 64``: the kernels hold
+    64 neighbours per query; the rest comes from continuation searches ("the K' nearest strictly
+    after the last one found", ``spt_grid_knn_after_f32``), 64 at a time."""
     _lib.require_cuda(query, search)
     q = query.detach().float().contiguous()
     s = q if search is query else search.detach().float().contiguous()
@@ -101,7 +103,7 @@ def frnn_grid_points(query, search, K, r, squared=True, inclusive=False, cell_si
         return dist, idx
     if ns == 0:
         return dist.fill_(-1), idx.fill_(-1)
-    cs, origin, dims = _grid_for(s, r, K, cell_size, self_search=search is query)
+    cs, origin, dims = _grid_for(s, r, min(K, 64), cell_size, self_search=search is query)
     # self-search of a large cloud: keep the grid's cell order of the points, the kernels
     # that gather neighbourhoods afterwards (geometric_features) visit points in that order
     order = torch.empty(ns, dtype=torch.int32, device=dev) \
@@ -111,13 +113,36 @@ def frnn_grid_points(query, search, K, r, squared=True, inclusive=False, cell_si
     ws = _workspace(nb, dev)
     o3 = (ctypes.c_float * 3)(*origin)
     d3 = (ctypes.c_int32 * 3)(*dims)
+    k0 = min(K, 64)
+    chunk_i = idx if K <= 64 else torch.empty((nq, k0), dtype=torch.int64, device=dev)
+    chunk_d = dist if K <= 64 else torch.empty((nq, k0), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         st = _lib.lib.spt_grid_knn_f32(
-            _lib.ptr(q), nq, _lib.ptr(s), ns, K, float(r), cs,
+            _lib.ptr(q), nq, _lib.ptr(s), ns, k0, float(r), cs,
             ctypes.cast(o3, ctypes.c_void_p), ctypes.cast(d3, ctypes.c_void_p), 1,
-            int(inclusive), int(squared), _lib.ptr(idx), _lib.ptr(dist), _lib.ptr(order),
-            _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+            int(inclusive), 1 if K > 64 else int(squared), _lib.ptr(chunk_i), _lib.ptr(chunk_d),
+            _lib.ptr(order), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
     _lib.check(st, "spt_grid_knn_f32")
+    if K > 64:
+        idx[:, :k0], dist[:, :k0] = chunk_i, chunk_d
+        done = k0
+        while done < K:
+            kk = min(64, K - done)
+            after_i = idx[:, done - 1].contiguous()
+            after_d = dist[:, done - 1].contiguous()            # squared (kept so until the end)
+            ci = torch.empty((nq, kk), dtype=torch.int64, device=dev)
+            cd = torch.empty((nq, kk), dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                st = _lib.lib.spt_grid_knn_after_f32(
+                    _lib.ptr(q), nq, _lib.ptr(s), ns, kk, float(r), cs,
+                    ctypes.cast(o3, ctypes.c_void_p), ctypes.cast(d3, ctypes.c_void_p),
+                    int(inclusive), 1, _lib.ptr(after_i), _lib.ptr(after_d), _lib.ptr(ci),
+                    _lib.ptr(cd), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+            _lib.check(st, "spt_grid_knn_after_f32")
+            idx[:, done:done + kk], dist[:, done:done + kk] = ci, cd
+            done += kk
+        if not squared:
+            dist = torch.where(idx >= 0, dist.clamp(min=0).sqrt(), dist)
     if order is not None:
         _remember_order(search, order)
     return dist, idx
@@ -330,8 +355,8 @@ def cluster_radius_nn_graph(x_points, idx, k_max=100, gap=0, batch=None, trim=Tr
     from .csr import csr_of
     from .ops import segment_reduce
     _lib.require_cuda(x_points, idx)
-    if k_max + 1 > 64:
-        raise NotImplementedError("the grid kNN kernel holds up to 64 neighbours (k_max <= 63; "
+    if k_max + 1 > 256:
+        raise NotImplementedError("k_max <= 255 (four chained 64-neighbour searches; "
                                   "the reference's configs use 30)")
     x = x_points.detach().float().contiguous()
     dev = x.device

@@ -44,7 +44,9 @@ def test_anchors_match_the_reference(c, dev):
 
 @pytest.mark.parametrize("seed,nseg,hi,k_max,gap,trim", [
     (1, 300, 60, 20, 0.5, True), (2, 50, 400, 10, 0.3, True), (3, 500, 8, 30, 1.0, False),
-    (4, 40, 30, 63, 2.0, True), (5, 200, 20, 5, 0.0, True)])
+    (4, 40, 30, 63, 2.0, True), (5, 200, 20, 5, 0.0, True),
+    # k_max above one 64-neighbour search: chained continuation searches (reference default 100)
+    (6, 400, 12, 100, 3.0, True), (7, 150, 25, 140, 6.0, False)])
 def test_graph_and_intermediates_match_the_oracle(seed, nseg, hi, k_max, gap, trim, dev):
     from superpoint_transformer_amd.neighbors import cluster_radius_nn_graph
     g = torch.Generator().manual_seed(seed)
@@ -78,10 +80,21 @@ def test_euclidean_convention_switch(dev):
     assert torch.equal(ei.cpu(), rei)
 
 
-def test_k_max_above_kernel_capacity_is_refused(dev):
+def test_default_k_max_on_the_reference_fixture(dev):
+    """k_max = 100 (the reference's default, neighbors.py:491) on the fixture cloud: more
+    neighbours than one search holds; the graph equals the oracle's."""
+    from superpoint_transformer_amd.neighbors import cluster_radius_nn_graph
+    pos, idx = t("c0_pos"), t("c0_idx")
+    ei, d = cluster_radius_nn_graph(pos.to(dev), idx.to(dev), k_max=100, gap=1.0)
+    rei, rd, _ = O.cluster_radius_nn_graph(pos, idx, 100, 1.0)
+    assert torch.equal(ei.cpu(), rei)
+    assert torch.allclose(d.cpu(), rd, atol=0, rtol=1e-6)
+
+
+def test_k_max_beyond_four_searches_is_refused(dev):
     from superpoint_transformer_amd.neighbors import cluster_radius_nn_graph
     with pytest.raises(NotImplementedError):
-        cluster_radius_nn_graph(t("c0_pos").to(dev), t("c0_idx").to(dev), k_max=100, gap=1.0)
+        cluster_radius_nn_graph(t("c0_pos").to(dev), t("c0_idx").to(dev), k_max=300, gap=1.0)
 
 
 def test_graph_at_scene_scale(dev):

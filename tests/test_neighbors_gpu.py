@@ -66,6 +66,29 @@ def test_self_search_cell_path_is_bit_exact(name, K, r, cell, inclusive, dev):
         assert torch.equal(dist.cpu(), rd), f"path {path}"
 
 
+@pytest.mark.parametrize("name,K,r", [("mixed", 101, 2.0), ("mixed", 65, 0.4), ("mixed", 130, 60.0),
+                                      ("lattice", 200, 1.1), ("tiny", 70, 2.0)])
+@pytest.mark.parametrize("squared", [True, False])
+def test_more_than_64_neighbours_by_continuation(name, K, r, squared, dev):
+    """K > 64: the first 64 come from the usual search, the rest from continuation searches
+    ("strictly after the last one found" in (d2, index) order) - lattice ties straddle the
+    cut, lists shorter than 64 must stay -1 padded, two-set search included."""
+    from superpoint_transformer_amd import neighbors as NB
+    xyz = _clouds()[name]
+    p = xyz.to(dev)
+    rd, ri = O.frnn_grid_points(xyz, xyz, K, r)
+    if not squared:
+        rd = torch.where(ri >= 0, rd.clamp(min=0).sqrt(), rd)
+    dist, idx = NB.frnn_grid_points(p, p, K, r, squared=squared)
+    assert torch.equal(idx.cpu(), ri)
+    assert torch.equal(dist.cpu(), rd)
+    q = xyz[::7] + 0.01
+    rd, ri = O.frnn_grid_points(q, xyz, K, r)
+    dist, idx = NB.frnn_grid_points(q.to(dev), p, K, r)
+    assert torch.equal(idx.cpu(), ri)
+    assert torch.equal(dist.cpu(), rd)
+
+
 def test_self_search_paths_agree_on_a_voxel_cloud(dev):
     """2 M-point voxelised surfaces at the S3DIS settings: the two self-search kernels
     agree bit for bit (indices and squared distances) on every row."""
