@@ -219,6 +219,21 @@ int spt_edge_attn_bwd_f32(const float* qkv, int64_t n, int H, int D, int Dv,
                           float* gedge_attr, float* gWk, float* gbk, float* gWq,
                           float* gbq, float* gWv, float* gbv, void* ws,
                           size_t ws_bytes, spt_stream_t stream);
+/* Same with gedge_attr_accumulate != 0: d edge_attr is ADDED (f32 hardware atomics) to what
+ * gedge_attr already holds instead of stored.  The transformer blocks of a stage all read the same
+ * edge_attr (src/nn/stage.py:137-141), so their backward passes share one gradient buffer instead
+ * of leaving autograd to sum 3-4 [E,F] tensors. */
+int spt_edge_attn_bwd_acc_f32(const float* qkv, int64_t n, int H, int D, int Dv,
+                              const int32_t* erowptr, const int32_t* eperm,
+                              const int32_t* tgt_sorted, int64_t e,
+                              const float* edge_attr, int F, const float* Wk,
+                              const float* bk, const float* Wq, const float* bq,
+                              const float* Wv, const float* bv, int scale_mode,
+                              float scale_a, const float* out, const float* m,
+                              const float* z, const float* gout, float* gqkv,
+                              float* gedge_attr, int gedge_attr_accumulate, float* gWk,
+                              float* gbk, float* gWq, float* gbq, float* gWv, float* gbv,
+                              void* ws, size_t ws_bytes, spt_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Radius-bounded exact kNN on a uniform grid                        (a9)

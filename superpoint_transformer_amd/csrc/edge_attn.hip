@@ -431,7 +431,8 @@ __global__ __launch_bounds__(EA_WAVES * 64, 1) void edge_attn_bwd_kernel(
     const float* __restrict__ Wv, const float* __restrict__ bv, int scale_mode,
     float scale_a, const float* __restrict__ out, const float* __restrict__ mbuf,
     const float* __restrict__ zbuf, const float* __restrict__ gout,
-    float* __restrict__ gqkv, float* __restrict__ gea, float* __restrict__ partial) {
+    float* __restrict__ gqkv, float* __restrict__ gea, float* __restrict__ partial,
+    int gea_acc) {
   constexpr int KROW = 64 * QPL, VROW = 64 * VPL;
   constexpr int SLAB = EA_TE * (F + KROW + VROW);
   __shared__ __attribute__((aligned(16))) float slab_all[EA_WAVES][2][SLAB];
@@ -632,12 +633,18 @@ __global__ __launch_bounds__(EA_WAVES * 64, 1) void edge_attn_bwd_kernel(
             const int col = ((lane >> 5) & 1) * 16 + ((lane >> 4) & 1) * 8 +
                             ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
             const float tot = pf[0] + __shfl_xor(pf[0], 1, 64);
-            if ((lane & 1) == 0) gea[e * F + col] = tot;
+            if ((lane & 1) == 0) {
+              if (gea_acc) unsafeAtomicAdd(gea + e * F + col, tot);
+              else gea[e * F + col] = tot;
+            }
           } else {
 #pragma unroll
             for (int f = 0; f < F; ++f) {
               const float tot = wave_reduce_sum(pf[f]);
-              if (lane == 0) gea[e * F + f] = tot;
+              if (lane == 0) {
+                if (gea_acc) unsafeAtomicAdd(gea + e * F + f, tot);
+                else gea[e * F + f] = tot;
+              }
             }
           }
         }
@@ -757,7 +764,7 @@ int attn_bwd_mfma_launch(const float* qkv, int64_t n, const int32_t* erowptr,
                          const float* Wk, const float* bk, const float* Wq, const float* bq,
                          const float* Wv, const float* bv, int scale_mode, float scale_a,
                          const float* out, const float* m, const float* z, const float* gout,
-                         float* gqkv, float* gea, float* partial, int split_bf16,
+                         float* gqkv, float* gea, int gea_acc, float* partial, int split_bf16,
                          int64_t e, int packed, hipStream_t stream);
 // 0: lane-per-output VALU kernels, 1: f32 matrix pipe (bitwise an fmaf chain), 2 (default):
 // split-bf16 on the bf16 matrix pipe (3 products per f32 product, ~10 ulp of f32), 3: plain
@@ -842,6 +849,14 @@ extern "C" int spt_edge_attn_fwd_f32(const float* qkv, int64_t n, int H, int D, 
 
 constexpr int EA_BWD_BLOCKS = 256;  // one 4-wave workgroup per CU (1 wave per SIMD)
 
+extern "C" int spt_edge_attn_bwd_acc_f32(const float*, int64_t, int, int, int, const int32_t*,
+                                         const int32_t*, const int32_t*, int64_t, const float*,
+                                         int, const float*, const float*, const float*,
+                                         const float*, const float*, const float*, int, float,
+                                         const float*, const float*, const float*, const float*,
+                                         float*, float*, int, float*, float*, float*, float*,
+                                         float*, float*, void*, size_t, spt_stream_t);
+
 extern "C" size_t spt_edge_attn_bwd_workspace_bytes(int H, int D, int Dv, int F) {
   const size_t len = (size_t)(2 * H * D + H * Dv) * (F + 1);
   return align_up((size_t)EA_BWD_BLOCKS * EA_WAVES * len * 4, 256) + align_up(len * 4, 256);
@@ -858,7 +873,30 @@ extern "C" int spt_edge_attn_bwd_f32(const float* qkv, int64_t n, int H, int D, 
                                      float* gedge_attr, float* gWk, float* gbk,
                                      float* gWq, float* gbq, float* gWv, float* gbv,
                                      void* ws, size_t ws_bytes, spt_stream_t stream_) {
+  return spt_edge_attn_bwd_acc_f32(qkv, n, H, D, Dv, erowptr, eperm, tgt_sorted, e, edge_attr, F,
+                                   Wk, bk, Wq, bq, Wv, bv, scale_mode, scale_a, out, m, z, gout,
+                                   gqkv, gedge_attr, 0, gWk, gbk, gWq, gbq, gWv, gbv, ws,
+                                   ws_bytes, stream_);
+}
+
+// Same, with `gedge_attr_accumulate` != 0: d edge_attr is ADDED to what gedge_attr holds (f32
+// hardware atomics, fire-and-forget) instead of stored - the blocks of one stage all read the same
+// edge_attr, so their backward passes can share one gradient buffer instead of autograd summing
+// 3-4 [E, F] tensors afterwards.
+extern "C" int spt_edge_attn_bwd_acc_f32(const float* qkv, int64_t n, int H, int D, int Dv,
+                                         const int32_t* erowptr, const int32_t* eperm,
+                                         const int32_t* tgt_sorted, int64_t e,
+                                         const float* edge_attr, int F, const float* Wk,
+                                         const float* bk, const float* Wq, const float* bq,
+                                         const float* Wv, const float* bv, int scale_mode,
+                                         float scale_a, const float* out, const float* m,
+                                         const float* z, const float* gout, float* gqkv,
+                                         float* gedge_attr, int gedge_attr_accumulate,
+                                         float* gWk, float* gbk, float* gWq, float* gbq,
+                                         float* gWv, float* gbv, void* ws, size_t ws_bytes,
+                                         spt_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  const int gea_acc = gedge_attr_accumulate != 0;
   SPT_CHECK_ARG(n >= 0 && e >= 0 && H >= 1 && D >= 1 && Dv >= 1, "bad shape");
   if (n == 0) return 0;
   SPT_CHECK_ARG(qkv && erowptr && out && m && z && gout && gqkv && (tgt_sorted || e == 0), "null pointer");
@@ -878,7 +916,7 @@ extern "C" int spt_edge_attn_bwd_f32(const float* qkv, int64_t n, int H, int D, 
   if (use_mfma() && attn_mfma_shape_ok(H, D, Dv, F, edge_attr, Wk, Wq, Wv)) {
     const int ntab = attn_bwd_mfma_launch(qkv, n, erowptr, eperm, tgt_sorted, edge_attr, Wk, bk,
                                           Wq, bq, Wv, bv, scale_mode, scale_a, out, m, z, gout,
-                                          gqkv, gedge_attr, partial,
+                                          gqkv, gedge_attr, gea_acc, partial,
                                           mfma_mode() == 2 ? 3 : (mfma_mode() == 3 ? 1 : 0), e,
                                           g_attn_bwd_packed, stream);
     attn_reduce_partials_kernel<<<(int)ceil_div((int64_t)len, 16), 256, 0, stream>>>(
@@ -898,7 +936,7 @@ extern "C" int spt_edge_attn_bwd_f32(const float* qkv, int64_t n, int H, int D, 
   }
   SPT_ATTN_DISPATCH(edge_attn_bwd_kernel, qkv, ld, n, sh, erowptr, eperm, tgt_sorted,
                     edge_attr, Wk, bk, Wq, bq, Wv, bv, scale_mode, scale_a, out, m, z,
-                    gout, gqkv, gedge_attr, partial);
+                    gout, gqkv, gedge_attr, partial, gea_acc);
 #undef SPT_ATTN_CASE
   if (has_rpe) {
     attn_reduce_partials_kernel<<<(int)ceil_div((int64_t)len, 16), 256, 0, stream>>>(

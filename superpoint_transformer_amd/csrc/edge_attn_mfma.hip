@@ -524,7 +524,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attn_bwd_mfma_kernel(
     const float* __restrict__ bv, int scale_mode, float scale_a, const float* __restrict__ out,
     const float* __restrict__ mbuf, const float* __restrict__ zbuf,
     const float* __restrict__ gout, float* __restrict__ gqkv, float* __restrict__ gea,
-    float* __restrict__ partial) {
+    float* __restrict__ partial, int gea_acc) {
   constexpr bool BF3 = PREC != 0, LO = PREC == 3;
   __shared__ __attribute__((aligned(16))) float slab_all[WAVES][2][SLAB];
   __shared__ __attribute__((aligned(16))) float dt_all[WAVES][DT_FLOATS];
@@ -794,8 +794,13 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attn_bwd_mfma_kernel(
         for (int r = 0; r < 4; ++r) {
           const int64_t e = __shfl(e_cur, 4 * g + r, 64);
           if (4 * g + r < cnt) {
-            gea[e * F + c] = C2[0][r];
-            gea[e * F + 16 + c] = C2[1][r];
+            if (gea_acc) {          // shared gradient buffer of the stage's blocks
+              unsafeAtomicAdd(gea + e * F + c, C2[0][r]);
+              unsafeAtomicAdd(gea + e * F + 16 + c, C2[1][r]);
+            } else {
+              gea[e * F + c] = C2[0][r];
+              gea[e * F + 16 + c] = C2[1][r];
+            }
           }
         }
         // ---- dW += D^T EA : A operand = the C-layout registers as they are ----------
@@ -914,7 +919,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attn_bwd_packed_kernel(
     const float* __restrict__ bv, int scale_mode, float scale_a, const float* __restrict__ out,
     const float* __restrict__ mbuf, const float* __restrict__ zbuf,
     const float* __restrict__ gout, float* __restrict__ gqkv, float* __restrict__ gea,
-    float* __restrict__ partial) {
+    float* __restrict__ partial, int gea_acc) {
   static_assert(PREC == 1 || PREC == 3, "bf16 matrix pipe only");
   constexpr bool LO = PREC == 3;
   __shared__ __attribute__((aligned(16))) float slab_all[WAVES][2][SLAB];
@@ -1243,8 +1248,13 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attn_bwd_packed_kernel(
       for (int r = 0; r < 4; ++r) {
         const int64_t e = __shfl(e_cur, 4 * g + r, 64);
         if (4 * g + r < cnt) {
-          gea[e * F + c] = C2[0][r];
-          gea[e * F + 16 + c] = C2[1][r];
+          if (gea_acc) {            // shared gradient buffer of the stage's blocks
+            unsafeAtomicAdd(gea + e * F + c, C2[0][r]);
+            unsafeAtomicAdd(gea + e * F + 16 + c, C2[1][r]);
+          } else {
+            gea[e * F + c] = C2[0][r];
+            gea[e * F + 16 + c] = C2[1][r];
+          }
         }
       }
       // ---- dW += D^T EA ------------------------------------------------------------------------
@@ -1338,7 +1348,7 @@ int attn_bwd_mfma_launch(const float* qkv, int64_t n, const int32_t* erowptr,
                          const float* Wk, const float* bk, const float* Wq, const float* bq,
                          const float* Wv, const float* bv, int scale_mode, float scale_a,
                          const float* out, const float* m, const float* z, const float* gout,
-                         float* gqkv, float* gea, float* partial, int split_bf16,
+                         float* gqkv, float* gea, int gea_acc, float* partial, int split_bf16,
                          int64_t e, int packed, hipStream_t stream) {
   const int64_t blocks = ceil_div(n, mfma::WAVES);
   const int grid = (int)(blocks < ATTN_BWD_MFMA_BLOCKS ? blocks : ATTN_BWD_MFMA_BLOCKS);
@@ -1350,25 +1360,25 @@ int attn_bwd_mfma_launch(const float* qkv, int64_t n, const int32_t* erowptr,
     if (split_bf16 == 3)
       mfma::attn_bwd_packed_kernel<3><<<pgrid, mfma::WAVES * 64, 0, stream>>>(
           qkv, 192, n, e, erowptr, eperm, tgt, ntiles, ea, Wk, bk, Wq, bq, Wv, bv, scale_mode,
-          scale_a, out, m, z, gout, gqkv, gea, partial);
+          scale_a, out, m, z, gout, gqkv, gea, partial, gea_acc);
     else
       mfma::attn_bwd_packed_kernel<1><<<pgrid, mfma::WAVES * 64, 0, stream>>>(
           qkv, 192, n, e, erowptr, eperm, tgt, ntiles, ea, Wk, bk, Wq, bq, Wv, bv, scale_mode,
-          scale_a, out, m, z, gout, gqkv, gea, partial);
+          scale_a, out, m, z, gout, gqkv, gea, partial, gea_acc);
     return pgrid * mfma::WAVES;
   }
   if (split_bf16 == 3)
     mfma::attn_bwd_mfma_kernel<3><<<grid, mfma::WAVES * 64, 0, stream>>>(
         qkv, 192, n, erowptr, eperm, tgt, ea, Wk, bk, Wq, bq, Wv, bv, scale_mode, scale_a, out, m,
-        z, gout, gqkv, gea, partial);
+        z, gout, gqkv, gea, partial, gea_acc);
   else if (split_bf16 == 1)
     mfma::attn_bwd_mfma_kernel<1><<<grid, mfma::WAVES * 64, 0, stream>>>(
         qkv, 192, n, erowptr, eperm, tgt, ea, Wk, bk, Wq, bq, Wv, bv, scale_mode, scale_a, out, m,
-        z, gout, gqkv, gea, partial);
+        z, gout, gqkv, gea, partial, gea_acc);
   else
     mfma::attn_bwd_mfma_kernel<0><<<grid, mfma::WAVES * 64, 0, stream>>>(
         qkv, 192, n, erowptr, eperm, tgt, ea, Wk, bk, Wq, bq, Wv, bv, scale_mode, scale_a, out, m,
-        z, gout, gqkv, gea, partial);
+        z, gout, gqkv, gea, partial, gea_acc);
   return grid * mfma::WAVES;  // number of partial tables written
 }
 

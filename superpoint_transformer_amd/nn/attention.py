@@ -96,9 +96,10 @@ class SelfAttentionBlock(nn.Module):
             b = None if b is None else b.repeat(self.num_heads)
         return w, b
 
-    def forward(self, x, edge_index, edge_attr=None):
+    def forward(self, x, edge_index, edge_attr=None, ea_grad=None):
         """x [N, Cx]; edge_index [2, E] (row 0 = querying source, row 1 = key
-        target; any order) or an ``EdgeCSR``; edge_attr [E, in_rpe_dim]."""
+        target; any order) or an ``EdgeCSR``; edge_attr [E, in_rpe_dim]; ``ea_grad``: the
+        stage's shared edge_attr gradient buffer (``ops.EdgeAttrGradShare``) or None."""
         if self.in_proj is not None:
             x = ops.linear(x, self.in_proj.weight, self.in_proj.bias)
         qkv = ops.linear(x, self.qkv.weight, self.qkv.bias)
@@ -113,7 +114,8 @@ class SelfAttentionBlock(nn.Module):
         x = ops.edge_attention(
             qkv, edge_index, edge_attr if (k_rpe or q_rpe or v_rpe) else None,
             k_rpe=k_rpe, q_rpe=q_rpe, v_rpe=v_rpe, num_heads=self.num_heads,
-            qk_dim=self.qk_dim, scale_mode=self.scale_mode, scale_a=self.scale_a)
+            qk_dim=self.qk_dim, scale_mode=self.scale_mode, scale_a=self.scale_a,
+            ea_grad=ea_grad)
         if self.out_proj is not None:
             x = ops.linear(x, self.out_proj.weight, self.out_proj.bias)
         if self.out_drop is not None:

@@ -8,6 +8,7 @@ lets GraphNorm skip its ``batch.max()`` host sync."""
 import torch
 from torch import nn
 
+from .. import ops
 from ..csr import edge_csr_of
 from .fusion import CatFusion, fusion_factory
 from .mlp import MLP
@@ -144,10 +145,14 @@ class Stage(nn.Module):
             if edge_index is not None and not hasattr(edge_index, "erowptr") \
                     and edge_index.shape[1] > 0:
                 edge_index = edge_csr_of(edge_index, x.shape[0])   # once per stage
+            # the blocks all read the same edge_attr: one shared gradient buffer
+            share = ops.EdgeAttrGradShare() if (
+                edge_attr is not None and len(self.transformer_blocks) > 1
+                and torch.is_grad_enabled() and edge_attr.requires_grad) else None
             for block in self.transformer_blocks:
                 x, norm_index, edge_index = block(
                     x, norm_index, edge_index=edge_index, edge_attr=edge_attr,
-                    num_graphs=num_graphs)
+                    num_graphs=num_graphs, ea_grad=share)
         if self.out_mlp is not None:
             x = self.out_mlp(x, batch=norm_index, batch_size=num_graphs)
         return x, diameter_parent

@@ -57,7 +57,8 @@ class TransformerBlock(nn.Module):
         self.drop_path = DropPath(drop_path) if drop_path is not None and drop_path > 0 \
             else nn.Identity()
 
-    def forward(self, x, norm_index, edge_index=None, edge_attr=None, num_graphs=None):
+    def forward(self, x, norm_index, edge_index=None, edge_attr=None, num_graphs=None,
+                ea_grad=None):
         shortcut = x
         has_edges = edge_index is not None and \
             (getattr(edge_index, "e", None) or getattr(edge_index, "shape", (0, 0))[1]) > 0
@@ -65,10 +66,10 @@ class TransformerBlock(nn.Module):
             pass
         elif self.pre_norm:
             x = self._forward_norm(self.sa_norm, x, norm_index, num_graphs)
-            x = self.sa(x, edge_index, edge_attr=edge_attr)
+            x = self.sa(x, edge_index, edge_attr=edge_attr, ea_grad=ea_grad)
             x = shortcut + self.drop_path(x)
         else:
-            x = self.sa(x, edge_index, edge_attr=edge_attr)
+            x = self.sa(x, edge_index, edge_attr=edge_attr, ea_grad=ea_grad)
             x = self.drop_path(x)
             x = self._forward_norm(self.sa_norm, shortcut + x, norm_index, num_graphs)
 

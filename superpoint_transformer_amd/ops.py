@@ -362,9 +362,36 @@ def _f32c(t):
     return t.contiguous()
 
 
+class EdgeAttrGradShare:
+    """One gradient buffer for the ``edge_attr`` of a stage: every transformer block of the
+    stage reads the same ``edge_attr`` (src/nn/stage.py:137-141), so instead of each attention
+    backward returning its own [E, F] tensor for autograd to sum, the blocks accumulate into one
+    buffer (``spt_edge_attn_bwd_acc_f32``) and only the block that ran FIRST in the forward - the
+    last one autograd reaches, every later block depends on its output - hands it to autograd.
+
+    Valid for one forward pass over sequentially dependent blocks, which is what ``Stage.forward``
+    creates it for; a backward that stops short of the first block (``autograd.grad`` on an
+    intermediate block's inputs) would not see the edge_attr gradient - do not pass a share in
+    that case."""
+
+    __slots__ = ("tensor", "count", "buf")
+
+    def __init__(self):
+        self.tensor, self.count, self.buf = None, 0, None
+
+    def enter(self, edge_attr):
+        if self.tensor is None:
+            self.tensor = edge_attr
+        elif self.tensor is not edge_attr:
+            raise ValueError("EdgeAttrGradShare: the blocks were given different edge_attr tensors")
+        self.count += 1
+        return self.count - 1
+
+
 class _EdgeAttention(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, qkv, ecsr, edge_attr, Wk, bk, Wq, bq, Wv, bv, H, D, scale_mode, scale_a):
+    def forward(ctx, qkv, ecsr, edge_attr, Wk, bk, Wq, bq, Wv, bv, H, D, scale_mode, scale_a,
+                share=None):
         _lib.require_cuda(qkv)
         q2 = _f32c(qkv)
         n, ld = q2.shape
@@ -392,6 +419,10 @@ class _EdgeAttention(torch.autograd.Function):
         ctx.has_ea = ea is not None
         ctx.meta = (ecsr, H, D, Dv, F, scale_mode, scale_a, qkv.dtype,
                     None if edge_attr is None else edge_attr.dtype)
+        ctx.share = ctx.rank = None
+        if (share is not None and edge_attr is not None and edge_attr.dtype == torch.float32
+                and edge_attr.requires_grad and (Wk is not None or Wq is not None or Wv is not None)):
+            ctx.share, ctx.rank = share, share.enter(edge_attr)
         return out.to(qkv.dtype)
 
     @staticmethod
@@ -408,33 +439,45 @@ class _EdgeAttention(torch.autograd.Function):
         dev = q2.device
         g = _f32c(gout)
         gqkv = torch.empty_like(q2)
-        gea = torch.empty_like(ea) if ea is not None else None
+        share, acc = ctx.share, 0
+        if share is not None and share.buf is not None:
+            gea, acc = share.buf, 1                      # a later block already started the sum
+        else:
+            gea = torch.empty_like(ea) if ea is not None else None
+            if share is not None:
+                share.buf = gea
         gps = [torch.empty_like(t) if t is not None else None for t in ps]
         nb = _lib.lib.spt_edge_attn_bwd_workspace_bytes(H, D, Dv, max(F, 1))
         ws = _workspace(nb, dev)
         with torch.cuda.device(dev):
-            st = _lib.lib.spt_edge_attn_bwd_f32(
+            st = _lib.lib.spt_edge_attn_bwd_acc_f32(
                 _lib.ptr(q2), n, H, D, Dv, _lib.ptr(ecsr.erowptr), _lib.ptr(ecsr.eperm),
                 _lib.ptr(ecsr.tgt_sorted), ecsr.e, _lib.ptr(ea), F,
                 *[_lib.ptr(t) for t in ps], scale_mode, scale_a, _lib.ptr(out),
-                _lib.ptr(m), _lib.ptr(z), _lib.ptr(g), _lib.ptr(gqkv), _lib.ptr(gea),
+                _lib.ptr(m), _lib.ptr(z), _lib.ptr(g), _lib.ptr(gqkv), _lib.ptr(gea), acc,
                 *[_lib.ptr(t) for t in gps], _lib.ptr(ws), ws.numel(),
                 _lib.stream_ptr(dev))
-        _lib.check(st, "spt_edge_attn_bwd_f32")
+        _lib.check(st, "spt_edge_attn_bwd_acc_f32")
         if gea is not None and not (any(ctx.present[0::2])):
             gea = None
+        if share is not None:
+            if ctx.rank == 0:
+                share.buf = None                         # handed over; a second backward restarts
+            else:
+                gea = None                               # the first block returns the sum
         return (gqkv.to(q_dtype), None, None if gea is None else gea.to(ea_dtype),
-                *gps, None, None, None, None)
+                *gps, None, None, None, None, None)
 
 
 def edge_attention(qkv, edge_index, edge_attr=None, k_rpe=None, q_rpe=None, v_rpe=None,
-                   num_heads=1, qk_dim=8, scale_mode=0, scale_a=1.0):
+                   num_heads=1, qk_dim=8, scale_mode=0, scale_a=1.0, ea_grad=None):
     """out[s] = sum_e softmax_e(<q_e, k_e>) v_e over the edges leaving s.
 
     ``qkv`` [N, 2*H*D + C] is the output of the block's qkv Linear;
     ``edge_index`` a [2,E] tensor or an :class:`EdgeCSR`; ``k_rpe`` etc. are
     (weight, bias) pairs of the RPE Linears or None.  Returns [N, C]
-    (before out_proj)."""
+    (before out_proj).  ``ea_grad``: an :class:`EdgeAttrGradShare` common to the blocks of a
+    stage (their d edge_attr accumulate into one buffer)."""
     ecsr = edge_csr_of(edge_index, qkv.shape[0])
 
     def wb(p):
@@ -444,7 +487,8 @@ def edge_attention(qkv, edge_index, edge_attr=None, k_rpe=None, q_rpe=None, v_rp
     Wq, bq = wb(q_rpe)
     Wv, bv = wb(v_rpe)
     return _EdgeAttention.apply(qkv, ecsr, edge_attr, Wk, bk, Wq, bq, Wv, bv,
-                                int(num_heads), int(qk_dim), int(scale_mode), float(scale_a))
+                                int(num_heads), int(qk_dim), int(scale_mode), float(scale_a),
+                                ea_grad if torch.is_grad_enabled() else None)
 
 
 # ---------------------------------------------------------------------------

@@ -276,3 +276,54 @@ def test_attention_backward_tilings_match_oracle(degrees, packed, dev):
     _check(ead.grad, ea64.grad, "g_edge_attr")
     for k, v in blk.named_parameters():
         _check(v.grad, p[k].grad, "g_" + k, rel_to_max=True)
+
+
+@pytest.mark.parametrize("mode", [2, 1, 0])
+def test_shared_edge_attr_gradient_of_a_stage(mode, dev):
+    """Three chained blocks reading one edge_attr: with the stage's shared gradient buffer
+    (the blocks' d edge_attr accumulate in the kernel, the first block hands the sum to
+    autograd) every gradient equals the one autograd sums from three separate tensors - on the
+    packed / per-node MFMA kernels (mode 2), the f32 pipe (1) and the VALU kernels (0); a second
+    backward through the same graph (retain_graph) restarts the buffer."""
+    from superpoint_transformer_amd import _lib, ops, nn as N
+    gen = torch.Generator().manual_seed(31)
+    n, H, D, dim, F = 500, 16, 4, 64, 32
+    ei = _rand_graph(gen, n, 12.0).to(dev)
+    blocks = [N.SelfAttentionBlock(dim, num_heads=H, out_dim=None, qk_dim=D, in_rpe_dim=F,
+                                   k_rpe=True, q_rpe=True, v_rpe=True).to(dev) for _ in range(3)]
+    x = torch.randn(n, dim, generator=gen).to(dev)
+    ea = (torch.randn(ei.shape[1], F, generator=gen) * 0.5).to(dev)
+    gw = torch.randn(n, dim, generator=gen).to(dev)
+
+    def run(share, twice=False):
+        xd, ead = x.clone().requires_grad_(), ea.clone().requires_grad_()
+        for b in blocks:
+            b.zero_grad()
+        h = xd
+        for b in blocks:
+            h = h + b(h, ei, edge_attr=ead, ea_grad=share)
+        loss = (h * gw).sum()
+        if twice:
+            loss.backward(retain_graph=True)
+            xd.grad = ead.grad = None
+            for b in blocks:
+                b.zero_grad()
+        loss.backward()
+        return [xd.grad, ead.grad] + [p.grad.clone() for b in blocks for p in b.parameters()]
+
+    prev = _lib.lib.spt_attn_use_mfma(mode)
+    try:
+        ref = run(None)
+        got = run(ops.EdgeAttrGradShare())
+        again = run(ops.EdgeAttrGradShare(), twice=True)
+    finally:
+        _lib.lib.spt_attn_use_mfma(prev)
+    for a, b, c in zip(ref, got, again):
+        tol = 1e-5 * float(a.abs().max())                  # atomics: summation order only
+        assert float((a - b).abs().max()) <= tol
+        assert float((a - c).abs().max()) <= tol
+    with pytest.raises(ValueError):
+        sh = ops.EdgeAttrGradShare()
+        xd = x.clone().requires_grad_()
+        blocks[0](xd, ei, edge_attr=ea.clone().requires_grad_(), ea_grad=sh)
+        blocks[1](xd, ei, edge_attr=ea.clone().requires_grad_(), ea_grad=sh)
