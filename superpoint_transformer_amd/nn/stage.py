@@ -147,7 +147,8 @@ class Stage(nn.Module):
                 edge_index = edge_csr_of(edge_index, x.shape[0])   # once per stage
             # the blocks all read the same edge_attr: one shared gradient buffer
             share = ops.EdgeAttrGradShare() if (
-                edge_attr is not None and len(self.transformer_blocks) > 1
+                ops.share_edge_attr_grad() and edge_attr is not None
+                and len(self.transformer_blocks) > 1
                 and torch.is_grad_enabled() and edge_attr.requires_grad) else None
             for block in self.transformer_blocks:
                 x, norm_index, edge_index = block(

@@ -3,6 +3,8 @@
 Every function here launches a kernel of libspt_hip.so on torch's current
 stream; there is no eager-PyTorch path.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -360,6 +362,19 @@ def _f32c(t):
     if t.dtype != torch.float32:
         t = t.float()
     return t.contiguous()
+
+
+_EA_SHARE = os.environ.get("SPT_EA_GRAD_SHARE", "1") != "0"
+
+
+def share_edge_attr_grad(on=None):
+    """Whether ``Stage.forward`` lets its blocks accumulate d edge_attr in one buffer (default on;
+    ``SPT_EA_GRAD_SHARE=0`` in the environment turns it off).  Returns the previous setting."""
+    global _EA_SHARE
+    prev = _EA_SHARE
+    if on is not None:
+        _EA_SHARE = bool(on)
+    return prev
 
 
 class EdgeAttrGradShare:

@@ -7,11 +7,18 @@ duration in microseconds, share of GPU time) for captures written in the
 default rocpd format.
 """
 import csv
+import glob
+import os
 import sqlite3
 import sys
 
 
 def main(path):
+    if os.path.isdir(path):                     # a rocprofv3 -d directory: take its database
+        dbs = glob.glob(os.path.join(path, "**", "*.db"), recursive=True)
+        if not dbs:
+            sys.exit(f"no .db under {path}")
+        path = dbs[0]
     c = sqlite3.connect(path)
     rows = c.execute(
         "select name, count(*), sum(end-start)/1e3, avg(end-start)/1e3, "

@@ -1,7 +1,10 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-(cd /tmp && timeout 500 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS -d /tmp/pmc_step -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-preprocess > /tmp/pmc_step.log 2>&1)
-python tools/pmc_query.py /tmp/pmc_step "%fmlp%" > gpurun_out/r2q_pmc_fmlp.txt 2>&1
-grep -E "bwd_kernel_bf<16, 8|bwd_kernel_bf<8, 4|fwd_kernel<16, 8" gpurun_out/r2q_pmc_fmlp.txt | cut -c1-30,40-140
-tail -3 /tmp/pmc_step.log
+timeout 900 python -m pytest tests/test_attention_gpu.py tests/test_fullsize_gpu.py tests/test_model_gpu.py -m gpu -x -q 2>&1 | tail -8
+timeout 200 python tools/attn_microbench.py --mode 2 --packed 1 2>&1 | tail -4
+timeout 200 python tools/attn_microbench.py --mode 2 --packed 0 2>&1 | tail -2
+for sh in 1 0; do
+  echo "share=$sh"
+  SPT_EA_GRAD_SHARE=$sh timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-preprocess 2>/dev/null | cut -c100-200
+done
