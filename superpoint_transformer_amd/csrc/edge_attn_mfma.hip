@@ -148,6 +148,37 @@ __device__ __forceinline__ void tile_issue(const float* __restrict__ qkv, int ld
   }
 }
 
+// Same, with the tile's ids in LDS (ids[0..15] = edge rows, ids[16..31] = targets; `e0` >= 0:
+// no edge permutation, rows are e0 + u): every lane reads the id of the row its chunk belongs
+// to - no cross-lane shuffles, one LDS round trip for the six reads.
+__device__ __forceinline__ void tile_issue_ids(const float* __restrict__ qkv, int ld,
+                                               const float* __restrict__ ea, const int* ids,
+                                               int64_t e0, int cnt, float* buf, int lane) {
+  int e2[2], t4[4];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) e2[p] = ids[p * 8 + (lane >> 3)];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) t4[i] = ids[TE + i * 4 + (lane >> 4)];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int u = p * 8 + (lane >> 3), ch = lane & 7;
+    const int64_t e = e0 >= 0 ? e0 + u : (int64_t)e2[p];
+    if (u < cnt)
+      lds_dma16(ea + (size_t)e * F + ((ch ^ (u & 7)) << 2), buf + p * 256);
+  }
+  float* kbuf = buf + EA_FLOATS;
+  float* vbuf = kbuf + TE * ROW;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int u = i * 4 + (lane >> 4), ch = lane & 15;
+    const int64_t t = t4[i];
+    if (u < cnt) {
+      lds_dma16(qkv + t * ld + 64 + ch * 4, kbuf + i * 256);
+      lds_dma16(qkv + t * ld + 128 + ch * 4, vbuf + i * 256);
+    }
+  }
+}
+
 // B operands of the RPE GEMM: lane (g, c) holds W[16 b + c][4 step + g]
 __device__ __forceinline__ void load_b(const float* __restrict__ W, int g, int c,
                                        float (&B)[NB][8]) {
@@ -901,6 +932,19 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attn_bwd_mfma_kernel(
 // (gqkv is zero-filled by the entry point); dk / dv were atomic already.  The node owning a
 // wave's first edge comes from one binary search of the CSR pointers at the wave's start; from
 // there the nodes are walked in order.
+// -DSPT_ATTN_PROFILE: per-section cycle counts (s_memtime) of one wave, printed at its end -
+// a measurement build only (tools/attn_microbench.py against gpurun_variants/), never shipped
+#ifdef SPT_ATTN_PROFILE
+#define SPT_PROBE(i)                                              \
+  {                                                               \
+    const uint64_t now_ = __builtin_amdgcn_s_memtime();           \
+    prof[i] += now_ - tlast;                                      \
+    tlast = now_;                                                 \
+  }
+#else
+#define SPT_PROBE(i)
+#endif
+
 struct NodeCtx {
   // ml = m + log(z + 1e-16): the softmax weight of an edge is exp(p - ml) (one value and one
   // select per head instead of m and 1/z)
@@ -924,6 +968,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attn_bwd_packed_kernel(
   constexpr bool LO = PREC == 3;
   __shared__ __attribute__((aligned(16))) float slab_all[WAVES][2][SLAB];
   __shared__ __attribute__((aligned(16))) float dt_all[WAVES][DT_FLOATS];
+  __shared__ __attribute__((aligned(16))) int ids_all[WAVES][2][2 * TE];   // the last free KB
   __shared__ __attribute__((aligned(16))) __bf16 wb_hi[WB_ELEMS];
   __shared__ __attribute__((aligned(16))) __bf16 wb_lo[WB_ELEMS];
   const int lane = threadIdx.x & 63;
@@ -1054,37 +1099,60 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attn_bwd_packed_kernel(
     }
     // ---- tile pipeline: cur in LDS buffer bsel, nxt streaming into bsel ^ 1, indices of the
     //      tile after that in VGPRs -----------------------------------------------------------
+    // The ids of a tile (edge rows, targets) travel by LDS-DMA too, two tiles ahead, into a
+    // two-slot ring (slot = tile & 1).  As register loads they cost a stall per tile: the
+    // values lived in AGPRs across the iteration, the move there needs the data, so the compiler
+    // put a vmcnt(0) right behind the load - with the next tile's DMA in flight (in-kernel cycle
+    // counts: 17 % of the loop in "issue the next tile").
     int bsel = 0;
-    int e_cur = 0, t_cur = 0, e_nxt = 0, t_nxt = 0, e_nn = 0, t_nn = 0;
+    int e_cur = 0, t_cur = 0;
     auto cnt_of = [&](int64_t t) {
       const int64_t r = E - t * TE;
       return (int)(t < t_end ? (r < TE ? r : TE) : 0);
     };
-    auto load_idx = [&](int64_t t, int& e_l, int& t_l) {
-      e_l = 0;
-      t_l = 0;
-      if (lane < cnt_of(t)) {
-        e_l = eperm ? eperm[t * TE + lane] : (int)(t * TE + lane);
-        t_l = tgt[t * TE + lane];
+    int* ids_ring = ids_all[wid][0];
+    auto ids_issue = [&](int64_t t) {                   // lanes 0-15: edge rows, 16-31: targets
+      const int u = lane & 15;
+      if (lane < 2 * TE && u < cnt_of(t) && (lane >= TE || eperm)) {
+        const int32_t* src = (lane < TE ? eperm : tgt) + t * TE + u;
+        lds_dma4(reinterpret_cast<const float*>(src),
+                 reinterpret_cast<float*>(ids_ring + (t & 1) * 2 * TE));
       }
     };
     float* base = slab_all[wid][0];
-    load_idx(t_begin, e_cur, t_cur);
+    ids_issue(t_begin);
+    ids_issue(t_begin + 1);
     wait_vmem_all();
-    tile_issue(qkv, ld, ea, e_cur, t_cur, cnt_of(t_begin), base, lane);
-    load_idx(t_begin + 1, e_nxt, t_nxt);
+    tile_issue_ids(qkv, ld, ea, ids_ring + (t_begin & 1) * 2 * TE,
+                   eperm ? (int64_t)-1 : t_begin * TE, cnt_of(t_begin), base, lane);
 
+#ifdef SPT_ATTN_PROFILE
+    uint64_t prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t tlast = __builtin_amdgcn_s_memtime();
+#endif
     for (int64_t t = t_begin; t < t_end; ++t) {
       wait_vmem_all();                                   // tile t landed, indices of t + 1 too
+      SPT_PROBE(0)
       if (!a_ready) {                                    // first iteration: the wave's first node
         pop_node();
         a_ready = true;
       } else if (b_state == 1 || b_state == 2) {
         convert_b();                                     // requested before this wait: landed
       }
+      SPT_PROBE(1)
+      {
+        // this tile's ids for the scatters below, then the slot is free for tile t + 2
+        const int* mine = ids_ring + (t & 1) * 2 * TE;
+        e_cur = eperm ? mine[lane & 15] : (int)(t * TE) + (lane & 15);
+        t_cur = mine[TE + (lane & 15)];
+      }
       if (t + 1 < t_end)
-        tile_issue(qkv, ld, ea, e_nxt, t_nxt, cnt_of(t + 1), base + (bsel ^ 1) * SLAB, lane);
-      load_idx(t + 2, e_nn, t_nn);
+        tile_issue_ids(qkv, ld, ea, ids_ring + ((t + 1) & 1) * 2 * TE,
+                       eperm ? (int64_t)-1 : (t + 1) * TE, cnt_of(t + 1),
+                       base + (bsel ^ 1) * SLAB, lane);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // e_cur / t_cur are out of the slot
+      ids_issue(t + 2);
+      SPT_PROBE(2)
       const float* slab = base + bsel * SLAB;
       const float* kslab = slab + EA_FLOATS;
       const float* vslab = kslab + TE * ROW;
@@ -1125,6 +1193,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attn_bwd_packed_kernel(
           Cv[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, vh, Cv[b], 0, 0, 0);
         }
       }
+      SPT_PROBE(3)
       // ---- per-edge gradients: rows below `split` belong to A, the rest (up to `hi`) to B;
       //      more than two nodes in the tile -> further passes over the remaining rows ---------
       const float* kp = kslab + 4 * g * ROW + c;
@@ -1181,6 +1250,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attn_bwd_packed_kernel(
         }
         lo = hi;
       }
+      SPT_PROBE(4)
 #pragma unroll
       for (int b = 0; b < NB; ++b)
 #pragma unroll
@@ -1209,7 +1279,13 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attn_bwd_packed_kernel(
           }
         }
       }
+      SPT_PROBE(5)
       // ---- d edge_attr = D W ---------------------------------------------------------------
+      // (the rows' edge ids first, all four shuffles in flight under the D-tile round trip:
+      // taken one by one next to their stores they cost an LDS round trip each)
+      int e4[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) e4[r] = __shfl(e_cur, 4 * g + r, 64);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -1224,6 +1300,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attn_bwd_packed_kernel(
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      asm volatile("" : "+v"(e4[0]), "+v"(e4[1]), "+v"(e4[2]), "+v"(e4[3]));
       f32x4 C2[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
       {
         const float* arow = dt + c * DT_STRIDE + 8 * g;
@@ -1246,7 +1323,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attn_bwd_packed_kernel(
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int64_t e = __shfl(e_cur, 4 * g + r, 64);
+        const int64_t e = e4[r];
         if (4 * g + r < cnt) {
           if (gea_acc) {            // shared gradient buffer of the stage's blocks
             unsafeAtomicAdd(gea + e * F + c, C2[0][r]);
@@ -1257,7 +1334,8 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attn_bwd_packed_kernel(
           }
         }
       }
-      // ---- dW += D^T EA ------------------------------------------------------------------------
+SPT_PROBE(6)
+            // ---- dW += D^T EA ------------------------------------------------------------------------
       {
         s16x4 Eh[2], El[2];
 #pragma unroll
@@ -1290,12 +1368,19 @@ __global__ __launch_bounds__(WAVES * 64, 1) void attn_bwd_packed_kernel(
           }
         }
       }
+      SPT_PROBE(7)
       // rotate the pipeline
-      e_cur = e_nxt; t_cur = t_nxt;
-      e_nxt = e_nn; t_nxt = t_nn;
       bsel ^= 1;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     }
+#ifdef SPT_ATTN_PROFILE
+    if (lane == 0 && (wave == 5 || wave == 517))
+      printf("attn_bwd_packed wave %ld tiles %ld cycles: wait %lu node %lu issue %lu regemm %lu "
+             "pass %lu atomics %lu dea %lu dw %lu\n", (long)wave, (long)(t_end - t_begin),
+             (unsigned long)prof[0], (unsigned long)prof[1], (unsigned long)prof[2],
+             (unsigned long)prof[3], (unsigned long)prof[4], (unsigned long)prof[5],
+             (unsigned long)prof[6], (unsigned long)prof[7]);
+#endif
     // nodes left open at the end of the wave's range: their remaining rows belong to the next
     // wave; what this wave accumulated goes out now
     if (a_ready && A.node < N) finish_node(A);
