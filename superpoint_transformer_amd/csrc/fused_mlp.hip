@@ -44,11 +44,48 @@ __device__ __forceinline__ void wave_sync_lds() {
 // with the per-column tables read from LDS (tab = am | sc | bs, KT floats each).
 // Rows >= cnt and columns >= K become 0.  RAW != nullptr also keeps the raw values.
 // IND: the tile's rows are x[rid] with rid held by lane rr of `rid_l` (a gathered tile).
-template <int KP, int LD, int KT, bool IND = false>
+template <int KP, int LD, int KT, bool IND = false, int GRP = 4>
 __device__ __forceinline__ void stage_tile(const float* __restrict__ x, int64_t row0, int cnt,
                                            int K, bool pre, const float* tab, float slope,
                                            float* lds, float* raw, int lane, int rid_l = 0) {
-  if ((K & 3) == 0) {
+  if (K == KP) {
+    // whole rows of 16-byte chunks, trip count known: the loads of up to four chunks per lane
+    // are issued together and consumed afterwards - ONE memory round trip per group instead of
+    // one per chunk (in-kernel cycle counts: this loop, load -> use -> ds_write per chunk, was
+    // 58 % of the 64 -> 128 forward kernel and 18 % of its backward)
+    constexpr int CH = KP / 4, NIT = (TR * CH + 63) / 64;
+#pragma unroll 1
+    for (int i0 = 0; i0 < NIT; i0 += GRP) {
+      float4 v[GRP];
+#pragma unroll
+      for (int j = 0; j < GRP; ++j) {
+        const int q = lane + 64 * (i0 + j), rr = q / CH, k = (q - rr * CH) << 2;
+        v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i0 + j < NIT) {
+          const int64_t xr = IND ? (int64_t)__shfl(rid_l, rr < TR ? rr : 0, 64) : row0 + rr;
+          if (q < TR * CH && rr < cnt) v[j] = *reinterpret_cast<const float4*>(x + xr * K + k);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < GRP; ++j) {
+        const int q = lane + 64 * (i0 + j), rr = q / CH, k = (q - rr * CH) << 2;
+        if (i0 + j < NIT && q < TR * CH) {
+          float4 w = v[j];
+          if (raw) *reinterpret_cast<float4*>(raw + rr * LD + k) = w;
+          if (pre && rr < cnt) {
+            const float4 a = *reinterpret_cast<const float4*>(tab + k);
+            const float4 s = *reinterpret_cast<const float4*>(tab + KT + k);
+            const float4 b = *reinterpret_cast<const float4*>(tab + 2 * KT + k);
+            w.x = fmaf(w.x - a.x, s.x, b.x); w.y = fmaf(w.y - a.y, s.y, b.y);
+            w.z = fmaf(w.z - a.z, s.z, b.z); w.w = fmaf(w.w - a.w, s.w, b.w);
+            w.x = w.x > 0.f ? w.x : w.x * slope; w.y = w.y > 0.f ? w.y : w.y * slope;
+            w.z = w.z > 0.f ? w.z : w.z * slope; w.w = w.w > 0.f ? w.w : w.w * slope;
+          }
+          *reinterpret_cast<float4*>(lds + rr * LD + k) = w;
+        }
+      }
+    }
+  } else if ((K & 3) == 0) {
     const int CH = K >> 2;
     for (int q = lane; q < TR * CH; q += 64) {
       const int rr = q / CH, k = (q - rr * CH) << 2;
@@ -90,6 +127,21 @@ __device__ __forceinline__ void load_table(float* dst, const float* __restrict__
   for (int i = threadIdx.x; i < cap; i += WAVES * 64) dst[i] = (src && i < n) ? src[i] : 0.f;
 }
 
+// -DSPT_FMLP_PROFILE: per-section cycle counts (s_memtime) of wave 5 of the 64 -> 128 kernels,
+// printed at its end - a measurement build only (gpurun_variants/), never shipped
+#ifdef SPT_FMLP_PROFILE
+#define FM_PROBE(i)                                               \
+  {                                                               \
+    const uint64_t now_ = __builtin_amdgcn_s_memtime();           \
+    prof[i] += now_ - tlast;                                      \
+    tlast = now_;                                                 \
+  }
+#define FM_PROBE_INIT uint64_t prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint64_t tlast = __builtin_amdgcn_s_memtime();
+#else
+#define FM_PROBE(i)
+#define FM_PROBE_INIT
+#endif
+
 // ---- forward -------------------------------------------------------------------
 // K4 = ceil(K/4) k-steps, NBK = N/16 column blocks.
 template <int K4, int NBK>
@@ -128,12 +180,15 @@ __global__ __launch_bounds__(WAVES * 64, 2) void fwd_kernel(
   const int64_t ntiles = (r1 - r0 + TR - 1) / TR;
   const int64_t wave = (int64_t)blockIdx.x * WAVES + wid;
   const int64_t nwaves = (int64_t)gridDim.x * WAVES;
+  FM_PROBE_INIT
   for (int64_t t = wave; t < ntiles; t += nwaves) {
     const int64_t row0 = r0 + t * TR;
     const int cnt = (int)((r1 - row0) < TR ? (r1 - row0) : TR);
     wave_sync_lds();
+    FM_PROBE(3)
     stage_tile<KP, LDA, KP>(x, row0, cnt, K, pre, tab, slope, al, nullptr, lane);
     wave_sync_lds();
+    FM_PROBE(0)
     float A[K4];
 #pragma unroll
     for (int st = 0; st < K4; ++st) A[st] = al[c * LDA + 4 * st + g];
@@ -145,6 +200,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void fwd_kernel(
 #pragma unroll
       for (int nb = 0; nb < NBK; ++nb)
         C[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[st], B[nb][st], C[nb], 0, 0, 0);
+    FM_PROBE(1)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int rr = 4 * g + r;
@@ -159,7 +215,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void fwd_kernel(
         }
       }
     }
+    FM_PROBE(2)
   }
+#ifdef SPT_FMLP_PROFILE
+  if (K4 == 16 && NBK == 8 && lane == 0 && wave == 5)
+    printf("fmlp fwd<16,8> wave 5 cycles: stage %lu mfma %lu store+stats %lu looptop %lu\n",
+           (unsigned long)prof[0], (unsigned long)prof[1], (unsigned long)prof[2],
+           (unsigned long)prof[3]);
+#endif
 #pragma unroll
   for (int nb = 0; nb < NBK; ++nb) {
     const double a = xg_sum_d(s1[nb]), b = xg_sum_d(s2[nb]);
@@ -701,10 +764,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_kernel_bf(
   }
   int rid_l = rid_n, seg_l = seg_n;
   load_ids(wave + nwaves);
+  FM_PROBE_INIT
   for (int64_t t = wave; t < ntiles; t += nwaves) {
     const int64_t row0 = r0 + t * TR;
     const int cnt = (int)((r1 - row0) < TR ? (r1 - row0) : TR);
     wave_sync_lds();
+    FM_PROBE(5)
     if constexpr (PIPE) {
       // stage the prefetched chunks, then request the next tile's while this one computes
 #pragma unroll
@@ -726,28 +791,54 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_kernel_bf(
         *reinterpret_cast<float4*>(xl + rr * LDX + k) = p_x[i];
       }
     } else {
-      for (int q = lane; q < TR * CH; q += 64) {
-        const int rr = q / CH, n = (q - rr * CH) << 2;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        const int rid = POOLED ? __shfl(rid_l, rr, 64) : 0;
-        const int64_t sg = POOLED ? (int64_t)__shfl(seg_l, rr, 64) : 0;
-        if (rr < cnt) {
-          const int64_t hr = POOLED ? (int64_t)rid : row0 + rr;
-          const float4 hv = *reinterpret_cast<const float4*>(h + hr * N + n);
-          float4 gv;
-          if constexpr (POOLED) {
-            const int4 a4 = *reinterpret_cast<const int4*>(arg + sg * N + n);
-            const float4 g4 = *reinterpret_cast<const float4*>(gout + sg * N + n);
-            gv = make_float4(a4.x == rid ? g4.x : 0.f, a4.y == rid ? g4.y : 0.f,
-                             a4.z == rid ? g4.z : 0.f, a4.w == rid ? g4.w : 0.f);
-          } else {
-            gv = *reinterpret_cast<const float4*>(gy + (row0 + rr) * N + n);
+      // chunks in groups of GS: all loads of a group first, then their transforms - one
+      // memory round trip per group instead of one per chunk
+      // (the pooled 64 -> 128 kernel has no registers to spare: 256 with the gW accumulators)
+      constexpr int NITG = TR * CH / 64, GS = NITG < 2 ? 1 : 2;
+      static_assert(TR * CH % 64 == 0, "whole waves of chunks");
+#pragma unroll 1
+      for (int i0 = 0; i0 < NITG; i0 += GS) {
+        float4 hv[GS], gv[GS];
+        int4 av[POOLED ? GS : 1];
+        int ridv[GS];
+#pragma unroll
+        for (int j = 0; j < GS; ++j) {
+          const int q = lane + 64 * (i0 + j), rr = q / CH, n = (q - rr * CH) << 2;
+          ridv[j] = POOLED ? __shfl(rid_l, rr, 64) : 0;
+          const int64_t sg = POOLED ? (int64_t)__shfl(seg_l, rr, 64) : 0;
+          hv[j] = gv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if constexpr (POOLED) av[j] = make_int4(-1, -1, -1, -1);
+          if (rr < cnt) {
+            const int64_t hr = POOLED ? (int64_t)ridv[j] : row0 + rr;
+            hv[j] = *reinterpret_cast<const float4*>(h + hr * N + n);
+            if constexpr (POOLED) {
+              av[j] = *reinterpret_cast<const int4*>(arg + sg * N + n);
+              gv[j] = *reinterpret_cast<const float4*>(gout + sg * N + n);
+            } else {
+              gv[j] = *reinterpret_cast<const float4*>(gy + (row0 + rr) * N + n);
+            }
           }
-          v = gh_of(hv, gv, n);
         }
-        *reinterpret_cast<float4*>(gl + rr * LDG + n) = v;
+#pragma unroll
+        for (int j = 0; j < GS; ++j) {
+          const int q = lane + 64 * (i0 + j), rr = q / CH, n = (q - rr * CH) << 2;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (rr < cnt) {
+            float4 g4 = gv[j];
+            if constexpr (POOLED) {
+              const int rid = ridv[j];
+              g4 = make_float4(av[j].x == rid ? g4.x : 0.f, av[j].y == rid ? g4.y : 0.f,
+                               av[j].z == rid ? g4.z : 0.f, av[j].w == rid ? g4.w : 0.f);
+            }
+            v = gh_of(hv[j], g4, n);
+          }
+          *reinterpret_cast<float4*>(gl + rr * LDG + n) = v;
+        }
       }
-      stage_tile<KPP, LDX, KPP, POOLED>(xprev, row0, cnt, K, false, pt, pslope, xl, nullptr, lane, rid_l);
+      FM_PROBE(0)
+      stage_tile<KPP, LDX, KPP, POOLED, (POOLED && NBK >= 8) ? 2 : 4>(xprev, row0, cnt, K, false, pt, pslope, xl,
+                                                                        nullptr, lane, rid_l);
+      FM_PROBE(1)
     }
     const int rid_cur = rid_l;                 // the gx scatter below needs this tile's row ids
     if constexpr (PIPE) load_raw(t + nwaves, rid_n, seg_n);
@@ -755,6 +846,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_kernel_bf(
     seg_l = seg_n;
     load_ids(t + 2 * nwaves);
     wave_sync_lds();
+    FM_PROBE(2)
     // ---- gW += gh^T y_prev ------------------------------------------------------------
     {
       bf16x4 Xh[KB], Xl[KB];
@@ -785,6 +877,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_kernel_bf(
         for (int kb = 0; kb < KB; ++kb) C3[nb][kb] = mfma3_16<LO>(gh4, gl4, Xh[kb], Xl[kb], C3[nb][kb]);
       }
     }
+    FM_PROBE(3)
     // ---- gx = gh W (+ statistics for the previous GraphNorm's backward) ------------------
     if constexpr (NEED_GX) {
       f32x4 CX[KB];
@@ -830,7 +923,15 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_kernel_bf(
         }
       }
     }
+    FM_PROBE(4)
   }
+#ifdef SPT_FMLP_PROFILE
+  if (K4 == 16 && NBK == 8 && lane == 0 && wave == 5)
+    printf("fmlp bwd<16,8,pooled=%d> wave 5 cycles: stage_gh %lu stage_x %lu ids+sync %lu dW %lu "
+           "dX+store+stats %lu looptop %lu\n", (int)POOLED, (unsigned long)prof[0],
+           (unsigned long)prof[1], (unsigned long)prof[2], (unsigned long)prof[3],
+           (unsigned long)prof[4], (unsigned long)prof[5]);
+#endif
   float* gwp = gw_partial + (size_t)wave * N * K;
 #pragma unroll
   for (int nb = 0; nb < NBK; ++nb)
