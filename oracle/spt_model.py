@@ -112,6 +112,8 @@ def spt_forward(model, levels, dtype=torch.float64, keep_graph=False):
     def f(t):
         return None if t is None else t.to(dtype)
 
+    if getattr(model, "nano", False):
+        return _spt_forward_nano(model, levels, dtype, f)
     nd = model.num_down_stages
     lv0 = levels[0]
     x, _ = stage(model.first_stage, f(lv0.get("x")) if model.use_node_hf else None,
@@ -149,6 +151,58 @@ def spt_forward(model, levels, dtype=torch.float64, keep_graph=False):
         x, _ = stage(model.up_stages[i], fused, lv.get("batch"), f(lv["pos"]),
                      lv.get("node_size"), lv.get("super_index"), lv.get("edge_index"),
                      eattr.get(lvl), dtype)
+        ups.append(x)
+    if model.output_stage_wise:
+        return [x] + ups[::-1][1:] + [down[-1]]
+    return x
+
+
+def _spt_forward_nano(model, levels, dtype, f):
+    """spt.py:760-879 with ``nano=True``: ``levels[0]`` is NAG level 1 (the first level the model
+    sees); its handcrafted features go through ``node_mlps[0]`` / ``h_edge_mlps[0]`` into the
+    first Stage (a full Stage with transformer blocks), stage i then works on ``levels[i + 1]``."""
+    nd = model.num_down_stages
+
+    def hf(lv, k):
+        ni, ei = lv.get("batch"), lv.get("edge_index")
+        xh, ea = f(lv.get("x")), f(lv.get("edge_attr"))
+        if model.node_mlps[k] is not None and xh is not None:
+            xh = mlp(model.node_mlps[k], xh, ni, dtype)
+        if model.h_edge_mlps[k] is not None and ea is not None:
+            ea = mlp(model.h_edge_mlps[k], ea, None if ni is None else ni[ei[0]], dtype)
+        return xh, ea
+
+    node_x, eattr = {}, {}
+    lv = levels[0]
+    node_x[0], eattr[0] = hf(lv, 0)
+    top = nd
+    x, _ = stage(model.first_stage, node_x[0] if model.use_node_hf else None, lv.get("batch"),
+                 f(lv["pos"]), lv.get("node_size"), None if top == 0 else lv.get("super_index"),
+                 lv.get("edge_index"), eattr[0], dtype)
+    down = [x]
+    for i in range(nd):
+        lv = levels[i + 1]
+        st = model.down_stages[i]
+        node_x[i + 1], eattr[i + 1] = hf(lv, i + 1)
+        pooled = O.scatter(x, levels[i]["super_index"], 0, None, lv["pos"].shape[0],
+                           st.down_pool_block.reduce)
+        xp = node_x[i + 1] if model.use_node_hf else None
+        fused = pooled if xp is None else torch.cat((xp, pooled), dim=1)
+        x, _ = stage(st, fused, lv.get("batch"), f(lv["pos"]), lv.get("node_size"),
+                     None if i + 1 == top else lv.get("super_index"), lv.get("edge_index"),
+                     eattr[i + 1], dtype)
+        down.append(x)
+    ups = []
+    for i in range(model.num_up_stages):
+        lvl = nd - i - 1
+        lv = levels[lvl]
+        skip = down[-(2 + i)]
+        xh = node_x.get(lvl) if model.use_node_hf else None
+        xc = skip if xh is None else torch.cat((skip, xh), dim=1)
+        unp = O.index_unpool(x, lv["super_index"])
+        x, _ = stage(model.up_stages[i], torch.cat((xc, unp), dim=1), lv.get("batch"),
+                     f(lv["pos"]), lv.get("node_size"), lv.get("super_index"),
+                     lv.get("edge_index"), eattr.get(lvl), dtype)
         ups.append(x)
     if model.output_stage_wise:
         return [x] + ups[::-1][1:] + [down[-1]]

@@ -787,12 +787,13 @@ using namespace spt;
     SPT_ATTN_CASE(FN, 1, 1, 32, __VA_ARGS__)                                   \
     SPT_ATTN_CASE(FN, 1, 2, 32, __VA_ARGS__)                                   \
     SPT_ATTN_CASE(FN, 2, 2, 32, __VA_ARGS__)                                   \
+    SPT_ATTN_CASE(FN, 1, 1, 16, __VA_ARGS__)  /* nano: 16-D edge encodings */  \
     SPT_ATTN_CASE(FN, 1, 1, 18, __VA_ARGS__)                                   \
     SPT_ATTN_CASE(FN, 1, 2, 18, __VA_ARGS__)                                   \
     SPT_ATTN_CASE(FN, 2, 2, 18, __VA_ARGS__)                                   \
     if (!done__)                                                               \
       return ::spt::fail(-4, "%s: unsupported attention shape H=%d D=%d Dv=%d F=%d " \
-                         "(built: H*D<=128, H*Dv<=128, F in {18,32})", __func__, H, D, Dv, F); \
+                         "(built: H*D<=128, H*Dv<=128, F in {18,32}; F=16 with H*D, H*Dv <= 64)", __func__, H, D, Dv, F); \
   } while (0)
 
 extern "C" int spt_attn_bwd_packed(int on) {

@@ -37,6 +37,19 @@ def spt64_config(point_in=8, edge_in=18):
         fusion="cat", output_stage_wise=True)
 
 
+def nano2_config(seg_in=8, edge_in=18):
+    """configs/model/semantic/nano-2.yaml on datamodule/semantic/s3dis_nano.yaml: no level-0
+    stage, the NAG starts at level 1 with 8 handcrafted segment features through a node MLP to
+    16, dims 16, qk_dim 2 (value dim 1), edge MLP to 16."""
+    cfg = spt64_config(8, edge_in)
+    d, inj = 16, 3 + 1 + 16
+    cfg.update(nano=True, point_mlp=None, down_dim=[d, d], down_pool_dim=[128, d],
+               down_in_mlp=[[inj, d, d], [inj + d, d, d]], up_dim=[d],
+               up_in_mlp=[[inj + d + d, d, d]], node_mlp=[seg_in, d, d],
+               h_edge_mlp=[edge_in, d, d], qk_dim=2, in_rpe_dim=d)
+    return cfg
+
+
 def spt128_config(point_in=8, edge_in=18):
     """SPT-128 of configs/experiment/semantic/kitti360.yaml:22-27: the same spt-2 tree
     (2 down stages, 1 up) with `_down_dim` / `_up_dim` 128 (value dim 8 per head),

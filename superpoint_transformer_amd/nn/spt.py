@@ -5,15 +5,17 @@ fuse -> transformer blocks) going up, UpNFuseStages (unpool -> fuse ->
 blocks) coming back down to level 1.  Constructor arguments and module names
 (``first_stage``, ``down_stages``, ``up_stages``, ``node_mlps``,
 ``h_edge_mlps``, ``v_edge_mlps``) follow the reference so that its state
-dicts load.  ``nano=True`` (no level-0 stage) and the sparse-CNN point encoder
-are outside the hot path and raise."""
+dicts load.  ``nano=True`` (spt.py:486-521, 786-797: no level-0 stage - the NAG starts at level
+1, whose handcrafted features go through ``node_mlps[0]`` / ``h_edge_mlps[0]`` into a full
+``Stage`` with transformer blocks) is built; the sparse-CNN point encoder is outside the hot
+path and raises."""
 from torch import nn
 
 from .fusion import CatFusion
 from .mlp import MLP
 from .norm import GraphNorm
 from .pool import MaxPool, pool_factory
-from .stage import DownNFuseStage, PointStage, UpNFuseStage
+from .stage import DownNFuseStage, PointStage, Stage, UpNFuseStage
 from .transformer import VersionHolder
 
 __all__ = ["SPT"]
@@ -81,11 +83,9 @@ class SPT(nn.Module):
                  use_diameter_parent=False, pool="max", unpool="index", fusion="cat",
                  norm_mode="graph", output_stage_wise=False, version="3.0.0", **ignored):
         super().__init__()
-        if nano:
-            raise NotImplementedError("nano SPT (no level-0 stage) is not on the HIP path yet")
         if norm_mode != "graph":
             raise NotImplementedError("only norm_mode='graph' is built")
-        self.nano = False
+        self.nano = nano = bool(nano)
         self.use_pos, self.use_node_hf = use_pos, use_node_hf
         self.use_diameter, self.use_diameter_parent = use_diameter, use_diameter_parent
         self.output_stage_wise = output_stage_wise
@@ -102,19 +102,16 @@ class SPT(nn.Module):
             up_dim, up_in_mlp, up_out_mlp, up_mlp_drop, up_num_heads, up_num_blocks,
             up_ffn_ratio, up_residual_drop, up_attn_drop, up_drop_path)
         # in_mlp entries are themselves lists: _listify must not broadcast them
-        num_down, num_up = len(down_dim), len(up_dim)
+        # spt.py:450-483: with nano the first entry of every down_* list configures the first
+        # Stage, and the handcrafted-feature MLPs get one more entry (run before that Stage)
+        num_down, num_up = len(down_dim) - nano, len(up_dim)
 
         needs_h_edge = any(b > 0 for b in down_num_blocks + up_num_blocks)
-        self.node_mlps = _mlps(node_mlp if use_node_hf else None, num_down, mlp_activation,
-                               mlp_norm, share_hf_mlps)
-        self.h_edge_mlps = _mlps(h_edge_mlp if needs_h_edge else None, num_down,
+        self.node_mlps = _mlps(node_mlp if use_node_hf else None, num_down + nano,
+                               mlp_activation, mlp_norm, share_hf_mlps)
+        self.h_edge_mlps = _mlps(h_edge_mlp if needs_h_edge else None, num_down + nano,
                                  mlp_activation, mlp_norm, share_hf_mlps)
         self.v_edge_mlps = _mlps(None, num_down, mlp_activation, mlp_norm, share_hf_mlps)
-
-        self.first_stage = PointStage(
-            point_mlp, mlp_activation=mlp_activation, mlp_norm=mlp_norm, mlp_drop=point_drop,
-            use_pos=use_pos, use_diameter_parent=use_diameter_parent,
-            version_holder=self.version_holder)
         self.feature_fusion = CatFusion()
 
         common = dict(mlp_activation=mlp_activation, mlp_norm=mlp_norm, qk_dim=qk_dim,
@@ -126,10 +123,23 @@ class SPT(nn.Module):
                       use_diameter=use_diameter, use_diameter_parent=use_diameter_parent,
                       blocks_share_rpe=blocks_share_rpe, heads_share_rpe=heads_share_rpe,
                       version_holder=self.version_holder)
+        if nano:                                              # spt.py:486-521
+            self.first_stage = Stage(
+                down_dim[0], num_blocks=down_num_blocks[0], in_mlp=down_in_mlp[0],
+                out_mlp=down_out_mlp[0], mlp_drop=down_mlp_drop[0],
+                num_heads=down_num_heads[0], ffn_ratio=down_ffn_ratio[0],
+                residual_drop=down_residual_drop[0], attn_drop=down_attn_drop[0],
+                drop_path=down_drop_path[0], k_rpe=k_rpe, q_rpe=q_rpe, **common)
+        else:
+            self.first_stage = PointStage(
+                point_mlp, mlp_activation=mlp_activation, mlp_norm=mlp_norm,
+                mlp_drop=point_drop, use_pos=use_pos, use_diameter_parent=use_diameter_parent,
+                version_holder=self.version_holder)
         if num_down > 0:
-            dk = _rpe_per_stage(k_rpe, num_down, 18, qk_dim, stages_share_rpe)
-            dq = _rpe_per_stage(q_rpe and not (k_rpe and qk_share_rpe), num_down, 18, qk_dim,
-                                stages_share_rpe)
+            # the per-stage lists keep the length of down_dim: entry 0 is the nano Stage's
+            dk = [None] * nano + _rpe_per_stage(k_rpe, num_down, 18, qk_dim, stages_share_rpe)
+            dq = [None] * nano + _rpe_per_stage(q_rpe and not (k_rpe and qk_share_rpe), num_down,
+                                                18, qk_dim, stages_share_rpe)
             self.down_stages = nn.ModuleList([
                 DownNFuseStage(
                     down_dim[i], num_blocks=down_num_blocks[i], in_mlp=down_in_mlp[i],
@@ -138,7 +148,7 @@ class SPT(nn.Module):
                     residual_drop=down_residual_drop[i], attn_drop=down_attn_drop[i],
                     drop_path=down_drop_path[i], k_rpe=dk[i], q_rpe=dq[i],
                     pool=pool_factory(pool[i], down_pool_dim[i]), fusion=fusion, **common)
-                for i in range(num_down)])
+                for i in range(nano, num_down + nano)])
         else:
             self.down_stages = None
         if num_up > 0:
@@ -180,6 +190,8 @@ class SPT(nn.Module):
         the number of clouds in the batch.  Returns level-1 features (or the
         stage-wise list), like spt.py:760-879."""
         B = _get(nag, "num_clouds", None) if not isinstance(nag, (list, tuple)) else None
+        if self.nano:
+            return self._forward_nano(nag, B)
         levels = [nag[i] for i in range(self.num_down_stages + 1)]
         sizes = [_get(lv, "pos").shape[0] for lv in levels]
 
@@ -235,6 +247,67 @@ class SPT(nn.Module):
                 edge_attr=edge_attrs.get(i_level), num_super=sizes[i_level + 1], num_graphs=B)
             up_outputs.append(x)
 
+        if self.output_stage_wise:
+            return [x] + up_outputs[::-1][1:] + [down_outputs[-1]]
+        return x
+
+    def _forward_nano(self, nag, B):
+        """spt.py:760-879 with ``nano=True``: ``nag[1]`` is the first level the model sees
+        (``nag.start_i_level == 1``); stage i works on level i + 1."""
+        nd = self.num_down_stages
+        levels = {i: nag[i] for i in range(1, nd + 2)}
+        sizes = {i: _get(lv, "pos").shape[0] for i, lv in levels.items()}
+        top = nd + 1
+
+        def hf(i_level, k):
+            """node / edge handcrafted features of a level through their MLPs (spt.py:786-797,
+            823-835)"""
+            lv = levels[i_level]
+            ni, ei = _get(lv, "batch"), _get(lv, "edge_index")
+            xh, ea = _get(lv, "x"), _get(lv, "edge_attr")
+            if self.node_mlps[k] is not None and xh is not None:
+                xh = self.node_mlps[k](xh, batch=ni, batch_size=B)
+            if self.h_edge_mlps[k] is not None and ea is not None:
+                ea = self.h_edge_mlps[k](ea, batch=None if ni is None else ni[ei[0]],
+                                         batch_size=B)
+            return xh, ea
+
+        node_x, edge_attrs = {}, {}
+        lv = levels[1]
+        node_x[1], edge_attrs[1] = hf(1, 0)
+        x, _ = self.first_stage(                              # spt.py:893-913
+            node_x[1] if self.use_node_hf else None, _get(lv, "batch"), pos=_get(lv, "pos"),
+            node_size=_get(lv, "node_size"),
+            super_index=None if top == 1 else _get(lv, "super_index"),
+            edge_index=_get(lv, "edge_index"), edge_attr=edge_attrs[1],
+            num_super=None if top == 1 else sizes[2], num_graphs=B)
+        down_outputs = [x]
+        for i_stage in range(nd):
+            i_level = i_stage + 2
+            lv = levels[i_level]
+            node_x[i_level], edge_attrs[i_level] = hf(i_level, i_stage + 1)
+            is_last = i_level == top
+            x, _ = self.down_stages[i_stage](                 # spt.py:915-930
+                node_x[i_level] if self.use_node_hf else None, x, _get(lv, "batch"),
+                _get(levels[i_level - 1], "super_index"), pos=_get(lv, "pos"),
+                node_size=_get(lv, "node_size"),
+                super_index=None if is_last else _get(lv, "super_index"),
+                edge_index=_get(lv, "edge_index"), edge_attr=edge_attrs[i_level],
+                num_super=sizes[i_level], num_graphs=B,
+                num_super_parent=None if is_last else sizes[i_level + 1])
+            down_outputs.append(x)
+        up_outputs = []
+        for i_stage in range(self.num_up_stages):             # spt.py:860-868
+            i_level = nd - i_stage
+            lv = levels[i_level]
+            x_skip = down_outputs[-(2 + i_stage)]
+            xh = node_x.get(i_level) if self.use_node_hf else None
+            x, _ = self.up_stages[i_stage](
+                self.feature_fusion(x_skip, xh), x, _get(lv, "batch"), _get(lv, "super_index"),
+                pos=_get(lv, "pos"), node_size=_get(lv, "node_size"),
+                super_index=_get(lv, "super_index"), edge_index=_get(lv, "edge_index"),
+                edge_attr=edge_attrs.get(i_level), num_super=sizes[i_level + 1], num_graphs=B)
+            up_outputs.append(x)
         if self.output_stage_wise:
             return [x] + up_outputs[::-1][1:] + [down_outputs[-1]]
         return x

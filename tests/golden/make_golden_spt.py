@@ -15,6 +15,10 @@ Two configurations, each derived from the reference's config tree:
   * spt128 - configs/experiment/semantic/kitti360.yaml (same spt-2 tree with
              _down_dim/_up_dim 128, no_ffn False, down_ffn_ratio 1)
 both on a 2-cloud batch: 3 levels, 8 point features, 18-D edge features.
+  * nano2  - configs/experiment/semantic/s3dis_nano.yaml -> model/semantic/nano-2.yaml
+             (nano=True: no level-0 stage, the NAG starts at level 1 with 8 handcrafted segment
+             features; dims 16, qk_dim 2, node / edge MLPs to 16) on levels 1-2 of the same
+             kind of batch.
 
 Outputs: every input tensor, the state dict (names = the reference's), the
 stage-wise outputs, and d(loss)/d(parameter) for loss = sum_i <out_i, gw_i>.
@@ -86,16 +90,16 @@ def load_reference_spt():
         setattr(Data, name, env[name])
 
     class NAG:
-        def __init__(self, levels):
+        def __init__(self, levels, start_i_level=0):
             self._list = levels
-            self.start_i_level = 0
+            self.start_i_level = start_i_level
 
-        def __getitem__(self, i):
-            return self._list[i]
+        def __getitem__(self, i):                  # absolute level index (nag.py:133-160)
+            return self._list[i - self.start_i_level]
 
         num_levels = property(lambda self: len(self._list))
-        absolute_num_levels = property(lambda self: len(self._list))
-        end_i_level = property(lambda self: len(self._list) - 1)
+        absolute_num_levels = property(lambda self: len(self._list) + self.start_i_level)
+        end_i_level = property(lambda self: len(self._list) + self.start_i_level - 1)
 
     exec(compile(cut("src/data/nag.py", "NAG", "add_keys_to"), "nag.py", "exec"), env)
     NAG.add_keys_to = env["add_keys_to"]                       # nag.py:834-868
@@ -137,6 +141,20 @@ def config(which, point_in=8, edge_in=18):
         blocks_share_rpe=False, heads_share_rpe=False, use_pos=True, use_node_hf=True,
         use_diameter=False, use_diameter_parent=True, pool="max", unpool="index",
         fusion="cat", norm_mode="graph", output_stage_wise=True)
+    return cfg
+
+
+def config_nano(seg_in=8, edge_in=18):
+    """model/semantic/nano-2.yaml on datamodule/semantic/s3dis_nano.yaml: 8 segment features
+    (linearity, planarity, scattering, verticality, elevation, rgb), _node_mlp_out =
+    _h_edge_mlp_out = 16, _node_injection_dim = 3 + 1 + 16, qk_dim 2."""
+    cfg = config("spt64")
+    d, inj = 16, 3 + 1 + 16
+    cfg.update(
+        nano=True, point_mlp=None, down_dim=[d, d], down_pool_dim=[128, d],
+        down_in_mlp=[[inj, d, d], [inj + d, d, d]], up_dim=[d],
+        up_in_mlp=[[inj + d + d, d, d]], node_mlp=[seg_in, d, d], h_edge_mlp=[edge_in, d, d],
+        qk_dim=2, in_rpe_dim=d)
     return cfg
 
 
@@ -199,11 +217,47 @@ def run(which, SPT, Data, NAG, gen):
           f"{sum(p.numel() for p in model.parameters())} parameters")
 
 
+def run_nano(SPT, Data, NAG, gen):
+    torch.manual_seed(79)
+    model = SPT(**config_nano()).double()
+    with torch.no_grad():
+        for p in model.parameters():
+            p.copy_((p + 0.05 * torch.randn(p.shape, generator=gen).double()).float().double())
+    levels = synth_levels(gen, n0=2000, n1=900, n2=130)[1:]    # levels 1 and 2 of a hierarchy
+    for lv in levels:
+        lv["x"] = mg.rnd(gen, lv["pos"].shape[0], 8)
+    nag = NAG([Data(**{k: v for k, v in lv.items() if v is not None}) for lv in levels],
+              start_i_level=1)
+    outs = model(nag)
+    gws = [mg.rnd(gen, *o.shape) for o in outs]
+    sum((o * g).sum() for o, g in zip(outs, gws)).backward()
+    arrays = {}
+    for i, lv in enumerate(levels):
+        for k, v in lv.items():
+            if v is not None:
+                arrays[f"l{i + 1}__{k}"] = v
+    for i, (o, g) in enumerate(zip(outs, gws)):
+        arrays[f"out{i}"] = o
+        arrays[f"gw{i}"] = g
+    for k, p in model.named_parameters():
+        arrays["p__" + k] = p.detach().float()
+        assert p.grad is not None, k
+        arrays["g__" + k] = p.grad.float()
+    arrays["num_clouds"] = 2
+    out = {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else v)
+           for k, v in arrays.items()}
+    np.savez_compressed(os.path.join(HERE, "spt_forward_nano2.npz"), **out)
+    print(f"wrote spt_forward_nano2.npz: {len(out)} arrays, "
+          f"{sum(p.numel() for p in model.parameters())} parameters")
+
+
 def main():
     SPT, Data, NAG = load_reference_spt()
-    gen = torch.Generator().manual_seed(4242)
-    for which in ("spt64", "spt128"):
-        run(which, SPT, Data, NAG, gen)
+    if "--nano-only" not in sys.argv:
+        gen = torch.Generator().manual_seed(4242)
+        for which in ("spt64", "spt128"):
+            run(which, SPT, Data, NAG, gen)
+    run_nano(SPT, Data, NAG, torch.Generator().manual_seed(4343))
 
 
 if __name__ == "__main__":

@@ -75,6 +75,7 @@ CASES = [
     (200, 25.0, 16, 4, 8, 32, "kqv", None),      # SPT-128: value dim 8
     (150, 8.0, 32, 4, 4, 32, "kqv", "d+g"),      # scannet: 32 heads
     (120, 6.0, 16, 2, 1, 18, "kqv", "d"),        # nano: qk_dim 2, dim 16, raw 18-D edge features
+    (130, 7.0, 16, 2, 1, 16, "kqv", None),       # nano-2: qk_dim 2, dim 16, edge MLP to 16
     (100, 5.0, 16, 4, 4, 32, "k", "g"),
     (100, 5.0, 16, 4, 4, 32, "v", 0.37),
     (100, 5.0, 8, 8, 8, 32, "", None),           # no RPE at all

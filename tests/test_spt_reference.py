@@ -1,7 +1,9 @@
 """Whole-backbone parity against the REFERENCE'S OWN ``SPT.forward``
 (src/models/components/spt.py:760-944, run in f64 by
 tests/golden/make_golden_spt.py) for the two shipped widths: SPT-64 (S3DIS /
-DALES) and SPT-128 (KITTI-360: value dim 8, FFN on).
+DALES) and SPT-128 (KITTI-360: value dim 8, FFN on), and for the nano family
+(nano-2 on the s3dis_nano features: no level-0 stage, the NAG starts at level 1; dims 16,
+qk_dim 2, value dim 1, 16-D edge encodings).
 
 CPU: the reference's state dict loads into the product container with
 ``strict=True`` (same module tree and parameter names) and the oracle
@@ -25,12 +27,13 @@ def _load(which):
     from superpoint_transformer_amd import hotpath
     from superpoint_transformer_amd.nn import SPT
     g = load_golden(f"spt_forward_{which}.npz")
-    cfg = hotpath.spt64_config() if which == "spt64" else hotpath.spt128_config()
+    cfg = {"spt64": hotpath.spt64_config, "spt128": hotpath.spt128_config,
+           "nano2": hotpath.nano2_config}[which]()
     net = SPT(**cfg)
     sd = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("p__")}
     net.load_state_dict(sd, strict=True)          # names and shapes = the reference's
     levels = []
-    for i in range(3):
+    for i in ((1, 2) if which == "nano2" else range(3)):     # nano: the NAG starts at level 1
         lv = {}
         for k in ("pos", "x", "edge_attr"):
             if f"l{i}__{k}" in g:
@@ -45,7 +48,7 @@ def _load(which):
     return net, levels, outs, gws, grads, int(g["num_clouds"])
 
 
-@pytest.mark.parametrize("which", ["spt64", "spt128"])
+@pytest.mark.parametrize("which", ["spt64", "spt128", "nano2"])
 def test_oracle_model_matches_reference_spt_forward(which):
     net, levels, outs, gws, grads, _ = _load(which)
     net = net.double()
@@ -61,7 +64,7 @@ def test_oracle_model_matches_reference_spt_forward(which):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("which", ["spt64", "spt128"])
+@pytest.mark.parametrize("which", ["spt64", "spt128", "nano2"])
 def test_hip_model_matches_reference_spt_forward(which, dev):
     net, levels, outs, gws, grads, clouds = _load(which)
 
@@ -77,8 +80,8 @@ def test_hip_model_matches_reference_spt_forward(which, dev):
         def __init__(self, lv):
             self.levels = lv
 
-        def __getitem__(self, i):
-            return self.levels[i]
+        def __getitem__(self, i):                  # absolute level index
+            return self.levels[i - (1 if which == "nano2" else 0)]
 
     dl = [{k: (v.to(dev).float() if torch.is_tensor(v) and v.is_floating_point()
                else v.to(dev) if torch.is_tensor(v) else v) for k, v in lv.items()}
