@@ -76,6 +76,12 @@ int spt_csr_build(const int64_t* idx, int64_t n, int64_t num_seg,
 int spt_segcsr_reduce_f32(int op, const float* x, const int32_t* perm,
                           const int32_t* rowptr, int64_t n, int64_t num_seg,
                           int c, float* out, int32_t* arg, spt_stream_t stream);
+/* Max + arg of 128-channel rows over >= 65 536 rows (the level-0 -> level-1 pool) runs a
+ * row-streaming kernel: a wave owns a contiguous range of CSR positions cut at segment boundaries
+ * and streams sixteen 512-byte rows at a time whatever segments they belong to (1, default;
+ * SPT_SEG_STREAM=0 in the environment or 0 here = the lane-group-per-segment kernel for every
+ * shape).  Bit-identical results.  Returns the previous setting. */
+int spt_segcsr_use_stream(int on);
 
 /* Backward of the above w.r.t. x (a2):
  *   SUM : gx[i,:] = gout[idx[i],:]

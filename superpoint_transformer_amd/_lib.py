@@ -49,6 +49,7 @@ SIGNATURES = {
                                          _p, _p, _int, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "spt_grid_knn_workspace_bytes": (_sz, [_i64, _i64]),
     "spt_knn_use_cell_path": (_int, [_int]),
+    "spt_segcsr_use_stream": (_int, [_int]),
     "spt_grid_knn_after_f32": (_int, [_p, _i64, _p, _i64, _int, _f32, _f32, _p, _p, _int, _int, _p, _p,
                                       _p, _p, _p, _sz, _p]),
     "spt_grid_knn_f32": (_int, [_p, _i64, _p, _i64, _int, _f32, _f32, _p, _p, _int, _int, _int,

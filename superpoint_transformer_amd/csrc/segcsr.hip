@@ -8,6 +8,7 @@
 // empty segment -> 0 (arg = n), mean divides by max(count,1), min/max gradient
 // goes to the arg element only, ties -> first occurrence (CPU kernel rule).
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.hpp"
 
@@ -337,6 +338,226 @@ __global__ __launch_bounds__(256) void segcsr_reduce_kernel(
   }
 }
 
+// ---- segment max of 128-channel rows, row-streaming formulation ------------------------------
+// The kernel above gives every segment a lane group: a segment of 35 rows (the mean of the
+// level-0 -> level-1 pool) is 16 + 16 + 3 rows in flight, the group waits for its own perm ->
+// row chain twice, and a wave is as slow as its longest segment.  Here a wave owns a contiguous
+// range of CSR POSITIONS (cut at segment boundaries, so no segment is shared between waves and
+// nothing is merged afterwards) and streams its rows sixteen at a time, whatever segments they
+// belong to: one 512-byte row per load instruction (64 lanes x 2 channels), the row ids of the
+// next chunk prefetched as one coalesced load, a segment's result written the moment its last
+// row has been combined.  Control flow is wave-uniform (a row belongs to one segment for all
+// lanes).  Same combine rule, same affine expression, bit-identical results.
+// segments [sa, sb) of one graph (one set of coefficient rows): their rows are the contiguous
+// CSR positions [rowptr[sa], rowptr[sb])
+template <bool AFF>
+__device__ __forceinline__ void segmax_stream_range(
+    const float* __restrict__ x, const int32_t* __restrict__ perm,
+    const int32_t* __restrict__ rowptr, int64_t n, int64_t num_seg, float* __restrict__ out,
+    int32_t* __restrict__ arg, int64_t sa, int64_t sb, const float (&t_am)[4],
+    const float (&t_sc)[4], const float (&t_bs)[4], float slope, int lane) {
+  // a row = 32 lanes x 4 channels; the two half-waves take the even / odd positions of the
+  // stream (2 rows per load instruction, 4 channels per combine: half the instructions per byte
+  // of a 64-lane x 2-channel row).  Both halves work on the same segment unless a boundary falls
+  // between an even position and the odd one after it (1 pair in ~35): that pair is taken one
+  // position at a time.
+  // (12 rows per chunk with the affine map: its 12 coefficient registers then still leave room
+  // for 5 waves per SIMD)
+  constexpr int C = 128, CHK = AFF ? 12 : 16, V = 4;
+  const int hf = lane >> 5;                               // 0: even positions, 1: odd positions
+  const int c0 = (lane & 31) * V;
+  const bool leaky01 = AFF && slope >= 0.f && slope <= 1.f;
+  float acc[V];
+  int32_t ar[V];
+#pragma unroll
+  for (int k = 0; k < V; ++k) {
+    acc[k] = op_identity<SPT_MAX>();
+    ar[k] = 0x7fffffff;
+  }
+  // result of segment s: the odd half's partial joins the even half's, which writes the row
+  auto emit = [&](int64_t s, bool empty) {
+    Vec<V> o;
+    int32_t oa[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      const float ov = __shfl_xor(acc[k], 32, 64);
+      const int32_t orr = __shfl_xor(ar[k], 32, 64);
+      combine<SPT_MAX, true, float>(acc[k], ar[k], ov, orr);
+      o.v[k] = empty ? 0.f : acc[k];
+      oa[k] = (!empty && ar[k] != 0x7fffffff) ? ar[k] : (int32_t)n;
+      acc[k] = op_identity<SPT_MAX>();
+      ar[k] = 0x7fffffff;
+    }
+    if (hf == 0) {
+      stv<V>(out + s * C + c0, o);
+      sti<V>(arg + s * C + c0, oa);
+    }
+  };
+  int64_t s = sa;
+  int64_t j = __builtin_amdgcn_readfirstlane(rowptr[sa]);
+  const int64_t jend = __builtin_amdgcn_readfirstlane(rowptr[sb]);
+  int64_t cur_end = __builtin_amdgcn_readfirstlane(rowptr[s + 1]);
+  // the end of the segment AFTER the current one is requested a segment ahead and only made
+  // uniform when it becomes current: a segment boundary then costs no memory round trip
+  int32_t nxt_v = (s + 2 <= num_seg) ? rowptr[s + 2] : 0;
+  auto advance = [&]() {                                  // s -> s + 1
+    ++s;
+    cur_end = __builtin_amdgcn_readfirstlane(nxt_v);
+    nxt_v = (s + 2 <= num_seg) ? rowptr[s + 2] : 0;
+  };
+  // position p was the last one combined: close every segment that ends there
+  auto close_at = [&](int64_t p) {
+    if (p + 1 == cur_end) {
+      emit(s, false);
+      advance();
+      while (s < sb && cur_end == p + 1) {                // empty segments behind it
+        emit(s, true);
+        advance();
+      }
+    }
+  };
+  while (s < sb && cur_end == j) {                       // leading empty segments
+    emit(s, true);
+    advance();
+  }
+  if (s >= sb) return;
+  auto ids_of = [&](int64_t jj) {                        // lane u < 16: row id of position jj + u
+    const int64_t p = jj + (lane & 15);
+    return (p < jend) ? (perm ? perm[p] : (int32_t)p) : 0;
+  };
+  auto take = [&](const Vec<V>& v, int32_t r) {           // one row into the lane's partial
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      float a = v.v[k];
+      if constexpr (AFF) {
+        a = fmaf(a - t_am[k], t_sc[k], t_bs[k]);           // same expression as gn_apply
+        a = leaky01 ? fmaxf(a, a * slope) : (a > 0.f ? a : a * slope);
+      }
+      combine<SPT_MAX, true, float>(acc[k], ar[k], a, r);
+    }
+  };
+  int32_t idn = ids_of(j);
+  for (; j < jend; j += CHK) {
+    const int32_t idc = idn;
+    idn = ids_of(j + CHK);
+    Vec<V> v[CHK / 2];
+    auto row_of = [&](int q) {                            // the lane's row of pair q
+      const int32_t r0 = __builtin_amdgcn_readlane(idc, 2 * q);
+      const int32_t r1 = __builtin_amdgcn_readlane(idc, 2 * q + 1);
+      return hf ? r1 : r0;
+    };
+    // unconditional loads (positions past the end read row ids_of() = 0 and are never combined):
+    // a load under a per-lane condition is followed by a wait and a select, which serialises the
+    // eight loads of the chunk
+#pragma unroll
+    for (int q = 0; q < CHK / 2; ++q) v[q] = ldv<V>(x + (int64_t)row_of(q) * C + c0);
+#pragma unroll
+    for (int q = 0; q < CHK / 2; ++q) {
+      const int64_t p0 = j + 2 * q;
+      if (p0 < jend) {
+        const int32_t rq = row_of(q);
+        if (p0 + 1 < cur_end && p0 + 1 < jend) {             // both rows in the current segment
+          take(v[q], rq);
+          close_at(p0 + 1);
+        } else {                                             // a boundary between them (or the end)
+          if (hf == 0) take(v[q], rq);
+          close_at(p0);
+          if (p0 + 1 < jend) {
+            if (hf == 1) take(v[q], rq);
+            close_at(p0 + 1);
+          }
+        }
+      }
+    }
+  }
+}
+
+template <bool AFF>
+__global__ __launch_bounds__(256, 5) void segmax_stream_kernel(
+    const float* __restrict__ x, const int32_t* __restrict__ perm,
+    const int32_t* __restrict__ rowptr, int64_t n, int64_t num_seg, float* __restrict__ out,
+    int32_t* __restrict__ arg, Affine af, int64_t rows_per_wave) {
+  constexpr int C = 128;
+  const int lane = threadIdx.x & 63;
+  const int c0 = (lane & 31) * 4;
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  // first segment whose start is >= p (num_seg when there is none)
+  auto lower = [&](int64_t p) {
+    int64_t lo = 0, hi = num_seg;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if ((int64_t)__builtin_amdgcn_readfirstlane(rowptr[mid]) >= p) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+  };
+  const int64_t sa = lower(wave * rows_per_wave);
+  const int64_t sb = (wave == nwaves - 1) ? num_seg : lower((wave + 1) * rows_per_wave);
+  float t_am[4] = {0.f, 0.f, 0.f, 0.f}, t_sc[4] = {0.f, 0.f, 0.f, 0.f}, t_bs[4] = {0.f, 0.f, 0.f, 0.f};
+  // the coefficient rows depend on the segment's graph: the wave's segments are taken graph by
+  // graph (graphs are contiguous runs of segments; a range spans more than one at B - 1 places)
+  int64_t s_lo = sa;
+  while (s_lo < sb) {
+    int64_t s_hi = sb;
+    if constexpr (AFF) {
+      int64_t g = 0;
+      if (af.seg_graph) {
+        g = __builtin_amdgcn_readfirstlane((int)af.seg_graph[s_lo]);
+        if ((int64_t)__builtin_amdgcn_readfirstlane((int)af.seg_graph[sb - 1]) != g) {
+          int64_t lo = s_lo + 1, hi = sb;                   // first segment of another graph
+          while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if ((int64_t)__builtin_amdgcn_readfirstlane((int)af.seg_graph[mid]) != g) hi = mid;
+            else lo = mid + 1;
+          }
+          s_hi = lo;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        t_am[k] = af.am[g * C + c0 + k];
+        t_sc[k] = af.sc[g * C + c0 + k];
+        t_bs[k] = af.bs[c0 + k];
+      }
+    }
+    segmax_stream_range<AFF>(x, perm, rowptr, n, num_seg, out, arg, s_lo, s_hi, t_am, t_sc, t_bs,
+                             af.slope, lane);
+    s_lo = s_hi;
+  }
+}
+
+static int g_seg_stream = -1;   // -1: from the environment (SPT_SEG_STREAM=0 turns it off)
+static bool seg_stream_on() {
+  if (g_seg_stream < 0) {
+    const char* e = getenv("SPT_SEG_STREAM");
+    g_seg_stream = (e && e[0] == '0') ? 0 : 1;
+  }
+  return g_seg_stream != 0;
+}
+// max + arg of 128-channel rows over many rows: the row-streaming kernel
+static bool seg_stream_shape(int c, int64_t n, bool want_arg) {
+  return seg_stream_on() && c == 128 && want_arg && n >= (1 << 16);
+}
+template <bool AFF>
+static void launch_stream(const float* x, const int32_t* perm, const int32_t* rowptr, int64_t n,
+                          int64_t num_seg, float* out, int32_t* arg, const Affine& af,
+                          hipStream_t stream) {
+  // 8 waves per SIMD over the whole chip, at least 256 rows per wave
+  // one resident round: 5 waves per SIMD (96 registers) over the whole chip - with more waves
+  // than fit at once the last partial round costs more than finer ranges balance (measured:
+  // 5 120 waves 1.51 ms, 8 192: 1.59, 32 768: 1.60 at 15 M rows)
+  static const int64_t kWaves = [] {
+    const char* e = getenv("SPT_SEG_STREAM_WAVES");
+    return e ? (int64_t)atoll(e) : (int64_t)0;
+  }();
+  int64_t waves = kWaves > 0 ? kWaves : (int64_t)256 * 4 * 5;
+  if (waves * 256 > n) waves = n / 256 > 4 ? n / 256 : 4;
+  const int grid = (int)ceil_div(waves, (int64_t)4);
+  const int64_t rows_per_wave = n / ((int64_t)grid * 4) + 1;
+  segmax_stream_kernel<AFF><<<grid, 256, 0, stream>>>(x, perm, rowptr, n, num_seg, out, arg, af,
+                                                      rows_per_wave);
+}
+
 // Row-parallel "gather with modifier":
 //   MODE 0: out[i,:] = src[idx[i],:]                      (gather / sum bwd)
 //   MODE 1: out[i,:] = src[idx[i],:] / max(count[idx[i]],1)   (mean bwd)
@@ -583,6 +804,12 @@ static void launch_gather(int vec, const float* src, const int32_t* arg,
 
 using namespace spt;
 
+extern "C" int spt_segcsr_use_stream(int on) {
+  const int prev = seg_stream_on() ? 1 : 0;
+  g_seg_stream = on != 0;
+  return prev;
+}
+
 extern "C" int spt_segcsr_reduce_f32(int op, const float* x, const int32_t* perm,
                                      const int32_t* rowptr, int64_t n,
                                      int64_t num_seg, int c, float* out,
@@ -606,7 +833,10 @@ extern "C" int spt_segcsr_reduce_f32(int op, const float* x, const int32_t* perm
       launch_reduce_vec<SPT_MIN>(rs.vec, want_arg, x, perm, rowptr, n, num_seg, c, rs.lpr_log2, rpg_log2, out, arg, stream);
       break;
     default:
-      launch_reduce_vec<SPT_MAX>(rs.vec, want_arg, x, perm, rowptr, n, num_seg, c, rs.lpr_log2, rpg_log2, out, arg, stream);
+      if (seg_stream_shape(c, n, want_arg))
+        launch_stream<false>(x, perm, rowptr, n, num_seg, out, arg, Affine{}, stream);
+      else
+        launch_reduce_vec<SPT_MAX>(rs.vec, want_arg, x, perm, rowptr, n, num_seg, c, rs.lpr_log2, rpg_log2, out, arg, stream);
       break;
   }
   SPT_CHECK_LAUNCH();
@@ -632,8 +862,11 @@ extern "C" int spt_segcsr_max_affine_f32(const float* x, const int32_t* perm,
   const int grid = (int)(want < cap ? (want > 0 ? want : 1) : cap);
   Affine af;
   af.am = am; af.sc = scale; af.bs = bias; af.seg_graph = seg_graph; af.slope = act_slope;
-  segcsr_reduce_kernel<SPT_MAX, 4, true, true><<<grid, 256, 0, stream>>>(
-      x, perm, rowptr, n, num_seg, c, rs.lpr_log2, rpg_log2, out, arg, af);
+  if (seg_stream_shape(c, n, true))
+    launch_stream<true>(x, perm, rowptr, n, num_seg, out, arg, af, stream);
+  else
+    segcsr_reduce_kernel<SPT_MAX, 4, true, true><<<grid, 256, 0, stream>>>(
+        x, perm, rowptr, n, num_seg, c, rs.lpr_log2, rpg_log2, out, arg, af);
   SPT_CHECK_LAUNCH();
   return 0;
 }

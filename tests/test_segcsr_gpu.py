@@ -174,3 +174,85 @@ def test_large_scale_properties(dev):
     assert torch.equal(x.gather(0, rows), mx[nonempty])               # arg is a witness
     assert torch.equal(idx[rows[:, 0]], torch.nonzero(nonempty)[:, 0])
     assert bool((mx[idx] >= x).all())                                  # upper bound
+
+
+def _segments(kind, n, gen):
+    if kind == "lognormal":                       # the level-0 -> level-1 shape: mean 35, wide
+        nseg = n // 35
+        w = torch.exp(torch.randn(nseg, generator=gen))
+        idx = torch.multinomial(w / w.sum(), n, replacement=True, generator=gen)
+        return idx, nseg + 9                      # + trailing empty segments
+    if kind == "empties":                         # far more segments than rows can fill
+        nseg = n // 2
+        return torch.randint(0, nseg, (n,), generator=gen) // 3 * 3, nseg
+    if kind == "giant":                           # one segment with a third of the rows
+        nseg = 3000
+        idx = torch.randint(1, nseg, (n,), generator=gen)
+        idx[torch.rand(n, generator=gen) < 0.34] = 1500
+        return idx, nseg
+    nseg = n // 200                               # "sorted": rows already in CSR order
+    return torch.sort(torch.randint(0, nseg, (n,), generator=gen)).values, nseg
+
+
+@pytest.mark.parametrize("kind", ["lognormal", "empties", "giant", "sorted"])
+@pytest.mark.parametrize("n", [65_536, 300_017])
+def test_row_streaming_max_equals_lane_group_kernel_and_oracle(kind, n, dev):
+    """128-channel max + arg over >= 65 536 rows runs the row-streaming kernel (a wave owns a range
+    of CSR positions cut at segment boundaries): values AND arg rows bit-identical to the
+    lane-group-per-segment kernel and to the oracle, with forced ties (few distinct values),
+    empty segments in front of / between / behind the others, a segment far longer than a wave's
+    range, and rows that are already sorted."""
+    from superpoint_transformer_amd import _lib
+    ops, csr = _ops()
+    gen = torch.Generator().manual_seed(n + len(kind))
+    idx, nseg = _segments(kind, n, gen)
+    x = torch.randint(-4, 5, (n, 128), generator=gen).float()
+    x += (torch.rand(n, 128, generator=gen) < 0.3).float() * torch.randn(n, 128, generator=gen)
+    res = []
+    for on in (1, 0):
+        prev = _lib.lib.spt_segcsr_use_stream(on)
+        try:
+            csr.forget(idx)
+            res.append(ops.segment_reduce(x.to(dev), idx.to(dev), nseg, "max", return_arg=True))
+        finally:
+            _lib.lib.spt_segcsr_use_stream(prev)
+    assert torch.equal(res[0][0], res[1][0])
+    assert torch.equal(res[0][1], res[1][1])
+    ref, rarg = O.scatter_max(x.double(), idx, dim_size=nseg)
+    assert torch.equal(res[0][0].cpu().double(), ref)
+    assert torch.equal(res[0][1].cpu().long(), rarg)
+
+
+@pytest.mark.parametrize("rows,B", [(150_000, 1), (200_003, 3)])
+def test_row_streaming_max_with_the_fused_norm_equals_lane_group_kernel(rows, B, dev):
+    """The pool that evaluates the point MLP's last GraphNorm + LeakyReLU on the fly
+    (spt_segcsr_max_affine_f32), row-streaming vs lane-group kernel: pooled values, arg rows and
+    therefore every gradient bit-identical; several graphs (the coefficient rows change with the
+    segment's graph)."""
+    from superpoint_transformer_amd import _lib, nn as N
+    g = torch.Generator().manual_seed(rows)
+    mlp = N.MLP([12, 32, 64, 128], norm=N.GraphNorm).to(dev)
+    mlp.FUSE_MIN_ROWS = 0
+    x = (torch.randn(rows, 12, generator=g) * 2 + 0.5).to(dev)
+    batch = (torch.arange(rows) * B // rows).to(dev) if B > 1 else None
+    nseg = rows // 35 // B
+    seg = torch.randint(0, nseg, (rows,), generator=g).to(dev)
+    if B > 1:
+        seg = batch * nseg + seg
+    seg_graph = None if B == 1 else (torch.arange(nseg * B, device=dev) // nseg)
+    gw = torch.randn(nseg * B, 128, generator=g).to(dev)
+    res = []
+    for on in (1, 0):
+        prev = _lib.lib.spt_segcsr_use_stream(on)
+        try:
+            xd = x.clone().requires_grad_()
+            mlp.zero_grad()
+            y = mlp.forward_max_pooled(xd, seg, nseg * B, batch=batch, batch_size=B,
+                                       seg_graph=seg_graph)
+            (y * gw).sum().backward()
+            res.append([y.detach().clone(), xd.grad.clone()] +
+                       [p.grad.clone() for p in mlp.parameters()])
+        finally:
+            _lib.lib.spt_segcsr_use_stream(prev)
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
