@@ -482,6 +482,15 @@ int spt_edge_affinity_features_bwd_f32(const float* x, const float* gout, int64_
 int spt_skinny_linear_supported(int K, int N);
 int spt_skinny_linear_f32(const float* x, int64_t rows, int K, const float* W, const float* bias,
                           int N, float* y, spt_stream_t stream);
+/* Weight gradient of the same Linear: gw[N,K] = gy[rows,N]^T x[rows,K] (src/nn/attention.py's qkv /
+ * out_proj under autograd), a reduction over 10^5..10^7 rows.  K in {32, 64}, N a multiple of 64;
+ * f32 in / f32 accumulate on the matrix pipe, per-wave partials summed in a fixed order
+ * (deterministic).  gb[N] (nullable) receives the column sums of gy - the bias gradient - from the
+ * same pass.  ws: spt_skinny_dw_workspace_bytes(K, N) bytes of device scratch. */
+int spt_skinny_dw_supported(int K, int N);
+size_t spt_skinny_dw_workspace_bytes(int K, int N);
+int spt_skinny_dw_f32(const float* gy, const float* x, int64_t rows, int N, int K, float* gw,
+                      float* gb, void* ws, size_t ws_bytes, spt_stream_t stream);
 
 /* Pieces of the GraphNorm two-pass scheme for callers that produce / consume the
  * per-graph totals themselves (the fused MLP layers below).  totals layout:

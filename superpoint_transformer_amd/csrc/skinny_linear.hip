@@ -10,7 +10,9 @@
 // launch, the A tile is staged through LDS with the next tile's global loads in flight
 // during the MFMAs (v_mfma_f32_16x16x4_f32: f32 in, f32 accumulate).
 //
-// dX = G W is the same kernel on (G, W^T); dW stays a batched library GEMM (ops.py).
+// dX = G W is the same kernel on (G, W^T).  dW = G^T X (a reduction over 10^5..10^7 rows into a
+// <= 192 x 64 block) has its own kernel below: the library ran it as a batched GEMM over row
+// chunks at ~0.36 ms per 10-GFLOP product (profiles/r02z: the Cijk_..._MT16x32x512 rows).
 #include "common.hpp"
 
 namespace spt {
@@ -101,11 +103,167 @@ __global__ __launch_bounds__(WAVES * 64, (K4 <= 32) ? 2 : 1) void skinny_linear_
   }
 }
 
+// dW[n, k] = sum_rows G[row, n] X[row, k].  blockIdx.y = 64-column slab of G; a wave strides the
+// 16-row tiles, keeps its [64 x K] partial in MFMA accumulators (v_mfma_f32_16x16x4_f32: the
+// contraction index is the tile's rows, four at a time; f32 in, f32 accumulate) and writes it
+// once; a second kernel sums the per-wave partials in a fixed order (deterministic).
+template <int K4>
+__global__ __launch_bounds__(WAVES * 64, 2) void skinny_dw_kernel(
+    const float* __restrict__ gy, const float* __restrict__ x, int64_t rows, int N,
+    float* __restrict__ partial) {
+  constexpr int K = 4 * K4, KB = K / 16, LDG = SLAB + 4, LDX = K + 4;
+  constexpr int VG = TR * SLAB / 4 / 64, VX = TR * K / 4 / 64;   // float4 per lane per tile
+  static_assert(K % 16 == 0 && TR * K % 256 == 0, "K is a multiple of 16");
+  __shared__ __attribute__((aligned(16))) float g_lds[WAVES][TR * LDG];
+  __shared__ __attribute__((aligned(16))) float x_lds[WAVES][TR * LDX];
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, c = lane & 15;
+  const int n0 = blockIdx.y * SLAB;
+  float* gl = g_lds[wid];
+  float* xl = x_lds[wid];
+  f32x4 C[4][KB];                                       // C[nb][kb][r] = dW[n0 + 16 nb + 4 g + r][16 kb + c]
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};                 // column sums of G (the bias gradient)
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) C[nb][kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int64_t ntiles = (rows + TR - 1) / TR;
+  const int64_t wave = (int64_t)blockIdx.x * WAVES + wid;
+  const int64_t nwaves = (int64_t)gridDim.x * WAVES;
+  float4 ng[VG], nx[VX];
+  auto fetch = [&](int64_t t) {                         // rows past the end read as zero
+#pragma unroll
+    for (int v = 0; v < VG; ++v) {
+      const int q = v * 64 + lane, rr = q / (SLAB / 4), ch = q - rr * (SLAB / 4);
+      const int64_t row = t * TR + rr;
+      ng[v] = (row < rows) ? *reinterpret_cast<const float4*>(gy + row * N + n0 + ch * 4)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int v = 0; v < VX; ++v) {
+      const int q = v * 64 + lane, rr = q / K4, ch = q - rr * K4;
+      const int64_t row = t * TR + rr;
+      nx[v] = (row < rows) ? *reinterpret_cast<const float4*>(x + row * K + ch * 4)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  if (wave < ntiles) fetch(wave);
+  for (int64_t t = wave; t < ntiles; t += nwaves) {
+    wave_sync_lds();
+#pragma unroll
+    for (int v = 0; v < VG; ++v) {
+      const int q = v * 64 + lane, rr = q / (SLAB / 4), ch = q - rr * (SLAB / 4);
+      *reinterpret_cast<float4*>(gl + rr * LDG + ch * 4) = ng[v];
+    }
+#pragma unroll
+    for (int v = 0; v < VX; ++v) {
+      const int q = v * 64 + lane, rr = q / K4, ch = q - rr * K4;
+      *reinterpret_cast<float4*>(xl + rr * LDX + ch * 4) = nx[v];
+    }
+    wave_sync_lds();
+    if (t + nwaves < ntiles) fetch(t + nwaves);         // in flight during the MFMAs
+#pragma unroll
+    for (int st = 0; st < TR / 4; ++st) {               // rows 4 st + g of the tile
+      float A[4], B[KB];
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) A[nb] = gl[(4 * st + g) * LDG + 16 * nb + c];
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) B[kb] = xl[(4 * st + g) * LDX + 16 * kb + c];
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) {
+        bsum[nb] += A[nb];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+          C[nb][kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[nb], B[kb], C[nb][kb], 0, 0, 0);
+      }
+    }
+  }
+  // partial[wave][slab][64 x K | 64]
+  float* pw = partial + ((size_t)wave * gridDim.y + blockIdx.y) * (SLAB * K + SLAB);
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb) {
+    float v = bsum[nb];
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    if (g == 0) pw[SLAB * K + 16 * nb + c] = v;
+  }
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pw[(size_t)(16 * nb + 4 * g + r) * K + 16 * kb + c] = C[nb][kb][r];
+}
+
+// gw[slab * 64 + i][k] (and gb[slab * 64 + i]) = sum over waves, ascending, of the partials
+__global__ __launch_bounds__(256) void skinny_dw_reduce_kernel(const float* __restrict__ partial,
+                                                               int nwaves, int slabs, int K,
+                                                               float* __restrict__ gw,
+                                                               float* __restrict__ gb) {
+  const int per = SLAB * K + SLAB;
+  const int i = blockIdx.x * 256 + threadIdx.x;         // element of a slab's [64 x K | 64] record
+  if (i >= slabs * per) return;
+  const int slab = i / per, e = i - slab * per;
+  float acc = 0.f;
+  int w = 0;
+  for (; w + 4 <= nwaves; w += 4) {
+    const float a0 = partial[((size_t)w * slabs + slab) * per + e];
+    const float a1 = partial[((size_t)(w + 1) * slabs + slab) * per + e];
+    const float a2 = partial[((size_t)(w + 2) * slabs + slab) * per + e];
+    const float a3 = partial[((size_t)(w + 3) * slabs + slab) * per + e];
+    acc += a0; acc += a1; acc += a2; acc += a3;
+  }
+  for (; w < nwaves; ++w) acc += partial[((size_t)w * slabs + slab) * per + e];
+  if (e < SLAB * K) gw[(size_t)slab * SLAB * K + e] = acc;
+  else if (gb) gb[slab * SLAB + e - SLAB * K] = acc;
+}
+
 }  // namespace skinny
 }  // namespace spt
 
 using namespace spt;
 using namespace spt::skinny;
+
+constexpr int DW_BLOCKS = 256;                          // x 4 waves: partial tables per slab
+
+extern "C" int spt_skinny_dw_supported(int K, int N) {
+  return (K == 32 || K == 64) && N >= SLAB && N % SLAB == 0 && N <= 1024;
+}
+extern "C" size_t spt_skinny_dw_workspace_bytes(int K, int N) {
+  return (size_t)DW_BLOCKS * WAVES * N * (K + 1) * sizeof(float);
+}
+// gw[N, K] = gy[rows, N]^T x[rows, K]  (the weight gradient of y = x W^T + b); gb[N] = column
+// sums of gy (the bias gradient), or null
+extern "C" int spt_skinny_dw_f32(const float* gy, const float* x, int64_t rows, int N, int K,
+                                 float* gw, float* gb, void* ws, size_t ws_bytes,
+                                 spt_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPT_CHECK_ARG(rows >= 0, "bad shape");
+  SPT_CHECK_ARG(spt_skinny_dw_supported(K, N), "(K, N) not built");
+  SPT_CHECK_ARG(gw && (rows == 0 || (gy && x)), "null pointer");
+  SPT_CHECK_ARG(ws && ws_bytes >= spt_skinny_dw_workspace_bytes(K, N), "workspace too small");
+  const int slabs = N / SLAB;
+  if (rows == 0) {
+    hipMemsetAsync(gw, 0, (size_t)N * K * sizeof(float), stream);
+    if (gb) hipMemsetAsync(gb, 0, (size_t)N * sizeof(float), stream);
+    return 0;
+  }
+  const int64_t tiles = ceil_div(rows, TR);
+  int64_t bx = ceil_div(tiles, WAVES);
+  const int64_t cap = DW_BLOCKS / slabs > 1 ? DW_BLOCKS / slabs : 1;
+  if (bx > cap) bx = cap;
+  const dim3 grid((unsigned)bx, (unsigned)slabs);
+  float* partial = (float*)ws;
+  if (K == 32)
+    skinny_dw_kernel<8><<<grid, WAVES * 64, 0, stream>>>(gy, x, rows, N, partial);
+  else
+    skinny_dw_kernel<16><<<grid, WAVES * 64, 0, stream>>>(gy, x, rows, N, partial);
+  skinny_dw_reduce_kernel<<<(N * (K + 1) + 255) / 256, 256, 0, stream>>>(partial, (int)bx * WAVES, slabs,
+                                                                         K, gw, gb);
+  SPT_CHECK_LAUNCH();
+  return 0;
+}
 
 extern "C" int spt_skinny_linear_supported(int K, int N) {
   return (K == 32 || K == 64 || K == 128 || K == 192) && N >= SLAB && N % SLAB == 0 && N <= 1024;

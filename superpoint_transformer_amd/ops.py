@@ -552,11 +552,35 @@ def _dw_batched(g, x):
     return gw
 
 
+def _skinny_dw_ok(g, x):
+    return (x.is_cuda and x.dtype == torch.float32 and g.dtype == torch.float32
+            and x.shape[0] >= _SKINNY_MIN_ROWS
+            and _lib.lib.spt_skinny_dw_supported(x.shape[1], g.shape[1]))
+
+
+def _skinny_dw(g, x, want_bias=False):
+    """dW = G^T X (and, from the same pass, db = column sums of G) on the MFMA kernel of
+    csrc/skinny_linear.hip (per-wave partials, fixed-order sum)."""
+    g, x = g.contiguous(), x.detach().contiguous()
+    rows, k = x.shape
+    n = g.shape[1]
+    gw = torch.empty((n, k), dtype=torch.float32, device=x.device)
+    gb = torch.empty(n, dtype=torch.float32, device=x.device) if want_bias else None
+    nb = _lib.lib.spt_skinny_dw_workspace_bytes(k, n)
+    ws = _workspace(nb, x.device)
+    with torch.cuda.device(x.device):
+        st = _lib.lib.spt_skinny_dw_f32(_lib.ptr(g), _lib.ptr(x), rows, n, k, _lib.ptr(gw),
+                                        _lib.ptr(gb), _lib.ptr(ws), ws.numel(),
+                                        _lib.stream_ptr(x.device))
+    _lib.check(st, "spt_skinny_dw_f32")
+    return (gw, gb) if want_bias else gw
+
+
 class _TallLinear(torch.autograd.Function):
     """y = x W^T (+ b) for [rows >> features] operands.  Forward and dX run on the
     hand-written skinny-GEMM kernel when the shape is built (K in {32,64,128,192},
-    N % 64 == 0 - the attention block's qkv / out_proj), else on the library; dW is a
-    batched library GEMM over row chunks."""
+    N % 64 == 0 - the attention block's qkv / out_proj), else on the library; dW on the
+    skinny dW kernel (K in {32, 64}) or a batched library GEMM over row chunks."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -575,9 +599,15 @@ class _TallLinear(torch.autograd.Function):
             wt = weight.detach().t().contiguous()           # [K, N]: dX = G (W^T)^T
             gx = _skinny_launch(g, wt, None) if _skinny_ok(g, wt) else g @ weight
         gw = gb = None
+        want_gb = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            gw = _dw_batched(g, x) if x.shape[0] >= 4 * _DW_CHUNK else g.t() @ x
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+            if _skinny_dw_ok(g, x):
+                gw = _skinny_dw(g, x, want_gb)
+                if want_gb:
+                    gw, gb = gw
+            else:
+                gw = _dw_batched(g, x) if x.shape[0] >= 4 * _DW_CHUNK else g.t() @ x
+        if want_gb and gb is None:
             gb = g.sum(0)
         return gx, gw, gb
 

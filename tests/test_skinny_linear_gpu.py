@@ -48,3 +48,24 @@ def test_unsupported_shapes_and_small_inputs_use_the_library(dev):
     assert torch.equal(ops.linear(x, w), torch.nn.functional.linear(x, w))
     with pytest.raises(RuntimeError):
         ops._skinny_launch(torch.randn(5000, 48, device=dev), torch.randn(64, 48, device=dev), None)
+
+
+@pytest.mark.parametrize("rows", [1, 15, 16, 17, 4099, 70001, 428_571])
+@pytest.mark.parametrize("K,N", [(64, 192), (64, 64), (32, 64), (32, 128)])
+def test_weight_gradient_kernel_matches_float64(rows, K, N, dev):
+    """dW = G^T X on the skinny dW kernel (f32 MFMA, per-wave partials, fixed-order sum) against
+    float64: the error is that of an f32 sum over `rows` terms - bar 1e-6 * sqrt(rows) of the
+    largest |g||x| product scale - incl. last tiles that are not full and fewer tiles than waves;
+    deterministic (two runs agree bit for bit)."""
+    from superpoint_transformer_amd import ops
+    g = torch.Generator().manual_seed(rows + K + N)
+    x = torch.randn(rows, K, generator=g)
+    go = torch.randn(rows, N, generator=g)
+    gw, gb = ops._skinny_dw(go.to(dev), x.to(dev), want_bias=True)
+    gw2 = ops._skinny_dw(go.to(dev), x.to(dev))
+    assert torch.equal(gw, gw2)
+    rb = go.double().sum(0)
+    assert (gb.cpu().double() - rb).abs().max() < 2e-6 * max(rows, 16) ** 0.5 * float(go.abs().max()) + 1e-6 * float(rb.abs().max())
+    ref = go.double().t() @ x.double()
+    tol = 2e-6 * max(rows, 16) ** 0.5 * float(go.abs().max()) * float(x.abs().max()) + 1e-6 * float(ref.abs().max())
+    assert (gw.cpu().double() - ref).abs().max() < tol

@@ -1,6 +1,4 @@
 cd $GRAFT_REPO_ROOT
-for on in 1 0 1 0 1 0; do
-  SPT_SEG_STREAM=$on timeout 300 python bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-preprocess 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.readline()); r=d['roofline']; print('stream=$on ms/step', d['ms_per_step'], 'segmax ms', r['ms_per_launch'], 'frac', r['frac'])"
-done
+timeout 900 python -m pytest tests/test_skinny_linear_gpu.py tests/test_model_gpu.py tests/test_spt_reference.py -m gpu -x -q 2>&1 | tail -5
+timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-preprocess 2>/dev/null | cut -c100-200
+timeout 200 python bench.py --scene T --steps 30 --warmup 5 --no-cpu-baseline --no-preprocess 2>/dev/null | cut -c100-200
