@@ -29,6 +29,8 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=10)
     p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--settle", type=float, default=3.0,
+                   help="seconds of untimed steps before the warm-up steps (GPU clock ramp)")
     p.add_argument("--scene", default="S")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-preprocess", action="store_true")
@@ -213,6 +215,13 @@ def main():
     nag = make_nag(args.scene, seed=1234 + rank, device=dev)
     path = hotpath.build(nag, dev, world=world, stages=args.stages, mode=args.mode, model=args.model)
 
+    # A process that is the first to touch a box's GPU runs its first seconds ~10 % slow (clock
+    # ramp; measured: the same binary 74.6 ms/step in the first process of a fresh box, 67.3 in
+    # the fifth): untimed steps until `--settle` seconds have passed, then the W warm-up steps.
+    t_settle = time.perf_counter()
+    while time.perf_counter() - t_settle < args.settle:
+        path.step()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         path.step()
     path.reset_kernel_timers()

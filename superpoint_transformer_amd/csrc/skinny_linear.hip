@@ -29,8 +29,10 @@ __device__ __forceinline__ void wave_sync_lds() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// K = 4 K4.  blockIdx.y = column slab; waves of blockIdx.x stride the row tiles.
-template <int K4>
+// K = 4 K4.  blockIdx.y = column slab of NBS 16-column blocks (4: N a multiple of 64; 1: the
+// narrow heads, N <= 16 - the classifiers' 13 classes - with the missing columns read as zero
+// and not stored); waves of blockIdx.x stride the row tiles.
+template <int K4, int NBS = 4>
 __global__ __launch_bounds__(WAVES * 64, (K4 <= 32) ? 2 : 1) void skinny_linear_kernel(
     const float* __restrict__ x, int64_t rows, const float* __restrict__ W,
     const float* __restrict__ bias, int N, float* __restrict__ y) {
@@ -39,17 +41,18 @@ __global__ __launch_bounds__(WAVES * 64, (K4 <= 32) ? 2 : 1) void skinny_linear_
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, c = lane & 15;
-  const int n0 = blockIdx.y * SLAB;
+  const int n0 = blockIdx.y * (16 * NBS);
   float* al = a_lds[wid];
 
-  float B[4][K4];                                       // lane (g, c): W[n0 + 16 nb + c][4 st + g]
-  float bb[4];
+  float B[NBS][K4];                                     // lane (g, c): W[n0 + 16 nb + c][4 st + g]
+  float bb[NBS];
 #pragma unroll
-  for (int nb = 0; nb < 4; ++nb) {
-    const float* wr = W + (size_t)(n0 + 16 * nb + c) * K;
+  for (int nb = 0; nb < NBS; ++nb) {
+    const bool nv = n0 + 16 * nb + c < N;
+    const float* wr = W + (size_t)(nv ? n0 + 16 * nb + c : 0) * K;
 #pragma unroll
-    for (int st = 0; st < K4; ++st) B[nb][st] = wr[4 * st + g];
-    bb[nb] = bias ? bias[n0 + 16 * nb + c] : 0.f;
+    for (int st = 0; st < K4; ++st) B[nb][st] = nv ? wr[4 * st + g] : 0.f;
+    bb[nb] = (bias && nv) ? bias[n0 + 16 * nb + c] : 0.f;
   }
 
   const int64_t ntiles = (rows + TR - 1) / TR;
@@ -82,13 +85,13 @@ __global__ __launch_bounds__(WAVES * 64, (K4 <= 32) ? 2 : 1) void skinny_linear_
     float A[K4];
 #pragma unroll
     for (int st = 0; st < K4; ++st) A[st] = al[c * LDA + 4 * st + g];
-    f32x4 C[4];
+    f32x4 C[NBS];
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) C[nb] = (f32x4){bb[nb], bb[nb], bb[nb], bb[nb]};
+    for (int nb = 0; nb < NBS; ++nb) C[nb] = (f32x4){bb[nb], bb[nb], bb[nb], bb[nb]};
 #pragma unroll
     for (int st = 0; st < K4; ++st)
 #pragma unroll
-      for (int nb = 0; nb < 4; ++nb)
+      for (int nb = 0; nb < NBS; ++nb)
         C[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[st], B[nb][st], C[nb], 0, 0, 0);
     const int64_t row0 = t * TR;
 #pragma unroll
@@ -97,7 +100,8 @@ __global__ __launch_bounds__(WAVES * 64, (K4 <= 32) ? 2 : 1) void skinny_linear_
       if (row < rows) {
         float* yr = y + row * N + n0 + c;
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb) __builtin_nontemporal_store(C[nb][r], yr + 16 * nb);
+        for (int nb = 0; nb < NBS; ++nb)
+          if (NBS == 4 || n0 + 16 * nb + c < N) __builtin_nontemporal_store(C[nb][r], yr + 16 * nb);
       }
     }
   }
@@ -179,44 +183,134 @@ __global__ __launch_bounds__(WAVES * 64, 2) void skinny_dw_kernel(
       }
     }
   }
-  // partial[wave][slab][64 x K | 64]
-  float* pw = partial + ((size_t)wave * gridDim.y + blockIdx.y) * (SLAB * K + SLAB);
+  // partial[wave][N x K | N]: this block fills rows n0 .. n0 + 63 of its wave's record
+  float* pw = partial + (size_t)wave * ((size_t)N * K + N);
 #pragma unroll
   for (int nb = 0; nb < 4; ++nb) {
     float v = bsum[nb];
     v += __shfl_xor(v, 16, 64);
     v += __shfl_xor(v, 32, 64);
-    if (g == 0) pw[SLAB * K + 16 * nb + c] = v;
+    if (g == 0) pw[(size_t)N * K + n0 + 16 * nb + c] = v;
   }
 #pragma unroll
   for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) pw[(size_t)(16 * nb + 4 * g + r) * K + 16 * kb + c] = C[nb][kb][r];
+      for (int r = 0; r < 4; ++r)
+        pw[(size_t)(n0 + 16 * nb + 4 * g + r) * K + 16 * kb + c] = C[nb][kb][r];
 }
 
-// gw[slab * 64 + i][k] (and gb[slab * 64 + i]) = sum over waves, ascending, of the partials
-__global__ __launch_bounds__(256) void skinny_dw_reduce_kernel(const float* __restrict__ partial,
-                                                               int nwaves, int slabs, int K,
-                                                               float* __restrict__ gw,
-                                                               float* __restrict__ gb) {
-  const int per = SLAB * K + SLAB;
-  const int i = blockIdx.x * 256 + threadIdx.x;         // element of a slab's [64 x K | 64] record
-  if (i >= slabs * per) return;
-  const int slab = i / per, e = i - slab * per;
+// sums of per-wave records [ntab][len], fixed order: 16 columns x 64 slices per 1024-thread block
+// (a thread sums <= ntab / 64 records, 4 loads in flight), then the 64 slice sums in order.
+// Columns below `split` go to out0, the rest to out1 (weight gradient | bias gradient).
+__global__ __launch_bounds__(1024) void sum_tables_kernel(const float* __restrict__ partial, int ntab,
+                                                          int len, int split, float* __restrict__ out0,
+                                                          float* __restrict__ out1) {
+  __shared__ float sl[64][17];
+  const int cl = threadIdx.x & 15;
+  const int col = blockIdx.x * 16 + cl;
+  const int slice = threadIdx.x >> 4;
   float acc = 0.f;
-  int w = 0;
-  for (; w + 4 <= nwaves; w += 4) {
-    const float a0 = partial[((size_t)w * slabs + slab) * per + e];
-    const float a1 = partial[((size_t)(w + 1) * slabs + slab) * per + e];
-    const float a2 = partial[((size_t)(w + 2) * slabs + slab) * per + e];
-    const float a3 = partial[((size_t)(w + 3) * slabs + slab) * per + e];
-    acc += a0; acc += a1; acc += a2; acc += a3;
+  if (col < len) {
+    const int per = (ntab + 63) / 64;
+    const int lo = slice * per, hi = (lo + per < ntab) ? lo + per : ntab;
+    int k = lo;
+    for (; k + 4 <= hi; k += 4) {
+      const float a0 = partial[(size_t)k * len + col], a1 = partial[(size_t)(k + 1) * len + col];
+      const float a2 = partial[(size_t)(k + 2) * len + col], a3 = partial[(size_t)(k + 3) * len + col];
+      acc += a0; acc += a1; acc += a2; acc += a3;
+    }
+    for (; k < hi; ++k) acc += partial[(size_t)k * len + col];
   }
-  for (; w < nwaves; ++w) acc += partial[((size_t)w * slabs + slab) * per + e];
-  if (e < SLAB * K) gw[(size_t)slab * SLAB * K + e] = acc;
-  else if (gb) gb[slab * SLAB + e - SLAB * K] = acc;
+  sl[slice][cl] = acc;
+  __syncthreads();
+  if (slice == 0 && col < len) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 64; ++k) t += sl[k][cl];
+    if (col < split) out0[col] = t;
+    else if (out1) out1[col - split] = t;
+  }
+}
+
+// Backward of a NARROW Linear (N <= 16 outputs, K = 64 inputs: the classifier heads, src/nn/mlp.py:
+// 128-142) in one pass over x and gy: lane = input column k.  Per row the N gradient values are
+// wave-uniform (read out of a register tile with v_readlane), so dX[row, k] = sum_n g_n W[n, k]
+// and dW[n, k] += g_n x[row, k] are 2 N fused multiply-adds per lane, db[n] += g_n.  The library
+// ran these as three GEMMs / reductions of 0.1-0.7 ms each at 428 571 rows (a [13 x 64] result).
+// Per-wave partials of (dW, db), summed in a fixed order by sum_tables_kernel.
+template <int NMAX>
+__global__ __launch_bounds__(256) void narrow_linear_bwd_kernel(
+    const float* __restrict__ gy, const float* __restrict__ x, const float* __restrict__ W,
+    int64_t rows, int N, float* __restrict__ gx, float* __restrict__ partial) {
+  constexpr int K = 64, RT = 16;                        // rows per step
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  float w[NMAX], aw[NMAX], ab[NMAX];
+#pragma unroll
+  for (int n = 0; n < NMAX; ++n) {
+    w[n] = (n < N) ? W[(size_t)n * K + lane] : 0.f;
+    aw[n] = ab[n] = 0.f;
+  }
+  const int64_t nsteps = (rows + RT - 1) / RT;
+  for (int64_t t = wave; t < nsteps; t += nwaves) {
+    const int64_t row0 = t * RT;
+    const int cnt = (int)((rows - row0) < RT ? (rows - row0) : RT);
+    // the step's gradient values: RT * N <= 256 floats, element e in lane e & 63 of gt[e >> 6]
+    float gt[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = q * 64 + lane;
+      gt[q] = (e < cnt * N) ? gy[row0 * N + e] : 0.f;
+    }
+    float xr[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) xr[r] = (r < cnt) ? x[(row0 + r) * K + lane] : 0.f;
+    if (N == NMAX) {                                    // compile-time element positions
+#pragma unroll
+      for (int r = 0; r < RT; ++r) {
+        float dx = 0.f;
+#pragma unroll
+        for (int n = 0; n < NMAX; ++n) {
+          const int e = r * NMAX + n;
+          const float gv = __builtin_bit_cast(
+              float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gt[e >> 6]), e & 63));
+          dx = fmaf(gv, w[n], dx);
+          aw[n] = fmaf(gv, xr[r], aw[n]);
+          ab[n] += gv;
+        }
+        if (gx && r < cnt) gx[(row0 + r) * K + lane] = dx;
+      }
+    } else {
+      for (int r = 0; r < cnt; ++r) {
+        float dx = 0.f;
+        for (int n = 0; n < N; ++n) {
+          const int e = r * N + n;
+          const float src = (e >> 6) == 0 ? gt[0] : ((e >> 6) == 1 ? gt[1] : ((e >> 6) == 2 ? gt[2] : gt[3]));
+          const float gv = __shfl(src, e & 63, 64);
+          dx = fmaf(gv, w[n], dx);
+#pragma unroll
+          for (int m = 0; m < NMAX; ++m) {
+            aw[m] = (m == n) ? fmaf(gv, xr[r < RT ? r : 0], aw[m]) : aw[m];
+            ab[m] = (m == n) ? ab[m] + gv : ab[m];
+          }
+        }
+        if (gx) gx[(row0 + r) * K + lane] = dx;
+      }
+    }
+  }
+  float* pw = partial + (size_t)wave * ((size_t)N * K + N);   // [N x K | N]
+#pragma unroll
+  for (int n = 0; n < NMAX; ++n)
+    if (n < N) pw[n * K + lane] = aw[n];
+  if (lane < N) {
+    float v = 0.f;
+#pragma unroll
+    for (int n = 0; n < NMAX; ++n) v = (lane == n) ? ab[n] : v;
+    pw[N * K + lane] = v;
+  }
 }
 
 }  // namespace skinny
@@ -259,14 +353,15 @@ extern "C" int spt_skinny_dw_f32(const float* gy, const float* x, int64_t rows, 
     skinny_dw_kernel<8><<<grid, WAVES * 64, 0, stream>>>(gy, x, rows, N, partial);
   else
     skinny_dw_kernel<16><<<grid, WAVES * 64, 0, stream>>>(gy, x, rows, N, partial);
-  skinny_dw_reduce_kernel<<<(N * (K + 1) + 255) / 256, 256, 0, stream>>>(partial, (int)bx * WAVES, slabs,
-                                                                         K, gw, gb);
+  sum_tables_kernel<<<(N * (K + 1) + 15) / 16, 1024, 0, stream>>>(partial, (int)bx * WAVES, N * (K + 1),
+                                                                  N * K, gw, gb);
   SPT_CHECK_LAUNCH();
   return 0;
 }
 
 extern "C" int spt_skinny_linear_supported(int K, int N) {
-  return (K == 32 || K == 64 || K == 128 || K == 192) && N >= SLAB && N % SLAB == 0 && N <= 1024;
+  const bool kok = K == 32 || K == 64 || K == 128 || K == 192;
+  return kok && ((N >= SLAB && N % SLAB == 0 && N <= 1024) || (N >= 1 && N <= 16 && K <= 128));
 }
 
 extern "C" int spt_skinny_linear_f32(const float* x, int64_t rows, int K, const float* W,
@@ -276,18 +371,68 @@ extern "C" int spt_skinny_linear_f32(const float* x, int64_t rows, int K, const 
   SPT_CHECK_ARG(spt_skinny_linear_supported(K, N), "(K, N) not built");
   if (rows == 0) return 0;
   SPT_CHECK_ARG(x && W && y, "null pointer");
-  const int slabs = N / SLAB;
+  const bool narrow = N <= 16;
+  const int slabs = narrow ? 1 : N / SLAB;
   const int64_t tiles = ceil_div(rows, TR);
   int64_t bx = ceil_div(tiles, WAVES);
   const int64_t cap = (int64_t)256 * 8 / slabs > 1 ? (int64_t)256 * 8 / slabs : 1;
   if (bx > cap) bx = cap;
   const dim3 grid((unsigned)bx, (unsigned)slabs);
+  if (narrow) {
+    switch (K) {
+      case 32:  skinny_linear_kernel<8, 1><<<grid, WAVES * 64, 0, stream>>>(x, rows, W, bias, N, y); break;
+      case 64:  skinny_linear_kernel<16, 1><<<grid, WAVES * 64, 0, stream>>>(x, rows, W, bias, N, y); break;
+      default:  skinny_linear_kernel<32, 1><<<grid, WAVES * 64, 0, stream>>>(x, rows, W, bias, N, y); break;
+    }
+    SPT_CHECK_LAUNCH();
+    return 0;
+  }
   switch (K) {
     case 32:  skinny_linear_kernel<8><<<grid, WAVES * 64, 0, stream>>>(x, rows, W, bias, N, y); break;
     case 64:  skinny_linear_kernel<16><<<grid, WAVES * 64, 0, stream>>>(x, rows, W, bias, N, y); break;
     case 128: skinny_linear_kernel<32><<<grid, WAVES * 64, 0, stream>>>(x, rows, W, bias, N, y); break;
     default:  skinny_linear_kernel<48><<<grid, WAVES * 64, 0, stream>>>(x, rows, W, bias, N, y); break;
   }
+  SPT_CHECK_LAUNCH();
+  return 0;
+}
+
+constexpr int NARROW_BLOCKS = 256;                      // x 4 waves of partial (dW, db)
+
+extern "C" int spt_narrow_linear_bwd_supported(int K, int N) { return K == 64 && N >= 1 && N <= 16; }
+extern "C" size_t spt_narrow_linear_bwd_workspace_bytes(int K, int N) {
+  return (size_t)NARROW_BLOCKS * 4 * (16 * K + 16) * sizeof(float);
+}
+// Backward of y = x W^T + b with N <= 16, K = 64 in one pass: gx[rows,K] = gy W (nullable),
+// gw[N,K] = gy^T x, gb[N] = column sums of gy (nullable).
+extern "C" int spt_narrow_linear_bwd_f32(const float* gy, const float* x, const float* W,
+                                         int64_t rows, int N, int K, float* gx, float* gw,
+                                         float* gb, void* ws, size_t ws_bytes,
+                                         spt_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPT_CHECK_ARG(rows >= 0, "bad shape");
+  SPT_CHECK_ARG(spt_narrow_linear_bwd_supported(K, N), "(K, N) not built");
+  SPT_CHECK_ARG(W && gw && (rows == 0 || (gy && x)), "null pointer");
+  SPT_CHECK_ARG(ws && ws_bytes >= spt_narrow_linear_bwd_workspace_bytes(K, N), "workspace too small");
+  if (rows == 0) {
+    hipMemsetAsync(gw, 0, (size_t)N * K * sizeof(float), stream);
+    if (gb) hipMemsetAsync(gb, 0, (size_t)N * sizeof(float), stream);
+    return 0;
+  }
+  int64_t bx = ceil_div(ceil_div(rows, (int64_t)16), (int64_t)4);
+  if (bx > NARROW_BLOCKS) bx = NARROW_BLOCKS;
+  float* partial = (float*)ws;
+  int nmax;
+  if (N == 13) {
+    nmax = 13;
+    narrow_linear_bwd_kernel<13><<<(int)bx, 256, 0, stream>>>(gy, x, W, rows, N, gx, partial);
+  } else {
+    nmax = 16;
+    narrow_linear_bwd_kernel<16><<<(int)bx, 256, 0, stream>>>(gy, x, W, rows, N, gx, partial);
+  }
+  (void)nmax;
+  sum_tables_kernel<<<(N * (K + 1) + 15) / 16, 1024, 0, stream>>>(partial, (int)bx * 4, N * (K + 1), N * K,
+                                                                  gw, gb);
   SPT_CHECK_LAUNCH();
   return 0;
 }

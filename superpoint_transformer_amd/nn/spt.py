@@ -222,7 +222,7 @@ class SPT(nn.Module):
             ea = _get(lv, "edge_attr")
             ei = _get(lv, "edge_index")
             if self.h_edge_mlps[i_stage] is not None and ea is not None:   # spt.py:827-835
-                eb = None if ni is None else ni[ei[0]]
+                eb = None if (ni is None or B == 1) else ni[ei[0]]     # one cloud: one graph
                 ea = self.h_edge_mlps[i_stage](ea, batch=eb, batch_size=B)
             node_x[i_level], edge_attrs[i_level] = xh, ea
             is_last = i_level == len(levels) - 1
@@ -268,7 +268,7 @@ class SPT(nn.Module):
             if self.node_mlps[k] is not None and xh is not None:
                 xh = self.node_mlps[k](xh, batch=ni, batch_size=B)
             if self.h_edge_mlps[k] is not None and ea is not None:
-                ea = self.h_edge_mlps[k](ea, batch=None if ni is None else ni[ei[0]],
+                ea = self.h_edge_mlps[k](ea, batch=None if (ni is None or B == 1) else ni[ei[0]],
                                          batch_size=B)
             return xh, ea
 

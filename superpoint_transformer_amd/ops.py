@@ -594,6 +594,25 @@ class _TallLinear(torch.autograd.Function):
     def backward(ctx, g):
         x, weight = ctx.saved_tensors
         g = g.contiguous()
+        if (x.is_cuda and x.dtype == torch.float32 and g.dtype == torch.float32
+                and weight.dtype == torch.float32 and x.shape[0] >= _SKINNY_MIN_ROWS
+                and _lib.lib.spt_narrow_linear_bwd_supported(x.shape[1], g.shape[1])):
+            # narrow head: dX, dW and db from one pass over (x, g)
+            xc, wc = x.detach().contiguous(), weight.detach().contiguous()
+            rows, k = xc.shape
+            n = g.shape[1]
+            dev = xc.device
+            gx = torch.empty_like(xc) if ctx.needs_input_grad[0] else None
+            gw = torch.empty((n, k), dtype=torch.float32, device=dev)
+            gb = torch.empty(n, dtype=torch.float32, device=dev) if ctx.has_bias else None
+            nb = _lib.lib.spt_narrow_linear_bwd_workspace_bytes(k, n)
+            ws = _workspace(nb, dev)
+            with torch.cuda.device(dev):
+                st = _lib.lib.spt_narrow_linear_bwd_f32(
+                    _lib.ptr(g), _lib.ptr(xc), _lib.ptr(wc), rows, n, k, _lib.ptr(gx),
+                    _lib.ptr(gw), _lib.ptr(gb), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+            _lib.check(st, "spt_narrow_linear_bwd_f32")
+            return gx, gw, gb
         gx = None
         if ctx.needs_input_grad[0]:
             wt = weight.detach().t().contiguous()           # [K, N]: dX = G (W^T)^T
@@ -630,8 +649,8 @@ def graph_ranges(batch, num_graphs, rows):
     """Host row ranges [B+1] of the graphs when ``batch`` is sorted (clouds of a
     NAGBatch are contiguous), else None.  One host sync per batch tensor (memoised
     on the tensor, like the CSR views)."""
-    if batch is None:
-        return [0, rows]
+    if batch is None or (num_graphs is not None and int(num_graphs) == 1):
+        return [0, rows]                                 # one graph: nothing to look at
     memo = getattr(batch, _GPTR_ATTR, None)
     key = (batch._version, int(num_graphs), batch.data_ptr(), batch.numel())
     if memo is not None and memo[0] == key:

@@ -42,7 +42,8 @@ def test_linear_autograd_matches_torch(dev):
 def test_unsupported_shapes_and_small_inputs_use_the_library(dev):
     from superpoint_transformer_amd import ops, _lib
     assert not _lib.lib.spt_skinny_linear_supported(48, 64)
-    assert not _lib.lib.spt_skinny_linear_supported(64, 13)
+    assert not _lib.lib.spt_skinny_linear_supported(64, 40)
+    assert _lib.lib.spt_skinny_linear_supported(64, 13)        # narrow heads are built
     x = torch.randn(100, 64, device=dev)
     w = torch.randn(192, 64, device=dev)
     assert torch.equal(ops.linear(x, w), torch.nn.functional.linear(x, w))
@@ -69,3 +70,27 @@ def test_weight_gradient_kernel_matches_float64(rows, K, N, dev):
     ref = go.double().t() @ x.double()
     tol = 2e-6 * max(rows, 16) ** 0.5 * float(go.abs().max()) * float(x.abs().max()) + 1e-6 * float(ref.abs().max())
     assert (gw.cpu().double() - ref).abs().max() < tol
+
+
+@pytest.mark.parametrize("rows", [4096, 4099, 70001, 428_571])
+@pytest.mark.parametrize("K,N", [(64, 13), (64, 16), (64, 5), (32, 13), (128, 7)])
+def test_narrow_head_linear_autograd_matches_float64(rows, K, N, dev):
+    """The classifier heads (64 -> 13): forward on the skinny kernel's narrow variant; backward
+    (dX, dW, db) in one pass on the narrow kernel where K = 64, else on the library.  Against
+    float64 torch with the bars of the wide kernels."""
+    from superpoint_transformer_amd import ops
+    g = torch.Generator().manual_seed(rows + K + N)
+    x = torch.randn(rows, K, generator=g).to(dev).requires_grad_()
+    w = (torch.randn(N, K, generator=g) * 0.2).to(dev).requires_grad_()
+    b = torch.randn(N, generator=g).to(dev).requires_grad_()
+    go = torch.randn(rows, N, generator=g).to(dev)
+    y = ops.linear(x, w, b)
+    gx, gw, gb = torch.autograd.grad(y, (x, w, b), go)
+    xd, wd, bd = (t.detach().double().requires_grad_() for t in (x, w, b))
+    yr = torch.nn.functional.linear(xd, wd, bd)
+    rx, rw, rb = torch.autograd.grad(yr, (xd, wd, bd), go.double())
+    assert (y.double() - yr).abs().max() < 2e-6 * K * float(x.abs().max()) * float(w.abs().max())
+    assert (gx.double() - rx).abs().max() < 2e-6 * N * float(go.abs().max()) * float(w.abs().max()) + 1e-6
+    tol = 2e-6 * rows ** 0.5 * float(go.abs().max()) * float(x.abs().max())
+    assert (gw.double() - rw).abs().max() < tol + 1e-6 * float(rw.abs().max())
+    assert (gb.double() - rb).abs().max() < tol + 1e-6 * float(rb.abs().max())
