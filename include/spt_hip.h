@@ -578,6 +578,22 @@ int spt_fused_linear_bwd_pooled_f32(
     float pre_slope, const float* W, float* gx, float* gW, int accumulate, double* prev_total,
     void* ws, size_t ws_bytes, spt_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * Cross-entropy of the classifier heads' logits                (train step)
+ * torch.nn.CrossEntropyLoss(ignore_index=...) of configs/model/semantic/default.yaml:47-49 as
+ * src/models/semantic.py applies it per output level: mean over the rows whose target is not
+ * ignore_index of logsumexp(logits[row]) - logits[row, target[row]].  C <= 32 classes.
+ *   fwd: lse[rows] (kept for the backward), loss[1], count[1] (rows that counted, as f32);
+ *        ws: spt_cross_entropy_workspace_bytes(rows).  Deterministic (f64 partial sums, fixed order).
+ *   bwd: glogits = (softmax - onehot) * gout[0] / count[0]; gout / count are device scalars. */
+size_t spt_cross_entropy_workspace_bytes(int64_t rows);
+int spt_cross_entropy_fwd_f32(const float* logits, const int64_t* target, int64_t rows, int C,
+                              int64_t ignore_index, float* lse, float* loss, float* count,
+                              void* ws, size_t ws_bytes, spt_stream_t stream);
+int spt_cross_entropy_bwd_f32(const float* logits, const int64_t* target, const float* lse,
+                              int64_t rows, int C, int64_t ignore_index, const float* gout,
+                              const float* count, float* glogits, spt_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

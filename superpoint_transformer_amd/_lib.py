@@ -99,6 +99,9 @@ SIGNATURES = {
     "spt_narrow_linear_bwd_supported": (_int, [_int, _int]),
     "spt_narrow_linear_bwd_workspace_bytes": (_sz, [_int, _int]),
     "spt_narrow_linear_bwd_f32": (_int, [_p, _p, _p, _i64, _int, _int, _p, _p, _p, _p, _sz, _p]),
+    "spt_cross_entropy_workspace_bytes": (_sz, [_i64]),
+    "spt_cross_entropy_fwd_f32": (_int, [_p, _p, _i64, _int, _i64, _p, _p, _p, _p, _sz, _p]),
+    "spt_cross_entropy_bwd_f32": (_int, [_p, _p, _p, _i64, _int, _i64, _p, _p, _p, _p]),
     "spt_skinny_dw_supported": (_int, [_int, _int]),
     "spt_skinny_dw_workspace_bytes": (_sz, [_int, _int]),
     "spt_skinny_dw_f32": (_int, [_p, _p, _i64, _int, _int, _p, _p, _p, _sz, _p]),

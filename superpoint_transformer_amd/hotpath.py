@@ -164,7 +164,7 @@ class SPTTrainStep:
         self.labels = [torch.randint(0, NUM_CLASSES, (self.n[i],), device=dev, generator=g)
                        for i in (1, 2)]
         self.lambdas = [1.0, 50.0]               # configs/model/semantic/default.yaml:12
-        self.loss_fn = nn.CrossEntropyLoss()
+        self.loss_fn = ops.cross_entropy          # CrossEntropyLoss(), mean reduction, on csrc/loss.hip
         n0, c = self.n[0], 128
         self.tname = f"segcsr_reduce_fwd:3:{n0}x{c}"
         ops.enable_timer(self.tname)
@@ -254,7 +254,7 @@ class SPTPanopticStep(SPTTrainStep):
         ne = self.nag.levels[1]["obj_edge_index"].shape[1]
         self.affinity = (torch.rand(ne, device=dev, generator=g) < 0.5).float()
         self.lambdas = [1.0, 50.0]
-        self.loss_fn = nn.CrossEntropyLoss()
+        self.loss_fn = ops.cross_entropy          # CrossEntropyLoss(), mean reduction, on csrc/loss.hip
         self.bce = nn.BCEWithLogitsLoss()
         self.pool_c = 64
         self.tname = f"segcsr_reduce_fwd:3:{self.n[0]}x64"

@@ -640,6 +640,55 @@ def linear(x, weight, bias=None):
 
 
 # ---------------------------------------------------------------------------
+# Cross-entropy of the heads' logits (csrc/loss.hip)
+# ---------------------------------------------------------------------------
+class _CrossEntropy(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, ignore_index):
+        _lib.require_cuda(logits, target)
+        lg = _f32c(logits)
+        tg = target.long().contiguous()
+        rows, c = lg.shape
+        dev = lg.device
+        lse = torch.empty(rows, dtype=torch.float32, device=dev)
+        out = torch.empty(2, dtype=torch.float32, device=dev)          # loss | count
+        nb = _lib.lib.spt_cross_entropy_workspace_bytes(rows)
+        ws = _workspace(nb, dev)
+        with torch.cuda.device(dev):
+            st = _lib.lib.spt_cross_entropy_fwd_f32(
+                _lib.ptr(lg), _lib.ptr(tg), rows, c, int(ignore_index), _lib.ptr(lse),
+                _lib.ptr(out), _lib.ptr(out[1:]), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+        _lib.check(st, "spt_cross_entropy_fwd_f32")
+        ctx.save_for_backward(lg, tg, lse, out)
+        ctx.meta = (int(ignore_index), logits.dtype)
+        return out[0].to(logits.dtype)
+
+    @staticmethod
+    def backward(ctx, gout):
+        lg, tg, lse, out = ctx.saved_tensors
+        ignore_index, dtype = ctx.meta
+        rows, c = lg.shape
+        dev = lg.device
+        g = gout.detach().float().reshape(1).contiguous()
+        glog = torch.empty_like(lg)
+        with torch.cuda.device(dev):
+            st = _lib.lib.spt_cross_entropy_bwd_f32(
+                _lib.ptr(lg), _lib.ptr(tg), _lib.ptr(lse), rows, c, ignore_index, _lib.ptr(g),
+                _lib.ptr(out[1:]), _lib.ptr(glog), _lib.stream_ptr(dev))
+        _lib.check(st, "spt_cross_entropy_bwd_f32")
+        return glog.to(dtype), None, None
+
+
+def cross_entropy(logits, target, ignore_index=-100):
+    """``torch.nn.functional.cross_entropy(logits, target, ignore_index=...)`` (mean reduction, no
+    class weights) for [rows, C <= 32] logits on the HIP kernels; anything else goes to torch."""
+    if (logits.is_cuda and logits.dim() == 2 and 1 <= logits.shape[1] <= 32
+            and logits.shape[0] >= 1 and target.dim() == 1):
+        return _CrossEntropy.apply(logits, target, ignore_index)
+    return torch.nn.functional.cross_entropy(logits, target, ignore_index=ignore_index)
+
+
+# ---------------------------------------------------------------------------
 # Fused MLP: [bias-free Linear -> GraphNorm -> LeakyReLU] x L  (src/nn/mlp.py:8-94)
 # ---------------------------------------------------------------------------
 _GPTR_ATTR = "_spt_graph_ranges"

@@ -1,4 +1,5 @@
 cd $GRAFT_REPO_ROOT
-for v in "" "SPT_DBG_NO_NARROW=1" "SPT_DBG_NO_B1=1" "SPT_DBG_NO_DW=1" ""; do
-  echo "== $v"; env $v timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-preprocess 2>/dev/null | cut -c100-160
-done
+timeout 900 python -m pytest tests/test_loss_gpu.py tests/test_model_gpu.py tests/test_modes_gpu.py -m gpu -x -q 2>&1 | tail -4
+timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-preprocess 2>/dev/null | cut -c100-200
+timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-preprocess 2>/dev/null | cut -c100-200
+timeout 200 python bench.py --scene T --steps 30 --warmup 5 --no-cpu-baseline --no-preprocess 2>/dev/null | cut -c100-200
