@@ -59,6 +59,17 @@ def _rpe_per_stage(rpe, num_stages, in_dim, out_dim, stages_share):
     return [rpe] * num_stages
 
 
+def _share_for(edge_attr):
+    """A gradient-buffer share for every attention block that will read ``edge_attr`` in this
+    forward pass, or None (no gradient wanted / sharing off)."""
+    import torch
+    from .. import ops
+    if (edge_attr is not None and ops.share_edge_attr_grad() and torch.is_grad_enabled()
+            and edge_attr.requires_grad):
+        return ops.EdgeAttrGradShare()
+    return None
+
+
 def _get(data, key, default=None):
     if isinstance(data, dict):
         return data.get(key, default)
@@ -210,7 +221,7 @@ class SPT(nn.Module):
             num_graphs=B,
             pool_to_parent=(norm_index(levels[1]),) if fuse_pool else None)
 
-        down_outputs, node_x, edge_attrs = [], {}, {}
+        down_outputs, node_x, edge_attrs, ea_shares = [], {}, {}, {}
         for i_stage in range(self.num_down_stages):
             i_level = i_stage + 1
             lv = levels[i_level]
@@ -225,13 +236,18 @@ class SPT(nn.Module):
                 eb = None if (ni is None or B == 1) else ni[ei[0]]     # one cloud: one graph
                 ea = self.h_edge_mlps[i_stage](ea, batch=eb, batch_size=B)
             node_x[i_level], edge_attrs[i_level] = xh, ea
+            # the down stage and, later, the up stage of this level read the same edge_attr:
+            # one gradient buffer for all their blocks (the first block of the down stage - the
+            # last one autograd reaches - hands it over)
+            ea_shares[i_level] = _share_for(ea)
             is_last = i_level == len(levels) - 1
             x, diameter = stage(                                            # spt.py:915-930
                 xh if self.use_node_hf else None, x, ni, _get(levels[i_level - 1], "super_index"),
                 pos=_get(lv, "pos"), node_size=_get(lv, "node_size"),
                 super_index=None if is_last else _get(lv, "super_index"),
                 edge_index=ei, edge_attr=ea, num_super=sizes[i_level], num_graphs=B,
-                num_super_parent=None if is_last else sizes[i_level + 1])
+                num_super_parent=None if is_last else sizes[i_level + 1],
+                ea_grad=ea_shares[i_level])
             down_outputs.append(x)
 
         up_outputs = []
@@ -244,7 +260,8 @@ class SPT(nn.Module):
                 self.feature_fusion(x_skip, xh), x, norm_index(lv), _get(lv, "super_index"),
                 pos=_get(lv, "pos"), node_size=_get(lv, "node_size"),
                 super_index=_get(lv, "super_index"), edge_index=_get(lv, "edge_index"),
-                edge_attr=edge_attrs.get(i_level), num_super=sizes[i_level + 1], num_graphs=B)
+                edge_attr=edge_attrs.get(i_level), num_super=sizes[i_level + 1], num_graphs=B,
+                ea_grad=ea_shares.get(i_level))
             up_outputs.append(x)
 
         if self.output_stage_wise:

@@ -91,7 +91,7 @@ class Stage(nn.Module):
 
     def forward(self, x, norm_index, pos=None, diameter=None, node_size=None,
                 super_index=None, edge_index=None, edge_attr=None, num_super=None,
-                num_graphs=None, pool_to_parent=None):
+                num_graphs=None, pool_to_parent=None, ea_grad=None):
         """``pool_to_parent`` = (parent batch vector or None): when the stage is only an
         in_mlp (PointStage) whose output feeds nothing but the max-pool to the parents, the
         pooled features are returned instead (``PooledToParent``) and the MLP's last
@@ -146,10 +146,13 @@ class Stage(nn.Module):
                     and edge_index.shape[1] > 0:
                 edge_index = edge_csr_of(edge_index, x.shape[0])   # once per stage
             # the blocks all read the same edge_attr: one shared gradient buffer
-            share = ops.EdgeAttrGradShare() if (
-                ops.share_edge_attr_grad() and edge_attr is not None
-                and len(self.transformer_blocks) > 1
-                and torch.is_grad_enabled() and edge_attr.requires_grad) else None
+            # (``ea_grad``: a share handed down by SPT.forward, common to the down and the up
+            # stage of a level, which read the same edge_attr too)
+            share = ea_grad
+            if share is None and (ops.share_edge_attr_grad() and edge_attr is not None
+                                  and len(self.transformer_blocks) > 1
+                                  and torch.is_grad_enabled() and edge_attr.requires_grad):
+                share = ops.EdgeAttrGradShare()
             for block in self.transformer_blocks:
                 x, norm_index, edge_index = block(
                     x, norm_index, edge_index=edge_index, edge_attr=edge_attr,
@@ -179,7 +182,8 @@ class DownNFuseStage(Stage):
 
     def forward(self, x_parent, x_child, norm_index, pool_index, pos=None, diameter=None,
                 node_size=None, super_index=None, edge_index=None, edge_attr=None,
-                v_edge_attr=None, num_super=None, num_graphs=None, num_super_parent=None):
+                v_edge_attr=None, num_super=None, num_graphs=None, num_super_parent=None,
+                ea_grad=None):
         if isinstance(x_child, PooledToParent):
             x_pooled = x_child.x
         else:
@@ -189,7 +193,7 @@ class DownNFuseStage(Stage):
         return super().forward(x_fused, norm_index, pos=pos, node_size=node_size,
                                super_index=super_index, edge_index=edge_index,
                                edge_attr=edge_attr, num_super=num_super_parent,
-                               num_graphs=num_graphs)
+                               num_graphs=num_graphs, ea_grad=ea_grad)
 
 
 class UpNFuseStage(Stage):
@@ -205,13 +209,13 @@ class UpNFuseStage(Stage):
 
     def forward(self, x_child, x_parent, norm_index, unpool_index, pos=None, diameter=None,
                 node_size=None, super_index=None, edge_index=None, edge_attr=None,
-                num_super=None, num_graphs=None):
+                num_super=None, num_graphs=None, ea_grad=None):
         x_unpool = self.unpool(x_parent, unpool_index)
         x_fused = self.fusion(x_child, x_unpool)
         return super().forward(x_fused, norm_index, pos=pos, node_size=node_size,
                                super_index=super_index, edge_index=edge_index,
                                edge_attr=edge_attr, num_super=num_super,
-                               num_graphs=num_graphs)
+                               num_graphs=num_graphs, ea_grad=ea_grad)
 
 
 class PointStage(Stage):
