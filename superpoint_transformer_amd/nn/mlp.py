@@ -113,4 +113,5 @@ class Classifier(nn.Module):
         self.classifier = nn.Linear(in_dim, num_classes, bias=bias)
 
     def forward(self, x):
-        return self.classifier(x)
+        # the head's Linear on the skinny kernels (narrow variant: 13 classes; backward = one pass)
+        return ops.linear(x, self.classifier.weight, self.classifier.bias)
