@@ -106,17 +106,49 @@ __device__ __forceinline__ void stage_tile(const float* __restrict__ x, int64_t 
     }
     // zero the padding columns [K, KP) once per tile (K % 4 == 0 => KP == K: nothing)
   } else {
-    for (int q = lane; q < TR * KP; q += 64) {
-      const int rr = q / KP, k = q - rr * KP;
-      float v = 0.f;
-      const int64_t xr = IND ? (int64_t)__shfl(rid_l, rr, 64) : row0 + rr;
-      if (rr < cnt && k < K) v = x[xr * K + k];
-      if (raw) raw[rr * LD + k] = v;
-      if (pre && rr < cnt && k < K) {
-        v = fmaf(v - tab[k], tab[KT + k], tab[2 * KT + k]);
-        v = (v > 0.f) ? v : v * slope;
+    // rows that are not whole 16-byte chunks (K = 18: the raw edge features): element loads,
+    // issued for the whole tile before the first one is used (they were load -> use -> ds_write
+    // one at a time: five dependent round trips per tile)
+    if constexpr (KP > 32) {                            // wide rows never come here unaligned
+      for (int q = lane; q < TR * KP; q += 64) {
+        const int rr = q / KP, k = q - rr * KP;
+        float v = 0.f;
+        const int64_t xr = IND ? (int64_t)__shfl(rid_l, rr, 64) : row0 + rr;
+        if (rr < cnt && k < K) v = x[xr * K + k];
+        if (raw) raw[rr * LD + k] = v;
+        if (pre && rr < cnt && k < K) {
+          v = fmaf(v - tab[k], tab[KT + k], tab[2 * KT + k]);
+          v = (v > 0.f) ? v : v * slope;
+        }
+        lds[rr * LD + k] = v;
       }
-      lds[rr * LD + k] = v;
+      return;
+    }
+    constexpr int NE = KP > 32 ? 1 : (TR * KP + 63) / 64;
+    float v[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      const int q = lane + 64 * i, rr = (q / KP) < TR ? q / KP : TR - 1, k = q - (q / KP) * KP;
+      const int64_t xr = IND ? (int64_t)__shfl(rid_l, rr, 64) : row0 + rr;
+      // clamped in-range address for the masked-out elements: an unconditional load keeps the
+      // loads back to back (a load under a per-lane condition is followed by a wait + select)
+      const bool ok = q < TR * KP && rr < cnt && k < K;
+      const float t = x[ok ? xr * K + k : 0];
+      v[i] = ok ? t : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      const int q = lane + 64 * i;
+      if (q < TR * KP) {
+        const int rr = q / KP, k = q - rr * KP;
+        float w = v[i];
+        if (raw) raw[rr * LD + k] = w;
+        if (pre && rr < cnt && k < K) {
+          w = fmaf(w - tab[k], tab[KT + k], tab[2 * KT + k]);
+          w = (w > 0.f) ? w : w * slope;
+        }
+        lds[rr * LD + k] = w;
+      }
     }
   }
 }
