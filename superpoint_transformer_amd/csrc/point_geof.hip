@@ -190,13 +190,19 @@ __global__ __launch_bounds__(256) void point_geof_dense_kernel(
     for (int c0 = 0; c0 < k; c0 += GEOF_CH) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
+      // unconditional loads from clamped addresses, all eight issued before the first is used
+      // and masked afterwards: under a per-lane condition, or with the LDS store right behind
+      // it, every load was followed by its own wait (eight dependent round trips)
+      int64_t iv[8];
 #pragma unroll
       for (int p = 0; p < 8; ++p) {
-        const int row = 8 * p + sub;
-        const int64_t ri = __shfl(i, row, 64);
-        const int col = c0 + cc;
-        il[row * GEOF_LD + cc] = (ri >= 0 && col < k) ? nn[ri * k + col] : -1;
+        const int64_t ri = __shfl(i, 8 * p + sub, 64);
+        const bool ok = ri >= 0 && c0 + cc < k;
+        iv[p] = nn[ok ? ri * k + c0 + cc : 0];
+        iv[p] = ok ? iv[p] : -1;
       }
+#pragma unroll
+      for (int p = 0; p < 8; ++p) il[(8 * p + sub) * GEOF_LD + cc] = iv[p];
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -212,9 +218,25 @@ __global__ __launch_bounds__(256) void point_geof_dense_kernel(
             have_origin = true;
           }
       }
+      // the chunk's eight position gathers in flight together (missing neighbours read point 0
+      // and are masked), then the moment sums in neighbour order
+      float gx[GEOF_CH], gy[GEOF_CH], gz[GEOF_CH];
+#pragma unroll
+      for (int q = 0; q < GEOF_CH; ++q) {
+        const int64_t tq = t[q] >= 0 ? t[q] : 0;
+        gx[q] = xyz[tq * 3];
+        gy[q] = xyz[tq * 3 + 1];
+        gz[q] = xyz[tq * 3 + 2];
+      }
 #pragma unroll
       for (int q = 0; q < GEOF_CH; ++q)
-        if (t[q] >= 0) accumulate(xyz, t[q], px, py, pz, s1, s2, cnt);
+        if (t[q] >= 0) {
+          const double dx = (double)gx[q] - px, dy = (double)gy[q] - py, dz = (double)gz[q] - pz;
+          s1[0] += dx; s1[1] += dy; s1[2] += dz;
+          s2[0] += dx * dx; s2[1] += dx * dy; s2[2] += dx * dz;
+          s2[3] += dy * dy; s2[4] += dy * dz; s2[5] += dz * dz;
+          ++cnt;
+        }
     }
     if (i >= 0) finish_features(s1, s2, cnt, k_min, post, feats + i * 11);
   }
