@@ -219,7 +219,16 @@ def main():
     # ramp; measured: the same binary 74.6 ms/step in the first process of a fresh box, 67.3 in
     # the fifth): untimed steps until `--settle` seconds have passed, then the W warm-up steps.
     t_settle = time.perf_counter()
-    while time.perf_counter() - t_settle < args.settle:
+    while True:
+        go = time.perf_counter() - t_settle < args.settle
+        if world > 1:
+            # every rank must run the same number of steps (a step holds a collective): stop
+            # as soon as ANY rank's time is up
+            flag = torch.tensor([1.0 if go else 0.0], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            go = bool(flag.item() > 0)
+        if not go:
+            break
         path.step()
         torch.cuda.synchronize()
     for _ in range(args.warmup):

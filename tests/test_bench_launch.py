@@ -31,8 +31,9 @@ def test_gpus_2_spawns_two_ranks_share_gpu():
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--settle", "1.0",      # the settle phase holds a collective per step too
                         "--scene", "R", "--no-cpu-baseline", "--no-preprocess"],
-                       env=env, capture_output=True, text=True, timeout=900)
+                       env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
