@@ -24,7 +24,7 @@ def test_cross_entropy_matches_torch(rows, C, ignore, dev):
     ld = logits.detach().double().requires_grad_()
     ref = torch.nn.functional.cross_entropy(ld, target, ignore_index=ii)
     (ref * w.double()).backward()
-    assert abs(float(loss) - float(ref)) <= 1e-6 * max(1.0, abs(float(ref)))
+    assert abs(float(loss.detach()) - float(ref.detach())) <= 1e-6 * max(1.0, abs(float(ref.detach())))
     assert float((logits.grad.double() - ld.grad).abs().max()) <= 1e-6 * float(ld.grad.abs().max()) + 1e-12
     # deterministic
     loss2 = ops.cross_entropy(logits.detach(), target, ignore_index=ii)

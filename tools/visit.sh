@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 400 python -m pytest tests/test_bench_launch.py -m gpu -x -q 2>&1 | tail -3
+timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3
