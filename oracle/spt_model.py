@@ -102,6 +102,28 @@ def stage(s, x, norm_index, pos, node_size, super_index, edge_index, edge_attr, 
     return x, diam_parent
 
 
+def pool_children(pool, x_child, x_parent, index, v_edge_attr, num_pool, dtype):
+    """The down stage's pool (src/nn/stage.py:429-431): an aggregation (pool.py:44-81) or an
+    attentive pool with queries from the parents' features or learnt (pool.py:84-360;
+    default ``qk_scale`` only)."""
+    if getattr(pool, "reduce", None) is not None:
+        return O.scatter(x_child, index, 0, None, num_pool, pool.reduce)
+    p = {}
+    for name in ("kv", "k_rpe", "q_rpe", "in_proj", "out_proj"):
+        lin = getattr(pool, name, None)
+        if lin is not None:
+            p[name + ".weight"] = _p(lin.weight, dtype)
+            p[name + ".bias"] = _p(lin.bias, dtype)
+    if isinstance(pool.q, nn.Linear):                               # pool.py:304
+        query = x_parent @ _p(pool.q.weight, dtype).t()
+        if pool.q.bias is not None:
+            query = query + _p(pool.q.bias, dtype)
+    else:                                                           # pool.py:360
+        query = _p(pool.q, dtype).repeat(num_pool, 1)
+    return O.attentive_pool(x_child, query, index, v_edge_attr, p, pool.num_heads, pool.qk_dim,
+                            num_pool, None, pool.heads_share_rpe)
+
+
 def spt_forward(model, levels, dtype=torch.float64, keep_graph=False):
     """``levels``: list of dicts (pos, x, super_index, node_size, batch,
     edge_index, edge_attr) of CPU tensors.  Returns what SPT.forward returns.
@@ -131,9 +153,12 @@ def spt_forward(model, levels, dtype=torch.float64, keep_graph=False):
         if model.h_edge_mlps[i] is not None and ea is not None:
             ea = mlp(model.h_edge_mlps[i], ea, None if ni is None else ni[ei[0]], dtype)
         node_x[i + 1], eattr[i + 1] = xh, ea
-        pooled = O.scatter(x, levels[i]["super_index"], 0, None, lv["pos"].shape[0],
-                           st.down_pool_block.reduce)
         xp = xh if model.use_node_hf else None
+        v_ea = f(levels[i].get("v_edge_attr"))                       # spt.py:836-841, 929
+        if model.v_edge_mlps[i] is not None and v_ea is not None:
+            v_ea = mlp(model.v_edge_mlps[i], v_ea, levels[i].get("batch"), dtype)
+        pooled = pool_children(st.down_pool_block, x, xp, levels[i]["super_index"], v_ea,
+                               lv["pos"].shape[0], dtype)
         fused = pooled if xp is None else torch.cat((xp, pooled), dim=1)
         last = i + 1 == len(levels) - 1 or i + 1 == nd and levels[i + 1].get("super_index") is None
         x, _ = stage(st, fused, ni, f(lv["pos"]), lv.get("node_size"),

@@ -80,8 +80,11 @@ def _scatter_minmax(src, index, dim_size, is_max):
     out = torch.zeros((n, C), dtype=src.dtype)
     arg = torch.full((n, C), N, dtype=torch.int64)
     if N:
-        red = torch.full((n, C), float("-inf") if is_max else float("inf"),
-                         dtype=src.dtype)
+        if src.is_floating_point():
+            lim = float("-inf") if is_max else float("inf")
+        else:                                    # integer sources (src/data/instance.py:192)
+            lim = torch.iinfo(src.dtype).min if is_max else torch.iinfo(src.dtype).max
+        red = torch.full((n, C), lim, dtype=src.dtype)
         red.scatter_reduce_(0, index.view(-1, 1).expand(N, C), flat,
                             "amax" if is_max else "amin", include_self=True)
         hit = flat == red[index]
@@ -324,6 +327,64 @@ def self_attention(x, edge_index, edge_attr, p, num_heads, qk_dim):
     if p.get("out_proj.weight") is not None:           # attention.py:318-319
         out = out @ p["out_proj.weight"].t() + p["out_proj.bias"]
     return out
+
+
+def qk_scale(s, dim, num_heads, spec=None):
+    """src/utils/nn.py:75-127: the scale of the queries of group ``s`` for every spelling of
+    ``qk_scale`` (None and 'd.g' = D * G, 'd+g', 'd', 'g', or a number used as is)."""
+    if spec is not None and not isinstance(spec, str):
+        return spec
+    D = (dim // num_heads) ** -0.5
+    G = (s.bincount() ** -0.5)[s].view(-1, 1, 1)
+    key = "dg" if spec is None else spec.lower().replace(" ", "")
+    if key in ("d+g", "g+d"):
+        return D + G
+    if key in ("dg", "gd", "d*g", "g*d", "d.g", "g.d"):
+        return D * G
+    if key == "d":
+        return D
+    if key == "g":
+        return G
+    raise ValueError(spec)
+
+
+def attentive_pool(x_child, query, index, edge_attr, p, num_heads, qk_dim, num_pool,
+                   spec=None, heads_share_rpe=False):
+    """src/nn/pool.py:160-245: ``query`` [Np, H*D] is what ``_get_query`` returned; ``p`` maps
+    kv.*, k_rpe.*, q_rpe.*, in_proj.*, out_proj.* (each optional but kv) to tensors."""
+    H, D = num_heads, qk_dim
+
+    def lin(name, x):
+        y = x @ p[name + ".weight"].t()
+        if p.get(name + ".bias") is not None:
+            y = y + p[name + ".bias"]
+        return y
+
+    if p.get("in_proj.weight") is not None:                   # pool.py:177-178
+        x_child = lin("in_proj", x_child)
+    nc = x_child.shape[0]
+    kv = lin("kv", x_child)
+    dim = kv.shape[1] - D * H
+    q = query[index].view(nc, H, D)                            # pool.py:187-189
+    k = kv[:, :D * H].view(nc, H, D)
+    v = kv[:, D * H:].view(nc, H, -1)
+    sc = qk_scale(index, dim, H, spec)
+    q = q * (sc.to(q.dtype) if torch.is_tensor(sc) else sc)   # pool.py:192
+
+    def rpe(name):
+        r = lin(name, edge_attr)
+        return (r.repeat(1, H) if heads_share_rpe else r).view(nc, H, -1)
+
+    if p.get("k_rpe.weight") is not None:                      # pool.py:203-219
+        k = k + rpe("k_rpe")
+    if p.get("q_rpe.weight") is not None:
+        q = q + rpe("q_rpe")
+    compat = torch.einsum("nhd,nhd->nh", q, k)                 # pool.py:222
+    attn = pyg_softmax(compat, index, num_nodes=num_pool)      # pool.py:225
+    x = scatter_sum((v * attn.unsqueeze(-1)).reshape(nc, dim), index, 0, None, num_pool)
+    if p.get("out_proj.weight") is not None:                   # pool.py:236-237
+        x = lin("out_proj", x)
+    return x
 
 
 # --------------------------------------------------------------------------
@@ -892,3 +953,131 @@ def subedges(points, index, edge_index, ratio=0.2, k_min=20, cycles=3, margin=0.
         T_out.append(tid[qt])
         U_out.append(torch.full((k,), e, dtype=torch.long))
     return edge_index, torch.vstack((torch.cat(S_out), torch.cat(T_out))), torch.cat(U_out)
+
+
+# --------------------------------------------------------------------------
+# Cluster-object overlaps of the panoptic path (src/data/instance.py) - plain
+# loops over numpy arrays, sized for test cases of a few hundred clusters.
+# An "instance" here is the tuple (pointers, obj, count, y) of int64 arrays.
+# --------------------------------------------------------------------------
+
+
+def instance_from_dense(cluster, obj, count, y):
+    """InstanceData(..., dense=True) (instance.py:70-100): duplicate (cluster, obj) pairs
+    merged with their counts summed, pairs grouped by cluster and ordered by obj inside."""
+    cluster, obj, count, y = (np.asarray(t, dtype=np.int64) for t in (cluster, obj, count, y))
+    merged = {}
+    for c, o, n, l in zip(cluster, obj, count, y):
+        key = (int(c), int(o))
+        prev = merged.get(key, (0, int(l)))
+        merged[key] = (prev[0] + int(n), int(l))
+    keys = sorted(merged)
+    num = max(k[0] for k in keys) + 1
+    sizes = np.zeros(num, dtype=np.int64)
+    for c, _ in keys:
+        sizes[c] += 1
+    assert (sizes > 0).all(), "Indices must be dense"          # sparse.py:28
+    ptr = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    return (ptr, np.array([k[1] for k in keys], dtype=np.int64),
+            np.array([merged[k][0] for k in keys], dtype=np.int64),
+            np.array([merged[k][1] for k in keys], dtype=np.int64))
+
+
+def instance_indices(ptr):
+    return np.repeat(np.arange(len(ptr) - 1), np.diff(ptr))
+
+
+def instance_major(inst, num_classes=None):
+    """instance.py:160-236: per cluster the overlap with the largest count (first on ties);
+    when at least one void-dominated cluster holds <= 50 % void points, EVERY void-dominated
+    cluster takes its largest non-void overlap instead."""
+    ptr, obj, count, y = inst
+    nc = num_classes if num_classes else int(y.max()) + 1
+    n = len(ptr) - 1
+    void = (y < 0) | (y >= nc)
+    best, best_nv = np.zeros(n, np.int64), np.zeros(n, np.int64)
+    tot = np.zeros(n, np.int64)
+    for c in range(n):
+        lo, hi = ptr[c], ptr[c + 1]
+        best[c] = lo + int(np.argmax(count[lo:hi]))
+        best_nv[c] = lo + int(np.argmax(count[lo:hi] * ~void[lo:hi]))
+        tot[c] = count[lo:hi].sum()
+    o, k, l = obj[best].copy(), count[best].copy(), y[best].copy()
+    mv = (l < 0) | (l >= nc)
+    if not mv.any():
+        return o, k, l
+    if ((k / tot) > 0.5)[mv].all():
+        return o, k, l
+    o[mv], l[mv] = obj[best_nv][mv], y[best_nv][mv]
+    k[mv] = (count * ~void)[best_nv][mv]
+    return o, k, l
+
+
+def instance_iou_and_size(inst, pair_cropped_count=None):
+    """instance.py:268-298 (f32 division like the reference's int / int)."""
+    ptr, obj, count, y = inst
+    idx = instance_indices(ptr)
+    a = np.array([count[idx == i].sum() for i in idx], dtype=np.int64)
+    b = np.array([count[obj == o].sum() for o in obj], dtype=np.int64)
+    if pair_cropped_count is not None:
+        b = b + pair_cropped_count
+    iou = count.astype(np.float32) / (a + b - count).astype(np.float32)
+    return iou, a, b
+
+
+def instance_estimate_centroid(inst, cluster_pos, mode="iou"):
+    """instance.py:300-352: objects in increasing index order."""
+    ptr, obj, count, y = inst
+    idx = instance_indices(ptr)
+    iou, a, b = instance_iou_and_size(inst)
+    if mode == "iou":
+        w = iou.astype(np.float64)
+    elif mode == "product-iou":
+        w = count.astype(np.float64) ** 2 / (a * b)
+    elif mode == "overlap":
+        w = count.astype(np.float64)
+    else:
+        raise NotImplementedError
+    ids = np.unique(obj)
+    pos = np.zeros((len(ids), cluster_pos.shape[1]))
+    for j, o in enumerate(ids):
+        m = obj == o
+        pos[j] = (cluster_pos[idx[m]].astype(np.float64) * w[m, None]).sum(0) / w[m].sum()
+    return pos, ids
+
+
+def instance_graph(inst, edge_index, num_classes=None, smooth_affinity=True):
+    """instance.py:354-460: trimmed graph (i < j, sorted, unique, no loops) and per edge
+    ``(|i & obj_j| / |i| + |j & obj_i| / |j|) / 2`` or ``obj_i == obj_j``."""
+    ptr, obj, count, y = inst
+    pairs = sorted({(min(int(s), int(t)), max(int(s), int(t)))
+                    for s, t in zip(edge_index[0], edge_index[1]) if s != t})
+    e = np.array(pairs, dtype=np.int64).reshape(-1, 2).T
+    if e.size == 0:
+        return e, np.zeros(0, np.float32)
+    major = instance_major(inst, num_classes)[0]
+    if not smooth_affinity:
+        return e, (major[e[0]] == major[e[1]]).astype(np.float32)
+    idx = instance_indices(ptr)
+    overlap = {(int(c), int(o)): int(n) for c, o, n in zip(idx, obj, count)}
+    size = np.array([count[ptr[c]:ptr[c + 1]].sum() for c in range(len(ptr) - 1)])
+    aff = np.zeros(e.shape[1], np.float32)
+    for k, (i, j) in enumerate(pairs):
+        oij = np.float32(overlap.get((i, int(major[j])), 0))
+        oji = np.float32(overlap.get((j, int(major[i])), 0))
+        aff[k] = (oij / np.float32(size[i]) + oji / np.float32(size[j])) / np.float32(2)
+    return e, aff
+
+
+def instance_search_void(inst, num_classes):
+    """instance.py:462-546."""
+    ptr, obj, count, y = inst
+    idx = instance_indices(ptr)
+    void = (y < 0) | (y >= num_classes)
+    n = len(ptr) - 1
+    cl_void = np.zeros(n, bool)
+    for c in range(n):
+        lo, hi = ptr[c], ptr[c + 1]
+        cl_void[c] = count[lo:hi][void[lo:hi]].sum() / np.float32(count[lo:hi].sum()) > 0.5
+    crop = np.array([count[(obj == o) & cl_void[idx]].sum() for o in obj], dtype=np.int64)
+    return cl_void, void | cl_void[idx], crop

@@ -6,7 +6,8 @@ and its neighbours need - attributes, the cluster CSR, edges - with the same
 ``select`` contract, argument names and return tuples
 (src/data/cluster.py:79-140, src/data/data.py:286-470, src/data/nag.py:306-399,
 672-711), executed by the kernels of ``csrc/select.hip`` and ``csrc/sampling.hip``.
-Not mirrored: HDF5 I/O, batching, instance labels, visualisation.
+Instance labels (``obj``: an ``instance.InstanceData``) follow selection and batching.
+Not mirrored: HDF5 writing, visualisation.
 """
 import copy
 
@@ -42,6 +43,11 @@ def _is_arange(idx, n):
 
 def _count(t):
     return int(t.item())
+
+
+def _is_instance_data(item):
+    from .instance import InstanceData                 # instance.py imports this module
+    return isinstance(item, InstanceData)
 
 
 def consecutive_cluster(src, num_labels=None, gather=None):
@@ -191,7 +197,7 @@ class Data:
         for v in self._store.values():
             if torch.is_tensor(v):
                 return v.device
-            if isinstance(v, Cluster):
+            if isinstance(v, Cluster) or _is_instance_data(v):
                 return v.device
         return torch.device("cpu")
 
@@ -290,6 +296,9 @@ class Data:
             if isinstance(item, Cluster):
                 data[key] = item.select(idx, update_sub=False)[0]
                 continue
+            if _is_instance_data(item):                               # data.py:437-439
+                data[key] = item.select(idx)
+                continue
             is_tensor = torch.is_tensor(item)
             node_sized = is_tensor and item.dim() > 0 and item.shape[0] == n
             edge_sized = is_tensor and item.dim() > 0 and item.shape[0] == n_e
@@ -303,6 +312,14 @@ class Data:
                 data[key] = copy.deepcopy(item)
         data.num_nodes = k
         return data, out_sub, out_super
+
+
+    def estimate_instance_centroid(self, mode="iou"):
+        """``(obj_pos, obj_idx)`` of the target objects from the positions of the clusters
+        overlapping them (data.py:941-974)."""
+        if "obj" not in self._store:
+            return None, None
+        return self.obj.estimate_centroid(self.pos, mode=mode)
 
 
 class NAG:
@@ -393,6 +410,8 @@ class NAG:
                         base += int(v.pointers[-1])
                     d[key] = Cluster(torch.cat(ptr),
                                      torch.cat([v.points + lo[j] for j, v in enumerate(vals)]))
+                elif _is_instance_data(vals[0]):
+                    d[key] = type(vals[0]).from_list(vals)
                 elif torch.is_tensor(vals[0]):
                     d[key] = torch.cat(vals, dim=0)
                 else:

@@ -8,7 +8,7 @@ import torch
 from . import _lib
 from .ops import _workspace
 
-__all__ = ["frnn_grid_points", "knn_1", "knn_2", "neighbors_dense_to_csr",
+__all__ = ["frnn_grid_points", "knn_1", "knn_1_graph", "knn_2", "neighbors_dense_to_csr",
            "geometric_features", "GEOF_COLUMNS", "cluster_radius_nn_graph",
            "scatter_nearest_neighbor"]
 
@@ -171,6 +171,27 @@ def knn_1(xyz, k, r_max=1, batch=None, oversample=False, self_is_neighbor=False,
     if self_is_neighbor:
         return idx, dist
     return idx[:, 1:], dist[:, 1:]
+
+
+def knn_1_graph(xyz, k, r_max=1, batch=None, oversample=False, self_is_neighbor=False,
+                trim=True):
+    """``knn_1`` as a duplicate-free edge list with the (smallest) distance of each edge;
+    ``trim``: undirected edges kept once, i < j, no loops (neighbors.py:126-183)."""
+    neighbors, distances = knn_1(xyz, k, r_max=r_max, batch=batch, oversample=oversample,
+                                 self_is_neighbor=self_is_neighbor)
+    n = xyz.shape[0]
+    source = torch.arange(n, device=xyz.device).repeat_interleave(k)
+    target = neighbors.flatten()
+    found = target != -1
+    source, target, d = source[found], target[found], distances.flatten()[found]
+    if trim:
+        lo, hi = torch.minimum(source, target), torch.maximum(source, target)
+        keep = lo != hi
+        source, target, d = lo[keep], hi[keep], d[keep]
+    key, inv = torch.unique(source * n + target, sorted=True, return_inverse=True)
+    dmin = torch.full((key.numel(),), float("inf"), dtype=d.dtype, device=d.device)
+    dmin.scatter_reduce_(0, inv, d, "amin")
+    return torch.stack([key // n, key % n]), dmin
 
 
 def knn_2(x_search, x_query, k, r_max=1, batch_search=None, batch_query=None, squared=True):

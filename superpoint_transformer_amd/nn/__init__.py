@@ -7,7 +7,8 @@ from .fusion import (AdditiveFusion, CatFusion, TakeFirstFusion, TakeSecondFusio
                      fusion_factory)
 from .mlp import FFN, MLP, Classifier
 from .norm import INDEX_BASED_NORMS, GraphNorm, UnitSphereNorm
-from .pool import MaxPool, MeanPool, MinPool, SumPool, pool_factory
+from .pool import (AttentivePool, AttentivePoolWithLearntQueries, BaseAttentivePool, MaxPool,
+                   MeanPool, MinPool, StdPool, SumPool, pool_factory)
 from .stage import DownNFuseStage, PointStage, Stage, UpNFuseStage
 from .transformer import TransformerBlock, VersionHolder
 from .unpool import IndexUnpool

@@ -14,7 +14,7 @@ from torch import nn
 from .fusion import CatFusion
 from .mlp import MLP
 from .norm import GraphNorm
-from .pool import MaxPool, pool_factory
+from .pool import BaseAttentivePool, MaxPool, pool_factory
 from .stage import DownNFuseStage, PointStage, Stage, UpNFuseStage
 from .transformer import VersionHolder
 
@@ -122,7 +122,11 @@ class SPT(nn.Module):
                                mlp_activation, mlp_norm, share_hf_mlps)
         self.h_edge_mlps = _mlps(h_edge_mlp if needs_h_edge else None, num_down + nano,
                                  mlp_activation, mlp_norm, share_hf_mlps)
-        self.v_edge_mlps = _mlps(None, num_down, mlp_activation, mlp_norm, share_hf_mlps)
+        # vertical (child -> parent) edge features only feed attentive pools (spt.py:453-483)
+        needs_v_edge = num_down > 0 and isinstance(
+            pool_factory(pool[0], down_pool_dim[0]), BaseAttentivePool)
+        self.v_edge_mlps = _mlps(v_edge_mlp if needs_v_edge else None, num_down, mlp_activation,
+                                 mlp_norm, share_hf_mlps)
         self.feature_fusion = CatFusion()
 
         common = dict(mlp_activation=mlp_activation, mlp_norm=mlp_norm, qk_dim=qk_dim,
@@ -240,13 +244,14 @@ class SPT(nn.Module):
             # one gradient buffer for all their blocks (the first block of the down stage - the
             # last one autograd reaches - hands it over)
             ea_shares[i_level] = _share_for(ea)
+            v_ea = self._v_edge_attr(i_stage, levels[i_level - 1], B)
             is_last = i_level == len(levels) - 1
             x, diameter = stage(                                            # spt.py:915-930
                 xh if self.use_node_hf else None, x, ni, _get(levels[i_level - 1], "super_index"),
                 pos=_get(lv, "pos"), node_size=_get(lv, "node_size"),
                 super_index=None if is_last else _get(lv, "super_index"),
-                edge_index=ei, edge_attr=ea, num_super=sizes[i_level], num_graphs=B,
-                num_super_parent=None if is_last else sizes[i_level + 1],
+                edge_index=ei, edge_attr=ea, v_edge_attr=v_ea, num_super=sizes[i_level],
+                num_graphs=B, num_super_parent=None if is_last else sizes[i_level + 1],
                 ea_grad=ea_shares[i_level])
             down_outputs.append(x)
 
@@ -267,6 +272,20 @@ class SPT(nn.Module):
         if self.output_stage_wise:
             return [x] + up_outputs[::-1][1:] + [down_outputs[-1]]
         return x
+
+    def _v_edge_attr(self, i_stage, child, B):
+        """The children's vertical edge features for the pool of down stage ``i_stage``, through
+        their MLP when there is one (spt.py:836-841, 929).  The reference reads the features
+        from the PARENT level there while normalising with the children's index - shapes that
+        only agree by accident; the children's own ``v_edge_attr`` (what
+        ``_on_the_fly_vertical_edge_features`` writes, transforms/graph.py:1411-1414, and what
+        spt.py:929 hands to the stage when there is no MLP) is used here."""
+        v_ea = _get(child, "v_edge_attr")
+        mlp = self.v_edge_mlps[i_stage]
+        if mlp is None or v_ea is None:
+            return v_ea
+        ni = _get(child, "batch")
+        return mlp(v_ea, batch=None if (ni is None or B == 1) else ni, batch_size=B)
 
     def _forward_nano(self, nag, B):
         """spt.py:760-879 with ``nano=True``: ``nag[1]`` is the first level the model sees
@@ -310,6 +329,7 @@ class SPT(nn.Module):
                 node_size=_get(lv, "node_size"),
                 super_index=None if is_last else _get(lv, "super_index"),
                 edge_index=_get(lv, "edge_index"), edge_attr=edge_attrs[i_level],
+                v_edge_attr=self._v_edge_attr(i_stage, levels[i_level - 1], B),
                 num_super=sizes[i_level], num_graphs=B,
                 num_super_parent=None if is_last else sizes[i_level + 1])
             down_outputs.append(x)

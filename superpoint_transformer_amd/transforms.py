@@ -9,7 +9,7 @@ from . import _lib
 
 __all__ = ["horizontal_edge_features", "EDGE_FEATURE_COLUMNS", "NodeSize", "SampleSubNodes",
            "SampleSegments", "SampleEdges", "OnTheFlyHorizontalEdgeFeatures",
-           "SampleRadiusSubgraphs"]
+           "SampleRadiusSubgraphs", "OnTheFlyInstanceGraph", "segment_sampling_weights"]
 
 EDGE_FEATURE_COLUMNS = [
     "mean_off_x", "mean_off_y", "mean_off_z", "std_off_x", "std_off_y", "std_off_z",
@@ -110,12 +110,31 @@ class SampleSubNodes:
         return nag.select(self.low, idx)
 
 
+def segment_sampling_weights(nag, i_level, by_size=False, by_class=False):
+    """Probability of drawing each level-``i_level`` segment (sampling.py:771-798 and
+    895-921, the same lines twice): uniform, plus - ``by_size`` - the cube root of the number
+    of points it holds, plus - ``by_class`` - the rarity of the rarest class it contains
+    (``y`` = per-segment label histogram), each term normalised to sum 1 before it is added."""
+    data = nag[i_level]
+    w = torch.ones(data.num_nodes, device=nag.device)
+    if by_size:
+        sw = nag.get_sub_size(i_level, low=0) ** 0.333
+        w = w + sw / sw.sum()
+    if by_class and "y" in data:
+        scores = 1 / (data.y.sum(dim=0).sqrt() + 1)
+        scores = scores / scores.sum()
+        cw = (data.y.gt(0) * scores.view(1, -1)).max(dim=1).values
+        w = w + (cw / cw.sum()).squeeze()
+    return w / w.sum()
+
+
 class SampleSegments:
     """Drop a ``ratio`` of the segments of every level >= 1, from the top level down
-    (src/transforms/sampling.py:718-807; ``by_class`` is not mirrored)."""
+    (src/transforms/sampling.py:718-807)."""
 
-    def __init__(self, ratio=0.2, by_size=False):
-        self.ratio, self.by_size = ratio, by_size
+    def __init__(self, ratio=0.2, by_size=False, by_class=False):
+        assert isinstance(ratio, list) and all(0 <= r < 1 for r in ratio) or (0 <= ratio < 1)
+        self.ratio, self.by_size, self.by_class = ratio, by_size, by_class
 
     def __call__(self, nag):
         L = nag.num_levels
@@ -125,11 +144,8 @@ class SampleSegments:
                 continue
             n = nag[i].num_nodes
             keep = n - int(n * ratio[i - 1])
-            w = torch.ones(n, device=nag.device)
-            if self.by_size:
-                sw = nag.get_sub_size(i, low=0).float() ** 0.333
-                w = w + sw / sw.sum()
-            idx = torch.multinomial(w / w.sum(), keep, replacement=False)
+            w = segment_sampling_weights(nag, i, self.by_size, self.by_class)
+            idx = torch.multinomial(w, keep, replacement=False)
             nag = nag.select(i, idx)
         return nag
 
@@ -182,20 +198,17 @@ class SampleRadiusSubgraphs:
     """Keep the level-``i_level`` nodes within ``r`` of ``k`` random seed nodes (at most
     the ``k_max`` nearest per seed), each neighbourhood as its own batch item when
     ``disjoint`` (src/transforms/sampling.py:810-1000, 1094-1230).  Seeds are drawn like
-    the reference (uniform ``torch.multinomial``, spread over the batch items when the
-    level carries a ``batch``; ``by_size`` / ``by_class`` are not mirrored); ``idx_seed``
-    overrides the draw."""
+    the reference (``torch.multinomial`` over ``segment_sampling_weights``, spread over the
+    batch items when the level carries a ``batch``); ``idx_seed`` overrides the draw."""
 
     def __init__(self, r=2, k_max=10000, i_level=1, k=1, use_batch=True, disjoint=False,
-                 cylindrical=False, idx_seed=None):
+                 cylindrical=False, idx_seed=None, by_size=False, by_class=False):
         self.r, self.k_max, self.i_level, self.k = r, k_max, i_level, k
         self.use_batch, self.disjoint, self.cylindrical, self.idx_seed = \
             use_batch, disjoint, cylindrical, idx_seed
+        self.by_size, self.by_class = by_size, by_class
 
-    def _seeds(self, data, k):
-        n = data.num_nodes
-        dev = data.device
-        w = torch.ones(n, device=dev)
+    def _seeds(self, data, k, w):
         batch = data.batch if "batch" in data else None
         if batch is None or not self.use_batch:
             return torch.multinomial(w, k, replacement=False)
@@ -245,8 +258,73 @@ class SampleRadiusSubgraphs:
         i_level = nag.num_levels - 1 if self.i_level == -1 else self.i_level
         data = nag[i_level]
         k = self.k if self.k < data.num_nodes else 1
-        seeds = self.idx_seed if self.idx_seed is not None else self._seeds(data, k)
+        seeds = self.idx_seed if self.idx_seed is not None else self._seeds(
+            data, k, segment_sampling_weights(nag, i_level, self.by_size, self.by_class))
         balls = [self._ball(data, int(s)) for s in seeds]
         if self.disjoint:
             return NAG.from_nag_list([nag.select(i_level, idx) for idx in balls])
         return nag.select(i_level, torch.unique(torch.cat(balls)))
+
+
+class OnTheFlyInstanceGraph:
+    """Targets of the panoptic heads, built every batch (src/transforms/instance.py:18-257):
+    the trimmed graph between the level-``level`` segments (``obj_edge_index``: the existing
+    edges, or segments with points / centroids within ``radius``), the affinity of each edge
+    from the segments' overlaps with the annotated objects (``obj_edge_affinity``,
+    ``InstanceData.instance_graph``) and the position of each segment's target object
+    (``obj_pos``)."""
+
+    _ADJACENCY_MODES = ["available", "radius-atomic", "radius-centroid"]
+    _CENTROID_MODES = ["iou", "ratio-product"]
+
+    def __init__(self, level=1, num_classes=None, adjacency_mode="radius-atomic", k_max=30,
+                 radius=1, use_batch=True, centroid_mode="iou", centroid_level=1,
+                 smooth_affinity=True):
+        assert adjacency_mode.lower() in self._ADJACENCY_MODES, \
+            f"Expected 'mode' to be one of {self._ADJACENCY_MODES}"
+        assert centroid_mode.lower() in self._CENTROID_MODES, \
+            f"Expected 'mode' to be one of {self._CENTROID_MODES}"
+        self.level, self.num_classes = level, num_classes
+        self.adjacency_mode, self.k_max, self.radius = adjacency_mode.lower(), k_max, radius
+        self.use_batch, self.centroid_mode = use_batch, centroid_mode.lower()
+        self.centroid_level, self.smooth_affinity = centroid_level, smooth_affinity
+
+    def __call__(self, nag):
+        from .graph import to_trimmed
+        from .instance import _consecutive
+        from .neighbors import cluster_radius_nn_graph, knn_1_graph
+        if self.level is None or self.level < 0:
+            return nag
+        if not 0 <= self.level < nag.num_levels:
+            raise AssertionError(f"level {self.level} is not in the NAG")
+        data = nag[self.level]
+        batch = data.batch if (self.use_batch and "batch" in data) else None
+        if self.adjacency_mode == "available":
+            obj_edge_index = data.edge_index if data.has_edges else None
+        elif self.adjacency_mode == "radius-atomic":
+            obj_edge_index, _ = cluster_radius_nn_graph(
+                nag[0].pos, nag.get_super_index(self.level, low=0), k_max=self.k_max,
+                gap=self.radius, batch=batch)
+        else:
+            obj_edge_index, _ = knn_1_graph(data.pos, self.k_max, r_max=self.radius, batch=batch)
+        if obj_edge_index is None:
+            obj_edge_index = torch.empty(2, 0, dtype=torch.long, device=data.device)
+
+        if "obj" not in data:                               # no annotations: graph only
+            data.obj_edge_index = to_trimmed(obj_edge_index)
+            data.obj_edge_affinity = None
+            data.obj_pos = None
+            return nag
+
+        data.obj_edge_index, data.obj_edge_affinity = data.obj.instance_graph(
+            obj_edge_index, num_classes=self.num_classes, smooth_affinity=self.smooth_affinity)
+
+        # position of each segment's target object: objects' centroids estimated at
+        # ``centroid_level``, looked up through a common dense numbering of the object ids
+        i_level = min(self.centroid_level, nag.num_levels - 1)
+        obj_pos, obj_idx = nag[i_level].estimate_instance_centroid(mode=self.centroid_mode)
+        sp_obj_idx = data.obj.major(num_classes=self.num_classes)[0]
+        joint = torch.cat((sp_obj_idx, obj_idx))
+        dense = _consecutive(joint)[0]
+        data.obj_pos = obj_pos[dense[:sp_obj_idx.numel()]]
+        return nag

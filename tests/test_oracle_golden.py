@@ -198,3 +198,22 @@ def test_down_stage_composition_matches_reference():
 
 def test_up_stage_composition_matches_reference():
     _stage_mirror(load_golden("up_stage.npz"), "up")
+
+
+def test_attentive_pools_against_the_reference_modules():
+    """src/nn/pool.py:84-360 (fixture: tests/golden/make_golden_pool.py, float64)."""
+    G = load_golden("attentive_pool.npz")
+    cases = {"a": dict(H=16, D=4, spec=None, share=False),
+             "b": dict(H=4, D=8, spec="d+g", share=True),
+             "c": dict(H=8, D=2, spec=0.7, share=False)}
+    for tag, c in cases.items():
+        p = {k[len(tag) + 5:]: t64(G[k]) for k in G if k.startswith(tag + "__p__")}
+        xp, index = t64(G[f"{tag}__x_parent"]), tl(G[f"{tag}__index"])
+        if "q.weight" in p:
+            query = xp @ p["q.weight"].t() + p["q.bias"]
+        else:
+            query = p["q"].repeat(xp.shape[0], 1)
+        out = O.attentive_pool(t64(G[f"{tag}__x_child"]), query, index,
+                               t64(G[f"{tag}__edge_attr"]), p, c["H"], c["D"], xp.shape[0],
+                               c["spec"], c["share"])
+        torch.testing.assert_close(out, t64(G[f"{tag}__out"]), rtol=1e-10, atol=1e-10)
