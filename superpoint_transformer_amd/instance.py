@@ -24,11 +24,9 @@ def _consecutive(src):
     ``inv`` the dense relabelling in sorted key order and ``perm[u]`` the LAST position holding
     key u (what PyG's CPU scatter_ leaves; every call site reads properties shared by all
     holders of a key)."""
-    uniq, inv = torch.unique(src, sorted=True, return_inverse=True)
-    pos = torch.arange(src.numel(), device=src.device)
-    perm = torch.zeros(uniq.numel(), dtype=torch.int64, device=src.device)
-    perm.scatter_reduce_(0, inv, pos, "amax", include_self=False)
-    return inv, perm
+    uniq, inv, counts = torch.unique(src, sorted=True, return_inverse=True, return_counts=True)
+    order = torch.argsort(inv, stable=True)
+    return inv, order[counts.cumsum(0) - 1]
 
 
 class InstanceData:

@@ -6,6 +6,7 @@ import ctypes
 import torch
 
 from . import _lib
+from . import ops
 from .ops import _workspace
 
 __all__ = ["frnn_grid_points", "knn_1", "knn_1_graph", "knn_2", "neighbors_dense_to_csr",
@@ -189,8 +190,9 @@ def knn_1_graph(xyz, k, r_max=1, batch=None, oversample=False, self_is_neighbor=
         keep = lo != hi
         source, target, d = lo[keep], hi[keep], d[keep]
     key, inv = torch.unique(source * n + target, sorted=True, return_inverse=True)
-    dmin = torch.full((key.numel(),), float("inf"), dtype=d.dtype, device=d.device)
-    dmin.scatter_reduce_(0, inv, d, "amin")
+    if key.numel() == 0:
+        return torch.stack([key, key]), d
+    dmin = ops.segment_reduce(d, inv, key.numel(), "min")
     return torch.stack([key // n, key % n]), dmin
 
 

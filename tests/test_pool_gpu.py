@@ -74,22 +74,23 @@ def test_attentive_pool_of_a_large_level(dev):
     xp = torch.randn(n_parent, 64, generator=g).to(dev)
     ea = (torch.randn(nc, 9, generator=g) * 0.5).to(dev)
     y = pool(xc, xp, index, edge_attr=ea)
-    with torch.no_grad():
-        p = {k: v.double() for k, v in pool.state_dict().items()}
-        q = (xp.double() @ p["q.weight"].T + p["q.bias"])[index].view(nc, 16, 4)
-        kv = xc.double() @ p["kv.weight"].T + p["kv.bias"]
-        k = kv[:, :64].view(nc, 16, 4) + (ea.double() @ p["k_rpe.weight"].T + p["k_rpe.bias"]).view(nc, 16, 4)
-        cnt = torch.bincount(index, minlength=n_parent).double()
-        q = q * (4 ** -0.5) * (cnt ** -0.5)[index].view(-1, 1, 1)
+    with torch.no_grad():                                       # the same chain in f64, on the host
+        p = {k: v.double().cpu() for k, v in pool.state_dict().items()}
+        ix, xcd, ead = index.cpu(), xc.double().cpu(), ea.double().cpu()
+        q = (xp.double().cpu() @ p["q.weight"].T + p["q.bias"])[ix].view(nc, 16, 4)
+        kv = xcd @ p["kv.weight"].T + p["kv.bias"]
+        k = kv[:, :64].view(nc, 16, 4) + (ead @ p["k_rpe.weight"].T + p["k_rpe.bias"]).view(nc, 16, 4)
+        cnt = torch.bincount(ix, minlength=n_parent).double()
+        q = q * (4 ** -0.5) * (cnt ** -0.5)[ix].view(-1, 1, 1)
         c = (q * k).sum(-1)
-        mx = torch.full((n_parent, 16), -1e300, dtype=torch.float64, device=dev)
-        mx.scatter_reduce_(0, index.view(-1, 1).expand(nc, 16), c, "amax")
-        e = (c - mx[index]).exp()
-        z = torch.zeros((n_parent, 16), dtype=torch.float64, device=dev).index_add_(0, index, e)
-        a = e / (z[index] + 1e-16)
-        ref = torch.zeros((n_parent, 64), dtype=torch.float64, device=dev).index_add_(
-            0, index, (kv[:, 64:].view(nc, 16, 4) * a.unsqueeze(-1)).view(nc, 64))
-    _close(y.detach(), ref.cpu(), "out")
+        mx = torch.full((n_parent, 16), -1e300, dtype=torch.float64)
+        mx.scatter_reduce_(0, ix.view(-1, 1).expand(nc, 16), c, "amax")
+        e = (c - mx[ix]).exp()
+        z = torch.zeros((n_parent, 16), dtype=torch.float64).index_add_(0, ix, e)
+        a = e / (z[ix] + 1e-16)
+        ref = torch.zeros((n_parent, 64), dtype=torch.float64).index_add_(
+            0, ix, (kv[:, 64:].view(nc, 16, 4) * a.unsqueeze(-1)).view(nc, 64))
+    _close(y.detach(), ref, "out")
 
 
 def test_std_pool_and_factory(dev):
