@@ -522,6 +522,48 @@ def geometric_features(xyz, nn, k_min=1, add_self_as_neighbor=True):
     return f
 
 
+def geometric_features_optimal(xyz, nn, k_min=1, k_step=1, k_min_search=1,
+                               add_self_as_neighbor=True, return_margin=False):
+    """src/utils/geometry.py:248-287 (k_step >= 0): ``geometric_features`` of the first k
+    neighbours for k = k0, the multiples of k_step and k_max, keeping per point the size whose
+    eigenvalues have the lowest eigenentropy (strict comparison: the first such size on
+    ties).  ``return_margin``: also the gap between the lowest and second lowest entropy of
+    each point over its DISTINCT neighbourhoods (a partial neighbourhood repeats itself for
+    every k past its size - exact ties, resolved by the strict comparison): how safely an
+    f32 implementation picks the same size."""
+    N = nn.shape[0]
+    if add_self_as_neighbor:
+        nn = torch.cat((torch.arange(N).view(-1, 1), nn), dim=1)
+    k_max = nn.shape[1]
+    k0 = max(k_min, k_min_search)
+    best = entropy = None
+    ents, seen = [], None
+    for k in range(k0, k_max + 1):
+        if (k > k0) and (k % k_step != 0) and (k != k_max):     # geometry.py:257-258
+            continue
+        sub = nn[:, :k]
+        ptr, val, sizes = neighbors_dense_to_csr(sub)
+        idx = torch.repeat_interleave(torch.arange(N), ptr[1:] - ptr[:-1])
+        ev, _ = scatter_pca(xyz[val], idx, N)
+        e = ev / (ev.sum(dim=1).view(-1, 1) + 1e-3)              # geometry.py:268-270
+        ent = (-e * torch.log(e + 1e-3)).sum(dim=1)
+        f = geometric_features(xyz, sub, k_min, add_self_as_neighbor=False)
+        repeat = torch.zeros(N, dtype=torch.bool) if seen is None else sizes == seen
+        ents.append(torch.where(repeat, torch.full_like(ent, float("inf")), ent))
+        seen = sizes
+        if best is None:
+            best, entropy = f, ent
+            continue
+        better = ent < entropy                                    # geometry.py:282-286
+        best[better] = f[better]
+        entropy[better] = ent[better]
+    if not return_margin:
+        return best
+    top = torch.stack(ents, dim=1).sort(dim=1).values
+    margin = top[:, 1] - top[:, 0] if top.shape[1] > 1 else torch.full((N,), float("inf"))
+    return best, margin
+
+
 # --------------------------------------------------------------------------
 # on-the-fly horizontal edge features + self loops (SURVEY 8f row f1)
 # --------------------------------------------------------------------------

@@ -9,7 +9,7 @@ from . import _lib
 from . import ops
 from .ops import _workspace
 
-__all__ = ["frnn_grid_points", "knn_1", "knn_1_graph", "knn_2", "neighbors_dense_to_csr",
+__all__ = ["frnn_grid_points", "knn_1", "knn_1_graph", "oversample_partial_neighborhoods", "knn_2", "neighbors_dense_to_csr",
            "geometric_features", "GEOF_COLUMNS", "cluster_radius_nn_graph",
            "scatter_nearest_neighbor"]
 
@@ -164,14 +164,30 @@ def knn_1(xyz, k, r_max=1, batch=None, oversample=False, self_is_neighbor=False,
     """k nearest OTHER points within r_max of every point (neighbors.py:51-123):
     searches k+1 and drops the first column (the point itself).  Returns
     (neighbors [N,k] int64 with -1 padding, distances [N,k])."""
-    if oversample:
-        raise NotImplementedError("oversample_partial_neighborhoods is not on the HIP path")
     p = _batch_offset(xyz, batch, r_max)
     ks = k if self_is_neighbor else k + 1
     dist, idx = frnn_grid_points(p, p, ks, r_max, squared=squared)
-    if self_is_neighbor:
-        return idx, dist
-    return idx[:, 1:], dist[:, 1:]
+    if not self_is_neighbor:
+        idx, dist = idx[:, 1:], dist[:, 1:]
+    if oversample:
+        idx, dist = oversample_partial_neighborhoods(idx.contiguous(), dist.contiguous(), k)
+    return idx, dist
+
+
+def oversample_partial_neighborhoods(neighbors, distances, k):
+    """Fill the missing (-1) entries of every neighbourhood holding 1..k-1 neighbours with
+    uniform draws among the neighbours it does hold, distances following (neighbors.py:420-488;
+    neighbours sorted by increasing distance, so the missing ones are the last).  An empty
+    neighbourhood stays empty.  In place, like the reference."""
+    assert neighbors.dim() == distances.dim() == 2
+    found = (neighbors != -1).sum(dim=1)
+    row, col = torch.where(neighbors == -1)
+    n_valid = found[row]
+    # the reference's 0.9999 keeps rand() ~ 1 from indexing one past the valid entries
+    pick = (n_valid * torch.rand(row.numel(), device=neighbors.device) * 0.9999).floor().long()
+    neighbors[row, col] = neighbors[row, pick]
+    distances[row, col] = distances[row, pick]
+    return neighbors, distances
 
 
 def knn_1_graph(xyz, k, r_max=1, batch=None, oversample=False, self_is_neighbor=False,
@@ -279,7 +295,45 @@ def spatial_order(xyz, points_per_cell=32):
     return order[:n]
 
 
-def geometric_features(xyz, nn, k_min=1, add_self_as_neighbor=True, raw=False, order=None):
+def _geometric_features_optimal(xyz, nn, k_min, k_step, k_min_search, add_self, raw, order):
+    """geometry.py:248-287: the features of the neighbourhood size - among k0 = max(k_min,
+    k_min_search), the multiples of ``k_step`` and k_max - whose eigenvalues have the lowest
+    eigenentropy, per point (first such size on ties).  One launch of the feature kernel per
+    candidate size on the first k columns; the eigenvalues are read back from its length /
+    scattering / planarity columns (l1 = length, l3 = scattering (l1 + 1e-3),
+    l2 = l3 + planarity (l1 + 1e-3))."""
+    k_max = nn.shape[1] + int(add_self)                     # columns including the point itself
+    k0 = max(k_min, k_min_search)
+    sizes = [k for k in range(k0, k_max + 1)
+             if not ((k > k0) and (k % k_step != 0) and (k != k_max))]
+    if not sizes:
+        raise ValueError(f"no neighbourhood size to search: max(k_min, k_min_search) = {k0} "
+                         f"exceeds the {k_max} neighbours given")
+    best = entropy = None
+    for k in sizes:
+        f = geometric_features(xyz, nn[:, :k - int(add_self)], k_min=k_min,
+                               add_self_as_neighbor=add_self, raw=True, order=order)
+        l1 = f[:, 7]
+        l3 = f[:, 2] * (l1 + 1e-3)
+        l2 = l3 + f[:, 1] * (l1 + 1e-3)
+        ev = torch.stack((l3, l2, l1), dim=1) ** 2
+        e = ev / (ev.sum(dim=1, keepdim=True) + 1e-3)
+        ent = (-e * torch.log(e + 1e-3)).sum(dim=1)
+        if best is None:
+            best, entropy = f, ent
+            continue
+        better = ent < entropy
+        best = torch.where(better.view(-1, 1), f, best)
+        entropy = torch.where(better, ent, entropy)
+    if not raw:                                             # geometry.py:121, 124
+        best[:, 3] *= 2
+        flip = best[:, 6] < 0
+        best[flip, 4:7] *= -1
+    return best
+
+
+def geometric_features(xyz, nn, k_min=1, add_self_as_neighbor=True, raw=False, order=None,
+                       k_step=-1, k_min_search=25):
     """[N,11] features in pgeof's column order (``GEOF_COLUMNS``) from dense
     neighbours ``nn`` [N,k] (-1 = missing).  ``raw=False`` includes the tail of
     ``geometric_features`` (verticality * 2, normals flipped to z >= 0,
@@ -287,7 +341,11 @@ def geometric_features(xyz, nn, k_min=1, add_self_as_neighbor=True, raw=False, o
     order a preceding ``knn_1`` left on this tensor (neighbourhoods gathered by one wave then
     overlap: 11.8 vs 17.4 ms at 15 M shuffled points), else as stored; ``False`` forces "as
     stored"; a permutation (e.g. ``spatial_order(xyz)``) is used as given.  The result does
-    not depend on it."""
+    not depend on it.  ``k_step >= 0``: per point, the neighbourhood size of lowest
+    eigenentropy (``nn`` sorted by increasing distance; see ``_geometric_features_optimal``)."""
+    if k_step is not None and k_step >= 0:
+        return _geometric_features_optimal(xyz, nn, int(k_min), int(k_step), int(k_min_search),
+                                           bool(add_self_as_neighbor), raw, order)
     _lib.require_cuda(xyz, nn)
     p = xyz.detach().float().contiguous()
     nn = nn.contiguous()

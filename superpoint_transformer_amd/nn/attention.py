@@ -4,11 +4,17 @@ Same constructor, parameter names (``qkv``, ``k_rpe``, ``q_rpe``, ``v_rpe``,
 ``in_proj``, ``out_proj``) and forward signature as the reference, so its
 checkpoints load and ``TransformerBlock`` / ``Stage`` call it unchanged.  The
 dense Linears (qkv, out_proj) stay on rocBLAS through PyTorch; everything
-between them is ONE kernel launch (``ops.edge_attention``)."""
+between them is ONE kernel launch (``ops.edge_attention``).
+
+Two options no shipped configuration turns on - RPE from node-feature differences
+(``k_delta_rpe`` / ``q_delta_rpe``) and dropout on the attention weights while training - take
+the reference's op-by-op route instead, every op on the segment-CSR kernels
+(``_forward_composed``)."""
 import torch
 from torch import nn
 
 from .. import ops
+from ..csr import EdgeCSR, csr_of
 
 __all__ = ["SelfAttentionBlock"]
 
@@ -65,21 +71,20 @@ class SelfAttentionBlock(nn.Module):
             self.q_rpe = nn.Linear(in_rpe_dim, qk_rpe_dim) \
                 if q_rpe and not (k_rpe and qk_share_rpe) else None
         self.v_rpe = enc(v_rpe, v_rpe_dim)
-        if (not isinstance(k_delta_rpe, bool)) or k_delta_rpe \
-                or (not isinstance(q_delta_rpe, bool)) or q_delta_rpe:
-            raise NotImplementedError(
-                "k_delta_rpe / q_delta_rpe are not built on the HIP path (they are "
-                "off in every shipped SPT config, configs/model/semantic/_attention.yaml:22-23)")
-        self.k_delta_rpe = None
-        self.q_delta_rpe = None
+        # attention.py:138-150: encoders of x[target] - x[source]
+        if not isinstance(k_delta_rpe, bool):
+            self.k_delta_rpe = k_delta_rpe
+        else:
+            self.k_delta_rpe = nn.Linear(dim, qk_rpe_dim) if k_delta_rpe else None
+        if not isinstance(q_delta_rpe, bool):
+            self.q_delta_rpe = q_delta_rpe
+        else:
+            self.q_delta_rpe = nn.Linear(dim, qk_rpe_dim) \
+                if q_delta_rpe and not (k_delta_rpe and qk_share_rpe) else None
 
         self.in_proj = nn.Linear(in_dim, dim) if in_dim is not None else None
         self.out_proj = nn.Linear(dim, out_dim) if out_dim is not None else None
-        if attn_drop is not None and attn_drop > 0:
-            raise NotImplementedError(
-                "attention dropout is not built on the HIP path (null in every "
-                "shipped SPT config, configs/model/semantic/_down.yaml:15-17)")
-        self.attn_drop = None
+        self.attn_drop = nn.Dropout(attn_drop) if attn_drop is not None and attn_drop > 0 else None
         self.out_drop = nn.Dropout(drop) if drop is not None and drop > 0 else None
 
     def _expand(self, lin, negate=False):
@@ -102,6 +107,9 @@ class SelfAttentionBlock(nn.Module):
         stage's shared edge_attr gradient buffer (``ops.EdgeAttrGradShare``) or None."""
         if self.in_proj is not None:
             x = ops.linear(x, self.in_proj.weight, self.in_proj.bias)
+        if (self.k_delta_rpe is not None or self.q_delta_rpe is not None
+                or (self.attn_drop is not None and self.training)):
+            return self._forward_composed(x, edge_index, edge_attr)
         qkv = ops.linear(x, self.qkv.weight, self.qkv.bias)
         k_rpe = q_rpe = v_rpe = None
         if edge_attr is not None:
@@ -116,6 +124,67 @@ class SelfAttentionBlock(nn.Module):
             k_rpe=k_rpe, q_rpe=q_rpe, v_rpe=v_rpe, num_heads=self.num_heads,
             qk_dim=self.qk_dim, scale_mode=self.scale_mode, scale_a=self.scale_a,
             ea_grad=ea_grad)
+        if self.out_proj is not None:
+            x = ops.linear(x, self.out_proj.weight, self.out_proj.bias)
+        if self.out_drop is not None:
+            x = self.out_drop(x)
+        return x
+
+    def _forward_composed(self, x, edge_index, edge_attr):
+        """attention.py:197-326 op by op (``x`` already through ``in_proj``): gathers of q / k / v
+        to the edges, the RPE Linears, the per-source softmax as segment max / sum, the weighted
+        values as a segment sum.  An ``EdgeCSR`` is walked in its own (source-sorted) order."""
+        H, D, n = self.num_heads, self.qk_dim, x.shape[0]
+        if isinstance(edge_index, EdgeCSR):
+            counts = (edge_index.erowptr[1:] - edge_index.erowptr[:-1]).long()
+            s = torch.arange(n, device=x.device).repeat_interleave(counts)
+            t = edge_index.tgt_sorted.long()
+            if edge_attr is not None:
+                edge_attr = ops.gather_rows(edge_attr, edge_index.eperm.long())
+        else:
+            s, t = edge_index[0].contiguous(), edge_index[1].contiguous()
+        E = s.numel()
+        csr = csr_of(s, n)
+        qkv = ops.linear(x, self.qkv.weight, self.qkv.bias)
+        q = ops.gather_rows(qkv[:, :D * H], s).view(E, H, D)
+        k = ops.gather_rows(qkv[:, D * H:2 * D * H], t).view(E, H, D)
+        v = ops.gather_rows(qkv[:, 2 * D * H:], t).view(E, H, -1)
+        if self.scale_mode == 2:                                   # src/utils/nn.py:75-127
+            q = q * self.scale_a
+        else:
+            g = (csr.counts().float() ** -0.5)[s].view(-1, 1, 1)
+            q = q * (self.scale_a * g if self.scale_mode == 0 else self.scale_a + g)
+
+        def rpe(lin, feat):
+            r = ops.linear(feat, lin.weight, lin.bias)
+            return (r.repeat(1, H) if self.heads_share_rpe else r).view(E, H, -1)
+
+        sign = -1.0 if self.q_on_minus_rpe else 1.0
+        if edge_attr is not None:
+            if self.k_rpe is not None:
+                k = k + rpe(self.k_rpe, edge_attr)
+            if self.q_rpe is not None:
+                q = q + rpe(self.q_rpe, sign * edge_attr)
+            elif self.k_rpe is not None and self.qk_share_rpe:
+                q = q + rpe(self.k_rpe, sign * edge_attr)
+        if self.k_delta_rpe is not None or self.q_delta_rpe is not None:
+            delta = ops.gather_rows(x, t) - ops.gather_rows(x, s)     # attention.py:258, 271
+            if self.k_delta_rpe is not None:
+                k = k + rpe(self.k_delta_rpe, delta)
+            if self.q_delta_rpe is not None:
+                q = q + rpe(self.q_delta_rpe, sign * delta)
+            elif self.k_delta_rpe is not None and self.qk_share_rpe and edge_attr is not None:
+                q = q + rpe(self.k_delta_rpe, sign * delta)
+        if self.v_rpe is not None and edge_attr is not None:
+            v = v + rpe(self.v_rpe, edge_attr)
+
+        compat = (q * k).sum(dim=-1)                                   # [E, H]
+        mx = ops.segment_reduce(compat.detach(), csr, None, "max")
+        e = (compat - ops.gather_rows(mx, s)).exp()
+        attn = e / ops.gather_rows(ops.segment_reduce(e, csr, None, "sum") + 1e-16, s)
+        if self.attn_drop is not None:
+            attn = self.attn_drop(attn)
+        x = ops.segment_reduce((v * attn.unsqueeze(-1)).reshape(E, self.dim), csr, None, "sum")
         if self.out_proj is not None:
             x = ops.linear(x, self.out_proj.weight, self.out_proj.bias)
         if self.out_drop is not None:

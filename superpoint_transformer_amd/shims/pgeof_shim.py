@@ -19,6 +19,20 @@ def compute_features(xyz, nn, nn_ptr, k_min=1, verbose=False):
 
 
 def compute_features_optimal(xyz, nn, nn_ptr, k_min=1, k_step=1, k_min_search=1, verbose=False):
-    raise NotImplementedError(
-        "optimal-neighbourhood search (k_step > 0) is off in the dataset configs "
-        "(k_step=-1, configs/datamodule/semantic/default.yaml:121-127) and not built")
+    """Per point the neighbourhood size (k_min_search, then every ``k_step``, up to all of its
+    list) of lowest eigenentropy.  pgeof's C++ is not available to pin against: the search
+    follows the reference's own torch restatement of it (src/utils/geometry.py:248-287), the
+    CSR lists spread to a -1-padded [N, longest] table."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    p = torch.from_numpy(np.ascontiguousarray(xyz, dtype=np.float32)).to(dev)
+    v = torch.from_numpy(np.ascontiguousarray(nn).astype(np.int64)).to(dev)
+    ptr = torch.from_numpy(np.ascontiguousarray(nn_ptr).astype(np.int64)).to(dev)
+    n = ptr.numel() - 1
+    sizes = ptr[1:] - ptr[:-1]
+    width = int(sizes.max()) if n else 0
+    row = torch.arange(n, device=dev).repeat_interleave(sizes)
+    dense = torch.full((n, max(width, 1)), -1, dtype=torch.int64, device=dev)
+    dense[row, torch.arange(v.numel(), device=dev) - ptr[:-1][row]] = v
+    f = _nb.geometric_features(p, dense, k_min=int(k_min), add_self_as_neighbor=False, raw=True,
+                               k_step=int(k_step), k_min_search=int(k_min_search))
+    return f.cpu().numpy()

@@ -328,3 +328,86 @@ def test_shared_edge_attr_gradient_of_a_stage(mode, dev):
         xd = x.clone().requires_grad_()
         blocks[0](xd, ei, edge_attr=ea.clone().requires_grad_(), ea_grad=sh)
         blocks[1](xd, ei, edge_attr=ea.clone().requires_grad_(), ea_grad=sh)
+
+
+# ---------------------------------------------------------------------------
+# The options outside the fused kernel (delta RPE, attention dropout): the op-by-op route
+# ---------------------------------------------------------------------------
+class _FixedDrop(torch.nn.Module):
+    """``a -> a * mask / (1 - p)`` in place of nn.Dropout: the same stand-in the fixture's
+    script gave the reference's module."""
+
+    def __init__(self, mask, p):
+        super().__init__()
+        self.mask, self.p = mask, p
+
+    def forward(self, a):
+        return a * self.mask.to(a.dtype) / (1 - self.p)
+
+
+def _option_block(tag):
+    from superpoint_transformer_amd import nn as N
+    if tag == "d":
+        return N.SelfAttentionBlock(64, num_heads=16, in_dim=48, out_dim=64, qk_dim=4,
+                                    in_rpe_dim=18, k_rpe=True, q_rpe=True, v_rpe=True,
+                                    k_delta_rpe=True, q_delta_rpe=True)
+    if tag == "s":
+        return N.SelfAttentionBlock(32, num_heads=4, qk_dim=8, qk_scale="d+g", in_rpe_dim=7,
+                                    k_rpe=True, q_rpe=True, k_delta_rpe=True, q_delta_rpe=True,
+                                    qk_share_rpe=True, q_on_minus_rpe=True, heads_share_rpe=True)
+    return N.SelfAttentionBlock(64, num_heads=16, out_dim=64, qk_dim=4, in_rpe_dim=32,
+                                k_rpe=True, q_rpe=True, v_rpe=True)
+
+
+@pytest.mark.parametrize("tag", ["d", "s", "m"])
+@pytest.mark.parametrize("as_csr", [False, True])
+def test_delta_rpe_and_attention_dropout_match_the_reference(tag, as_csr, dev):
+    """src/nn/attention.py:255-290 (RPE from x[target] - x[source], shared / negated variants)
+    and :309-311 (dropout on the attention weights; fixed keep-mask) against the reference's
+    own module (tests/golden/make_golden_attention_options.py)."""
+    from superpoint_transformer_amd.csr import edge_csr_of
+    G = load_golden("attention_options.npz")
+    g = {k[3:]: v for k, v in G.items() if k.startswith(tag + "__")}
+    blk = _option_block(tag)
+    sd = {k[3:]: torch.from_numpy(v).float() for k, v in g.items() if k.startswith("p__")}
+    blk.load_state_dict(sd, strict=True)                      # the reference's parameter names
+    blk = blk.to(dev)
+    ei = tl(g["edge_index"]).to(dev)
+    if tag == "m":
+        if as_csr:
+            pytest.skip("the fixture's mask is given in edge order")
+        blk.attn_drop = _FixedDrop(torch.from_numpy(g["mask"]).to(dev), float(g["p"]))
+    x = torch.from_numpy(g["x"]).float().to(dev).requires_grad_()
+    ea = torch.from_numpy(g["edge_attr"]).float().to(dev).requires_grad_()
+    out = blk(x, edge_csr_of(ei, x.shape[0]) if as_csr else ei, edge_attr=ea)
+    (out * torch.from_numpy(g["gw"]).float().to(dev)).sum().backward()
+    _check(out, t64(g["out"]), "out")
+    _check(x.grad, t64(g["g_x"]), "g_x")
+    _check(ea.grad, t64(g["g_edge_attr"]), "g_edge_attr")
+    for k, p in blk.named_parameters():
+        _check(p.grad, t64(g["g__" + k]), "g_" + k, rel_to_max=True)
+
+
+def test_attention_dropout_is_the_fused_kernel_in_eval_and_unbiased_in_training(dev):
+    from superpoint_transformer_amd import nn as N
+    gen = torch.Generator().manual_seed(17)
+    n = 400
+    ei = _rand_graph(gen, n, 12.0).to(dev)
+    x = torch.randn(n, 64, generator=gen).to(dev)
+    ea = (torch.randn(ei.shape[1], 32, generator=gen) * 0.5).to(dev)
+    torch.manual_seed(1)
+    plain = N.SelfAttentionBlock(64, num_heads=16, qk_dim=4, in_rpe_dim=32, k_rpe=True,
+                                 q_rpe=True, v_rpe=True).to(dev)
+    drop = N.SelfAttentionBlock(64, num_heads=16, qk_dim=4, in_rpe_dim=32, k_rpe=True,
+                                q_rpe=True, v_rpe=True, attn_drop=0.25).to(dev)
+    drop.load_state_dict(plain.state_dict())
+    with torch.no_grad():
+        ref = plain(x, ei, edge_attr=ea)
+        assert torch.equal(drop.eval()(x, ei, edge_attr=ea), ref)      # same kernel, same bits
+        drop.train()
+        a, b = drop(x, ei, edge_attr=ea), drop(x, ei, edge_attr=ea)
+        assert not torch.equal(a, b)                                     # fresh masks
+        mean = torch.stack([drop(x, ei, edge_attr=ea) for _ in range(200)]).mean(0)
+    # E[dropout(a)] = a: the mean of 200 draws is within a few standard errors of the plain output
+    assert float((mean - ref).abs().max()) < 0.25 * float(ref.abs().max())
+    assert float((mean - ref).abs().mean()) < 0.03 * float(ref.abs().mean()) + 0.01

@@ -304,3 +304,70 @@ def test_scatter_pca_entry_matches_reference_fixture(dev):
     # orthonormal columns everywhere
     eye = torch.eye(3, dtype=torch.float64)
     assert ((evec.transpose(1, 2) @ evec) - eye).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_optimal_neighbourhood_features_match_the_reference(tag, dev):
+    """k_step >= 0 (geometry.py:248-287): per point the neighbourhood size of lowest
+    eigenentropy, against the reference's own ``geometric_features_torch`` (f64 fixture).
+    Points whose two best DISTINCT sizes are closer than 1e-5 in entropy may legitimately pick
+    the other one in f32 and are left out (a handful at most)."""
+    from superpoint_transformer_amd import neighbors as NB
+    g = load_golden("geometric_features_optimal.npz")
+    xyz, nn = torch.from_numpy(g["xyz"]).float(), tl(g["nn"])
+    k_min, k_step, k_search = (int(v) for v in g[f"{tag}_cfg"])
+    f = NB.geometric_features(xyz.to(dev), nn.to(dev), k_min=k_min, k_step=k_step,
+                              k_min_search=k_search).cpu().double()
+    ref = t64(g[f"{tag}_feats"])
+    _, margin = O.geometric_features_optimal(xyz.double(), nn, k_min, k_step, k_search,
+                                             return_margin=True)
+    safe = margin > 1e-5
+    assert safe.float().mean() > 0.98
+    scal = [0, 1, 2, 7, 8, 10]
+    assert (f[safe][:, scal] - ref[safe][:, scal]).abs().max().item() <= 1e-4
+    generic = safe & (((nn >= 0).sum(1) + 1) >= 4)
+    assert (f[generic][:, 9] - ref[generic][:, 9]).abs().max().item() <= 1e-4
+    vec_ok = safe & (ref[:, 0] > 1e-3) & (ref[:, 1] > 1e-3)          # distinct eigenvalues
+    assert (f[vec_ok][:, 3:7] - ref[vec_ok][:, 3:7]).abs().max().item() <= 2e-4
+    assert vec_ok.float().mean() > 0.7
+    # the pgeof-shaped entry (CSR lists holding the point itself, raw columns)
+    if tag == "a":
+        from superpoint_transformer_amd.shims import pgeof_shim
+        full = torch.cat((torch.arange(xyz.shape[0]).view(-1, 1), nn), dim=1)
+        ptr, val, _ = O.neighbors_dense_to_csr(full)
+        raw = NB.geometric_features(xyz.to(dev), nn.to(dev), k_min=k_min, k_step=k_step,
+                                    k_min_search=k_search, raw=True).cpu().numpy()
+        got = pgeof_shim.compute_features_optimal(
+            xyz.numpy(), val.numpy().astype("uint32"), ptr.numpy().astype("uint32"),
+            k_min, k_step, k_search)
+        assert (got == raw).all()
+    with pytest.raises(ValueError):
+        NB.geometric_features(xyz.to(dev), nn.to(dev), k_min=1, k_step=2, k_min_search=40)
+
+
+def test_oversampled_partial_neighbourhoods(dev):
+    """neighbors.py:420-488: every missing entry of a partial neighbourhood becomes a copy of
+    one of its found neighbours (with its distance); found entries and empty rows untouched."""
+    from superpoint_transformer_amd import neighbors as NB
+    xyz = _clouds()["mixed"].to(dev)
+    k, r = 20, 0.35
+    nb0, d0 = NB.knn_1(xyz, k, r)
+    nb, d = NB.knn_1(xyz, k, r, oversample=True)
+    found = (nb0 >= 0).sum(1)
+    partial = (found > 0) & (found < k)
+    assert int(partial.sum()) > 100 and int((found == 0).sum()) >= 0
+    keep = nb0 >= 0
+    assert torch.equal(nb[keep], nb0[keep]) and torch.equal(d[keep], d0[keep])
+    assert torch.equal(nb[found == 0], nb0[found == 0])               # stays empty
+    assert bool((nb[found > 0] >= 0).all())                           # nothing missing any more
+    rows = torch.where(partial)[0]
+    filled = ~keep[rows]
+    # each filled entry (neighbour, distance) is one of the row's found pairs
+    same = (nb[rows].unsqueeze(2) == nb0[rows].unsqueeze(1)) & \
+           (d[rows].unsqueeze(2) == d0[rows].unsqueeze(1)) & keep[rows].unsqueeze(1)
+    assert bool(same.any(dim=2)[filled].all())
+    # and the draws are spread: some row with >= 4 found neighbours and >= 8 holes uses >= 2 of them
+    rich = rows[(found[rows] >= 4) & (found[rows] <= k - 8)]
+    if rich.numel():
+        distinct = torch.tensor([nb[i][~keep[i]].unique().numel() for i in rich[:50].tolist()])
+        assert int(distinct.max()) >= 2

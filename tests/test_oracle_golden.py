@@ -217,3 +217,23 @@ def test_attentive_pools_against_the_reference_modules():
                                t64(G[f"{tag}__edge_attr"]), p, c["H"], c["D"], xp.shape[0],
                                c["spec"], c["share"])
         torch.testing.assert_close(out, t64(G[f"{tag}__out"]), rtol=1e-10, atol=1e-10)
+
+
+def test_optimal_neighbourhood_features_match_reference():
+    """geometry.py:248-338 with k_step >= 0 (fixture: make_golden_geof_optimal.py)."""
+    g = load_golden("geometric_features_optimal.npz")
+    xyz, nn = t64(g["xyz"]), tl(g["nn"])
+    for tag in "abc":
+        k_min, k_step, k_search = (int(v) for v in g[f"{tag}_cfg"])
+        f = O.geometric_features_optimal(xyz, nn, k_min, k_step, k_search)
+        ref = t64(g[f"{tag}_feats"])
+        scal = [0, 1, 2, 7, 8, 9, 10]
+        torch.testing.assert_close(f[:, scal], ref[:, scal], rtol=1e-7, atol=1e-9)
+        # normals / verticality: away from repeated eigenvalues of the CHOSEN neighbourhood
+        # (linearity or planarity at 0 = two equal eigenvalues)
+        gap = (ref[:, 0] > 1e-6) & (ref[:, 1] > 1e-6)
+        torch.testing.assert_close(f[gap][:, 3:7], ref[gap][:, 3:7], rtol=1e-6, atol=1e-8)
+        assert gap.float().mean() > 0.8
+    # the search does something: sizes other than the largest get picked
+    full = O.geometric_features(xyz, nn, 3)
+    assert ((full[:, 7] - t64(g["a_feats"])[:, 7]).abs() > 1e-6).float().mean() > 0.2
