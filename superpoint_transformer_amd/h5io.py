@@ -167,9 +167,17 @@ def _tensor(a, device):
 def load_nag(path, device="cpu", low=0, high=-1, keys=None):
     """``NAG.load`` (src/data/nag.py:434-461): levels ``low..high`` of the file.  Per level:
     dense keys as tensors, ``sub`` as :class:`Cluster` (from ``_cluster_/sub``), ``y`` densified
-    from its CSR form (io.py:205-260), ``rgb`` rescaled to [0, 1]."""
+    from its CSR form (io.py:205-260), ``rgb`` rescaled to [0, 1], instance annotations
+    (``_instance_data_/obj``) as :class:`InstanceData`."""
+    return nag_from_datasets(read_h5(path), device=device, low=low, high=high, keys=keys,
+                             source=path)
+
+
+def nag_from_datasets(flat, device="cpu", low=0, high=-1, keys=None, source="<datasets>"):
+    """The same from the ``{"level_i/...": ndarray}`` table ``read_h5`` returns."""
     from .data import NAG, Cluster, Data
-    flat = read_h5(path)
+    from .instance import InstanceData
+    path = source
     names = sorted({k.split("/")[0] for k in flat if k.startswith("level_")},
                    key=lambda s: int(s.split("_")[1]))
     if not names:
@@ -204,5 +212,12 @@ def load_nag(path, device="cpu", low=0, high=-1, keys=None):
             rows = np.repeat(np.arange(shape[0]), ptr[1:] - ptr[:-1])
             y[rows, flat[yp + "columns"].astype(np.int64)] = flat[yp + "values"].astype(np.int64)
             attrs["y"] = torch.from_numpy(y).to(device)
+        ip = pre + "_instance_data_/"                  # data.py:716-718, csr.py:456-490:
+        for name in sorted({k[len(ip):].split("/")[0] for k in flat if k.startswith(ip)}):
+            if keys is not None and name not in keys:  # pointers + value_0..2 = obj, count, y
+                continue
+            grp = ip + name + "/"
+            attrs[name] = InstanceData(*(_tensor(flat[grp + d], device) for d in
+                                         ("pointers", "value_0", "value_1", "value_2")))
         levels.append(Data(**attrs))
     return NAG(levels)

@@ -50,3 +50,30 @@ def test_load_nag_builds_the_hierarchy():
     # partial read
     part = h5io.load_nag(H5, low=1, high=2, keys=["pos", "super_index"])
     assert part.num_levels == 2 and not hasattr(part[0], "sub") and hasattr(part[1], "sub")
+
+
+def test_instance_annotations_come_back_as_instance_data():
+    """``Data.save`` writes an InstanceData under ``_instance_data_/<key>`` as pointers +
+    value_0..2 = obj, count, y in the smallest integer types (data.py:716-718,
+    csr.py:456-490); the demo file has none, so the group is added to its dataset table."""
+    from superpoint_transformer_amd import h5io
+    from superpoint_transformer_amd.instance import InstanceData
+    flat = dict(h5io.read_h5(H5))
+    n1 = 1192
+    rng = np.random.default_rng(0)
+    sizes = rng.integers(1, 4, n1)
+    ptr = np.concatenate([[0], np.cumsum(sizes)])
+    m = int(ptr[-1])
+    grp = "level_1/_instance_data_/obj/"
+    flat[grp + "pointers"] = ptr.astype(np.int16)
+    flat[grp + "is_index_value"] = np.array([True, False, False])
+    flat[grp + "value_0"] = rng.integers(0, 50, m).astype(np.uint8)
+    flat[grp + "value_1"] = rng.integers(1, 3000, m).astype(np.int16)
+    flat[grp + "value_2"] = rng.integers(0, 13, m).astype(np.uint8)
+    nag = h5io.nag_from_datasets(flat)
+    obj = nag[1].obj
+    assert isinstance(obj, InstanceData) and obj.num_clusters == n1 and obj.num_overlaps == m
+    assert obj.obj.dtype == obj.count.dtype == obj.y.dtype == obj.pointers.dtype == torch.int64
+    assert np.array_equal(obj.count.numpy(), flat[grp + "value_1"].astype(np.int64))
+    assert "obj" not in nag[0] and "obj" not in nag[2]
+    assert "obj" not in h5io.nag_from_datasets(flat, keys=["pos", "super_index"])[1]
