@@ -7,7 +7,7 @@ and its neighbours need - attributes, the cluster CSR, edges - with the same
 (src/data/cluster.py:79-140, src/data/data.py:286-470, src/data/nag.py:306-399,
 672-711), executed by the kernels of ``csrc/select.hip`` and ``csrc/sampling.hip``.
 Instance labels (``obj``: an ``instance.InstanceData``) follow selection and batching.
-Not mirrored: HDF5 writing, visualisation.
+HDF5 reading / writing lives in ``h5io``.  Not mirrored: visualisation.
 """
 import copy
 

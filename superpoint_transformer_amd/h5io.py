@@ -1,4 +1,4 @@
-"""Reader of the reference's on-disk NAG format (HDF5) without h5py.
+"""Reader and writer of the reference's on-disk NAG format (HDF5) without h5py.
 
 Layout (``NAG.save`` src/data/nag.py:401-432 -> ``Data.save`` src/data/data.py:663-733,
 ``CSRData.save`` src/data/csr.py, ``save_dense_to_csr`` src/utils/io.py:180-202):
@@ -69,6 +69,27 @@ def _lib():
         "H5Tget_size": (ctypes.c_size_t, [_HID]),
         "H5Tget_sign": (ctypes.c_int, [_HID]),
         "H5Tclose": (ctypes.c_int, [_HID]),
+        "H5Tis_variable_str": (ctypes.c_int, [_HID]),
+        "H5Tcopy": (_HID, [_HID]),
+        "H5Tset_size": (ctypes.c_int, [_HID, ctypes.c_size_t]),
+        "H5Tset_cset": (ctypes.c_int, [_HID, ctypes.c_int]),
+        "H5Tset_fields": (ctypes.c_int, [_HID] + [ctypes.c_size_t] * 5),
+        "H5Tset_ebias": (ctypes.c_int, [_HID, ctypes.c_size_t]),
+        "H5Dvlen_reclaim": (ctypes.c_int, [_HID, _HID, _HID, ctypes.c_void_p]),
+        "H5Fcreate": (_HID, [ctypes.c_char_p, ctypes.c_uint, _HID, _HID]),
+        "H5Gcreate2": (_HID, [_HID, ctypes.c_char_p, _HID, _HID, _HID]),
+        "H5Lexists": (ctypes.c_int, [_HID, ctypes.c_char_p, _HID]),
+        "H5Screate": (_HID, [ctypes.c_int]),
+        "H5Screate_simple": (_HID, [ctypes.c_int, ctypes.POINTER(ctypes.c_uint64),
+                                    ctypes.POINTER(ctypes.c_uint64)]),
+        "H5Dcreate2": (_HID, [_HID, ctypes.c_char_p, _HID, _HID, _HID, _HID, _HID]),
+        "H5Dwrite": (ctypes.c_int, [_HID, _HID, _HID, _HID, _HID, ctypes.c_void_p]),
+        "H5Acreate2": (_HID, [_HID, ctypes.c_char_p, _HID, _HID, _HID, _HID]),
+        "H5Awrite": (ctypes.c_int, [_HID, _HID, ctypes.c_void_p]),
+        "H5Aopen": (_HID, [_HID, ctypes.c_char_p, _HID]),
+        "H5Aexists": (ctypes.c_int, [_HID, ctypes.c_char_p]),
+        "H5Aread": (ctypes.c_int, [_HID, _HID, ctypes.c_void_p]),
+        "H5Aclose": (ctypes.c_int, [_HID]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -80,14 +101,14 @@ def _lib():
 
 
 _H5G_GROUP, _H5G_DATASET = 0, 1
-_H5T_INTEGER, _H5T_FLOAT = 0, 1
+_H5T_INTEGER, _H5T_FLOAT, _H5T_STRING = 0, 1, 3
 
 
 def _native(lib, name):
     return _HID.in_dll(lib, name).value
 
 
-def _read_dataset(lib, loc, name):
+def _read_dataset(lib, loc, name, strings=False):
     d = lib.H5Dopen2(loc, name.encode(), 0)
     if d < 0:
         raise OSError(f"cannot open dataset {name}")
@@ -108,6 +129,16 @@ def _read_dataset(lib, loc, name):
             elif cls == _H5T_INTEGER:
                 np_dt = np.dtype(f"{'i' if sign else 'u'}{size}")
                 mem = f"H5T_NATIVE_{'' if sign else 'U'}INT{8 * size}_g"
+            elif cls == _H5T_STRING and strings and lib.H5Tis_variable_str(tp) > 0 and nd == 1:
+                # variable-length strings (h5py writes a list of str this way: data.py:732)
+                ptrs = (ctypes.c_char_p * max(shape[0], 1))()
+                if shape[0]:
+                    if lib.H5Dread(d, tp, 0, 0, 0, ctypes.cast(ptrs, ctypes.c_void_p)) < 0:
+                        raise OSError(f"H5Dread failed on {name}")
+                out = np.array([ptrs[i].decode("utf-8") for i in range(shape[0])], dtype=object)
+                if shape[0]:
+                    lib.H5Dvlen_reclaim(tp, sp, 0, ctypes.cast(ptrs, ctypes.c_void_p))
+                return out
             else:
                 return None                           # strings / compounds: metadata, skipped
             out = np.empty(shape, dtype=np_dt)
@@ -123,7 +154,7 @@ def _read_dataset(lib, loc, name):
         lib.H5Dclose(d)
 
 
-def _walk(lib, loc, prefix, out):
+def _walk(lib, loc, prefix, out, strings=False):
     n = ctypes.c_uint64()
     lib.H5Gget_num_objs(loc, ctypes.byref(n))
     buf = ctypes.create_string_buffer(1024)
@@ -134,27 +165,49 @@ def _walk(lib, loc, prefix, out):
         if kind == _H5G_GROUP:
             g = lib.H5Gopen2(loc, name.encode(), 0)
             try:
-                _walk(lib, g, prefix + name + "/", out)
+                _walk(lib, g, prefix + name + "/", out, strings)
             finally:
                 lib.H5Gclose(g)
         elif kind == _H5G_DATASET:
-            a = _read_dataset(lib, loc, name)
+            a = _read_dataset(lib, loc, name, strings)
             if a is not None:
                 out[prefix + name] = a
 
 
-def read_h5(path):
-    """Every numeric dataset of the file as ``{'group/sub/name': ndarray}``."""
+def read_h5(path, strings=False):
+    """Every numeric dataset of the file as ``{'group/sub/name': ndarray}``; ``strings``: also
+    the 1-D variable-length string datasets (object arrays of str)."""
     lib = _lib()
     f = lib.H5Fopen(os.fsencode(path), 0, 0)          # H5F_ACC_RDONLY, H5P_DEFAULT
     if f < 0:
         raise OSError(f"cannot open {path} as HDF5")
     out = {}
     try:
-        _walk(lib, f, "", out)
+        _walk(lib, f, "", out, strings)
     finally:
         lib.H5Fclose(f)
     return out
+
+
+def read_root_attr(path, name):
+    """An integer attribute of the root group (``start_i_level``, nag.py:427), or None."""
+    lib = _lib()
+    f = lib.H5Fopen(os.fsencode(path), 0, 0)
+    if f < 0:
+        raise OSError(f"cannot open {path} as HDF5")
+    try:
+        if lib.H5Aexists(f, name.encode()) <= 0:
+            return None
+        a = lib.H5Aopen(f, name.encode(), 0)
+        try:
+            v = ctypes.c_int64()
+            if lib.H5Aread(a, _native(lib, "H5T_NATIVE_INT64_g"), ctypes.byref(v)) < 0:
+                raise OSError(f"H5Aread failed on {name}")
+            return int(v.value)
+        finally:
+            lib.H5Aclose(a)
+    finally:
+        lib.H5Fclose(f)
 
 
 def _tensor(a, device):
@@ -221,3 +274,204 @@ def nag_from_datasets(flat, device="cpu", low=0, high=-1, keys=None, source="<da
                                          ("pointers", "value_0", "value_1", "value_2")))
         levels.append(Data(**attrs))
     return NAG(levels)
+
+
+# ---------------------------------------------------------------------------------------------
+# Writing: NAG.save (src/data/nag.py:401-432) -> Data.save (src/data/data.py:663-733),
+# CSRData.save (src/data/csr.py:456-490), save_tensor / save_dense_to_csr (src/utils/io.py:47-202)
+# ---------------------------------------------------------------------------------------------
+_FILE_TYPES = {"uint8": "H5T_STD_U8LE_g", "int8": "H5T_STD_I8LE_g", "int16": "H5T_STD_I16LE_g",
+               "int32": "H5T_STD_I32LE_g", "int64": "H5T_STD_I64LE_g", "float32": "H5T_IEEE_F32LE_g",
+               "float64": "H5T_IEEE_F64LE_g"}
+
+
+def _half_type(lib):
+    """IEEE binary16 the way h5py declares it: a copy of F32LE with 1 + 5 + 10 bit fields."""
+    t = lib.H5Tcopy(_native(lib, "H5T_IEEE_F32LE_g"))
+    lib.H5Tset_fields(t, 15, 10, 5, 0, 10)
+    lib.H5Tset_size(t, 2)
+    lib.H5Tset_ebias(t, 15)
+    return t
+
+
+def _ensure_group(lib, f, path, opened):
+    """Create the groups along ``a/b/c`` (once) and return the handle of the last one."""
+    loc, sofar = f, ""
+    for part in path.split("/"):
+        sofar = part if not sofar else sofar + "/" + part
+        if sofar not in opened:
+            g = lib.H5Gcreate2(loc, part.encode(), 0, 0, 0)
+            if g < 0:
+                raise OSError(f"cannot create group {sofar}")
+            opened[sofar] = g
+        loc = opened[sofar]
+    return loc
+
+
+def _write_dataset(lib, loc, name, a):
+    if isinstance(a, (list, tuple)) or (isinstance(a, np.ndarray) and a.dtype == object):
+        items = [str(x) for x in a]
+        if not items:                                  # h5py turns [] into an empty f64 dataset
+            a = np.zeros(0, dtype=np.float64)
+        else:
+            tp = lib.H5Tcopy(_native(lib, "H5T_C_S1_g"))
+            lib.H5Tset_size(tp, ctypes.c_size_t(-1).value)          # H5T_VARIABLE
+            lib.H5Tset_cset(tp, 1)                                  # H5T_CSET_UTF8
+            dims = (ctypes.c_uint64 * 1)(len(items))
+            sp = lib.H5Screate_simple(1, dims, None)
+            d = lib.H5Dcreate2(loc, name.encode(), tp, sp, 0, 0, 0)
+            try:
+                if d < 0:
+                    raise OSError(f"cannot create dataset {name}")
+                ptrs = (ctypes.c_char_p * len(items))(*[x.encode("utf-8") for x in items])
+                if lib.H5Dwrite(d, tp, 0, 0, 0, ctypes.cast(ptrs, ctypes.c_void_p)) < 0:
+                    raise OSError(f"H5Dwrite failed on {name}")
+            finally:
+                if d >= 0:
+                    lib.H5Dclose(d)
+                lib.H5Sclose(sp)
+                lib.H5Tclose(tp)
+            return
+    a = np.asarray(a)
+    if not a.flags.c_contiguous:                       # (ascontiguousarray would make 0-d 1-d)
+        a = a.copy(order="C")
+    if a.dtype == np.bool_:
+        a = a.astype(np.uint8)
+    own = None
+    if a.dtype == np.float16:
+        own = tp = _half_type(lib)
+    elif a.dtype.name in _FILE_TYPES:
+        tp = _native(lib, _FILE_TYPES[a.dtype.name])
+    else:
+        raise TypeError(f"{name}: dtype {a.dtype} has no HDF5 mapping here")
+    dims = (ctypes.c_uint64 * max(a.ndim, 1))(*a.shape)
+    sp = lib.H5Screate_simple(a.ndim, dims, None) if a.ndim else lib.H5Screate(0)
+    d = lib.H5Dcreate2(loc, name.encode(), tp, sp, 0, 0, 0)
+    try:
+        if d < 0:
+            raise OSError(f"cannot create dataset {name}")
+        if a.size and lib.H5Dwrite(d, tp, 0, 0, 0, a.ctypes.data_as(ctypes.c_void_p)) < 0:
+            raise OSError(f"H5Dwrite failed on {name}")
+    finally:
+        if d >= 0:
+            lib.H5Dclose(d)
+        lib.H5Sclose(sp)
+        if own is not None:
+            lib.H5Tclose(own)
+
+
+def write_h5(path, datasets, root_attrs=None):
+    """``{'group/sub/name': ndarray | list of str}`` -> an HDF5 file (little-endian standard
+    types, contiguous layout - what h5py's ``create_dataset(data=...)`` produces); ``root_attrs``:
+    integer attributes of the root group."""
+    lib = _lib()
+    f = lib.H5Fcreate(os.fsencode(path), 2, 0, 0)      # H5F_ACC_TRUNC
+    if f < 0:
+        raise OSError(f"cannot create {path}")
+    opened = {}
+    try:
+        for name, val in (root_attrs or {}).items():
+            sp = lib.H5Screate(0)                      # scalar
+            a = lib.H5Acreate2(f, name.encode(), _native(lib, "H5T_STD_I64LE_g"), sp, 0, 0)
+            v = ctypes.c_int64(int(val))
+            lib.H5Awrite(a, _native(lib, "H5T_NATIVE_INT64_g"), ctypes.byref(v))
+            lib.H5Aclose(a)
+            lib.H5Sclose(sp)
+        for key, a in datasets.items():
+            grp, _, name = key.rpartition("/")
+            loc = _ensure_group(lib, f, grp, opened) if grp else f
+            _write_dataset(lib, loc, name, a)
+    finally:
+        for g in reversed(list(opened.values())):
+            lib.H5Gclose(g)
+        lib.H5Fclose(f)
+
+
+def _optimal_int(t):
+    """cast_to_optimal_integer_type (src/utils/tensor.py:223-241): the first of uint8, int16,
+    int32, int64 that holds every value; empty -> uint8."""
+    a = t.detach().cpu().numpy()
+    if a.dtype == np.bool_:
+        return a.astype(np.uint8)
+    if a.size == 0:
+        return a.astype(np.uint8)
+    lo, hi = int(a.min()), int(a.max())
+    for dt in (np.uint8, np.int16, np.int32, np.int64):
+        info = np.iinfo(dt)
+        if info.min <= lo and hi <= info.max:
+            return a.astype(dt)
+    raise ValueError(f"Could not cast dtype={a.dtype} to integer.")
+
+
+def _np_dtype(torch_dtype):
+    return {torch.float16: np.float16, torch.float32: np.float32, torch.float64: np.float64,
+            torch.half: np.float16, torch.float: np.float32, torch.double: np.float64}[torch_dtype]
+
+
+def _numpyfy(t, fp_dtype):
+    """cast_numpyfy (src/utils/tensor.py:268-285)."""
+    if not t.is_floating_point():
+        return _optimal_int(t)
+    return t.detach().cpu().numpy().astype(_np_dtype(fp_dtype))
+
+
+def nag_to_datasets(nag, y_to_csr=True, pos_dtype=torch.float, fp_dtype=torch.float,
+                    rgb_to_byte=True, start_i_level=0):
+    """The dataset table ``NAG.save`` writes (nag.py:401-432, data.py:663-733)."""
+    from .data import Cluster
+    from .instance import InstanceData
+    out = {}
+    for i in range(nag.num_levels):
+        data = nag[i]
+        pre = f"level_{i + start_i_level}/"
+        n = data.num_nodes
+        n_e = data.num_edges
+        not_indexable = []
+        for k, val in data:
+            if k == "pos_offset":
+                out[pre + k] = _numpyfy(val, torch.double)
+            elif k == "pos":
+                out[pre + k] = _numpyfy(val, pos_dtype)
+            elif k == "y" and val.dim() > 1 and y_to_csr:                    # io.py:180-202
+                rows, cols = val.nonzero(as_tuple=True)
+                ptr = torch.cat([torch.zeros(1, dtype=torch.long, device=val.device),
+                                 torch.bincount(rows, minlength=val.shape[0]).cumsum(0)])
+                g = pre + "_csr_/y/"
+                out[g + "pointers"] = _numpyfy(ptr, fp_dtype)
+                out[g + "columns"] = _numpyfy(cols, fp_dtype)
+                out[g + "values"] = _numpyfy(val[rows, cols], fp_dtype)
+                out[g + "shape"] = np.array(val.shape)
+            elif k in ("rgb", "mean_rgb") and rgb_to_byte:
+                v = (val * 255).byte() if val.is_floating_point() else val.byte()
+                out[pre + k] = v.cpu().numpy()
+            elif isinstance(val, Cluster):
+                g = pre + f"_cluster_/{k}/"
+                out[g + "pointers"] = _numpyfy(val.pointers, fp_dtype)
+                out[g + "is_index_value"] = np.array([1], dtype=np.uint8)   # cluster.py: [True]
+                out[g + "value_0"] = _numpyfy(val.points, fp_dtype)
+            elif isinstance(val, InstanceData):
+                g = pre + f"_instance_data_/{k}/"
+                out[g + "pointers"] = _numpyfy(val.pointers, fp_dtype)
+                out[g + "is_index_value"] = np.array([1, 0, 0], dtype=np.uint8)
+                for j, v in enumerate(val.values):
+                    out[g + f"value_{j}"] = _numpyfy(v, fp_dtype)
+            elif torch.is_tensor(val):
+                out[pre + k] = _numpyfy(val, fp_dtype)
+            else:
+                raise NotImplementedError(
+                    f"Cannot save attribute {k} with unsupported type {type(val)}")
+            node_sized = torch.is_tensor(val) and val.dim() > 0 and val.shape[0] == n
+            if not node_sized or ("edge" in k and not k.startswith("v_edge") and n_e == n):
+                not_indexable.append(k)                                      # data.py:730-732
+        out[pre + "_not_indexable_"] = not_indexable
+    return out
+
+
+def save_nag(nag, path, y_to_csr=True, pos_dtype=torch.float, fp_dtype=torch.float,
+             rgb_to_byte=True, start_i_level=0):
+    """``NAG.save`` (src/data/nag.py:401-432): one ``level_<i>`` group per level, tensors in the
+    smallest integer type that holds them / ``fp_dtype`` (``pos`` in ``pos_dtype``), label
+    histograms CSR-compressed, colours as bytes, ``sub`` / ``obj`` as CSR groups, the names of the
+    non-node attributes, and the root attribute ``start_i_level``."""
+    write_h5(path, nag_to_datasets(nag, y_to_csr, pos_dtype, fp_dtype, rgb_to_byte, start_i_level),
+             root_attrs={"start_i_level": start_i_level})

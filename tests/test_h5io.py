@@ -77,3 +77,76 @@ def test_instance_annotations_come_back_as_instance_data():
     assert np.array_equal(obj.count.numpy(), flat[grp + "value_1"].astype(np.int64))
     assert "obj" not in nag[0] and "obj" not in nag[2]
     assert "obj" not in h5io.nag_from_datasets(flat, keys=["pos", "super_index"])[1]
+
+
+def test_write_h5_round_trips_every_dataset_of_the_demo_file(tmp_path):
+    from superpoint_transformer_amd import h5io
+    ref = h5io.read_h5(H5, strings=True)
+    out = str(tmp_path / "copy.h5")
+    h5io.write_h5(out, ref, root_attrs={"start_i_level": 0})
+    got = h5io.read_h5(out, strings=True)
+    assert list(got) == list(ref) or set(got) == set(ref)
+    for k, a in ref.items():
+        b = got[k]
+        assert a.dtype == b.dtype and a.shape == b.shape, k
+        assert (list(a) == list(b)) if a.dtype == object else np.array_equal(a, b), k
+    assert h5io.read_root_attr(out, "start_i_level") == 0
+    # half floats (fp_dtype=torch.half is the datasets' default for features) and scalars
+    h = {"g/half": np.linspace(-3, 3, 77, dtype=np.float16).reshape(7, 11),
+         "g/sub/scalar": np.array(5, dtype=np.int32), "empty": np.zeros((0, 3), np.float32),
+         "names": ["a", "bc"], "none": []}
+    h5io.write_h5(out, h)
+    back = h5io.read_h5(out, strings=True)
+    assert np.array_equal(back["g/half"], h["g/half"].astype(np.float32))
+    assert back["g/sub/scalar"].shape == () and int(back["g/sub/scalar"]) == 5
+    assert back["empty"].shape == (0, 3) and list(back["names"]) == ["a", "bc"]
+    assert back["none"].dtype == np.float64 and back["none"].shape == (0,)
+
+
+def test_saving_the_loaded_demo_nag_reproduces_the_reference_file(tmp_path):
+    """``load_nag`` then ``save_nag`` must write what the reference's own ``NAG.save`` wrote:
+    same dataset names, the same (smallest) integer types, byte colours, CSR label histograms,
+    cluster groups, non-indexable names (a set in the reference: compared as sets)."""
+    from superpoint_transformer_amd import h5io
+    ref = h5io.read_h5(H5, strings=True)
+    out = str(tmp_path / "resaved.h5")
+    h5io.save_nag(h5io.load_nag(H5), out)
+    got = h5io.read_h5(out, strings=True)
+    assert set(got) == set(ref)
+    for k, a in ref.items():
+        b = got[k]
+        if k.endswith("_not_indexable_"):
+            assert a.dtype == b.dtype and set(a) == set(b), k
+            continue
+        assert a.dtype == b.dtype and a.shape == b.shape, (k, a.dtype, b.dtype)
+        if k.endswith("/rgb"):
+            assert np.abs(a.astype(int) - b.astype(int)).max() <= 1, k       # x/255*255 in f32
+        else:
+            assert np.array_equal(a, b), k
+    assert h5io.read_root_attr(out, "start_i_level") == h5io.read_root_attr(H5, "start_i_level")
+    again = h5io.load_nag(out)
+    first = h5io.load_nag(H5)
+    assert again.num_points == first.num_points
+    assert torch.equal(again[1].sub.points, first[1].sub.points)
+
+
+def test_instance_annotations_are_saved_like_the_reference_saves_them(tmp_path):
+    from superpoint_transformer_amd import h5io
+    from superpoint_transformer_amd.data import NAG, Data
+    from superpoint_transformer_amd.instance import InstanceData
+    ptr = torch.tensor([0, 2, 3, 6])
+    obj = InstanceData(ptr, torch.tensor([7, 300, 7, 1, 2, 70000]), torch.tensor([5, 1, 9, 2, 2, 2]),
+                       torch.tensor([0, 3, 0, 1, 1, -1]))
+    nag = NAG([Data(pos=torch.rand(3, 3), obj=obj, rgb=torch.rand(3, 3))])
+    out = str(tmp_path / "inst.h5")
+    h5io.save_nag(nag, out, fp_dtype=torch.half)
+    flat = h5io.read_h5(out, strings=True)
+    g = "level_0/_instance_data_/obj/"
+    assert flat[g + "pointers"].dtype == np.uint8 and flat[g + "value_0"].dtype == np.int32
+    assert flat[g + "value_1"].dtype == np.uint8 and flat[g + "value_2"].dtype == np.int16
+    assert list(flat[g + "is_index_value"]) == [1, 0, 0]
+    assert flat["level_0/pos"].dtype == np.float32 and flat["level_0/rgb"].dtype == np.uint8
+    assert list(flat["level_0/_not_indexable_"]) == ["obj"]
+    back = h5io.load_nag(out)[0].obj
+    for a, b in zip(back.values + [back.pointers], obj.values + [obj.pointers]):
+        assert torch.equal(a, b)
