@@ -29,7 +29,9 @@ def install(force=False):
     }
     tg = _module("torch_geometric", __path__=[])
     tgu = _module("torch_geometric.utils", softmax=pyg_shim.softmax, degree=pyg_shim.degree,
-                  scatter=pyg_shim.scatter, coalesce=pyg_shim.coalesce)
+                  scatter=pyg_shim.scatter, coalesce=pyg_shim.coalesce,
+                  remove_self_loops=pyg_shim.remove_self_loops,
+                  add_self_loops=pyg_shim.add_self_loops, to_undirected=pyg_shim.to_undirected)
     tgn = _module("torch_geometric.nn", __path__=[])
     aggr = _module("torch_geometric.nn.aggr", SumAggregation=pyg_shim.SumAggregation,
                    MeanAggregation=pyg_shim.MeanAggregation,

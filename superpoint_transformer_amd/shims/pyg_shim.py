@@ -110,3 +110,44 @@ def coalesce(edge_index, edge_attr=_MISSING, num_nodes=None, reduce="sum", **unu
         return ei, None
     red = "sum" if reduce in ("add", "sum") else reduce
     return ei, scatter_shim.scatter(edge_attr, inv, 0, None, uniq.numel(), red)
+
+
+def remove_self_loops(edge_index, edge_attr=None):
+    """torch_geometric.utils.remove_self_loops (src/utils/graph.py:8-10, 497): always a pair."""
+    keep = edge_index[0] != edge_index[1]
+    return edge_index[:, keep], None if edge_attr is None else edge_attr[keep]
+
+
+def add_self_loops(edge_index, edge_attr=None, fill_value=None, num_nodes=None):
+    """torch_geometric.utils.add_self_loops (src/transforms/graph.py:7, 1445-1449): one (i, i)
+    edge per node appended; their attributes are ``fill_value`` (a number or a row; 1 when
+    omitted) or, for a reduction name, that reduction of each node's incoming edge attributes."""
+    n = int(num_nodes) if num_nodes is not None else (int(edge_index.max()) + 1 if edge_index.numel() else 0)
+    loops = torch.arange(n, device=edge_index.device, dtype=edge_index.dtype).repeat(2, 1)
+    if edge_attr is not None:
+        shape = (n,) + tuple(edge_attr.shape[1:])
+        if fill_value is None:
+            fill = edge_attr.new_full(shape, 1.0)
+        elif isinstance(fill_value, (int, float)):
+            fill = edge_attr.new_full(shape, fill_value)
+        elif torch.is_tensor(fill_value):
+            fill = fill_value.to(edge_attr.device, edge_attr.dtype)
+            fill = fill.expand(shape).contiguous() if fill.dim() != edge_attr.dim() or fill.shape[0] != n \
+                else fill
+        elif isinstance(fill_value, str):
+            fill = scatter_shim.scatter(edge_attr, edge_index[1], 0, None, n, fill_value)
+        else:
+            raise AttributeError("No valid 'fill_value' provided")
+        edge_attr = torch.cat([edge_attr, fill], dim=0)
+    return torch.cat([edge_index, loops], dim=1), edge_attr
+
+
+def to_undirected(edge_index, edge_attr=_MISSING, num_nodes=None, reduce="add"):
+    """torch_geometric.utils.to_undirected (src/transforms/sampling.py:5): both directions of
+    every edge, duplicates merged with ``reduce``."""
+    missing = isinstance(edge_attr, str) and edge_attr == _MISSING
+    ei = torch.cat([edge_index, edge_index.flip(0)], dim=1)
+    if missing or edge_attr is None:
+        out = coalesce(ei, None, num_nodes, reduce)[0]
+        return out if missing else (out, None)
+    return coalesce(ei, torch.cat([edge_attr, edge_attr], dim=0), num_nodes, reduce)

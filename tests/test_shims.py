@@ -55,7 +55,7 @@ def test_reference_hot_path_modules_import_unchanged_on_the_shims():
         sys.modules.setdefault("git", types.ModuleType("git"))
         U = sys.modules["src.utils"]
         for sub in ("dict", "parameter", "version", "nn", "tensor", "sparse", "edge",
-                    "scatter", "neighbors", "geometry"):
+                    "scatter", "neighbors", "geometry", "graph"):
             m = importlib.import_module(f"src.utils.{sub}")
             for k in getattr(m, "__all__", []):
                 setattr(U, k, getattr(m, k))
@@ -75,6 +75,24 @@ def test_reference_hot_path_modules_import_unchanged_on_the_shims():
         assert {k: tuple(v.shape) for k, v in blk.state_dict().items()} == \
                {k: tuple(v.shape) for k, v in mine.state_dict().items()}
         assert N.MaxPool.__mro__[2].__module__.endswith("pyg_shim")
+        # same for the option / pool mirrors added in round 2
+        kw = dict(num_heads=4, qk_dim=8, in_rpe_dim=7, k_rpe=True, q_rpe=True, k_delta_rpe=True,
+                  q_delta_rpe=True)
+        for theirs, own in ((N.SelfAttentionBlock(32, **kw), ours.SelfAttentionBlock(32, **kw)),
+                            (N.SelfAttentionBlock(32, qk_share_rpe=True, **kw),
+                             ours.SelfAttentionBlock(32, qk_share_rpe=True, **kw))):
+            assert {k: tuple(v.shape) for k, v in theirs.state_dict().items()} == \
+                   {k: tuple(v.shape) for k, v in own.state_dict().items()}
+        P = sys.modules["src.nn.pool"]
+        pk = dict(dim=64, num_heads=16, in_dim=40, out_dim=96, qk_dim=4, in_rpe_dim=9, k_rpe=True,
+                  q_rpe=True)
+        for theirs, own in ((P.AttentivePool(q_in_dim=48, **pk), ours.AttentivePool(q_in_dim=48, **pk)),
+                            (P.AttentivePoolWithLearntQueries(**pk),
+                             ours.AttentivePoolWithLearntQueries(**pk))):
+            assert {k: tuple(v.shape) for k, v in theirs.state_dict().items()} == \
+                   {k: tuple(v.shape) for k, v in own.state_dict().items()}
+        assert isinstance(P.pool_factory("std"), P.StdPool) and isinstance(
+            ours.pool_factory("std"), ours.StdPool)
     finally:
         for k in [k for k in sys.modules if k == "src" or k.startswith("src.")]:
             del sys.modules[k]
@@ -126,3 +144,24 @@ def test_frnn_and_pgeof_shims(dev):
     # raw pgeof layout: undo geometric_features' tail on the oracle side
     assert np.abs(f[:, [0, 1, 2, 7, 8, 9, 10]] - ref[:, [0, 1, 2, 7, 8, 9, 10]].numpy()).max() <= 1e-4
     assert np.abs(f[:, 3] * 2 - ref[:, 3].numpy()).max() <= 2e-3
+
+
+def test_edge_list_helpers_follow_pyg():
+    """remove_self_loops / add_self_loops / to_undirected of torch_geometric.utils (imported by
+    src/utils/graph.py:8-10, src/transforms/graph.py:7, src/transforms/sampling.py:5): index
+    plumbing, checked on the host."""
+    from superpoint_transformer_amd.shims import pyg_shim as S
+    ei = torch.tensor([[0, 1, 2, 2, 3], [1, 1, 0, 2, 0]])
+    ea = torch.arange(10.0).view(5, 2)
+    e2, a2 = S.remove_self_loops(ei, ea)
+    assert e2.tolist() == [[0, 2, 3], [1, 0, 0]] and a2.tolist() == ea[[0, 2, 4]].tolist()
+    assert S.remove_self_loops(ei)[1] is None
+    e3, a3 = S.add_self_loops(ei, ea, fill_value=0.5, num_nodes=5)
+    assert e3[:, 5:].tolist() == [[0, 1, 2, 3, 4]] * 2 and e3[:, :5].tolist() == ei.tolist()
+    assert a3.shape == (10, 2) and bool((a3[5:] == 0.5).all()) and a3[:5].tolist() == ea.tolist()
+    e4, a4 = S.add_self_loops(ei)
+    assert e4.shape == (2, 9) and a4 is None                      # 4 nodes inferred
+    und = S.to_undirected(torch.tensor([[0, 1, 3], [1, 0, 2]]))
+    assert und.tolist() == [[0, 1, 2, 3], [1, 0, 3, 2]]           # sorted, duplicates merged
+    und2, none = S.to_undirected(torch.tensor([[0], [4]]), None)
+    assert und2.tolist() == [[0, 4], [4, 0]] and none is None
