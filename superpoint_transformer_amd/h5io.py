@@ -360,10 +360,10 @@ def _write_dataset(lib, loc, name, a):
             lib.H5Tclose(own)
 
 
-def write_h5(path, datasets, root_attrs=None):
+def write_h5(path, datasets, root_attrs=None, groups=()):
     """``{'group/sub/name': ndarray | list of str}`` -> an HDF5 file (little-endian standard
     types, contiguous layout - what h5py's ``create_dataset(data=...)`` produces); ``root_attrs``:
-    integer attributes of the root group."""
+    integer attributes of the root group; ``groups``: groups to create even if they stay empty."""
     lib = _lib()
     f = lib.H5Fcreate(os.fsencode(path), 2, 0, 0)      # H5F_ACC_TRUNC
     if f < 0:
@@ -377,6 +377,8 @@ def write_h5(path, datasets, root_attrs=None):
             lib.H5Awrite(a, _native(lib, "H5T_NATIVE_INT64_g"), ctypes.byref(v))
             lib.H5Aclose(a)
             lib.H5Sclose(sp)
+        for grp in groups:
+            _ensure_group(lib, f, grp.strip("/"), opened)
         for key, a in datasets.items():
             grp, _, name = key.rpartition("/")
             loc = _ensure_group(lib, f, grp, opened) if grp else f

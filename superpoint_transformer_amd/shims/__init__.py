@@ -20,8 +20,10 @@ def _module(name, **attrs):
     return m
 
 
-def install(force=False):
-    """Register the shims in ``sys.modules`` under the reference's import names."""
+def install(force=False, with_h5py=False):
+    """Register the shims in ``sys.modules`` under the reference's import names.
+    ``with_h5py``: also ``h5py`` (the subset the reference's I/O uses, on libhdf5 through
+    ctypes) - opt-in, for boxes without h5py."""
     table = {
         "torch_scatter": scatter_shim,
         "pgeof": pgeof_shim,
@@ -53,6 +55,9 @@ def install(force=False):
         "torch_geometric.nn.inits": inits, "torch_geometric.nn.pool": pool,
         "torch_geometric.nn.pool.consecutive": cons,
     })
+    if with_h5py:
+        from . import h5py_shim
+        table["h5py"] = h5py_shim
     for name, mod in table.items():
         if force or name not in sys.modules:
             sys.modules[name] = mod

@@ -150,3 +150,114 @@ def test_instance_annotations_are_saved_like_the_reference_saves_them(tmp_path):
     back = h5io.load_nag(out)[0].obj
     for a, b in zip(back.values + [back.pointers], obj.values + [obj.pointers]):
         assert torch.equal(a, b)
+
+
+def _reference_io_on_the_h5py_shim():
+    """src/utils/io.py, src/data/csr.py, cluster.py, instance.py imported verbatim with ``h5py``
+    = the shim over libhdf5 (h5py itself is not installed in this image)."""
+    import importlib
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import make_golden_select as mgs
+    from superpoint_transformer_amd.shims import h5py_shim
+    U, csr, cluster = mgs.load_reference()               # installs an inert h5py stand-in ...
+    sys.modules["h5py"] = h5py_shim                      # ... replaced by the working one
+    io = importlib.reload(importlib.import_module("src.utils.io"))
+    for name in ("save_tensor", "load_tensor", "save_dense_to_csr", "load_csr_to_dense"):
+        setattr(U, name, getattr(io, name))
+    csr = importlib.reload(csr)
+    cluster = importlib.reload(cluster)
+    from oracle import spt_oracle as O
+    graph_mod = sys.modules.get("src.utils.graph")
+    if graph_mod is None:
+        sys.modules["torch_geometric.utils"].coalesce = O.coalesce
+        sys.modules["torch_geometric.utils"].remove_self_loops = O.remove_self_loops
+        edge = importlib.import_module("src.utils.edge")
+        U.edge_wise_points = edge.edge_wise_points
+        sys.modules["src.utils.scatter"].edge_wise_points = edge.edge_wise_points
+        graph_mod = importlib.import_module("src.utils.graph")
+    U.to_trimmed = graph_mod.to_trimmed
+    inst = importlib.reload(importlib.import_module("src.data.instance"))
+    return h5py_shim, io, csr, cluster, inst
+
+
+@pytest.fixture
+def clean_modules():
+    """The golden-script hooks register stand-ins under the reference's import names
+    (torch_scatter, torch_geometric, src.*): leave ``sys.modules`` as it was found."""
+    import sys
+    before = dict(sys.modules)
+    path = list(sys.path)
+    yield
+    for k in list(sys.modules):
+        if k not in before:
+            del sys.modules[k]
+    for k, v in before.items():
+        sys.modules[k] = v
+    sys.path[:] = path
+
+
+def test_reference_readers_and_writers_run_on_the_h5py_shim(tmp_path, clean_modules):
+    """The reference's own load_tensor / load_csr_to_dense / Cluster.load read the demo file
+    through the shim and agree with ``load_nag``; its own save_tensor / save_dense_to_csr /
+    CSRData.save / InstanceData.save write through the shim exactly what ``save_nag`` writes."""
+    from superpoint_transformer_amd import h5io
+    from superpoint_transformer_amd.data import NAG, Cluster, Data
+    from superpoint_transformer_amd.instance import InstanceData
+    h5py, io, csr, cluster, inst = _reference_io_on_the_h5py_shim()
+    mine = h5io.load_nag(H5)
+    with h5py.File(H5, "r") as f:
+        assert f.attrs["start_i_level"] == 0 and "level_3" in f and "level_4" not in f
+        assert sorted(f.keys()) == ["level_0", "level_1", "level_2", "level_3"]
+        g = f["level_1"]
+        assert isinstance(g, h5py.Group) and isinstance(g["pos"], h5py.Dataset)
+        assert [s.decode("utf-8") for s in g["_not_indexable_"]] == ["sub", "edge_attr", "edge_index"]
+        pos = io.load_tensor(g, key="pos")
+        assert torch.equal(pos, mine[1].pos)
+        si = io.load_tensor(f["level_0"]["super_index"], non_fp_to_long=True)
+        assert torch.equal(si, mine[0].super_index)
+        rows = torch.tensor([5, 0, 77])
+        assert torch.equal(io.load_tensor(g["pos"], idx=rows), mine[1].pos[rows])
+        y = io.load_csr_to_dense(g["_csr_"]["y"], non_fp_to_long=True)
+        assert torch.equal(y, mine[1].y)
+        sub, _ = cluster.Cluster.load(g["_cluster_"]["sub"], non_fp_to_long=True)
+        assert torch.equal(sub.pointers, mine[1].sub.pointers)
+        assert torch.equal(sub.points, mine[1].sub.points)
+
+    # writing: the reference's code through the shim vs save_nag, same content
+    gen = torch.Generator().manual_seed(0)
+    n = 300
+    hist = torch.randint(0, 400, (n, 14), generator=gen) * (torch.rand(n, 14, generator=gen) < 0.2)
+    hist[:, 3] = hist[:, 3].clamp(min=1)         # the reference's dense_to_csr needs no empty row
+    si = torch.randint(0, 70000, (n,), generator=gen)
+    feat = torch.randn(n, 4, generator=gen)
+    ptr = torch.cat([torch.zeros(1, dtype=torch.long),
+                     torch.randint(1, 4, (n,), generator=gen).cumsum(0)])
+    m = int(ptr[-1])
+    obj = (torch.randint(0, 90000, (m,), generator=gen), torch.randint(1, 200, (m,), generator=gen),
+           torch.randint(-1, 13, (m,), generator=gen))
+    pts = torch.randperm(m, generator=gen)
+    ref_path, my_path = str(tmp_path / "ref.h5"), str(tmp_path / "mine.h5")
+    with h5py.File(ref_path, "w") as f:
+        f.attrs["start_i_level"] = 0
+        g = f.create_group("level_0")
+        io.save_tensor(feat, g, "x", fp_dtype=torch.half)
+        io.save_tensor(feat[:, :3].double() * 1000, g, "pos", fp_dtype=torch.float)
+        io.save_tensor(si, g, "super_index", fp_dtype=torch.half)
+        io.save_dense_to_csr(hist, f.create_group(f"{g.name}/_csr_/y"), fp_dtype=torch.half)
+        cluster.Cluster(ptr, pts).save(f.create_group(f"{g.name}/_cluster_/sub"), fp_dtype=torch.half)
+        inst.InstanceData(ptr, *obj).save(f.create_group(f"{g.name}/_instance_data_/obj"),
+                                          fp_dtype=torch.half)
+        g["_not_indexable_"] = ["sub", "obj"]
+    data = Data(x=feat, pos=feat[:, :3].double() * 1000, super_index=si, y=hist,
+                sub=Cluster(ptr, pts), obj=InstanceData(ptr, *obj))
+    h5io.save_nag(NAG([data]), my_path, fp_dtype=torch.half)
+    a, b = h5io.read_h5(ref_path, strings=True), h5io.read_h5(my_path, strings=True)
+    assert set(a) == set(b)
+    for k in a:
+        assert a[k].dtype == b[k].dtype and a[k].shape == b[k].shape, (k, a[k].dtype, b[k].dtype)
+        assert (set(a[k]) == set(b[k])) if a[k].dtype == object else np.array_equal(a[k], b[k]), k
+    assert h5io.read_root_attr(ref_path, "start_i_level") == 0
+    back = inst.InstanceData.load(h5py.File(my_path, "r")["level_0/_instance_data_/obj"],
+                                  non_fp_to_long=True)
+    assert torch.equal(back.obj, obj[0]) and torch.equal(back.count, obj[1])
