@@ -261,3 +261,63 @@ def test_reference_readers_and_writers_run_on_the_h5py_shim(tmp_path, clean_modu
     back = inst.InstanceData.load(h5py.File(my_path, "r")["level_0/_instance_data_/obj"],
                                   non_fp_to_long=True)
     assert torch.equal(back.obj, obj[0]) and torch.equal(back.count, obj[1])
+
+
+def test_reference_data_load_on_the_shim_agrees_with_load_nag(clean_modules):
+    """``Data.load`` (src/data/data.py:735-935) cut out of the reference with ``ast`` -
+    unmodified - and run level by level on the demo file through the h5py shim, against
+    ``h5io.load_nag`` (integers to int64, colours to float, label histograms dense)."""
+    import ast
+    import time as _time
+    from superpoint_transformer_amd import h5io
+    h5py, io, csr, cluster, inst = _reference_io_on_the_h5py_shim()
+    import sys
+    U = sys.modules["src.utils"]
+    tree = ast.parse(open("/root/reference/src/data/data.py").read())
+    cdef = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "Data")
+    fn = next(n for n in cdef.body if isinstance(n, ast.FunctionDef) and n.name == "load")
+    fn.returns, fn.decorator_list = None, []
+    for a in fn.args.args:
+        a.annotation = None
+    color = {"torch": torch}                       # color.py imports colorhash: cut the two helpers
+    ctree = ast.parse(open("/root/reference/src/utils/color.py").read())
+    helpers = [n for n in ctree.body if isinstance(n, ast.FunctionDef)
+               and n.name in ("to_float_rgb", "to_byte_rgb")]
+    exec(compile(ast.Module(body=helpers, type_ignores=[]), "color.py", "exec"), color)
+
+    class Duck:
+        _NOT_INDEXABLE = ["_csr_", "_cluster_", "_instance_data_", "edge_index", "edge_attr",
+                          "_slice_dict", "_inc_dict", "_num_graphs"]
+
+        def __init__(self, **kw):
+            self.items = kw
+
+    ns = {"torch": torch, "np": np, "h5py": h5py, "time": _time.time, "tensor_idx": U.tensor_idx,
+          "is_arange": U.is_arange, "load_tensor": io.load_tensor,
+          "load_tensor_dict": io.load_tensor_dict, "load_csr_to_dense": io.load_csr_to_dense,
+          "Cluster": cluster.Cluster, "InstanceData": inst.InstanceData, "Data": Duck, "Batch": None,
+          "to_float_rgb": color["to_float_rgb"], "to_byte_rgb": color["to_byte_rgb"]}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "data.py", "exec"), ns)
+    mine = h5io.load_nag(H5)
+    with h5py.File(H5, "r") as f:
+        for i in range(4):
+            ref = ns["load"](Duck, f[f"level_{i}"], non_fp_to_long=True, rgb_to_float=True).items
+            got = mine[i]
+            keys = set(got.keys)
+            if i == 0:
+                assert "sub" not in ref
+            else:
+                keys |= {"sub"} if "sub" not in keys else set()
+            assert keys == set(ref), (i, keys ^ set(ref))
+            for k, v in ref.items():
+                if k == "sub":
+                    if k in got:
+                        assert torch.equal(v.pointers, got.sub.pointers)
+                        assert torch.equal(v.points, got.sub.points)
+                    continue
+                assert v.dtype == got[k].dtype and torch.equal(v, got[k]), (i, k)
+        # a subset of the keys, like NAG.load(keys=...)
+        ref = ns["load"](Duck, f["level_1"], keys=["pos", "y"], non_fp_to_long=True).items
+        sel = h5io.load_nag(H5, low=1, high=1, keys=["pos", "y"])[0]
+        assert set(ref) == set(sel.keys) == {"pos", "y"}
+        assert torch.equal(ref["y"], sel.y)
