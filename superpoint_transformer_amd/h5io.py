@@ -210,23 +210,29 @@ def read_root_attr(path, name):
         lib.H5Fclose(f)
 
 
-def _tensor(a, device):
+def _tensor(a, device, to_long=True):
     t = torch.from_numpy(np.ascontiguousarray(a))
-    if not t.is_floating_point():
+    if to_long and not t.is_floating_point():
         t = t.long()                                   # io.py load_tensor(non_fp_to_long=True)
     return t.to(device)
 
 
-def load_nag(path, device="cpu", low=0, high=-1, keys=None):
+def load_nag(path, device="cpu", low=0, high=-1, keys=None, non_fp_to_long=True,
+             rgb_to_float=True):
     """``NAG.load`` (src/data/nag.py:434-461): levels ``low..high`` of the file.  Per level:
     dense keys as tensors, ``sub`` as :class:`Cluster` (from ``_cluster_/sub``), ``y`` densified
     from its CSR form (io.py:205-260), ``rgb`` rescaled to [0, 1], instance annotations
-    (``_instance_data_/obj``) as :class:`InstanceData`."""
+    (``_instance_data_/obj``) as :class:`InstanceData`.  ``non_fp_to_long`` / ``rgb_to_float``
+    are the reference's switches of the same name (io.py:83-92, data.py:925-929) with the values
+    the device pipeline wants as defaults (the reference defaults to the compressed integer types
+    and byte colours and casts later with ``NAGCast``); index tensors of ``sub`` / ``obj`` / the
+    CSR histogram are always int64."""
     return nag_from_datasets(read_h5(path), device=device, low=low, high=high, keys=keys,
-                             source=path)
+                             source=path, non_fp_to_long=non_fp_to_long, rgb_to_float=rgb_to_float)
 
 
-def nag_from_datasets(flat, device="cpu", low=0, high=-1, keys=None, source="<datasets>"):
+def nag_from_datasets(flat, device="cpu", low=0, high=-1, keys=None, source="<datasets>",
+                      non_fp_to_long=True, rgb_to_float=True):
     """The same from the ``{"level_i/...": ndarray}`` table ``read_h5`` returns."""
     from .data import NAG, Cluster, Data
     from .instance import InstanceData
@@ -249,9 +255,14 @@ def nag_from_datasets(flat, device="cpu", low=0, high=-1, keys=None, source="<da
                 continue
             if keys is not None and rest not in keys:
                 continue
-            t = _tensor(a, device)
-            if rest in ("rgb", "mean_rgb") and a.dtype == np.uint8:
-                t = t.float() / 255                    # data.py:830-833
+            t = _tensor(a, device, non_fp_to_long)
+            if rest in ("rgb", "mean_rgb"):            # data.py:925-929, utils/color.py:17-29
+                if rgb_to_float:
+                    t = t.float()
+                    t = (t / 255 if t.numel() and float(t.max()) > 1 else t).clamp(min=0, max=1)
+                else:
+                    t = (t * 255 if t.is_floating_point() and (not t.numel() or float(t.max()) <= 1)
+                         else t).clamp(min=0, max=255).byte()
             attrs[rest] = t
         cp = pre + "_cluster_/sub/"
         if cp + "pointers" in flat and i > low:        # nag.py:452-458: `sub` of the lowest
@@ -261,9 +272,12 @@ def nag_from_datasets(flat, device="cpu", low=0, high=-1, keys=None, source="<da
         if yp + "pointers" in flat and (keys is None or "y" in keys):
             ptr = flat[yp + "pointers"].astype(np.int64)
             shape = tuple(int(v) for v in flat[yp + "shape"])
-            y = np.zeros(shape, dtype=np.int64)
+            vals = flat[yp + "values"]
+            if non_fp_to_long and vals.dtype.kind in "iub":
+                vals = vals.astype(np.int64)           # else: the stored type (sparse.py:63-90)
+            y = np.zeros(shape, dtype=vals.dtype)
             rows = np.repeat(np.arange(shape[0]), ptr[1:] - ptr[:-1])
-            y[rows, flat[yp + "columns"].astype(np.int64)] = flat[yp + "values"].astype(np.int64)
+            y[rows, flat[yp + "columns"].astype(np.int64)] = vals
             attrs["y"] = torch.from_numpy(y).to(device)
         ip = pre + "_instance_data_/"                  # data.py:716-718, csr.py:456-490:
         for name in sorted({k[len(ip):].split("/")[0] for k in flat if k.startswith(ip)}):

@@ -316,6 +316,14 @@ def test_reference_data_load_on_the_shim_agrees_with_load_nag(clean_modules):
                         assert torch.equal(v.points, got.sub.points)
                     continue
                 assert v.dtype == got[k].dtype and torch.equal(v, got[k]), (i, k)
+        # the reference's defaults: compressed integer types, byte colours
+        raw = h5io.load_nag(H5, non_fp_to_long=False, rgb_to_float=False)
+        for i in range(4):
+            ref = ns["load"](Duck, f[f"level_{i}"]).items
+            for k, v in ref.items():
+                if k != "sub":
+                    assert v.dtype == raw[i][k].dtype and torch.equal(v, raw[i][k]), (i, k, v.dtype)
+        assert raw[0].rgb.dtype == torch.uint8 and raw[0].super_index.dtype == torch.int16
         # a subset of the keys, like NAG.load(keys=...)
         ref = ns["load"](Duck, f["level_1"], keys=["pos", "y"], non_fp_to_long=True).items
         sel = h5io.load_nag(H5, low=1, high=1, keys=["pos", "y"])[0]
