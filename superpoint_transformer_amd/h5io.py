@@ -218,7 +218,7 @@ def _tensor(a, device, to_long=True):
 
 
 def load_nag(path, device="cpu", low=0, high=-1, keys=None, non_fp_to_long=True,
-             rgb_to_float=True):
+             rgb_to_float=True, keys_low=None):
     """``NAG.load`` (src/data/nag.py:434-461): levels ``low..high`` of the file.  Per level:
     dense keys as tensors, ``sub`` as :class:`Cluster` (from ``_cluster_/sub``), ``y`` densified
     from its CSR form (io.py:205-260), ``rgb`` rescaled to [0, 1], instance annotations
@@ -226,13 +226,16 @@ def load_nag(path, device="cpu", low=0, high=-1, keys=None, non_fp_to_long=True,
     are the reference's switches of the same name (io.py:83-92, data.py:925-929) with the values
     the device pipeline wants as defaults (the reference defaults to the compressed integer types
     and byte colours and casts later with ``NAGCast``); index tensors of ``sub`` / ``obj`` / the
-    CSR histogram are always int64."""
+    CSR histogram are always int64.  ``keys``: the attributes to read (``sub``, ``y``, ``obj``
+    count like any other name); ``keys_low``: the same for level ``low`` only (the datasets read
+    point features at the lowest level and segment features above: datasets/base.py:1098-1104)."""
     return nag_from_datasets(read_h5(path), device=device, low=low, high=high, keys=keys,
-                             source=path, non_fp_to_long=non_fp_to_long, rgb_to_float=rgb_to_float)
+                             source=path, non_fp_to_long=non_fp_to_long, rgb_to_float=rgb_to_float,
+                             keys_low=keys_low)
 
 
 def nag_from_datasets(flat, device="cpu", low=0, high=-1, keys=None, source="<datasets>",
-                      non_fp_to_long=True, rgb_to_float=True):
+                      non_fp_to_long=True, rgb_to_float=True, keys_low=None):
     """The same from the ``{"level_i/...": ndarray}`` table ``read_h5`` returns."""
     from .data import NAG, Cluster, Data
     from .instance import InstanceData
@@ -244,9 +247,13 @@ def nag_from_datasets(flat, device="cpu", low=0, high=-1, keys=None, source="<da
     nlev = len(names)
     high = nlev - 1 if high < 0 else min(high, nlev - 1)
     levels = []
+    if keys_low is None and keys is not None:          # nag.py:489
+        keys_low = keys
+    keys_above = keys
     for i in range(low, high + 1):
         pre = f"level_{i}/"
         attrs = {}
+        keys = keys_low if i == low else keys_above
         for k, a in flat.items():
             if not k.startswith(pre):
                 continue
@@ -265,8 +272,10 @@ def nag_from_datasets(flat, device="cpu", low=0, high=-1, keys=None, source="<da
                          else t).clamp(min=0, max=255).byte()
             attrs[rest] = t
         cp = pre + "_cluster_/sub/"
-        if cp + "pointers" in flat and i > low:        # nag.py:452-458: `sub` of the lowest
-            attrs["sub"] = Cluster(_tensor(flat[cp + "pointers"], device),    # loaded level is dropped
+        if cp + "pointers" in flat and (keys is None or "sub" in keys):
+            # kept at the lowest loaded level too: NAG.get_sub_size counts the points of a
+            # level that was not loaded through it (nag.py:73-89)
+            attrs["sub"] = Cluster(_tensor(flat[cp + "pointers"], device),
                                    _tensor(flat[cp + "value_0"], device))
         yp = pre + "_csr_/y/"
         if yp + "pointers" in flat and (keys is None or "y" in keys):

@@ -49,7 +49,10 @@ def test_load_nag_builds_the_hierarchy():
     assert nag[1].edge_index.shape == (2, 9158) and nag[1].edge_attr.shape == (9158, 7)
     # partial read
     part = h5io.load_nag(H5, low=1, high=2, keys=["pos", "super_index"])
-    assert part.num_levels == 2 and not hasattr(part[0], "sub") and hasattr(part[1], "sub")
+    assert part.num_levels == 2 and set(part[0].keys) == set(part[1].keys) == {"pos", "super_index"}
+    # `sub` is a key like any other (data.py:887-903) and stays on the lowest loaded level
+    part = h5io.load_nag(H5, low=1, high=2, keys=["pos", "sub"])
+    assert "sub" in part[0] and "sub" in part[1] and part[0].sub.num_points == 41568
 
 
 def test_instance_annotations_come_back_as_instance_data():
@@ -329,3 +332,12 @@ def test_reference_data_load_on_the_shim_agrees_with_load_nag(clean_modules):
         sel = h5io.load_nag(H5, low=1, high=1, keys=["pos", "y"])[0]
         assert set(ref) == set(sel.keys) == {"pos", "y"}
         assert torch.equal(ref["y"], sel.y)
+        # the dataset's call (datasets/base.py:1098-1104): one key set for the lowest level,
+        # another above; `sub` only where asked for - and kept at the lowest loaded level
+        low_keys, up_keys = ["pos", "sub", "super_index", "normal"], ["pos", "edge_index", "sub"]
+        part = h5io.load_nag(H5, low=1, keys_low=low_keys, keys=up_keys)
+        for i, ks in ((1, low_keys), (2, up_keys), (3, up_keys)):
+            ref = ns["load"](Duck, f[f"level_{i}"], keys=ks, non_fp_to_long=True).items
+            assert set(ref) == set(part[i - 1].keys), (i, set(ref) ^ set(part[i - 1].keys))
+            assert torch.equal(ref["sub"].points, part[i - 1].sub.points)
+            assert torch.equal(ref["pos"], part[i - 1].pos)
