@@ -154,7 +154,7 @@ def _read_dataset(lib, loc, name, strings=False):
         lib.H5Dclose(d)
 
 
-def _walk(lib, loc, prefix, out, strings=False):
+def _walk(lib, loc, prefix, out, strings=False, select=None):
     n = ctypes.c_uint64()
     lib.H5Gget_num_objs(loc, ctypes.byref(n))
     buf = ctypes.create_string_buffer(1024)
@@ -163,27 +163,32 @@ def _walk(lib, loc, prefix, out, strings=False):
         name = buf.value.decode()
         kind = lib.H5Gget_objtype_by_idx(loc, i)
         if kind == _H5G_GROUP:
+            if select is not None and not select(prefix + name + "/"):
+                continue                               # a whole group nobody asked for
             g = lib.H5Gopen2(loc, name.encode(), 0)
             try:
-                _walk(lib, g, prefix + name + "/", out, strings)
+                _walk(lib, g, prefix + name + "/", out, strings, select)
             finally:
                 lib.H5Gclose(g)
         elif kind == _H5G_DATASET:
+            if select is not None and not select(prefix + name):
+                continue
             a = _read_dataset(lib, loc, name, strings)
             if a is not None:
                 out[prefix + name] = a
 
 
-def read_h5(path, strings=False):
+def read_h5(path, strings=False, select=None):
     """Every numeric dataset of the file as ``{'group/sub/name': ndarray}``; ``strings``: also
-    the 1-D variable-length string datasets (object arrays of str)."""
+    the 1-D variable-length string datasets (object arrays of str).  ``select(name) -> bool``
+    (names of groups end with '/') skips datasets and whole groups without reading them."""
     lib = _lib()
     f = lib.H5Fopen(os.fsencode(path), 0, 0)          # H5F_ACC_RDONLY, H5P_DEFAULT
     if f < 0:
         raise OSError(f"cannot open {path} as HDF5")
     out = {}
     try:
-        _walk(lib, f, "", out, strings)
+        _walk(lib, f, "", out, strings, select)
     finally:
         lib.H5Fclose(f)
     return out
@@ -229,9 +234,27 @@ def load_nag(path, device="cpu", low=0, high=-1, keys=None, non_fp_to_long=True,
     CSR histogram are always int64.  ``keys``: the attributes to read (``sub``, ``y``, ``obj``
     count like any other name); ``keys_low``: the same for level ``low`` only (the datasets read
     point features at the lowest level and segment features above: datasets/base.py:1098-1104)."""
-    return nag_from_datasets(read_h5(path), device=device, low=low, high=high, keys=keys,
-                             source=path, non_fp_to_long=non_fp_to_long, rgb_to_float=rgb_to_float,
-                             keys_low=keys_low)
+    k_low = keys if keys_low is None and keys is not None else keys_low
+
+    def wanted(name):
+        """Only the levels and attributes asked for are read off the disk (a 15 M-point level
+        holds a dozen feature arrays; a training sample wants a few of them)."""
+        parts = name.split("/")
+        if not parts[0].startswith("level_"):
+            return True
+        lvl = int(parts[0].split("_")[1])
+        if lvl < low or (high >= 0 and lvl > high):
+            return False
+        ks = k_low if lvl == low else keys
+        if ks is None or len(parts) < 2 or parts[1] == "":
+            return True
+        if parts[1] in ("_csr_", "_cluster_", "_instance_data_"):
+            return len(parts) < 3 or parts[2] == "" or parts[2] in ks
+        return parts[1] in ks
+
+    return nag_from_datasets(read_h5(path, select=wanted), device=device, low=low, high=high,
+                             keys=keys, source=path, non_fp_to_long=non_fp_to_long,
+                             rgb_to_float=rgb_to_float, keys_low=keys_low)
 
 
 def nag_from_datasets(flat, device="cpu", low=0, high=-1, keys=None, source="<datasets>",
@@ -244,8 +267,8 @@ def nag_from_datasets(flat, device="cpu", low=0, high=-1, keys=None, source="<da
                    key=lambda s: int(s.split("_")[1]))
     if not names:
         raise ValueError(f"{path}: no /level_<i> groups (not a NAG file)")
-    nlev = len(names)
-    high = nlev - 1 if high < 0 else min(high, nlev - 1)
+    top = int(names[-1].split("_")[1])                 # absolute index of the highest level present
+    high = top if high < 0 else min(high, top)
     levels = []
     if keys_low is None and keys is not None:          # nag.py:489
         keys_low = keys

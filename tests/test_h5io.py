@@ -341,3 +341,25 @@ def test_reference_data_load_on_the_shim_agrees_with_load_nag(clean_modules):
             assert set(ref) == set(part[i - 1].keys), (i, set(ref) ^ set(part[i - 1].keys))
             assert torch.equal(ref["sub"].points, part[i - 1].sub.points)
             assert torch.equal(ref["pos"], part[i - 1].pos)
+
+
+def test_only_the_requested_levels_and_keys_are_read_off_the_disk():
+    from superpoint_transformer_amd import h5io
+    seen = []
+    real = h5io._read_dataset
+
+    def spy(lib, loc, name, strings=False):
+        seen.append(name)
+        return real(lib, loc, name, strings)
+
+    h5io._read_dataset = spy
+    try:
+        part = h5io.load_nag(H5, low=1, high=2, keys_low=["pos", "sub"], keys=["pos", "y"])
+    finally:
+        h5io._read_dataset = real
+    assert part.num_levels == 2 and set(part[0].keys) == {"pos", "sub"} and set(part[1].keys) == {"pos", "y"}
+    # level 1: pos + the two datasets of sub (+ is_index_value); level 2: pos + the four of y
+    assert sorted(seen) == sorted(["pos", "pointers", "value_0", "is_index_value",
+                                   "pos", "pointers", "columns", "values", "shape"])
+    full = h5io.load_nag(H5)
+    assert torch.equal(part[0].pos, full[1].pos) and torch.equal(part[1].y, full[2].y)
