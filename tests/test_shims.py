@@ -165,3 +165,19 @@ def test_edge_list_helpers_follow_pyg():
     assert und.tolist() == [[0, 1, 2, 3], [1, 0, 3, 2]]           # sorted, duplicates merged
     und2, none = S.to_undirected(torch.tensor([[0], [4]]), None)
     assert und2.tolist() == [[0, 4], [4, 0]] and none is None
+
+
+def test_h5py_name_is_opt_in():
+    from superpoint_transformer_amd import shims
+    had = sys.modules.pop("h5py", None)
+    try:
+        assert "h5py" not in shims.install() and "h5py" not in sys.modules
+        assert "h5py" in shims.install(with_h5py=True)
+        h5 = sys.modules["h5py"]
+        assert issubclass(h5.File, h5.Group) and hasattr(h5, "Dataset")
+        with pytest.raises(ValueError):
+            h5.File("/tmp/never-created.h5", "a")
+    finally:
+        sys.modules.pop("h5py", None)
+        if had is not None:
+            sys.modules["h5py"] = had
