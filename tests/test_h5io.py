@@ -363,3 +363,70 @@ def test_only_the_requested_levels_and_keys_are_read_off_the_disk():
                                    "pos", "pointers", "columns", "values", "shape"])
     full = h5io.load_nag(H5)
     assert torch.equal(part[0].pos, full[1].pos) and torch.equal(part[1].y, full[2].y)
+
+
+@pytest.mark.parametrize("flags", [dict(), dict(y_to_csr=False), dict(rgb_to_byte=False),
+                                   dict(pos_dtype=torch.double, fp_dtype=torch.half)])
+def test_reference_data_save_on_the_shim_writes_what_save_nag_writes(flags, tmp_path, clean_modules):
+    """``Data.save`` (src/data/data.py:663-733) cut out of the reference with ``ast`` and run on
+    a duck-typed store holding the reference's own Cluster / InstanceData objects, through the
+    h5py shim - against ``h5io.save_nag`` on the mirror objects with the same tensors, for the
+    switches of ``NAG.save``."""
+    import ast
+    from superpoint_transformer_amd import h5io
+    from superpoint_transformer_amd.data import NAG, Cluster, Data
+    from superpoint_transformer_amd.instance import InstanceData
+    h5py, io, csr, cluster, inst = _reference_io_on_the_h5py_shim()
+    tree = ast.parse(open("/root/reference/src/data/data.py").read())
+    cdef = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "Data")
+    fn = next(n for n in cdef.body if isinstance(n, ast.FunctionDef) and n.name == "save")
+    fn.returns = None
+    for a in fn.args.args:
+        a.annotation = None
+    ns = {"torch": torch, "np": np, "h5py": h5py, "save_tensor": io.save_tensor,
+          "save_dense_to_csr": io.save_dense_to_csr, "Cluster": cluster.Cluster,
+          "InstanceData": inst.InstanceData, "CSRData": csr.CSRData}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "data.py", "exec"), ns)
+
+    gen = torch.Generator().manual_seed(4)
+    n, e = 200, 700
+    ptr = torch.cat([torch.zeros(1, dtype=torch.long), torch.randint(1, 5, (n,), generator=gen).cumsum(0)])
+    m = int(ptr[-1])
+    pts = torch.randperm(m, generator=gen)
+    ov = (torch.randint(0, 500, (m,), generator=gen), torch.randint(1, 90, (m,), generator=gen),
+          torch.randint(0, 13, (m,), generator=gen))
+    hist = torch.randint(0, 70000, (n, 14), generator=gen) * (torch.rand(n, 14, generator=gen) < 0.3)
+    hist[:, 0] = hist[:, 0].clamp(min=1)
+    tensors = dict(pos=torch.randn(n, 3, generator=gen).double() * 1e4, rgb=torch.rand(n, 3, generator=gen),
+                   x=torch.randn(n, 5, generator=gen), y=hist,
+                   super_index=torch.randint(0, 40, (n,), generator=gen),
+                   edge_index=torch.randint(0, n, (2, e), generator=gen),
+                   edge_attr=torch.randn(e, 7, generator=gen),
+                   pos_offset=torch.tensor([1234567.125, 7654321.5, 12.0], dtype=torch.double))
+
+    class Duck:
+        def __init__(self, **kw):
+            self.store = kw
+
+        def items(self):
+            return self.store.items()
+
+        keys = property(lambda self: list(self.store))
+
+        def node_attrs(self):          # PyG: tensors whose first dimension is the node count
+            return [k for k, v in self.store.items()
+                    if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == n and "edge" not in k]
+
+    ref_path, my_path = str(tmp_path / "ref.h5"), str(tmp_path / "mine.h5")
+    theirs = Duck(**tensors, sub=cluster.Cluster(ptr, pts), obj=inst.InstanceData(ptr, *ov))
+    with h5py.File(ref_path, "w") as f:
+        f.attrs["start_i_level"] = 0
+        ns["save"](theirs, f.create_group("level_0"), **flags)
+    ours = Data(**tensors, sub=Cluster(ptr, pts), obj=InstanceData(ptr, *ov))
+    ours.num_nodes = n
+    h5io.save_nag(NAG([ours]), my_path, **flags)
+    a, b = h5io.read_h5(ref_path, strings=True), h5io.read_h5(my_path, strings=True)
+    assert set(a) == set(b), set(a) ^ set(b)
+    for k in a:
+        assert a[k].dtype == b[k].dtype and a[k].shape == b[k].shape, (k, a[k].dtype, b[k].dtype)
+        assert (set(a[k]) == set(b[k])) if a[k].dtype == object else np.array_equal(a[k], b[k]), k
