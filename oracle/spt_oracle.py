@@ -1123,3 +1123,25 @@ def instance_search_void(inst, num_classes):
         cl_void[c] = count[lo:hi][void[lo:hi]].sum() / np.float32(count[lo:hi].sum()) > 0.5
     crop = np.array([count[(obj == o) & cl_void[idx]].sum() for o in obj], dtype=np.int64)
     return cl_void, void | cl_void[idx], crop
+
+
+# --------------------------------------------------------------------------
+# Segment sampling weights (src/transforms/sampling.py:771-798 and 895-921)
+# --------------------------------------------------------------------------
+
+
+def segment_sampling_weights(node_size, y_hist, by_size=False, by_class=False):
+    """Uniform + (by_size) cube root of the number of points + (by_class) rarity of the rarest
+    class held, each normalised to sum 1 before it is added; f32 like the reference."""
+    n = len(node_size)
+    w = np.ones(n, np.float32)
+    if by_size:
+        sw = np.asarray(node_size, np.float32) ** np.float32(0.333)
+        w = w + sw / sw.sum()
+    if by_class and y_hist is not None:
+        h = np.asarray(y_hist)
+        sc = np.float32(1) / (np.sqrt(h.sum(0).astype(np.float32)) + np.float32(1))
+        sc = sc / sc.sum()
+        cw = ((h > 0) * sc[None]).max(1)
+        w = w + cw / cw.sum()
+    return w / w.sum()

@@ -237,22 +237,22 @@ def test_segment_sampling_weights(dev):
     hist[:, 2] = 0                                                # a class nobody holds
     nag = NAG([Data(pos=torch.randn(n0, 3, generator=g).to(dev), super_index=si.to(dev)),
                Data(pos=torch.randn(n1, 3, generator=g).to(dev), y=hist.to(dev))])
-    size = np.bincount(si.numpy(), minlength=n1).astype(np.float32)
-    h = hist.numpy()
+    size = np.bincount(si.numpy(), minlength=n1)
     for by_size in (False, True):
         for by_class in (False, True):
-            w = np.ones(n1, np.float32)
-            if by_size:
-                sw = size ** np.float32(0.333)
-                w = w + sw / sw.sum()
-            if by_class:
-                sc = 1 / (np.sqrt(h.sum(0).astype(np.float32)) + 1)
-                sc = sc / sc.sum()
-                cw = ((h > 0) * sc[None]).max(1)
-                w = w + cw / cw.sum()
-            w = w / w.sum()
+            w = O.segment_sampling_weights(size, hist.numpy(), by_size, by_class)
             got = segment_sampling_weights(nag, 1, by_size, by_class)
             np.testing.assert_allclose(got.cpu().numpy(), w, rtol=2e-6)
+    # and against the weights the reference's own SampleSegments hands to torch.multinomial
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "sampling_weights.npz"))
+    gsi, gy = torch.from_numpy(gold["super_index"]), torch.from_numpy(gold["y"])
+    gnag = NAG([Data(pos=torch.zeros(gsi.numel(), 3, device=dev), super_index=gsi.to(dev)),
+                Data(pos=torch.zeros(gy.shape[0], 3, device=dev), y=gy.to(dev))])
+    for by_size in (False, True):
+        for by_class in (False, True):
+            got = segment_sampling_weights(gnag, 1, by_size, by_class)
+            np.testing.assert_allclose(got.cpu().numpy(), gold[f"w_{int(by_size)}{int(by_class)}"],
+                                       rtol=5e-6)
     out = SampleSegments(ratio=0.25, by_size=True, by_class=True)(nag)
     assert out[1].num_nodes == n1 - int(n1 * 0.25)
     sub = SampleRadiusSubgraphs(r=1.0, k=3, i_level=1, by_size=True, by_class=True)(nag)

@@ -103,3 +103,18 @@ def test_vertical_edge_feature_kernel_matches_reference_fixture(dev):
                                    {k: v.to(dev) for k, v in p.items()})
     torch.testing.assert_close(out.cpu(), torch.from_numpy(g["v_edge_attr"]), rtol=1e-6, atol=1e-7)
     assert float(out[3, :3].abs().sum()) == 0.0          # the degenerate child: direction 0
+
+
+def test_sampling_weights_oracle_matches_the_reference():
+    """sampling.py:771-798 (fixture: the weights the reference's own SampleSegments._process
+    hands to torch.multinomial, tests/golden/make_golden_sampling_weights.py)."""
+    import numpy as np
+    from conftest import load_golden
+    from oracle import spt_oracle as O
+    g = load_golden("sampling_weights.npz")
+    size = np.bincount(g["super_index"], minlength=g["y"].shape[0])
+    for by_size in (False, True):
+        for by_class in (False, True):
+            w = O.segment_sampling_weights(size, g["y"], by_size, by_class)
+            np.testing.assert_allclose(w, g[f"w_{int(by_size)}{int(by_class)}"], rtol=1e-6)
+    assert np.abs(g["w_11"] - g["w_00"]).max() > 1e-5            # the terms do something
