@@ -118,3 +118,19 @@ def test_sampling_weights_oracle_matches_the_reference():
             w = O.segment_sampling_weights(size, g["y"], by_size, by_class)
             np.testing.assert_allclose(w, g[f"w_{int(by_size)}{int(by_class)}"], rtol=1e-6)
     assert np.abs(g["w_11"] - g["w_00"]).max() > 1e-5            # the terms do something
+
+
+def test_oversampling_reproduces_the_reference_draw_for_draw():
+    """neighbors.py:420-488: the port consumes the generator like the reference (one uniform
+    per missing entry, row-major), so under the fixture's seed the CPU result is identical to
+    what the reference's own function returned (tests/golden/make_golden_oversample.py)."""
+    from conftest import load_golden
+    from superpoint_transformer_amd.neighbors import oversample_partial_neighborhoods
+    g = load_golden("oversample.npz")
+    nb, d = torch.from_numpy(g["neighbors"]).clone(), torch.from_numpy(g["distances"]).clone()
+    torch.manual_seed(int(g["seed"]))
+    out_nb, out_d = oversample_partial_neighborhoods(nb, d, int(g["k"]))
+    assert torch.equal(out_nb, torch.from_numpy(g["out_neighbors"]))
+    assert torch.equal(out_d, torch.from_numpy(g["out_distances"]))
+    empty = (torch.from_numpy(g["neighbors"]) >= 0).sum(1) == 0
+    assert bool((out_nb[empty] == -1).all()) and bool((out_nb[~empty] >= 0).all())
