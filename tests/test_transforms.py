@@ -134,3 +134,27 @@ def test_oversampling_reproduces_the_reference_draw_for_draw():
     assert torch.equal(out_d, torch.from_numpy(g["out_distances"]))
     empty = (torch.from_numpy(g["neighbors"]) >= 0).sum(1) == 0
     assert bool((out_nb[empty] == -1).all()) and bool((out_nb[~empty] >= 0).all())
+
+
+def test_subgraph_seeds_reproduce_the_reference_draw_for_draw():
+    """sampling.py:922-948: seeds spread over the clouds of the batch (shuffled cloud order,
+    k // clouds each, the remainder to the last) or drawn from the whole level.  The port
+    consumes the generator like the reference, so under the fixture's seed the CPU draw equals
+    what the reference's own ``BaseSampleSubgraphs._process`` drew
+    (tests/golden/make_golden_seeds.py); the weights are the oracle's (pinned separately)."""
+    import numpy as np
+    from conftest import load_golden
+    from oracle import spt_oracle as O
+    from superpoint_transformer_amd.data import Data
+    from superpoint_transformer_amd.transforms import SampleRadiusSubgraphs
+    g = load_golden("subgraph_seeds.npz")
+    batch = torch.from_numpy(g["batch"])
+    size = np.bincount(g["super_index"], minlength=batch.numel())
+    for tag in "abc":
+        k, use_batch, by_size, by_class = (int(v) for v in g[f"{tag}_cfg"])
+        w = torch.from_numpy(O.segment_sampling_weights(size, g["y"], bool(by_size), bool(by_class)))
+        t = SampleRadiusSubgraphs(k=k, use_batch=bool(use_batch))
+        data = Data(pos=torch.zeros(batch.numel(), 3), batch=batch)
+        torch.manual_seed(int(g["seed"]))
+        seeds = t._seeds(data, k, w)
+        assert torch.equal(seeds, torch.from_numpy(g[f"{tag}_seeds"])), tag
