@@ -9,7 +9,8 @@ from . import _lib
 
 __all__ = ["horizontal_edge_features", "EDGE_FEATURE_COLUMNS", "NodeSize", "SampleSubNodes",
            "SampleSegments", "SampleEdges", "OnTheFlyHorizontalEdgeFeatures",
-           "SampleRadiusSubgraphs", "OnTheFlyInstanceGraph", "segment_sampling_weights"]
+           "SampleRadiusSubgraphs", "OnTheFlyInstanceGraph", "segment_sampling_weights",
+           "NAGRestrictSize"]
 
 EDGE_FEATURE_COLUMNS = [
     "mean_off_x", "mean_off_y", "mean_off_z", "std_off_x", "std_off_y", "std_off_z",
@@ -264,6 +265,61 @@ class SampleRadiusSubgraphs:
         if self.disjoint:
             return NAG.from_nag_list([nag.select(i_level, idx) for idx in balls])
         return nag.select(i_level, torch.unique(torch.cat(balls)))
+
+
+def _per_level(level, default, value, num_levels, start=0):
+    """``fill_list_with_string_indexing`` (src/utils/list.py:46-91): ``value`` on the levels
+    ``level`` names - an int, 'all', 'i+' (level i and above) or 'i-' (the levels BELOW i) - and
+    ``default`` elsewhere."""
+    out = [default] * num_levels
+    if isinstance(level, int):
+        out[level] = value
+    elif level == "all":
+        out[start:] = [value] * (num_levels - start)
+    elif level[-1] == "+":
+        i = int(level[:-1])
+        out[i:] = [value] * (num_levels - i)
+    elif level[-1] == "-":
+        i = int(level[:-1])
+        out[:i] = [value] * i
+    else:
+        raise ValueError(f"Unsupported level={level}")
+    return out
+
+
+class NAGRestrictSize:
+    """Cap the number of nodes and / or edges of the levels ``level`` by uniform random removal
+    (src/transforms/sampling.py:1346-1423; in the training pipeline after the samplers, with
+    ``level='1+'``): surplus nodes go through ``NAG.select`` (their descendants and ancestors
+    follow), surplus edges are dropped with their attributes."""
+
+    def __init__(self, level="1+", num_nodes=0, num_edges=0):
+        self.level, self.num_nodes, self.num_edges = level, num_nodes, num_edges
+
+    def __call__(self, nag):
+        L = nag.num_levels
+        nodes = _per_level(self.level, -1, self.num_nodes, L)
+        edges = _per_level(self.level, -1, self.num_edges, L)
+        for i in range(L):
+            nag = self._restrict_level(nag, i, nodes[i], edges[i])
+        return nag
+
+    @staticmethod
+    def _restrict_level(nag, i_level, num_nodes, num_edges):
+        d = nag[i_level]
+        if d.num_nodes > num_nodes and num_nodes > 0:
+            idx = torch.multinomial(torch.ones(d.num_nodes, device=nag.device), num_nodes,
+                                    replacement=False)
+            nag = nag.select(i_level, idx)
+            d = nag[i_level]
+        if d.num_edges > num_edges and num_edges > 0:
+            idx = torch.multinomial(torch.ones(d.num_edges, device=nag.device), num_edges,
+                                    replacement=False)
+            keys = [k for k in ["edge_attr"] + d.edge_keys if k in d]      # before the cut
+            d.edge_index = d.edge_index[:, idx]
+            for key in keys:
+                d[key] = d[key][idx]
+        return nag
 
 
 class OnTheFlyInstanceGraph:

@@ -168,3 +168,28 @@ def test_disjoint_radius_subgraphs_become_batch_items(dev):
     model = SPTSegmenter(**spt64_config(out[0].x.shape[1], 18)).to(dev)
     logits = model(out)
     assert logits[0].shape[0] == out.num_points[1] and torch.isfinite(logits[0]).all()
+
+
+def test_restrict_size_caps_nodes_and_edges_of_the_upper_levels(dev):
+    """NAGRestrictSize (sampling.py:1346-1423) with the training pipeline's ``level='1+'``: the
+    surplus level-1 nodes leave through ``NAG.select`` (the same draw = the same result), the
+    surplus edges are dropped with their attributes; level 0 is not capped itself."""
+    from superpoint_transformer_amd.synthetic import make_raw_nag
+    from superpoint_transformer_amd.transforms import NAGRestrictSize, NodeSize
+    nag = NodeSize(0)(make_raw_nag("R", device=dev))
+    n = nag.num_points
+    cap_n, cap_e = n[1] // 2, 3000
+    torch.manual_seed(11)
+    idx = torch.multinomial(torch.ones(n[1], device=dev), cap_n, replacement=False)
+    expect = nag.select(1, idx)
+    torch.manual_seed(11)
+    out = NAGRestrictSize(level="1+", num_nodes=cap_n, num_edges=cap_e)(nag)
+    check_hierarchy(out)
+    assert out.num_points[1] == cap_n and out.num_points[0] == expect.num_points[0] < n[0]
+    assert torch.equal(out[0].pos, expect[0].pos) and torch.equal(out[1].pos, expect[1].pos)
+    assert out.num_points[2] <= cap_n                      # level 2 was under the cap or cut to it
+    for i in (1, 2):
+        assert out[i].num_edges <= cap_e
+        assert out[i].edge_attr.shape[0] == out[i].num_edges
+    same = NAGRestrictSize(level="1+", num_nodes=10 ** 9, num_edges=10 ** 9)(out)
+    assert same.num_points == out.num_points and same[1].num_edges == out[1].num_edges

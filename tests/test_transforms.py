@@ -158,3 +158,26 @@ def test_subgraph_seeds_reproduce_the_reference_draw_for_draw():
         torch.manual_seed(int(g["seed"]))
         seeds = t._seeds(data, k, w)
         assert torch.equal(seeds, torch.from_numpy(g[f"{tag}_seeds"])), tag
+
+
+def test_restrict_size_keeps_the_edges_the_reference_keeps():
+    """sampling.py:1405-1423, edge branch, draw for draw under the fixture's seed (CPU
+    generator; tests/golden/make_golden_restrict.py) - and the level spellings of
+    src/utils/list.py:46-91."""
+    from conftest import load_golden
+    from superpoint_transformer_amd.data import NAG, Data
+    from superpoint_transformer_amd.transforms import NAGRestrictSize, _per_level
+    g = load_golden("restrict_size.npz")
+    n = int(g["num_nodes"])
+    lvl = Data(pos=torch.zeros(n, 3), edge_index=torch.from_numpy(g["in_edge_index"]),
+               edge_attr=torch.from_numpy(g["in_edge_attr"]), edge_w=torch.from_numpy(g["in_edge_w"]))
+    nag = NAG([Data(pos=torch.zeros(5, 3)), lvl])
+    torch.manual_seed(int(g["seed"]))
+    out = NAGRestrictSize(level="1+", num_nodes=0, num_edges=int(g["num_edges"]))(nag)
+    for k in ("edge_index", "edge_attr", "edge_w"):
+        assert torch.equal(out[1][k], torch.from_numpy(g["out_" + k])), k
+    assert out[1].num_edges == 700 and out[0].num_nodes == 5
+    assert _per_level("1+", -1, 9, 4) == [-1, 9, 9, 9] and _per_level("2-", -1, 9, 4) == [9, 9, -1, -1]
+    assert _per_level("all", -1, 9, 3, start=1) == [-1, 9, 9] and _per_level(2, 0, 9, 3) == [0, 0, 9]
+    with pytest.raises(ValueError):
+        _per_level("1x", 0, 1, 3)
