@@ -209,7 +209,8 @@ size_t spt_edge_attn_bwd_workspace_bytes(int H, int D, int Dv, int F);
  * spt_attn_use_mfma(mode) selects process-wide and returns the previous mode; tests
  * cross-check all three at full scene size. */
 int spt_attn_use_mfma(int mode);
-/* Backward tiling of the bf16-pipe modes (2, 3): 1 (default) = 16-edge tiles over the edge
+/* Backward tiling of the bf16-pipe modes (2, 3): 2 (default) = the edge-lane kernel described
+ * below when the caller's workspace allows it (else 1); 1 = 16-edge tiles over the edge
  * stream, at most two consecutive source nodes per pass, tiles 100 % full (dq by atomicAdd: a
  * node may be cut between two waves); 0 = one tile set per source node (62-69 % full at mean
  * degree 16).  Same results up to f32 summation order.  Returns the previous setting. */
@@ -240,6 +241,60 @@ int spt_edge_attn_bwd_acc_f32(const float* qkv, int64_t n, int H, int D, int Dv,
                               float* gedge_attr, int gedge_attr_accumulate, float* gWk,
                               float* gbk, float* gWq, float* gbq, float* gWv, float* gbv,
                               void* ws, size_t ws_bytes, spt_stream_t stream);
+
+/* Per-call formulation: the *_ex entries take a `mode` word instead of reading the process-wide
+ * switches above, so two callers (two models at different precisions, two streams) never change
+ * each other's arithmetic.  mode < 0 (SPT_ATTN_DEFAULT): the process defaults.  Otherwise
+ *   bits 0-1  precision: SPT_ATTN_VALU 0, SPT_ATTN_F32 1 (f32 matrix pipe), SPT_ATTN_SPLIT_BF16 2,
+ *             SPT_ATTN_BF16 3 (operands rounded to bf16);
+ *   bits 4-5  backward tiling of the bf16-pipe precisions: 0 auto (edge-lane when the workspace
+ *             allows), SPT_ATTN_BWD_PER_NODE, SPT_ATTN_BWD_PACKED, SPT_ATTN_BWD_EDGE_LANE.
+ * Edge-lane backward (csrc/edge_attn_el.hip; H=16, D=Dv=4, F=32): 16-edge tiles over the CSR edge
+ * stream, a wave owns half of the heads; the recompute GEMM runs transposed so that a lane holds
+ * whole heads of ONE edge (no redundant softmax math, per-edge node rows fetched by LDS-DMA, any
+ * number of source nodes per tile), dq is reduced per source node on the matrix pipe, two waves
+ * per SIMD.  dk / dv are NOT scattered with atomics (the chip retires ~320 G f32 atomic adds / s:
+ * 2.8 ms for one level-1 call): the per-edge [dk | dv] rows are streamed to the workspace in CSR
+ * order and summed per target through (tperm, trowptr) = spt_csr_build(tgt_sorted, e, n) - a CSR
+ * view of the TARGETS over the CSR positions, built once per batch and level - in a fixed order
+ * (deterministic).  It needs the scratch of spt_edge_attn_bwd_ex_workspace_bytes(n, e, ...)
+ * (per-node rows + 512 B per edge), that view, and optionally src_sorted [e] int32 =
+ * edge_index[0] in CSR order (NULL: rebuilt from erowptr).  Without the view or the workspace the
+ * packed kernel runs instead.
+ * With gedge_attr_accumulate == 0 the edge-lane kernel zero-fills gedge_attr first (both waves of
+ * a pair add their halves). */
+#define SPT_ATTN_DEFAULT (-1)
+#define SPT_ATTN_VALU 0
+#define SPT_ATTN_F32 1
+#define SPT_ATTN_SPLIT_BF16 2
+#define SPT_ATTN_BF16 3
+#define SPT_ATTN_BWD_PER_NODE (1 << 4)
+#define SPT_ATTN_BWD_PACKED (2 << 4)
+#define SPT_ATTN_BWD_EDGE_LANE (3 << 4)
+int spt_edge_attn_fwd_ex_f32(const float* qkv, int64_t n, int H, int D, int Dv,
+                             const int32_t* erowptr, const int32_t* eperm,
+                             const int32_t* tgt_sorted, int64_t e,
+                             const float* edge_attr, int F, const float* Wk,
+                             const float* bk, const float* Wq, const float* bq,
+                             const float* Wv, const float* bv, int scale_mode,
+                             float scale_a, float* out, float* m, float* z, int mode,
+                             spt_stream_t stream);
+size_t spt_edge_attn_bwd_ex_workspace_bytes(int64_t n, int64_t e, int H, int D, int Dv, int F);
+/* 1 when the edge-lane backward is built for this head layout AND the process defaults select it
+ * (a caller uses it to decide whether to build the target view). */
+int spt_edge_attn_bwd_el_supported(int H, int D, int Dv, int F);
+int spt_edge_attn_bwd_ex_f32(const float* qkv, int64_t n, int H, int D, int Dv,
+                             const int32_t* erowptr, const int32_t* eperm,
+                             const int32_t* tgt_sorted, const int32_t* src_sorted,
+                             const int32_t* tperm, const int32_t* trowptr,
+                             int64_t e, const float* edge_attr, int F, const float* Wk,
+                             const float* bk, const float* Wq, const float* bq,
+                             const float* Wv, const float* bv, int scale_mode,
+                             float scale_a, const float* out, const float* m,
+                             const float* z, const float* gout, float* gqkv,
+                             float* gedge_attr, int gedge_attr_accumulate, float* gWk,
+                             float* gbk, float* gWq, float* gbq, float* gWv, float* gbv,
+                             int mode, void* ws, size_t ws_bytes, spt_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Radius-bounded exact kNN on a uniform grid                        (a9)

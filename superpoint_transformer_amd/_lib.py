@@ -47,6 +47,13 @@ SIGNATURES = {
     "spt_edge_attn_bwd_acc_f32": (_int, [_p, _i64, _int, _int, _int, _p, _p, _p, _i64, _p, _int,
                                          _p, _p, _p, _p, _p, _p, _int, _f32, _p, _p, _p, _p,
                                          _p, _p, _int, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "spt_edge_attn_fwd_ex_f32": (_int, [_p, _i64, _int, _int, _int, _p, _p, _p, _i64, _p, _int,
+                                        _p, _p, _p, _p, _p, _p, _int, _f32, _p, _p, _p, _int, _p]),
+    "spt_edge_attn_bwd_ex_workspace_bytes": (_sz, [_i64, _i64, _int, _int, _int, _int]),
+    "spt_edge_attn_bwd_el_supported": (_int, [_int, _int, _int, _int]),
+    "spt_edge_attn_bwd_ex_f32": (_int, [_p, _i64, _int, _int, _int, _p, _p, _p, _p, _p, _p, _i64, _p, _int,
+                                        _p, _p, _p, _p, _p, _p, _int, _f32, _p, _p, _p, _p,
+                                        _p, _p, _int, _p, _p, _p, _p, _p, _p, _int, _p, _sz, _p]),
     "spt_grid_knn_workspace_bytes": (_sz, [_i64, _i64]),
     "spt_knn_use_cell_path": (_int, [_int]),
     "spt_segcsr_use_stream": (_int, [_int]),

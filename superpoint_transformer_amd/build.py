@@ -31,6 +31,7 @@ FLAGS = [
 #   (v_accvgpr_read / write), because its MFMA results feed VALU code.
 PER_FILE_FLAGS = {
     "edge_attn_mfma.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+    "edge_attn_el.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
     "fused_mlp.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
 }
 

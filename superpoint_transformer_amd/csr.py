@@ -97,11 +97,34 @@ class EdgeCSR:
     ``erowptr`` [n+1], ``eperm`` [e] (stable), ``tgt_sorted`` [e] int32 =
     edge_index[1] in CSR order."""
 
-    __slots__ = ("erowptr", "eperm", "tgt_sorted", "n", "e")
+    __slots__ = ("erowptr", "eperm", "tgt_sorted", "n", "e", "_view", "_src_sorted", "_tview")
 
-    def __init__(self, erowptr, eperm, tgt_sorted, n, e):
+    def __init__(self, erowptr, eperm, tgt_sorted, n, e, view=None):
         self.erowptr, self.eperm, self.tgt_sorted, self.n, self.e = \
             erowptr, eperm, tgt_sorted, n, e
+        self._view = view
+        self._src_sorted = None
+        self._tview = None
+
+    def target_view(self):
+        """CSR view of ``tgt_sorted`` over the CSR positions (which positions point INTO node t,
+        ascending), built on first use: the attention backward sums dk / dv per target through it
+        instead of scattering them with atomics."""
+        if self._tview is None:
+            self._tview = build_csr(self.tgt_sorted.long(), self.n)
+        return self._tview
+
+    def src_sorted(self):
+        """int32 [e]: edge_index[0] in CSR order (the source node of every CSR position), built on
+        first use - the edge-lane attention backward fetches per-edge node rows through it."""
+        if self._src_sorted is None:
+            if self._view is not None:
+                self._src_sorted = self._view.pos_seg()
+            else:
+                cnt = (self.erowptr[1:] - self.erowptr[:-1]).long()
+                self._src_sorted = torch.repeat_interleave(
+                    torch.arange(self.n, device=cnt.device, dtype=torch.int32), cnt)
+        return self._src_sorted
 
 
 def edge_csr_of(edge_index, num_nodes):
@@ -116,7 +139,7 @@ def edge_csr_of(edge_index, num_nodes):
     view = build_csr(edge_index[0], num_nodes)
     # plumbing: the targets in CSR order (one gather per batch and level)
     tgt_sorted = edge_index[1].index_select(0, view.perm.long()).to(torch.int32)
-    ecsr = EdgeCSR(view.rowptr, view.perm, tgt_sorted, int(num_nodes), edge_index.shape[1])
+    ecsr = EdgeCSR(view.rowptr, view.perm, tgt_sorted, int(num_nodes), edge_index.shape[1], view)
     if memo is None or any(k[0] != edge_index._version for k in memo):
         memo = {}
         try:

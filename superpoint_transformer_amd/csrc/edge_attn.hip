@@ -766,6 +766,16 @@ int attn_bwd_mfma_launch(const float* qkv, int64_t n, const int32_t* erowptr,
                          const float* out, const float* m, const float* z, const float* gout,
                          float* gqkv, float* gea, int gea_acc, float* partial, int split_bf16,
                          int64_t e, int packed, hipStream_t stream);
+// edge_attn_el.hip: edge-lane backward (two waves per SIMD)
+size_t attn_bwd_el_workspace_bytes(int64_t n, int64_t e);
+int attn_bwd_el_launch(const float* qkv, int64_t n, const int32_t* erowptr, const int32_t* eperm,
+                       const int32_t* tgt, const int32_t* src, const int32_t* tperm,
+                       const int32_t* trowptr, int64_t e, const float* ea,
+                       const float* Wk, const float* bk, const float* Wq, const float* bq,
+                       const float* Wv, const float* bv, int scale_mode, float scale_a,
+                       const float* out, const float* m, const float* z, const float* gout,
+                       float* gqkv, float* gea, float* partial, void* ws, int prec,
+                       hipStream_t stream);
 // 0: lane-per-output VALU kernels, 1: f32 matrix pipe (bitwise an fmaf chain), 2 (default):
 // split-bf16 on the bf16 matrix pipe (3 products per f32 product, ~10 ulp of f32), 3: plain
 // bf16 operands, f32 accumulate (the bf16 precision mode)
@@ -775,8 +785,16 @@ static int mfma_mode() {
   return g_attn_mfma;
 }
 static bool use_mfma() { return mfma_mode() != 0; }
-// backward tiles over the edge stream (1, default, bf16-pipe modes) or per node (0)
-static int g_attn_bwd_packed = 1;
+// backward of the bf16-pipe modes: 2 (default) edge-lane kernel (edge_attn_el.hip; needs the
+// larger workspace of spt_edge_attn_bwd_ex_workspace_bytes, else 1 is used), 1 packed tiles over
+// the edge stream, 0 one tile set per source node
+static int g_attn_bwd_packed = 2;
+// per-call mode word (include/spt_hip.h): < 0 = the process defaults above
+static int mode_precision(int mode) { return mode < 0 ? mfma_mode() : (mode & 3); }
+static int mode_bwd_form(int mode) {
+  const int f = mode < 0 ? 0 : ((mode >> 4) & 3);
+  return f == 0 ? g_attn_bwd_packed : f - 1;
+}
 }  // namespace spt
 
 using namespace spt;
@@ -798,7 +816,7 @@ using namespace spt;
 
 extern "C" int spt_attn_bwd_packed(int on) {
   const int prev = g_attn_bwd_packed;
-  g_attn_bwd_packed = on ? 1 : 0;
+  g_attn_bwd_packed = on < 0 ? 0 : (on > 2 ? 2 : on);
   return prev;
 }
 
@@ -816,15 +834,28 @@ extern "C" int spt_edge_attn_fwd_f32(const float* qkv, int64_t n, int H, int D, 
                                      const float* Wv, const float* bv, int scale_mode,
                                      float scale_a, float* out, float* m, float* z,
                                      spt_stream_t stream_) {
+  return spt_edge_attn_fwd_ex_f32(qkv, n, H, D, Dv, erowptr, eperm, tgt_sorted, e, edge_attr, F, Wk,
+                                  bk, Wq, bq, Wv, bv, scale_mode, scale_a, out, m, z, -1, stream_);
+}
+
+extern "C" int spt_edge_attn_fwd_ex_f32(const float* qkv, int64_t n, int H, int D, int Dv,
+                                        const int32_t* erowptr, const int32_t* eperm,
+                                        const int32_t* tgt_sorted, int64_t e,
+                                        const float* edge_attr, int F, const float* Wk,
+                                        const float* bk, const float* Wq, const float* bq,
+                                        const float* Wv, const float* bv, int scale_mode,
+                                        float scale_a, float* out, float* m, float* z, int mode,
+                                        spt_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  const int prec = mode_precision(mode);
   SPT_CHECK_ARG(n >= 0 && e >= 0 && H >= 1 && D >= 1 && Dv >= 1, "bad shape");
   if (n == 0) return 0;
   SPT_CHECK_ARG(qkv && erowptr && out && (tgt_sorted || e == 0), "null pointer");
   SPT_CHECK_ARG((m == nullptr) == (z == nullptr), "pass both m and z or neither");
-  if (use_mfma() && attn_mfma_shape_ok(H, D, Dv, F, edge_attr, Wk, Wq, Wv)) {
+  if (prec != 0 && attn_mfma_shape_ok(H, D, Dv, F, edge_attr, Wk, Wq, Wv)) {
     attn_fwd_mfma_launch(qkv, n, erowptr, eperm, tgt_sorted, edge_attr, Wk, bk, Wq, bq, Wv, bv,
                          scale_mode, scale_a, out, m, z,
-                         mfma_mode() == 2 ? 3 : (mfma_mode() == 3 ? 1 : 0), stream);
+                         prec == 2 ? 3 : (prec == 3 ? 1 : 0), stream);
     SPT_CHECK_LAUNCH();
     return 0;
   }
@@ -850,17 +881,22 @@ extern "C" int spt_edge_attn_fwd_f32(const float* qkv, int64_t n, int H, int D, 
 
 constexpr int EA_BWD_BLOCKS = 256;  // one 4-wave workgroup per CU (1 wave per SIMD)
 
-extern "C" int spt_edge_attn_bwd_acc_f32(const float*, int64_t, int, int, int, const int32_t*,
-                                         const int32_t*, const int32_t*, int64_t, const float*,
-                                         int, const float*, const float*, const float*,
-                                         const float*, const float*, const float*, int, float,
-                                         const float*, const float*, const float*, const float*,
-                                         float*, float*, int, float*, float*, float*, float*,
-                                         float*, float*, void*, size_t, spt_stream_t);
-
-extern "C" size_t spt_edge_attn_bwd_workspace_bytes(int H, int D, int Dv, int F) {
+static size_t attn_tables_bytes(int H, int D, int Dv, int F) {
   const size_t len = (size_t)(2 * H * D + H * Dv) * (F + 1);
   return align_up((size_t)EA_BWD_BLOCKS * EA_WAVES * len * 4, 256) + align_up(len * 4, 256);
+}
+
+extern "C" size_t spt_edge_attn_bwd_workspace_bytes(int H, int D, int Dv, int F) {
+  return attn_tables_bytes(H, D, Dv, F);
+}
+
+extern "C" int spt_edge_attn_bwd_el_supported(int H, int D, int Dv, int F) {
+  return H == 16 && D == 4 && Dv == 4 && F == 32 && g_attn_bwd_packed == 2 && mfma_mode() >= 2;
+}
+
+extern "C" size_t spt_edge_attn_bwd_ex_workspace_bytes(int64_t n, int64_t e, int H, int D, int Dv,
+                                                       int F) {
+  return attn_tables_bytes(H, D, Dv, F) + attn_bwd_el_workspace_bytes(n, e);
 }
 
 extern "C" int spt_edge_attn_bwd_f32(const float* qkv, int64_t n, int H, int D, int Dv,
@@ -874,10 +910,10 @@ extern "C" int spt_edge_attn_bwd_f32(const float* qkv, int64_t n, int H, int D, 
                                      float* gedge_attr, float* gWk, float* gbk,
                                      float* gWq, float* gbq, float* gWv, float* gbv,
                                      void* ws, size_t ws_bytes, spt_stream_t stream_) {
-  return spt_edge_attn_bwd_acc_f32(qkv, n, H, D, Dv, erowptr, eperm, tgt_sorted, e, edge_attr, F,
-                                   Wk, bk, Wq, bq, Wv, bv, scale_mode, scale_a, out, m, z, gout,
-                                   gqkv, gedge_attr, 0, gWk, gbk, gWq, gbq, gWv, gbv, ws,
-                                   ws_bytes, stream_);
+  return spt_edge_attn_bwd_ex_f32(qkv, n, H, D, Dv, erowptr, eperm, tgt_sorted, nullptr, nullptr,
+                                  nullptr, e, edge_attr, F, Wk, bk, Wq, bq, Wv, bv, scale_mode,
+                                  scale_a, out, m, z, gout, gqkv, gedge_attr, 0, gWk, gbk, gWq, gbq,
+                                  gWv, gbv, -1, ws, ws_bytes, stream_);
 }
 
 // Same, with `gedge_attr_accumulate` != 0: d edge_attr is ADDED to what gedge_attr holds (f32
@@ -896,8 +932,34 @@ extern "C" int spt_edge_attn_bwd_acc_f32(const float* qkv, int64_t n, int H, int
                                          float* gWk, float* gbk, float* gWq, float* gbq,
                                          float* gWv, float* gbv, void* ws, size_t ws_bytes,
                                          spt_stream_t stream_) {
+  return spt_edge_attn_bwd_ex_f32(qkv, n, H, D, Dv, erowptr, eperm, tgt_sorted, nullptr, nullptr,
+                                  nullptr, e, edge_attr, F, Wk, bk, Wq, bq, Wv, bv, scale_mode,
+                                  scale_a, out, m, z, gout, gqkv, gedge_attr, gedge_attr_accumulate,
+                                  gWk, gbk, gWq, gbq, gWv, gbv, -1, ws, ws_bytes, stream_);
+}
+
+// The general entry: `src_sorted` (nullable) = source node of every CSR position (edge_index[0]
+// in CSR order); `tperm` / `trowptr` (nullable, both or none) = CSR view of tgt_sorted over the
+// CSR positions (spt_csr_build on tgt_sorted): the edge-lane backward sums dk / dv per target
+// through it instead of scattering them with atomics; `mode` = per-call formulation word (< 0:
+// process defaults).
+extern "C" int spt_edge_attn_bwd_ex_f32(const float* qkv, int64_t n, int H, int D, int Dv,
+                                        const int32_t* erowptr, const int32_t* eperm,
+                                        const int32_t* tgt_sorted, const int32_t* src_sorted,
+                                        const int32_t* tperm, const int32_t* trowptr,
+                                        int64_t e, const float* edge_attr, int F, const float* Wk,
+                                        const float* bk, const float* Wq, const float* bq,
+                                        const float* Wv, const float* bv, int scale_mode,
+                                        float scale_a, const float* out, const float* m,
+                                        const float* z, const float* gout, float* gqkv,
+                                        float* gedge_attr, int gedge_attr_accumulate,
+                                        float* gWk, float* gbk, float* gWq, float* gbq,
+                                        float* gWv, float* gbv, int mode, void* ws,
+                                        size_t ws_bytes, spt_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   const int gea_acc = gedge_attr_accumulate != 0;
+  const int prec = mode_precision(mode);
+  int form = mode_bwd_form(mode);
   SPT_CHECK_ARG(n >= 0 && e >= 0 && H >= 1 && D >= 1 && Dv >= 1, "bad shape");
   if (n == 0) return 0;
   SPT_CHECK_ARG(qkv && erowptr && out && m && z && gout && gqkv && (tgt_sorted || e == 0), "null pointer");
@@ -907,19 +969,38 @@ extern "C" int spt_edge_attn_bwd_acc_f32(const float* qkv, int64_t n, int H, int
   const int qpl = per_lane(H * D), vpl = per_lane(H * Dv);
   const int ld = 2 * H * D + H * Dv;
   const size_t len = (size_t)ld * (F + 1);
-  const size_t need = spt_edge_attn_bwd_workspace_bytes(H, D, Dv, F);
+  const size_t need = attn_tables_bytes(H, D, Dv, F);
   SPT_CHECK_ARG(!has_rpe || (ws && ws_bytes >= need), "workspace too small");
   float* partial = has_rpe ? (float*)ws : nullptr;
-  float* total = has_rpe ? (float*)((char*)ws + align_up((size_t)EA_BWD_BLOCKS * EA_WAVES * len * 4, 256)) : nullptr;
+  const size_t partial_bytes = align_up((size_t)EA_BWD_BLOCKS * EA_WAVES * len * 4, 256);
+  float* total = has_rpe ? (float*)((char*)ws + partial_bytes) : nullptr;
   const int grid = (int)(ceil_div(n, EA_WAVES) < EA_BWD_BLOCKS ? ceil_div(n, EA_WAVES) : EA_BWD_BLOCKS);
-  // k / v columns of gqkv receive atomics: start from zero (q columns are overwritten)
-  hipMemsetAsync(gqkv, 0, (size_t)n * ld * 4, stream);
-  if (use_mfma() && attn_mfma_shape_ok(H, D, Dv, F, edge_attr, Wk, Wq, Wv)) {
-    const int ntab = attn_bwd_mfma_launch(qkv, n, erowptr, eperm, tgt_sorted, edge_attr, Wk, bk,
-                                          Wq, bq, Wv, bv, scale_mode, scale_a, out, m, z, gout,
-                                          gqkv, gedge_attr, gea_acc, partial,
-                                          mfma_mode() == 2 ? 3 : (mfma_mode() == 3 ? 1 : 0), e,
-                                          g_attn_bwd_packed, stream);
+  const bool el_ok = prec >= 2 && e > 0 && tperm &&
+                     attn_mfma_shape_ok(H, D, Dv, F, edge_attr, Wk, Wq, Wv);
+  // gqkv receives atomics: start from zero (the edge-lane path initialises it itself)
+  if (!(form == 2 && el_ok && ws_bytes >= need + attn_bwd_el_workspace_bytes(n, e)))
+    hipMemsetAsync(gqkv, 0, (size_t)n * ld * 4, stream);
+  if (prec != 0 && attn_mfma_shape_ok(H, D, Dv, F, edge_attr, Wk, Wq, Wv)) {
+    int ntab;
+    const size_t need_el = need + attn_bwd_el_workspace_bytes(n, e);
+    if (form == 2 && mode >= 0 && ((mode >> 4) & 3) == 3)
+      SPT_CHECK_ARG(ws_bytes >= need_el && prec >= 2 && tperm && trowptr,
+                    "edge-lane backward: workspace of spt_edge_attn_bwd_ex_workspace_bytes, the "
+                    "target CSR view and a bf16-pipe precision are required");
+    SPT_CHECK_ARG((tperm == nullptr) == (trowptr == nullptr), "pass both tperm and trowptr or neither");
+    if (form == 2 && prec >= 2 && e > 0 && ws_bytes >= need_el && tperm) {
+      // d edge_attr is accumulated by both waves of a pair: start from zero when storing
+      if (!gea_acc) hipMemsetAsync(gedge_attr, 0, (size_t)e * F * 4, stream);
+      ntab = attn_bwd_el_launch(qkv, n, erowptr, eperm, tgt_sorted, src_sorted, tperm, trowptr, e,
+                                edge_attr, Wk,
+                                bk, Wq, bq, Wv, bv, scale_mode, scale_a, out, m, z, gout, gqkv,
+                                gedge_attr, partial, (char*)ws + need, prec == 2 ? 3 : 1, stream);
+    } else {
+      ntab = attn_bwd_mfma_launch(qkv, n, erowptr, eperm, tgt_sorted, edge_attr, Wk, bk,
+                                  Wq, bq, Wv, bv, scale_mode, scale_a, out, m, z, gout,
+                                  gqkv, gedge_attr, gea_acc, partial,
+                                  prec == 2 ? 3 : (prec == 3 ? 1 : 0), e, form != 0, stream);
+    }
     attn_reduce_partials_kernel<<<(int)ceil_div((int64_t)len, 16), 256, 0, stream>>>(
         partial, ntab, (int)len, total);
     attn_unpack_grads_kernel<<<(int)ceil_div((int64_t)len, 256), 256, 0, stream>>>(

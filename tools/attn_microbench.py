@@ -16,12 +16,12 @@ ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--n", type=int, default=428571)
 ap.add_argument("--e", type=int, default=7030000)
 ap.add_argument("--mode", type=int, default=2, help="2 split-bf16 MFMA, 1 f32 MFMA, 0 VALU")
-ap.add_argument("--packed", type=int, default=1, help="backward tiles over the edge stream (1) or per node (0)")
+ap.add_argument("--packed", type=int, default=2, help="backward tiles over the edge stream (1) or per node (0)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 from superpoint_transformer_amd import _lib
 _lib.lib.spt_attn_use_mfma(a.mode)
-_lib.lib.spt_attn_bwd_packed(a.packed)
+_lib.lib.spt_attn_bwd_packed(a.packed)  # 2 edge-lane, 1 packed, 0 per node
 g = torch.Generator(device=dev).manual_seed(0)
 n, e = a.n, a.e
 s = torch.randint(0, n, (e,), device=dev, generator=g)
