@@ -283,11 +283,18 @@ size_t spt_edge_attn_bwd_ex_workspace_bytes(int64_t n, int64_t e, int H, int D, 
 /* 1 when the edge-lane backward is built for this head layout AND the process defaults select it
  * (a caller uses it to decide whether to build the target view). */
 int spt_edge_attn_bwd_el_supported(int H, int D, int Dv, int F);
+/* [ceil(e / 16)][48] int32 tile records of the edge-lane backward (edge rows | targets | sources of
+ * 16 consecutive CSR positions): depends on the graph only, built once per batch and level by the
+ * caller (tile_ids = NULL: rebuilt in the workspace on every call). */
+int spt_attn_pack_tile_ids(const int32_t* eperm, const int32_t* tgt_sorted,
+                           const int32_t* src_sorted, int64_t e, int32_t* tile_ids,
+                           spt_stream_t stream);
 int spt_edge_attn_bwd_ex_f32(const float* qkv, int64_t n, int H, int D, int Dv,
                              const int32_t* erowptr, const int32_t* eperm,
                              const int32_t* tgt_sorted, const int32_t* src_sorted,
-                             const int32_t* tperm, const int32_t* trowptr,
-                             int64_t e, const float* edge_attr, int F, const float* Wk,
+                             const int32_t* tile_ids, const int32_t* tperm,
+                             const int32_t* trowptr, int64_t e, const float* edge_attr, int F,
+                             const float* Wk,
                              const float* bk, const float* Wq, const float* bq,
                              const float* Wv, const float* bv, int scale_mode,
                              float scale_a, const float* out, const float* m,

@@ -51,7 +51,8 @@ SIGNATURES = {
                                         _p, _p, _p, _p, _p, _p, _int, _f32, _p, _p, _p, _int, _p]),
     "spt_edge_attn_bwd_ex_workspace_bytes": (_sz, [_i64, _i64, _int, _int, _int, _int]),
     "spt_edge_attn_bwd_el_supported": (_int, [_int, _int, _int, _int]),
-    "spt_edge_attn_bwd_ex_f32": (_int, [_p, _i64, _int, _int, _int, _p, _p, _p, _p, _p, _p, _i64, _p, _int,
+    "spt_attn_pack_tile_ids": (_int, [_p, _p, _p, _i64, _p, _p]),
+    "spt_edge_attn_bwd_ex_f32": (_int, [_p, _i64, _int, _int, _int, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _int,
                                         _p, _p, _p, _p, _p, _p, _int, _f32, _p, _p, _p, _p,
                                         _p, _p, _int, _p, _p, _p, _p, _p, _p, _int, _p, _sz, _p]),
     "spt_grid_knn_workspace_bytes": (_sz, [_i64, _i64]),

@@ -97,7 +97,8 @@ class EdgeCSR:
     ``erowptr`` [n+1], ``eperm`` [e] (stable), ``tgt_sorted`` [e] int32 =
     edge_index[1] in CSR order."""
 
-    __slots__ = ("erowptr", "eperm", "tgt_sorted", "n", "e", "_view", "_src_sorted", "_tview")
+    __slots__ = ("erowptr", "eperm", "tgt_sorted", "n", "e", "_view", "_src_sorted", "_tview",
+                 "_tile_ids")
 
     def __init__(self, erowptr, eperm, tgt_sorted, n, e, view=None):
         self.erowptr, self.eperm, self.tgt_sorted, self.n, self.e = \
@@ -105,6 +106,23 @@ class EdgeCSR:
         self._view = view
         self._src_sorted = None
         self._tview = None
+        self._tile_ids = None
+
+    def tile_ids(self):
+        """int32 [ceil(e / 16), 48]: the edge-lane attention backward's tile records (edge rows |
+        targets | sources of 16 consecutive CSR positions), built on first use."""
+        if self._tile_ids is None:
+            dev = self.tgt_sorted.device
+            nt = (self.e + 15) // 16
+            out = torch.empty((max(nt, 1), 48), dtype=torch.int32, device=dev)
+            src = self.src_sorted()
+            with torch.cuda.device(dev):
+                st = _lib.lib.spt_attn_pack_tile_ids(
+                    _lib.ptr(self.eperm), _lib.ptr(self.tgt_sorted), _lib.ptr(src), self.e,
+                    _lib.ptr(out), _lib.stream_ptr(dev))
+            _lib.check(st, "spt_attn_pack_tile_ids")
+            self._tile_ids = out
+        return self._tile_ids
 
     def target_view(self):
         """CSR view of ``tgt_sorted`` over the CSR positions (which positions point INTO node t,

@@ -768,13 +768,15 @@ int attn_bwd_mfma_launch(const float* qkv, int64_t n, const int32_t* erowptr,
                          int64_t e, int packed, hipStream_t stream);
 // edge_attn_el.hip: edge-lane backward (two waves per SIMD)
 size_t attn_bwd_el_workspace_bytes(int64_t n, int64_t e);
+void attn_pack_tile_ids_launch(const int32_t* eperm, const int32_t* tgt, const int32_t* src,
+                               int64_t e, int32_t* ids3, hipStream_t stream);
 int attn_bwd_el_launch(const float* qkv, int64_t n, const int32_t* erowptr, const int32_t* eperm,
-                       const int32_t* tgt, const int32_t* src, const int32_t* tperm,
-                       const int32_t* trowptr, int64_t e, const float* ea,
+                       const int32_t* tgt, const int32_t* src, const int32_t* tile_ids,
+                       const int32_t* tperm, const int32_t* trowptr, int64_t e, const float* ea,
                        const float* Wk, const float* bk, const float* Wq, const float* bq,
                        const float* Wv, const float* bv, int scale_mode, float scale_a,
                        const float* out, const float* m, const float* z, const float* gout,
-                       float* gqkv, float* gea, float* partial, void* ws, int prec,
+                       float* gqkv, float* gea, int gea_acc, float* partial, void* ws, int prec,
                        hipStream_t stream);
 // 0: lane-per-output VALU kernels, 1: f32 matrix pipe (bitwise an fmaf chain), 2 (default):
 // split-bf16 on the bf16 matrix pipe (3 products per f32 product, ~10 ulp of f32), 3: plain
@@ -911,9 +913,9 @@ extern "C" int spt_edge_attn_bwd_f32(const float* qkv, int64_t n, int H, int D, 
                                      float* gWq, float* gbq, float* gWv, float* gbv,
                                      void* ws, size_t ws_bytes, spt_stream_t stream_) {
   return spt_edge_attn_bwd_ex_f32(qkv, n, H, D, Dv, erowptr, eperm, tgt_sorted, nullptr, nullptr,
-                                  nullptr, e, edge_attr, F, Wk, bk, Wq, bq, Wv, bv, scale_mode,
-                                  scale_a, out, m, z, gout, gqkv, gedge_attr, 0, gWk, gbk, gWq, gbq,
-                                  gWv, gbv, -1, ws, ws_bytes, stream_);
+                                  nullptr, nullptr, e, edge_attr, F, Wk, bk, Wq, bq, Wv, bv,
+                                  scale_mode, scale_a, out, m, z, gout, gqkv, gedge_attr, 0, gWk, gbk,
+                                  gWq, gbq, gWv, gbv, -1, ws, ws_bytes, stream_);
 }
 
 // Same, with `gedge_attr_accumulate` != 0: d edge_attr is ADDED to what gedge_attr holds (f32
@@ -933,21 +935,37 @@ extern "C" int spt_edge_attn_bwd_acc_f32(const float* qkv, int64_t n, int H, int
                                          float* gWv, float* gbv, void* ws, size_t ws_bytes,
                                          spt_stream_t stream_) {
   return spt_edge_attn_bwd_ex_f32(qkv, n, H, D, Dv, erowptr, eperm, tgt_sorted, nullptr, nullptr,
-                                  nullptr, e, edge_attr, F, Wk, bk, Wq, bq, Wv, bv, scale_mode,
-                                  scale_a, out, m, z, gout, gqkv, gedge_attr, gedge_attr_accumulate,
-                                  gWk, gbk, gWq, gbq, gWv, gbv, -1, ws, ws_bytes, stream_);
+                                  nullptr, nullptr, e, edge_attr, F, Wk, bk, Wq, bq, Wv, bv,
+                                  scale_mode, scale_a, out, m, z, gout, gqkv, gedge_attr,
+                                  gedge_attr_accumulate, gWk, gbk, gWq, gbq, gWv, gbv, -1, ws,
+                                  ws_bytes, stream_);
+}
+
+// [ceil(e / 16)][48] int32 tile records of the edge-lane backward: per 16 CSR positions the edge
+// rows (eperm, or the positions when NULL), targets and sources (positions beyond e repeat the last
+// edge).  Depends on the graph only: a caller builds it once per batch and level and hands it to
+// spt_edge_attn_bwd_ex_f32 (which otherwise rebuilds it in its workspace on every call).
+extern "C" int spt_attn_pack_tile_ids(const int32_t* eperm, const int32_t* tgt_sorted,
+                                      const int32_t* src_sorted, int64_t e, int32_t* tile_ids,
+                                      spt_stream_t stream_) {
+  SPT_CHECK_ARG(e >= 0 && (e == 0 || (tgt_sorted && src_sorted && tile_ids)), "null pointer");
+  attn_pack_tile_ids_launch(eperm, tgt_sorted, src_sorted, e, tile_ids, (hipStream_t)stream_);
+  SPT_CHECK_LAUNCH();
+  return 0;
 }
 
 // The general entry: `src_sorted` (nullable) = source node of every CSR position (edge_index[0]
-// in CSR order); `tperm` / `trowptr` (nullable, both or none) = CSR view of tgt_sorted over the
+// in CSR order); `tile_ids` (nullable) = spt_attn_pack_tile_ids of the graph; `tperm` / `trowptr`
+// (nullable, both or none) = CSR view of tgt_sorted over the
 // CSR positions (spt_csr_build on tgt_sorted): the edge-lane backward sums dk / dv per target
 // through it instead of scattering them with atomics; `mode` = per-call formulation word (< 0:
 // process defaults).
 extern "C" int spt_edge_attn_bwd_ex_f32(const float* qkv, int64_t n, int H, int D, int Dv,
                                         const int32_t* erowptr, const int32_t* eperm,
                                         const int32_t* tgt_sorted, const int32_t* src_sorted,
-                                        const int32_t* tperm, const int32_t* trowptr,
-                                        int64_t e, const float* edge_attr, int F, const float* Wk,
+                                        const int32_t* tile_ids, const int32_t* tperm,
+                                        const int32_t* trowptr, int64_t e, const float* edge_attr,
+                                        int F, const float* Wk,
                                         const float* bk, const float* Wq, const float* bq,
                                         const float* Wv, const float* bv, int scale_mode,
                                         float scale_a, const float* out, const float* m,
@@ -989,12 +1007,11 @@ extern "C" int spt_edge_attn_bwd_ex_f32(const float* qkv, int64_t n, int H, int 
                     "target CSR view and a bf16-pipe precision are required");
     SPT_CHECK_ARG((tperm == nullptr) == (trowptr == nullptr), "pass both tperm and trowptr or neither");
     if (form == 2 && prec >= 2 && e > 0 && ws_bytes >= need_el && tperm) {
-      // d edge_attr is accumulated by both waves of a pair: start from zero when storing
-      if (!gea_acc) hipMemsetAsync(gedge_attr, 0, (size_t)e * F * 4, stream);
-      ntab = attn_bwd_el_launch(qkv, n, erowptr, eperm, tgt_sorted, src_sorted, tperm, trowptr, e,
-                                edge_attr, Wk,
+      ntab = attn_bwd_el_launch(qkv, n, erowptr, eperm, tgt_sorted, src_sorted, tile_ids, tperm,
+                                trowptr, e, edge_attr, Wk,
                                 bk, Wq, bq, Wv, bv, scale_mode, scale_a, out, m, z, gout, gqkv,
-                                gedge_attr, partial, (char*)ws + need, prec == 2 ? 3 : 1, stream);
+                                gedge_attr, gea_acc, partial, (char*)ws + need, prec == 2 ? 3 : 1,
+                                stream);
     } else {
       ntab = attn_bwd_mfma_launch(qkv, n, erowptr, eperm, tgt_sorted, edge_attr, Wk, bk,
                                   Wq, bq, Wv, bv, scale_mode, scale_a, out, m, z, gout,

@@ -60,35 +60,45 @@ constexpr int NBW = 2;            // 16-column blocks of each projection owned b
 constexpr int WAVES = 8;          // per workgroup: 4 tile streams x 2 head halves, one workgroup per CU
 constexpr int LD = 192;           // qkv row length
 
-// per-wave LDS map, in floats
-constexpr int L_EA = 0;                        // [16][32] edge_attr rows, 16-B chunks XOR-swizzled
-constexpr int L_G = L_EA + TE * F;             // 8 x [64 lanes][4]: (k, v, q, gout) x 2 blocks
-constexpr int L_DM = L_G + 8 * 256;            // [64 lanes][4]: delta x 2, ml x 2
-constexpr int L_SC = L_DM + 256;               // [64 lanes]: qk scale of the edge's source
+// LDS map, in floats.  Per wave:
+constexpr int L_G = 0;                         // 4 x [64 lanes][4]: (k, v) rows of the targets x 2 blocks
 constexpr int DT_LD = 36;                      // 32 words + 4: conflict-free both ways
-constexpr int L_DT = L_SC + 64;                // [16 edges][DT_LD] words (hi << 16 | lo), one projection
-constexpr int L_IDS = L_DT + TE * DT_LD;       // 3 slots x (edge row, target, source) x 16
-constexpr int L_TBL = L_IDS + 3 * 48;          // rank[16], node[16], scale[16]
-constexpr int L_END = L_TBL + 48;
+constexpr int L_DT = L_G + 4 * 256;            // [16 edges][DT_LD] words (hi << 16 | lo), one projection
+constexpr int L_TBL = L_DT + TE * DT_LD;       // rank[16], node[16]
+constexpr int L_END = L_TBL + 32;
+// per pair of waves (the two head halves of one tile stream):
+constexpr int P_EA = 0;                        // 2 x [16][32] edge_attr rows (16-B chunks XOR-swizzled)
+constexpr int P_IDS = P_EA + 2 * TE * F;       // 4 slots x (edge row, target, source) x 16
+constexpr int P_MB = P_IDS + 4 * 48;           // [64 lanes][8]: the leader's half of d edge_attr
+constexpr int P_GEA = P_MB + 512;              // [2][64 lanes][4]: what gedge_attr holds for the tile (accumulate)
+constexpr int P_FLAG = P_GEA + 512;            // hand-shake counters (F_*)
+constexpr int P_END = P_FLAG + 8;
+constexpr int F_EA = 0;       // leader -> follower: edge_attr rows of tile k and ids of tile k + 1 landed (k + 1)
+constexpr int F_TOP = 1;      // follower -> leader: operands of tile k read (k + 1)
+constexpr int F_MB = 2;       // leader -> follower: mailbox holds tile k (k + 1)
+constexpr int F_MBFREE = 3;   // follower -> leader: mailbox of tile k consumed (k + 1)
+constexpr int F_DONE = 4;     // follower -> leader: tile k finished, its id slot is free (k + 1)
 // shared by the workgroup: padded bf16 copies of [Wk; Wq; Wv] (row = output column, 32 + 8 bf16:
 // 80-byte rows put the 16 lanes of a ds_read_b128 group on distinct bank windows) and the biases
 constexpr int WB_LD = F + 8;
 constexpr int WB_ELEMS = 192 * WB_LD;
 
-// outstanding VMEM operations per iteration, in issue order (every count is static: no memory
-// instruction in the loop sits under a data-dependent branch except the dq atomics, issued last)
-constexpr int N_TOP_MIN = 4;      // edge_attr rows of tile t + 1 (2) + ids of tile t + 2 (2, 3 with eperm)
-#ifdef SPT_EL_NO_NODE
-constexpr int N_GATHER = 4;
-#else
-constexpr int N_GATHER = 10;      // 8 row pieces + (delta, ml) + scale of tile t + 1
-#endif
-constexpr int N_KV = 4;           // dk / dv rows of tile t (streaming stores)
-#ifdef SPT_EL_NO_GEA
-constexpr int N_GEA = 0;
-#else
-constexpr int N_GEA = 8;          // d edge_attr atomics of tile t
-#endif
+// Outstanding VMEM operations per iteration, in issue order (every count is static: no memory
+// instruction in the loop sits under a data-dependent branch except the dq atomics, issued last):
+//   leader  : [top] ids of tile k+2 (1), node rows of tile k (5), edge_attr rows of tile k+1 (2)
+//             [core] dk/dv rows (4)  [mid] k / v gathers of tile k+1 (4)  [tail] dq atomics (0..8)
+//   follower: [top] node rows of tile k (5), old d edge_attr rows of tile k (2)
+//             [core] dk/dv rows (4)  [mid] k / v gathers of tile k+1 (4)
+//             [tail] d edge_attr rows (2), dq atomics (0..8)
+// The node rows (q * scale, gout, (delta, ml) of the edge's SOURCE: the 16 edges of a tile share
+// one to three sources, so these hit the L1) are register loads: an LDS-DMA instruction costs
+// the CU ~84 cycles whatever it hits (~12 B / clk / CU), an L1-hitting register load a fraction.
+constexpr int N_TOP = 3;
+constexpr int N_NODE = 5;         // (q*scale, gout) x 2 blocks + (delta, ml)
+constexpr int N_GATHER = 4;       // (k, v) x 2 blocks
+constexpr int N_KV = 4;
+constexpr int N_GEA = 2;
+constexpr int N_OLD = 2;
 
 __device__ __forceinline__ void lds_dma16(const float* g, float* lds) {
   const unsigned a = __builtin_amdgcn_readfirstlane(
@@ -109,6 +119,21 @@ __device__ __forceinline__ void wait_vm() {
 }
 __device__ __forceinline__ void wait_lds() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+// pair hand-shake through LDS counters (monotonic per launch).  LDS operations of a wave are
+// performed in order, so data written before flag_set() is visible to whoever saw the flag.
+typedef __attribute__((address_space(3))) volatile int lds_flag_t;   // ds_read / ds_write, never flat
+__device__ __forceinline__ void flag_set(lds_flag_t* f, int v) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  *f = v;
+}
+__device__ __forceinline__ void flag_wait(lds_flag_t* f, int v) {
+  int spins = 0;
+  while (__builtin_amdgcn_readfirstlane(*f) < v) {
+    __builtin_amdgcn_s_sleep(1);
+    if (++spins > (1 << 22)) __builtin_trap();   // a lost partner: fail loudly, never hang the GPU
+  }
+  asm volatile("" ::: "memory");
 }
 __device__ __forceinline__ void lds_order() {   // this wave's LDS writes before its later reads
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -151,12 +176,13 @@ __device__ __forceinline__ float qk_scale_of(int mode, float a, int deg) {
 // ---- per-node rows the backward reads per edge --------------------------------------------
 //   dm[node][hh][g][{delta(bl=0), delta(bl=1), ml(bl=0), ml(bl=1)}],  head = 4 (2 hh + bl) + g
 //     delta = <gout, out> of the head, ml = m + log(z + 1e-16) (softmax weight = exp(p - ml))
-//   scl[node] = qk scale of the node (0 for a node without edges)
-// One thread per (node, head).  Also zero-fills the q columns of gqkv.
+//   qs[node][64] = q * qk-scale of the node,  scl[node] = that scale (0 for a node without edges)
+// One thread per (node, head).  Also zero-fills the q columns of gqkv (dq arrives by atomics).
 __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(
-    const float* __restrict__ gout, const float* __restrict__ out, const float* __restrict__ m,
-    const float* __restrict__ z, const int32_t* __restrict__ erowptr, int64_t N, int scale_mode,
-    float scale_a, float* __restrict__ dm, float* __restrict__ scl, float* __restrict__ gqkv) {
+    const float* __restrict__ qkv, const float* __restrict__ gout, const float* __restrict__ out,
+    const float* __restrict__ m, const float* __restrict__ z, const int32_t* __restrict__ erowptr,
+    int64_t N, int scale_mode, float scale_a, float* __restrict__ dm, float* __restrict__ qs,
+    float* __restrict__ scl, float* __restrict__ gqkv) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t node = idx >> 4;
   const int h = (int)(idx & 15);
@@ -169,12 +195,13 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(
   float* rec = dm + node * 32 + hh * 16 + g * 4;
   rec[bl] = delta;
   rec[2 + bl] = ml;
-  // the q columns of gqkv receive dq by atomics (per tile and node): start from zero
+  const int deg = erowptr[node + 1] - erowptr[node];
+  const float scale = deg > 0 ? qk_scale_of(scale_mode, scale_a, deg) : 0.f;
+  const float4 q4 = *reinterpret_cast<const float4*>(qkv + node * LD + 4 * h);
+  *reinterpret_cast<float4*>(qs + node * 64 + 4 * h) =
+      make_float4(q4.x * scale, q4.y * scale, q4.z * scale, q4.w * scale);
+  if (h == 0) scl[node] = scale;
   *reinterpret_cast<float4*>(gqkv + node * LD + 4 * h) = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (h == 0) {
-    const int deg = erowptr[node + 1] - erowptr[node];
-    scl[node] = deg > 0 ? qk_scale_of(scale_mode, scale_a, deg) : 0.f;
-  }
 }
 
 // source node of every CSR position (when the caller does not hand it over)
@@ -186,13 +213,29 @@ __global__ __launch_bounds__(256) void expand_rowptr_kernel(const int32_t* __res
   for (int j = a; j < b; ++j) src[j] = (int32_t)node;
 }
 
+// ids of a tile in one 192-byte record: [16 edge rows | 16 targets | 16 sources]; positions beyond
+// the edge list repeat the last edge (they run with softmax weight 0)
+__global__ __launch_bounds__(256) void pack_tile_ids_kernel(
+    const int32_t* __restrict__ eperm, const int32_t* __restrict__ tgt,
+    const int32_t* __restrict__ src, int64_t E, int64_t ntiles, int32_t* __restrict__ ids3) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= ntiles * 48) return;
+  const int64_t tile = i / 48;
+  const int l = (int)(i - tile * 48);
+  int64_t j = tile * TE + (l & 15);
+  j = j < E ? j : E - 1;
+  ids3[i] = l < 16 ? (eperm ? eperm[j] : (int32_t)j) : (l < 32 ? tgt[j] : src[j]);
+}
+
 // gqkv[t][64 .. 191] = sum over the edges INTO t of their [dk | dv] rows, in ascending CSR position
 // (tperm / trowptr = CSR view of the targets over the CSR-by-source positions; stable sort ->
 // a fixed summation order -> deterministic).  Half a wave per target node: 32 lanes x 16 bytes =
-// one 512-byte row per load, eight rows in flight.
+// one 512-byte row per load, eight rows in flight.  The same pass applies the node's qk scale to
+// the q columns (the main kernel adds the unscaled dq of the node's edges).
 __global__ __launch_bounds__(256) void attn_kv_reduce_kernel(
     const float* __restrict__ dkv, const int32_t* __restrict__ tperm,
-    const int32_t* __restrict__ trowptr, int64_t N, float* __restrict__ gqkv) {
+    const int32_t* __restrict__ trowptr, const float* __restrict__ scl, int64_t N,
+    float* __restrict__ gqkv) {
   const int lane = threadIdx.x & 31;
   const int64_t half = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 5;
   const int64_t nhalf = ((int64_t)gridDim.x * 256) >> 5;
@@ -223,6 +266,10 @@ __global__ __launch_bounds__(256) void attn_kv_reduce_kernel(
       }
     }
     *reinterpret_cast<f32x4*>(gqkv + t * LD + 64 + 4 * lane) = acc;
+    if (lane < 16) {          // the q columns hold the unscaled sum of dq over the node's edges
+      f32x4* qp = reinterpret_cast<f32x4*>(gqkv + t * LD + 4 * lane);
+      *qp = *qp * scl[t];
+    }
   }
 }
 
@@ -247,26 +294,31 @@ __global__ __launch_bounds__(256) void attn_kv_reduce_kernel(
 
 template <int PREC>
 __global__ __launch_bounds__(WAVES * 64, 2) void attn_bwd_el_kernel(
-    const float* __restrict__ qkv, int64_t E, const int32_t* __restrict__ eperm,
-    const int32_t* __restrict__ tgt, const int32_t* __restrict__ src, int64_t ntiles, int64_t tpw,
-    const float* __restrict__ ea, const float* __restrict__ Wk, const float* __restrict__ bk,
-    const float* __restrict__ Wq, const float* __restrict__ bq, const float* __restrict__ Wv,
-    const float* __restrict__ bv, const float* __restrict__ dm, const float* __restrict__ scl,
-    const float* __restrict__ gout, float* __restrict__ gqkv, float* __restrict__ gea,
-    float* __restrict__ dkv, float* __restrict__ partial) {
+    const float* __restrict__ qkv, int64_t E, const int32_t* __restrict__ ids3, int64_t ntiles,
+    int64_t tpw, const float* __restrict__ ea, const float* __restrict__ Wk,
+    const float* __restrict__ bk, const float* __restrict__ Wq, const float* __restrict__ bq,
+    const float* __restrict__ Wv, const float* __restrict__ bv, const float* __restrict__ dm,
+    const float* __restrict__ qs, const float* __restrict__ gout, float* __restrict__ gqkv,
+    float* __restrict__ gea, int gea_acc, float* __restrict__ dkv, float* __restrict__ partial) {
   static_assert(PREC == 1 || PREC == 3, "bf16 matrix pipe only");
   constexpr bool LO = PREC == 3;
-  __shared__ __attribute__((aligned(16))) float lds_all[WAVES][L_END];
+  __shared__ __attribute__((aligned(16))) float lds_wave[WAVES][L_END];
+  __shared__ __attribute__((aligned(16))) float lds_pair[WAVES / 2][P_END];
   __shared__ __attribute__((aligned(16))) __bf16 wb_hi[WB_ELEMS];
   __shared__ __attribute__((aligned(16))) __bf16 wb_lo[LO ? WB_ELEMS : 8];
   __shared__ __attribute__((aligned(16))) float bias_lds[192];
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, c = lane & 15;
-  float* L = lds_all[wid];
+  float* L = lds_wave[wid];
+  float* P = lds_pair[wid >> 1];
+  lds_flag_t* flg = (lds_flag_t*)(__attribute__((address_space(3))) void*)(P + P_FLAG);
   const int64_t wave = (int64_t)blockIdx.x * WAVES + wid;
   const int64_t pair = wave >> 1;
-  const int hh = (int)(wave & 1);           // head half: blocks b = 2 hh + bl of every projection
+  const int hh = wid & 1;                   // head half: blocks b = 2 hh + bl of every projection
+  const bool leader = hh == 0;              // leader: fetches the pair's edge_attr rows and tile ids;
+                                            // follower: combines and writes the pair's d edge_attr
+  const bool acc = gea_acc != 0;
 
   // ---- operands ---------------------------------------------------------------------------
   auto Wof = [&](int p) { return p == 0 ? Wk : (p == 1 ? Wq : Wv); };
@@ -287,9 +339,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_bwd_el_kernel(
     const float* bp = p3 == 0 ? bk : (p3 == 1 ? bq : bv);
     bias_lds[threadIdx.x] = bp ? bp[n] : 0.f;
   }
+  if (lane < 8) flg[lane] = 0;
   __syncthreads();
-  // d edge_attr GEMM, B operand (16x16x32 over the wave's 32 output columns of a projection),
-  // resident: lane (g, c), slot i holds W[16 (2 hh + (i >> 2)) + 4 g + (i & 3)][16 fb + c]
+  // d edge_attr GEMM, resident operand (16x16x32 over the wave's 32 output columns of a
+  // projection): lane (g, c), slot i holds W[16 (2 hh + (i >> 2)) + 4 g + (i & 3)][16 fb + c] -
+  // as the A operand it yields the transposed product  dEA^T[f][e] = W^T D^T
   bf16x8 Wbh[3][2], Wbl[3][2];
 #pragma unroll
   for (int p = 0; p < 3; ++p) {
@@ -317,74 +371,93 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_bwd_el_kernel(
   const int64_t t_begin = pair * tpw;
   const int64_t t_end = (t_begin + tpw < ntiles) ? t_begin + tpw : ntiles;
   if (t_begin < t_end) {
-    int* ids_ring = reinterpret_cast<int*>(L + L_IDS);
+    int* ids_ring = reinterpret_cast<int*>(P + P_IDS);
     const int64_t t_last = t_end - 1;
-    // position of row u of tile t in the CSR edge order, clamped to the last edge: rows beyond
-    // the edge list duplicate it with softmax weight 0 (every gradient they carry is 0)
-    auto pos_of = [&](int64_t t, int u) -> int64_t {
-      const int64_t j = t * TE + u;
-      return j < E ? j : E - 1;
-    };
-    auto issue_ids = [&](int64_t t, int slot) {        // lanes 0-15 edge rows, 16-31 targets, 32-47 sources
+    auto issue_ids = [&](int64_t t, int slot) {        // one 192-byte record: 48 lanes x 4 bytes
       t = t < t_last ? t : t_last;
-      const int which = lane >> 4;
-      const int64_t j = pos_of(t, lane & 15);
-      // three masked instructions (a 3-way pointer select would go through a scratch table)
-      if (which == 0 && eperm) lds_dma4(eperm + j, L + L_IDS + slot * 48);
-      if (which == 1) lds_dma4(tgt + j, L + L_IDS + slot * 48);
-      if (which == 2) lds_dma4(src + j, L + L_IDS + slot * 48);
+      if (lane < 48) lds_dma4(ids3 + t * 48 + lane, P + P_IDS + slot * 48);
     };
-    auto issue_ea = [&](int64_t t, int slot) {
-      t = t < t_last ? t : t_last;
+    auto issue_ea = [&](int slot, int buf) {
       const int* ids = ids_ring + slot * 48;
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
         const int u = p * 8 + (lane >> 3), ch = lane & 7;
-        const int64_t e = eperm ? (int64_t)ids[u] : pos_of(t, u);
-        lds_dma16(ea + e * F + ((ch ^ (u & 7)) << 2), L + L_EA + p * 256);
+        const int64_t e = ids[u];
+        lds_dma16(ea + e * F + ((ch ^ (u & 7)) << 2), P + P_EA + buf * TE * F + p * 256);
       }
+    };
+    auto issue_old = [&](int slot) {                   // what gedge_attr holds for the tile's edges:
+      const int* ids = ids_ring + slot * 48;           // lane (g, c): row of edge c, columns 16 fb + 4 g ..
+      const float* row = gea + (int64_t)ids[c] * F + 4 * g;
+      lds_dma16(row, P + P_GEA);
+      lds_dma16(row + 16, P + P_GEA + 256);
     };
     auto issue_gather = [&](int slot) {
       const int* ids = ids_ring + slot * 48;
-      const int64_t tc = ids[16 + c], sc = ids[32 + c];
+      const int64_t tc = ids[16 + c];
       const float* kv = qkv + tc * LD + 32 * hh + 4 * g;
-      const float* qq = qkv + sc * LD + 32 * hh + 4 * g;
-      const float* gg = gout + sc * 64 + 32 * hh + 4 * g;
       float* G = L + L_G;
 #pragma unroll
       for (int bl = 0; bl < NBW; ++bl) {
-        lds_dma16(kv + 64 + 16 * bl, G + (4 * bl + 0) * 256);
-        lds_dma16(kv + 128 + 16 * bl, G + (4 * bl + 1) * 256);
-#ifndef SPT_EL_NO_NODE
-        lds_dma16(qq + 16 * bl, G + (4 * bl + 2) * 256);
-        lds_dma16(gg + 16 * bl, G + (4 * bl + 3) * 256);
-#endif
+        lds_dma16(kv + 64 + 16 * bl, G + (2 * bl + 0) * 256);
+        lds_dma16(kv + 128 + 16 * bl, G + (2 * bl + 1) * 256);
       }
+    };
+    // node rows of the tile's edges, straight into registers (asm: invisible to the compiler's
+    // wait-count pass, waited for by hand before the per-edge math)
+    f32x4 nq[NBW], ng[NBW], ndm;
+    auto issue_node = [&](int slot) {
+      const int* ids = ids_ring + slot * 48;
+      const int64_t sc = ids[32 + c];
+      const float* qq = qs + sc * 64 + 32 * hh + 4 * g;
+      const float* gg = gout + sc * 64 + 32 * hh + 4 * g;
+      const float* dd = dm + sc * 32 + hh * 16 + g * 4;
 #ifndef SPT_EL_NO_NODE
-      lds_dma16(dm + sc * 32 + hh * 16 + g * 4, L + L_DM);
-      lds_dma4(scl + sc, L + L_SC);
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(nq[0]) : "v"(qq) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, off offset:64" : "=v"(nq[1]) : "v"(qq) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ng[0]) : "v"(gg) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, off offset:64" : "=v"(ng[1]) : "v"(gg) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ndm) : "v"(dd) : "memory");
+#else   // measurement variant: no node rows (garbage results)
+      asm volatile("" : "=v"(nq[0]), "=v"(nq[1]), "=v"(ng[0]), "=v"(ng[1]), "=v"(ndm) : "v"(qq), "v"(gg), "v"(dd));
 #endif
     };
+#define SPT_NODE_WAIT(N)                                                              \
+  asm volatile("s_waitcnt vmcnt(" #N ")"                                             \
+               : "+v"(nq[0]), "+v"(nq[1]), "+v"(ng[0]), "+v"(ng[1]), "+v"(ndm)::"memory")
 
-    // ---- prologue: ids of the first two tiles, then the first tile's data -------------------
-    int s0 = 0, s1 = 1, s2 = 2;                  // ring slots of tiles t, t + 1, t + 2
-    issue_ids(t_begin, s0);
-    issue_ids(t_begin + 1, s1);
-    wait_vm<0>();
-    issue_ea(t_begin, s0);
-    issue_gather(s0);
+    // ---- prologue: ids of the first two tiles, the first tile's edge_attr rows (leader), then
+    //      every wave's own gathered rows --------------------------------------------------------
+    if (leader) {
+      issue_ids(t_begin, 0);
+      issue_ids(t_begin + 1, 1);
+      wait_vm<0>();
+      issue_ea(0, 0);
+      wait_vm<0>();
+      flag_set(flg + F_EA, 1);
+    } else {
+      flag_wait(flg + F_EA, 1);
+    }
+    issue_gather(0);
     wait_vm<0>();
 
 #ifdef SPT_ATTN_PROFILE
     uint64_t prof[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t tlast = __builtin_amdgcn_s_memtime();
 #endif
-    for (int64_t t = t_begin; t < t_end; ++t) {
-      // edge_attr rows of tile t and the ids of tile t + 1 have landed; the gathered rows of
-      // tile t and the atomics of tile t - 1 may still be in flight
-      wait_vm<N_KV + N_GATHER + N_GEA>();
+    int k = 0;                                    // tile index within the pair's range
+    for (int64_t t = t_begin; t < t_end; ++t, ++k) {
+      const int s0 = k & 3, s1 = (k + 1) & 3, s2 = (k + 2) & 3;   // id ring slots of tiles k, k+1, k+2
+      if (leader) {
+        // edge_attr rows of tile k and the ids of tile k + 1 have landed; behind them in the queue:
+        // the dk / dv rows of tile k - 1, the gathers of tile k, dq atomics
+        wait_vm<N_KV + N_GATHER>();
+        flag_set(flg + F_EA, k + 1);
+      } else {
+        flag_wait(flg + F_EA, k + 1);
+      }
       SPT_PROBE(0)
-      const float* slab = L + L_EA;
+      const float* slab = P + P_EA + (k & 1) * TE * F;
       // B operand of the recompute GEMM: lane (g, c) holds ea[edge c][8 g .. 8 g + 7]
       bf16x8 Ah, Al;
       {
@@ -410,10 +483,25 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_bwd_el_kernel(
       }
       const int* ids = ids_ring + s0 * 48;
       const int s_c = ids[32 + c];                                    // source node of edge c
-      wait_lds();                                 // the edge_attr slab and slot s0 are consumed
+      wait_lds();                                 // the edge_attr slab is consumed
       SPT_PROBE(1)
-      issue_ea(t + 1, s1);
-      issue_ids(t + 2, s2);
+      // Both roles put exactly TWO requests behind the node rows (leader: the next tile's
+      // edge_attr rows; follower: what gedge_attr holds for this tile - fetched in store mode too,
+      // unused there), so that ONE unbranched counted wait serves both: the wait names the loads'
+      // destination registers, and behind a branch the compiler copies them BEFORE the wait.
+      if (leader) {
+        // slot s2 held tile k - 2: the follower must have finished that tile (it reads the edge
+        // rows last); buffer (k + 1) & 1 held tile k - 1: the follower must have read its operands
+        flag_wait(flg + F_DONE, k - 1);
+        issue_ids(t + 2, s2);
+        issue_node(s0);
+        flag_wait(flg + F_TOP, k);
+        issue_ea(s1, (k + 1) & 1);
+      } else {
+        flag_set(flg + F_TOP, k + 1);
+        issue_node(s0);
+        issue_old(s0);
+      }
       SPT_PROBE(2)
 
       // ---- recompute GEMM, transposed: C[o = 16 b + 4 g + r][e = c] ---------------------------
@@ -462,51 +550,48 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_bwd_el_kernel(
 
       // ---- per-edge gradients, in place: Ck <- dk, Cq <- dq, Cv <- dv -------------------------
       SPT_PROBE(3)
-      wait_vm<N_GEA + N_TOP_MIN>();                  // the gathered rows of tile t have landed
+      // the gathered k / v rows and the node rows of tile k have landed; behind them in the queue:
+      // two requests of this tile's top (see there)
+      SPT_NODE_WAIT(2);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       SPT_PROBE(4)
       {
         const float* Gb = L + L_G + lane * 4;
-        const f32x4 dmv = *reinterpret_cast<const f32x4*>(L + L_DM + lane * 4);
-        const float scale = L[L_SC + lane];
+        const f32x4 dmv = ndm;
         const bool valid = t * TE + c < E;
         {
           int* tb = reinterpret_cast<int*>(L + L_TBL);
           tb[c] = rank;                           // every lane group writes the same values
           tb[16 + rank] = s_c;
-          L[L_TBL + 32 + rank] = scale;
         }
 #pragma unroll
         for (int bl = 0; bl < NBW; ++bl) {
-          const f32x4 kt = *reinterpret_cast<const f32x4*>(Gb + (4 * bl + 0) * 256);
-          const f32x4 vt = *reinterpret_cast<const f32x4*>(Gb + (4 * bl + 1) * 256);
-          const f32x4 qr = *reinterpret_cast<const f32x4*>(Gb + (4 * bl + 2) * 256);
-          const f32x4 gs = *reinterpret_cast<const f32x4*>(Gb + (4 * bl + 3) * 256);
-          float k[4], q[4], v[4];
+          const f32x4 kt = *reinterpret_cast<const f32x4*>(Gb + (2 * bl + 0) * 256);
+          const f32x4 vt = *reinterpret_cast<const f32x4*>(Gb + (2 * bl + 1) * 256);
+          const f32x4 qr = nq[bl];
+          const f32x4 gs = ng[bl];
+          float kk[4], q[4], v[4];
 #pragma unroll
           for (int d = 0; d < 4; ++d) {
-            k[d] = Ck[bl][d] + kt[d];
-            q[d] = fmaf(qr[d], scale, Cq[bl][d]);
+            kk[d] = Ck[bl][d] + kt[d];
+            q[d] = Cq[bl][d] + qr[d];
             v[d] = Cv[bl][d] + vt[d];
           }
-          const float p = fmaf(q[3], k[3], fmaf(q[2], k[2], fmaf(q[1], k[1], q[0] * k[0])));
+          const float p = fmaf(q[3], kk[3], fmaf(q[2], kk[2], fmaf(q[1], kk[1], q[0] * kk[0])));
           const float a = valid ? __expf(p - dmv[2 + bl]) : 0.f;
           const float da = fmaf(gs[3], v[3], fmaf(gs[2], v[2], fmaf(gs[1], v[1], gs[0] * v[0])));
           const float dc = a * (da - dmv[bl]);
 #pragma unroll
           for (int d = 0; d < 4; ++d) {
             Ck[bl][d] = dc * q[d];
-            Cq[bl][d] = dc * k[d];
+            Cq[bl][d] = dc * kk[d];
             Cv[bl][d] = a * gs[d];
           }
         }
-      }
-      // dk / dv rows of the tile's edges, CSR order: row j = [dk (64) | dv (64)], this lane's four
-      // dims of head 4 b + g of edge c - 16-byte non-temporal stores, summed per target later
-      {
-        const int64_t j = pos_of(t, c);
-        float* drow = dkv + j * 128 + 32 * hh + 4 * g;
-        const bool valid = t * TE + c < E;        // rows beyond the edge list own no row
-        if (valid) {
+        // dk / dv rows of the tile's edges, CSR order: row j = [dk (64) | dv (64)], this lane's four
+        // dims of head 4 b + g of edge c - 16-byte non-temporal stores, summed per target later
+        float* drow = dkv + (t * TE + c) * 128 + 32 * hh + 4 * g;
+        if (valid) {                              // rows beyond the edge list own no row
 #pragma unroll
           for (int bl = 0; bl < NBW; ++bl) {
             __builtin_nontemporal_store(Ck[bl], reinterpret_cast<f32x4*>(drow + 16 * bl));
@@ -516,27 +601,26 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_bwd_el_kernel(
       }
       wait_lds();                                 // the gathered rows are consumed
       SPT_PROBE(5)
-      issue_gather(s1);                           // rows of tile t + 1 (its ids landed at the top)
+      issue_gather(s1);                           // rows of tile k + 1 (its ids landed at the top)
       SPT_PROBE(6)
 
       // ---- per projection p (k, q, v), fenced for the scheduler so that one projection's
       //      operands die before the next one's are built:
-      //   (1) split D_p once: packed halves = A operand of  d edge_attr += D_p W_p ; one word
+      //   (1) split D_p once: packed halves = B operand of  d edge_attr^T += W_p^T D_p^T ; one word
       //       (hi << 16 | lo) per value -> LDS
       //   (2) read the words back transposed (lane = output column 16 bl + c, registers = edges
-      //       4 g + i): A operand of  dW_p += D_p^T EA ; k, v: values back in f32 for the atomics on
-      //       the target rows (64-byte runs); q: reduced per source node of the tile on the matrix
-      //       pipe, sum_e S[n][e] dq[e][o]
+      //       4 g + i): A operand of  dW_p += D_p^T EA , and B operand of the reduction per source
+      //       node of the tile on the matrix pipe, sum_e S[n][e] D[e][o]: dq of the nodes (p == 1)
+      //       and, summed over the node rows, the bias gradient of every block
+      // C2[fb][r] = d edge_attr[edge c][16 fb + 4 g + r], the wave's 96 columns' share
       f32x4 C2[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
       f32x4 Cn[NBW];                              // dq per node: Cn[n = 4 g + r][o = 16 b + c]
       i32x4 nd4;
-      f32x4 sc4;
       s16x4 S;                                    // S[n = c][e = 4 g + i] = 1 if edge e belongs to node n
       {
         const int* tb = reinterpret_cast<const int*>(L + L_TBL);
         const i32x4 rk4 = *reinterpret_cast<const i32x4*>(tb + 4 * g);
         nd4 = *reinterpret_cast<const i32x4*>(tb + 16 + 4 * g);
-        sc4 = *reinterpret_cast<const f32x4*>(L + L_TBL + 32 + 4 * g);
 #pragma unroll
         for (int i = 0; i < 4; ++i) S[i] = rk4[i] == c ? (short)0x3F80 : (short)0;
       }
@@ -564,10 +648,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_bwd_el_kernel(
 #pragma unroll
           for (int fb = 0; fb < 2; ++fb) {
             if constexpr (LO) {
-              C2[fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Dl, Wbh[p][fb], C2[fb], 0, 0, 0);
-              C2[fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Dh, Wbl[p][fb], C2[fb], 0, 0, 0);
+              C2[fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wbh[p][fb], Dl, C2[fb], 0, 0, 0);
+              C2[fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wbl[p][fb], Dh, C2[fb], 0, 0, 0);
             }
-            C2[fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Dh, Wbh[p][fb], C2[fb], 0, 0, 0);
+            C2[fb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wbh[p][fb], Dh, C2[fb], 0, 0, 0);
           }
         }
         lds_order();
@@ -589,8 +673,6 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_bwd_el_kernel(
             }
             C3[q6][fb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(Th, Eh[fb], C3[q6][fb], 0, 0, 0);
           }
-          // per source node of the tile on the matrix pipe: sum_e S[n][e] D[e][o] - dq of the nodes
-          // (p == 1) and, summed over the node rows, the bias gradient of every block
           f32x4 Cs = (f32x4){0.f, 0.f, 0.f, 0.f};
           if constexpr (LO) Cs = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(S, Tl, Cs, 0, 0, 0);
           Cs = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(S, Th, Cs, 0, 0, 0);
@@ -601,47 +683,48 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_bwd_el_kernel(
         __builtin_amdgcn_sched_barrier(0);
       }
       SPT_PROBE(7)
-      // d edge_attr rows (both waves of the pair add their halves)
-      {
-        i32x4 e4;                                 // edge rows of edges 4 g + r (slot s0 is still ours)
-        if (eperm) {
-          e4 = *reinterpret_cast<const i32x4*>(ids + 4 * g);
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) e4[r] = (int)pos_of(t, 4 * g + r);
+      // ---- d edge_attr rows: the leader hands its half over, the follower adds (to what the
+      //      buffer holds, in accumulate mode: each row is owned by exactly one tile, so this is a
+      //      plain read-modify-write) and stores 16 bytes per lane --------------------------------
+      if (leader) {
+        flag_wait(flg + F_MBFREE, k);             // the follower has consumed tile k - 1
+        *reinterpret_cast<f32x4*>(P + P_MB + lane * 8) = C2[0];
+        *reinterpret_cast<f32x4*>(P + P_MB + lane * 8 + 4) = C2[1];
+        flag_set(flg + F_MB, k + 1);
+      } else {
+        flag_wait(flg + F_MB, k + 1);
+        C2[0] += *reinterpret_cast<const f32x4*>(P + P_MB + lane * 8);
+        C2[1] += *reinterpret_cast<const f32x4*>(P + P_MB + lane * 8 + 4);
+        flag_set(flg + F_MBFREE, k + 1);
+        wait_vm<N_KV + N_GATHER>();               // the old rows (issued at the top) have landed
+        if (acc) {
+          C2[0] += *reinterpret_cast<const f32x4*>(P + P_GEA + lane * 4);
+          C2[1] += *reinterpret_cast<const f32x4*>(P + P_GEA + 256 + lane * 4);
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float* row = gea + (int64_t)e4[r] * F + c;
-#ifndef SPT_EL_NO_GEA
-          SPT_EL_ADD(row, C2[0][r]);
-          SPT_EL_ADD(row + 16, C2[1][r]);
-#else
-          asm volatile("" :: "v"(C2[0][r]), "v"(C2[1][r]), "v"(row));
-#endif
+        float* row = gea + (int64_t)ids[c] * F + 4 * g;
+        if (t * TE + c < E) {                     // rows beyond the edge list own no row (only the
+          *reinterpret_cast<f32x4*>(row) = C2[0];        // last tile of the edge list has any: no later
+          *reinterpret_cast<f32x4*>(row + 16) = C2[1];   // iteration counts on these two stores)
         }
       }
-      // dq of the tile's nodes (the only data-dependent memory instructions: issued last)
+      // dq of the tile's nodes, unscaled (the reduction pass applies the node's qk scale); the
+      // only data-dependent memory instructions: issued last
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         if (4 * g + r < nn) {
           float* row = gqkv + (int64_t)nd4[r] * LD + 32 * hh + c;
 #pragma unroll
-          for (int bl = 0; bl < NBW; ++bl) unsafeAtomicAdd(row + 16 * bl, Cn[bl][r] * sc4[r]);
+          for (int bl = 0; bl < NBW; ++bl) unsafeAtomicAdd(row + 16 * bl, Cn[bl][r]);
         }
       }
+      if (!leader) flag_set(flg + F_DONE, k + 1);
       SPT_PROBE(8)
-      // rotate the id ring
-      const int s_old = s0;
-      s0 = s1;
-      s1 = s2;
-      s2 = s_old;
       lds_order();
     }
 #ifdef SPT_ATTN_PROFILE
-    if (lane == 0 && (wave == 5 || wave == 1030))
+    if (lane == 0 && (wave == 4 || wave == 5 || wave == 1030))
       printf("attn_bwd_el wave %ld tiles %ld cycles: topwait %lu operands %lu issue_top %lu regemm+rank %lu "
-             "gwait %lu core %lu issue_g %lu rounds %lu tail-atomics %lu\n", (long)wave,
+             "gwait %lu core %lu issue_g %lu rounds %lu tail %lu\n", (long)wave,
              (long)(t_end - t_begin), (unsigned long)prof[0], (unsigned long)prof[1],
              (unsigned long)prof[2], (unsigned long)prof[3], (unsigned long)prof[4],
              (unsigned long)prof[5], (unsigned long)prof[6], (unsigned long)prof[7],
@@ -673,51 +756,69 @@ constexpr int ATTN_EL_MAX_PAIRS = 1024;     // 256 workgroups of 4 pairs: one wo
 
 size_t attn_bwd_el_workspace_bytes(int64_t n, int64_t e) {
   const size_t ee = (size_t)(e > 0 ? e : 1);
-  return align_up((size_t)n * 32 * 4, 256) + align_up((size_t)n * 4, 256) +
-         align_up(ee * 4, 256) + align_up(ee * 128 * 4, 256);
+  const size_t ntiles = (ee + el::TE - 1) / el::TE;
+  return align_up((size_t)n * 32 * 4, 256) + align_up((size_t)n * 64 * 4, 256) +
+         align_up((size_t)n * 4, 256) + align_up(ee * 4, 256) + align_up(ntiles * 48 * 4, 256) +
+         align_up(ee * 128 * 4, 256);
 }
 
 // returns the number of partial tables written (<= ATTN_EL_MAX_PAIRS).  gqkv needs no
-// initialisation: the q columns are zero-filled by the prep kernel (dq is added per tile and node),
-// the k / v columns are written by the reduction.
+// initialisation: the q columns are zero-filled by the prep kernel (dq is added per tile and node)
+// and scaled by the reduction, which writes the k / v columns.
+void attn_pack_tile_ids_launch(const int32_t* eperm, const int32_t* tgt, const int32_t* src,
+                               int64_t e, int32_t* ids3, hipStream_t stream) {
+  const int64_t ntiles = ceil_div(e, (int64_t)el::TE);
+  if (ntiles > 0)
+    el::pack_tile_ids_kernel<<<(int)ceil_div(ntiles * 48, 256), 256, 0, stream>>>(eperm, tgt, src, e,
+                                                                                  ntiles, ids3);
+}
+
 int attn_bwd_el_launch(const float* qkv, int64_t n, const int32_t* erowptr, const int32_t* eperm,
-                       const int32_t* tgt, const int32_t* src, const int32_t* tperm,
-                       const int32_t* trowptr, int64_t e, const float* ea,
+                       const int32_t* tgt, const int32_t* src, const int32_t* tile_ids,
+                       const int32_t* tperm, const int32_t* trowptr, int64_t e, const float* ea,
                        const float* Wk, const float* bk, const float* Wq, const float* bq,
                        const float* Wv, const float* bv, int scale_mode, float scale_a,
                        const float* out, const float* m, const float* z, const float* gout,
-                       float* gqkv, float* gea, float* partial, void* ws, int prec,
+                       float* gqkv, float* gea, int gea_acc, float* partial, void* ws, int prec,
                        hipStream_t stream) {
+  const int64_t ntiles = ceil_div(e, (int64_t)el::TE);
   char* w = (char*)ws;
   float* dm = (float*)w;
   w += align_up((size_t)n * 32 * 4, 256);
+  float* qs = (float*)w;
+  w += align_up((size_t)n * 64 * 4, 256);
   float* scl = (float*)w;
   w += align_up((size_t)n * 4, 256);
   int32_t* srcbuf = (int32_t*)w;
   w += align_up((size_t)(e > 0 ? e : 1) * 4, 256);
+  int32_t* ids3 = (int32_t*)w;
+  w += align_up((size_t)ntiles * 48 * 4, 256);
   float* dkv = (float*)w;
   el::attn_bwd_prep_kernel<<<(int)ceil_div(n * 16, 256), 256, 0, stream>>>(
-      gout, out, m, z, erowptr, n, scale_mode, scale_a, dm, scl, gqkv);
-  if (!src) {
-    el::expand_rowptr_kernel<<<(int)ceil_div(n, 256), 256, 0, stream>>>(erowptr, n, srcbuf);
-    src = srcbuf;
+      qkv, gout, out, m, z, erowptr, n, scale_mode, scale_a, dm, qs, scl, gqkv);
+  if (!tile_ids) {
+    if (!src) {
+      el::expand_rowptr_kernel<<<(int)ceil_div(n, 256), 256, 0, stream>>>(erowptr, n, srcbuf);
+      src = srcbuf;
+    }
+    attn_pack_tile_ids_launch(eperm, tgt, src, e, ids3, stream);
+    tile_ids = ids3;
   }
-  const int64_t ntiles = ceil_div(e, (int64_t)el::TE);
   int64_t pairs = ntiles < ATTN_EL_MAX_PAIRS ? ntiles : ATTN_EL_MAX_PAIRS;
   const int64_t tpw = ceil_div(ntiles, pairs);
   pairs = ceil_div(ntiles, tpw);
   const int grid = (int)ceil_div(pairs, el::WAVES / 2);
   if (prec == 3)
     el::attn_bwd_el_kernel<3><<<grid, el::WAVES * 64, 0, stream>>>(
-        qkv, e, eperm, tgt, src, ntiles, tpw, ea, Wk, bk, Wq, bq, Wv, bv, dm, scl, gout, gqkv, gea,
+        qkv, e, tile_ids, ntiles, tpw, ea, Wk, bk, Wq, bq, Wv, bv, dm, qs, gout, gqkv, gea, gea_acc,
         dkv, partial);
   else
     el::attn_bwd_el_kernel<1><<<grid, el::WAVES * 64, 0, stream>>>(
-        qkv, e, eperm, tgt, src, ntiles, tpw, ea, Wk, bk, Wq, bq, Wv, bv, dm, scl, gout, gqkv, gea,
+        qkv, e, tile_ids, ntiles, tpw, ea, Wk, bk, Wq, bq, Wv, bv, dm, qs, gout, gqkv, gea, gea_acc,
         dkv, partial);
   const int64_t rblocks = ceil_div(n, (int64_t)8);
   el::attn_kv_reduce_kernel<<<(int)(rblocks < 256 * 16 ? rblocks : 256 * 16), 256, 0, stream>>>(
-      dkv, tperm, trowptr, n, gqkv);
+      dkv, tperm, trowptr, scl, n, gqkv);
   return grid * (el::WAVES / 2);
 }
 

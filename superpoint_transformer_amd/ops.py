@@ -464,15 +464,17 @@ class _EdgeAttention(torch.autograd.Function):
         gps = [torch.empty_like(t) if t is not None else None for t in ps]
         nb = _lib.lib.spt_edge_attn_bwd_ex_workspace_bytes(n, ecsr.e, H, D, Dv, max(F, 1))
         ws = _workspace(nb, dev)
-        src = tperm = trowptr = None
+        src = tids = tperm = trowptr = None
         if ea is not None and ecsr.e > 0 and _lib.lib.spt_edge_attn_bwd_el_supported(H, D, Dv, F):
             src = ecsr.src_sorted()
+            tids = ecsr.tile_ids()
             tv = ecsr.target_view()
             tperm, trowptr = tv.perm, tv.rowptr
         with torch.cuda.device(dev):
             st = _lib.lib.spt_edge_attn_bwd_ex_f32(
                 _lib.ptr(q2), n, H, D, Dv, _lib.ptr(ecsr.erowptr), _lib.ptr(ecsr.eperm),
-                _lib.ptr(ecsr.tgt_sorted), _lib.ptr(src), _lib.ptr(tperm), _lib.ptr(trowptr),
+                _lib.ptr(ecsr.tgt_sorted), _lib.ptr(src), _lib.ptr(tids), _lib.ptr(tperm),
+                _lib.ptr(trowptr),
                 ecsr.e, _lib.ptr(ea), F,
                 *[_lib.ptr(t) for t in ps], scale_mode, scale_a, _lib.ptr(out),
                 _lib.ptr(m), _lib.ptr(z), _lib.ptr(g), _lib.ptr(gqkv), _lib.ptr(gea), acc,
