@@ -26,7 +26,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
 def parse():
     p = argparse.ArgumentParser()
-    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--gpus", type=int, default=None,
+                   help="ranks = GPUs of this node (default: WORLD_SIZE when a launcher set it, else 1)")
     p.add_argument("--steps", type=int, default=10)
     p.add_argument("--warmup", type=int, default=3)
     p.add_argument("--settle", type=float, default=3.0,
@@ -34,6 +35,8 @@ def parse():
     p.add_argument("--scene", default="S")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-preprocess", action="store_true")
+    p.add_argument("--no-f32-exact", action="store_true",
+                   help="skip the 5 extra steps that time the f32-matrix-pipe variant of the step")
     p.add_argument("--cpu-scale", type=float, default=None)
     p.add_argument("--stages", default="all")
     p.add_argument("--mode", default="train", choices=["train", "infer", "panoptic"],
@@ -87,7 +90,7 @@ def cpu_baseline(scene, scale):
             break
     dt = sorted(times)[len(times) // 2]
     return {"value": round(n[0] / dt / 1e6, 4), "unit": "Mpoints/s",
-            "cores": torch.get_num_threads(), "kind": "port",
+            "cores": os.cpu_count(), "threads_used": torch.get_num_threads(), "kind": "port",
             "sample": f"scene {scene} scaled x{scale:.4g}: N=({n[0]},{n[1]},{n[2]}), median of "
                       f"{len(times)} reps of SPT-64 fwd+loss+bwd on torch-CPU f32 via oracle/spt_model.py",
             "cut_pursuit": "not timed - dependency unavailable (the reference's CPU partition is "
@@ -152,7 +155,7 @@ def cpu_preprocess_baseline(scene, n_sample=6000):
     O.geometric_features(pos.double(), nb, k_min=1)
     dt = time.perf_counter() - t0
     return {"value": round(n_sample / dt / 1e6, 5), "unit": "Mpoints/s",
-            "cores": torch.get_num_threads(), "kind": "port",
+            "cores": os.cpu_count(), "threads_used": torch.get_num_threads(), "kind": "port",
             "sample": f"{n_sample} points, exhaustive kNN + eigenfeatures via oracle/spt_oracle.py"}
 
 
@@ -180,10 +183,14 @@ def launch_ranks(args):
 
 def main():
     args = parse()
+    if args.gpus is None:
+        # under torchrun / an external launcher WORLD_SIZE decides; alone, one GPU
+        args.gpus = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         launch_ranks(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
+        # only an EXPLICIT --gpus that contradicts the launcher is an error
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -196,8 +203,16 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # SPT_FORCE_COLLECTIVES=1: initialise the process group (RCCL) and run the gradient all-reduce
+    # even with ONE rank - proves nothing about scaling, but executes the collective path on a
+    # one-GPU box (tests/test_rccl_gpu.py)
+    force_dist = os.environ.get("SPT_FORCE_COLLECTIVES") == "1"
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if force_dist and world == 1:
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if not share and torch.cuda.device_count() < world:
             raise SystemExit(f"bench.py: --gpus {world} needs {world} visible devices, "
                              f"found {torch.cuda.device_count()}")
@@ -236,7 +251,7 @@ def main():
     path.reset_kernel_timers()
 
     def barrier():
-        if world > 1:
+        if world > 1 or force_dist:
             if share:
                 dist.barrier()
             else:
@@ -256,6 +271,22 @@ def main():
     value = world * n0 * args.steps / dt / 1e6
     roof = path.roofline(HBM_PEAK_GBS)
     workload = path.describe(args.scene, SCENES.get(args.scene))
+
+    # The default "f32" mode runs the attention GEMMs and the fused layers' backward GEMMs as three
+    # bf16 products per f32 product (~10 ulp of f32; every f32 parity bar holds): print what the
+    # same step costs on the f32 matrix pipe everywhere next to it (untimed for `value`).
+    exact_ms = None
+    if args.dtype == "f32" and world == 1 and args.mode == "train" and not args.no_f32_exact:
+        precision.set_matrix_precision("f32-exact")
+        for _ in range(2):
+            path.step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            path.step()
+        torch.cuda.synchronize()
+        exact_ms = (time.perf_counter() - t1) / 3 * 1e3
+        precision.set_matrix_precision(args.dtype)
 
     cpu = None
     pre = None
@@ -286,8 +317,11 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": {"f32": "f32", "f32-exact": "f32",
+            "dtype": {"f32": "f32 (bf16x3 matrix operands: hi*hi + lo*hi + hi*lo per f32 product, f32 "
+                             "accumulate, storage and statistics)",
+                      "f32-exact": "f32 (f32 matrix pipe)",
                       "bf16": "bf16 (matrix operands; f32 accumulate, storage and statistics)"}[args.dtype],
+            "ms_per_step_f32_exact": round(exact_ms, 4) if exact_ms else None,
             "data": "synthetic",
             "config": {
                 "workload": workload,
@@ -302,7 +336,7 @@ def main():
             "preprocess": pre,
         }
         print(json.dumps(line))
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

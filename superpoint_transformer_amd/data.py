@@ -158,6 +158,14 @@ class Data:
     (cluster of each node in the level above), ``sub`` (Cluster over the level below)."""
 
     _NODE_HINT = ("pos", "x", "rgb", "y", "super_index", "node_size", "normal")
+    # attributes that read as None when absent: the reference's Data answers None for its own
+    # optional properties (src/data/data.py:64-101) and PyG's Data for x / y / edge_index /
+    # edge_attr, and callers test `data.obj_pos is None` (a transform that assigns None to a
+    # key leaves it absent here: __setattr__ pops it)
+    _OPTIONAL = frozenset((
+        "pos", "rgb", "obj", "semantic_pred", "neighbor_index", "sub", "super_index",
+        "v_edge_attr", "x", "y", "edge_index", "edge_attr", "batch", "obj_pos",
+        "obj_edge_index", "obj_edge_affinity", "node_size", "normal"))
 
     def __init__(self, **attrs):
         object.__setattr__(self, "_store", {})
@@ -169,6 +177,8 @@ class Data:
         store = object.__getattribute__(self, "_store")
         if key in store:
             return store[key]
+        if key in Data._OPTIONAL:
+            return None
         raise AttributeError(key)
 
     def __setattr__(self, key, value):

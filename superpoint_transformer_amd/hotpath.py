@@ -11,6 +11,8 @@ RCCL (``parallel.FlatGradAllReduce``).
 ``ScatterChain``: only the hierarchical segment-CSR scatter kernels (max pool
 fwd/bwd L0->L1->L2 + unpool fwd/bwd), kept as a kernel-level benchmark.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -63,8 +65,8 @@ def spt128_config(point_in=8, edge_in=18):
 
 
 def _pmc_traffic(timer_name):
-    """HBM bytes per launch of the roofline kernel as measured with rocprofv3 PMC
-    counters on this exact shape (profiles/traffic.json; FETCH_SIZE doubled per
+    """HBM bytes per launch of a roofline kernel as measured with rocprofv3 PMC counters on this
+    exact shape (profiles/traffic.json: {"bytes", "source", ...}; FETCH_SIZE doubled per
     MI355X_MICROARCH.md's gfx950 correction).  None when no capture exists."""
     import json
     import os
@@ -72,7 +74,7 @@ def _pmc_traffic(timer_name):
                         "profiles", "traffic.json")
     try:
         with open(path) as f:
-            return json.load(f).get(timer_name, {}).get("bytes")
+            return json.load(f).get(timer_name) or None
     except (OSError, ValueError):
         return None
 
@@ -155,7 +157,8 @@ class SPTTrainStep:
                                                          nag[1]["edge_attr"].shape[1])).to(dev)
         self.params = [p for p in self.model.parameters()]
         parallel.broadcast_parameters(self.params, src=0)
-        self.bucket = parallel.FlatGradAllReduce(self.params)
+        self.bucket = parallel.FlatGradAllReduce(
+            self.params, always=os.environ.get("SPT_FORCE_COLLECTIVES") == "1")
         # one multi-tensor kernel for the 130 parameter tensors (matters at train-batch sizes,
         # where the step is launch-bound)
         self.opt = torch.optim.AdamW(self.params, lr=1e-3, weight_decay=1e-4,
@@ -168,17 +171,36 @@ class SPTTrainStep:
         n0, c = self.n[0], 128
         self.tname = f"segcsr_reduce_fwd:3:{n0}x{c}"
         ops.enable_timer(self.tname)
+        self._enable_kernel_timers()
         self.last_loss = None
+
+    def _enable_kernel_timers(self):
+        """HIP-event timers (launch stream) around the ops whose kernels lead the step's GPU time."""
+        n1 = self.n[1]
+        e1 = self.nag.levels[1]["edge_index"].shape[1]
+        self.k_timers = {
+            "attn_bwd": f"edge_attn_bwd:{n1}:{e1}",
+            "attn_fwd": f"edge_attn_fwd:{n1}:{e1}",
+            "mlp_bwd_pooled": "fused_linear_bwd_pooled:64x128:",
+            "mlp_fwd": "fused_linear_fwd:64x128:",
+        }
+        for key, name in self.k_timers.items():
+            ops.enable_timer(name, prefix=key.startswith("mlp"))
+        self.level1 = (n1, e1)
 
     def reset_kernel_timers(self):
         ops.reset_timers()
+        self._timed_steps = 0
 
     def _forget_csr(self):
         for lv in self.nag.levels:
             _csr.forget(lv.get("super_index"), lv.get("edge_index"), lv.get("batch"))
 
+    _timed_steps = 0
+
     def step(self):
         self._forget_csr()
+        self._timed_steps += 1
         logits = self.model(self.nag)
         loss = sum(l * self.loss_fn(lg, y) for l, lg, y in zip(self.lambdas, logits, self.labels))
         self.bucket.zero()
@@ -189,20 +211,64 @@ class SPTTrainStep:
         return loss
 
     def roofline(self, peak_gbs):
+        """North-star entry (the L0->L1 segment-CSR max) + `kernels`: the ops leading the step's
+        GPU time, each with its SURVEY 8(d) algorithmic bytes / FLOPs per launch and the mean
+        duration measured with HIP events on the launch stream over the timed steps."""
         n0, n1 = self.n[0], self.n[1]
         c = getattr(self, "pool_c", 128)
         bytes_ = n0 * (4 * c + 4) + n1 * (8 * c + 4)
         ms = ops.timer_mean_ms(self.tname)
         ach = bytes_ / (ms * 1e-3) / 1e9 if ms else None
-        return {"bound": "hbm", "kernel": f"segcsr_reduce_kernel<MAX,VEC4,ARG> L0->L1 C={c} (in the train step: with the "
-                          "point MLP's last GraphNorm + LeakyReLU applied on the fly)",
+        traffic = _pmc_traffic(self.tname)
+        roof = {"bound": "hbm",
+                "kernel": "spt::segmax_stream_kernel<true> (L0->L1 segment max + arg, C=%d, the point MLP's "
+                          "last GraphNorm + LeakyReLU applied on the fly)" % c
+                if c == 128 and n0 >= 65536 else "spt::segcsr_reduce_kernel<3, 4, true> (L0->L1 segment max + arg)",
                 "achieved": round(ach, 1) if ach else None, "peak": peak_gbs,
                 "unit": "GB/s", "frac": round(ach / peak_gbs, 4) if ach else None,
-                "traffic": _pmc_traffic(self.tname),
-                "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an "
-                                  "earlier visit on this shape; a committed constant, not a live counter)",
+                "traffic": traffic.get("bytes") if traffic else None,
+                "traffic_source": traffic.get("source") if traffic else None,
                 "bytes_per_launch": bytes_,
                 "ms_per_launch": round(ms, 4) if ms else None}
+        kernels = []
+        if getattr(self, "k_timers", None):
+            n1, e1 = self.level1
+            f32_matrix_tf = 157.3                      # MI355X_MICROARCH.md: f32-in MFMA = f32 vector peak
+            rows = n0
+            spec = {
+                # SURVEY 8(d) a6: backward 264 B/edge + 2 176 B/node, ~37.4 kFLOP/edge (3 GEMMs of the
+                # forward's 12.3 kFLOP + the per-edge math); forward 136 B/edge + 1 156 B/node, 12.6 kFLOP
+                "attn_bwd": ("spt::el::attn_bwd_el_kernel<3> + spt::el::attn_kv_reduce_kernel + "
+                             "spt::el::attn_bwd_prep_kernel + spt::attn_reduce_partials_kernel (one level-1 "
+                             "attention backward: all kernels of the call)",
+                             264 * e1 + 2176 * n1, 37.4e3 * e1),
+                "attn_fwd": ("spt::mfma::attn_fwd_mfma_kernel<3> (one level-1 attention forward)",
+                             136 * e1 + 1156 * n1, 12.6e3 * e1),
+                # fused tall-MLP layers, 64 -> 128 at level 0: forward reads x (4K) writes h (4N) per row;
+                # pooled backward reads h (4N) + x (4K), writes gx (4K) per row, + (gout, arg) per segment
+                "mlp_bwd_pooled": ("spt::fmlp::bwd_kernel_bf<16, 8, true, 8, true, true, false> (64 -> 128 "
+                                   "backward of the point MLP's top layer with the L0->L1 pool's backward inside)",
+                                   rows * (4 * 128 + 8 * 64) + n1 * 1024, 2 * 2 * 64 * 128 * rows),
+                "mlp_fwd": ("spt::fmlp::fwd_kernel<16, 8> (64 -> 128 forward)",
+                            rows * 4 * (64 + 128), 2 * 64 * 128 * rows),
+            }
+            for key, (kname, kbytes, kflops) in spec.items():
+                tms = ops.timer_mean_ms(self.k_timers[key])
+                if not tms:
+                    continue
+                gbs = kbytes / (tms * 1e-3) / 1e9
+                tfs = kflops / (tms * 1e-3) / 1e12
+                tr = _pmc_traffic(key)
+                kernels.append({
+                    "kernel": kname, "ms_per_launch": round(tms, 4),
+                    "launches_per_step": ops.timer_count(self.k_timers[key]) // max(self._timed_steps, 1),
+                    "bytes_per_launch": int(kbytes), "achieved": round(gbs, 1), "unit": "GB/s",
+                    "frac": round(gbs / peak_gbs, 4),
+                    "flops_per_launch": float(kflops), "achieved_tflops": round(tfs, 2),
+                    "frac_f32_matrix_peak": round(tfs / f32_matrix_tf, 4),
+                    "traffic": tr.get("bytes") if tr else None})
+        roof["kernels"] = kernels
+        return roof
 
     def describe(self, scene, sizes):
         return f"{self.name}; synthetic NAG scene {scene} (N0,N1,N2,E1,E2,clouds)={sizes}"

@@ -15,10 +15,19 @@ _OPS = {"sum": 0, "add": 0, "mean": 1, "min": 2, "max": 3}
 # Optional per-kernel HIP-event timers (bench.py's roofline leg): name -> list
 # of (start, end) events recorded on the stream the kernel is launched on.
 _TIMERS = {}
+_TIMER_PREFIXES = []
 
 
-def enable_timer(name):
+def enable_timer(name, prefix=False):
+    """Record a HIP event pair (torch's current stream = the launch stream) around every call site
+    named ``name`` (``prefix=True``: every site whose name starts with it, pooled under it)."""
     _TIMERS[name] = []
+    if prefix and name not in _TIMER_PREFIXES:
+        _TIMER_PREFIXES.append(name)
+
+
+def timer_count(name):
+    return len(_TIMERS.get(name) or [])
 
 
 def timer_mean_ms(name):
@@ -37,6 +46,11 @@ def reset_timers():
 class _timed:
     def __init__(self, name):
         self.rec = _TIMERS.get(name)
+        if self.rec is None and _TIMER_PREFIXES:
+            for p in _TIMER_PREFIXES:
+                if name.startswith(p):
+                    self.rec = _TIMERS[p]
+                    break
 
     def __enter__(self):
         if self.rec is not None:
@@ -422,7 +436,7 @@ class _EdgeAttention(torch.autograd.Function):
         out = torch.empty((n, H * Dv), dtype=torch.float32, device=dev)
         m = torch.empty((n, H), dtype=torch.float32, device=dev)
         z = torch.empty((n, H), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with torch.cuda.device(dev), _timed(f"edge_attn_fwd:{n}:{ecsr.e}"):
             st = _lib.lib.spt_edge_attn_fwd_f32(
                 _lib.ptr(q2), n, H, D, Dv, _lib.ptr(ecsr.erowptr), _lib.ptr(ecsr.eperm),
                 _lib.ptr(ecsr.tgt_sorted), ecsr.e, _lib.ptr(ea), F,
@@ -470,7 +484,7 @@ class _EdgeAttention(torch.autograd.Function):
             tids = ecsr.tile_ids()
             tv = ecsr.target_view()
             tperm, trowptr = tv.perm, tv.rowptr
-        with torch.cuda.device(dev):
+        with torch.cuda.device(dev), _timed(f"edge_attn_bwd:{n}:{ecsr.e}"):
             st = _lib.lib.spt_edge_attn_bwd_ex_f32(
                 _lib.ptr(q2), n, H, D, Dv, _lib.ptr(ecsr.erowptr), _lib.ptr(ecsr.eperm),
                 _lib.ptr(ecsr.tgt_sorted), _lib.ptr(src), _lib.ptr(tids), _lib.ptr(tperm),
@@ -761,11 +775,12 @@ def _fmlp_forward(x, batch, ranges, eps_list, slope_list, params, apply_last=Tru
                 pa = ps = pb = None
                 if pre is not None:
                     pa, ps, pb = pre[0][g], pre[1][g], pre[2]
-                st = _lib.lib.spt_fused_linear_fwd_f32(
-                    _lib.ptr(cur), ranges[g], ranges[g + 1], K, _lib.ptr(Ws[l]), N,
-                    _lib.ptr(pa), _lib.ptr(ps), _lib.ptr(pb),
-                    float(slope_list[l - 1]) if l else 1.0, _lib.ptr(h),
-                    _lib.ptr(total[g]), _lib.ptr(ws), ws.numel(), sp)
+                with _timed(f"fused_linear_fwd:{K}x{N}:{ranges[g + 1] - ranges[g]}"):
+                    st = _lib.lib.spt_fused_linear_fwd_f32(
+                        _lib.ptr(cur), ranges[g], ranges[g + 1], K, _lib.ptr(Ws[l]), N,
+                        _lib.ptr(pa), _lib.ptr(ps), _lib.ptr(pb),
+                        float(slope_list[l - 1]) if l else 1.0, _lib.ptr(h),
+                        _lib.ptr(total[g]), _lib.ptr(ws), ws.numel(), sp)
                 _lib.check(st, "spt_fused_linear_fwd_f32")
             mean = torch.empty((B, N), dtype=torch.float32, device=dev)
             rstd, am, sc = (torch.empty_like(mean) for _ in range(3))
@@ -845,15 +860,16 @@ def _fmlp_backward(saved, meta, gy, top_total=None, pooled=None):
                     pa, ps, pb = pre[2][g], pre[3][g], gnb[l - 1]
                 if pooled is not None and l == L - 1:
                     p_gout, p_arg, p_csr = pooled
-                    st = _lib.lib.spt_fused_linear_bwd_pooled_f32(
-                        _lib.ptr(p_gout), _lib.ptr(p_arg), _lib.ptr(p_csr.perm),
-                        _lib.ptr(p_csr.pos_seg()), _lib.ptr(hs[l]), ranges[g], ranges[g + 1], N,
-                        _lib.ptr(am[g]), _lib.ptr(sc[g]), _lib.ptr(gnb[l]), float(slopes[l]),
-                        _lib.ptr(c1[g]), _lib.ptr(c2[g]), _lib.ptr(c3[g]), _lib.ptr(xprev), K,
-                        _lib.ptr(pa), _lib.ptr(ps), _lib.ptr(pb),
-                        float(slopes[l - 1]) if l else 1.0, _lib.ptr(Ws[l]), _lib.ptr(gx),
-                        _lib.ptr(gW), 1 if g else 0, _lib.ptr(ptot[g]) if l else None,
-                        _lib.ptr(ws), ws.numel(), sp)
+                    with _timed(f"fused_linear_bwd_pooled:{K}x{N}:{ranges[g + 1] - ranges[g]}"):
+                        st = _lib.lib.spt_fused_linear_bwd_pooled_f32(
+                            _lib.ptr(p_gout), _lib.ptr(p_arg), _lib.ptr(p_csr.perm),
+                            _lib.ptr(p_csr.pos_seg()), _lib.ptr(hs[l]), ranges[g], ranges[g + 1], N,
+                            _lib.ptr(am[g]), _lib.ptr(sc[g]), _lib.ptr(gnb[l]), float(slopes[l]),
+                            _lib.ptr(c1[g]), _lib.ptr(c2[g]), _lib.ptr(c3[g]), _lib.ptr(xprev), K,
+                            _lib.ptr(pa), _lib.ptr(ps), _lib.ptr(pb),
+                            float(slopes[l - 1]) if l else 1.0, _lib.ptr(Ws[l]), _lib.ptr(gx),
+                            _lib.ptr(gW), 1 if g else 0, _lib.ptr(ptot[g]) if l else None,
+                            _lib.ptr(ws), ws.numel(), sp)
                     _lib.check(st, "spt_fused_linear_bwd_pooled_f32")
                     continue
                 st = _lib.lib.spt_fused_linear_bwd_f32(

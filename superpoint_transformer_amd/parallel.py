@@ -40,9 +40,12 @@ class FlatGradAllReduce:
     """All gradients of ``params`` as views into one flat f32 buffer; ``reduce()``
     averages it over the ranks with ONE collective."""
 
-    def __init__(self, params, group=None):
+    def __init__(self, params, group=None, always=False):
+        """``always``: run the collective even in a one-rank group (exercises the RCCL path on a
+        one-GPU box; a sum over one rank leaves the buffer unchanged)."""
         self.params = [p for p in params if p.requires_grad]
         self.group = group
+        self.always = bool(always)
         total = sum(p.numel() for p in self.params)
         dev = self.params[0].device if self.params else torch.device("cpu")
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
@@ -59,7 +62,7 @@ class FlatGradAllReduce:
         self.flat.zero_()
 
     def reduce(self):
-        if self.world > 1:
+        if self.world > 1 or (self.always and dist.is_initialized()):
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
             self.flat.div_(self.world)
         return self.flat

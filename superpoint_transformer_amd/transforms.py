@@ -378,7 +378,11 @@ class OnTheFlyInstanceGraph:
         # position of each segment's target object: objects' centroids estimated at
         # ``centroid_level``, looked up through a common dense numbering of the object ids
         i_level = min(self.centroid_level, nag.num_levels - 1)
-        obj_pos, obj_idx = nag[i_level].estimate_instance_centroid(mode=self.centroid_mode)
+        # 'ratio-product' is the transform's name (transforms/instance.py:101-119) for what
+        # InstanceData.estimate_centroid implements as 'product-iou' (data/instance.py:337): the
+        # reference forwards the string unchanged and raises there; it is mapped here
+        mode = "product-iou" if self.centroid_mode == "ratio-product" else self.centroid_mode
+        obj_pos, obj_idx = nag[i_level].estimate_instance_centroid(mode=mode)
         sp_obj_idx = data.obj.major(num_classes=self.num_classes)[0]
         joint = torch.cat((sp_obj_idx, obj_idx))
         dense = _consecutive(joint)[0]

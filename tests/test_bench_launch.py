@@ -41,3 +41,15 @@ def test_gpus_2_spawns_two_ranks_share_gpu():
     assert out["n_gpus"] == 2
     assert out["config"]["parallelism"] == "dp2"
     assert out["value"] > 0
+
+
+def test_world_size_from_the_launcher_is_taken_when_gpus_is_not_given():
+    """`torchrun --nproc-per-node=2 bench.py` (no --gpus): the ranks must run, not exit on a
+    mismatch with a default of 1 (here they stop at the missing GPU, a different message)."""
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT="29999", CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="")
+    r = subprocess.run([sys.executable, BENCH, "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    msg = (r.stdout + r.stderr)
+    assert "launcher started" not in msg
+    assert r.returncode != 0 and "MI355X" in msg
