@@ -82,6 +82,17 @@ int spt_segcsr_reduce_f32(int op, const float* x, const int32_t* perm,
  * SPT_SEG_STREAM=0 in the environment or 0 here = the lane-group-per-segment kernel for every
  * shape).  Bit-identical results.  Returns the previous setting. */
 int spt_segcsr_use_stream(int on);
+/* Same two entries with the formulation chosen PER CALL (-1: process default, 0: lane group per
+ * segment, 1: row-streaming where it applies); they touch no process-wide state. */
+int spt_segcsr_reduce_ex_f32(int op, const float* x, const int32_t* perm,
+                             const int32_t* rowptr, int64_t n, int64_t num_seg,
+                             int c, float* out, int32_t* arg, int formulation,
+                             spt_stream_t stream);
+int spt_segcsr_max_affine_ex_f32(const float* x, const int32_t* perm, const int32_t* rowptr,
+                                 int64_t n, int64_t num_seg, int c, const float* am,
+                                 const float* scale, const float* bias, float act_slope,
+                                 const int64_t* seg_graph, float* out, int32_t* arg,
+                                 int formulation, spt_stream_t stream);
 
 /* Backward of the above w.r.t. x (a2):
  *   SUM : gx[i,:] = gout[idx[i],:]
@@ -280,9 +291,9 @@ int spt_edge_attn_fwd_ex_f32(const float* qkv, int64_t n, int H, int D, int Dv,
                              float scale_a, float* out, float* m, float* z, int mode,
                              spt_stream_t stream);
 size_t spt_edge_attn_bwd_ex_workspace_bytes(int64_t n, int64_t e, int H, int D, int Dv, int F);
-/* 1 when the edge-lane backward is built for this head layout AND the process defaults select it
- * (a caller uses it to decide whether to build the target view). */
-int spt_edge_attn_bwd_el_supported(int H, int D, int Dv, int F);
+/* 1 when the edge-lane backward is built for this head layout AND `mode` (< 0: the process
+ * defaults) selects it (a caller uses it to decide whether to build the target view). */
+int spt_edge_attn_bwd_el_supported(int H, int D, int Dv, int F, int mode);
 /* [ceil(e / 16)][48] int32 tile records of the edge-lane backward (edge rows | targets | sources of
  * 16 consecutive CSR positions): depends on the graph only, built once per batch and level by the
  * caller (tile_ids = NULL: rebuilt in the workspace on every call). */
@@ -327,6 +338,13 @@ size_t spt_grid_knn_workspace_bytes(int64_t ns, int64_t ncells);
  * call).  spt_knn_use_cell_path(0|1) selects process-wide and returns the previous
  * setting; tests cross-check the two bit for bit. */
 int spt_knn_use_cell_path(int on);
+/* spt_grid_knn_f32 with the formulation chosen per call (-1: process default, 0: one wave per
+ * query, 1: cell-centric self-search where it applies). */
+int spt_grid_knn_ex_f32(const float* query, int64_t nq, const float* search, int64_t ns,
+                        int K, float r, float cell_size, const float* origin,
+                        const int32_t* dims, int order_queries_by_cell, int inclusive,
+                        int squared, int64_t* idx, float* dist, int32_t* cell_order,
+                        int formulation, void* ws, size_t ws_bytes, spt_stream_t stream);
 /* Bounding box of a cloud, the input of the host-side grid description above
  * (src/utils/neighbors.py has no counterpart: FRNN derives its grid internally).
  * lo_hi: DEVICE float[12]; [0..3) = min, [3..6) = max, [6..12) scratch. */
@@ -632,6 +650,29 @@ int spt_fused_linear_bwd_f32(const float* gy, const float* h, int64_t r0, int64_
  * arguments as spt_fused_linear_bwd_f32.  spt_fused_linear_pooled_supported: built shapes, under
  * the current matrix mode (split-bf16 kernels only). */
 int spt_fused_linear_pooled_supported(int K, int N);
+/* Per-call matrix mode (no process-wide state): the *_ex entries take `mode` = 0..3 as
+ * spt_fused_linear_use_split_bf16 describes them (< 0: the process default), so that two models
+ * at different precisions, or two streams, never change each other's arithmetic. */
+int spt_fused_linear_pooled_supported_ex(int K, int N, int mode);
+int spt_fused_linear_fwd_ex_f32(const float* x, int64_t r0, int64_t r1, int K, const float* W,
+                                int N, const float* pre_am, const float* pre_scale,
+                                const float* pre_bias, float pre_slope, float* h, double* total,
+                                int mode, void* ws, size_t ws_bytes, spt_stream_t stream);
+int spt_fused_linear_bwd_ex_f32(const float* gy, const float* h, int64_t r0, int64_t r1, int N,
+                                const float* am, const float* scale, const float* bias,
+                                float slope, const float* c1, const float* c2, const float* c3,
+                                const float* xprev, int K, const float* pre_am,
+                                const float* pre_scale, const float* pre_bias, float pre_slope,
+                                const float* W, float* gx, float* gW, int accumulate,
+                                double* prev_total, int mode, void* ws, size_t ws_bytes,
+                                spt_stream_t stream);
+int spt_fused_linear_bwd_pooled_ex_f32(
+    const float* gout, const int32_t* arg, const int32_t* perm, const int32_t* pos_seg,
+    const float* h, int64_t p0, int64_t p1, int N, const float* am, const float* scale,
+    const float* bias, float slope, const float* c1, const float* c2, const float* c3,
+    const float* xprev, int K, const float* pre_am, const float* pre_scale, const float* pre_bias,
+    float pre_slope, const float* W, float* gx, float* gW, int accumulate, double* prev_total,
+    int mode, void* ws, size_t ws_bytes, spt_stream_t stream);
 int spt_fused_linear_bwd_pooled_f32(
     const float* gout, const int32_t* arg, const int32_t* perm, const int32_t* pos_seg,
     const float* h, int64_t p0, int64_t p1, int N, const float* am, const float* scale,

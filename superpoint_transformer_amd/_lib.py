@@ -50,7 +50,7 @@ SIGNATURES = {
     "spt_edge_attn_fwd_ex_f32": (_int, [_p, _i64, _int, _int, _int, _p, _p, _p, _i64, _p, _int,
                                         _p, _p, _p, _p, _p, _p, _int, _f32, _p, _p, _p, _int, _p]),
     "spt_edge_attn_bwd_ex_workspace_bytes": (_sz, [_i64, _i64, _int, _int, _int, _int]),
-    "spt_edge_attn_bwd_el_supported": (_int, [_int, _int, _int, _int]),
+    "spt_edge_attn_bwd_el_supported": (_int, [_int, _int, _int, _int, _int]),
     "spt_attn_pack_tile_ids": (_int, [_p, _p, _p, _i64, _p, _p]),
     "spt_edge_attn_bwd_ex_f32": (_int, [_p, _i64, _int, _int, _int, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _int,
                                         _p, _p, _p, _p, _p, _p, _int, _f32, _p, _p, _p, _p,
@@ -58,6 +58,11 @@ SIGNATURES = {
     "spt_grid_knn_workspace_bytes": (_sz, [_i64, _i64]),
     "spt_knn_use_cell_path": (_int, [_int]),
     "spt_segcsr_use_stream": (_int, [_int]),
+    "spt_segcsr_reduce_ex_f32": (_int, [_int, _p, _p, _p, _i64, _i64, _int, _p, _p, _int, _p]),
+    "spt_segcsr_max_affine_ex_f32": (_int, [_p, _p, _p, _i64, _i64, _int, _p, _p, _p, _f32, _p, _p, _p,
+                                            _int, _p]),
+    "spt_grid_knn_ex_f32": (_int, [_p, _i64, _p, _i64, _int, _f32, _f32, _p, _p, _int, _int, _int,
+                                   _p, _p, _p, _int, _p, _sz, _p]),
     "spt_grid_knn_after_f32": (_int, [_p, _i64, _p, _i64, _int, _f32, _f32, _p, _p, _int, _int, _p, _p,
                                       _p, _p, _p, _sz, _p]),
     "spt_grid_knn_f32": (_int, [_p, _i64, _p, _i64, _int, _f32, _f32, _p, _p, _int, _int, _int,
@@ -90,6 +95,15 @@ SIGNATURES = {
     "spt_fused_linear_bwd_pooled_f32": (_int, [_p, _p, _p, _p, _p, _i64, _i64, _int, _p, _p, _p, _f32,
                                                _p, _p, _p, _p, _int, _p, _p, _p, _f32, _p, _p, _p,
                                                _int, _p, _p, _sz, _p]),
+    "spt_fused_linear_pooled_supported_ex": (_int, [_int, _int, _int]),
+    "spt_fused_linear_fwd_ex_f32": (_int, [_p, _i64, _i64, _int, _p, _int, _p, _p, _p, _f32, _p, _p,
+                                           _int, _p, _sz, _p]),
+    "spt_fused_linear_bwd_ex_f32": (_int, [_p, _p, _i64, _i64, _int, _p, _p, _p, _f32, _p, _p, _p,
+                                           _p, _int, _p, _p, _p, _f32, _p, _p, _p, _int, _p, _int, _p,
+                                           _sz, _p]),
+    "spt_fused_linear_bwd_pooled_ex_f32": (_int, [_p, _p, _p, _p, _p, _i64, _i64, _int, _p, _p, _p, _f32,
+                                                  _p, _p, _p, _p, _int, _p, _p, _p, _f32, _p, _p, _p,
+                                                  _int, _p, _int, _p, _sz, _p]),
     "spt_fused_linear_workspace_bytes": (_sz, [_int, _int]),
     "spt_fused_linear_fwd_f32": (_int, [_p, _i64, _i64, _int, _p, _int, _p, _p, _p, _f32, _p, _p,
                                         _p, _sz, _p]),

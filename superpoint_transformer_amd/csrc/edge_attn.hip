@@ -892,8 +892,9 @@ extern "C" size_t spt_edge_attn_bwd_workspace_bytes(int H, int D, int Dv, int F)
   return attn_tables_bytes(H, D, Dv, F);
 }
 
-extern "C" int spt_edge_attn_bwd_el_supported(int H, int D, int Dv, int F) {
-  return H == 16 && D == 4 && Dv == 4 && F == 32 && g_attn_bwd_packed == 2 && mfma_mode() >= 2;
+extern "C" int spt_edge_attn_bwd_el_supported(int H, int D, int Dv, int F, int mode) {
+  return H == 16 && D == 4 && Dv == 4 && F == 32 && mode_bwd_form(mode) == 2 &&
+         mode_precision(mode) >= 2;
 }
 
 extern "C" size_t spt_edge_attn_bwd_ex_workspace_bytes(int64_t n, int64_t e, int H, int D, int Dv,

@@ -1057,7 +1057,8 @@ using namespace spt::fmlp;
 // 2: forward too;  3: plain bf16 operands (hi halves only) in both directions - the bf16
 //    precision mode.  Process-wide, returns the previous setting.
 static int g_fmlp_mode = 1;
-#define g_fmlp_split_bf16 (g_fmlp_mode >= 1)
+// per-call mode word of the *_ex entries: < 0 = the process default above, else 0..3
+static inline int fmlp_mode_of(int mode) { return mode < 0 ? g_fmlp_mode : (mode > 3 ? 3 : mode); }
 extern "C" int spt_fused_linear_use_split_bf16(int mode) {
   const int prev = g_fmlp_mode;
   g_fmlp_mode = mode < 0 ? 0 : (mode > 3 ? 3 : mode);
@@ -1068,8 +1069,11 @@ extern "C" int spt_fused_linear_use_split_bf16(int mode) {
 // 64 -> 64 panoptic, 32 -> 64 for small MLPs)
 #define SPT_FMLP_POOLED_SHAPES(X) X(16, 8) X(16, 4) X(8, 4)
 extern "C" int spt_fused_linear_pooled_supported(int K, int N) {
+  return spt_fused_linear_pooled_supported_ex(K, N, -1);
+}
+extern "C" int spt_fused_linear_pooled_supported_ex(int K, int N, int mode) {
   const int k4 = (K + 3) / 4, nbk = N / 16;
-  if (N % 16 || g_fmlp_mode < 1) return 0;
+  if (N % 16 || fmlp_mode_of(mode) < 1) return 0;
 #define X(a, b) if (k4 == a && nbk == b) return 1;
   SPT_FMLP_POOLED_SHAPES(X)
 #undef X
@@ -1099,7 +1103,16 @@ extern "C" int spt_fused_linear_fwd_f32(const float* x, int64_t r0, int64_t r1, 
                                         const float* pre_scale, const float* pre_bias,
                                         float pre_slope, float* h, double* total, void* ws,
                                         size_t ws_bytes, spt_stream_t stream_) {
+  return spt_fused_linear_fwd_ex_f32(x, r0, r1, K, W, N, pre_am, pre_scale, pre_bias, pre_slope, h,
+                                     total, -1, ws, ws_bytes, stream_);
+}
+extern "C" int spt_fused_linear_fwd_ex_f32(const float* x, int64_t r0, int64_t r1, int K,
+                                           const float* W, int N, const float* pre_am,
+                                           const float* pre_scale, const float* pre_bias,
+                                           float pre_slope, float* h, double* total, int mode,
+                                           void* ws, size_t ws_bytes, spt_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  const int g_fmlp_mode = fmlp_mode_of(mode);   // shadows the process default inside this call
   SPT_CHECK_ARG(r1 >= r0 && K >= 1 && N >= 16, "bad shape");
   SPT_CHECK_ARG(spt_fused_linear_supported(K, N), "(K, N) not built");
   SPT_CHECK_ARG(x && W && h && total && ws, "null pointer");
@@ -1141,9 +1154,22 @@ extern "C" int spt_fused_linear_bwd_pooled_f32(
     const float* xprev, int K, const float* pre_am, const float* pre_scale, const float* pre_bias,
     float pre_slope, const float* W, float* gx, float* gW, int accumulate, double* prev_total,
     void* ws, size_t ws_bytes, spt_stream_t stream_) {
+  return spt_fused_linear_bwd_pooled_ex_f32(gout, arg, perm, pos_seg, h, p0, p1, N, am, scale, bias,
+                                            slope, c1, c2, c3, xprev, K, pre_am, pre_scale, pre_bias,
+                                            pre_slope, W, gx, gW, accumulate, prev_total, -1, ws,
+                                            ws_bytes, stream_);
+}
+extern "C" int spt_fused_linear_bwd_pooled_ex_f32(
+    const float* gout, const int32_t* arg, const int32_t* perm, const int32_t* pos_seg,
+    const float* h, int64_t p0, int64_t p1, int N, const float* am, const float* scale,
+    const float* bias, float slope, const float* c1, const float* c2, const float* c3,
+    const float* xprev, int K, const float* pre_am, const float* pre_scale, const float* pre_bias,
+    float pre_slope, const float* W, float* gx, float* gW, int accumulate, double* prev_total,
+    int mode, void* ws, size_t ws_bytes, spt_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  const int g_fmlp_mode = fmlp_mode_of(mode);
   SPT_CHECK_ARG(p1 >= p0 && K >= 1 && N >= 16, "bad shape");
-  SPT_CHECK_ARG(spt_fused_linear_pooled_supported(K, N), "(K, N) has no pooled kernel in this matrix mode");
+  SPT_CHECK_ARG(spt_fused_linear_pooled_supported_ex(K, N, g_fmlp_mode), "(K, N) has no pooled kernel in this matrix mode");
   SPT_CHECK_ARG(gout && arg && perm && pos_seg && h && am && scale && bias && c1 && c2 && c3 &&
                 xprev && W && gW && gx && ws, "null pointer");
   SPT_CHECK_ARG(ws_bytes >= spt_fused_linear_workspace_bytes(K, N), "workspace too small");
@@ -1193,7 +1219,22 @@ extern "C" int spt_fused_linear_bwd_f32(const float* gy, const float* h, int64_t
                                         float* gx, float* gW, int accumulate,
                                         double* prev_total, void* ws, size_t ws_bytes,
                                         spt_stream_t stream_) {
+  return spt_fused_linear_bwd_ex_f32(gy, h, r0, r1, N, am, scale, bias, slope, c1, c2, c3, xprev, K,
+                                     pre_am, pre_scale, pre_bias, pre_slope, W, gx, gW, accumulate,
+                                     prev_total, -1, ws, ws_bytes, stream_);
+}
+extern "C" int spt_fused_linear_bwd_ex_f32(const float* gy, const float* h, int64_t r0, int64_t r1,
+                                           int N, const float* am, const float* scale,
+                                           const float* bias, float slope, const float* c1,
+                                           const float* c2, const float* c3, const float* xprev,
+                                           int K, const float* pre_am, const float* pre_scale,
+                                           const float* pre_bias, float pre_slope, const float* W,
+                                           float* gx, float* gW, int accumulate,
+                                           double* prev_total, int mode, void* ws, size_t ws_bytes,
+                                           spt_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  const int g_fmlp_mode = fmlp_mode_of(mode);
+  const bool g_fmlp_split_bf16 = g_fmlp_mode >= 1;
   SPT_CHECK_ARG(r1 >= r0 && K >= 1 && N >= 16, "bad shape");
   SPT_CHECK_ARG(spt_fused_linear_supported(K, N), "(K, N) not built");
   SPT_CHECK_ARG(gy && h && am && scale && bias && c1 && c2 && c3 && xprev && W && gW && ws,

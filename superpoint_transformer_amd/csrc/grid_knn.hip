@@ -655,7 +655,10 @@ extern "C" int spt_spatial_order(const float* xyz, int64_t n, float cell_size, c
 // process-wide switch between the two self-search kernels (tests cross-check them; 1 = shared
 // candidate streams, 0 = wave per query); returns the previous setting
 static int g_knn_cell_path = 1;
-static bool knn_cell_path_enabled() { return g_knn_cell_path != 0; }
+static thread_local int tl_knn_cell_path = -1;   // per-call choice of spt_grid_knn_ex_f32
+static bool knn_cell_path_enabled() {
+  return tl_knn_cell_path >= 0 ? tl_knn_cell_path != 0 : g_knn_cell_path != 0;
+}
 extern "C" int spt_knn_use_cell_path(int on) {
   const int prev = g_knn_cell_path;
   g_knn_cell_path = on ? 1 : 0;
@@ -683,6 +686,23 @@ extern "C" int spt_grid_knn_f32(const float* query, int64_t nq, const float* sea
   return grid_knn_impl(query, nq, search, ns, K, r, cell_size, origin, dims,
                        order_queries_by_cell, inclusive, squared, nullptr, nullptr, idx, dist,
                        cell_order, ws, ws_bytes, stream_);
+}
+
+// Same with the formulation chosen per call (-1: the process default; 0: one wave per query;
+// 1: cell-centric self-search where it applies) - no process-wide state involved.
+extern "C" int spt_grid_knn_ex_f32(const float* query, int64_t nq, const float* search,
+                                   int64_t ns, int K, float r, float cell_size,
+                                   const float* origin, const int32_t* dims,
+                                   int order_queries_by_cell, int inclusive, int squared,
+                                   int64_t* idx, float* dist, int32_t* cell_order, int formulation,
+                                   void* ws, size_t ws_bytes, spt_stream_t stream_) {
+  const int prev = tl_knn_cell_path;
+  tl_knn_cell_path = formulation < 0 ? -1 : (formulation != 0);
+  const int st = grid_knn_impl(query, nq, search, ns, K, r, cell_size, origin, dims,
+                               order_queries_by_cell, inclusive, squared, nullptr, nullptr, idx,
+                               dist, cell_order, ws, ws_bytes, stream_);
+  tl_knn_cell_path = prev;
+  return st;
 }
 
 // The K neighbours ranked strictly AFTER (after_d2[q], after_idx[q]) in the (squared distance,

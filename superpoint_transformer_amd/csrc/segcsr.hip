@@ -527,7 +527,15 @@ __global__ __launch_bounds__(256, 5) void segmax_stream_kernel(
 }
 
 static int g_seg_stream = -1;   // -1: from the environment (SPT_SEG_STREAM=0 turns it off)
+// per-call choice of the *_ex entries (thread-local, set for the duration of one call)
+static thread_local int tl_seg_stream = -1;
+struct SegStreamScope {
+  int prev;
+  explicit SegStreamScope(int f) : prev(tl_seg_stream) { tl_seg_stream = f < 0 ? -1 : (f != 0); }
+  ~SegStreamScope() { tl_seg_stream = prev; }
+};
 static bool seg_stream_on() {
+  if (tl_seg_stream >= 0) return tl_seg_stream != 0;
   if (g_seg_stream < 0) {
     const char* e = getenv("SPT_SEG_STREAM");
     g_seg_stream = (e && e[0] == '0') ? 0 : 1;
@@ -841,6 +849,25 @@ extern "C" int spt_segcsr_reduce_f32(int op, const float* x, const int32_t* perm
   }
   SPT_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int spt_segcsr_reduce_ex_f32(int op, const float* x, const int32_t* perm,
+                                        const int32_t* rowptr, int64_t n, int64_t num_seg, int c,
+                                        float* out, int32_t* arg, int formulation,
+                                        spt_stream_t stream_) {
+  SegStreamScope scope(formulation);
+  return spt_segcsr_reduce_f32(op, x, perm, rowptr, n, num_seg, c, out, arg, stream_);
+}
+
+extern "C" int spt_segcsr_max_affine_ex_f32(const float* x, const int32_t* perm,
+                                            const int32_t* rowptr, int64_t n, int64_t num_seg,
+                                            int c, const float* am, const float* scale,
+                                            const float* bias, float act_slope,
+                                            const int64_t* seg_graph, float* out, int32_t* arg,
+                                            int formulation, spt_stream_t stream_) {
+  SegStreamScope scope(formulation);
+  return spt_segcsr_max_affine_f32(x, perm, rowptr, n, num_seg, c, am, scale, bias, act_slope,
+                                   seg_graph, out, arg, stream_);
 }
 
 extern "C" int spt_segcsr_max_affine_f32(const float* x, const int32_t* perm,

@@ -6,7 +6,7 @@ from .dropout import DropPath
 from .fusion import (AdditiveFusion, CatFusion, TakeFirstFusion, TakeSecondFusion,
                      fusion_factory)
 from .mlp import FFN, MLP, Classifier
-from .norm import INDEX_BASED_NORMS, GraphNorm, UnitSphereNorm
+from .norm import INDEX_BASED_NORMS, GraphNorm, InstanceNorm, LayerNorm, UnitSphereNorm
 from .pool import (AttentivePool, AttentivePoolWithLearntQueries, BaseAttentivePool, MaxPool,
                    MeanPool, MinPool, StdPool, SumPool, pool_factory)
 from .stage import DownNFuseStage, PointStage, Stage, UpNFuseStage

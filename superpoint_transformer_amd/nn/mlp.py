@@ -41,7 +41,8 @@ class MLP(nn.Module):
         while i < len(mods):
             lin = mods[i]
             gn = mods[i + 1] if i + 1 < len(mods) else None
-            if not (isinstance(lin, nn.Linear) and lin.bias is None and isinstance(gn, GraphNorm)):
+            if not (isinstance(lin, nn.Linear) and lin.bias is None and isinstance(gn, GraphNorm)
+                    and not gn.generic):
                 return None
             act = mods[i + 2] if i + 2 < len(mods) else None
             if isinstance(act, nn.LeakyReLU):

@@ -9,6 +9,7 @@ dicts load.  ``nano=True`` (spt.py:486-521, 786-797: no level-0 stage - the NAG 
 1, whose handcrafted features go through ``node_mlps[0]`` / ``h_edge_mlps[0]`` into a full
 ``Stage`` with transformer blocks) is built; the sparse-CNN point encoder is outside the hot
 path and raises."""
+import torch
 from torch import nn
 
 from .fusion import CatFusion
@@ -92,10 +93,15 @@ class SPT(nn.Module):
                  share_hf_mlps=False, stages_share_rpe=False, blocks_share_rpe=False,
                  heads_share_rpe=False, use_pos=True, use_node_hf=True, use_diameter=False,
                  use_diameter_parent=False, pool="max", unpool="index", fusion="cat",
-                 norm_mode="graph", output_stage_wise=False, version="3.0.0", **ignored):
+                 norm_mode="graph", output_stage_wise=False, version="3.0.0",
+                 matrix_precision=None, **ignored):
         super().__init__()
-        if norm_mode != "graph":
-            raise NotImplementedError("only norm_mode='graph' is built")
+        # not in the reference: "f32" | "bf16" | "f32-exact" pins this model's GEMM precision
+        # (precision.matrix_precision, per call); None = whatever is active around the call
+        self.matrix_precision = matrix_precision
+        if norm_mode not in ("graph", "node", "segment"):
+            raise NotImplementedError(f"Unknown mode='{norm_mode}'")      # data.py:130
+        self.norm_mode = norm_mode
         self.nano = nano = bool(nano)
         self.use_pos, self.use_node_hf = use_pos, use_node_hf
         self.use_diameter, self.use_diameter_parent = use_diameter, use_diameter_parent
@@ -200,6 +206,21 @@ class SPT(nn.Module):
         return self.first_stage.out_dim
 
     def forward(self, nag):
+        if self.norm_mode != "graph":
+            # group index = one group per node / per (segment, cloud): the statistics of every
+            # GraphNorm run on the segment-CSR kernels, the fused few-sorted-graphs routes are off
+            if self.nano:
+                raise NotImplementedError("norm_mode != 'graph' is not built for nano models")
+            for m in self.modules():
+                if isinstance(m, GraphNorm):
+                    m.generic = True
+        if self.matrix_precision is None:
+            return self._forward(nag)
+        from .. import precision
+        with precision.matrix_precision(self.matrix_precision):
+            return self._forward(nag)
+
+    def _forward(self, nag):
         """``nag[i]`` exposes pos, x, super_index, node_size, batch, edge_index,
         edge_attr (attributes or dict keys).  ``nag.num_clouds`` (optional) is
         the number of clouds in the batch.  Returns level-1 features (or the
@@ -210,8 +231,21 @@ class SPT(nn.Module):
         levels = [nag[i] for i in range(self.num_down_stages + 1)]
         sizes = [_get(lv, "pos").shape[0] for lv in levels]
 
-        def norm_index(lv):                                  # Data.norm_index('graph')
-            return _get(lv, "batch")
+        def norm_index(lv):                                  # Data.norm_index(mode), data.py:103-130
+            batch = _get(lv, "batch")
+            if self.norm_mode == "graph":
+                return batch
+            n = _get(lv, "pos").shape[0]
+            dev = _get(lv, "pos").device
+            if self.norm_mode == "node":
+                return torch.arange(n, device=dev)
+            sup = _get(lv, "super_index")
+            if sup is None:
+                sup = torch.zeros(n, dtype=torch.long, device=dev)
+            if batch is None:
+                return sup
+            nb = B if B is not None else int(batch.max()) + 1
+            return sup * nb + batch
 
         d0 = levels[0]
         # the point features feed nothing but the max-pool of the first down stage: let the
@@ -237,7 +271,8 @@ class SPT(nn.Module):
             ea = _get(lv, "edge_attr")
             ei = _get(lv, "edge_index")
             if self.h_edge_mlps[i_stage] is not None and ea is not None:   # spt.py:827-835
-                eb = None if (ni is None or B == 1) else ni[ei[0]]     # one cloud: one graph
+                one = B == 1 and self.norm_mode == "graph"              # one cloud: one graph
+                eb = None if (ni is None or one) else ni[ei[0]]
                 ea = self.h_edge_mlps[i_stage](ea, batch=eb, batch_size=B)
             node_x[i_level], edge_attrs[i_level] = xh, ea
             # the down stage and, later, the up stage of this level read the same edge_attr:
@@ -284,6 +319,8 @@ class SPT(nn.Module):
         mlp = self.v_edge_mlps[i_stage]
         if mlp is None or v_ea is None:
             return v_ea
+        if self.norm_mode != "graph":
+            raise NotImplementedError("vertical edge MLPs with norm_mode != 'graph' are not built")
         ni = _get(child, "batch")
         return mlp(v_ea, batch=None if (ni is None or B == 1) else ni, batch_size=B)
 

@@ -8,6 +8,7 @@ import os
 import torch
 
 from . import _lib
+from . import precision as _precision
 from .csr import EdgeCSR, SegmentCSR, csr_of, edge_csr_of
 
 _OPS = {"sum": 0, "add": 0, "mean": 1, "min": 2, "max": 3}
@@ -436,13 +437,15 @@ class _EdgeAttention(torch.autograd.Function):
         out = torch.empty((n, H * Dv), dtype=torch.float32, device=dev)
         m = torch.empty((n, H), dtype=torch.float32, device=dev)
         z = torch.empty((n, H), dtype=torch.float32, device=dev)
+        mode = _precision.attention_mode()       # per call; the backward runs in the same mode
         with torch.cuda.device(dev), _timed(f"edge_attn_fwd:{n}:{ecsr.e}"):
-            st = _lib.lib.spt_edge_attn_fwd_f32(
+            st = _lib.lib.spt_edge_attn_fwd_ex_f32(
                 _lib.ptr(q2), n, H, D, Dv, _lib.ptr(ecsr.erowptr), _lib.ptr(ecsr.eperm),
                 _lib.ptr(ecsr.tgt_sorted), ecsr.e, _lib.ptr(ea), F,
                 *[_lib.ptr(t) for t in ps], scale_mode, scale_a, _lib.ptr(out),
-                _lib.ptr(m), _lib.ptr(z), _lib.stream_ptr(dev))
-        _lib.check(st, "spt_edge_attn_fwd_f32")
+                _lib.ptr(m), _lib.ptr(z), mode, _lib.stream_ptr(dev))
+        _lib.check(st, "spt_edge_attn_fwd_ex_f32")
+        ctx.mode = mode
         ctx.save_for_backward(q2, ea, *[t for t in ps if t is not None], out, m, z)
         ctx.present = [t is not None for t in ps]
         ctx.has_ea = ea is not None
@@ -479,7 +482,7 @@ class _EdgeAttention(torch.autograd.Function):
         nb = _lib.lib.spt_edge_attn_bwd_ex_workspace_bytes(n, ecsr.e, H, D, Dv, max(F, 1))
         ws = _workspace(nb, dev)
         src = tids = tperm = trowptr = None
-        if ea is not None and ecsr.e > 0 and _lib.lib.spt_edge_attn_bwd_el_supported(H, D, Dv, F):
+        if ea is not None and ecsr.e > 0 and _lib.lib.spt_edge_attn_bwd_el_supported(H, D, Dv, F, ctx.mode):
             src = ecsr.src_sorted()
             tids = ecsr.tile_ids()
             tv = ecsr.target_view()
@@ -492,7 +495,7 @@ class _EdgeAttention(torch.autograd.Function):
                 ecsr.e, _lib.ptr(ea), F,
                 *[_lib.ptr(t) for t in ps], scale_mode, scale_a, _lib.ptr(out),
                 _lib.ptr(m), _lib.ptr(z), _lib.ptr(g), _lib.ptr(gqkv), _lib.ptr(gea), acc,
-                *[_lib.ptr(t) for t in gps], -1, _lib.ptr(ws), ws.numel(),
+                *[_lib.ptr(t) for t in gps], ctx.mode, _lib.ptr(ws), ws.numel(),
                 _lib.stream_ptr(dev))
         _lib.check(st, "spt_edge_attn_bwd_ex_f32")
         if gea is not None and not (any(ctx.present[0::2])):
@@ -745,7 +748,7 @@ def fused_mlp_supported(dims):
                for k, n in zip(dims[:-1], dims[1:]))
 
 
-def _fmlp_forward(x, batch, ranges, eps_list, slope_list, params, apply_last=True):
+def _fmlp_forward(x, batch, ranges, eps_list, slope_list, params, apply_last=True, fmode=-1):
     """Forward of the fused layer chain.  Returns (y or None, saved tensors, hs[-1], tables of
     the last GraphNorm): with ``apply_last=False`` the last norm + activation are left to the
     consumer (the fused max-pool)."""
@@ -776,12 +779,12 @@ def _fmlp_forward(x, batch, ranges, eps_list, slope_list, params, apply_last=Tru
                 if pre is not None:
                     pa, ps, pb = pre[0][g], pre[1][g], pre[2]
                 with _timed(f"fused_linear_fwd:{K}x{N}:{ranges[g + 1] - ranges[g]}"):
-                    st = _lib.lib.spt_fused_linear_fwd_f32(
+                    st = _lib.lib.spt_fused_linear_fwd_ex_f32(
                         _lib.ptr(cur), ranges[g], ranges[g + 1], K, _lib.ptr(Ws[l]), N,
                         _lib.ptr(pa), _lib.ptr(ps), _lib.ptr(pb),
                         float(slope_list[l - 1]) if l else 1.0, _lib.ptr(h),
-                        _lib.ptr(total[g]), _lib.ptr(ws), ws.numel(), sp)
-                _lib.check(st, "spt_fused_linear_fwd_f32")
+                        _lib.ptr(total[g]), fmode, _lib.ptr(ws), ws.numel(), sp)
+                _lib.check(st, "spt_fused_linear_fwd_ex_f32")
             mean = torch.empty((B, N), dtype=torch.float32, device=dev)
             rstd, am, sc = (torch.empty_like(mean) for _ in range(3))
             st = _lib.lib.spt_graphnorm_tables_f32(
@@ -809,7 +812,8 @@ def _fmlp_backward(saved, meta, gy, top_total=None, pooled=None):
     them (the max-pool route computes them from the pool's sparse gradient).
     ``pooled = (gout, arg, csr)``: the top layer consumes the pool's gradient directly
     (``spt_fused_linear_bwd_pooled_f32``), ``gy`` is then None."""
-    L, ranges, slopes, in_dtype, need_gx0 = meta
+    L, ranges, slopes, in_dtype, need_gx0 = meta[:5]
+    fmode = meta[5] if len(meta) > 5 else -1          # the matrix mode the forward ran in
     sv = list(saved)
     x2, batch = sv[0], sv[1]
     hs = sv[2:2 + L]
@@ -861,7 +865,7 @@ def _fmlp_backward(saved, meta, gy, top_total=None, pooled=None):
                 if pooled is not None and l == L - 1:
                     p_gout, p_arg, p_csr = pooled
                     with _timed(f"fused_linear_bwd_pooled:{K}x{N}:{ranges[g + 1] - ranges[g]}"):
-                        st = _lib.lib.spt_fused_linear_bwd_pooled_f32(
+                        st = _lib.lib.spt_fused_linear_bwd_pooled_ex_f32(
                             _lib.ptr(p_gout), _lib.ptr(p_arg), _lib.ptr(p_csr.perm),
                             _lib.ptr(p_csr.pos_seg()), _lib.ptr(hs[l]), ranges[g], ranges[g + 1], N,
                             _lib.ptr(am[g]), _lib.ptr(sc[g]), _lib.ptr(gnb[l]), float(slopes[l]),
@@ -869,18 +873,18 @@ def _fmlp_backward(saved, meta, gy, top_total=None, pooled=None):
                             _lib.ptr(pa), _lib.ptr(ps), _lib.ptr(pb),
                             float(slopes[l - 1]) if l else 1.0, _lib.ptr(Ws[l]), _lib.ptr(gx),
                             _lib.ptr(gW), 1 if g else 0, _lib.ptr(ptot[g]) if l else None,
-                            _lib.ptr(ws), ws.numel(), sp)
-                    _lib.check(st, "spt_fused_linear_bwd_pooled_f32")
+                            fmode, _lib.ptr(ws), ws.numel(), sp)
+                    _lib.check(st, "spt_fused_linear_bwd_pooled_ex_f32")
                     continue
-                st = _lib.lib.spt_fused_linear_bwd_f32(
+                st = _lib.lib.spt_fused_linear_bwd_ex_f32(
                     _lib.ptr(g_cur), _lib.ptr(hs[l]), ranges[g], ranges[g + 1], N,
                     _lib.ptr(am[g]), _lib.ptr(sc[g]), _lib.ptr(gnb[l]), float(slopes[l]),
                     _lib.ptr(c1[g]), _lib.ptr(c2[g]), _lib.ptr(c3[g]), _lib.ptr(xprev), K,
                     _lib.ptr(pa), _lib.ptr(ps), _lib.ptr(pb),
                     float(slopes[l - 1]) if l else 1.0, _lib.ptr(Ws[l]), _lib.ptr(gx),
                     _lib.ptr(gW), 1 if g else 0, _lib.ptr(ptot[g]) if l else None,
-                    _lib.ptr(ws), ws.numel(), sp)
-                _lib.check(st, "spt_fused_linear_bwd_f32")
+                    fmode, _lib.ptr(ws), ws.numel(), sp)
+                _lib.check(st, "spt_fused_linear_bwd_ex_f32")
             grads[4 * l], grads[4 * l + 1], grads[4 * l + 2], grads[4 * l + 3] = gW, gw_n, gb_n, ga_n
             if l:
                 g_cur, total = gx, ptot
@@ -896,9 +900,10 @@ class _FusedMLP(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, batch, ranges, eps_list, slope_list, *params):
-        y, saved, _, _ = _fmlp_forward(x, batch, ranges, eps_list, slope_list, params)
+        fmode = _precision.fused_mode()
+        y, saved, _, _ = _fmlp_forward(x, batch, ranges, eps_list, slope_list, params, fmode=fmode)
         ctx.save_for_backward(*saved)
-        ctx.meta = (len(eps_list), ranges, list(slope_list), x.dtype, x.requires_grad)
+        ctx.meta = (len(eps_list), ranges, list(slope_list), x.dtype, x.requires_grad, fmode)
         return y.to(x.dtype)
 
     @staticmethod
@@ -915,8 +920,9 @@ class _FusedMLPMaxPool(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, batch, ranges, eps_list, slope_list, csr, seg_graph, *params):
+        fmode = _precision.fused_mode()
         _, saved, h_last, (am, sc, bs) = _fmlp_forward(x, batch, ranges, eps_list, slope_list,
-                                                        params, apply_last=False)
+                                                        params, apply_last=False, fmode=fmode)
         R, N = h_last.shape
         dev = h_last.device
         out = torch.empty((csr.num_seg, N), dtype=torch.float32, device=dev)
@@ -931,7 +937,7 @@ class _FusedMLPMaxPool(torch.autograd.Function):
         ctx.save_for_backward(arg, *saved)
         ctx.csr = csr
         ctx.seg_graph = seg_graph
-        ctx.meta = (len(eps_list), ranges, list(slope_list), x.dtype, x.requires_grad)
+        ctx.meta = (len(eps_list), ranges, list(slope_list), x.dtype, x.requires_grad, fmode)
         return out.to(x.dtype)
 
     @staticmethod
@@ -968,7 +974,7 @@ class _FusedMLPMaxPool(torch.autograd.Function):
         # numbered graph by graph, as NAG batches are).
         K_top = saved[2 + 5 * L + (L - 1)].shape[1]
         pooled_ok = (total is not None and L > 1
-                     and _lib.lib.spt_fused_linear_pooled_supported(int(K_top), int(N)) == 1
+                     and _lib.lib.spt_fused_linear_pooled_supported_ex(int(K_top), int(N), ctx.meta[5]) == 1
                      and (B == 1 or graph_ranges(ctx.seg_graph, B, ctx.csr.num_seg) is not None))
         if pooled_ok:
             gx0, grads = _fmlp_backward(saved, ctx.meta, None, top_total=total,

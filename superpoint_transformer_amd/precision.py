@@ -9,35 +9,64 @@ switch, configs/trainer/gpu.yaml:7-10).
                      statistics, softmax and segment reductions stay f32 (master weights in f32,
                      like Lightning's bf16-mixed).  Tested at rtol 2e-2.
 ``"f32-exact"``      f32 matrix pipe everywhere (1/16 of the bf16 pipe's rate).
+
+The mode travels PER CALL: ``matrix_precision(mode)`` (a context manager on a ``contextvars``
+variable: per thread / task) and ``SPT(..., matrix_precision=...)`` make the autograd wrappers of
+``ops`` pass the mode word to the ``*_ex`` entry points of the C ABI, which read no process-wide
+state - two models at different precisions, on different streams or threads, never change each
+other's arithmetic (tests/test_modes_gpu.py).  The backward of an op runs in the mode its forward
+ran in.  ``set_matrix_precision`` is the older process-wide default (the library's own setters):
+it applies wherever no per-call mode is active.
 """
 import contextlib
+import contextvars
 
 from . import _lib
 
 _MODES = {"f32": (2, 1), "bf16": (3, 3), "f32-exact": (1, 0)}   # (attention, fused MLP)
-_current = "f32"
+_default = "f32"
+_active = contextvars.ContextVar("spt_matrix_precision", default=None)
+
+
+def _check(mode):
+    if mode not in _MODES:
+        raise ValueError(f"precision must be one of {sorted(_MODES)}")
 
 
 def set_matrix_precision(mode):
-    """Process-wide; returns the previous mode name."""
-    global _current
-    if mode not in _MODES:
-        raise ValueError(f"precision must be one of {sorted(_MODES)}")
+    """Process-wide default (the library's setters); returns the previous mode name."""
+    global _default
+    _check(mode)
     a, m = _MODES[mode]
     _lib.lib.spt_attn_use_mfma(a)
     _lib.lib.spt_fused_linear_use_split_bf16(m)
-    prev, _current = _current, mode
+    prev, _default = _default, mode
     return prev
 
 
 def get_matrix_precision():
-    return _current
+    return _active.get() or _default
+
+
+def attention_mode():
+    """Mode word for ``spt_edge_attn_*_ex_f32``: -1 (library default) unless a per-call mode is active."""
+    mode = _active.get()
+    return -1 if mode is None else _MODES[mode][0]
+
+
+def fused_mode():
+    """Mode word for ``spt_fused_linear_*_ex_f32``."""
+    mode = _active.get()
+    return -1 if mode is None else _MODES[mode][1]
 
 
 @contextlib.contextmanager
 def matrix_precision(mode):
-    prev = set_matrix_precision(mode)
+    """Per-call mode for everything launched inside the block (this thread / task only)."""
+    if mode is not None:
+        _check(mode)
+    token = _active.set(mode)
     try:
         yield
     finally:
-        set_matrix_precision(prev)
+        _active.reset(token)

@@ -5,7 +5,8 @@ from torch import nn
 
 from .. import ops
 from ..csr import csr_of
-from ..nn.norm import GraphNorm  # noqa: F401  (same parameters as PyG's: weight, bias, mean_scale)
+# same parameters as PyG's (GraphNorm: weight, bias, mean_scale; LayerNorm / InstanceNorm: weight, bias)
+from ..nn.norm import GraphNorm, InstanceNorm, LayerNorm  # noqa: F401
 from . import scatter_shim
 
 
@@ -58,22 +59,6 @@ class StdAggregation(nn.Module):
         mean2 = scatter_shim.scatter_mean(x * x, index, 0, None, dim_size)
         out = (mean2 - mean * mean).clamp(min=1e-5).sqrt()
         return out.masked_fill(out <= 1e-5 ** 0.5, 0.0)     # PyG: a clamped variance reads as 0
-
-
-class _NotOnPath(nn.Module):
-    def __init__(self, *a, **k):
-        super().__init__()
-        raise NotImplementedError(
-            f"{type(self).__name__} is not used by any shipped SPT config "
-            "(all norms are GraphNorm, configs/model/semantic/spt.yaml:19-21)")
-
-
-class LayerNorm(_NotOnPath):
-    pass
-
-
-class InstanceNorm(_NotOnPath):
-    pass
 
 
 def ones(t):

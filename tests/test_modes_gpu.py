@@ -159,3 +159,52 @@ def test_bf16_matrix_precision_mode(dev):
         ref = OM.mlp(copy.deepcopy(mlp).double().cpu(), xin.cpu().double(), None, torch.float64)
         assert ((y.detach().cpu().double() - ref).abs().max() / ref.abs().max()).item() < 2e-2
     assert precision.get_matrix_precision() == "f32"
+
+
+def test_two_models_at_different_precisions_interleaved_on_two_streams(dev):
+    """the C ABI holds no global state.  Two SPT-64 models pinned to different
+    matrix precisions (`SPT(matrix_precision=...)` -> the per-call mode word of the *_ex entries)
+    run forward + backward INTERLEAVED on two streams of one process: each reproduces what it
+    computes alone - the forward bit for bit, the gradients to f32 round-off (atomics) - and the
+    two differ from each other (the modes really are different arithmetic)."""
+    from superpoint_transformer_amd import hotpath
+    from superpoint_transformer_amd.synthetic import make_nag
+    nag = make_nag("R", seed=11, device=dev, sizes=(30000, 900, 350, 14000, 10000, 2))
+
+    class View:
+        levels = nag.levels
+        num_clouds = 2
+
+        def __getitem__(self, i):
+            return self.levels[i]
+
+    def build(mode):
+        torch.manual_seed(3)
+        cfg = hotpath.spt64_config(nag[0]["x"].shape[1], nag[1]["edge_attr"].shape[1])
+        m = hotpath.SPTSegmenter(**cfg).to(dev)
+        m.net.matrix_precision = mode
+        return m
+
+    def run(model, stream):
+        with torch.cuda.stream(stream):
+            model.zero_grad(set_to_none=True)
+            out = model(View())[0]
+            out.square().mean().backward()
+            g = model.net.down_stages[0].transformer_blocks[0].sa.qkv.weight.grad.clone()
+        return out.detach(), g
+
+    ma, mb = build("f32-exact"), build("bf16")
+    main = torch.cuda.current_stream()
+    ref_a = run(ma, main)
+    ref_b = run(mb, main)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = {}
+    for rep in range(3):                      # interleave: A fwd+bwd on s1 while B runs on s2
+        outs["a"] = run(ma, s1)
+        outs["b"] = run(mb, s2)
+    torch.cuda.synchronize()
+    assert torch.equal(outs["a"][0], ref_a[0]) and torch.equal(outs["b"][0], ref_b[0])
+    for got, ref in ((outs["a"][1], ref_a[1]), (outs["b"][1], ref_b[1])):
+        assert (got - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+    assert (ref_a[0] - ref_b[0]).abs().max().item() > 1e-5 * ref_a[0].abs().max().item()

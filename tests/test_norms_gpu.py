@@ -103,3 +103,129 @@ def test_graph_norm_large_mean_is_stable(dev):
     # the saved statistics are f32 like the reference's: at |mean| = 1000 the mean
     # itself rounds by 3e-5 = 0.3% of sigma (and the f32 inputs are spaced 6e-5)
     _close(y, ref, tol=1e-2)
+
+
+def _pyg_layer_norm(x, batch, w, b, eps, mode):
+    """torch_geometric 2.3.0 nn/norm/layer_norm.py restated in f64 torch ops."""
+    if mode == "node":
+        return torch.nn.functional.layer_norm(x, (x.shape[1],), w, b, eps)
+    if batch is None:
+        x = x - x.mean()
+        out = x / (x.std(unbiased=False) + eps)
+    else:
+        B = int(batch.max()) + 1
+        norm = torch.bincount(batch, minlength=B).clamp(min=1).to(x.dtype).mul(x.shape[1]).view(-1, 1)
+        mean = torch.zeros(B, x.shape[1], dtype=x.dtype).index_add_(0, batch, x).sum(-1, keepdim=True) / norm
+        x = x - mean[batch]
+        var = torch.zeros(B, x.shape[1], dtype=x.dtype).index_add_(0, batch, x * x).sum(-1, keepdim=True) / norm
+        out = x / (var + eps).sqrt()[batch]
+    return out * w + b if w is not None else out
+
+
+def _pyg_instance_norm(x, batch, w, b, eps):
+    """torch_geometric 2.3.0 nn/norm/instance_norm.py (training statistics) in f64."""
+    if batch is None:
+        batch = torch.zeros(x.shape[0], dtype=torch.long)
+    B = int(batch.max()) + 1
+    cnt = torch.bincount(batch, minlength=B).clamp(min=1).to(x.dtype).view(-1, 1)
+    mean = torch.zeros(B, x.shape[1], dtype=x.dtype).index_add_(0, batch, x) / cnt
+    out = x - mean[batch]
+    var = torch.zeros(B, x.shape[1], dtype=x.dtype).index_add_(0, batch, out * out) / cnt
+    out = out / (var + eps).sqrt()[batch]
+    return out * w + b if w is not None else out
+
+
+@pytest.mark.parametrize("kind", ["layer-graph", "layer-node", "layer-nobatch", "instance", "instance-affine"])
+def test_layer_and_instance_norm_match_the_pyg_formulas(kind, dev):
+    """The two other index-based norms src/nn/norm.py:5 re-exports (the shims used to raise):
+    forward and gradients against the f64 restatement, unsorted group index with an empty group."""
+    from superpoint_transformer_amd import nn as N
+    torch.manual_seed(4)
+    n, c = 5000, 64
+    x = torch.randn(n, c) * 2 + 0.5
+    batch = torch.randint(0, 7, (n,))
+    batch[batch == 3] = 4                                   # group 3 is empty
+    if kind.startswith("layer"):
+        mode = "node" if kind == "layer-node" else "graph"
+        m = N.LayerNorm(c, mode=mode)
+    else:
+        m = N.InstanceNorm(c, affine=kind.endswith("affine"))
+    with torch.no_grad():
+        for p in m.parameters():
+            p.copy_(torch.randn_like(p) * 0.3 + 1.0)
+    b_in = None if kind == "layer-nobatch" else batch
+    xd = x.to(dev).requires_grad_()
+    md = m.to(dev)
+    out = md(xd, None if b_in is None else b_in.to(dev))
+    gw = torch.randn(n, c)
+    (out * gw.to(dev)).sum().backward()
+    x64 = x.double().requires_grad_()
+    w = m.weight.detach().cpu().double() if m.weight is not None else None
+    b = m.bias.detach().cpu().double() if m.bias is not None else None
+    if kind.startswith("layer"):
+        ref = _pyg_layer_norm(x64, b_in, w, b, m.eps, m.mode)
+    else:
+        ref = _pyg_instance_norm(x64, b_in, w, b, m.eps)
+    (ref * gw.double()).sum().backward()
+    _close(out, ref.detach(), 2e-5)
+    _close(xd.grad, x64.grad, 1e-4)
+
+
+@pytest.mark.parametrize("norm_mode", ["segment", "node"])
+def test_spt_norm_modes_node_and_segment_match_the_oracle(norm_mode, dev):
+    """`norm_mode` of SPT (src/models/components/spt.py:368-379 -> Data.norm_index,
+    src/data/data.py:103-130): every GraphNorm normalises per node / per (segment, cloud) group
+    instead of per cloud - statistics on the segment-CSR kernels.  Against the f64 oracle fed
+    the same group index."""
+    import copy
+    from oracle import spt_model as OM
+    from superpoint_transformer_amd import hotpath
+    from superpoint_transformer_amd.synthetic import make_nag
+    small = make_nag("R", seed=9, device="cpu", sizes=(20000, 700, 260, 9000, 7000, 2))
+    torch.manual_seed(1)
+    cfg = hotpath.spt64_config(small[0]["x"].shape[1], small[1]["edge_attr"].shape[1])
+    cfg["norm_mode"] = norm_mode
+    model = hotpath.SPTSegmenter(**cfg)
+    ref = copy.deepcopy(model).double()
+
+    def norm_index(lv, n):
+        batch = lv.get("batch")
+        if norm_mode == "node":
+            return torch.arange(n)
+        sup = lv.get("super_index")
+        if sup is None:
+            sup = torch.zeros(n, dtype=torch.long)
+        return sup * 2 + batch if batch is not None else sup
+    ref_levels = []
+    for lv in small.levels:
+        d = dict(lv)
+        d["batch"] = norm_index(lv, lv["pos"].shape[0])
+        ref_levels.append(d)
+    outs = OM.spt_forward(ref.net, ref_levels, dtype=torch.float64)
+    # groups of one or two nodes divide by sqrt(var + eps) ~ sqrt(eps): the reference's own f32
+    # evaluation moves by 2e-2 of the output scale in 'segment' mode - the bar follows it, as in
+    # tests/test_model_gpu.py
+    outs32 = OM.spt_forward(copy.deepcopy(model).net, ref_levels, dtype=torch.float32)
+
+    class View:
+        levels = [{k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in lv.items()}
+                  for lv in small.levels]
+        num_clouds = 2
+
+        def __getitem__(self, i):
+            return self.levels[i]
+    gm = model.to(dev)
+    feats = gm.net(View())
+    feats = feats if isinstance(feats, (list, tuple)) else [feats]
+    outs = outs if isinstance(outs, (list, tuple)) else [outs]
+    outs32 = outs32 if isinstance(outs32, (list, tuple)) else [outs32]
+    for a, r, r32 in zip(feats, outs, outs32):
+        scale = max(r.abs().max().item(), 1e-6)
+        own = (r32.double() - r).abs().max().item() / scale
+        err = (a.detach().cpu().double() - r).abs().max().item() / scale
+        assert err < max(2e-3, 3 * own), f"{norm_mode}: {err:.3e} (f32 oracle: {own:.3e})"
+    feats[0].square().mean().backward()                     # the composite route differentiates
+    g = gm.net.down_stages[0].transformer_blocks[0].sa.qkv.weight.grad
+    # ('node': every group is one row, x - mean_scale * mean = 0 at initialisation: the features
+    # collapse to the norms' biases and this gradient is legitimately zero)
+    assert torch.isfinite(g).all() and (norm_mode == "node" or g.abs().sum().item() > 0)
