@@ -143,20 +143,26 @@ def preprocess_leg(scene, n_points, dev, reps=5):
             "ms_total": round(dt * 1e3, 3), "reps": reps}
 
 
-def cpu_preprocess_baseline(scene, n_sample=6000):
-    """Same leg through the CPU oracle (exhaustive kNN + torch-CPU eigenfeatures)."""
-    from oracle import spt_oracle as O
+def cpu_preprocess_baseline(scene, n_sample):
+    """Same leg on the host cores through the CPU twin (oracle/cpu/spt_cpu.cpp: the same exact
+    grid kNN contract + the eigenfeatures in f64, OpenMP over all cores) on a bounded sample of
+    the same cloud - the same ALGORITHM class on the CPU, not an O(N^2) strawman."""
+    from oracle import cpu_twin as T
     from superpoint_transformer_amd.synthetic import make_voxel_cloud
     voxel, k, r = PRE_CFG.get(scene, PRE_CFG["S"])
-    pos = make_voxel_cloud(n_sample, voxel=voxel, seed=4321, device="cpu", extent=(6.0, 6.0, 3.0))
+    pos = make_voxel_cloud(n_sample, voxel=voxel, seed=4321, device="cpu", **PRE_GEOM.get(scene, {}))
     n_sample = pos.shape[0]
+    threads = os.cpu_count() or 1
     t0 = time.perf_counter()
-    nb, _ = O.knn_1(pos, k, r)
-    O.geometric_features(pos.double(), nb, k_min=1)
-    dt = time.perf_counter() - t0
-    return {"value": round(n_sample / dt / 1e6, 5), "unit": "Mpoints/s",
-            "cores": os.cpu_count(), "threads_used": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n_sample} points, exhaustive kNN + eigenfeatures via oracle/spt_oracle.py"}
+    nb, _ = T.knn_1(pos, k, r, threads=threads)
+    t1 = time.perf_counter()
+    T.point_geof(pos, nb, k_min=1, threads=threads)
+    t2 = time.perf_counter()
+    return {"value": round(n_sample / (t2 - t0) / 1e6, 4), "unit": "Mpoints/s",
+            "cores": os.cpu_count(), "threads_used": threads, "kind": "port",
+            "s_knn": round(t1 - t0, 3), "s_geof": round(t2 - t1, 3),
+            "sample": f"{n_sample} points of the same synthetic cloud generator: exact grid kNN "
+                      f"(k={k}, r={r}) + eigenfeatures via oracle/cpu/libspt_cpu.so (OpenMP)"}
 
 
 def _free_port():
@@ -302,7 +308,8 @@ def main():
         if not args.no_cpu_baseline:
             cpu = cpu_baseline(args.scene, args.cpu_scale)
             if pre is not None:
-                pre["cpu_baseline"] = cpu_preprocess_baseline(args.scene)
+                # the SAME cloud size as the GPU leg (a few seconds on the box's cores)
+                pre["cpu_baseline"] = cpu_preprocess_baseline(args.scene, n0)
 
     if rank == 0:
         line = {
