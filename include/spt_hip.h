@@ -217,8 +217,8 @@ size_t spt_edge_attn_bwd_workspace_bytes(int H, int D, int Dv, int F);
  *                MFMA (16x the f32 pipe's rate), f32 accumulate: ~10 ulp of f32 per product;
  *   1            matrix pipe, f32 in / f32 accumulate (bitwise an fmaf chain);
  *   0            generic lane-per-output VALU kernels (every other shape uses these).
- * spt_attn_use_mfma(mode) selects process-wide and returns the previous mode; tests
- * cross-check all three at full scene size. */
+ * spt_attn_use_mfma(mode) selects process-wide and returns the previous mode (mode < -1: query
+ * only, nothing changes); tests cross-check all three at full scene size. */
 int spt_attn_use_mfma(int mode);
 /* Backward tiling of the bf16-pipe modes (2, 3): 2 (default) = the edge-lane kernel described
  * below when the caller's workspace allows it (else 1); 1 = 16-edge tiles over the edge

@@ -20,6 +20,7 @@ from torch import nn
 from . import spt_oracle as O
 
 
+LEAKY = None        # test hook: replaces leaky_relu(x, slope) (tests pin the derivative taken AT a kink)
 KEEP_GRAPH = False  # True: parameters stay attached (CPU module, autograd through the oracle)
 
 
@@ -39,7 +40,7 @@ def mlp(m, x, batch, dtype):
             if layer.bias is not None:
                 x = x + _p(layer.bias, dtype)
         elif isinstance(layer, nn.LeakyReLU):
-            x = torch.nn.functional.leaky_relu(x, layer.negative_slope)
+            x = (LEAKY or torch.nn.functional.leaky_relu)(x, layer.negative_slope)
         elif hasattr(layer, "mean_scale"):
             x = graph_norm(layer, x, batch, dtype)
         elif isinstance(layer, nn.Dropout):

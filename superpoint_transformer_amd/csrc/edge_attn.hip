@@ -824,6 +824,7 @@ extern "C" int spt_attn_bwd_packed(int on) {
 
 extern "C" int spt_attn_use_mfma(int mode) {
   const int prev = mfma_mode();
+  if (mode < -1) return prev;            // query only
   g_attn_mfma = mode < 0 ? 0 : (mode > 3 ? 3 : mode);
   return prev;
 }

@@ -44,15 +44,32 @@ __global__ __launch_bounds__(WAVES * 64, (K4 <= 32) ? 2 : 1) void skinny_linear_
   const int n0 = blockIdx.y * (16 * NBS);
   float* al = a_lds[wid];
 
+  // W's slab [16 NBS x K] reaches the B-operand registers through LDS: the workgroup reads it
+  // once with coalesced float4 loads (the waves' A-tile buffers double as the staging area: the
+  // slab is 16 NBS x K <= WAVES x 16 x K floats), each lane then picks its K4 x NBS values with
+  // LDS reads.  (Per-lane dword loads straight from global - 16 rows x 16 B per instruction, K4 x
+  // NBS instructions per wave - cost more than the tile's MFMAs at train-batch row counts, where
+  // a wave only sees one or two tiles.)
   float B[NBS][K4];                                     // lane (g, c): W[n0 + 16 nb + c][4 st + g]
   float bb[NBS];
+  {
+    float* wl = &a_lds[0][0];                           // [16 NBS][LDA]
+    constexpr int WV = 16 * NBS * K4;                   // float4 of the slab
+    for (int q = threadIdx.x; q < WV; q += WAVES * 64) {
+      const int rr = q / K4, k4 = q - rr * K4;
+      const bool nv = n0 + rr < N;
+      const float4 wv = nv ? *reinterpret_cast<const float4*>(W + (size_t)(n0 + rr) * K + 4 * k4)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(wl + rr * LDA + 4 * k4) = wv;
+    }
+    __syncthreads();
 #pragma unroll
-  for (int nb = 0; nb < NBS; ++nb) {
-    const bool nv = n0 + 16 * nb + c < N;
-    const float* wr = W + (size_t)(nv ? n0 + 16 * nb + c : 0) * K;
+    for (int nb = 0; nb < NBS; ++nb) {
 #pragma unroll
-    for (int st = 0; st < K4; ++st) B[nb][st] = nv ? wr[4 * st + g] : 0.f;
-    bb[nb] = (bias && nv) ? bias[n0 + 16 * nb + c] : 0.f;
+      for (int st = 0; st < K4; ++st) B[nb][st] = wl[(16 * nb + c) * LDA + 4 * st + g];
+      bb[nb] = (bias && n0 + 16 * nb + c < N) ? bias[n0 + 16 * nb + c] : 0.f;
+    }
+    __syncthreads();
   }
 
   const int64_t ntiles = (rows + TR - 1) / TR;
@@ -113,8 +130,10 @@ __global__ __launch_bounds__(WAVES * 64, (K4 <= 32) ? 2 : 1) void skinny_linear_
 // once; a second kernel sums the per-wave partials in a fixed order (deterministic).
 template <int K4>
 __global__ __launch_bounds__(WAVES * 64, 2) void skinny_dw_kernel(
-    const float* __restrict__ gy, const float* __restrict__ x, int64_t rows, int N,
+    const float* __restrict__ gy, const float* __restrict__ x, int64_t rows, int N, int KF,
     float* __restrict__ partial) {
+  // KF = the layer's full input width: blockIdx.z = K-column slab of x (KF = 128 runs as two
+  // 64-column slabs, each re-reading its G slab - G is the small operand at these widths)
   constexpr int K = 4 * K4, KB = K / 16, LDG = SLAB + 4, LDX = K + 4;
   constexpr int VG = TR * SLAB / 4 / 64, VX = TR * K / 4 / 64;   // float4 per lane per tile
   static_assert(K % 16 == 0 && TR * K % 256 == 0, "K is a multiple of 16");
@@ -124,6 +143,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void skinny_dw_kernel(
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, c = lane & 15;
   const int n0 = blockIdx.y * SLAB;
+  const int k0 = blockIdx.z * K;
   float* gl = g_lds[wid];
   float* xl = x_lds[wid];
   f32x4 C[4][KB];                                       // C[nb][kb][r] = dW[n0 + 16 nb + 4 g + r][16 kb + c]
@@ -148,7 +168,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void skinny_dw_kernel(
     for (int v = 0; v < VX; ++v) {
       const int q = v * 64 + lane, rr = q / K4, ch = q - rr * K4;
       const int64_t row = t * TR + rr;
-      nx[v] = (row < rows) ? *reinterpret_cast<const float4*>(x + row * K + ch * 4)
+      nx[v] = (row < rows) ? *reinterpret_cast<const float4*>(x + row * KF + k0 + ch * 4)
                            : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
@@ -184,13 +204,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void skinny_dw_kernel(
     }
   }
   // partial[wave][N x K | N]: this block fills rows n0 .. n0 + 63 of its wave's record
-  float* pw = partial + (size_t)wave * ((size_t)N * K + N);
+  float* pw = partial + (size_t)wave * ((size_t)N * KF + N);
 #pragma unroll
   for (int nb = 0; nb < 4; ++nb) {
     float v = bsum[nb];
     v += __shfl_xor(v, 16, 64);
     v += __shfl_xor(v, 32, 64);
-    if (g == 0) pw[(size_t)N * K + n0 + 16 * nb + c] = v;
+    if (g == 0 && k0 == 0) pw[(size_t)N * KF + n0 + 16 * nb + c] = v;
   }
 #pragma unroll
   for (int nb = 0; nb < 4; ++nb)
@@ -198,7 +218,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void skinny_dw_kernel(
     for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        pw[(size_t)(n0 + 16 * nb + 4 * g + r) * K + 16 * kb + c] = C[nb][kb][r];
+        pw[(size_t)(n0 + 16 * nb + 4 * g + r) * KF + k0 + 16 * kb + c] = C[nb][kb][r];
 }
 
 // sums of per-wave records [ntab][len], fixed order: 16 columns x 64 slices per 1024-thread block
@@ -322,7 +342,7 @@ using namespace spt::skinny;
 constexpr int DW_BLOCKS = 256;                          // x 4 waves: partial tables per slab
 
 extern "C" int spt_skinny_dw_supported(int K, int N) {
-  return (K == 32 || K == 64) && N >= SLAB && N % SLAB == 0 && N <= 1024;
+  return (K == 32 || K == 64 || K == 128) && N >= SLAB && N % SLAB == 0 && N <= 1024;
 }
 extern "C" size_t spt_skinny_dw_workspace_bytes(int K, int N) {
   return (size_t)DW_BLOCKS * WAVES * N * (K + 1) * sizeof(float);
@@ -345,14 +365,15 @@ extern "C" int spt_skinny_dw_f32(const float* gy, const float* x, int64_t rows, 
   }
   const int64_t tiles = ceil_div(rows, TR);
   int64_t bx = ceil_div(tiles, WAVES);
-  const int64_t cap = DW_BLOCKS / slabs > 1 ? DW_BLOCKS / slabs : 1;
+  const int kslabs = K > 64 ? K / 64 : 1;
+  const int64_t cap = DW_BLOCKS / (slabs * kslabs) > 1 ? DW_BLOCKS / (slabs * kslabs) : 1;
   if (bx > cap) bx = cap;
-  const dim3 grid((unsigned)bx, (unsigned)slabs);
+  const dim3 grid((unsigned)bx, (unsigned)slabs, (unsigned)kslabs);
   float* partial = (float*)ws;
   if (K == 32)
-    skinny_dw_kernel<8><<<grid, WAVES * 64, 0, stream>>>(gy, x, rows, N, partial);
+    skinny_dw_kernel<8><<<grid, WAVES * 64, 0, stream>>>(gy, x, rows, N, K, partial);
   else
-    skinny_dw_kernel<16><<<grid, WAVES * 64, 0, stream>>>(gy, x, rows, N, partial);
+    skinny_dw_kernel<16><<<grid, WAVES * 64, 0, stream>>>(gy, x, rows, N, K, partial);
   sum_tables_kernel<<<(N * (K + 1) + 15) / 16, 1024, 0, stream>>>(partial, (int)bx * WAVES, N * (K + 1),
                                                                   N * K, gw, gb);
   SPT_CHECK_LAUNCH();

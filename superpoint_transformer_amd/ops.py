@@ -526,9 +526,202 @@ def edge_attention(qkv, edge_index, edge_attr=None, k_rpe=None, q_rpe=None, v_rp
     Wk, bk = wb(k_rpe)
     Wq, bq = wb(q_rpe)
     Wv, bv = wb(v_rpe)
-    return _EdgeAttention.apply(qkv, ecsr, edge_attr, Wk, bk, Wq, bq, Wv, bv,
-                                int(num_heads), int(qk_dim), int(scale_mode), float(scale_a),
-                                ea_grad if torch.is_grad_enabled() else None)
+    H, D = int(num_heads), int(qk_dim)
+    share = ea_grad if torch.is_grad_enabled() else None
+    split = _matrix_pipe_split(qkv, edge_attr, Wk, Wq, Wv, H, D)
+    if split is None:
+        return _EdgeAttention.apply(qkv, ecsr, edge_attr, Wk, bk, Wq, bq, Wv, bv, H, D,
+                                    int(scale_mode), float(scale_a), share)
+    # wider head layouts (SPT-128: 16 heads of value dim 8; 32 heads) on the matrix-pipe kernels
+    G, J, _ = split
+    return _EdgeAttentionSplit.apply(qkv, ecsr, edge_attr, Wk, bk, Wq, bq, Wv, bv, H, G, J,
+                                     int(scale_mode), float(scale_a), share)
+
+
+class _EdgeAttentionSplit(torch.autograd.Function):
+    """Wider head layouts on the matrix-pipe kernels, by decomposition.
+
+    The MFMA / edge-lane kernels are built for 16 heads of qk_dim 4 and value dim 4.  Heads are
+    independent attention problems and, within a head, the value dims only enter through
+    out = sum_e a_e v_e (linear in v; its backward dc = a (<g, v> - <g, out>) is a SUM over the
+    value dims), so H = 16 G heads of value dim 4 J decompose EXACTLY into G x J problems of the
+    built shape: head group g, value slice j -> columns [q_g | k_g | v_g[:, :, 4j:4j+4]] with the
+    matching rows of the RPE weights.  Every pass recomputes the softmax of its head group (the
+    price: J x the q / k work).  SPT-128 (KITTI-360: H 16, value dim 8) = 2 passes, 32 heads x 4
+    (ScanNet) = 2 passes.
+
+    One autograd node for all passes: the operands of every pass are laid out by ONE gather
+    ([G J, N, 192]), the passes write into slabs of one buffer, d edge_attr accumulates in place
+    (``acc``) and the q / k / weight gradients of a head group's J passes are summed by one
+    reduction each - a per-pass autograd graph (slices, cat, CopySlices, AccumulateGrad) cost
+    ~40 five-microsecond launches per block, which is what a train batch's step time is made of."""
+
+    @staticmethod
+    def _cols(H, G, J, dev):
+        key = (H, G, J, str(dev))
+        c = _SPLIT_COLS.get(key)
+        if c is None:
+            QK, Dv = H * 4, 4 * J
+            cols = []
+            for gi in range(G):
+                for j in range(J):
+                    qc = torch.arange(64 * gi, 64 * gi + 64)
+                    vc = (2 * QK + (16 * gi + torch.arange(16)).view(16, 1) * Dv + 4 * j
+                          + torch.arange(4).view(1, 4)).reshape(64)
+                    cols.append(torch.cat([qc, QK + qc, vc]))
+            c = _SPLIT_COLS[key] = torch.stack(cols).to(dev)            # [G J, 192]
+        return c
+
+    @staticmethod
+    def forward(ctx, qkv, ecsr, edge_attr, Wk, bk, Wq, bq, Wv, bv, H, G, J, scale_mode, scale_a,
+                share=None):
+        _lib.require_cuda(qkv)
+        q2 = _f32c(qkv)
+        n = q2.shape[0]
+        dev = q2.device
+        ea = _f32c(edge_attr)
+        if ecsr.n != n or ea.shape[0] != ecsr.e:
+            raise ValueError("qkv / edge_attr rows do not match the graph")
+        P, Dv, F = G * J, 4 * J, 32
+        cols = _EdgeAttentionSplit._cols(H, G, J, dev)
+        qa = q2[:, cols.view(-1)].view(n, P, 192).transpose(0, 1).contiguous()       # [P, n, 192]
+        Wk2, Wq2 = _f32c(Wk), _f32c(Wq)
+        bk2, bq2 = _f32c(bk), _f32c(bq)
+        Wva = _f32c(Wv).view(G, 16, J, 4, F).permute(0, 2, 1, 3, 4).contiguous()      # [G, J, 64, F]
+        bva = None if bv is None else _f32c(bv).view(G, 16, J, 4).permute(0, 2, 1, 3).contiguous()
+        oa = torch.empty((P, n, 64), dtype=torch.float32, device=dev)
+        m = torch.empty((P, n, 16), dtype=torch.float32, device=dev)
+        z = torch.empty((P, n, 16), dtype=torch.float32, device=dev)
+        mode = _precision.attention_mode()
+        with torch.cuda.device(dev):
+            for gi in range(G):
+                cs = slice(64 * gi, 64 * gi + 64)
+                for j in range(J):
+                    p = gi * J + j
+                    with _timed(f"edge_attn_fwd:{n}:{ecsr.e}"):
+                        st = _lib.lib.spt_edge_attn_fwd_ex_f32(
+                            _lib.ptr(qa[p]), n, 16, 4, 4, _lib.ptr(ecsr.erowptr), _lib.ptr(ecsr.eperm),
+                            _lib.ptr(ecsr.tgt_sorted), ecsr.e, _lib.ptr(ea), F,
+                            _lib.ptr(Wk2[cs]), _lib.ptr(None if bk2 is None else bk2[cs]),
+                            _lib.ptr(Wq2[cs]), _lib.ptr(None if bq2 is None else bq2[cs]),
+                            _lib.ptr(Wva[gi, j]), _lib.ptr(None if bva is None else bva[gi, j]),
+                            scale_mode, scale_a, _lib.ptr(oa[p]), _lib.ptr(m[p]), _lib.ptr(z[p]),
+                            mode, _lib.stream_ptr(dev))
+                    _lib.check(st, "spt_edge_attn_fwd_ex_f32")
+        ctx.mode = mode
+        ctx.save_for_backward(qa, ea, Wk2, Wq2, Wva, oa, m, z,
+                              *[t for t in (bk2, bq2, bva) if t is not None])
+        ctx.has_b = [t is not None for t in (bk2, bq2, bva)]
+        ctx.meta = (ecsr, H, G, J, scale_mode, scale_a, qkv.dtype, edge_attr.dtype)
+        ctx.share = ctx.rank = None
+        if share is not None and edge_attr.dtype == torch.float32 and edge_attr.requires_grad:
+            ctx.share, ctx.rank = share, share.enter(edge_attr)
+        out = oa.view(G, J, n, 16, 4).permute(2, 0, 3, 1, 4).reshape(n, H * Dv)
+        return out.to(qkv.dtype)
+
+    @staticmethod
+    def backward(ctx, gout):
+        ecsr, H, G, J, scale_mode, scale_a, q_dtype, ea_dtype = ctx.meta
+        saved = list(ctx.saved_tensors)
+        qa, ea, Wk2, Wq2, Wva, oa, m, z = saved[:8]
+        rest = saved[8:]
+        bk2, bq2, bva = [rest.pop(0) if h else None for h in ctx.has_b]
+        P, n = qa.shape[0], qa.shape[1]
+        dev, F, Dv, QK = qa.device, 32, 4 * J, 4 * H
+        ga = _f32c(gout).view(n, G, 16, J, 4).permute(1, 3, 0, 2, 4).contiguous().view(P, n, 64)
+        gqa = torch.empty_like(qa)
+        share, acc = ctx.share, 0
+        if share is not None and share.buf is not None:
+            gea, acc = share.buf, 1
+        else:
+            gea = torch.empty_like(ea)
+            if share is not None:
+                share.buf = gea
+        gWk = torch.empty((P, 64, F), dtype=torch.float32, device=dev)
+        gWq = torch.empty_like(gWk)
+        gWv = torch.empty_like(gWk)
+        gbk = torch.empty((P, 64), dtype=torch.float32, device=dev) if bk2 is not None else None
+        gbq = torch.empty((P, 64), dtype=torch.float32, device=dev) if bq2 is not None else None
+        gbv = torch.empty((P, 64), dtype=torch.float32, device=dev) if bva is not None else None
+        nb = _lib.lib.spt_edge_attn_bwd_ex_workspace_bytes(n, ecsr.e, 16, 4, 4, F)
+        ws = _workspace(nb, dev)
+        src = tids = tperm = trowptr = None
+        if ecsr.e > 0 and _lib.lib.spt_edge_attn_bwd_el_supported(16, 4, 4, F, ctx.mode):
+            src, tids, tv = ecsr.src_sorted(), ecsr.tile_ids(), ecsr.target_view()
+            tperm, trowptr = tv.perm, tv.rowptr
+        with torch.cuda.device(dev):
+            for gi in range(G):
+                cs = slice(64 * gi, 64 * gi + 64)
+                for j in range(J):
+                    p = gi * J + j
+                    with _timed(f"edge_attn_bwd:{n}:{ecsr.e}"):
+                        st = _lib.lib.spt_edge_attn_bwd_ex_f32(
+                            _lib.ptr(qa[p]), n, 16, 4, 4, _lib.ptr(ecsr.erowptr), _lib.ptr(ecsr.eperm),
+                            _lib.ptr(ecsr.tgt_sorted), _lib.ptr(src), _lib.ptr(tids), _lib.ptr(tperm),
+                            _lib.ptr(trowptr), ecsr.e, _lib.ptr(ea), F,
+                            _lib.ptr(Wk2[cs]), _lib.ptr(None if bk2 is None else bk2[cs]),
+                            _lib.ptr(Wq2[cs]), _lib.ptr(None if bq2 is None else bq2[cs]),
+                            _lib.ptr(Wva[gi, j]), _lib.ptr(None if bva is None else bva[gi, j]),
+                            scale_mode, scale_a, _lib.ptr(oa[p]), _lib.ptr(m[p]), _lib.ptr(z[p]),
+                            _lib.ptr(ga[p]), _lib.ptr(gqa[p]), _lib.ptr(gea), acc,
+                            _lib.ptr(gWk[p]), _lib.ptr(None if gbk is None else gbk[p]),
+                            _lib.ptr(gWq[p]), _lib.ptr(None if gbq is None else gbq[p]),
+                            _lib.ptr(gWv[p]), _lib.ptr(None if gbv is None else gbv[p]),
+                            ctx.mode, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+                    _lib.check(st, "spt_edge_attn_bwd_ex_f32")
+                    acc = 1
+        # q / k (and their encoders') gradients: the sum over a head group's J value slices
+        g5 = gqa.view(G, J, n, 192)
+        gqk = g5[..., :128].sum(1) if J > 1 else g5[:, 0, :, :128]             # [G, n, 128]
+        gqkv = torch.cat([gqk[..., :64].permute(1, 0, 2).reshape(n, QK),
+                          gqk[..., 64:].permute(1, 0, 2).reshape(n, QK),
+                          g5[..., 128:].reshape(G, J, n, 16, 4).permute(2, 0, 3, 1, 4).reshape(n, H * Dv)], 1)
+
+        def over_j(t, tail):
+            if t is None:
+                return None
+            t = t.view(G, J, *tail)
+            return (t.sum(1) if J > 1 else t[:, 0]).reshape(G * tail[0], *tail[1:])
+
+        def value_rows(t, tail):                       # [G, J, 16, 4, ...] -> rows h * Dv + 4 j + d
+            if t is None:
+                return None
+            t = t.view(G, J, 16, 4, *tail)
+            return t.permute(0, 2, 1, 3, *range(4, 4 + len(tail))).reshape(H * Dv, *tail)
+
+        if share is not None:
+            if ctx.rank == 0:
+                share.buf = None
+            else:
+                gea = None
+        return (gqkv.to(q_dtype), None, None if gea is None else gea.to(ea_dtype),
+                over_j(gWk, (64, F)), over_j(gbk, (64,)), over_j(gWq, (64, F)), over_j(gbq, (64,)),
+                value_rows(gWv, (F,)), value_rows(gbv, ()), None, None, None, None, None, None)
+
+
+_SPLIT_COLS = {}
+
+
+def _matrix_pipe_split(qkv, edge_attr, Wk, Wq, Wv, H, D):
+    """(G, J, Dv) when a head layout other than the built (16, 4, 4) decomposes into G x J passes
+    of it (H = 16 G, qk_dim 4, value dim 4 J, in_rpe_dim 32, all three RPE encoders, a matrix-pipe
+    precision active); None for the built shape itself and for everything else (generic kernels)."""
+    if D != 4 or H % 16 or edge_attr is None or Wk is None or Wq is None or Wv is None:
+        return None
+    if edge_attr.shape[1] != 32:
+        return None
+    C = qkv.shape[1] - 2 * H * D
+    if C <= 0 or C % H:
+        return None
+    Dv = C // H
+    if Dv % 4 or (H == 16 and Dv == 4):
+        return None
+    mode = _precision.attention_mode()
+    if mode < 0:
+        mode = _lib.lib.spt_attn_use_mfma(-2)          # query: any value < -1 leaves the default
+    if (mode & 3) == 0:
+        return None
+    return H // 16, Dv // 4, Dv
 
 
 # ---------------------------------------------------------------------------

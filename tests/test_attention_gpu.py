@@ -74,6 +74,7 @@ CASES = [
     (300, 10.0, 16, 4, 4, 32, "kqv", None),
     (200, 25.0, 16, 4, 8, 32, "kqv", None),      # SPT-128: value dim 8
     (150, 8.0, 32, 4, 4, 32, "kqv", "d+g"),      # scannet: 32 heads
+    (140, 9.0, 32, 4, 8, 32, "kqv", None),       # both: 2 head groups x 2 value slices (matrix pipe only)
     (120, 6.0, 16, 2, 1, 18, "kqv", "d"),        # nano: qk_dim 2, dim 16, raw 18-D edge features
     (130, 7.0, 16, 2, 1, 16, "kqv", None),       # nano-2: qk_dim 2, dim 16, edge MLP to 16
     (100, 5.0, 16, 4, 4, 32, "k", "g"),
@@ -411,3 +412,46 @@ def test_attention_dropout_is_the_fused_kernel_in_eval_and_unbiased_in_training(
     # E[dropout(a)] = a: the mean of 200 draws is within a few standard errors of the plain output
     assert float((mean - ref).abs().max()) < 0.25 * float(ref.abs().max())
     assert float((mean - ref).abs().mean()) < 0.03 * float(ref.abs().mean()) + 0.01
+
+
+@pytest.mark.parametrize("H,Dv", [(16, 8), (32, 4)])
+def test_wider_head_layouts_decompose_onto_the_matrix_pipe_kernels(H, Dv, dev):
+    """SPT-128 (KITTI-360: 16 heads, value dim 8) and 32 heads (ScanNet) run as G x J passes
+    of the built (16, 4, 4, 32) matrix-pipe kernels (ops._matrix_pipe_split): heads are independent,
+    the value dims of a head only enter linearly - the decomposition is exact.
+    Against the generic VALU kernels of the same call (precision 0), forward and every gradient."""
+    from superpoint_transformer_amd import _lib, ops, precision
+    gen = torch.Generator().manual_seed(H * 10 + Dv)
+    n, D, F = 400, 4, 32
+    ei = _rand_graph(gen, n, 12.0)
+    E = ei.shape[1]
+    qkv = torch.randn(n, 2 * H * D + H * Dv, generator=gen)
+    ea = torch.randn(E, F, generator=gen) * 0.4
+    W = [(torch.randn(c, F, generator=gen) * 0.1, torch.randn(c, generator=gen) * 0.1)
+         for c in (H * D, H * D, H * Dv)]
+    gw = torch.randn(n, H * Dv, generator=gen)
+
+    def run(mode_name):
+        q = qkv.to(dev).requires_grad_()
+        e = ea.to(dev).requires_grad_()
+        ps = [(w.to(dev).requires_grad_(), b.to(dev).requires_grad_()) for w, b in W]
+        if mode_name is None:                               # generic kernels: process default 0
+            prev = _lib.lib.spt_attn_use_mfma(0)
+            try:
+                assert ops._matrix_pipe_split(q, e, ps[0][0], ps[1][0], ps[2][0], H, D) is None
+                out = ops.edge_attention(q, ei.to(dev), e, *ps, num_heads=H, qk_dim=D, scale_a=0.7)
+                (out * gw.to(dev)).sum().backward()
+            finally:
+                _lib.lib.spt_attn_use_mfma(prev)
+        else:
+            with precision.matrix_precision(mode_name):
+                split = ops._matrix_pipe_split(q, e, ps[0][0], ps[1][0], ps[2][0], H, D)
+                assert split == (H // 16, Dv // 4, Dv)
+                out = ops.edge_attention(q, ei.to(dev), e, *ps, num_heads=H, qk_dim=D, scale_a=0.7)
+                (out * gw.to(dev)).sum().backward()
+        return [out.detach(), q.grad, e.grad] + [t.grad for p in ps for t in p]
+
+    ref = run(None)
+    got = run("f32")
+    for a, r in zip(got, ref):
+        assert (a - r).abs().max().item() <= 1e-5 + 2e-4 * r.abs().max().item()

@@ -38,8 +38,9 @@ def _worker(rank, world, port, out):
             g = torch.Generator().manual_seed(1000 * step + scenes[step % len(scenes)])
             x = torch.randn(16, 6, generator=g)
             model(x).square().mean().backward()
-            assert bucket.check_views()               # autograd accumulated in place
-            local.append(bucket.flat.clone())
+            assert not bucket.check_views()           # autograd wrote plain per-parameter tensors
+            local.append(bucket.pack().clone())
+            assert bucket.check_views()               # packed: every p.grad aliases the flat buffer
             bucket.reduce()
             opt.step()
         w = torch.cat([p.detach().flatten() for p in model.parameters()])
@@ -68,7 +69,10 @@ def test_two_rank_gloo_data_parallel_step():
 def test_single_process_is_a_no_op():
     model = torch.nn.Linear(4, 2)
     bucket = parallel.FlatGradAllReduce(model.parameters())
+    bucket.zero()
     model(torch.ones(3, 4)).sum().backward()
-    before = bucket.flat.clone()
+    assert torch.equal(bucket.reduce(), torch.zeros(10)) and not bucket.check_views()   # untouched
+    before = bucket.pack().clone()
+    assert torch.equal(before[:8], torch.full((8,), 3.0)) and bucket.check_views()
     assert torch.equal(bucket.reduce(), before)
     assert parallel.shard_items(5, 0, 1) == [0, 1, 2, 3, 4]

@@ -26,10 +26,10 @@ from superpoint_transformer_amd import hotpath, parallel
 from superpoint_transformer_amd.synthetic import make_nag
 nag = make_nag("R", seed=5, device=dev, sizes=(20000, 600, 250, 9000, 7000, 2))
 path = hotpath.SPTTrainStep(nag, dev, world=1)
-assert path.bucket.always and path.bucket.check_views()
+assert path.bucket.always
 loss = path.step()                       # forward + loss + backward + all-reduce + AdamW
 torch.cuda.synchronize()
-assert torch.isfinite(loss).item()
+assert torch.isfinite(loss).item() and path.bucket.check_views()
 before = path.bucket.flat.clone()
 after = path.bucket.reduce().clone()     # one more collective on the filled buffer
 torch.cuda.synchronize()

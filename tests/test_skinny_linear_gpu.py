@@ -52,7 +52,7 @@ def test_unsupported_shapes_and_small_inputs_use_the_library(dev):
 
 
 @pytest.mark.parametrize("rows", [1, 15, 16, 17, 4099, 70001, 428_571])
-@pytest.mark.parametrize("K,N", [(64, 192), (64, 64), (32, 64), (32, 128)])
+@pytest.mark.parametrize("K,N", [(64, 192), (64, 64), (32, 64), (32, 128), (128, 128), (128, 256)])
 def test_weight_gradient_kernel_matches_float64(rows, K, N, dev):
     """dW = G^T X on the skinny dW kernel (f32 MFMA, per-wave partials, fixed-order sum) against
     float64: the error is that of an f32 sum over `rows` terms - bar 1e-6 * sqrt(rows) of the

@@ -98,8 +98,127 @@ def test_hip_model_matches_reference_spt_forward(which, dev):
         return ((a.double() - r).abs().max() / r.abs().max().clamp(min=1e-2)).item()
 
     below_pool = max(rel(g32[k], grads[k]) for k in grads if k.startswith("first_stage."))
+    hip = {}
     for k, p in gm.named_parameters():
         assert p.grad is not None, k
-        err = rel(p.grad.detach().cpu(), grads[k])
-        err32 = below_pool if k.startswith("first_stage.") else rel(g32[k], grads[k])
-        assert err <= max(1e-3, 3 * err32), f"{k}: hip {err:.3e} vs f32-oracle {err32:.3e}"
+        hip[k] = p.grad.detach().cpu().double()
+    bar = {k: max(1e-3, 3 * (below_pool if k.startswith("first_stage.") else rel(g32[k], grads[k])))
+           for k in grads}
+
+    def failures(ref):
+        return [f"{k}: hip {rel(hip[k], ref[k]):.3e} vs bar {bar[k]:.3e}" for k in ref
+                if rel(hip[k], ref[k]) > bar[k]]
+
+    bad = failures(grads)
+    if bad:
+        # LeakyReLU inputs within f32 rounding of zero: which side of the kink an f32 evaluation
+        # lands on is not defined by the reference (one flipped element moves every gradient
+        # upstream of it by ~1e-2).  Find the derivative choices AT those elements that explain the
+        # HIP gradients and hold the HIP path to the same bars against THAT exact f64 gradient.
+        ref2, flips, cand = _kink_resolved_gradients(net, net32, levels, gws, grads, hip)
+        bad2 = failures(ref2)
+        assert not bad2, (f"{len(bad)} tensors off the reference; {len(flips)} of {len(cand)} kink "
+                          f"elements flipped still leaves: {bad2[:5]}")
+
+
+class _KinkLeaky(torch.autograd.Function):
+    """leaky_relu whose derivative follows the given side mask (identical to the plain one away
+    from x == 0; at elements the caller marks, the other one-sided derivative)."""
+
+    @staticmethod
+    def forward(ctx, x, slope, pos):
+        ctx.save_for_backward(pos)
+        ctx.slope = slope
+        return torch.nn.functional.leaky_relu(x, slope)
+
+    @staticmethod
+    def backward(ctx, g):
+        (pos,) = ctx.saved_tensors
+        return g * torch.where(pos, 1.0, ctx.slope).to(g.dtype), None, None
+
+
+def _oracle_gradients(net, levels, gws, dtype, flips=(), record=None):
+    """Parameter gradients of the oracle restatement; ``flips`` = [(leaky call, flat element)] whose
+    derivative is taken on the other side; ``record`` collects every LeakyReLU input."""
+    calls = [0]
+
+    def leaky(x, slope):
+        i = calls[0]
+        calls[0] += 1
+        if record is not None:
+            record.append(x.detach().clone())
+        pos = x.detach() > 0
+        for c, e in flips:
+            if c == i:
+                pos.view(-1)[e] ^= True
+        return _KinkLeaky.apply(x, slope, pos)
+
+    m = copy.deepcopy(net).cpu().to(dtype)
+    OM.LEAKY = leaky
+    try:
+        got = OM.spt_forward(m, levels, dtype=dtype, keep_graph=True)
+        sum((a * w.to(dtype)).sum() for a, w in zip(got, gws)).backward()
+    finally:
+        OM.LEAKY = None
+    return {k: p.grad.double() for k, p in m.named_parameters()}
+
+
+def _kink_candidates(h64, h32):
+    cand = []
+    for i, (a, b) in enumerate(zip(h64, h32)):
+        tau = 16 * (a - b.double()).square().mean().sqrt() + 1e-12
+        cand += [(i, int(e)) for e in (a.abs().view(-1) < tau).nonzero().flatten()]
+    return cand
+
+
+def _kink_resolved_gradients(net, net32, levels, gws, grads, hip, max_candidates=32):
+    """Exact f64 oracle gradients with the LeakyReLU derivative taken on the side that explains
+    ``hip`` at the elements whose f64 input lies within f32 arithmetic error of zero
+    (|h| < 16 x the layer's rms |h64 - h32|).  The effects of sparse flips add up to first order:
+    one oracle backward per candidate gives its effect, a least-squares fit against the observed
+    deviation picks the flipped set, and one more backward evaluates that set exactly."""
+    h64, h32 = [], []
+    base = _oracle_gradients(net, levels, gws, torch.float64, record=h64)
+    for k in grads:                                     # the restatement IS the fixture's reference
+        assert (base[k] - grads[k]).abs().max() <= 1e-6 * grads[k].abs().max().clamp(min=1e-12), k
+    _oracle_gradients(net32, levels, gws, torch.float32, record=h32)
+    cand = _kink_candidates(h64, h32)
+    cand = sorted(set(cand), key=cand.index)
+    assert 0 < len(cand) <= max_candidates, f"{len(cand)} LeakyReLU inputs within f32 error of zero"
+    keys = list(grads)
+    scale = {k: grads[k].abs().max().clamp(min=1e-2) for k in keys}
+
+    def flat(d, ref=None):
+        return torch.cat([((d[k] - (ref[k] if ref else 0)) / scale[k]).flatten() for k in keys])
+
+    cols = torch.stack([flat(_oracle_gradients(net, levels, gws, torch.float64, flips=[c]), base)
+                        for c in cand], 1)
+    live = cols.abs().amax(0) > 0                      # (an element under a max-pool that did not
+    sol = torch.zeros(len(cand), dtype=cols.dtype)     #  select it has no effect at all)
+    sol[live] = torch.linalg.lstsq(cols[:, live], flat(hip, base).unsqueeze(1),
+                                   driver="gelsd").solution.flatten()
+    flips = [c for c, s_ in zip(cand, sol) if s_ > 0.5]
+    return _oracle_gradients(net, levels, gws, torch.float64, flips=flips), flips, cand
+
+
+def test_kink_resolution_recovers_a_planted_flip():
+    """The helper the GPU test falls back on: gradients evaluated with the derivative of two
+    near-zero LeakyReLU inputs taken on the other side are (a) off the reference by far more than
+    the parity bar and (b) traced back to exactly those two elements."""
+    net, levels, outs, gws, grads, _ = _load("spt128")
+    net32 = copy.deepcopy(net).float()
+    h64 = []
+    _oracle_gradients(net, levels, gws, torch.float64, record=h64)
+    # the two inputs closest to zero in the last two LeakyReLU calls
+    planted = [(i, int(h64[i].abs().view(-1).argmin())) for i in (len(h64) - 1, len(h64) - 2)]
+    fake = _oracle_gradients(net, levels, gws, torch.float64, flips=planted)
+    worst = max(((fake[k] - grads[k]).abs().max() / grads[k].abs().max().clamp(min=1e-2)).item()
+                for k in grads)
+    assert worst > 1e-3
+    import unittest.mock as mock
+    plain = _kink_candidates
+    with mock.patch(__name__ + "._kink_candidates", lambda a, b: planted + plain(a, b)):
+        ref2, flips, cand = _kink_resolved_gradients(net, net32, levels, gws, grads, fake)
+    assert sorted(flips) == sorted(planted)
+    for k in grads:
+        assert (ref2[k] - fake[k]).abs().max() <= 1e-12 * max(1.0, fake[k].abs().max().item())

@@ -11,7 +11,8 @@ from superpoint_transformer_amd import hotpath, synthetic  # noqa: E402
 scene = sys.argv[1] if len(sys.argv) > 1 else "S"
 dev = torch.device("cuda:0")
 nag = synthetic.make_nag(scene, device=dev)
-step = hotpath.build(nag, dev, 1, "all")
+model = sys.argv[2] if len(sys.argv) > 2 else "spt64"
+step = hotpath.build(nag, dev, 1, "all", model=model)
 for _ in range(3):
     step.step()
 torch.cuda.synchronize()
