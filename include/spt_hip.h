@@ -654,6 +654,13 @@ int spt_fused_linear_pooled_supported(int K, int N);
  * spt_fused_linear_use_split_bf16 describes them (< 0: the process default), so that two models
  * at different precisions, or two streams, never change each other's arithmetic. */
 int spt_fused_linear_pooled_supported_ex(int K, int N, int mode);
+/* Tile staging of the split-bf16 / bf16 backward kernels: LDS-DMA (global_load_lds: one memory
+ * round trip per 16-row tile, csrc/fused_mlp_dma.hip; default, where the (K, N) is built: 64->128,
+ * 64->64, 32->64) or register-staged (csrc/fused_mlp.hip).  Same arithmetic, same summation order
+ * inside a tile.  Process-wide: spt_fused_linear_bwd_use_dma(0 | 1) (< 0: query), returns the
+ * previous setting; per call: OR SPT_FMLP_BWD_REGISTER_STAGED into the `mode` of the *_ex entries. */
+#define SPT_FMLP_BWD_REGISTER_STAGED 4
+int spt_fused_linear_bwd_use_dma(int on);
 int spt_fused_linear_fwd_ex_f32(const float* x, int64_t r0, int64_t r1, int K, const float* W,
                                 int N, const float* pre_am, const float* pre_scale,
                                 const float* pre_bias, float pre_slope, float* h, double* total,

@@ -1041,6 +1041,16 @@ static int grid_for(int64_t rows, int per_cu) {
 }
 
 }  // namespace fmlp
+
+// fused_mlp_dma.hip: the backward with LDS-DMA tile staging
+bool fmlp_dma_supported(int K, int N);
+int fmlp_dma_bwd_launch(bool pooled, bool lo, const float* gy, const float* h, int64_t r0, int64_t r1,
+                        int N, const float* am, const float* sc, const float* bs, float slope,
+                        const float* c1, const float* c2, const float* c3, const float* xprev, int K,
+                        const float* pam, const float* psc, const float* pbs, float pslope,
+                        const float* W, float* gx, float* gw_partial, double* pstat_partial,
+                        const int32_t* perm, const int32_t* pos_seg, const float* gout,
+                        const int32_t* arg, hipStream_t stream);
 }  // namespace spt
 
 using namespace spt;
@@ -1058,7 +1068,17 @@ using namespace spt::fmlp;
 //    precision mode.  Process-wide, returns the previous setting.
 static int g_fmlp_mode = 1;
 // per-call mode word of the *_ex entries: < 0 = the process default above, else 0..3
-static inline int fmlp_mode_of(int mode) { return mode < 0 ? g_fmlp_mode : (mode > 3 ? 3 : mode); }
+static inline int fmlp_mode_of(int mode) { return mode < 0 ? g_fmlp_mode : (mode & 3); }
+// Backward formulation of the split-bf16 / bf16 modes: 1 (default) = tiles staged by LDS-DMA
+// (fused_mlp_dma.hip) where the shape is built, 0 = register-staged everywhere.  Per call: bit 2
+// of the mode word (SPT_FMLP_BWD_REGISTER_STAGED) forces the register-staged kernels.
+static int g_fmlp_dma = 1;
+static inline bool fmlp_dma_of(int mode) { return mode < 0 ? g_fmlp_dma != 0 : !(mode & 4); }
+extern "C" int spt_fused_linear_bwd_use_dma(int on) {
+  const int prev = g_fmlp_dma;
+  if (on >= 0) g_fmlp_dma = on != 0;
+  return prev;
+}
 extern "C" int spt_fused_linear_use_split_bf16(int mode) {
   const int prev = g_fmlp_mode;
   g_fmlp_mode = mode < 0 ? 0 : (mode > 3 ? 3 : mode);
@@ -1195,7 +1215,13 @@ extern "C" int spt_fused_linear_bwd_pooled_ex_f32(
           nullptr, h, p0, p1, am, scale, bias, slope, c1, c2, c3, xprev, K, pre_am, pre_scale,   \
           pre_bias, pre_slope, W, gx, gwp, prev_total ? pst : nullptr, perm, pos_seg, gout, arg); \
   }
-  SPT_FMLP_POOLED_SHAPES(X)
+  if (fmlp_dma_of(mode) && fmlp_dma_supported(K, N)) {
+    nw = fmlp_dma_bwd_launch(true, g_fmlp_mode != 3, nullptr, h, p0, p1, N, am, scale, bias, slope, c1,
+                             c2, c3, xprev, K, pre_am, pre_scale, pre_bias, pre_slope, W, gx, gwp,
+                             prev_total ? pst : nullptr, perm, pos_seg, gout, arg, stream);
+  } else {
+    SPT_FMLP_POOLED_SHAPES(X)
+  }
 #undef X
   reduce_tables_kernel<float><<<(N * K + 15) / 16, 1024, 0, stream>>>(gwp, nw, N * K, gW, accumulate);
   if (prev_total)
@@ -1285,7 +1311,13 @@ extern "C" int spt_fused_linear_bwd_ex_f32(const float* gy, const float* h, int6
           gy, h, r0, r1, am, scale, bias, slope, c1, c2, c3, xprev, K, pre_am, pre_scale,        \
           pre_bias, pre_slope, W, nullptr, gwp, nullptr);                                        \
   }
-  SPT_FMLP_SHAPES(X)
+  if (g_fmlp_split_bf16 && gx && fmlp_dma_of(mode) && fmlp_dma_supported(K, N)) {
+    nw = fmlp_dma_bwd_launch(false, g_fmlp_mode != 3, gy, h, r0, r1, N, am, scale, bias, slope, c1, c2,
+                             c3, xprev, K, pre_am, pre_scale, pre_bias, pre_slope, W, gx, gwp,
+                             prev_total ? pst : nullptr, nullptr, nullptr, nullptr, nullptr, stream);
+  } else {
+    SPT_FMLP_SHAPES(X)
+  }
 #undef X
   reduce_tables_kernel<float><<<(N * K + 15) / 16, 1024, 0, stream>>>(gwp, nw, N * K, gW, accumulate);
   if (prev_total)

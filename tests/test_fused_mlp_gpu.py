@@ -162,3 +162,58 @@ def test_mlp_folded_into_the_max_pool_equals_mlp_then_pool(rows, nseg, B, dev):
     # order
     for a, b in zip(gpf, gpu_):
         assert torch.allclose(a, b, rtol=1e-4, atol=2e-5 * float(b.abs().max()))
+
+
+@pytest.mark.parametrize("K,N", [(64, 128), (32, 64), (64, 64)])
+@pytest.mark.parametrize("rows,nseg", [(10_007, 300), (4_099, 1500), (17, 2)])
+@pytest.mark.parametrize("pooled", [True, False])
+def test_dma_staged_backward_is_bitwise_the_register_staged_one(K, N, rows, nseg, pooled, dev):
+    """csrc/fused_mlp_dma.hip (tiles staged by global_load_lds, swizzled LDS layout, gx leaving as
+    whole rows) against csrc/fused_mlp.hip's register-staged kernels through the C ABI: same
+    products, same summation order inside a tile and across the per-wave tables - gx, gW and the
+    f64 statistics agree BIT FOR BIT.  Covers a short last tile (rows % 16 != 0), tiles over more
+    segments than one (gout, arg) DMA holds (nseg 1500: ~3 rows per segment -> the global-load
+    path) and fewer tiles than waves."""
+    from superpoint_transformer_amd import _lib
+    g = torch.Generator().manual_seed(rows + K + N)
+    si = torch.randint(0, nseg, (rows,), generator=g)
+    si[:nseg] = torch.arange(nseg)                              # every segment has a row
+    perm = torch.argsort(si, stable=True)
+    pos_seg = si[perm]
+    rowptr = torch.zeros(nseg + 1, dtype=torch.long)
+    rowptr[1:] = torch.cumsum(torch.bincount(si, minlength=nseg), 0)
+    off = (torch.rand(nseg, N, generator=g) * (rowptr[1:] - rowptr[:-1]).view(-1, 1)).long()
+    arg = perm[rowptr[:-1].view(-1, 1) + off]
+    t = lambda *s: torch.randn(*s, generator=g).to(dev)
+    gout, h, x, W, gy = t(nseg, N), t(rows, N), t(rows, K), t(N, K) * 0.1, t(rows, N)
+    tabN = [(torch.rand(N, generator=g) + 0.5).to(dev) for _ in range(6)]
+    tabK = [(torch.rand(K, generator=g) + 0.5).to(dev) for _ in range(3)]
+    perm_d, seg_d, arg_d = perm.int().to(dev), pos_seg.int().to(dev), arg.int().contiguous().to(dev)
+    ws = torch.empty(_lib.lib.spt_fused_linear_workspace_bytes(K, N), dtype=torch.uint8, device=dev)
+    P = _lib.ptr
+
+    def run(mode):
+        gx = torch.full((rows, K), float("nan"), device=dev)
+        gW = torch.empty(N, K, device=dev)
+        prev = torch.empty(2 * K + 1, dtype=torch.float64, device=dev)
+        if pooled:
+            st = _lib.lib.spt_fused_linear_bwd_pooled_ex_f32(
+                P(gout), P(arg_d), P(perm_d), P(seg_d), P(h), 0, rows, N, P(tabN[0]), P(tabN[1]),
+                P(tabN[2]), 0.01, P(tabN[3]), P(tabN[4]), P(tabN[5]), P(x), K, P(tabK[0]), P(tabK[1]),
+                P(tabK[2]), 0.2, P(W), P(gx), P(gW), 0, P(prev), mode, P(ws), ws.numel(),
+                _lib.stream_ptr(dev))
+        else:
+            st = _lib.lib.spt_fused_linear_bwd_ex_f32(
+                P(gy), P(h), 0, rows, N, P(tabN[0]), P(tabN[1]), P(tabN[2]), 0.01, P(tabN[3]),
+                P(tabN[4]), P(tabN[5]), P(x), K, P(tabK[0]), P(tabK[1]), P(tabK[2]), 0.2, P(W), P(gx),
+                P(gW), 0, P(prev), mode, P(ws), ws.numel(), _lib.stream_ptr(dev))
+        _lib.check(st, "fused backward")
+        torch.cuda.synchronize()
+        return gx, gW, prev
+
+    for precision in (1, 3):                                    # split-bf16, bf16
+        a = run(precision)
+        b = run(precision | 4)                                  # SPT_FMLP_BWD_REGISTER_STAGED
+        assert bool(torch.isfinite(a[0]).all())                 # every row of gx was written
+        for u, v in zip(a, b):
+            assert torch.equal(u, v)

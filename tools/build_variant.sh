@@ -7,7 +7,7 @@ NAME=$1; SRC=$2; shift 2
 OBJ=superpoint_transformer_amd/lib/obj
 mkdir -p gpurun_variants /tmp/variant_$NAME
 EXTRA=""
-case $SRC in edge_attn_mfma.hip|edge_attn_el.hip|fused_mlp.hip) EXTRA="-mllvm -amdgpu-mfma-vgpr-form=1";; esac
+case $SRC in edge_attn_mfma.hip|edge_attn_el.hip|fused_mlp.hip|fused_mlp_dma.hip) EXTRA="-mllvm -amdgpu-mfma-vgpr-form=1";; esac
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result $EXTRA "$@" \
   -c superpoint_transformer_amd/csrc/$SRC -o /tmp/variant_$NAME/${SRC%.hip}.o
 OBJS=$(ls $OBJ/*.o | grep -v "/${SRC%.hip}.o")

@@ -1,5 +1,5 @@
 # PMC passes over tools/attn_microbench.py (one rocprofv3 run per counter group); prints per-kernel averages
-# usage: bash tools/pmc_passes.sh <kernel-name-pattern> [microbench args...]
+# usage: [PMC_BENCH=tools/fmlp_bwd_bench.py] bash tools/pmc_passes.sh <kernel-name-pattern> [microbench args...]
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 PAT=$1; shift
@@ -9,6 +9,6 @@ for G in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_I
          "TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum" "TA_DATA_STALLED_BY_TC_CYCLES_sum TA_TOTAL_WAVEFRONTS_sum" \
          "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" "TCC_TAG_STALL_sum TCC_ATOMIC_sum" "GRBM_GUI_ACTIVE"; do
   i=$((i+1)); rm -rf /tmp/pmc$i
-  (cd /tmp && rocprofv3 --pmc $G -d /tmp/pmc$i -o p -- python $GRAFT_REPO_ROOT/tools/attn_microbench.py --reps 2 "$@" > /tmp/pmc$i.log 2>&1)
+  (cd /tmp && rocprofv3 --pmc $G -d /tmp/pmc$i -o p -- python $GRAFT_REPO_ROOT/${PMC_BENCH:-tools/attn_microbench.py} --reps 2 "$@" > /tmp/pmc$i.log 2>&1)
   python tools/pmc_query.py /tmp/pmc$i "%$PAT%" 2>&1 | grep -v "^no .db"
 done
