@@ -149,6 +149,15 @@ int spt_unit_sphere_norm_f32(const float* pos, const int64_t* idx,
                              const float* w_f32, const int64_t* w_i64,
                              int64_t n, int64_t num_seg, float* pos_out,
                              float* diam, float* center, spt_stream_t stream);
+/* The same statistics with the stage's input assembly (src/nn/stage.py:249-271, the three
+ * fusion concatenations for use_pos / use_diameter_parent) done by the writing pass:
+ * xcat [n, 4 + cx] = [diam[idx] | pos_normalised | x], x [n, cx] with cx % 4 == 0 - the
+ * normalised positions, the gathered parent diameter and the copy of x are never materialised. */
+int spt_unit_sphere_assemble_f32(const float* pos, const int64_t* idx,
+                                 const int32_t* perm, const int32_t* rowptr,
+                                 const float* w_f32, const int64_t* w_i64,
+                                 int64_t n, int64_t num_seg, const float* x, int cx,
+                                 float* xcat, float* diam, float* center, spt_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * GraphNorm forward / backward, optionally fused with LeakyReLU      (a5)

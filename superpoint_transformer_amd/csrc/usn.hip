@@ -147,9 +147,47 @@ __global__ __launch_bounds__(256) void usn_apply_kernel(
   }
 }
 
+// out[i] = [diam[idx[i]] | (pos[i] - center[idx[i]]) / (diam[idx[i]] + 1e-2) | x[i]]: the stage input
+// [diameter_parent | normalized_pos | x] of src/nn/stage.py:249-271 written in ONE pass (the
+// normalised positions, the gathered diameter and the copy of x never exist on their own).
+// One thread per 16-byte chunk of the output (C = 4 + cx floats per row, cx % 4 == 0): a wave
+// writes 1 KB contiguously; chunk 0 of a row is formed from (idx, pos, center, diam), the others
+// are copies of x.  (A wave-per-64-rows variant with all header loads in one lane group measured
+// slower: two dependent round trips per block with nothing else in flight.)
+struct f3 { float x, y, z; };
+template <typename I>
+__global__ __launch_bounds__(256) void usn_assemble_kernel(
+    const float* __restrict__ pos, const int64_t* __restrict__ idx,
+    const float* __restrict__ center, const float* __restrict__ diam,
+    const float* __restrict__ x, int cx4, int64_t n, float* __restrict__ out) {
+  const I c4 = (I)(cx4 + 1);
+  const I total = (I)n * c4;
+  const I stride = (I)gridDim.x * blockDim.x;
+  for (I q = (I)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += stride) {
+    const I i = q / c4;
+    const int j = (int)(q - i * c4);
+    float4 v;
+    if (j == 0) {
+      const int64_t s = idx ? idx[i] : 0;
+      const f3 p = *reinterpret_cast<const f3*>(pos + (int64_t)i * 3);
+      const f3 ce = *reinterpret_cast<const f3*>(center + s * 3);
+      const float dm = diam[s], d = dm + 1e-2f;
+      v = make_float4(dm, (p.x - ce.x) / d, (p.y - ce.y) / d, (p.z - ce.z) / d);
+    } else {
+      v = *(reinterpret_cast<const float4*>(x) + ((int64_t)i * cx4 + (j - 1)));
+    }
+    *(reinterpret_cast<float4*>(out) + (int64_t)q) = v;
+  }
+}
+
 }  // namespace spt
 
 using namespace spt;
+
+static int usn_launch(const float* pos, const int64_t* idx, const int32_t* perm,
+                      const int32_t* rowptr, const float* w_f32, const int64_t* w_i64, int64_t n,
+                      int64_t num_seg, float* pos_out, const float* x, int cx, float* xcat,
+                      float* diam, float* center, hipStream_t stream);
 
 extern "C" int spt_unit_sphere_norm_f32(const float* pos, const int64_t* idx,
                                         const int32_t* perm, const int32_t* rowptr,
@@ -157,10 +195,32 @@ extern "C" int spt_unit_sphere_norm_f32(const float* pos, const int64_t* idx,
                                         int64_t n, int64_t num_seg, float* pos_out,
                                         float* diam, float* center,
                                         spt_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+  SPT_CHECK_ARG(n == 0 || pos_out, "null pos_out");
+  return usn_launch(pos, idx, perm, rowptr, w_f32, w_i64, n, num_seg, pos_out, nullptr, 0, nullptr,
+                    diam, center, (hipStream_t)stream_);
+}
+
+// UnitSphereNorm + the stage's input assembly: xcat [n, 4 + cx] = [diam[idx] | pos_normalised | x]
+// (x [n, cx] row-major, cx % 4 == 0, 16-byte aligned), diam / center as above.
+extern "C" int spt_unit_sphere_assemble_f32(const float* pos, const int64_t* idx,
+                                            const int32_t* perm, const int32_t* rowptr,
+                                            const float* w_f32, const int64_t* w_i64, int64_t n,
+                                            int64_t num_seg, const float* x, int cx, float* xcat,
+                                            float* diam, float* center, spt_stream_t stream_) {
+  SPT_CHECK_ARG(cx >= 4 && cx % 4 == 0, "x needs a multiple of 4 columns");
+  SPT_CHECK_ARG(n == 0 || (x && xcat), "null x / xcat");
+  SPT_CHECK_ARG(((uintptr_t)x | (uintptr_t)xcat) % 16 == 0, "x / xcat must be 16-byte aligned");
+  return usn_launch(pos, idx, perm, rowptr, w_f32, w_i64, n, num_seg, nullptr, x, cx, xcat, diam,
+                    center, (hipStream_t)stream_);
+}
+
+static int usn_launch(const float* pos, const int64_t* idx, const int32_t* perm,
+                      const int32_t* rowptr, const float* w_f32, const int64_t* w_i64, int64_t n,
+                      int64_t num_seg, float* pos_out, const float* x, int cx, float* xcat,
+                      float* diam, float* center, hipStream_t stream) {
   SPT_CHECK_ARG(n >= 0 && num_seg >= 1, "bad shape");
   SPT_CHECK_ARG(rowptr && diam && center, "null pointer");
-  SPT_CHECK_ARG(n == 0 || (pos && pos_out), "null pos");
+  SPT_CHECK_ARG(n == 0 || pos, "null pos");
   SPT_CHECK_ARG(!(w_f32 && w_i64), "pass at most one weight array");
   SPT_CHECK_ARG(idx || num_seg == 1, "idx may be null only for a single segment");
   const int64_t avg = n / num_seg;
@@ -176,7 +236,17 @@ extern "C" int spt_unit_sphere_norm_f32(const float* pos, const int64_t* idx,
     usn_stats_group_kernel<<<grid, 256, 0, stream>>>(pos, perm, rowptr, w_f32, w_i64,
                                                      num_seg, g_log2, center, diam);
   }
-  if (n > 0)
+  if (n > 0 && xcat)
+  {
+    const int64_t chunks = n * (cx / 4 + 1);
+    if (chunks + (int64_t)256 * 4096 < ((int64_t)1 << 32))          // 32-bit index arithmetic
+      usn_assemble_kernel<uint32_t><<<stream_grid(chunks, 256), 256, 0, stream>>>(
+          pos, idx, center, diam, x, cx / 4, n, xcat);
+    else
+      usn_assemble_kernel<int64_t><<<stream_grid(chunks, 256), 256, 0, stream>>>(
+          pos, idx, center, diam, x, cx / 4, n, xcat);
+  }
+  else if (n > 0)
     usn_apply_kernel<<<stream_grid(n, 256), 256, 0, stream>>>(pos, idx, center, diam, n,
                                                               pos_out);
   SPT_CHECK_LAUNCH();

@@ -89,24 +89,7 @@ class Stage(nn.Module):
             return self.in_mlp.out_dim
         return self.dim
 
-    def forward(self, x, norm_index, pos=None, diameter=None, node_size=None,
-                super_index=None, edge_index=None, edge_attr=None, num_super=None,
-                num_graphs=None, pool_to_parent=None, ea_grad=None):
-        """``pool_to_parent`` = (parent batch vector or None): when the stage is only an
-        in_mlp (PointStage) whose output feeds nothing but the max-pool to the parents, the
-        pooled features are returned instead (``PooledToParent``) and the MLP's last
-        norm + activation run inside the pool's read."""
-        ref = x if x is not None else pos if pos is not None else diameter
-        if ref is None:
-            if super_index is None:
-                raise ValueError("Could not infer basic info from input arguments")
-            n, dtype, device = super_index.shape[0], torch.float, super_index.device
-        else:
-            n, dtype, device = ref.shape[0], ref.dtype, ref.device
-
-        # position / diameter injection (stage.py:249-271): every fusion prepends its
-        # columns, so [diameter_parent | diameter | normalized_pos | x] is built by ONE
-        # concatenation instead of up to three passes over the level's rows
+    def _inject(self, x, pos, diameter, node_size, super_index, num_super, n, dtype, device):
         parts = [x]
         if pos is not None:                                   # stage.py:249-254
             normalized_pos, diameter_parent = self.pos_norm(
@@ -131,6 +114,34 @@ class Stage(nn.Module):
             x = parts[0]
         elif parts:
             x = torch.cat(parts, dim=1)
+        return x, diameter_parent
+
+    def forward(self, x, norm_index, pos=None, diameter=None, node_size=None,
+                super_index=None, edge_index=None, edge_attr=None, num_super=None,
+                num_graphs=None, pool_to_parent=None, ea_grad=None):
+        """``pool_to_parent`` = (parent batch vector or None): when the stage is only an
+        in_mlp (PointStage) whose output feeds nothing but the max-pool to the parents, the
+        pooled features are returned instead (``PooledToParent``) and the MLP's last
+        norm + activation run inside the pool's read."""
+        ref = x if x is not None else pos if pos is not None else diameter
+        if ref is None:
+            if super_index is None:
+                raise ValueError("Could not infer basic info from input arguments")
+            n, dtype, device = super_index.shape[0], torch.float, super_index.device
+        else:
+            n, dtype, device = ref.shape[0], ref.dtype, ref.device
+
+        # position / diameter injection (stage.py:249-271): every fusion prepends its
+        # columns, so [diameter_parent | diameter | normalized_pos | x] is built by ONE
+        # concatenation instead of up to three passes over the level's rows
+        if (self.use_pos and self.use_diameter_parent and not self.use_diameter
+                and not self.pos_norm.log_diameter and ops.unit_sphere_assemble_ok(x, pos)):
+            # [diameter_parent | normalized_pos | x] written by the normalisation's own pass
+            x, diameter_parent = ops.unit_sphere_assemble(x, pos, super_index, w=node_size,
+                                                          num_super=num_super)
+        else:
+            x, diameter_parent = self._inject(x, pos, diameter, node_size, super_index, num_super,
+                                              n, dtype, device)
 
         if (pool_to_parent is not None and self.in_mlp is not None and super_index is not None
                 and self.transformer_blocks is None and self.out_mlp is None):

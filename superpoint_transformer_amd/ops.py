@@ -245,10 +245,7 @@ def segment_sum_i64(x, index, num_seg=None):
 # ---------------------------------------------------------------------------
 # UnitSphereNorm (src/nn/norm.py:67-138)
 # ---------------------------------------------------------------------------
-def unit_sphere_norm(pos, idx, w=None, num_super=None):
-    """Returns (pos_normalised [n,3], diameter [num_super,1]) like
-    UnitSphereNorm.forward with log_diameter=False.  ``idx=None`` normalises
-    all rows together (norm.py:86-110).  No gradient: positions are data."""
+def _usn_args(pos, idx, w, num_super):
     _lib.require_cuda(pos)
     pos = pos.detach()
     if pos.dtype != torch.float32:
@@ -273,6 +270,14 @@ def unit_sphere_norm(pos, idx, w=None, num_super=None):
             wf = w.float()
         else:
             wi = w.long()
+    return pos, n, dev, num_seg, perm, rowptr, idx_t, wf, wi
+
+
+def unit_sphere_norm(pos, idx, w=None, num_super=None):
+    """Returns (pos_normalised [n,3], diameter [num_super,1]) like
+    UnitSphereNorm.forward with log_diameter=False.  ``idx=None`` normalises
+    all rows together (norm.py:86-110).  No gradient: positions are data."""
+    pos, n, dev, num_seg, perm, rowptr, idx_t, wf, wi = _usn_args(pos, idx, w, num_super)
     out = torch.empty_like(pos)
     diam = torch.empty(num_seg, dtype=torch.float32, device=dev)
     center = torch.empty((num_seg, 3), dtype=torch.float32, device=dev)
@@ -283,6 +288,45 @@ def unit_sphere_norm(pos, idx, w=None, num_super=None):
             _lib.ptr(center), _lib.stream_ptr(dev))
     _lib.check(st, "spt_unit_sphere_norm_f32")
     return out, diam.view(-1, 1)
+
+
+class _UnitSphereAssemble(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, pos, idx, w, num_super):
+        pos, n, dev, num_seg, perm, rowptr, idx_t, wf, wi = _usn_args(pos, idx, w, num_super)
+        x2 = _f32c(x.detach())
+        cx = x2.shape[1]
+        out = torch.empty((n, 4 + cx), dtype=torch.float32, device=dev)
+        diam = torch.empty(num_seg, dtype=torch.float32, device=dev)
+        center = torch.empty((num_seg, 3), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            st = _lib.lib.spt_unit_sphere_assemble_f32(
+                _lib.ptr(pos), _lib.ptr(idx_t), _lib.ptr(perm), _lib.ptr(rowptr), _lib.ptr(wf),
+                _lib.ptr(wi), n, num_seg, _lib.ptr(x2), cx, _lib.ptr(out), _lib.ptr(diam),
+                _lib.ptr(center), _lib.stream_ptr(dev))
+        _lib.check(st, "spt_unit_sphere_assemble_f32")
+        diam = diam.view(-1, 1)
+        ctx.mark_non_differentiable(diam)
+        ctx.x_dtype = x.dtype
+        return out, diam
+
+    @staticmethod
+    def backward(ctx, gout, _gdiam):
+        return gout[:, 4:].to(ctx.x_dtype), None, None, None, None
+
+
+def unit_sphere_assemble_ok(x, pos):
+    """Whether ``unit_sphere_assemble`` applies: f32 CUDA features of a multiple of 4 columns."""
+    return (torch.is_tensor(x) and torch.is_tensor(pos) and x.is_cuda and x.dim() == 2
+            and x.dtype == torch.float32 and x.shape[1] >= 4 and x.shape[1] % 4 == 0
+            and x.shape[0] == pos.shape[0])
+
+
+def unit_sphere_assemble(x, pos, idx, w=None, num_super=None):
+    """``(cat([diameter[idx], pos_normalised, x], 1), diameter)``: UnitSphereNorm and the three
+    fusion concatenations of a stage's input (src/nn/stage.py:249-271 with ``use_pos`` and
+    ``use_diameter_parent``) in one writing pass.  The gradient reaches ``x`` (a column slice)."""
+    return _UnitSphereAssemble.apply(x, pos, idx, w, num_super)
 
 
 # ---------------------------------------------------------------------------

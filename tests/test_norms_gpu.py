@@ -47,6 +47,34 @@ def test_unit_sphere_norm_random(n, nseg, weighted, dev):
     assert torch.equal(d.cpu(), rd.float())          # f32 boxes: exact
 
 
+@pytest.mark.parametrize("n,nseg,cx,weighted", [(1, 1, 8, False), (5000, 37, 8, True), (100003, 2900, 128, False),
+                                                (30000, 3, 256, True), (700, 900, 4, False), (4000, None, 8, True)])
+def test_unit_sphere_assemble_is_the_norm_followed_by_the_concatenation(n, nseg, cx, weighted, dev):
+    """ops.unit_sphere_assemble (one writing pass) against ops.unit_sphere_norm + the gather of the
+    parent diameter + torch.cat, the way Stage._inject builds the stage input: bit for bit, and the
+    gradient reaching x is the column slice of the output's.  ``nseg=None``: no super_index (the
+    last level: all rows normalised together, norm.py:86-110)."""
+    from superpoint_transformer_amd import ops
+    g = torch.Generator().manual_seed(n + cx)
+    pos = (torch.randn(n, 3, generator=g) * 5 + 20).float().to(dev)
+    idx = None if nseg is None else torch.randint(0, nseg, (n,), generator=g).to(dev)
+    w = torch.randint(0, 300, (n,), generator=g).to(dev) if weighted else None
+    x = torch.randn(n, cx, generator=g).to(dev)
+    gw = torch.randn(n, cx + 4, generator=g).to(dev)
+    npos, diam = ops.unit_sphere_norm(pos, idx, w, nseg)
+    dp = diam.repeat(n, 1) if idx is None else diam[idx]
+    xr = x.clone().requires_grad_()
+    ref = torch.cat([dp, npos, xr], 1)
+    (ref * gw).sum().backward()
+    assert ops.unit_sphere_assemble_ok(x, pos)
+    xa = x.clone().requires_grad_()
+    out, diam2 = ops.unit_sphere_assemble(xa, pos, idx, w, nseg)
+    (out * gw).sum().backward()
+    assert torch.equal(out, ref) and torch.equal(diam2, diam)
+    assert torch.equal(xa.grad, xr.grad)
+    assert not ops.unit_sphere_assemble_ok(x[:, :3], pos)        # 3 columns: the plain route
+
+
 @pytest.mark.parametrize("r,d,B,slope", [(1000, 64, 1, 1.0), (5000, 32, 3, 0.01), (40000, 128, 4, 0.01),
                                          (777, 18, 2, 1.0), (3, 64, 2, 0.2), (20000, 132, 1, 0.01),
                                          (9000, 7, 5, 1.0),
