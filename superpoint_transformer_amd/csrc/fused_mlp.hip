@@ -242,8 +242,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void fwd_kernel(
         for (int nb = 0; nb < NBK; ++nb) {
           const float v = C[nb][r];
           hr[16 * nb] = v;
+#ifndef SPT_FMLP_NO_STATS   /* measurement builds only */
           s1[nb] += (double)v;
           s2[nb] += (double)v * (double)v;
+#endif
         }
       }
     }

@@ -246,7 +246,7 @@ class SPTTrainStep:
                              136 * e1 + 1156 * n1, 12.6e3 * e1),
                 # fused tall-MLP layers, 64 -> 128 at level 0: forward reads x (4K) writes h (4N) per row;
                 # pooled backward reads h (4N) + x (4K), writes gx (4K) per row, + (gout, arg) per segment
-                "mlp_bwd_pooled": ("spt::fmlp::bwd_kernel_bf<16, 8, true, 8, true, true, false> (64 -> 128 "
+                "mlp_bwd_pooled": ("spt::fdma::bwd_dma_kernel<64, 128, 8, 2, true, true> (64 -> 128 "
                                    "backward of the point MLP's top layer with the L0->L1 pool's backward inside)",
                                    rows * (4 * 128 + 8 * 64) + n1 * 1024, 2 * 2 * 64 * 128 * rows),
                 "mlp_fwd": ("spt::fmlp::fwd_kernel<16, 8> (64 -> 128 forward)",

@@ -1,0 +1,27 @@
+#!/bin/bash
+# One visit: the default bench line, the other BASELINE configs, kernel stats of the train step at
+# scenes S and T (rocprofv3 --kernel-trace of the same command), PMC traffic of the roofline kernels.
+#   tools/round_profiles.sh <tag>      -> gpurun_out/<tag>_*
+cd $GRAFT_REPO_ROOT
+TAG=${1:-r03x}
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+python bench.py 2>/dev/null | grep '^{"metric' > gpurun_out/${TAG}_bench_sceneS.json
+python bench.py --scene T --no-cpu-baseline --no-preprocess 2>/dev/null | grep '^{"metric' > gpurun_out/${TAG}_bench_sceneT.json
+: > gpurun_out/${TAG}_bench_configs.jsonl
+for ARGS in "--mode infer --scene D" "--mode panoptic" "--model spt128 --scene T" "--dtype bf16" "--dtype f32-exact --no-f32-exact"; do
+  python bench.py $ARGS --no-cpu-baseline --no-preprocess --no-f32-exact --steps 8 2>/dev/null | grep '^{"metric' >> gpurun_out/${TAG}_bench_configs.jsonl
+done
+for SC in S T; do
+  rm -rf /tmp/kt_$SC
+  (cd /tmp && rocprofv3 --kernel-trace -d /tmp/kt_$SC -- python $GRAFT_REPO_ROOT/bench.py --scene $SC --steps 5 --warmup 2 --no-cpu-baseline --no-preprocess --no-f32-exact > /dev/null 2>&1)
+  python tools/rocpd_summary.py /tmp/kt_$SC > gpurun_out/${TAG}_spt64_trainstep_scene${SC}_kernel_stats.csv
+done
+rm -rf /tmp/kt_128
+(cd /tmp && rocprofv3 --kernel-trace -d /tmp/kt_128 -- python $GRAFT_REPO_ROOT/bench.py --model spt128 --scene T --steps 5 --warmup 2 --no-cpu-baseline --no-preprocess --no-f32-exact > /dev/null 2>&1)
+python tools/rocpd_summary.py /tmp/kt_128 > gpurun_out/${TAG}_spt128_trainstep_sceneT_kernel_stats.csv
+bash tools/pmc_step.sh > gpurun_out/${TAG}_pmc_step_traffic.txt 2>&1
+head -c 600 gpurun_out/${TAG}_bench_sceneS.json; echo; cut -c1-200 gpurun_out/${TAG}_bench_configs.jsonl | python -c "
+import sys, json
+for l in open('gpurun_out/${TAG}_bench_configs.jsonl'):
+    d = json.loads(l); print(d['config'].get('mode'), d['config'].get('net'), d['config'].get('scene'), d['dtype'][:12], d['ms_per_step'])"
