@@ -71,7 +71,11 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(
     const float* __restrict__ scale,  // [B,d] weight*rstd       (BWD, act mask)
     const float* __restrict__ bias,   // [d]                     (BWD, act mask)
     float slope, double* __restrict__ partial,
-    int b_lo, int Bc) {               // this launch owns graphs [b_lo, b_lo + Bc): its LDS table
+    int b_lo, int Bc,                 // this launch owns graphs [b_lo, b_lo + Bc): its LDS table
+    const float* __restrict__ mean = nullptr,     // BWD alternative to (am, scale): the saved
+    const float* __restrict__ rstd = nullptr,     // statistics + parameters, tables formed here
+    const float* __restrict__ weight = nullptr,   // exactly as gn_rebuild_tables_kernel does
+    const float* __restrict__ mean_scale = nullptr) {
   extern __shared__ __attribute__((aligned(16))) double tab[];
   const int row_len = 2 * d + 1;
   for (int i = threadIdx.x; i < Bc * row_len; i += GN_THREADS) tab[i] = 0.0;
@@ -96,8 +100,13 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(
     if constexpr (BWD) {
 #pragma unroll
       for (int k = 0; k < VEC; ++k) {
-        t_am[k] = cv ? am[b * d + c0 + k] : 0.f;
-        t_sc[k] = cv ? scale[b * d + c0 + k] : 0.f;
+        if (mean) {
+          t_am[k] = cv ? (float)((double)mean_scale[c0 + k] * (double)mean[b * d + c0 + k]) : 0.f;
+          t_sc[k] = cv ? (float)((double)weight[c0 + k] * (double)rstd[b * d + c0 + k]) : 0.f;
+        } else {
+          t_am[k] = cv ? am[b * d + c0 + k] : 0.f;
+          t_sc[k] = cv ? scale[b * d + c0 + k] : 0.f;
+        }
         t_bs[k] = cv ? bias[c0 + k] : 0.f;
       }
     }
@@ -194,6 +203,124 @@ __global__ __launch_bounds__(256) void gn_reduce_partials_kernel(
 #pragma unroll
     for (int k = 0; k < 16; ++k) t += sl[k][cl];   // fixed order: deterministic
     total[(size_t)b * row_len + col] = t;
+  }
+}
+
+// The same fixed-order reduction with the table formulas applied by the thread that ends up with
+// the totals: one launch instead of two between the statistics pass and the apply pass (at a
+// train batch's row counts a GraphNorm is five to nine ~5-20 us launches; these merges take three
+// of them away per forward + backward).  Arithmetic identical to the two-kernel sequences.
+// (All the partial rows a thread needs - 3 columns x the graphs it covers - are loaded in the
+// same loop iteration: one memory round trip per 16th of the blocks, as in the plain reduction.)
+template <int NV>
+__device__ __forceinline__ void gn_sliced_sums(const double* __restrict__ partial, int nblocks,
+                                               size_t stride, const size_t (&off)[NV], int nv,
+                                               int slice, int cl, double (*sl)[16][17],
+                                               double (&out)[NV]) {
+  double acc[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) acc[v] = 0.0;
+  const int per = (nblocks + 15) / 16;
+  const int lo = slice * per, hi = (lo + per < nblocks) ? lo + per : nblocks;
+  for (int k = lo; k < hi; ++k) {
+    double t[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) t[v] = v < nv ? partial[(size_t)k * stride + off[v]] : 0.0;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) acc[v] += t[v];
+  }
+#pragma unroll
+  for (int v = 0; v < NV; ++v) sl[v][slice][cl] = acc[v];
+  __syncthreads();
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += sl[v][k][cl];     // fixed order: deterministic
+    out[v] = t;
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_finalize_fwd_kernel(
+    const double* __restrict__ partial, int nblocks, int B, int d,
+    const float* __restrict__ weight, const float* __restrict__ mean_scale, float eps,
+    float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ am,
+    float* __restrict__ scale) {
+  __shared__ double sl[3][16][17];
+  const int b = blockIdx.x, cl = threadIdx.x & 15, slice = threadIdx.x >> 4;
+  const int c = blockIdx.y * 16 + cl, row_len = 2 * d + 1;
+  const int cc = c < d ? c : d - 1;
+  const size_t off[3] = {(size_t)b * row_len + cc, (size_t)b * row_len + d + cc,
+                         (size_t)b * row_len + 2 * d};
+  double s[3];
+  gn_sliced_sums<3>(partial, nblocks, (size_t)B * row_len, off, 3, slice, cl, sl, s);
+  if (slice != 0 || c >= d) return;
+  double n = s[2];
+  if (n < 1.0) n = 1.0;                       // scatter_mean: clamp(count, 1)
+  const double mu = s[0] / n;
+  const double a = (double)mean_scale[c];
+  double var = s[1] / n - (2.0 * a - a * a) * mu * mu;
+  if (var < 0.0) var = 0.0;
+  const double rs = 1.0 / sqrt(var + (double)eps);
+  const float mu32 = (float)mu, rs32 = (float)rs;
+  const int t = b * d + c;
+  mean[t] = mu32;
+  rstd[t] = rs32;
+  am[t] = (float)(a * (double)mu32);
+  scale[t] = (float)((double)weight[c] * (double)rs32);
+}
+
+constexpr int GN_FIN_B = 4;      // graphs one finalize_bwd block reduces side by side
+__global__ __launch_bounds__(256) void gn_finalize_bwd_kernel(
+    const double* __restrict__ partial, int nblocks, int B, int d,
+    const float* __restrict__ weight, const float* __restrict__ mean_scale,
+    const float* __restrict__ mean, const float* __restrict__ rstd,
+    float* __restrict__ am, float* __restrict__ scale, float* __restrict__ c1,
+    float* __restrict__ c2, float* __restrict__ c3, float* __restrict__ gweight,
+    float* __restrict__ gbias, float* __restrict__ gms) {
+  __shared__ double sl[3 * GN_FIN_B][16][17];
+  const int cl = threadIdx.x & 15, slice = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl, row_len = 2 * d + 1;
+  const int cc = c < d ? c : d - 1;
+  const bool own = slice == 0 && c < d;
+  const double w = (double)weight[cc], a = (double)mean_scale[cc];
+  double gw = 0.0, gb = 0.0, ga = 0.0;
+  for (int b0 = 0; b0 < B; b0 += GN_FIN_B) {
+    const int nb = (B - b0 < GN_FIN_B) ? B - b0 : GN_FIN_B;
+    size_t off[3 * GN_FIN_B];
+#pragma unroll
+    for (int j = 0; j < GN_FIN_B; ++j) {
+      const size_t rb = (size_t)(b0 + (j < nb ? j : 0)) * row_len;
+      off[3 * j] = rb + cc;
+      off[3 * j + 1] = rb + d + cc;
+      off[3 * j + 2] = rb + 2 * d;
+    }
+    double s3[3 * GN_FIN_B];
+    if (b0) __syncthreads();
+    gn_sliced_sums<3 * GN_FIN_B>(partial, nblocks, (size_t)B * row_len, off, 3 * nb, slice, cl, sl, s3);
+    if (!own) continue;
+    for (int j = 0; j < nb; ++j) {
+      const int b = b0 + j;
+      const double A = s3[3 * j], GO = s3[3 * j + 1];
+      double n = s3[3 * j + 2];
+      if (n < 1.0) n = 1.0;
+      const double s = (double)rstd[b * d + c], mu = (double)mean[b * d + c];
+      const double k2 = w * s * s * s * GO / n;
+      const double sumdo = w * s * A - k2 * n * mu * (1.0 - a);
+      c1[b * d + c] = (float)(w * s);
+      c2[b * d + c] = (float)k2;
+      c3[b * d + c] = (float)(a * sumdo / n);
+      am[b * d + c] = (float)(a * mu);           // = gn_rebuild_tables_kernel, for the apply pass
+      scale[b * d + c] = (float)(w * s);
+      gw += s * GO;
+      gb += A;
+      ga += -mu * sumdo;
+    }
+  }
+  if (own) {
+    gweight[c] = (float)gw;
+    gbias[c] = (float)gb;
+    gms[c] = (float)ga;
   }
 }
 
@@ -412,7 +539,9 @@ template <bool BWD>
 static void launch_stats(const GnPlan& p, const float* x, const float* gy,
                          const int64_t* batch, int64_t R, int d, int B,
                          const float* am, const float* scale, const float* bias,
-                         float slope, double* partial, hipStream_t stream) {
+                         float slope, double* partial, hipStream_t stream,
+                         const float* mean = nullptr, const float* rstd = nullptr,
+                         const float* weight = nullptr, const float* mean_scale = nullptr) {
   // The per-graph table lives in LDS (64 KiB without opting into more).  More graphs than
   // fit (num_graphs > 31 at d = 128) are covered by several launches, each owning a window
   // of graph ids and skipping the other rows; the usual 1..8 graphs take one launch.
@@ -421,11 +550,11 @@ static void launch_stats(const GnPlan& p, const float* x, const float* gy,
     const int Bc = (B - b_lo < cap) ? B - b_lo : cap;
     const size_t lds = (size_t)Bc * p.row_len * 8;
     if (p.sh.vec == 4)
-      gn_stats_kernel<4, BWD><<<p.nblocks, GN_THREADS, lds, stream>>>(x, gy, batch, R, d, B, p.sh.lpr_log2, am, scale, bias, slope, partial, b_lo, Bc);
+      gn_stats_kernel<4, BWD><<<p.nblocks, GN_THREADS, lds, stream>>>(x, gy, batch, R, d, B, p.sh.lpr_log2, am, scale, bias, slope, partial, b_lo, Bc, mean, rstd, weight, mean_scale);
     else if (p.sh.vec == 2)
-      gn_stats_kernel<2, BWD><<<p.nblocks, GN_THREADS, lds, stream>>>(x, gy, batch, R, d, B, p.sh.lpr_log2, am, scale, bias, slope, partial, b_lo, Bc);
+      gn_stats_kernel<2, BWD><<<p.nblocks, GN_THREADS, lds, stream>>>(x, gy, batch, R, d, B, p.sh.lpr_log2, am, scale, bias, slope, partial, b_lo, Bc, mean, rstd, weight, mean_scale);
     else
-      gn_stats_kernel<1, BWD><<<p.nblocks, GN_THREADS, lds, stream>>>(x, gy, batch, R, d, B, p.sh.lpr_log2, am, scale, bias, slope, partial, b_lo, Bc);
+      gn_stats_kernel<1, BWD><<<p.nblocks, GN_THREADS, lds, stream>>>(x, gy, batch, R, d, B, p.sh.lpr_log2, am, scale, bias, slope, partial, b_lo, Bc, mean, rstd, weight, mean_scale);
   }
 }
 
@@ -463,8 +592,8 @@ extern "C" int spt_graphnorm_fwd_f32(const float* x, const int64_t* batch, int64
   float* am = (float*)(base + p.off_am);
   float* scale = (float*)(base + p.off_scale);
   launch_stats<false>(p, x, nullptr, batch, r, d, B, nullptr, nullptr, nullptr, 1.f, partial, stream);
-  gn_reduce_partials_kernel<<<dim3(B, (p.row_len + 15) / 16), 256, 0, stream>>>(partial, p.nblocks, B, p.row_len, total);
-  gn_fwd_tables_kernel<<<(B * d + 255) / 256, 256, 0, stream>>>(total, B, d, weight, mean_scale, eps, mean, rstd, am, scale);
+  (void)total;
+  gn_finalize_fwd_kernel<<<dim3(B, (d + 15) / 16), 256, 0, stream>>>(partial, p.nblocks, B, d, weight, mean_scale, eps, mean, rstd, am, scale);
   if (r > 0) {
     if (p.sh.vec == 4)
       gn_apply_fwd_kernel<4><<<p.nblocks * 2, GN_THREADS, 0, stream>>>(x, batch, r, d, p.sh.lpr_log2, am, scale, bias, act_slope, y);
@@ -502,11 +631,12 @@ extern "C" int spt_graphnorm_bwd_f32(const float* x, const float* gy,
   float* c1 = (float*)(base + p.off_c1);
   float* c2 = (float*)(base + p.off_c2);
   float* c3 = (float*)(base + p.off_c3);
-  // rebuild (alpha*mu, weight*rstd) from the saved statistics
-  gn_rebuild_tables_kernel<<<(B * d + 255) / 256, 256, 0, stream>>>(mean, rstd, weight, mean_scale, B, d, am, scale);
-  launch_stats<true>(p, x, gy, batch, r, d, B, am, scale, bias, act_slope, partial, stream);
-  gn_reduce_partials_kernel<<<dim3(B, (p.row_len + 15) / 16), 256, 0, stream>>>(partial, p.nblocks, B, p.row_len, total);
-  gn_bwd_tables_kernel<<<(d + 127) / 128, 128, 0, stream>>>(total, B, d, weight, mean_scale, mean, rstd, c1, c2, c3, gweight, gbias, gmean_scale);
+  // (alpha*mu, weight*rstd) are rebuilt from the saved statistics inside the statistics pass
+  // (per graph change of a lane) and written out for the apply pass by the finalize kernel
+  launch_stats<true>(p, x, gy, batch, r, d, B, nullptr, nullptr, bias, act_slope, partial, stream,
+                     mean, rstd, weight, mean_scale);
+  (void)total;
+  gn_finalize_bwd_kernel<<<(d + 15) / 16, 256, 0, stream>>>(partial, p.nblocks, B, d, weight, mean_scale, mean, rstd, am, scale, c1, c2, c3, gweight, gbias, gmean_scale);
   if (r > 0) {
     if (p.sh.vec == 4)
       gn_apply_bwd_kernel<4><<<p.nblocks * 2, GN_THREADS, 0, stream>>>(x, gy, batch, r, d, p.sh.lpr_log2, am, scale, bias, act_slope, c1, c2, c3, gx);
