@@ -704,6 +704,7 @@ int spt_fused_linear_bwd_pooled_f32(
  * ignore_index of logsumexp(logits[row]) - logits[row, target[row]].  C <= 32 classes.
  *   fwd: lse[rows] (kept for the backward), loss[1], count[1] (rows that counted, as f32);
  *        ws: spt_cross_entropy_workspace_bytes(rows).  Deterministic (f64 partial sums, fixed order).
+ *        A target outside [0, C) other than ignore_index makes the loss NaN (torch: device assert).
  *   bwd: glogits = (softmax - onehot) * gout[0] / count[0]; gout / count are device scalars. */
 size_t spt_cross_entropy_workspace_bytes(int64_t rows);
 int spt_cross_entropy_fwd_f32(const float* logits, const int64_t* target, int64_t rows, int C,

@@ -43,6 +43,12 @@ __global__ __launch_bounds__(CE_BLOCK) void ce_fwd_kernel(
       for (int c = 0; c < CMAX; ++c) picked = (c == (int)t) ? v[c] : picked;
       li = (double)(l - picked);
       ci = 1.0;
+    } else if (t != ignore_index) {
+      // a label outside [0, C) that is not ignore_index is a bug upstream (wrong num_classes,
+      // unshifted void label): torch raises a device assert; here the loss comes out NaN instead
+      // of silently averaging over fewer rows
+      li = (double)NAN;
+      ci = 1.0;
     }
   }
   // wave sums, then the block's four waves in order

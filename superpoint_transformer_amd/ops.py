@@ -446,12 +446,39 @@ class EdgeAttrGradShare:
     Valid for one forward pass over sequentially dependent blocks, which is what ``Stage.forward``
     creates it for; a backward that stops short of the first block (``autograd.grad`` on an
     intermediate block's inputs) would not see the edge_attr gradient - do not pass a share in
-    that case."""
+    that case.
 
-    __slots__ = ("tensor", "count", "buf")
+    A backward that fails part-way, or one that re-enters a block before the first block has
+    handed the buffer over (a retained graph walked again after a partial ``autograd.grad``),
+    must not add onto what an earlier walk left behind: ``acquire`` starts a fresh buffer
+    whenever the entering block has already been seen in the current walk, ``abort`` drops it."""
+
+    __slots__ = ("tensor", "count", "buf", "seen")
 
     def __init__(self):
-        self.tensor, self.count, self.buf = None, 0, None
+        self.tensor, self.count, self.buf, self.seen = None, 0, None, set()
+
+    def acquire(self, rank, like):
+        """(buffer, acc) for the block of forward order ``rank``: acc = 1 when a later block of
+        THIS backward walk already started the sum."""
+        if rank in self.seen:                # a second walk without a hand-over: stale state
+            self.buf, self.seen = None, set()
+        self.seen.add(rank)
+        if self.buf is not None:
+            return self.buf, 1
+        self.buf = torch.empty_like(like)
+        return self.buf, 0
+
+    def release(self, rank):
+        """The buffer if ``rank`` is the block that hands it to autograd (the first one of the
+        forward), else None."""
+        if rank != 0:
+            return None
+        buf, self.buf, self.seen = self.buf, None, set()
+        return buf
+
+    def abort(self):
+        self.buf, self.seen = None, set()
 
     def enter(self, edge_attr):
         if self.tensor is None:
@@ -516,12 +543,10 @@ class _EdgeAttention(torch.autograd.Function):
         g = _f32c(gout)
         gqkv = torch.empty_like(q2)
         share, acc = ctx.share, 0
-        if share is not None and share.buf is not None:
-            gea, acc = share.buf, 1                      # a later block already started the sum
+        if share is not None:
+            gea, acc = share.acquire(ctx.rank, ea)       # acc: a later block already started the sum
         else:
             gea = torch.empty_like(ea) if ea is not None else None
-            if share is not None:
-                share.buf = gea
         gps = [torch.empty_like(t) if t is not None else None for t in ps]
         nb = _lib.lib.spt_edge_attn_bwd_ex_workspace_bytes(n, ecsr.e, H, D, Dv, max(F, 1))
         ws = _workspace(nb, dev)
@@ -541,14 +566,13 @@ class _EdgeAttention(torch.autograd.Function):
                 _lib.ptr(m), _lib.ptr(z), _lib.ptr(g), _lib.ptr(gqkv), _lib.ptr(gea), acc,
                 *[_lib.ptr(t) for t in gps], ctx.mode, _lib.ptr(ws), ws.numel(),
                 _lib.stream_ptr(dev))
+        if st != 0 and share is not None:
+            share.abort()                                # never leave a half-built sum behind
         _lib.check(st, "spt_edge_attn_bwd_ex_f32")
         if gea is not None and not (any(ctx.present[0::2])):
             gea = None
         if share is not None:
-            if ctx.rank == 0:
-                share.buf = None                         # handed over; a second backward restarts
-            else:
-                gea = None                               # the first block returns the sum
+            gea = share.release(ctx.rank)                # the first block returns the sum
         return (gqkv.to(q_dtype), None, None if gea is None else gea.to(ea_dtype),
                 *gps, None, None, None, None, None)
 
@@ -675,12 +699,10 @@ class _EdgeAttentionSplit(torch.autograd.Function):
         ga = _f32c(gout).view(n, G, 16, J, 4).permute(1, 3, 0, 2, 4).contiguous().view(P, n, 64)
         gqa = torch.empty_like(qa)
         share, acc = ctx.share, 0
-        if share is not None and share.buf is not None:
-            gea, acc = share.buf, 1
+        if share is not None:
+            gea, acc = share.acquire(ctx.rank, ea)
         else:
             gea = torch.empty_like(ea)
-            if share is not None:
-                share.buf = gea
         gWk = torch.empty((P, 64, F), dtype=torch.float32, device=dev)
         gWq = torch.empty_like(gWk)
         gWv = torch.empty_like(gWk)
@@ -712,6 +734,8 @@ class _EdgeAttentionSplit(torch.autograd.Function):
                             _lib.ptr(gWq[p]), _lib.ptr(None if gbq is None else gbq[p]),
                             _lib.ptr(gWv[p]), _lib.ptr(None if gbv is None else gbv[p]),
                             ctx.mode, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+                    if st != 0 and share is not None:
+                        share.abort()
                     _lib.check(st, "spt_edge_attn_bwd_ex_f32")
                     acc = 1
         # q / k (and their encoders') gradients: the sum over a head group's J value slices
@@ -734,10 +758,7 @@ class _EdgeAttentionSplit(torch.autograd.Function):
             return t.permute(0, 2, 1, 3, *range(4, 4 + len(tail))).reshape(H * Dv, *tail)
 
         if share is not None:
-            if ctx.rank == 0:
-                share.buf = None
-            else:
-                gea = None
+            gea = share.release(ctx.rank)
         return (gqkv.to(q_dtype), None, None if gea is None else gea.to(ea_dtype),
                 over_j(gWk, (64, F)), over_j(gbk, (64,)), over_j(gWq, (64, F)), over_j(gbq, (64,)),
                 value_rows(gWv, (F,)), value_rows(gbv, ()), None, None, None, None, None, None)

@@ -26,11 +26,22 @@ def _float_src(src, what):
     return src
 
 
-def _int_as_f32(src, what):
-    """Integer min / max through the f32 kernel is exact only below 2^24."""
-    if src.numel() and int(src.abs().max()) >= (1 << 24):
-        raise NotImplementedError(f"HIP shim: {what} of integers >= 2^24 (f32 kernel)")
-    return src.float()
+def _int_minmax(src, index, dim_size, op):
+    """Integer min / max on the f32 segment kernels, exact for |v| < 2^47 and without a host sync:
+    v = hi * 2^24 + lo (hi = v >> 24 floors, 0 <= lo < 2^24), the order of v is the lexicographic
+    order of (hi, lo) and both halves are exact in f32 - first the winning hi per segment, then
+    the winning lo among the rows that carry it (the others see a sentinel)."""
+    from ..csr import csr_of
+    csr = csr_of(index, dim_size)
+    v = src.long()
+    hi, lo = (v >> 24).float(), (v & 0xFFFFFF).float()
+    ohi = ops.segment_reduce(hi, csr, None, op)
+    sentinel = float(1 << 24) if op == "min" else -1.0
+    lo = torch.where(hi == ops.gather_rows(ohi, csr.idx), lo, torch.full_like(lo, sentinel))
+    olo, arg = ops.segment_reduce(lo, csr, None, op, return_arg=True)
+    empty = (csr.counts() == 0).view((-1,) + (1,) * (src.dim() - 1))
+    out = ohi.long() * (1 << 24) + olo.long()
+    return torch.where(empty, torch.zeros_like(out), out), arg
 
 
 def scatter_sum(src, index, dim=-1, out=None, dim_size=None):
@@ -58,8 +69,7 @@ def scatter_mean(src, index, dim=-1, out=None, dim_size=None):
 
 def _minmax(src, index, dim_size, op):
     if not src.is_floating_point():
-        o, a = ops.segment_reduce(_int_as_f32(src, f"scatter_{op}"), index, dim_size, op,
-                                  return_arg=True)
+        o, a = _int_minmax(src, index, dim_size, op)
         return o.to(src.dtype), a.long()
     o, a = ops.segment_reduce(_float_src(src, f"scatter_{op}"), index, dim_size, op, return_arg=True)
     return o.to(src.dtype), a.long()

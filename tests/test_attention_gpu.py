@@ -297,14 +297,18 @@ def test_shared_edge_attr_gradient_of_a_stage(mode, dev):
     ea = (torch.randn(ei.shape[1], F, generator=gen) * 0.5).to(dev)
     gw = torch.randn(n, dim, generator=gen).to(dev)
 
-    def run(share, twice=False):
+    def run(share, twice=False, partial_first=False):
         xd, ead = x.clone().requires_grad_(), ea.clone().requires_grad_()
         for b in blocks:
             b.zero_grad()
-        h = xd
+        hs = [xd]
         for b in blocks:
-            h = h + b(h, ei, edge_attr=ead, ea_grad=share)
-        loss = (h * gw).sum()
+            hs.append(hs[-1] + b(hs[-1], ei, edge_attr=ead, ea_grad=share))
+        loss = (hs[-1] * gw).sum()
+        if partial_first:
+            # a walk that stops short of the first block (gradient wrt the LAST block's input
+            # only) leaves the share half-built; the full walk afterwards must start afresh
+            torch.autograd.grad(loss, hs[-2], retain_graph=True)
         if twice:
             loss.backward(retain_graph=True)
             xd.grad = ead.grad = None
@@ -318,12 +322,14 @@ def test_shared_edge_attr_gradient_of_a_stage(mode, dev):
         ref = run(None)
         got = run(ops.EdgeAttrGradShare())
         again = run(ops.EdgeAttrGradShare(), twice=True)
+        stale = run(ops.EdgeAttrGradShare(), partial_first=True)
     finally:
         _lib.lib.spt_attn_use_mfma(prev)
-    for a, b, c in zip(ref, got, again):
+    for a, b, c, e in zip(ref, got, again, stale):
         tol = 1e-5 * float(a.abs().max())                  # atomics: summation order only
         assert float((a - b).abs().max()) <= tol
         assert float((a - c).abs().max()) <= tol
+        assert float((a - e).abs().max()) <= tol
     with pytest.raises(ValueError):
         sh = ops.EdgeAttrGradShare()
         xd = x.clone().requires_grad_()

@@ -36,3 +36,18 @@ def test_cross_entropy_falls_back_for_wide_or_odd_inputs(dev):
     x = torch.randn(100, 40, device=dev)
     t = torch.randint(0, 40, (100,), device=dev)
     assert torch.allclose(ops.cross_entropy(x, t), torch.nn.functional.cross_entropy(x, t))
+
+
+def test_cross_entropy_poisons_the_loss_on_a_label_out_of_range(dev):
+    """torch raises a device assert for a target outside [0, C) that is not ignore_index; the HIP
+    loss comes out NaN (never a silent mean over fewer rows), while ignore_index rows are skipped."""
+    from superpoint_transformer_amd import ops
+    lg = torch.randn(1000, 13, device=dev)
+    t = torch.randint(0, 13, (1000,), device=dev)
+    t[5] = -100
+    ok = ops.cross_entropy(lg, t, ignore_index=-100)
+    assert torch.isfinite(ok).item()
+    for bad in (13, -1, 1 << 40):
+        t2 = t.clone()
+        t2[17] = bad
+        assert torch.isnan(ops.cross_entropy(lg, t2, ignore_index=-100)).item()

@@ -181,3 +181,32 @@ def test_h5py_name_is_opt_in():
         sys.modules.pop("h5py", None)
         if had is not None:
             sys.modules["h5py"] = had
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("op", ["min", "max"])
+def test_integer_scatter_minmax_is_exact_beyond_2_to_24_and_needs_no_host_sync(op, dev):
+    """int64 sources (InstanceData.major on point-overlap counts) on the f32 segment kernels by
+    the (v >> 24, v & 0xFFFFFF) split: values up to 2^46, negatives, ties and empty segments
+    against torch on the CPU - values AND the arg of an attaining row."""
+    from superpoint_transformer_amd.shims import scatter_shim
+    g = torch.Generator().manual_seed(3)
+    n, ns = 20000, 700                                    # (some segments stay empty)
+    idx = torch.randint(0, ns - 50, (n,), generator=g)
+    big = torch.randint(-(1 << 46), 1 << 46, (n,), generator=g)
+    small = torch.randint(-5, 5, (n,), generator=g)       # many ties
+    for v in (big, small, torch.stack([big, small], 1)):
+        fn = scatter_shim.scatter_min if op == "min" else scatter_shim.scatter_max
+        out, arg = fn(v.to(dev), idx.to(dev), 0, None, ns)
+        out, arg = out.cpu(), arg.cpu()
+        v2 = v.view(n, -1)
+        init = torch.iinfo(torch.int64).max if op == "min" else torch.iinfo(torch.int64).min
+        ref = torch.full((ns, v2.shape[1]), init, dtype=torch.int64)
+        ref.scatter_reduce_(0, idx.view(-1, 1).expand_as(v2), v2, "amin" if op == "min" else "amax")
+        has = torch.bincount(idx, minlength=ns) > 0
+        o2, a2 = out.view(ns, -1), arg.view(ns, -1)
+        assert torch.equal(o2[has], ref[has]) and out.dtype == torch.int64
+        assert (o2[~has] == 0).all()                                       # torch_scatter: empty -> 0
+        rows = a2[has]
+        assert torch.equal(torch.gather(v2, 0, rows), ref[has])            # the arg attains the value
+        assert torch.equal(idx[rows], has.nonzero().expand_as(rows))       # ... inside its segment
