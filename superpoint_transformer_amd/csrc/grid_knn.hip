@@ -127,6 +127,18 @@ __device__ __forceinline__ uint64_t wave_sort(uint64_t key, int lane) {
   return key;
 }
 
+// two independent ascending sorts, lanes 0..31 and lanes 32..63 (15 compare-exchange steps
+// instead of 21, and two lists per pass): the 16-blocks alternate direction as in the full network,
+// the last merge runs ascending in both halves
+__device__ __forceinline__ uint64_t wave_sort_halves(uint64_t key, int lane) {
+  key = bitonic_merge_steps<2, 1>(key, lane);
+  key = bitonic_merge_steps<4, 2>(key, lane);
+  key = bitonic_merge_steps<8, 4>(key, lane);
+  key = bitonic_merge_steps<16, 8>(key, lane);
+  key = bitonic_merge_steps<64, 16>(key, lane);   // partners stay inside a half; ascending in both
+  return key;
+}
+
 // merge two ascending 64-lists, keep the 64 smallest, ascending
 __device__ __forceinline__ uint64_t wave_merge(uint64_t best, uint64_t cand_sorted, int lane) {
   // lane 63 - l = l ^ 63: mirror inside the rows (^15), then swap rows (^16) and halves (^32)
@@ -493,16 +505,75 @@ __global__ __launch_bounds__(KC_WAVES * 64) void knn_cell_kernel(
       kc_wave_sync();
       // ---- per query: 64-lane sort of its list, K results; the candidate rows of the next
       //      query are in flight while the current one sorts ---------------------------------
+      // lists of <= 32 candidates (K <= 32: the DALES setting k = 25) are sorted two queries at a
+      // time, one per half wave
+#ifdef SPT_KNN_NO_PAIR   /* measurement builds only */
+      const uint64_t small = 0ull;
+#else
+      const uint64_t small = (K <= 32) ? __ballot(ok && len <= 32) : 0ull;
+#endif
+      uint64_t big = todo_sort & ~small;
+      uint64_t pairs = small;
+      auto gidx = [&](int pos) {
+        int gi = 0;
+#pragma unroll
+        for (int ri = 0; ri < 9; ++ri) gi = pos >= rb_u[ri] ? rs_u[ri] + (pos - rb_u[ri]) : gi;
+        return gi;
+      };
+      // (the candidate rows of the next pair are in flight while the current one sorts)
+      auto next_pair = [&](int& qa, int& qb) {
+        qa = qb = -1;
+        if (!pairs) return;
+        qa = __ffsll((unsigned long long)pairs) - 1;
+        pairs &= pairs - 1;
+        qb = pairs ? __ffsll((unsigned long long)pairs) - 1 : qa;              // odd one out: alone
+        pairs &= pairs - 1;
+      };
+      auto fetch2 = [&](int qa, int qb) -> float4 {
+        float4 pc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (qa < 0) return pc;
+        const int qh = (lane < 32) ? qa : qb;                                  // the query of this half
+        const int n = __shfl(len, qh, 64);
+        if ((lane & 31) < n && (lane < 32 || qb != qa)) pc = sorted[gidx((int)L.list[lane & 31][qh])];
+        return pc;
+      };
+      int qa, qb;
+      next_pair(qa, qb);
+      float4 pc2 = fetch2(qa, qb);
+      while (qa >= 0) {
+        int na, nb2;
+        next_pair(na, nb2);
+        const float4 pn2 = fetch2(na, nb2);
+        const int qh = (lane < 32) ? qa : qb;
+        const int hl = lane & 31;
+        const bool live = lane < 32 || qb != qa;
+        const int n = __shfl(len, qh, 64);
+        float4 qq;
+        qq.x = __shfl(q.x, qh, 64);
+        qq.y = __shfl(q.y, qh, 64);
+        qq.z = __shfl(q.z, qh, 64);
+        const int64_t qi = (int64_t)(uint32_t)__shfl(__float_as_int(q.w), qh, 64);
+        uint64_t key = KNN_EMPTY;
+        if (hl < n && live)
+          key = ((uint64_t)__float_as_uint(kc_d2(qq, pc2)) << 32) | (uint32_t)__float_as_int(pc2.w);
+        key = wave_sort_halves(key, lane);
+        if (hl < K && live) {
+          const bool okk = key != KNN_EMPTY;
+          float d = __uint_as_float((uint32_t)(key >> 32));
+          if (!squared) d = sqrtf(d);
+          out_idx[qi * K + hl] = okk ? (int64_t)(uint32_t)(key & 0xffffffffu) : -1;
+          out_dist[qi * K + hl] = okk ? d : -1.0f;
+        }
+        qa = na;
+        qb = nb2;
+        pc2 = pn2;
+      }
+      todo_sort = big;
+      if (todo_sort == 0) continue;
       auto fetch = [&](int ql) -> float4 {
         float4 pc = make_float4(0.f, 0.f, 0.f, 0.f);
         const int n = __builtin_amdgcn_readlane(len, ql);
-        if (lane < n) {
-          const int pos = (int)L.list[lane][ql];
-          int gi = 0;
-#pragma unroll
-          for (int ri = 0; ri < 9; ++ri) gi = pos >= rb_u[ri] ? rs_u[ri] + (pos - rb_u[ri]) : gi;
-          pc = sorted[gi];
-        }
+        if (lane < n) pc = sorted[gidx((int)L.list[lane][ql])];
         return pc;
       };
       int ql = __ffsll((unsigned long long)todo_sort) - 1;
@@ -591,12 +662,23 @@ __global__ __launch_bounds__(256) void bbox_kernel(const float* __restrict__ xyz
     lo[q] = wave_reduce_min(lo[q]);
     hi[q] = wave_reduce_max(hi[q]);
   }
-  if ((threadIdx.x & 63) == 0) {                               // integer atomics: order-free
+  // one set of atomics per workgroup (per wave they were ~100 k contended updates of six words:
+  // 1.1 ms at 12 M points, 40x the time of the reads)
+  __shared__ float sl[4][6];
+  if ((threadIdx.x & 63) == 0) {
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
-      atomicMin(&keys[q], bbox_key(lo[q]));
-      atomicMax(&keys[3 + q], bbox_key(hi[q]));
+      sl[threadIdx.x >> 6][q] = lo[q];
+      sl[threadIdx.x >> 6][3 + q] = hi[q];
     }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {                                       // integer atomics: order-free
+    const int q = threadIdx.x;
+    float v = sl[0][q];
+    for (int w = 1; w < 4; ++w) v = q < 3 ? fminf(v, sl[w][q]) : fmaxf(v, sl[w][q]);
+    if (q < 3) atomicMin(&keys[q], bbox_key(v));
+    else atomicMax(&keys[q], bbox_key(v));
   }
 }
 
@@ -616,7 +698,11 @@ extern "C" int spt_bbox_f32(const float* xyz, int64_t n, float* lo_hi, spt_strea
   SPT_CHECK_ARG(n >= 1 && xyz && lo_hi, "bad arguments");
   uint32_t* keys = (uint32_t*)(lo_hi + 6);                     // caller provides 12 floats
   bbox_init_kernel<<<1, 256, 0, stream>>>(keys);
-  bbox_kernel<<<stream_grid(n, 256 * 8), 256, 0, stream>>>(xyz, n, keys);
+  {
+    int grid = stream_grid(n, 256 * 8);
+    if (grid > 1024) grid = 1024;
+    bbox_kernel<<<grid, 256, 0, stream>>>(xyz, n, keys);
+  }
   bbox_decode_kernel<<<1, 64, 0, stream>>>(keys, lo_hi);
   SPT_CHECK_LAUNCH();
   return 0;
