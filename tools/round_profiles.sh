@@ -21,6 +21,8 @@ rm -rf /tmp/kt_128
 (cd /tmp && rocprofv3 --kernel-trace -d /tmp/kt_128 -- python $GRAFT_REPO_ROOT/bench.py --model spt128 --scene T --steps 5 --warmup 2 --no-cpu-baseline --no-preprocess --no-f32-exact > /dev/null 2>&1)
 python tools/rocpd_summary.py /tmp/kt_128 > gpurun_out/${TAG}_spt128_trainstep_sceneT_kernel_stats.csv
 bash tools/pmc_step.sh > gpurun_out/${TAG}_pmc_step_traffic.txt 2>&1
+for SC in S D; do python tools/knn_bench.py $SC 0 3 2>/dev/null | tail -1; done > gpurun_out/${TAG}_preprocess_legs.txt
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
 head -c 600 gpurun_out/${TAG}_bench_sceneS.json; echo; cut -c1-200 gpurun_out/${TAG}_bench_configs.jsonl | python -c "
 import sys, json
 for l in open('gpurun_out/${TAG}_bench_configs.jsonl'):
