@@ -76,3 +76,30 @@ def test_single_process_is_a_no_op():
     assert torch.equal(before[:8], torch.full((8,), 3.0)) and bucket.check_views()
     assert torch.equal(bucket.reduce(), before)
     assert parallel.shard_items(5, 0, 1) == [0, 1, 2, 3, 4]
+
+
+def test_edge_attr_gradient_share_protocol_on_the_host():
+    """ops.EdgeAttrGradShare (host-side bookkeeping of the blocks that accumulate d edge_attr into
+    one buffer): the block of the LAST forward rank walks first and starts the buffer, later
+    walkers accumulate, rank 0 hands it over and resets; a rank seen twice without a hand-over (a
+    partial autograd.grad on a retained graph, then the full backward) starts a fresh buffer, and
+    abort() drops a half-built one."""
+    from superpoint_transformer_amd import ops
+    like = torch.zeros(5, 3)
+    sh = ops.EdgeAttrGradShare()
+    assert [sh.enter(like) for _ in range(3)] == [0, 1, 2]
+    with __import__("pytest").raises(ValueError):
+        sh.enter(torch.zeros(5, 3))                       # another edge_attr tensor
+    b2, acc = sh.acquire(2, like)
+    assert acc == 0 and b2.shape == like.shape
+    b1, acc = sh.acquire(1, like)
+    assert acc == 1 and b1 is b2
+    assert sh.release(1) is None and sh.release(2) is None
+    b0, acc = sh.acquire(0, like)
+    assert acc == 1 and sh.release(0) is b2 and sh.buf is None and not sh.seen
+    # partial walk (only rank 2), then the full one: rank 2 again -> fresh buffer, no stale sum
+    p, acc = sh.acquire(2, like)
+    q, acc2 = sh.acquire(2, like)
+    assert acc == 0 and acc2 == 0 and q is not p
+    sh.abort()
+    assert sh.buf is None and not sh.seen
