@@ -266,7 +266,12 @@ class SPTTrainStep:
                     "frac": round(gbs / peak_gbs, 4),
                     "flops_per_launch": float(kflops), "achieved_tflops": round(tfs, 2),
                     "frac_f32_matrix_peak": round(tfs / f32_matrix_tf, 4),
-                    "traffic": tr.get("bytes") if tr else None})
+                    "traffic": tr.get("bytes") if tr else None,
+                    # what the memory system actually moved per launch (PMC) over the same time:
+                    # the kernels of this list gather / scatter rows, their traffic is a multiple
+                    # of the algorithmic bytes by construction (k / v rows per EDGE, not per node)
+                    "traffic_gbs": round(tr["bytes"] / (tms * 1e-3) / 1e9, 1) if tr else None,
+                    "traffic_frac": round(tr["bytes"] / (tms * 1e-3) / 1e9 / peak_gbs, 4) if tr else None})
         roof["kernels"] = kernels
         return roof
 
