@@ -62,6 +62,13 @@ size_t spt_csr_build_workspace_bytes(int64_t n, int64_t num_seg);
 int spt_csr_build(const int64_t* idx, int64_t n, int64_t num_seg,
                   int32_t* perm, int32_t* rowptr,
                   void* ws, size_t ws_bytes, spt_stream_t stream);
+/* Companions of the view: pos_seg[j] = segment of CSR position j (= idx[perm[j]], expanded from
+ * rowptr: no gather), and out[j] = (int32) src[perm[j]] (e.g. edge_index[1] in CSR order) - one
+ * kernel each where the host side used three torch launches (cast, index_select, cast). */
+int spt_csr_pos_seg(const int32_t* rowptr, int64_t num_seg, int64_t n, int32_t* pos_seg,
+                    spt_stream_t stream);
+int spt_csr_gather_i64_i32(const int64_t* src, const int32_t* perm, int64_t n, int32_t* out,
+                           spt_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Segment reduce  out[s,:] = reduce_{i in seg s} x[i,:]      (a1, a4, a8)

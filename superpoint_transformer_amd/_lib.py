@@ -26,6 +26,8 @@ SIGNATURES = {
     "spt_last_error": (_c.c_char_p, []),
     "spt_csr_build_workspace_bytes": (_sz, [_i64, _i64]),
     "spt_csr_build": (_int, [_p, _i64, _i64, _p, _p, _p, _sz, _p]),
+    "spt_csr_pos_seg": (_int, [_p, _i64, _i64, _p, _p]),
+    "spt_csr_gather_i64_i32": (_int, [_p, _p, _i64, _p, _p]),
     "spt_segcsr_reduce_f32": (_int, [_int, _p, _p, _p, _i64, _i64, _int, _p, _p, _p]),
     "spt_segcsr_max_affine_f32": (_int, [_p, _p, _p, _i64, _i64, _int, _p, _p, _p, _f32, _p, _p, _p, _p]),
     "spt_segcsr_reduce_bwd_f32": (_int, [_int, _p, _p, _p, _p, _p, _i64, _i64, _int, _p, _p]),

@@ -33,7 +33,12 @@ class SegmentCSR:
     def pos_seg(self):
         """int32 [n]: segment of every CSR position (``idx[perm]``), built on first use."""
         if self._pos_seg is None:
-            self._pos_seg = self.idx.index_select(0, self.perm.long()).to(torch.int32)
+            out = torch.empty(max(self.n, 1), dtype=torch.int32, device=self.perm.device)
+            with torch.cuda.device(out.device):
+                st = _lib.lib.spt_csr_pos_seg(_lib.ptr(self.rowptr), self.num_seg, self.n,
+                                              _lib.ptr(out), _lib.stream_ptr(out.device))
+            _lib.check(st, "spt_csr_pos_seg")
+            self._pos_seg = out[:self.n]
         return self._pos_seg
 
     def counts(self):
@@ -156,7 +161,15 @@ def edge_csr_of(edge_index, num_nodes):
         return memo[key]
     view = build_csr(edge_index[0], num_nodes)
     # plumbing: the targets in CSR order (one gather per batch and level)
-    tgt_sorted = edge_index[1].index_select(0, view.perm.long()).to(torch.int32)
+    e = edge_index.shape[1]
+    tgt_sorted = torch.empty(max(e, 1), dtype=torch.int32, device=edge_index.device)[:e]
+    tgt64 = edge_index[1].contiguous()
+    if tgt64.dtype != torch.int64:
+        tgt64 = tgt64.long()
+    with torch.cuda.device(edge_index.device):
+        st = _lib.lib.spt_csr_gather_i64_i32(_lib.ptr(tgt64), _lib.ptr(view.perm), e,
+                                             _lib.ptr(tgt_sorted), _lib.stream_ptr(edge_index.device))
+    _lib.check(st, "spt_csr_gather_i64_i32")
     ecsr = EdgeCSR(view.rowptr, view.perm, tgt_sorted, int(num_nodes), edge_index.shape[1], view)
     if memo is None or any(k[0] != edge_index._version for k in memo):
         memo = {}

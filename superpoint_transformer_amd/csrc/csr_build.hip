@@ -49,3 +49,51 @@ extern "C" int spt_csr_build(const int64_t* idx, int64_t n, int64_t num_seg,
   SPT_CHECK_LAUNCH();
   return 0;
 }
+
+
+// ---- companions of the CSR view the host side otherwise builds with torch gathers ------------
+namespace spt {
+// pos_seg[j] = the segment of CSR position j (= idx[perm[j]], without touching idx: segment s
+// owns positions rowptr[s] .. rowptr[s + 1]).  One lane group of 16 per segment (segments of the
+// L0 -> L1 pool hold ~35 rows), coalesced stores.
+__global__ __launch_bounds__(256) void csr_pos_seg_kernel(const int32_t* __restrict__ rowptr,
+                                                          int64_t num_seg,
+                                                          int32_t* __restrict__ pos_seg) {
+  const int sub = threadIdx.x & 15;
+  const int64_t stride = (int64_t)gridDim.x * 16;
+  for (int64_t s = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); s < num_seg; s += stride) {
+    const int a = rowptr[s], b = rowptr[s + 1];
+    for (int j = a + sub; j < b; j += 16) pos_seg[j] = (int32_t)s;
+  }
+}
+// out[j] = (int32) src[perm[j]]: e.g. the targets of the edges in CSR order
+__global__ __launch_bounds__(256) void csr_gather_i64_i32_kernel(const int64_t* __restrict__ src,
+                                                                 const int32_t* __restrict__ perm,
+                                                                 int64_t n, int32_t* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride)
+    out[j] = (int32_t)src[perm[j]];
+}
+}  // namespace spt
+
+extern "C" int spt_csr_pos_seg(const int32_t* rowptr, int64_t num_seg, int64_t n, int32_t* pos_seg,
+                               spt_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPT_CHECK_ARG(num_seg >= 0 && n >= 0, "bad shape");
+  if (n == 0 || num_seg == 0) return 0;
+  SPT_CHECK_ARG(rowptr && pos_seg, "null pointer");
+  spt::csr_pos_seg_kernel<<<spt::stream_grid(num_seg, 16), 256, 0, stream>>>(rowptr, num_seg, pos_seg);
+  SPT_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int spt_csr_gather_i64_i32(const int64_t* src, const int32_t* perm, int64_t n,
+                                      int32_t* out, spt_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPT_CHECK_ARG(n >= 0, "bad shape");
+  if (n == 0) return 0;
+  SPT_CHECK_ARG(src && perm && out, "null pointer");
+  spt::csr_gather_i64_i32_kernel<<<spt::stream_grid(n, 256), 256, 0, stream>>>(src, perm, n, out);
+  SPT_CHECK_LAUNCH();
+  return 0;
+}
