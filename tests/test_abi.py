@@ -51,3 +51,33 @@ def test_product_never_imports_oracle():
                 assert not imp.search(txt) and not dyn.search(txt), f"{fn} imports the oracle"
                 assert "spt_oracle" not in txt and "spt_model" not in txt, \
                     f"{fn} references the oracle's modules"
+
+
+def test_host_side_dispatch_queries():
+    """Host-only entry points the autograd wrappers consult (no GPU needed): which (K, N) have a
+    fused layer / a pooled backward per matrix mode, which (H, D, Dv, F) take the edge-lane
+    attention backward, and the decomposition ops.edge_attention picks for wider head layouts."""
+    import torch
+    from superpoint_transformer_amd import _lib, ops
+    L = _lib.lib
+    assert L.spt_fused_linear_supported(64, 128) and L.spt_fused_linear_supported(12, 32)
+    assert not L.spt_fused_linear_supported(64, 100)
+    assert L.spt_fused_linear_pooled_supported_ex(64, 128, 1) and L.spt_fused_linear_pooled_supported_ex(32, 64, 3)
+    assert not L.spt_fused_linear_pooled_supported_ex(64, 128, 0)          # f32-exact: dense route
+    assert L.spt_skinny_dw_supported(128, 256) and not L.spt_skinny_dw_supported(48, 64)
+    assert L.spt_edge_attn_bwd_el_supported(16, 4, 4, 32, 2) and L.spt_edge_attn_bwd_el_supported(16, 4, 4, 32, -1)
+    assert not L.spt_edge_attn_bwd_el_supported(16, 4, 8, 32, 2)
+    assert not L.spt_edge_attn_bwd_el_supported(16, 4, 4, 32, 0)           # VALU precision
+    prev = L.spt_fused_linear_bwd_use_dma(-1)
+    assert L.spt_fused_linear_bwd_use_dma(0) == prev and L.spt_fused_linear_bwd_use_dma(prev) == 0
+
+    def split(H, Dv, F=32, enc=True):
+        qkv = torch.zeros(3, 2 * H * 4 + H * Dv)
+        ea = torch.zeros(5, F)
+        W = torch.zeros(H * 4, F) if enc else None
+        return ops._matrix_pipe_split(qkv, ea, W, W, W, H, 4)
+
+    assert split(16, 4) is None                                            # the built shape itself
+    assert split(16, 8) == (1, 2, 8) and split(32, 4) == (2, 1, 4) and split(32, 8) == (2, 2, 8)
+    assert split(16, 8, F=18) is None and split(16, 8, enc=False) is None and split(16, 6) is None
+    assert split(24, 4) is None
