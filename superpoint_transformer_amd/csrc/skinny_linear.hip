@@ -124,6 +124,81 @@ __global__ __launch_bounds__(WAVES * 64, (K4 <= 32) ? 2 : 1) void skinny_linear_
   }
 }
 
+// K = 192 (dX of the qkv Linear): 192 B-operand registers leave one wave per SIMD.  Here W's slab
+// stays in LDS for the whole launch and every MFMA takes its B operand from there (one 4-byte
+// LDS read per 32-cycle MFMA), 8-wave workgroups share the slab: two waves per SIMD.
+constexpr int WAVES_L = 8;
+template <int K4>
+__global__ __launch_bounds__(WAVES_L * 64, 2) void skinny_linear_wlds_kernel(
+    const float* __restrict__ x, int64_t rows, const float* __restrict__ W,
+    const float* __restrict__ bias, int N, float* __restrict__ y) {
+  constexpr int K = 4 * K4, LDA = K + 4, V = K4 / 4, NBS = 4;
+  __shared__ __attribute__((aligned(16))) float w_lds[16 * NBS * LDA];
+  __shared__ __attribute__((aligned(16))) float a_lds[WAVES_L][TR * LDA];
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, c = lane & 15;
+  const int n0 = blockIdx.y * (16 * NBS);
+  float* al = a_lds[wid];
+  for (int q = threadIdx.x; q < 16 * NBS * K4; q += WAVES_L * 64) {
+    const int rr = q / K4, k4 = q - rr * K4;
+    *reinterpret_cast<float4*>(w_lds + rr * LDA + 4 * k4) =
+        *reinterpret_cast<const float4*>(W + (size_t)(n0 + rr) * K + 4 * k4);
+  }
+  float bb[NBS];
+#pragma unroll
+  for (int nb = 0; nb < NBS; ++nb) bb[nb] = bias ? bias[n0 + 16 * nb + c] : 0.f;
+  __syncthreads();
+  const float* wl = w_lds + c * LDA + g;                // + 16 nb LDA + 4 st
+
+  const int64_t ntiles = (rows + TR - 1) / TR;
+  const int64_t wave = (int64_t)blockIdx.x * WAVES_L + wid;
+  const int64_t nwaves = (int64_t)gridDim.x * WAVES_L;
+  float4 nx[V];
+  auto fetch = [&](int64_t t) {
+    const int64_t base = t * TR * (int64_t)K;
+    const int64_t lim = rows * (int64_t)K;
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      const int64_t e = base + (int64_t)(v * 64 + lane) * 4;
+      nx[v] = (e < lim) ? *reinterpret_cast<const float4*>(x + e)
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  if (wave < ntiles) fetch(wave);
+  for (int64_t t = wave; t < ntiles; t += nwaves) {
+    wave_sync_lds();
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      const int q = (v * 64 + lane) * 4;
+      const int rr = q / K, k = q - rr * K;
+      *reinterpret_cast<float4*>(al + rr * LDA + k) = nx[v];
+    }
+    wave_sync_lds();
+    if (t + nwaves < ntiles) fetch(t + nwaves);         // in flight during the MFMAs
+    f32x4 C[NBS];
+#pragma unroll
+    for (int nb = 0; nb < NBS; ++nb) C[nb] = (f32x4){bb[nb], bb[nb], bb[nb], bb[nb]};
+#pragma unroll
+    for (int st = 0; st < K4; ++st) {
+      const float a = al[c * LDA + 4 * st + g];
+#pragma unroll
+      for (int nb = 0; nb < NBS; ++nb)
+        C[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wl[16 * nb * LDA + 4 * st], C[nb], 0, 0, 0);
+    }
+    const int64_t row0 = t * TR;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t row = row0 + 4 * g + r;
+      if (row < rows) {
+        float* yr = y + row * N + n0 + c;
+#pragma unroll
+        for (int nb = 0; nb < NBS; ++nb) __builtin_nontemporal_store(C[nb][r], yr + 16 * nb);
+      }
+    }
+  }
+}
+
 // dW[n, k] = sum_rows G[row, n] X[row, k].  blockIdx.y = 64-column slab of G; a wave strides the
 // 16-row tiles, keeps its [64 x K] partial in MFMA accumulators (v_mfma_f32_16x16x4_f32: the
 // contraction index is the tile's rows, four at a time; f32 in, f32 accumulate) and writes it
@@ -412,7 +487,14 @@ extern "C" int spt_skinny_linear_f32(const float* x, int64_t rows, int K, const 
     case 32:  skinny_linear_kernel<8><<<grid, WAVES * 64, 0, stream>>>(x, rows, W, bias, N, y); break;
     case 64:  skinny_linear_kernel<16><<<grid, WAVES * 64, 0, stream>>>(x, rows, W, bias, N, y); break;
     case 128: skinny_linear_kernel<32><<<grid, WAVES * 64, 0, stream>>>(x, rows, W, bias, N, y); break;
-    default:  skinny_linear_kernel<48><<<grid, WAVES * 64, 0, stream>>>(x, rows, W, bias, N, y); break;
+    default: {
+      int64_t b8 = ceil_div(tiles, WAVES_L);
+      const int64_t cap8 = (int64_t)256 * 2 / slabs > 1 ? (int64_t)256 * 2 / slabs : 1;
+      if (b8 > cap8) b8 = cap8;
+      skinny_linear_wlds_kernel<48><<<dim3((unsigned)b8, (unsigned)slabs), WAVES_L * 64, 0, stream>>>(
+          x, rows, W, bias, N, y);
+      break;
+    }
   }
   SPT_CHECK_LAUNCH();
   return 0;
