@@ -47,6 +47,14 @@ def parse():
                         "reference's shipped `precision: 32`, bf16 = its bf16 option (cfg #2)")
     p.add_argument("--model", default="spt64", choices=["spt64", "spt128"],
                    help="spt128 = the KITTI-360 width (cfg #4)")
+    p.add_argument("--graph", default="random", choices=["random", "local"],
+                   help="superpoint graph of the synthetic NAG: random = uniformly drawn endpoints (no "
+                        "locality: the stress case, default); local = kNN on the segment centroids (SURVEY 8d)")
+    p.add_argument("--order", default="storage", choices=["storage", "morton"],
+                   help="node order of levels 1-2: storage = shuffled (default), morton = along a Morton curve")
+    p.add_argument("--rebuild-csr", action="store_true",
+                   help="worst case: ignore the NAG's stored level CSR (nag[i+1].sub) and rebuild every "
+                        "CSR view with the device sort each step")
     return p.parse_args()
 
 
@@ -136,11 +144,37 @@ def preprocess_leg(scene, n_points, dev, reps=5):
     # median over the repetitions: one of them occasionally takes 5x (allocator / clocks)
     med = lambda v: sorted(v)[len(v) // 2]
     dt = med(t_all)
+    # SURVEY 8(d) algorithmic bytes: kNN >= 12 + K (8 + 4) B per point (the candidate scan itself is
+    # served by L2 / LDS: the kernel is VALU / LDS-issue bound, its HBM fraction is small BY DESIGN -
+    # the VALU-busy share of a PMC capture is the figure that says how close it is to its bound);
+    # eigenfeatures (k + 1) (4 + 12) + 44 B per point (gathered positions)
+    knn_b, geof_b = n_points * (12 + 12 * k), n_points * ((k + 1) * 16 + 44)
+    knn_gbs = knn_b / (med(t_knn) * 1e-3) / 1e9
+    geof_gbs = geof_b / (med(t_geof) * 1e-3) / 1e9
+    pmc = _preprocess_pmc(scene)
+    roof = {"knn": {"kernel": "spt::knn_cell_kernel (+ grid build, leftovers)", "bound": "valu",
+                    "bytes_per_launch": int(knn_b), "achieved": round(knn_gbs, 1), "unit": "GB/s",
+                    "frac_hbm": round(knn_gbs / HBM_PEAK_GBS, 4),
+                    "valu_busy": pmc.get("knn_valu_busy") if pmc else None,
+                    "valu_busy_source": pmc.get("source") if pmc else None},
+            "geof": {"kernel": "spt::point_geof_dense_kernel", "bound": "hbm",
+                     "bytes_per_launch": int(geof_b), "achieved": round(geof_gbs, 1), "unit": "GB/s",
+                     "peak": HBM_PEAK_GBS, "frac": round(geof_gbs / HBM_PEAK_GBS, 4)}}
     return {"value": round(n_points / dt / 1e6, 3), "unit": "Mpoints/s",
             "workload": f"knn_1(k={k}, r={r}) + geometric_features on {n_points} synthetic "
                         f"voxelised-surface points ({voxel} m lattice)",
             "ms_knn": round(med(t_knn), 3), "ms_geof": round(med(t_geof), 3),
-            "ms_total": round(dt * 1e3, 3), "reps": reps}
+            "ms_total": round(dt * 1e3, 3), "reps": reps, "roofline": roof}
+
+
+def _preprocess_pmc(scene):
+    """VALU-busy share of the kNN cell kernel from a committed PMC capture of this scene's
+    settings (profiles/traffic.json key ``preprocess@<scene>``), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            return json.load(f).get(f"preprocess@{scene}")
+    except (OSError, ValueError):
+        return None
 
 
 def cpu_preprocess_baseline(scene, n_sample):
@@ -236,8 +270,14 @@ def main():
 
     from superpoint_transformer_amd import precision
     precision.set_matrix_precision(args.dtype)
-    nag = make_nag(args.scene, seed=1234 + rank, device=dev)
-    path = hotpath.build(nag, dev, world=world, stages=args.stages, mode=args.mode, model=args.model)
+    from superpoint_transformer_amd import csr as _csr
+    _csr.use_sub_views(not args.rebuild_csr)
+    nag = make_nag(args.scene, seed=1234 + rank, device=dev, graph=args.graph, order=args.order)
+    path = hotpath.build(nag, dev, world=world, stages=args.stages, mode=args.mode, model=args.model,
+                         kernel_timers=True)
+    if args.graph == "random" and args.order == "storage":
+        # PMC captures (profiles/traffic.json) exist per (scene, net) of the default generator only
+        path.workload = f"{args.scene}/{args.model}" + ("" if args.mode == "train" else f"/{args.mode}")
 
     # A process that is the first to touch a box's GPU runs its first seconds ~10 % slow (clock
     # ramp; measured: the same binary 74.6 ms/step in the first process of a fresh box, 67.3 in
@@ -279,7 +319,21 @@ def main():
     n0 = nag.num_points[0]
     value = world * n0 * args.steps / dt / 1e6
     roof = path.roofline(HBM_PEAK_GBS)
-    workload = path.describe(args.scene, SCENES.get(args.scene))
+    workload = (path.describe(args.scene, SCENES.get(args.scene), args.graph)
+                if args.stages == "all" else path.describe(args.scene, SCENES.get(args.scene)))
+    if args.order != "storage":
+        workload += "; level-1/2 nodes stored along a Morton curve"
+
+    # what the step's one collective cost on this run's process group (RCCL over xGMI, or one
+    # rank under SPT_FORCE_COLLECTIVES=1); null without a process group
+    collective = None
+    bucket = getattr(path, "bucket", None)
+    if bucket is not None and dist.is_initialized():
+        bucket.pack()
+        us = bucket.time_allreduce_us()
+        collective = {"backend": dist.get_backend(), "ranks": dist.get_world_size(),
+                      "bytes": int(bucket.flat.numel() * 4),
+                      "allreduce_us": round(us, 1) if us is not None else None}
 
     # The default "f32" mode runs the attention GEMMs and the fused layers' backward GEMMs as three
     # bf16 products per f32 product (~10 ulp of f32; every f32 parity bar holds): print what the
@@ -340,8 +394,11 @@ def main():
                 "parallelism": f"dp{world}",
                 "mode": args.mode,
                 "net": args.model,
+                "graph": args.graph,
+                "csr_views": "rebuilt" if args.rebuild_csr else "nag.sub",
             },
             "roofline": roof,
+            "collective": collective,
             "cpu_baseline": cpu,
             "preprocess": pre,
         }

@@ -192,6 +192,22 @@ int spt_graphnorm_bwd_f32(const float* x, const float* gy, const int64_t* batch,
                           float* gx, float* gweight, float* gbias,
                           float* gmean_scale, void* ws, size_t ws_bytes,
                           spt_stream_t stream);
+/* Statistics + coefficient tables only (no apply pass): mean, rstd and the rows of
+ * y = (x - am[g]) * scale[g] + bias, all [num_graphs, d], for consumers that normalise on the fly
+ * (spt_skinny_linear_pre_f32).  ws: spt_graphnorm_workspace_bytes(). */
+int spt_graphnorm_stats_f32(const float* x, const int64_t* batch, int64_t r, int d, int num_graphs,
+                            const float* weight, const float* mean_scale, float eps, float* mean,
+                            float* rstd, float* am, float* scale, void* ws, size_t ws_bytes,
+                            spt_stream_t stream);
+/* spt_graphnorm_bwd_f32 with gx = gx_add + (backward of the norm); gx_add [r, d] or NULL: the
+ * gradient of the residual branch around a pre-norm joins in the apply pass. */
+int spt_graphnorm_bwd_acc_f32(const float* x, const float* gy, const int64_t* batch,
+                              int64_t r, int d, int num_graphs, const float* weight,
+                              const float* bias, const float* mean_scale,
+                              const float* mean, const float* rstd, float act_slope,
+                              const float* gx_add, float* gx, float* gweight, float* gbias,
+                              float* gmean_scale, void* ws, size_t ws_bytes,
+                              spt_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Fused sparse graph self-attention with relative-pose encodings   (a6.2-a6.7)
@@ -583,6 +599,23 @@ int spt_skinny_linear_f32(const float* x, int64_t rows, int K, const float* W, c
  * f32 in / f32 accumulate on the matrix pipe, per-wave partials summed in a fixed order
  * (deterministic).  gb[N] (nullable) receives the column sums of gy - the bias gradient - from the
  * same pass.  ws: spt_skinny_dw_workspace_bytes(K, N) bytes of device scratch. */
+/* The transformer block's pre-norm and residual folded into its two Linears
+ * (x = x + out_proj(attention(qkv(norm(x)))), src/nn/transformer.py:231-234):
+ *   pre_am / pre_scale [num_graphs, K], pre_bias [K]: x_n = (x - pre_am[g]) * pre_scale[g] +
+ *     pre_bias with g = batch[row] (batch NULL = one graph) applied while the rows are read - the
+ *     tables of spt_graphnorm_stats_f32; pre_am NULL = plain x;
+ *   residual [rows, N] or NULL: y = (x W^T + b) + residual.
+ * K in {32, 64, 128}, N a multiple of 64, num_graphs * K <= 1024 (spt_skinny_pre_supported). */
+int spt_skinny_pre_supported(int K, int N, int num_graphs);
+int spt_skinny_linear_pre_f32(const float* x, int64_t rows, int K, const float* W, const float* bias,
+                              int N, float* y, const float* pre_am, const float* pre_scale,
+                              const float* pre_bias, const int64_t* batch, int num_graphs,
+                              const float* residual, spt_stream_t stream);
+/* gw = gy^T norm(x) (+ gb): the weight gradient of the Linear above (same tables). */
+int spt_skinny_dw_pre_f32(const float* gy, const float* x, int64_t rows, int N, int K, float* gw,
+                          float* gb, const float* pre_am, const float* pre_scale,
+                          const float* pre_bias, const int64_t* batch, int num_graphs, void* ws,
+                          size_t ws_bytes, spt_stream_t stream);
 int spt_skinny_dw_supported(int K, int N);
 size_t spt_skinny_dw_workspace_bytes(int K, int N);
 int spt_skinny_dw_f32(const float* gy, const float* x, int64_t rows, int N, int K, float* gw,

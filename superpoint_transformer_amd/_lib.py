@@ -38,6 +38,10 @@ SIGNATURES = {
                                      _p, _p, _p, _p, _sz, _p]),
     "spt_graphnorm_bwd_f32": (_int, [_p, _p, _p, _i64, _int, _int, _p, _p, _p, _p, _p,
                                      _f32, _p, _p, _p, _p, _p, _sz, _p]),
+    "spt_graphnorm_stats_f32": (_int, [_p, _p, _i64, _int, _int, _p, _p, _f32, _p, _p, _p, _p,
+                                       _p, _sz, _p]),
+    "spt_graphnorm_bwd_acc_f32": (_int, [_p, _p, _p, _i64, _int, _int, _p, _p, _p, _p, _p,
+                                         _f32, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "spt_edge_attn_fwd_f32": (_int, [_p, _i64, _int, _int, _int, _p, _p, _p, _i64, _p, _int,
                                      _p, _p, _p, _p, _p, _p, _int, _f32, _p, _p, _p, _p]),
     "spt_edge_attn_bwd_workspace_bytes": (_sz, [_int, _int, _int, _int]),
@@ -132,6 +136,9 @@ SIGNATURES = {
     "spt_skinny_dw_workspace_bytes": (_sz, [_int, _int]),
     "spt_skinny_dw_f32": (_int, [_p, _p, _i64, _int, _int, _p, _p, _p, _sz, _p]),
     "spt_skinny_linear_f32": (_int, [_p, _i64, _int, _p, _p, _int, _p, _p]),
+    "spt_skinny_pre_supported": (_int, [_int, _int, _int]),
+    "spt_skinny_linear_pre_f32": (_int, [_p, _i64, _int, _p, _p, _int, _p, _p, _p, _p, _p, _int, _p, _p]),
+    "spt_skinny_dw_pre_f32": (_int, [_p, _p, _i64, _int, _int, _p, _p, _p, _p, _p, _p, _int, _p, _sz, _p]),
     "spt_index_inverse": (_int, [_p, _i64, _i64, _p, _p]),
     "spt_select_edges_workspace_bytes": (_sz, [_i64]),
     "spt_select_edges": (_int, [_p, _i64, _i64, _p, _i64, _p, _i64, _p, _p, _p, _sz, _p]),

@@ -96,6 +96,51 @@ def csr_of(idx, num_seg=None):
     return csr
 
 
+_USE_SUB_VIEWS = True
+
+
+def use_sub_views(on=True):
+    """Whether ``adopt_csr`` installs the CSR a NAG level already carries (``nag[i+1].sub``)
+    as the view of ``nag[i].super_index`` (default) or every view is rebuilt by the device
+    sort (the worst case: a batch whose levels carry no ``sub``).  Returns the old setting."""
+    global _USE_SUB_VIEWS
+    old, _USE_SUB_VIEWS = _USE_SUB_VIEWS, bool(on)
+    return old
+
+
+def adopt_csr(idx, num_seg, pointers, points):
+    """Install ``(pointers, points)`` as the memoised CSR view of ``idx`` - no sort.
+
+    The reference's NAG stores, next to every ``super_index``, the same partition as a CSR:
+    ``nag[i+1].sub`` with ``sub.points[sub.pointers[c]:sub.pointers[c+1]]`` the children of
+    cluster ``c`` (src/data/cluster.py:19-77; kept consistent by ``NAG.select``,
+    src/data/nag.py:306-399).  With the children of a cluster in ascending order - what the
+    stable sort of ``build_csr`` produces; the caller vouches for it (``Cluster.ascending``)
+    - the two views are the same arrays, so the per-batch sort of the level is skipped.
+    Only the int32 casts run (one pass over the level's ids)."""
+    if not _USE_SUB_VIEWS or idx is None:
+        return None
+    n = idx.numel()
+    num_seg = max(int(num_seg), 1)
+    if (points.numel() != n or pointers.numel() != num_seg + 1
+            or points.device != idx.device or pointers.device != idx.device):
+        return None                     # not the same partition / not resident: leave it to the sort
+    _lib.require_cuda(idx)
+    memo = getattr(idx, _ATTR, None)
+    key = (idx._version, num_seg, idx.data_ptr(), n)
+    if memo is not None and key in memo:
+        return memo[key]
+    csr = SegmentCSR(idx.detach(), points.to(torch.int32), pointers.to(torch.int32), n, num_seg)
+    if memo is None or any(k[0] != idx._version for k in memo):
+        memo = {}
+        try:
+            setattr(idx, _ATTR, memo)
+        except Exception:
+            return csr
+    memo[key] = csr
+    return csr
+
+
 class EdgeCSR:
     """Edges of an attention graph grouped by SOURCE node (edge_index[0] is the
     softmax group and the output row, src/nn/attention.py:207-208,307,315):

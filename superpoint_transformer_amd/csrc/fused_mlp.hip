@@ -1072,10 +1072,11 @@ static int g_fmlp_mode = 1;
 // per-call mode word of the *_ex entries: < 0 = the process default above, else 0..3
 static inline int fmlp_mode_of(int mode) { return mode < 0 ? g_fmlp_mode : (mode & 3); }
 // Backward formulation of the split-bf16 / bf16 modes: 1 (default) = tiles staged by LDS-DMA
-// (fused_mlp_dma.hip) where the shape is built, 0 = register-staged everywhere.  Per call: bit 2
-// of the mode word (SPT_FMLP_BWD_REGISTER_STAGED) forces the register-staged kernels.
+// (fused_mlp_dma.hip) where the shape is built, 0 = register-staged everywhere (the process-wide
+// switch holds under a per-call precision too, like the attention's formulation default).  Per
+// call: bit 2 of the mode word (SPT_FMLP_BWD_REGISTER_STAGED) forces the register-staged kernels.
 static int g_fmlp_dma = 1;
-static inline bool fmlp_dma_of(int mode) { return mode < 0 ? g_fmlp_dma != 0 : !(mode & 4); }
+static inline bool fmlp_dma_of(int mode) { return g_fmlp_dma != 0 && !(mode >= 0 && (mode & 4)); }
 extern "C" int spt_fused_linear_bwd_use_dma(int on) {
   const int prev = g_fmlp_dma;
   if (on >= 0) g_fmlp_dma = on != 0;

@@ -453,7 +453,9 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_bwd_kernel(
     const float* __restrict__ am, const float* __restrict__ scale,
     const float* __restrict__ bias, float slope, const float* __restrict__ c1,
     const float* __restrict__ c2, const float* __restrict__ c3,
-    float* __restrict__ gx) {
+    float* __restrict__ gx, const float* __restrict__ gadd) {
+  // gadd (nullable): a second gradient of x - the residual branch around the norm - added in
+  // this pass (gx = gadd + norm-backward) instead of by a separate elementwise launch
   const int lpr = 1 << lpr_log2;
   const int rpb = GN_THREADS >> lpr_log2;
   const int rsub = threadIdx.x >> lpr_log2;
@@ -465,7 +467,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_bwd_kernel(
   int cur = -1;
   const int64_t step = (int64_t)gridDim.x * rpb * GN_UNR;
   for (int64_t rb = (int64_t)blockIdx.x * rpb * GN_UNR; rb < R; rb += step) {
-    float v[GN_UNR][VEC], g[GN_UNR][VEC];
+    float v[GN_UNR][VEC], g[GN_UNR][VEC], ga[GN_UNR][VEC];
     int b[GN_UNR];
 #pragma unroll
     for (int u = 0; u < GN_UNR; ++u) {
@@ -474,6 +476,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_bwd_kernel(
       if (b[u] >= 0) {
         ld<VEC>(x + row * d + c0, v[u]);
         ld<VEC>(gy + row * d + c0, g[u]);
+        if (gadd) ld<VEC>(gadd + row * d + c0, ga[u]);
       }
     }
 #pragma unroll
@@ -499,6 +502,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_bwd_kernel(
           gg = (yy > 0.f) ? gg : gg * slope;
         }
         o[k] = fmaf(t_c1[k], gg, -fmaf(t_c2[k], oo, t_c3[k]));
+        if (gadd) o[k] += ga[u][k];
       }
       st<VEC>(gx + row * d + c0, o);
     }
@@ -608,6 +612,29 @@ extern "C" int spt_graphnorm_fwd_f32(const float* x, const int64_t* batch, int64
 
 // The backward recounts rows per graph in its own statistics pass, so no
 // forward state besides (mean, rstd) is needed.
+// Forward WITHOUT the apply pass: statistics of x and the coefficient tables of
+// y = (x - am[g]) * scale[g] + bias into caller buffers [num_graphs, d] - for consumers that
+// apply the norm on the fly while they read x (the pre-norm in front of the attention block's
+// qkv Linear: spt_skinny_linear_pre_f32).
+extern "C" int spt_graphnorm_stats_f32(const float* x, const int64_t* batch, int64_t r, int d,
+                                       int num_graphs, const float* weight,
+                                       const float* mean_scale, float eps, float* mean,
+                                       float* rstd, float* am, float* scale, void* ws,
+                                       size_t ws_bytes, spt_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int B = num_graphs;
+  SPT_CHECK_ARG(r >= 0 && d >= 1 && B >= 1, "bad shape");
+  GnPlan p;
+  SPT_CHECK_ARG(gn_plan(r, d, B, &p), "dim > 1024 unsupported");
+  if (int e = gn_check(r, d, B, p, ws, ws_bytes)) return e;
+  SPT_CHECK_ARG(weight && mean_scale && mean && rstd && am && scale && (r == 0 || x), "null pointer");
+  double* partial = (double*)((char*)ws + p.off_partial);
+  launch_stats<false>(p, x, nullptr, batch, r, d, B, nullptr, nullptr, nullptr, 1.f, partial, stream);
+  gn_finalize_fwd_kernel<<<dim3(B, (d + 15) / 16), 256, 0, stream>>>(partial, p.nblocks, B, d, weight, mean_scale, eps, mean, rstd, am, scale);
+  SPT_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int spt_graphnorm_bwd_f32(const float* x, const float* gy,
                                      const int64_t* batch, int64_t r, int d,
                                      int num_graphs, const float* weight,
@@ -616,6 +643,21 @@ extern "C" int spt_graphnorm_bwd_f32(const float* x, const float* gy,
                                      float act_slope, float* gx, float* gweight,
                                      float* gbias, float* gmean_scale, void* ws,
                                      size_t ws_bytes, spt_stream_t stream_) {
+  return spt_graphnorm_bwd_acc_f32(x, gy, batch, r, d, num_graphs, weight, bias, mean_scale, mean,
+                                   rstd, act_slope, nullptr, gx, gweight, gbias, gmean_scale, ws,
+                                   ws_bytes, stream_);
+}
+// Same, plus `gx_add` [r, d] (nullable): gx = gx_add + backward of the norm - the gradient of the
+// residual branch around a pre-norm (x = x + f(norm(x)), src/nn/transformer.py:231-234) joins in
+// the apply pass instead of a separate elementwise launch.
+extern "C" int spt_graphnorm_bwd_acc_f32(const float* x, const float* gy,
+                                         const int64_t* batch, int64_t r, int d,
+                                         int num_graphs, const float* weight,
+                                         const float* bias, const float* mean_scale,
+                                         const float* mean, const float* rstd,
+                                         float act_slope, const float* gx_add, float* gx,
+                                         float* gweight, float* gbias, float* gmean_scale,
+                                         void* ws, size_t ws_bytes, spt_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   const int B = num_graphs;
   SPT_CHECK_ARG(r >= 0 && d >= 1 && B >= 1, "bad shape");
@@ -639,11 +681,11 @@ extern "C" int spt_graphnorm_bwd_f32(const float* x, const float* gy,
   gn_finalize_bwd_kernel<<<(d + 15) / 16, 256, 0, stream>>>(partial, p.nblocks, B, d, weight, mean_scale, mean, rstd, am, scale, c1, c2, c3, gweight, gbias, gmean_scale);
   if (r > 0) {
     if (p.sh.vec == 4)
-      gn_apply_bwd_kernel<4><<<p.nblocks * 2, GN_THREADS, 0, stream>>>(x, gy, batch, r, d, p.sh.lpr_log2, am, scale, bias, act_slope, c1, c2, c3, gx);
+      gn_apply_bwd_kernel<4><<<p.nblocks * 2, GN_THREADS, 0, stream>>>(x, gy, batch, r, d, p.sh.lpr_log2, am, scale, bias, act_slope, c1, c2, c3, gx, gx_add);
     else if (p.sh.vec == 2)
-      gn_apply_bwd_kernel<2><<<p.nblocks * 2, GN_THREADS, 0, stream>>>(x, gy, batch, r, d, p.sh.lpr_log2, am, scale, bias, act_slope, c1, c2, c3, gx);
+      gn_apply_bwd_kernel<2><<<p.nblocks * 2, GN_THREADS, 0, stream>>>(x, gy, batch, r, d, p.sh.lpr_log2, am, scale, bias, act_slope, c1, c2, c3, gx, gx_add);
     else
-      gn_apply_bwd_kernel<1><<<p.nblocks * 2, GN_THREADS, 0, stream>>>(x, gy, batch, r, d, p.sh.lpr_log2, am, scale, bias, act_slope, c1, c2, c3, gx);
+      gn_apply_bwd_kernel<1><<<p.nblocks * 2, GN_THREADS, 0, stream>>>(x, gy, batch, r, d, p.sh.lpr_log2, am, scale, bias, act_slope, c1, c2, c3, gx, gx_add);
   }
   SPT_CHECK_LAUNCH();
   return 0;

@@ -32,12 +32,23 @@ __device__ __forceinline__ void wave_sync_lds() {
 // K = 4 K4.  blockIdx.y = column slab of NBS 16-column blocks (4: N a multiple of 64; 1: the
 // narrow heads, N <= 16 - the classifiers' 13 classes - with the missing columns read as zero
 // and not stored); waves of blockIdx.x stride the row tiles.
-template <int K4, int NBS = 4>
+// PRE: the rows of x go through a per-graph affine map on their way into the A tile,
+//   x_n = (x - pam[g][k]) * psc[g][k] + pbs[k],  g = batch[row] (0 when batch is null)
+// - the pre-norm GraphNorm in front of the attention block's qkv Linear (src/nn/transformer.py:
+// 231-234) applied while x is read, bitwise the values gn_apply_fwd_kernel would have written
+// (same fmaf), so the normalised [rows, K] tensor is never materialised.  Tables of PB graphs
+// live in LDS.  RES: y = (x W^T + b) + res (the block's residual `shortcut + out_proj(.)`).
+constexpr int PRE_MAX = 1024;  // floats per coefficient table in LDS (num_graphs x K)
+template <int K4, int NBS = 4, bool PRE = false, bool RES = false>
 __global__ __launch_bounds__(WAVES * 64, (K4 <= 32) ? 2 : 1) void skinny_linear_kernel(
     const float* __restrict__ x, int64_t rows, const float* __restrict__ W,
-    const float* __restrict__ bias, int N, float* __restrict__ y) {
+    const float* __restrict__ bias, int N, float* __restrict__ y,
+    const float* __restrict__ pam = nullptr, const float* __restrict__ psc = nullptr,
+    const float* __restrict__ pbs = nullptr, const int64_t* __restrict__ batch = nullptr, int PB = 1,
+    const float* __restrict__ res = nullptr) {
   constexpr int K = 4 * K4, LDA = K + 4, V = K4 / 4;   // V float4 per lane per tile
   __shared__ __attribute__((aligned(16))) float a_lds[WAVES][TR * LDA];
+  __shared__ __attribute__((aligned(16))) float ptab[PRE ? 2 * PRE_MAX + K : 4];   // am | sc | bias
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, c = lane & 15;
@@ -69,6 +80,13 @@ __global__ __launch_bounds__(WAVES * 64, (K4 <= 32) ? 2 : 1) void skinny_linear_
       for (int st = 0; st < K4; ++st) B[nb][st] = wl[(16 * nb + c) * LDA + 4 * st + g];
       bb[nb] = (bias && n0 + 16 * nb + c < N) ? bias[n0 + 16 * nb + c] : 0.f;
     }
+    if constexpr (PRE) {
+      for (int i = threadIdx.x; i < PB * K; i += WAVES * 64) {
+        ptab[i] = pam[i];
+        ptab[PRE_MAX + i] = psc[i];
+      }
+      for (int i = threadIdx.x; i < K; i += WAVES * 64) ptab[2 * PRE_MAX + i] = pbs[i];
+    }
     __syncthreads();
   }
 
@@ -78,6 +96,7 @@ __global__ __launch_bounds__(WAVES * 64, (K4 <= 32) ? 2 : 1) void skinny_linear_
 
   // the tile [16, K] is one contiguous run of 16 K floats: lane l takes float4 l, l+64, ...
   float4 nx[V];
+  int ng[V];                                            // graph of the row each float4 belongs to
   auto fetch = [&](int64_t t) {
     const int64_t base = t * TR * (int64_t)K;
     const int64_t lim = rows * (int64_t)K;
@@ -86,16 +105,40 @@ __global__ __launch_bounds__(WAVES * 64, (K4 <= 32) ? 2 : 1) void skinny_linear_
       const int64_t e = base + (int64_t)(v * 64 + lane) * 4;
       nx[v] = (e < lim) ? *reinterpret_cast<const float4*>(x + e)
                         : make_float4(0.f, 0.f, 0.f, 0.f);
+      if constexpr (PRE) {
+        const int64_t row = t * TR + ((v * 64 + lane) * 4) / K;
+        ng[v] = (batch && row < rows) ? (int)batch[row] : 0;
+      }
     }
   };
   if (wave < ntiles) fetch(wave);
   for (int64_t t = wave; t < ntiles; t += nwaves) {
+    // the residual values of this tile's outputs (C layout), requested before the staging
+    float rv[RES ? NBS : 1][4];
+    if constexpr (RES) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t row = t * TR + 4 * g + r;
+#pragma unroll
+        for (int nb = 0; nb < NBS; ++nb)
+          rv[nb][r] = (row < rows && (NBS == 4 || n0 + 16 * nb + c < N))
+                          ? res[row * N + n0 + c + 16 * nb] : 0.f;
+      }
+    }
     wave_sync_lds();
 #pragma unroll
     for (int v = 0; v < V; ++v) {
       const int q = (v * 64 + lane) * 4;                // element index inside the tile
       const int rr = q / K, k = q - rr * K;
-      *reinterpret_cast<float4*>(al + rr * LDA + k) = nx[v];
+      float4 w = nx[v];
+      if constexpr (PRE) {
+        const float4 a = *reinterpret_cast<const float4*>(ptab + ng[v] * K + k);
+        const float4 sc4 = *reinterpret_cast<const float4*>(ptab + PRE_MAX + ng[v] * K + k);
+        const float4 b4 = *reinterpret_cast<const float4*>(ptab + 2 * PRE_MAX + k);
+        w.x = fmaf(w.x - a.x, sc4.x, b4.x); w.y = fmaf(w.y - a.y, sc4.y, b4.y);
+        w.z = fmaf(w.z - a.z, sc4.z, b4.z); w.w = fmaf(w.w - a.w, sc4.w, b4.w);
+      }
+      *reinterpret_cast<float4*>(al + rr * LDA + k) = w;
     }
     wave_sync_lds();
     if (t + nwaves < ntiles) fetch(t + nwaves);         // in flight during the MFMAs
@@ -118,7 +161,8 @@ __global__ __launch_bounds__(WAVES * 64, (K4 <= 32) ? 2 : 1) void skinny_linear_
         float* yr = y + row * N + n0 + c;
 #pragma unroll
         for (int nb = 0; nb < NBS; ++nb)
-          if (NBS == 4 || n0 + 16 * nb + c < N) __builtin_nontemporal_store(C[nb][r], yr + 16 * nb);
+          if (NBS == 4 || n0 + 16 * nb + c < N)
+            __builtin_nontemporal_store(RES ? C[nb][r] + rv[nb][r] : C[nb][r], yr + 16 * nb);
       }
     }
   }
@@ -203,10 +247,14 @@ __global__ __launch_bounds__(WAVES_L * 64, 2) void skinny_linear_wlds_kernel(
 // 16-row tiles, keeps its [64 x K] partial in MFMA accumulators (v_mfma_f32_16x16x4_f32: the
 // contraction index is the tile's rows, four at a time; f32 in, f32 accumulate) and writes it
 // once; a second kernel sums the per-wave partials in a fixed order (deterministic).
-template <int K4>
+// PRE: x is normalised on the way in exactly like skinny_linear_kernel<.., PRE> does (the weight
+// gradient of a Linear behind an on-the-fly pre-norm needs the NORMALISED rows).
+template <int K4, bool PRE = false>
 __global__ __launch_bounds__(WAVES * 64, 2) void skinny_dw_kernel(
     const float* __restrict__ gy, const float* __restrict__ x, int64_t rows, int N, int KF,
-    float* __restrict__ partial) {
+    float* __restrict__ partial, const float* __restrict__ pam = nullptr,
+    const float* __restrict__ psc = nullptr, const float* __restrict__ pbs = nullptr,
+    const int64_t* __restrict__ batch = nullptr, int PB = 1) {
   // KF = the layer's full input width: blockIdx.z = K-column slab of x (KF = 128 runs as two
   // 64-column slabs, each re-reading its G slab - G is the small operand at these widths)
   constexpr int K = 4 * K4, KB = K / 16, LDG = SLAB + 4, LDX = K + 4;
@@ -214,6 +262,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void skinny_dw_kernel(
   static_assert(K % 16 == 0 && TR * K % 256 == 0, "K is a multiple of 16");
   __shared__ __attribute__((aligned(16))) float g_lds[WAVES][TR * LDG];
   __shared__ __attribute__((aligned(16))) float x_lds[WAVES][TR * LDX];
+  __shared__ __attribute__((aligned(16))) float ptab[PRE ? 2 * PRE_MAX + 4 * K4 : 4];   // am | sc | bias (this k-slab)
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, c = lane & 15;
@@ -230,7 +279,17 @@ __global__ __launch_bounds__(WAVES * 64, 2) void skinny_dw_kernel(
   const int64_t ntiles = (rows + TR - 1) / TR;
   const int64_t wave = (int64_t)blockIdx.x * WAVES + wid;
   const int64_t nwaves = (int64_t)gridDim.x * WAVES;
+  if constexpr (PRE) {                                  // columns k0 .. k0 + K of every graph's row
+    for (int i = threadIdx.x; i < PB * K; i += WAVES * 64) {
+      const int gph = i / K, k = i - gph * K;
+      ptab[i] = pam[gph * KF + k0 + k];
+      ptab[PRE_MAX + i] = psc[gph * KF + k0 + k];
+    }
+    for (int i = threadIdx.x; i < K; i += WAVES * 64) ptab[2 * PRE_MAX + i] = pbs[k0 + i];
+    __syncthreads();
+  }
   float4 ng[VG], nx[VX];
+  int xg[VX];                                           // graph of the row each x chunk belongs to
   auto fetch = [&](int64_t t) {                         // rows past the end read as zero
 #pragma unroll
     for (int v = 0; v < VG; ++v) {
@@ -245,6 +304,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void skinny_dw_kernel(
       const int64_t row = t * TR + rr;
       nx[v] = (row < rows) ? *reinterpret_cast<const float4*>(x + row * KF + k0 + ch * 4)
                            : make_float4(0.f, 0.f, 0.f, 0.f);
+      if constexpr (PRE) xg[v] = (row < rows) ? (batch ? (int)batch[row] : 0) : -1;
     }
   };
   if (wave < ntiles) fetch(wave);
@@ -258,7 +318,17 @@ __global__ __launch_bounds__(WAVES * 64, 2) void skinny_dw_kernel(
 #pragma unroll
     for (int v = 0; v < VX; ++v) {
       const int q = v * 64 + lane, rr = q / K4, ch = q - rr * K4;
-      *reinterpret_cast<float4*>(xl + rr * LDX + ch * 4) = nx[v];
+      float4 w = nx[v];
+      if constexpr (PRE) {
+        if (xg[v] >= 0) {                               // rows past the end stay zero
+          const float4 a = *reinterpret_cast<const float4*>(ptab + xg[v] * K + ch * 4);
+          const float4 sc4 = *reinterpret_cast<const float4*>(ptab + PRE_MAX + xg[v] * K + ch * 4);
+          const float4 b4 = *reinterpret_cast<const float4*>(ptab + 2 * PRE_MAX + ch * 4);
+          w.x = fmaf(w.x - a.x, sc4.x, b4.x); w.y = fmaf(w.y - a.y, sc4.y, b4.y);
+          w.z = fmaf(w.z - a.z, sc4.z, b4.z); w.w = fmaf(w.w - a.w, sc4.w, b4.w);
+        }
+      }
+      *reinterpret_cast<float4*>(xl + rr * LDX + ch * 4) = w;
     }
     wave_sync_lds();
     if (t + nwaves < ntiles) fetch(t + nwaves);         // in flight during the MFMAs
@@ -427,11 +497,29 @@ extern "C" size_t spt_skinny_dw_workspace_bytes(int K, int N) {
 extern "C" int spt_skinny_dw_f32(const float* gy, const float* x, int64_t rows, int N, int K,
                                  float* gw, float* gb, void* ws, size_t ws_bytes,
                                  spt_stream_t stream_) {
+  return spt_skinny_dw_pre_f32(gy, x, rows, N, K, gw, gb, nullptr, nullptr, nullptr, nullptr, 1, ws,
+                               ws_bytes, stream_);
+}
+// Same with x normalised on the fly: x_n = (x - pre_am[g]) * pre_scale[g] + pre_bias, g =
+// batch[row] (tables [num_graphs, K] / [K]; batch NULL = one graph) - the weight gradient of a
+// Linear fed by spt_skinny_linear_pre_f32.  pre_am NULL = plain x.
+extern "C" int spt_skinny_pre_supported(int K, int N, int num_graphs) {
+  return (K == 32 || K == 64 || K == 128) && N >= SLAB && N % SLAB == 0 && N <= 1024 &&
+         num_graphs >= 1 && num_graphs * K <= PRE_MAX;
+}
+extern "C" int spt_skinny_dw_pre_f32(const float* gy, const float* x, int64_t rows, int N, int K,
+                                     float* gw, float* gb, const float* pre_am,
+                                     const float* pre_scale, const float* pre_bias,
+                                     const int64_t* batch, int num_graphs, void* ws,
+                                     size_t ws_bytes, spt_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SPT_CHECK_ARG(rows >= 0, "bad shape");
   SPT_CHECK_ARG(spt_skinny_dw_supported(K, N), "(K, N) not built");
   SPT_CHECK_ARG(gw && (rows == 0 || (gy && x)), "null pointer");
   SPT_CHECK_ARG(ws && ws_bytes >= spt_skinny_dw_workspace_bytes(K, N), "workspace too small");
+  const bool pre = pre_am != nullptr;
+  SPT_CHECK_ARG(!pre || (pre_scale && pre_bias && spt_skinny_pre_supported(K, N, num_graphs)),
+                "pre-normalisation: incomplete tables or num_graphs * K too large");
   const int slabs = N / SLAB;
   if (rows == 0) {
     hipMemsetAsync(gw, 0, (size_t)N * K * sizeof(float), stream);
@@ -445,10 +533,18 @@ extern "C" int spt_skinny_dw_f32(const float* gy, const float* x, int64_t rows, 
   if (bx > cap) bx = cap;
   const dim3 grid((unsigned)bx, (unsigned)slabs, (unsigned)kslabs);
   float* partial = (float*)ws;
-  if (K == 32)
+  if (pre) {
+    if (K == 32)
+      skinny_dw_kernel<8, true><<<grid, WAVES * 64, 0, stream>>>(gy, x, rows, N, K, partial, pre_am,
+                                                                 pre_scale, pre_bias, batch, num_graphs);
+    else
+      skinny_dw_kernel<16, true><<<grid, WAVES * 64, 0, stream>>>(gy, x, rows, N, K, partial, pre_am,
+                                                                  pre_scale, pre_bias, batch, num_graphs);
+  } else if (K == 32) {
     skinny_dw_kernel<8><<<grid, WAVES * 64, 0, stream>>>(gy, x, rows, N, K, partial);
-  else
+  } else {
     skinny_dw_kernel<16><<<grid, WAVES * 64, 0, stream>>>(gy, x, rows, N, K, partial);
+  }
   sum_tables_kernel<<<(N * (K + 1) + 15) / 16, 1024, 0, stream>>>(partial, (int)bx * WAVES, N * (K + 1),
                                                                   N * K, gw, gb);
   SPT_CHECK_LAUNCH();
@@ -462,11 +558,29 @@ extern "C" int spt_skinny_linear_supported(int K, int N) {
 
 extern "C" int spt_skinny_linear_f32(const float* x, int64_t rows, int K, const float* W,
                                      const float* bias, int N, float* y, spt_stream_t stream_) {
+  return spt_skinny_linear_pre_f32(x, rows, K, W, bias, N, y, nullptr, nullptr, nullptr, nullptr, 1,
+                                   nullptr, stream_);
+}
+
+// y = norm(x) W^T + b (+ residual): the pre-norm of a transformer block folded into its qkv Linear
+// (x_n = (x - pre_am[g]) * pre_scale[g] + pre_bias applied while the rows are read; tables from
+// spt_graphnorm_stats_f32; pre_am NULL = plain x) and the block's residual folded into its out_proj
+// (`residual` [rows, N] or NULL: y = (x W^T + b) + residual) - src/nn/transformer.py:231-234.
+// K in {32, 64, 128}, N a multiple of 64 for either option.
+extern "C" int spt_skinny_linear_pre_f32(const float* x, int64_t rows, int K, const float* W,
+                                         const float* bias, int N, float* y, const float* pre_am,
+                                         const float* pre_scale, const float* pre_bias,
+                                         const int64_t* batch, int num_graphs,
+                                         const float* residual, spt_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SPT_CHECK_ARG(rows >= 0, "bad shape");
   SPT_CHECK_ARG(spt_skinny_linear_supported(K, N), "(K, N) not built");
   if (rows == 0) return 0;
   SPT_CHECK_ARG(x && W && y, "null pointer");
+  const bool pre = pre_am != nullptr, resid = residual != nullptr;
+  SPT_CHECK_ARG(!pre || (pre_scale && pre_bias && spt_skinny_pre_supported(K, N, num_graphs)),
+                "pre-normalisation: incomplete tables, unbuilt shape or num_graphs * K too large");
+  SPT_CHECK_ARG(!resid || spt_skinny_pre_supported(K, N, 1), "residual epilogue: unbuilt shape");
   const bool narrow = N <= 16;
   const int slabs = narrow ? 1 : N / SLAB;
   const int64_t tiles = ceil_div(rows, TR);
@@ -474,6 +588,26 @@ extern "C" int spt_skinny_linear_f32(const float* x, int64_t rows, int K, const 
   const int64_t cap = (int64_t)256 * 8 / slabs > 1 ? (int64_t)256 * 8 / slabs : 1;
   if (bx > cap) bx = cap;
   const dim3 grid((unsigned)bx, (unsigned)slabs);
+  if (pre || resid) {
+#define SPT_SKINNY_PR(K4)                                                                          \
+  if (pre && resid)                                                                                \
+    skinny_linear_kernel<K4, 4, true, true><<<grid, WAVES * 64, 0, stream>>>(                      \
+        x, rows, W, bias, N, y, pre_am, pre_scale, pre_bias, batch, num_graphs, residual);         \
+  else if (pre)                                                                                    \
+    skinny_linear_kernel<K4, 4, true, false><<<grid, WAVES * 64, 0, stream>>>(                     \
+        x, rows, W, bias, N, y, pre_am, pre_scale, pre_bias, batch, num_graphs, nullptr);          \
+  else                                                                                             \
+    skinny_linear_kernel<K4, 4, false, true><<<grid, WAVES * 64, 0, stream>>>(                     \
+        x, rows, W, bias, N, y, nullptr, nullptr, nullptr, nullptr, 1, residual);
+    switch (K) {
+      case 32:  SPT_SKINNY_PR(8) break;
+      case 64:  SPT_SKINNY_PR(16) break;
+      default:  SPT_SKINNY_PR(32) break;
+    }
+#undef SPT_SKINNY_PR
+    SPT_CHECK_LAUNCH();
+    return 0;
+  }
   if (narrow) {
     switch (K) {
       case 32:  skinny_linear_kernel<8, 1><<<grid, WAVES * 64, 0, stream>>>(x, rows, W, bias, N, y); break;

@@ -81,7 +81,11 @@ class Cluster:
     (src/data/cluster.py:19-58).  ``dense=True``: build it from a per-point cluster
     index (CSRData.__init__, src/data/csr.py:85-88)."""
 
-    def __init__(self, pointers, points, dense=False):
+    def __init__(self, pointers, points, dense=False, ascending=None):
+        # ascending: the points of every cluster are in increasing order (True / False / None =
+        # not known yet, checked on first use) - what lets the segment kernels take this CSR
+        # as the view of the level's super_index instead of sorting it (csr.adopt_csr)
+        self._ascending = ascending
         if dense:
             index = pointers.long()
             n = int(index.max()) + 1 if index.numel() else 0
@@ -92,6 +96,22 @@ class Cluster:
         else:
             self.pointers = pointers.long().contiguous()
             self.points = points.long().contiguous()
+
+    @property
+    def ascending(self):
+        """True when the points of every cluster are stored in increasing order.  Checked once
+        per object (one device pass + a host read); ``select`` and ``clone`` hand it on."""
+        if self._ascending is None:
+            m = self.points.numel()
+            if m < 2:
+                self._ascending = True
+            else:
+                ok = self.points[1:] > self.points[:-1]
+                starts = self.pointers[1:-1]
+                starts = starts[(starts > 0) & (starts < m)]
+                ok[starts - 1] = True
+                self._ascending = bool(ok.all())
+        return self._ascending
 
     @property
     def device(self):
@@ -117,7 +137,10 @@ class Cluster:
         return out
 
     def clone(self):
-        return Cluster(self.pointers.clone(), self.points.clone())
+        return Cluster(self.pointers.clone(), self.points.clone(), ascending=self._ascending)
+
+    def to(self, device):
+        return Cluster(self.pointers.to(device), self.points.to(device), ascending=self._ascending)
 
     def select(self, idx, update_sub=True, num_sub=None):
         """New Cluster made of the clusters ``idx`` (no duplicates), and - when
@@ -148,8 +171,11 @@ class Cluster:
         if not update_sub:
             # CSRData.select only: same clusters, ORIGINAL point ids
             old = idx_sub[:kept][new_pts[:kept]]
-            return Cluster(new_ptr, old), (None, None)
-        return Cluster(new_ptr, new_pts[:kept]), (idx_sub[:kept], sub_super[:kept])
+            return Cluster(new_ptr, old, ascending=self._ascending), (None, None)
+        # the kernel copies every kept cluster in its stored order and relabels the points
+        # by rank: an ascending cluster stays ascending
+        return (Cluster(new_ptr, new_pts[:kept], ascending=self._ascending),
+                (idx_sub[:kept], sub_super[:kept]))
 
 
 class Data:
@@ -189,7 +215,17 @@ class Data:
         else:
             self._store[key] = value
 
-    __getitem__ = __getattr__
+    def __getitem__(self, key):
+        """Strict: a key that is not stored raises ``KeyError`` (only ATTRIBUTE access answers
+        None for the reference's optional properties)."""
+        store = object.__getattribute__(self, "_store")
+        if key in store:
+            return store[key]
+        raise KeyError(key)
+
+    def get(self, key, default=None):
+        return object.__getattribute__(self, "_store").get(key, default)
+
     __setitem__ = __setattr__
 
     def __contains__(self, key):
@@ -295,7 +331,7 @@ class Data:
         if self.is_sub and update_super:                              # data.py:399-416
             new_si, idx_super = consecutive_cluster(self.super_index, num_super, gather=idx)
             data.super_index = new_si
-            super_sub = Cluster(new_si, torch.arange(k, device=dev), dense=True)
+            super_sub = Cluster(new_si, torch.arange(k, device=dev), dense=True, ascending=True)
             out_super = (idx_super, super_sub)
 
         skip = {"edge_index", "sub", "super_index", "neighbor_index", "neighbor_distance"}
@@ -418,8 +454,11 @@ class NAG:
                     for v in vals[1:]:
                         ptr.append(v.pointers[1:] + base)
                         base += int(v.pointers[-1])
+                    asc = [v._ascending for v in vals]
                     d[key] = Cluster(torch.cat(ptr),
-                                     torch.cat([v.points + lo[j] for j, v in enumerate(vals)]))
+                                     torch.cat([v.points + lo[j] for j, v in enumerate(vals)]),
+                                     ascending=True if all(a is True for a in asc) else
+                                     (False if any(a is False for a in asc) else None))
                 elif _is_instance_data(vals[0]):
                     d[key] = type(vals[0]).from_list(vals)
                 elif torch.is_tensor(vals[0]):

@@ -64,19 +64,42 @@ def spt128_config(point_in=8, edge_in=18):
     return cfg
 
 
-def _pmc_traffic(timer_name):
-    """HBM bytes per launch of a roofline kernel as measured with rocprofv3 PMC counters on this
-    exact shape (profiles/traffic.json: {"bytes", "source", ...}; FETCH_SIZE doubled per
-    MI355X_MICROARCH.md's gfx950 correction).  None when no capture exists."""
+def _pmc_traffic(op, workload):
+    """HBM bytes per launch of a roofline op as measured with rocprofv3 PMC counters on THIS
+    workload (profiles/traffic.json, written by tools/make_traffic_json.py from a
+    tools/pmc_step.sh capture; keys ``<op>@<scene>/<net>``; FETCH_SIZE doubled per
+    MI355X_MICROARCH.md's gfx950 correction).  None when no capture exists for the workload -
+    a line of another scene or model never borrows scene S's bytes."""
     import json
     import os
+    if not workload:
+        return None
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                         "profiles", "traffic.json")
     try:
         with open(path) as f:
-            return json.load(f).get(timer_name) or None
+            return json.load(f).get(f"{op}@{workload}") or None
     except (OSError, ValueError):
         return None
+
+
+def _kernel_names(mode):
+    """Kernels behind the four timed ops in matrix mode ``mode`` (precision.get_matrix_precision):
+    what the dispatch of csrc/edge_attn.hip / fused_mlp.hip launches for the SPT-64 head layout."""
+    if mode == "f32-exact":
+        return {"attn_bwd": "hipMemsetAsync + spt::mfma::attn_bwd_packed_kernel<0> (f32 matrix pipe) + "
+                            "spt::attn_reduce_partials_kernel",
+                "attn_fwd": "spt::mfma::attn_fwd_mfma_kernel<0> (f32 matrix pipe)",
+                "mlp_bwd_pooled": None,        # mode 0 has no pooled backward: dense route
+                "mlp_fwd": "spt::fmlp::fwd_kernel<16, 8> (f32 matrix pipe)"}
+    p = 3 if mode == "f32" else 1
+    lo = "true" if mode == "f32" else "false"
+    return {"attn_bwd": f"spt::el::attn_bwd_prep_kernel + spt::el::attn_bwd_el_kernel<{p}> + "
+                        "spt::el::attn_kv_reduce_kernel + spt::attn_reduce_partials_kernel",
+            "attn_fwd": f"spt::mfma::attn_fwd_mfma_kernel<{p}>",
+            "mlp_bwd_pooled": f"spt::fdma::bwd_dma_kernel<64, 128, 8, 2, {lo}, true>",
+            "mlp_fwd": "spt::fmlp::fwd_kernel<16, 8>" if mode == "f32"
+                       else "spt::fmlp::fwd_kernel_bf<16, 8, false>"}
 
 
 class SPTSegmenter(nn.Module):
@@ -146,9 +169,13 @@ class _NagView:
 class SPTTrainStep:
     name = "SPT-64 (spt-2, S3DIS cfg) fwd + CE loss + bwd + AdamW, incl. per-batch CSR builds"
 
-    def __init__(self, nag, dev, world=1, seed=0, model="spt64"):
+    def __init__(self, nag, dev, world=1, seed=0, model="spt64", kernel_timers=False):
+        """``kernel_timers``: HIP-event timers around the north-star kernel and the ops leading the
+        step (what ``roofline()`` reports) - a measurement aid, off unless asked for (bench.py)."""
         self.nag, self.dev, self.world = _NagView(nag), dev, world
         self.n = nag.num_points
+        self.net_name = model
+        self.workload = None                    # "<scene>/<net>": set by the caller that knows the scene
         torch.manual_seed(seed)
         if model != "spt64":
             self.name = self.name.replace("SPT-64 (spt-2, S3DIS cfg)",
@@ -170,8 +197,10 @@ class SPTTrainStep:
         self.loss_fn = ops.cross_entropy          # CrossEntropyLoss(), mean reduction, on csrc/loss.hip
         n0, c = self.n[0], 128
         self.tname = f"segcsr_reduce_fwd:3:{n0}x{c}"
-        ops.enable_timer(self.tname)
-        self._enable_kernel_timers()
+        self.k_timers = None
+        if kernel_timers:
+            ops.enable_timer(self.tname)
+            self._enable_kernel_timers()
         self.last_loss = None
 
     def _enable_kernel_timers(self):
@@ -213,13 +242,17 @@ class SPTTrainStep:
     def roofline(self, peak_gbs):
         """North-star entry (the L0->L1 segment-CSR max) + `kernels`: the ops leading the step's
         GPU time, each with its SURVEY 8(d) algorithmic bytes / FLOPs per launch and the mean
-        duration measured with HIP events on the launch stream over the timed steps."""
+        duration measured with HIP events on the launch stream over the timed steps.  Kernel
+        names follow the matrix mode that ran; bytes per launch are the op's bytes per step over
+        its launches per step (a batch of B clouds may take B launches); PMC traffic only where
+        a capture of this workload exists (profiles/traffic.json)."""
+        from . import precision
         n0, n1 = self.n[0], self.n[1]
         c = getattr(self, "pool_c", 128)
         bytes_ = n0 * (4 * c + 4) + n1 * (8 * c + 4)
         ms = ops.timer_mean_ms(self.tname)
         ach = bytes_ / (ms * 1e-3) / 1e9 if ms else None
-        traffic = _pmc_traffic(self.tname)
+        traffic = _pmc_traffic("segmax", self.workload)
         roof = {"bound": "hbm",
                 "kernel": "spt::segmax_stream_kernel<true> (L0->L1 segment max + arg, C=%d, the point MLP's "
                           "last GraphNorm + LeakyReLU applied on the fly)" % c
@@ -233,39 +266,41 @@ class SPTTrainStep:
         kernels = []
         if getattr(self, "k_timers", None):
             n1, e1 = self.level1
-            f32_matrix_tf = 157.3                      # MI355X_MICROARCH.md: f32-in MFMA = f32 vector peak
+            names = _kernel_names(precision.get_matrix_precision())
             rows = n0
+            steps = max(self._timed_steps, 1)
+            # bytes / FLOPs of the op PER STEP (all launches of the op in one step together):
+            # backward 264 B/edge + 2 176 B/node, ~37.4 kFLOP/edge (3 GEMMs of the
+            # forward's 12.3 kFLOP + the per-edge math); forward 136 B/edge + 1 156 B/node, 12.6 kFLOP;
+            # fused tall-MLP layers, 64 -> 128 at level 0: forward reads x (4K) writes h (4N) per row;
+            # pooled backward reads h (4N) + x (4K), writes gx (4K) per row, + (gout, arg) per segment
             spec = {
-                # backward 264 B/edge + 2 176 B/node, ~37.4 kFLOP/edge (3 GEMMs of the
-                # forward's 12.3 kFLOP + the per-edge math); forward 136 B/edge + 1 156 B/node, 12.6 kFLOP
-                "attn_bwd": ("spt::el::attn_bwd_el_kernel<3> + spt::el::attn_kv_reduce_kernel + "
-                             "spt::el::attn_bwd_prep_kernel + spt::attn_reduce_partials_kernel (one level-1 "
-                             "attention backward: all kernels of the call)",
-                             264 * e1 + 2176 * n1, 37.4e3 * e1),
-                "attn_fwd": ("spt::mfma::attn_fwd_mfma_kernel<3> (one level-1 attention forward)",
-                             136 * e1 + 1156 * n1, 12.6e3 * e1),
-                # fused tall-MLP layers, 64 -> 128 at level 0: forward reads x (4K) writes h (4N) per row;
-                # pooled backward reads h (4N) + x (4K), writes gx (4K) per row, + (gout, arg) per segment
-                "mlp_bwd_pooled": ("spt::fdma::bwd_dma_kernel<64, 128, 8, 2, true, true> (64 -> 128 "
-                                   "backward of the point MLP's top layer with the L0->L1 pool's backward inside)",
-                                   rows * (4 * 128 + 8 * 64) + n1 * 1024, 2 * 2 * 64 * 128 * rows),
-                "mlp_fwd": ("spt::fmlp::fwd_kernel<16, 8> (64 -> 128 forward)",
-                            rows * 4 * (64 + 128), 2 * 64 * 128 * rows),
+                "attn_bwd": ("one level-1 attention backward: all kernels of the call",
+                             264 * e1 + 2176 * n1, 37.4e3 * e1, True),
+                "attn_fwd": ("one level-1 attention forward", 136 * e1 + 1156 * n1, 12.6e3 * e1, True),
+                "mlp_bwd_pooled": ("64 -> 128 backward of the point MLP's top layer with the L0->L1 "
+                                   "pool's backward inside",
+                                   rows * (4 * 128 + 8 * 64) + n1 * 1024, 2 * 2 * 64 * 128 * rows, False),
+                "mlp_fwd": ("64 -> 128 forward of the point MLP's top layer",
+                            rows * 4 * (64 + 128), 2 * 64 * 128 * rows, False),
             }
-            for key, (kname, kbytes, kflops) in spec.items():
+            for key, (what, kbytes, kflops, per_call) in spec.items():
                 tms = ops.timer_mean_ms(self.k_timers[key])
-                if not tms:
+                if not tms or names.get(key) is None:
                     continue
+                per_step = ops.timer_count(self.k_timers[key]) / steps
+                if not per_call and per_step > 1:
+                    # the layer runs as one launch per cloud: the figures above cover the layer
+                    kbytes, kflops = kbytes / per_step, kflops / per_step
                 gbs = kbytes / (tms * 1e-3) / 1e9
                 tfs = kflops / (tms * 1e-3) / 1e12
-                tr = _pmc_traffic(key)
+                tr = _pmc_traffic(key, self.workload)
                 kernels.append({
-                    "kernel": kname, "ms_per_launch": round(tms, 4),
-                    "launches_per_step": ops.timer_count(self.k_timers[key]) // max(self._timed_steps, 1),
+                    "kernel": f"{names[key]} ({what})", "ms_per_launch": round(tms, 4),
+                    "launches_per_step": round(per_step, 2),
                     "bytes_per_launch": int(kbytes), "achieved": round(gbs, 1), "unit": "GB/s",
                     "frac": round(gbs / peak_gbs, 4),
-                    "flops_per_launch": float(kflops), "achieved_tflops": round(tfs, 2),
-                    "frac_f32_matrix_peak": round(tfs / f32_matrix_tf, 4),
+                    "flops_per_launch": float(kflops), "achieved_tflops_f32_equivalent": round(tfs, 2),
                     "traffic": tr.get("bytes") if tr else None,
                     # what the memory system actually moved per launch (PMC) over the same time:
                     # the kernels of this list gather / scatter rows, their traffic is a multiple
@@ -275,8 +310,14 @@ class SPTTrainStep:
         roof["kernels"] = kernels
         return roof
 
-    def describe(self, scene, sizes):
-        return f"{self.name}; synthetic NAG scene {scene} (N0,N1,N2,E1,E2,clouds)={sizes}"
+    def describe(self, scene, sizes, graph="random"):
+        views = ("level CSR views taken from the NAG's stored `sub` (nag[i+1].sub), edge views sorted per step"
+                 if _csr._USE_SUB_VIEWS and self.nag.levels[1].get("sub") is not None
+                 else "every CSR view rebuilt by the device sort per step (--rebuild-csr: a NAG without `sub`)")
+        kind = {"random": "uniformly random superpoint graph = no locality, the worst case for the "
+                          "attention's k / v gathers (stress case)",
+                "local": "kNN-on-centroids superpoint graph (SURVEY 8d), nodes in storage order"}[graph]
+        return (f"{self.name}; synthetic NAG scene {scene} (N0,N1,N2,E1,E2,clouds)={sizes}; {kind}; {views}")
 
 
 class SPTInferStep(SPTTrainStep):
@@ -284,13 +325,14 @@ class SPTInferStep(SPTTrainStep):
     eval mode, per-batch CSR builds included (src/models/semantic.py forward at test time)."""
     name = "SPT-64 (spt-2) forward only (eval, no_grad), incl. per-batch CSR builds"
 
-    def __init__(self, nag, dev, world=1, seed=0, model="spt64"):
-        super().__init__(nag, dev, world, seed, model)
+    def __init__(self, nag, dev, world=1, seed=0, model="spt64", kernel_timers=False):
+        super().__init__(nag, dev, world, seed, model, kernel_timers=kernel_timers)
         self.name = SPTInferStep.name if model == "spt64" else SPTInferStep.name.replace("SPT-64", "SPT-128")
         self.model.eval()
 
     def step(self):
         self._forget_csr()
+        self._timed_steps += 1
         with torch.no_grad():
             logits = self.model(self.nag)
         self.last_loss = logits[0]
@@ -305,9 +347,10 @@ class SPTPanopticStep(SPTTrainStep):
     name = ("SuperCluster panoptic (spt-2 + edge-affinity head) fwd + CE/BCE loss + bwd + AdamW, "
             "incl. per-batch CSR builds")
 
-    def __init__(self, nag, dev, world=1, seed=0, model="spt64"):
+    def __init__(self, nag, dev, world=1, seed=0, model="spt64", kernel_timers=False):
         self.nag, self.dev, self.world = _NagView(nag), dev, world
         self.n = nag.num_points
+        self.net_name, self.workload, self.k_timers = "spt64-panoptic", None, None
         torch.manual_seed(seed)
         self.model = SPTPanoptic(**panoptic_config(nag[0]["x"].shape[1],
                                                    nag[1]["edge_attr"].shape[1])).to(dev)
@@ -329,11 +372,13 @@ class SPTPanopticStep(SPTTrainStep):
         self.bce = nn.BCEWithLogitsLoss()
         self.pool_c = 64
         self.tname = f"segcsr_reduce_fwd:3:{self.n[0]}x64"
-        ops.enable_timer(self.tname)
+        if kernel_timers:
+            ops.enable_timer(self.tname)
         self.last_loss = None
 
     def step(self):
         self._forget_csr()
+        self._timed_steps += 1
         logits, aff = self.model(self.nag)
         loss = sum(l * self.loss_fn(lg, y) for l, lg, y in zip(self.lambdas, logits, self.labels))
         loss = loss + self.bce(aff, self.affinity)          # edge_affinity_loss_lambda: 1
@@ -346,6 +391,7 @@ class SPTPanopticStep(SPTTrainStep):
 
 class ScatterChain:
     name = "segment-CSR scatter chain (CSR build + max-pool fwd/bwd over L0->L1->L2 + unpool fwd/bwd)"
+    workload, k_timers, _timed_steps = None, None, 0
 
     def __init__(self, nag, dev, world=1):
         self.nag, self.dev, self.world = nag, dev, world
@@ -381,11 +427,11 @@ class ScatterChain:
         return f"{self.name}; scene {scene} {sizes}"
 
 
-def build(nag, dev, world=1, stages="all", mode="train", model="spt64"):
+def build(nag, dev, world=1, stages="all", mode="train", model="spt64", kernel_timers=False):
     if stages == "scatter":
         return ScatterChain(nag, dev, world)
     if mode == "infer":
-        return SPTInferStep(nag, dev, world, model=model)
+        return SPTInferStep(nag, dev, world, model=model, kernel_timers=kernel_timers)
     if mode == "panoptic":
-        return SPTPanopticStep(nag, dev, world, model=model)
-    return SPTTrainStep(nag, dev, world, model=model)
+        return SPTPanopticStep(nag, dev, world, model=model, kernel_timers=kernel_timers)
+    return SPTTrainStep(nag, dev, world, model=model, kernel_timers=kernel_timers)

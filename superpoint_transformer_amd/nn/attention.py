@@ -101,16 +101,40 @@ class SelfAttentionBlock(nn.Module):
             b = None if b is None else b.repeat(self.num_heads)
         return w, b
 
+    def _composed(self):
+        return (self.k_delta_rpe is not None or self.q_delta_rpe is not None
+                or (self.attn_drop is not None and self.training))
+
+    def forward_prenorm_residual(self, x, norm, norm_index, num_graphs, edge_index,
+                                 edge_attr=None, ea_grad=None):
+        """``x + self(norm(x), ...)`` - the pre-norm self-attention branch of a TransformerBlock
+        (src/nn/transformer.py:231-234) - with the GraphNorm applied inside the qkv Linear's read of
+        x and the residual added in the out_proj Linear's epilogue (``ops.norm_linear`` /
+        ``ops.linear_residual``: bitwise the unfused values, one apply pass and two elementwise adds
+        fewer per block).  Returns None when the fused route does not apply (the caller then runs
+        norm, block and add one after the other)."""
+        if (self.in_proj is not None or self.out_proj is None or self._composed()
+                or (self.out_drop is not None and self.training)
+                or getattr(norm, "generic", False)
+                or not ops.norm_linear_ok(x, norm_index, num_graphs, self.qkv.weight)
+                or not ops.linear_residual_ok(x, self.out_proj.weight)):
+            return None
+        qkv, x_res = ops.norm_linear(x, norm_index, num_graphs, norm.weight, norm.bias,
+                                     norm.mean_scale, norm.eps, self.qkv.weight, self.qkv.bias)
+        return self._attend(qkv, edge_index, edge_attr, ea_grad, residual=x_res)
+
     def forward(self, x, edge_index, edge_attr=None, ea_grad=None):
         """x [N, Cx]; edge_index [2, E] (row 0 = querying source, row 1 = key
         target; any order) or an ``EdgeCSR``; edge_attr [E, in_rpe_dim]; ``ea_grad``: the
         stage's shared edge_attr gradient buffer (``ops.EdgeAttrGradShare``) or None."""
         if self.in_proj is not None:
             x = ops.linear(x, self.in_proj.weight, self.in_proj.bias)
-        if (self.k_delta_rpe is not None or self.q_delta_rpe is not None
-                or (self.attn_drop is not None and self.training)):
+        if self._composed():
             return self._forward_composed(x, edge_index, edge_attr)
         qkv = ops.linear(x, self.qkv.weight, self.qkv.bias)
+        return self._attend(qkv, edge_index, edge_attr, ea_grad)
+
+    def _attend(self, qkv, edge_index, edge_attr, ea_grad, residual=None):
         k_rpe = q_rpe = v_rpe = None
         if edge_attr is not None:
             k_rpe = self._expand(self.k_rpe)
@@ -124,6 +148,8 @@ class SelfAttentionBlock(nn.Module):
             k_rpe=k_rpe, q_rpe=q_rpe, v_rpe=v_rpe, num_heads=self.num_heads,
             qk_dim=self.qk_dim, scale_mode=self.scale_mode, scale_a=self.scale_a,
             ea_grad=ea_grad)
+        if residual is not None:                  # forward_prenorm_residual: out_proj exists
+            return ops.linear_residual(x, self.out_proj.weight, self.out_proj.bias, residual)
         if self.out_proj is not None:
             x = ops.linear(x, self.out_proj.weight, self.out_proj.bias)
         if self.out_drop is not None:

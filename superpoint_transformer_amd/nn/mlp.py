@@ -1,5 +1,7 @@
-"""MLP / FFN / Classifier (src/nn/mlp.py).  Linear layers stay on rocBLAS via
-PyTorch; every ``GraphNorm -> LeakyReLU`` pair runs as ONE fused HIP pass."""
+"""MLP / FFN / Classifier (src/nn/mlp.py).  Tall ``Linear -> GraphNorm -> LeakyReLU`` stacks
+run as one fused HIP kernel per layer and direction (``ops.fused_mlp``); other Linears go through
+``ops.linear`` (the skinny-GEMM kernels where the shape is built, the library below 4 096 rows
+or for unbuilt shapes); a lone ``GraphNorm -> LeakyReLU`` pair is one fused pass."""
 from torch import nn
 
 from .. import ops
@@ -106,6 +108,21 @@ class FFN(MLP):
         out_dim = out_dim or dim
         super().__init__([dim, hidden_dim, out_dim], activation=activation,
                          last_activation=False, norm=None, last_norm=False, drop=drop)
+
+    def forward_prenorm_residual(self, x, norm, norm_index, num_graphs):
+        """``x + self(norm(x))`` (the FFN branch of a pre-norm TransformerBlock,
+        src/nn/transformer.py:246-249) with the GraphNorm applied inside the first Linear's read
+        of x and the residual added in the second Linear's epilogue; None when the fused route
+        does not apply."""
+        mods = list(self.mlp)
+        if not (len(mods) == 3 and isinstance(mods[0], nn.Linear) and isinstance(mods[2], nn.Linear)
+                and not getattr(norm, "generic", False)
+                and ops.norm_linear_ok(x, norm_index, num_graphs, mods[0].weight)
+                and ops.linear_residual_ok(x, mods[2].weight)):
+            return None
+        h, x_res = ops.norm_linear(x, norm_index, num_graphs, norm.weight, norm.bias,
+                                   norm.mean_scale, norm.eps, mods[0].weight, mods[0].bias)
+        return ops.linear_residual(mods[1](h), mods[2].weight, mods[2].bias, x_res)
 
 
 class Classifier(nn.Module):

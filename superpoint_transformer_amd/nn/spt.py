@@ -12,6 +12,7 @@ path and raises."""
 import torch
 from torch import nn
 
+from ..csr import adopt_csr
 from .fusion import CatFusion
 from .mlp import MLP
 from .norm import GraphNorm
@@ -75,6 +76,22 @@ def _get(data, key, default=None):
     if isinstance(data, dict):
         return data.get(key, default)
     return getattr(data, key, default)
+
+
+def _adopt_sub_views(levels):
+    """A NAG level stores its partition twice: ``super_index`` on the children and the same
+    clusters as a CSR on the parents (``nag[i+1].sub``, src/data/cluster.py:19-77).  Hand the
+    stored CSR to the segment kernels as the view of ``super_index`` (the pool, UnitSphereNorm,
+    the unpool's backward all group by it) instead of sorting the index again every batch."""
+    for lo, hi in zip(levels[:-1], levels[1:]):
+        si, sub = _get(lo, "super_index"), _get(hi, "sub")
+        if si is None or sub is None or not torch.is_tensor(si) or not si.is_cuda:
+            continue
+        pointers, points = getattr(sub, "pointers", None), getattr(sub, "points", None)
+        if pointers is None or points is None or points.device != si.device:
+            continue
+        if getattr(sub, "ascending", False):
+            adopt_csr(si, pointers.numel() - 1, pointers, points)
 
 
 class SPT(nn.Module):
@@ -230,6 +247,7 @@ class SPT(nn.Module):
             return self._forward_nano(nag, B)
         levels = [nag[i] for i in range(self.num_down_stages + 1)]
         sizes = [_get(lv, "pos").shape[0] for lv in levels]
+        _adopt_sub_views(levels)
 
         def norm_index(lv):                                  # Data.norm_index(mode), data.py:103-130
             batch = _get(lv, "batch")
@@ -330,6 +348,7 @@ class SPT(nn.Module):
         nd = self.num_down_stages
         levels = {i: nag[i] for i in range(1, nd + 2)}
         sizes = {i: _get(lv, "pos").shape[0] for i, lv in levels.items()}
+        _adopt_sub_views([levels[i] for i in range(1, nd + 2)])
         top = nd + 1
 
         def hf(i_level, k):

@@ -65,9 +65,18 @@ class TransformerBlock(nn.Module):
         if self.no_sa or not has_edges:
             pass
         elif self.pre_norm:
-            x = self._forward_norm(self.sa_norm, x, norm_index, num_graphs)
-            x = self.sa(x, edge_index, edge_attr=edge_attr, ea_grad=ea_grad)
-            x = shortcut + self.drop_path(x)
+            out = None
+            if isinstance(self.sa_norm, GraphNorm) and (
+                    isinstance(self.drop_path, nn.Identity) or not self.training):
+                # norm inside the qkv Linear's read, residual in the out_proj Linear's epilogue
+                out = self.sa.forward_prenorm_residual(x, self.sa_norm, norm_index, num_graphs,
+                                                       edge_index, edge_attr=edge_attr,
+                                                       ea_grad=ea_grad)
+            if out is None:
+                x = self._forward_norm(self.sa_norm, x, norm_index, num_graphs)
+                x = self.sa(x, edge_index, edge_attr=edge_attr, ea_grad=ea_grad)
+                out = shortcut + self.drop_path(x)
+            x = out
         else:
             x = self.sa(x, edge_index, edge_attr=edge_attr, ea_grad=ea_grad)
             x = self.drop_path(x)
@@ -78,9 +87,15 @@ class TransformerBlock(nn.Module):
             shortcut = x
 
         if not self.no_ffn and self.pre_norm:
-            x = self._forward_norm(self.ffn_norm, x, norm_index, num_graphs)
-            x = self.ffn(x)
-            x = shortcut + self.drop_path(x)
+            out = None
+            if isinstance(self.ffn_norm, GraphNorm) and (
+                    isinstance(self.drop_path, nn.Identity) or not self.training):
+                out = self.ffn.forward_prenorm_residual(x, self.ffn_norm, norm_index, num_graphs)
+            if out is None:
+                x = self._forward_norm(self.ffn_norm, x, norm_index, num_graphs)
+                x = self.ffn(x)
+                out = shortcut + self.drop_path(x)
+            x = out
         if not self.no_ffn and not self.pre_norm:
             x = self.ffn(x)
             x = self.drop_path(x)

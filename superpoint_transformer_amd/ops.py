@@ -17,6 +17,7 @@ _OPS = {"sum": 0, "add": 0, "mean": 1, "min": 2, "max": 3}
 # of (start, end) events recorded on the stream the kernel is launched on.
 _TIMERS = {}
 _TIMER_PREFIXES = []
+_TIMER_CAP = 8192            # event pairs kept per timer (timers are opt-in measurement aids)
 
 
 def enable_timer(name, prefix=False):
@@ -57,11 +58,14 @@ class _timed:
         if self.rec is not None:
             self.a = torch.cuda.Event(enable_timing=True)
             self.a.record()
+        return self
 
     def __exit__(self, *exc):
         if self.rec is not None:
             b = torch.cuda.Event(enable_timing=True)
             b.record()
+            if len(self.rec) >= _TIMER_CAP:      # a loop longer than a benchmark: keep the newest
+                del self.rec[:_TIMER_CAP // 2]
             self.rec.append((self.a, b))
 
 
@@ -548,10 +552,16 @@ class _EdgeAttention(torch.autograd.Function):
         else:
             gea = torch.empty_like(ea) if ea is not None else None
         gps = [torch.empty_like(t) if t is not None else None for t in ps]
-        nb = _lib.lib.spt_edge_attn_bwd_ex_workspace_bytes(n, ecsr.e, H, D, Dv, max(F, 1))
+        # the edge-lane formulation needs 512 B per edge + ~390 B per node of scratch on top of the
+        # weight-gradient tables: asked for only when that formulation will run (the scratch
+        # buffer is grow-only per device and stream)
+        el = bool(ea is not None and ecsr.e > 0
+                  and _lib.lib.spt_edge_attn_bwd_el_supported(H, D, Dv, F, ctx.mode))
+        nb = (_lib.lib.spt_edge_attn_bwd_ex_workspace_bytes(n, ecsr.e, H, D, Dv, max(F, 1)) if el
+              else _lib.lib.spt_edge_attn_bwd_workspace_bytes(H, D, Dv, max(F, 1)))
         ws = _workspace(nb, dev)
         src = tids = tperm = trowptr = None
-        if ea is not None and ecsr.e > 0 and _lib.lib.spt_edge_attn_bwd_el_supported(H, D, Dv, F, ctx.mode):
+        if el:
             src = ecsr.src_sorted()
             tids = ecsr.tile_ids()
             tv = ecsr.target_view()
@@ -709,10 +719,12 @@ class _EdgeAttentionSplit(torch.autograd.Function):
         gbk = torch.empty((P, 64), dtype=torch.float32, device=dev) if bk2 is not None else None
         gbq = torch.empty((P, 64), dtype=torch.float32, device=dev) if bq2 is not None else None
         gbv = torch.empty((P, 64), dtype=torch.float32, device=dev) if bva is not None else None
-        nb = _lib.lib.spt_edge_attn_bwd_ex_workspace_bytes(n, ecsr.e, 16, 4, 4, F)
+        el = bool(ecsr.e > 0 and _lib.lib.spt_edge_attn_bwd_el_supported(16, 4, 4, F, ctx.mode))
+        nb = (_lib.lib.spt_edge_attn_bwd_ex_workspace_bytes(n, ecsr.e, 16, 4, 4, F) if el
+              else _lib.lib.spt_edge_attn_bwd_workspace_bytes(16, 4, 4, F))
         ws = _workspace(nb, dev)
         src = tids = tperm = trowptr = None
-        if ecsr.e > 0 and _lib.lib.spt_edge_attn_bwd_el_supported(16, 4, 4, F, ctx.mode):
+        if el:
             src, tids, tv = ecsr.src_sorted(), ecsr.tile_ids(), ecsr.target_view()
             tperm, trowptr = tv.perm, tv.rowptr
         with torch.cuda.device(dev):
@@ -920,6 +932,164 @@ def linear(x, weight, bias=None):
     if x.dim() != 2 or not x.is_cuda or x.shape[0] < _SKINNY_MIN_ROWS:
         return torch.nn.functional.linear(x, weight, bias)
     return _TallLinear.apply(x, weight, bias)
+
+
+class _ResidualLinear(torch.autograd.Function):
+    """y = residual + (x W^T + b): a transformer block's `shortcut + out_proj(.)`
+    (src/nn/transformer.py:231-234, src/nn/attention.py:318-319) with the add in the skinny
+    kernel's epilogue (bitwise `residual + linear(x)`).  The residual's gradient is the incoming
+    gradient itself."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        xd, wd = x.detach().contiguous(), weight.detach().contiguous()
+        rows, k = xd.shape
+        n = wd.shape[0]
+        y = torch.empty((rows, n), dtype=torch.float32, device=xd.device)
+        with torch.cuda.device(xd.device):
+            st = _lib.lib.spt_skinny_linear_pre_f32(
+                _lib.ptr(xd), rows, k, _lib.ptr(wd),
+                _lib.ptr(None if bias is None else bias.detach().contiguous()), n, _lib.ptr(y),
+                None, None, None, None, 1, _lib.ptr(residual.detach().contiguous()),
+                _lib.stream_ptr(xd.device))
+        _lib.check(st, "spt_skinny_linear_pre_f32")
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        gx, gw, gb = _TallLinear.backward(ctx, g)
+        return gx, gw, gb, g
+
+
+_FUSE_PRENORM = os.environ.get("SPT_FUSE_PRENORM", "1") != "0"
+
+
+def fuse_prenorm(on=None):
+    """Switch of the folded pre-norm / residual route of the transformer blocks (default on;
+    ``SPT_FUSE_PRENORM=0`` in the environment turns it off).  Returns the previous setting."""
+    global _FUSE_PRENORM
+    prev = _FUSE_PRENORM
+    if on is not None:
+        _FUSE_PRENORM = bool(on)
+    return prev
+
+
+def linear_residual_ok(residual, weight):
+    """Whether ``linear_residual`` runs fused for a Linear with this weight whose output is
+    added to ``residual`` [rows, N]: tall f32 rows, (K, N) built."""
+    return bool(_FUSE_PRENORM and residual.dim() == 2 and residual.is_cuda
+                and residual.dtype == torch.float32 and weight.dtype == torch.float32
+                and residual.shape[0] >= _SKINNY_MIN_ROWS and residual.shape[1] == weight.shape[0]
+                and _lib.lib.spt_skinny_pre_supported(weight.shape[1], weight.shape[0], 1))
+
+
+def linear_residual(x, weight, bias, residual):
+    """``residual + F.linear(x, weight, bias)`` with the add folded into the Linear's kernel where
+    the shape is built (tall f32 operands, K in {32, 64, 128}, N a multiple of 64)."""
+    if (x.dim() == 2 and x.dtype == torch.float32 and x.shape[0] == residual.shape[0]
+            and linear_residual_ok(residual, weight)):
+        return _ResidualLinear.apply(x, weight, bias, residual)
+    return residual + linear(x, weight, bias)
+
+
+class _NormLinear(torch.autograd.Function):
+    """qkv = Linear(GraphNorm(x)) with the norm applied INSIDE the Linear's read of x
+    (`spt_graphnorm_stats_f32` + `spt_skinny_linear_pre_f32`): the pre-norm of a transformer block
+    (src/nn/transformer.py:231-234) without the normalised [rows, C] tensor ever being written.
+    Returns ``(y, x_res)``: ``x_res`` is x itself, handed back so that the block's residual
+    branch hangs on THIS node - the backward then receives both gradients of x and the norm's
+    backward kernel adds them in its own pass (`spt_graphnorm_bwd_acc_f32`), instead of autograd
+    summing two [rows, C] tensors with one more launch.  Values are bitwise those of
+    ``linear(graph_norm(x))``."""
+
+    @staticmethod
+    def forward(ctx, x, batch, num_graphs, gn_w, gn_b, gn_a, eps, weight, bias):
+        _lib.require_cuda(x)
+        xd = x.detach().contiguous()
+        rows, d = xd.shape
+        dev = xd.device
+        B = int(num_graphs)
+        if batch is not None:
+            batch = batch.contiguous()
+            if batch.dtype != torch.int64:
+                batch = batch.long()
+        w, b, a = (t.detach().float().contiguous() for t in (gn_w, gn_b, gn_a))
+        wd = weight.detach().contiguous()
+        bd = None if bias is None else bias.detach().contiguous()
+        n = wd.shape[0]
+        mean, rstd, am, sc = (torch.empty((B, d), dtype=torch.float32, device=dev) for _ in range(4))
+        y = torch.empty((rows, n), dtype=torch.float32, device=dev)
+        nb = _lib.lib.spt_graphnorm_workspace_bytes(rows, d, B)
+        ws = _workspace(nb, dev)
+        with torch.cuda.device(dev):
+            st = _lib.lib.spt_graphnorm_stats_f32(
+                _lib.ptr(xd), _lib.ptr(batch), rows, d, B, _lib.ptr(w), _lib.ptr(a), float(eps),
+                _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(am), _lib.ptr(sc), _lib.ptr(ws),
+                ws.numel(), _lib.stream_ptr(dev))
+            _lib.check(st, "spt_graphnorm_stats_f32")
+            st = _lib.lib.spt_skinny_linear_pre_f32(
+                _lib.ptr(xd), rows, d, _lib.ptr(wd), _lib.ptr(bd), n, _lib.ptr(y), _lib.ptr(am),
+                _lib.ptr(sc), _lib.ptr(b), _lib.ptr(batch), B, None, _lib.stream_ptr(dev))
+        _lib.check(st, "spt_skinny_linear_pre_f32")
+        ctx.save_for_backward(xd, batch, w, b, a, mean, rstd, am, sc, wd)
+        ctx.meta = (B, bias is not None)
+        return y, x
+
+    @staticmethod
+    def backward(ctx, gy, gres):
+        xd, batch, w, b, a, mean, rstd, am, sc, wd = ctx.saved_tensors
+        B, has_bias = ctx.meta
+        rows, d = xd.shape
+        n = wd.shape[0]
+        dev = xd.device
+        gy = gy.contiguous()
+        # gradient wrt the normalised rows: dX of the Linear
+        wt = wd.t().contiguous()
+        gxn = _skinny_launch(gy, wt, None) if _skinny_ok(gy, wt) else gy @ wd
+        # weight / bias gradient against the rows normalised on the fly
+        gw = torch.empty((n, d), dtype=torch.float32, device=dev)
+        gb = torch.empty(n, dtype=torch.float32, device=dev) if has_bias else None
+        ws = _workspace(_lib.lib.spt_skinny_dw_workspace_bytes(d, n), dev)
+        with torch.cuda.device(dev):
+            st = _lib.lib.spt_skinny_dw_pre_f32(
+                _lib.ptr(gy), _lib.ptr(xd), rows, n, d, _lib.ptr(gw), _lib.ptr(gb), _lib.ptr(am),
+                _lib.ptr(sc), _lib.ptr(b), _lib.ptr(batch), B, _lib.ptr(ws), ws.numel(),
+                _lib.stream_ptr(dev))
+        _lib.check(st, "spt_skinny_dw_pre_f32")
+        # the norm's backward, with the residual branch's gradient added in its apply pass
+        gx = torch.empty_like(xd)
+        g_w, g_b, g_a = (torch.empty(d, dtype=torch.float32, device=dev) for _ in range(3))
+        if gres is not None:
+            gres = gres.contiguous()
+        ws = _workspace(_lib.lib.spt_graphnorm_workspace_bytes(rows, d, B), dev)
+        with torch.cuda.device(dev):
+            st = _lib.lib.spt_graphnorm_bwd_acc_f32(
+                _lib.ptr(xd), _lib.ptr(gxn), _lib.ptr(batch), rows, d, B, _lib.ptr(w), _lib.ptr(b),
+                _lib.ptr(a), _lib.ptr(mean), _lib.ptr(rstd), 1.0, _lib.ptr(gres), _lib.ptr(gx),
+                _lib.ptr(g_w), _lib.ptr(g_b), _lib.ptr(g_a), _lib.ptr(ws), ws.numel(),
+                _lib.stream_ptr(dev))
+        _lib.check(st, "spt_graphnorm_bwd_acc_f32")
+        return gx, None, None, g_w, g_b, g_a, None, gw, gb
+
+
+def norm_linear_ok(x, batch, num_graphs, weight):
+    """Whether ``norm_linear`` runs fused: tall f32 rows, a built (K, N), few graphs."""
+    if not _FUSE_PRENORM or (batch is not None and num_graphs is None):
+        return False
+    B = 1 if batch is None else int(num_graphs)
+    return bool(x.dim() == 2 and x.is_cuda and x.dtype == torch.float32
+                and weight.dtype == torch.float32 and x.shape[0] >= _SKINNY_MIN_ROWS
+                and _lib.lib.spt_skinny_pre_supported(x.shape[1], weight.shape[0], B)
+                and _lib.lib.spt_skinny_dw_supported(x.shape[1], weight.shape[0]))
+
+
+def norm_linear(x, batch, num_graphs, gn_weight, gn_bias, gn_mean_scale, eps, weight, bias):
+    """``(linear(graph_norm(x, batch), weight, bias), x_res)`` - see ``_NormLinear``.  Callers
+    check ``norm_linear_ok`` first."""
+    B = 1 if batch is None else int(num_graphs)
+    return _NormLinear.apply(x, batch, B, gn_weight, gn_bias, gn_mean_scale, float(eps), weight, bias)
 
 
 # ---------------------------------------------------------------------------

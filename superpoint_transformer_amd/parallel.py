@@ -4,9 +4,11 @@ step.
 The reference trains with Lightning DDP (configs/trainer/ddp.yaml): each rank
 loads different clouds, one gradient all-reduce per step.  The whole SPT-64
 gradient is ~0.85 MB, so on an xGMI mesh the exchange is latency-bound: instead
-of DDP's bucketing / hook machinery, all parameter gradients live as VIEWS of
-one flat buffer and a single ``all_reduce`` (RCCL on GPUs - backend "nccl" -,
-gloo in the CPU tests) runs after backward."""
+of DDP's bucketing / hook machinery, autograd writes plain per-parameter
+gradients, ONE multi-tensor copy packs them into a flat buffer when a
+collective is due, and a single ``all_reduce`` (RCCL on GPUs - backend "nccl" -,
+gloo in the CPU tests) runs after backward; ``p.grad`` aliases the flat buffer
+from then on.  With one rank nothing is packed or sent."""
 import torch
 import torch.distributed as dist
 
@@ -92,11 +94,34 @@ class FlatGradAllReduce:
         return self.flat
 
     def reduce(self):
+        """Average the gradients over the ranks.  Returns the flat buffer when it holds them
+        (a collective ran, or ``pack()`` was called since the last ``zero()``), else ``None``:
+        in a one-rank group nothing is packed, ``p.grad`` are the per-parameter tensors autograd
+        wrote and ``flat`` is NOT valid - call ``pack()`` first to read the gradients flat
+        (norm logging, clipping on one buffer)."""
         if self.world > 1 or (self.always and dist.is_initialized()):
             self.pack()
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
             self.flat.div_(self.world)
-        return self.flat
+        return self.flat if self._packed else None
+
+    def time_allreduce_us(self, reps=20):
+        """Median wall time (microseconds) of the step's one collective on the flat buffer as it
+        is (a measurement helper for the bench line; the buffer's contents are averaged ``reps``
+        times, so call it after the timed region).  ``None`` without a process group."""
+        if not dist.is_initialized():
+            return None
+        import time
+        sync = torch.cuda.synchronize if self.flat.is_cuda else (lambda: None)
+        times = []
+        for _ in range(reps + 3):
+            sync()
+            t0 = time.perf_counter()
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+            sync()
+            times.append((time.perf_counter() - t0) * 1e6)
+        times = sorted(times[3:])
+        return times[len(times) // 2]
 
     def check_views(self):
         """True when every ``p.grad`` still aliases the flat buffer."""

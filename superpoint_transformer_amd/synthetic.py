@@ -3,10 +3,12 @@
 Recipe of SURVEY.md section 8(d), with the ratios measured on the reference's
 demo room (notebooks/demo_nag_v3.h5): |P0|/|P1| = 34.87, |P1|/|P2| = 2.38;
 level-0 -> level-1 segment sizes ~ clip(round(LogNormal(3.04, 1.0)), 1, 300);
-upper levels 1 + Geometric; directed+self-loop degree ~ N(16.4, 5.8) at level
-1 and N(30, 9) at level 2.  Level-0 rows are SHUFFLED so that ``super_index``
+upper levels 1 + Geometric; mean directed+self-loop degree 16.4 at level 1 and
+29.9 at level 2.  Level-0 rows are SHUFFLED so that ``super_index``
 is unsorted like the reference's (12 705 runs for 1 192 segments in the demo
 room), and edge targets are non-local (median |s-t| ~ 0.23 N in the demo).
+Default superpoint graph: uniformly random endpoints (``graph="random"``: a stress
+case); ``graph="local"`` builds it by kNN on the segment centroids.
 
 Everything is generated with torch on the requested device from one seed, so
 every rank / run sees the same scene for the same (seed, sizes).
@@ -60,10 +62,11 @@ def _super_index(gen, n_child, n_parent, kind, device, shuffle):
     return idx
 
 
-def _edges(gen, n, e_target, deg_mean, deg_std, device):
+def _edges(gen, n, e_target, device):
     """[2,E] directed edges incl. both directions and self loops, in the
     reference's final layout [i<j | j>i | loops] (transforms/graph.py:1268,
-    :1442-1446): row 0 (source = softmax group) is unsorted."""
+    :1442-1446): row 0 (source = softmax group) is unsorted.  Endpoints are drawn
+    UNIFORMLY (Poisson-like degrees around E / n, no spatial locality): the stress case."""
     m = max((e_target - n) // 2, 0)
     a = torch.randint(0, n, (m,), generator=gen, device=device)
     b = torch.randint(0, n, (m,), generator=gen, device=device)
@@ -74,6 +77,58 @@ def _edges(gen, n, e_target, deg_mean, deg_std, device):
     s = torch.cat([lo, hi, loops])
     t = torch.cat([hi, lo, loops])
     return torch.stack([s, t])
+
+
+def _knn_indices(pos, k):
+    """[n, k] indices of the k nearest other points (-1 padded): the HIP grid kNN on the GPU,
+    scipy's k-d tree for the CPU-baseline samples."""
+    if pos.is_cuda:
+        from .neighbors import knn_1
+        r = 4.0 * (pos.max(0).values - pos.min(0).values).max().item() * (k / max(pos.shape[0], 1)) ** (1 / 3)
+        nb, _ = knn_1(pos.contiguous(), k, max(r, 1e-3))
+        return nb
+    from scipy.spatial import cKDTree
+    import numpy as np
+    kk = min(k + 1, pos.shape[0])
+    _, idx = cKDTree(pos.numpy()).query(pos.numpy(), k=kk)
+    idx = np.asarray(idx).reshape(pos.shape[0], kk)[:, 1:]
+    out = torch.full((pos.shape[0], k), -1, dtype=torch.long)
+    out[:, :idx.shape[1]] = torch.from_numpy(idx.astype(np.int64))
+    return out
+
+
+def _edges_local(gen, pos, e_target, device):
+    """The superpoint graph of SURVEY 8(d): undirected edges between spatially nearest segment
+    centroids (every node proposes its k nearest, mutual proposals merge, a random subset hits
+    the edge budget), then the reference's final layout [i<j | j>i | loops] like ``_edges``."""
+    n = pos.shape[0]
+    m = max((e_target - n) // 2, 0)
+    k = max(1, min(45, int(math.ceil(1.6 * m / max(n, 1)))))
+    nb = _knn_indices(pos, k).to(device)
+    a = torch.arange(n, device=device).repeat_interleave(k)
+    b = nb.reshape(-1)
+    keep = (b >= 0) & (a != b)
+    a, b = a[keep], b[keep]
+    key = torch.unique(torch.minimum(a, b) * n + torch.maximum(a, b))
+    if key.numel() > m:
+        key = key[torch.randperm(key.numel(), generator=gen, device=device)[:m]]
+    lo, hi = key // n, key % n
+    loops = torch.arange(n, device=device)
+    return torch.stack([torch.cat([lo, hi, loops]), torch.cat([hi, lo, loops])])
+
+
+def _morton_order(pos):
+    """argsort of the 30-bit Morton code of ``pos`` (10 bits per axis)."""
+    lo, hi = pos.min(0).values, pos.max(0).values
+    q = ((pos - lo) / (hi - lo).clamp_min(1e-9) * 1023.0).long().clamp_(0, 1023)
+
+    def spread(v):
+        v = (v | (v << 16)) & 0x030000FF
+        v = (v | (v << 8)) & 0x0300F00F
+        v = (v | (v << 4)) & 0x030C30C3
+        return (v | (v << 2)) & 0x09249249
+
+    return torch.argsort(spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2), stable=True)
 
 
 class SyntheticNAG:
@@ -94,10 +149,18 @@ class SyntheticNAG:
 
 
 def make_nag(scene="S", seed=1234, device="cpu", sizes=None, point_dim=8,
-             edge_dim=18, scale=1.0, segment_dim=0):
+             edge_dim=18, scale=1.0, segment_dim=0, graph="random", order="storage"):
     """Build a 3-level synthetic NAG. ``scale`` < 1 shrinks every size
     proportionally (CPU-baseline samples).  ``segment_dim=0``: levels >= 1 carry
-    no handcrafted node features, like the S3DIS config (``segment_hf: []``)."""
+    no handcrafted node features, like the S3DIS config (``segment_hf: []``).
+
+    ``graph``: "random" (default) - edge endpoints drawn uniformly: no locality at all, the
+    worst case for everything that gathers rows by edge target (a stress case; degrees come out
+    Poisson-like around the mean, not the clipped normal of the demo room); "local" - the
+    kNN-on-centroids generator of SURVEY 8(d) (``_edges_local``).  ``order``: "storage"
+    (default) keeps the nodes of levels 1 and 2 in their shuffled order - spatial neighbours
+    are then far apart in memory, like the demo room (median |s - t| ~ 0.23 N); "morton" stores
+    them along a Morton curve (what a spatially sorted dataset would hand over)."""
     n0, n1, n2, e1, e2, b = sizes if sizes is not None else SCENES[scene]
     if scale != 1.0:
         n0, n1, n2 = (max(int(v * scale), 8) for v in (n0, n1, n2))
@@ -126,17 +189,47 @@ def make_nag(scene="S", seed=1234, device="cpu", sizes=None, point_dim=8,
     pos2 = torch.rand(n2, 3, generator=gen, device=device) * 40.0
     pos1 = pos2[si1] + rnd(n1, 3, s=1.5)
     pos0 = pos1[si0] + rnd(n0, 3, s=0.3)
+    if order == "morton":
+        # relabel levels 2 and 1 along a Morton curve (clouds stay contiguous: the cloud id is the
+        # primary key); children keep pointing at the same parents under the new numbering
+        def relabel(pos_l, b_l):
+            o = _morton_order(pos_l)
+            o = o[torch.argsort(b_l[o], stable=True)]
+            inv = torch.empty_like(o)
+            inv[o] = torch.arange(o.numel(), device=device)
+            return o, inv
+        o2, inv2 = relabel(pos2, b2)
+        pos2, b2, si1 = pos2[o2], b2[o2], inv2[si1]
+        o1, inv1_ = relabel(pos1, b1)
+        pos1, b1, si1, si0 = pos1[o1], b1[o1], si1[o1], inv1_[si0]
+    elif order != "storage":
+        raise ValueError("order must be 'storage' or 'morton'")
     ns1 = torch.bincount(si0, minlength=n1)
     ns2 = torch.zeros(n2, dtype=torch.long, device=device).index_add_(0, si1, ns1)
-    ei1 = _edges(gen, n1, e1, 16.4, 5.8, device)
-    ei2 = _edges(gen, n2, e2, 30.0, 9.0, device)
+    if graph == "local":
+        ei1 = _edges_local(gen, pos1, e1, device)
+        ei2 = _edges_local(gen, pos2, e2, device)
+    elif graph == "random":
+        ei1 = _edges(gen, n1, e1, device)
+        ei2 = _edges(gen, n2, e2, device)
+    else:
+        raise ValueError("graph must be 'random' or 'local'")
+
+    def sub_of(si, n_parent):
+        """The level's cluster CSR as a stored NAG carries it next to ``super_index``
+        (``nag[i+1].sub``, src/data/cluster.py:19-77): children of every cluster ascending."""
+        from .data import Cluster
+        ptr = torch.zeros(n_parent + 1, dtype=torch.long, device=device)
+        ptr[1:] = torch.cumsum(torch.bincount(si, minlength=n_parent), 0)
+        return Cluster(ptr, torch.argsort(si, stable=True), ascending=True)
+
     levels = [
         dict(pos=pos0, x=torch.rand(n0, point_dim, generator=gen, device=device),
              super_index=si0, batch=b0),
         dict(pos=pos1, x=rnd(n1, segment_dim) if segment_dim else None, super_index=si1, batch=b1, node_size=ns1,
-             edge_index=ei1, edge_attr=rnd(ei1.shape[1], edge_dim, s=0.3)),
+             edge_index=ei1, edge_attr=rnd(ei1.shape[1], edge_dim, s=0.3), sub=sub_of(si0, n1)),
         dict(pos=pos2, x=rnd(n2, segment_dim) if segment_dim else None, super_index=None, batch=b2, node_size=ns2,
-             edge_index=ei2, edge_attr=rnd(ei2.shape[1], edge_dim, s=0.3)),
+             edge_index=ei2, edge_attr=rnd(ei2.shape[1], edge_dim, s=0.3), sub=sub_of(si1, n2)),
     ]
     return SyntheticNAG(levels, b)
 
@@ -214,7 +307,7 @@ def make_raw_nag(scene="R", seed=1234, device="cpu", sizes=None, point_dim=8):
                  log_surface=torch.rand(n, 1, generator=gen, device=device),
                  log_volume=torch.rand(n, 1, generator=gen, device=device),
                  log_size=torch.rand(n, 1, generator=gen, device=device),
-                 sub=Cluster(sub_index, torch.arange(sub_n, device=device), dense=True),
+                 sub=Cluster(sub_index, torch.arange(sub_n, device=device), dense=True, ascending=True),
                  edge_index=ei, edge_attr=rnd(ei.shape[1], 7, s=0.3))
         if si is not None:
             d.super_index = si

@@ -71,10 +71,12 @@ def test_single_process_is_a_no_op():
     bucket = parallel.FlatGradAllReduce(model.parameters())
     bucket.zero()
     model(torch.ones(3, 4)).sum().backward()
-    assert torch.equal(bucket.reduce(), torch.zeros(10)) and not bucket.check_views()   # untouched
+    # one rank: nothing is packed, reduce() says so instead of handing out a stale buffer
+    assert bucket.reduce() is None and not bucket.check_views()
     before = bucket.pack().clone()
     assert torch.equal(before[:8], torch.full((8,), 3.0)) and bucket.check_views()
-    assert torch.equal(bucket.reduce(), before)
+    assert torch.equal(before, torch.cat([p.grad.reshape(-1) for p in model.parameters()]))
+    assert torch.equal(bucket.reduce(), before)                 # packed: the flat gradients
     assert parallel.shard_items(5, 0, 1) == [0, 1, 2, 3, 4]
 
 

@@ -1,0 +1,82 @@
+"""Level CSR views taken from the NAG's stored ``sub`` (src/data/cluster.py:19-77) instead of
+the per-batch device sort: the adopted view must be THE arrays the sort produces (bit-exact
+perm / rowptr), and a model step on adopted views bitwise the step on sorted ones."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _nag(dev, **kw):
+    from superpoint_transformer_amd.synthetic import make_nag
+    return make_nag("R", seed=11, device=dev, sizes=(30_000, 900, 380, 9_000, 7_000, 2), **kw)
+
+
+def test_adopted_view_is_the_sorted_view(dev):
+    from superpoint_transformer_amd import csr
+    nag = _nag(dev)
+    for lo, hi in ((0, 1), (1, 2)):
+        si, sub = nag[lo]["super_index"], nag[hi]["sub"]
+        n_par = nag[hi]["pos"].shape[0]
+        ref = csr.build_csr(si, n_par)
+        csr.forget(si)
+        got = csr.adopt_csr(si, n_par, sub.pointers, sub.points)
+        assert got is not None and csr.csr_of(si, n_par) is got          # memoised on the index
+        assert torch.equal(got.perm, ref.perm) and torch.equal(got.rowptr, ref.rowptr)
+        assert torch.equal(got.pos_seg(), ref.pos_seg())
+        csr.forget(si)
+    # a Cluster whose clusters are not ascending is refused by the model-side hook
+    sub = nag[1]["sub"]
+    bad = type(sub)(sub.pointers.clone(), sub.points.clone())
+    a, b = int(bad.pointers[0]), int(bad.pointers[1])
+    if b - a >= 2:
+        bad.points[a], bad.points[a + 1] = bad.points[a + 1].clone(), bad.points[a].clone()
+        assert bad.ascending is False and sub.ascending is True
+
+
+def test_select_keeps_clusters_ascending(dev):
+    from superpoint_transformer_amd.synthetic import make_raw_nag
+    nag = make_raw_nag("R", seed=3, device=dev, sizes=(20_000, 600, 250, 5_000, 4_000, 1))
+    g = torch.Generator(device="cpu").manual_seed(0)
+    idx = torch.randperm(600, generator=g)[:240].sort().values.to(dev)
+    out = nag.select(1, idx)
+    for lv in (1, 2):
+        sub = out[lv].sub
+        assert sub._ascending is True          # handed on by select ...
+        sub._ascending = None
+        assert sub.ascending is True           # ... and true on the data
+        # the selected NAG's stored CSR is the sorted view of its relabelled super_index
+        from superpoint_transformer_amd import csr
+        si = out[lv - 1].super_index
+        ref = csr.build_csr(si, sub.num_clusters)
+        assert torch.equal(ref.perm.long(), sub.points) and torch.equal(ref.rowptr.long(), sub.pointers)
+
+
+def test_model_step_on_adopted_views_is_bitwise_the_sorted_one(dev):
+    from superpoint_transformer_amd import csr, hotpath
+    nag = _nag(dev)
+    torch.manual_seed(0)
+    model = hotpath.SPTSegmenter(**hotpath.spt64_config(8, 18)).to(dev)
+    view = hotpath._NagView(nag)
+
+    def run(adopt):
+        old = csr.use_sub_views(adopt)
+        try:
+            for lv in nag.levels:
+                csr.forget(lv.get("super_index"), lv.get("edge_index"), lv.get("batch"))
+            m = copy.deepcopy(model)
+            out = m(view)
+            sum(o.square().mean() for o in out).backward()
+            return [o.detach().clone() for o in out], [p.grad.clone() for p in m.parameters()]
+        finally:
+            csr.use_sub_views(old)
+
+    o1, g1 = run(True)
+    assert getattr(nag[0]["super_index"], "_spt_csr_memo", None)   # the adopted view was installed
+    o0, g0 = run(False)
+    for a, b in zip(o1, o0):
+        assert torch.equal(a, b)
+    for a, b in zip(g1, g0):
+        assert torch.equal(a, b)

@@ -1,4 +1,11 @@
-"""Average PMC counter values per kernel from a rocprofv3 rocpd database."""
+"""Average PMC counter values per kernel from a rocprofv3 rocpd database.
+
+    python tools/pmc_query.py <dir with *.db> "%kernel pattern%"
+
+Prints, per (kernel, counter): the mean over all launches, the maximum, and the mean over the
+UPPER GROUP of launches (value above the midpoint of min and max) - a kernel launched on two
+graph levels per step (the attention kernels: level 1 and level 2) separates into its level-1
+calls (`hi`) and the rest that way; for a kernel with one launch shape the two means agree."""
 import glob
 import sqlite3
 import sys
@@ -16,7 +23,13 @@ for f in files:
     if not (kname and cname and vname):
         print("counters_collection columns:", cols)
         continue
-    q = (f"select {kname}, {cname}, avg({vname}), count(*), max({vname}) from counters_collection "
-         f"where {kname} like ? group by substr({kname},1,60), {cname}")
-    for r in c.execute(q, (pat,)):
-        print(f"{r[0][:48]:48s} {r[1]:28s} avg {r[2]:16.1f}  max {r[4]:16.1f}  n={r[3]}")
+    q = (f"select substr({kname},1,60), {cname}, {vname} from counters_collection "
+         f"where {kname} like ?")
+    groups = {}
+    for k, cn, v in c.execute(q, (pat,)):
+        groups.setdefault((k, cn), []).append(float(v))
+    for (k, cn), vals in sorted(groups.items()):
+        lo, hi = min(vals), max(vals)
+        top = [v for v in vals if v >= 0.5 * (lo + hi)]
+        print(f"{k[:48]:48s} {cn:28s} avg {sum(vals) / len(vals):16.1f}  max {hi:16.1f}  n={len(vals)}"
+              f"  hi {sum(top) / len(top):16.1f}  nhi={len(top)}")
