@@ -737,6 +737,35 @@ int spt_fused_linear_bwd_pooled_f32(
     float pre_slope, const float* W, float* gx, float* gW, int accumulate, double* prev_total,
     void* ws, size_t ws_bytes, spt_stream_t stream);
 
+/* The rows of SEVERAL graphs in ONE launch of the fused layer kernels (a batch of B clouds, or an
+ * index that is sorted only piecewise - the edge MLP's norm index norm_index[edge_index[0]],
+ * src/models/components/spt.py:829-836, is sorted inside each third of [i<j | j>i | loops]).
+ * Run r covers rows [run_r0[r], run_r1[r]) of graph run_graph[r]; HOST arrays, 1 <= nruns <= 16,
+ * sorted by graph, num_graphs <= 16.  Per-graph tables are [num_graphs, width] arrays, `total` /
+ * `prev_total` [num_graphs, 2 width + 1] (a graph without rows reads as zeros), gW = the sum over
+ * all runs.  Otherwise as the one-range entries above. */
+int spt_fused_linear_fwd_runs_f32(const float* x, int nruns, const int64_t* run_r0,
+                                  const int64_t* run_r1, const int32_t* run_graph, int num_graphs,
+                                  int K, const float* W, int N, const float* pre_am,
+                                  const float* pre_scale, const float* pre_bias, float pre_slope,
+                                  float* h, double* total, int mode, void* ws, size_t ws_bytes,
+                                  spt_stream_t stream);
+int spt_fused_linear_bwd_runs_f32(
+    const float* gy, const float* h, int nruns, const int64_t* run_r0, const int64_t* run_r1,
+    const int32_t* run_graph, int num_graphs, int N, const float* am, const float* scale,
+    const float* bias, float slope, const float* c1, const float* c2, const float* c3,
+    const float* xprev, int K, const float* pre_am, const float* pre_scale, const float* pre_bias,
+    float pre_slope, const float* W, float* gx, float* gW, double* prev_total, int mode, void* ws,
+    size_t ws_bytes, spt_stream_t stream);
+int spt_fused_linear_bwd_pooled_runs_f32(
+    const float* gout, const int32_t* arg, const int32_t* perm, const int32_t* pos_seg,
+    const float* h, int nruns, const int64_t* run_p0, const int64_t* run_p1,
+    const int32_t* run_graph, int num_graphs, int N, const float* am, const float* scale,
+    const float* bias, float slope, const float* c1, const float* c2, const float* c3,
+    const float* xprev, int K, const float* pre_am, const float* pre_scale, const float* pre_bias,
+    float pre_slope, const float* W, float* gx, float* gW, double* prev_total, int mode, void* ws,
+    size_t ws_bytes, spt_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * Cross-entropy of the classifier heads' logits                (train step)
  * torch.nn.CrossEntropyLoss(ignore_index=...) of configs/model/semantic/default.yaml:47-49 as

@@ -33,6 +33,21 @@ int fail(int code, const char* fmt, ...);
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
 
+// ---- fused MLP layers over the rows of SEVERAL graphs in one launch ----------------------------
+// run r = rows [r0[r], r1[r]) of graph g[r]; blockIdx.y selects the run, every per-graph
+// coefficient table is indexed by g[r], per-block / per-wave partial tables are laid out run by
+// run.  n == 0: the legacy one-range launch (the kernel's own r0 / r1 / table pointers).
+constexpr int FMLP_MAX_RUNS = 16;
+struct FmlpRuns {
+  int n;
+  int g[FMLP_MAX_RUNS];
+  int64_t r0[FMLP_MAX_RUNS], r1[FMLP_MAX_RUNS];
+};
+// partial tables of graph b: records [start[b], start[b] + count[b]) (runs sorted by graph)
+struct FmlpGroups {
+  int start[FMLP_MAX_RUNS], count[FMLP_MAX_RUNS];
+};
+
 // ---- device helpers ---------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 

@@ -174,14 +174,37 @@ __device__ __forceinline__ void load_table(float* dst, const float* __restrict__
 #define FM_PROBE_INIT
 #endif
 
+// Multi-run launches (FmlpRuns, common.hpp): blockIdx.y = run; the kernel's range, its per-graph
+// table rows and its slice of the partial tables are re-pointed here, the body is unchanged.
+#define SPT_FMLP_RUN_FWD(N_)                                                  \
+  if (rt.n > 0) {                                                             \
+    const int run_ = blockIdx.y, gph_ = rt.g[run_];                           \
+    r0 = rt.r0[run_];                                                         \
+    r1 = rt.r1[run_];                                                         \
+    if (am) { am += (size_t)gph_ * K; sc += (size_t)gph_ * K; }               \
+    partial += (size_t)run_ * gridDim.x * (2 * (N_) + 1);                     \
+  }
+#define SPT_FMLP_RUN_BWD(N_, NW_)                                             \
+  if (rt.n > 0) {                                                             \
+    const int run_ = blockIdx.y, gph_ = rt.g[run_];                           \
+    r0 = rt.r0[run_];                                                         \
+    r1 = rt.r1[run_];                                                         \
+    am += (size_t)gph_ * (N_); sc += (size_t)gph_ * (N_);                     \
+    c1 += (size_t)gph_ * (N_); c2 += (size_t)gph_ * (N_); c3 += (size_t)gph_ * (N_); \
+    if (pam) { pam += (size_t)gph_ * K; psc += (size_t)gph_ * K; }            \
+    gw_partial += (size_t)run_ * gridDim.x * (NW_) * (N_) * K;                \
+    if (pstat_partial) pstat_partial += (size_t)run_ * gridDim.x * (NW_) * (2 * K + 1); \
+  }
+
 // ---- forward -------------------------------------------------------------------
 // K4 = ceil(K/4) k-steps, NBK = N/16 column blocks.
 template <int K4, int NBK>
 __global__ __launch_bounds__(WAVES * 64, 2) void fwd_kernel(
     const float* __restrict__ x, int64_t r0, int64_t r1, int K, const float* __restrict__ W,
     const float* __restrict__ am, const float* __restrict__ sc, const float* __restrict__ bs,
-    float slope, float* __restrict__ h, double* __restrict__ partial) {
+    float slope, float* __restrict__ h, double* __restrict__ partial, FmlpRuns rt) {
   constexpr int KP = K4 * 4, LDA = KP + 4, N = NBK * 16;
+  SPT_FMLP_RUN_FWD(N)
   __shared__ __attribute__((aligned(16))) float a_lds[WAVES][TR * LDA];
   __shared__ __attribute__((aligned(16))) float tab[3 * KP];   // am | sc | bs of the previous norm
   __shared__ double red[WAVES][2 * N];
@@ -286,9 +309,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_kernel(
     const float* __restrict__ c3, const float* __restrict__ xprev, int K,
     const float* __restrict__ pam, const float* __restrict__ psc, const float* __restrict__ pbs,
     float pslope, const float* __restrict__ W, float* __restrict__ gx,
-    float* __restrict__ gw_partial, double* __restrict__ pstat_partial) {
+    float* __restrict__ gw_partial, double* __restrict__ pstat_partial, FmlpRuns rt) {
   constexpr int KP = K4 * 4, KB = (KP + 15) / 16, KPP = KB * 16, N = NBK * 16;
   constexpr int LDG = N + 4, LDX = KPP + 4;
+  SPT_FMLP_RUN_BWD(N, NW)
   __shared__ __attribute__((aligned(16))) float g_lds[NW][TR * LDG];   // gh tile
   __shared__ __attribute__((aligned(16))) float x_lds[NW][TR * LDX];   // RAW h_prev tile
   // row stride KPP + 16: lane groups g = 0..3 read rows 4 st + g, whose 16-float column
@@ -561,8 +585,9 @@ template <int K4, int NBK, bool LO>
 __global__ __launch_bounds__(WAVES * 64, 2) void fwd_kernel_bf(
     const float* __restrict__ x, int64_t r0, int64_t r1, int K, const float* __restrict__ W,
     const float* __restrict__ am, const float* __restrict__ sc, const float* __restrict__ bs,
-    float slope, float* __restrict__ h, double* __restrict__ partial) {
+    float slope, float* __restrict__ h, double* __restrict__ partial, FmlpRuns rt) {
   constexpr int KP = K4 * 4, KS = (KP + 31) / 32, KP32 = KS * 32, LDA = KP32 + 4, N = NBK * 16;
+  SPT_FMLP_RUN_FWD(N)
   __shared__ __attribute__((aligned(16))) float a_lds[WAVES][TR * LDA];
   __shared__ __attribute__((aligned(16))) float tab[3 * KP32];
   __shared__ double red[WAVES][2 * N];
@@ -671,12 +696,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_kernel_bf(
     const float* __restrict__ c3, const float* __restrict__ xprev, int K,
     const float* __restrict__ pam, const float* __restrict__ psc, const float* __restrict__ pbs,
     float pslope, const float* __restrict__ W, float* __restrict__ gx,
-    float* __restrict__ gw_partial, double* __restrict__ pstat_partial,
+    float* __restrict__ gw_partial, double* __restrict__ pstat_partial, FmlpRuns rt,
     const int32_t* __restrict__ perm = nullptr, const int32_t* __restrict__ pos_seg = nullptr,
     const float* __restrict__ gout = nullptr, const int32_t* __restrict__ arg = nullptr) {
   constexpr int KP = K4 * 4, KB = (KP + 15) / 16, KPP = KB * 16, N = NBK * 16;
   constexpr int NS = (N + 31) / 32, NP32 = NS * 32;
   constexpr int LDG = NP32 + 4, LDX = KPP + 4, LDT = NP32 + 8;
+  SPT_FMLP_RUN_BWD(N, NW)
   __shared__ __attribute__((aligned(16))) float g_lds[NW][TR * LDG];   // gh tile
   __shared__ __attribute__((aligned(16))) float x_lds[NW][TR * LDX];   // RAW h_prev tile
   __shared__ __attribute__((aligned(16))) __bf16 wt_hi[NEED_GX ? KPP * LDT : 8];
@@ -995,9 +1021,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_kernel_bf(
 // thread sums <= ntab / 64 partials, 4-way unrolled: the loop is pure load latency; the
 // 16-slice shape took 35-60 us per call, ~70 calls per train step at batch size)
 template <typename T>
-__global__ __launch_bounds__(1024) void reduce_tables_kernel(const T* __restrict__ partial,
-                                                             int ntab, int len,
-                                                             T* __restrict__ total, int accumulate) {
+__device__ __forceinline__ void reduce_tables_body(const T* __restrict__ partial, int ntab, int len,
+                                                   T* __restrict__ total, int accumulate) {
   __shared__ T sl[64][17];
   const int cl = threadIdx.x & 15;
   const int col = blockIdx.x * 16 + cl;
@@ -1023,6 +1048,21 @@ __global__ __launch_bounds__(1024) void reduce_tables_kernel(const T* __restrict
     total[col] = accumulate ? total[col] + t : t;
   }
 }
+template <typename T>
+__global__ __launch_bounds__(1024) void reduce_tables_kernel(const T* __restrict__ partial,
+                                                             int ntab, int len,
+                                                             T* __restrict__ total, int accumulate) {
+  reduce_tables_body<T>(partial, ntab, len, total, accumulate);
+}
+// one table per graph: blockIdx.y = graph, its records = [start, start + count) of `partial`
+template <typename T>
+__global__ __launch_bounds__(1024) void reduce_tables_groups_kernel(const T* __restrict__ partial,
+                                                                    FmlpGroups grp, int len,
+                                                                    T* __restrict__ total) {
+  const int b = blockIdx.y;
+  reduce_tables_body<T>(partial + (size_t)grp.start[b] * len, grp.count[b], len,
+                        total + (size_t)b * len, 0);
+}
 
 static int grid_for_nw(int64_t rows, int per_cu, int nwv) {
   const int64_t tiles = (rows + TR - 1) / TR;
@@ -1046,13 +1086,14 @@ static int grid_for(int64_t rows, int per_cu) {
 
 // fused_mlp_dma.hip: the backward with LDS-DMA tile staging
 bool fmlp_dma_supported(int K, int N);
-int fmlp_dma_bwd_launch(bool pooled, bool lo, const float* gy, const float* h, int64_t r0, int64_t r1,
-                        int N, const float* am, const float* sc, const float* bs, float slope,
-                        const float* c1, const float* c2, const float* c3, const float* xprev, int K,
-                        const float* pam, const float* psc, const float* pbs, float pslope,
-                        const float* W, float* gx, float* gw_partial, double* pstat_partial,
-                        const int32_t* perm, const int32_t* pos_seg, const float* gout,
-                        const int32_t* arg, hipStream_t stream);
+int fmlp_dma_bwd_launch(bool pooled, bool lo, const float* gy, const float* h, FmlpRuns rt,
+                        int64_t max_rows, int N, const float* am, const float* sc, const float* bs,
+                        float slope, const float* c1, const float* c2, const float* c3,
+                        const float* xprev, int K, const float* pam, const float* psc,
+                        const float* pbs, float pslope, const float* W, float* gx,
+                        float* gw_partial, double* pstat_partial, const int32_t* perm,
+                        const int32_t* pos_seg, const float* gout, const int32_t* arg,
+                        hipStream_t stream);
 }  // namespace spt
 
 using namespace spt;
@@ -1119,6 +1160,80 @@ extern "C" size_t spt_fused_linear_workspace_bytes(int K, int N) {
   return align_up(fwd > bwd ? fwd : bwd, 256) + 4096;
 }
 
+// ---- run tables -------------------------------------------------------------------------------
+// A launch covers `nruns` row ranges; run r = rows [r0[r], r1[r]) of graph g[r], runs sorted by
+// graph (host arrays).  Per-graph coefficient tables are [num_graphs, width] arrays indexed by
+// g[r]; `total` / `prev_total` are [num_graphs, 2 width + 1].
+static const char* fmlp_make_runs(int nruns, const int64_t* r0, const int64_t* r1, const int32_t* g,
+                                  int num_graphs, FmlpRuns* rt, int64_t* max_rows) {
+  if (nruns < 1 || nruns > FMLP_MAX_RUNS) return "1 <= nruns <= 16";
+  if (num_graphs < 1 || num_graphs > FMLP_MAX_RUNS) return "1 <= num_graphs <= 16";
+  if (!r0 || !r1 || !g) return "null run table";
+  rt->n = nruns;
+  *max_rows = 0;
+  for (int r = 0; r < nruns; ++r) {
+    if (r1[r] < r0[r] || g[r] < 0 || g[r] >= num_graphs) return "bad run";
+    if (r && g[r] < g[r - 1]) return "runs must be sorted by graph";
+    rt->r0[r] = r0[r];
+    rt->r1[r] = r1[r];
+    rt->g[r] = g[r];
+    if (r1[r] - r0[r] > *max_rows) *max_rows = r1[r] - r0[r];
+  }
+  return nullptr;
+}
+// records of graph b when every run owns `per_run` consecutive records
+static FmlpGroups fmlp_groups(const FmlpRuns& rt, int num_graphs, int per_run) {
+  FmlpGroups grp;
+  for (int b = 0; b < FMLP_MAX_RUNS; ++b) grp.start[b] = grp.count[b] = 0;
+  for (int r = 0; r < rt.n; ++r) {
+    const int b = rt.g[r];
+    if (grp.count[b] == 0) grp.start[b] = r * per_run;
+    grp.count[b] += per_run;
+  }
+  (void)num_graphs;
+  return grp;
+}
+
+static int fmlp_fwd_impl(const char* fn, const float* x, const FmlpRuns& rt, int64_t max_rows,
+                         int num_graphs, int K, const float* W, int N, const float* pre_am,
+                         const float* pre_scale, const float* pre_bias, float pre_slope, float* h,
+                         double* total, int mode, void* ws, size_t ws_bytes, hipStream_t stream) {
+  const int g_fmlp_mode = fmlp_mode_of(mode);   // shadows the process default inside this call
+  (void)fn;
+  SPT_CHECK_ARG(K >= 1 && N >= 16, "bad shape");
+  SPT_CHECK_ARG(spt_fused_linear_supported(K, N), "(K, N) not built");
+  SPT_CHECK_ARG(x && W && h && total && ws, "null pointer");
+  SPT_CHECK_ARG(ws_bytes >= spt_fused_linear_workspace_bytes(K, N), "workspace too small");
+  SPT_CHECK_ARG(!pre_am || (pre_scale && pre_bias), "incomplete pre-normalisation tables");
+  const int k4 = (K + 3) / 4, nbk = N / 16;
+  // small layers are latency-bound: give every SIMD 4 waves to overlap tiles (the
+  // 64 -> 128 layer holds W in 128 B-operand registers and fits 2)
+  const int per_cu = (k4 * nbk <= 32) ? 4 : 2;
+  int gx_ = grid_for(max_rows, per_cu);
+  const int cap = MAX_BLOCKS / rt.n;
+  if (gx_ > cap) gx_ = cap;
+  const dim3 grid((unsigned)gx_, (unsigned)rt.n);
+  double* partial = (double*)ws;
+#define X(a, b)                                                                        \
+  if (k4 == a && nbk == b) {                                                           \
+    if (g_fmlp_mode == 3)                                                              \
+      fwd_kernel_bf<a, b, false><<<grid, WAVES * 64, 0, stream>>>(x, 0, 0, K, W, pre_am, pre_scale, \
+                                                                  pre_bias, pre_slope, h, partial, rt); \
+    else if (g_fmlp_mode == 2)                                                         \
+      fwd_kernel_bf<a, b, true><<<grid, WAVES * 64, 0, stream>>>(x, 0, 0, K, W, pre_am, pre_scale, \
+                                                                 pre_bias, pre_slope, h, partial, rt);  \
+    else                                                                               \
+      fwd_kernel<a, b><<<grid, WAVES * 64, 0, stream>>>(x, 0, 0, K, W, pre_am, pre_scale, \
+                                                        pre_bias, pre_slope, h, partial, rt);  \
+  }
+  SPT_FMLP_SHAPES(X)
+#undef X
+  reduce_tables_groups_kernel<double><<<dim3((2 * N + 1 + 15) / 16, num_graphs), 1024, 0, stream>>>(
+      partial, fmlp_groups(rt, num_graphs, gx_), 2 * N + 1, total);
+  SPT_CHECK_LAUNCH();
+  return 0;
+}
+
 // h[r0:r1, :N] = act(gn_prev(x))[r0:r1, :K] W^T ; total[2N+1] = column sums, sums of
 // squares and the row count of h over [r0, r1)  (one graph).
 extern "C" int spt_fused_linear_fwd_f32(const float* x, int64_t r0, int64_t r1, int K,
@@ -1134,35 +1249,143 @@ extern "C" int spt_fused_linear_fwd_ex_f32(const float* x, int64_t r0, int64_t r
                                            const float* pre_scale, const float* pre_bias,
                                            float pre_slope, float* h, double* total, int mode,
                                            void* ws, size_t ws_bytes, spt_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  const int g_fmlp_mode = fmlp_mode_of(mode);   // shadows the process default inside this call
-  SPT_CHECK_ARG(r1 >= r0 && K >= 1 && N >= 16, "bad shape");
-  SPT_CHECK_ARG(spt_fused_linear_supported(K, N), "(K, N) not built");
-  SPT_CHECK_ARG(x && W && h && total && ws, "null pointer");
+  SPT_CHECK_ARG(r1 >= r0, "bad shape");
+  FmlpRuns rt;
+  rt.n = 1; rt.g[0] = 0; rt.r0[0] = r0; rt.r1[0] = r1;
+  return fmlp_fwd_impl(__func__, x, rt, r1 - r0, 1, K, W, N, pre_am, pre_scale, pre_bias, pre_slope,
+                       h, total, mode, ws, ws_bytes, (hipStream_t)stream_);
+}
+// The rows of SEVERAL graphs in one launch (see "run tables" above): pre_am / pre_scale
+// [num_graphs, K] (or NULL), total [num_graphs, 2N+1].
+extern "C" int spt_fused_linear_fwd_runs_f32(const float* x, int nruns, const int64_t* run_r0,
+                                             const int64_t* run_r1, const int32_t* run_graph,
+                                             int num_graphs, int K, const float* W, int N,
+                                             const float* pre_am, const float* pre_scale,
+                                             const float* pre_bias, float pre_slope, float* h,
+                                             double* total, int mode, void* ws, size_t ws_bytes,
+                                             spt_stream_t stream_) {
+  FmlpRuns rt;
+  int64_t max_rows;
+  const char* err = fmlp_make_runs(nruns, run_r0, run_r1, run_graph, num_graphs, &rt, &max_rows);
+  SPT_CHECK_ARG(!err, err ? err : "");
+  return fmlp_fwd_impl(__func__, x, rt, max_rows, num_graphs, K, W, N, pre_am, pre_scale, pre_bias,
+                       pre_slope, h, total, mode, ws, ws_bytes, (hipStream_t)stream_);
+}
+
+static int fmlp_bwd_impl(bool pooled, const float* gy, const float* gout, const int32_t* arg,
+                         const int32_t* perm, const int32_t* pos_seg, const float* h,
+                         const FmlpRuns& rt, int64_t max_rows, int num_graphs, int N,
+                         const float* am, const float* scale, const float* bias, float slope,
+                         const float* c1, const float* c2, const float* c3, const float* xprev,
+                         int K, const float* pre_am, const float* pre_scale, const float* pre_bias,
+                         float pre_slope, const float* W, float* gx, float* gW, int accumulate,
+                         double* prev_total, int mode, void* ws, size_t ws_bytes,
+                         hipStream_t stream) {
+  const int g_fmlp_mode = fmlp_mode_of(mode);
+  const bool g_fmlp_split_bf16 = g_fmlp_mode >= 1;
+  SPT_CHECK_ARG(K >= 1 && N >= 16, "bad shape");
+  SPT_CHECK_ARG(h && am && scale && bias && c1 && c2 && c3 && xprev && W && gW && ws, "null pointer");
   SPT_CHECK_ARG(ws_bytes >= spt_fused_linear_workspace_bytes(K, N), "workspace too small");
-  SPT_CHECK_ARG(!pre_am || (pre_scale && pre_bias), "incomplete pre-normalisation tables");
-  const int k4 = (K + 3) / 4, nbk = N / 16;
-  // small layers are latency-bound: give every SIMD 4 waves to overlap tiles (the
-  // 64 -> 128 layer holds W in 128 B-operand registers and fits 2)
-  const int per_cu = (k4 * nbk <= 32) ? 4 : 2;
-  const int grid = grid_for(r1 - r0, per_cu) < MAX_BLOCKS ? grid_for(r1 - r0, per_cu) : MAX_BLOCKS;
-  double* partial = (double*)ws;
-#define X(a, b)                                                                        \
-  if (k4 == a && nbk == b) {                                                           \
-    if (g_fmlp_mode == 3)                                                              \
-      fwd_kernel_bf<a, b, false><<<grid, WAVES * 64, 0, stream>>>(x, r0, r1, K, W, pre_am, pre_scale, \
-                                                                  pre_bias, pre_slope, h, partial); \
-    else if (g_fmlp_mode == 2)                                                         \
-      fwd_kernel_bf<a, b, true><<<grid, WAVES * 64, 0, stream>>>(x, r0, r1, K, W, pre_am, pre_scale, \
-                                                                 pre_bias, pre_slope, h, partial);  \
-    else                                                                               \
-      fwd_kernel<a, b><<<grid, WAVES * 64, 0, stream>>>(x, r0, r1, K, W, pre_am, pre_scale, \
-                                                        pre_bias, pre_slope, h, partial);  \
+  if (pooled) {
+    SPT_CHECK_ARG(spt_fused_linear_pooled_supported_ex(K, N, g_fmlp_mode),
+                  "(K, N) has no pooled kernel in this matrix mode");
+    SPT_CHECK_ARG(gout && arg && perm && pos_seg && gx, "null pointer");
+    SPT_CHECK_ARG(!prev_total || pre_am, "previous-layer statistics need its tables");
+  } else {
+    SPT_CHECK_ARG(spt_fused_linear_supported(K, N), "(K, N) not built");
+    SPT_CHECK_ARG(gy, "null pointer");
+    SPT_CHECK_ARG(!prev_total || (gx && pre_am), "previous-layer statistics need gx and its tables");
   }
-  SPT_FMLP_SHAPES(X)
+  const int k4 = (K + 3) / 4, nbk = N / 16;
+  int gx_ = 1, nwv = 1;                        // blocks per run, waves per block
+  float* gwp = (float*)ws;
+  double* pst = (double*)((char*)ws + align_up((size_t)MAX_BWD_WAVES * N * K * 4, 256));
+  double* pstp = prev_total ? pst : nullptr;
+  const int nr = rt.n;
+  auto cap_grid = [&](int g_, int nw_) {       // every run's waves own a record of the partial tables
+    const int cap = MAX_BWD_WAVES / (nw_ * nr);
+    return g_ > cap ? (cap < 1 ? 1 : cap) : g_;
+  };
+#define XP(a, b)                                                                                 \
+  if (k4 == a && nbk == b) {                                                                     \
+    /* (the register-prefetch variant PIPE = true measured slower: 7.3 vs 6.7 ms at 64 -> 128; */ \
+    /* at one wave per SIMD nothing overlaps the ~1 450 VALU instructions per tile)            */ \
+    constexpr bool big = (a * b >= 32);                                                          \
+    constexpr int NWB = (a * b > 128) ? 4 : (big ? 8 : 4);                                       \
+    gx_ = cap_grid(grid_for_nw(max_rows, (a * b > 128) ? 1 : (big ? ((a * b <= 32) ? 2 : 1) : 4), NWB), NWB); \
+    nwv = NWB;                                                                                   \
+    const dim3 grid((unsigned)gx_, (unsigned)nr);                                                \
+    if (g_fmlp_mode == 3)                                                                        \
+      bwd_kernel_bf<a, b, true, NWB, false, true><<<grid, NWB * 64, 0, stream>>>(                \
+          nullptr, h, 0, 0, am, scale, bias, slope, c1, c2, c3, xprev, K, pre_am, pre_scale,     \
+          pre_bias, pre_slope, W, gx, gwp, pstp, rt, perm, pos_seg, gout, arg);                  \
+    else                                                                                         \
+      bwd_kernel_bf<a, b, true, NWB, true, true><<<grid, NWB * 64, 0, stream>>>(                 \
+          nullptr, h, 0, 0, am, scale, bias, slope, c1, c2, c3, xprev, K, pre_am, pre_scale,     \
+          pre_bias, pre_slope, W, gx, gwp, pstp, rt, perm, pos_seg, gout, arg);                  \
+  }
+#define X(a, b)                                                                                  \
+  if (k4 == a && nbk == b) {                                                                     \
+    constexpr bool big = (a * b >= 32);   /* W as LDS B operands, 8-wave blocks */              \
+    constexpr int NWV = big ? 8 : 4;                                                             \
+    /* workgroups per CU the registers / LDS allow: 4 x 4 waves for the small layers, */         \
+    /* 2 x 8 waves while the LDS tiles stay under 80 KB, else 1 x 8 */                            \
+    /* split-bf16: the K = 132 layer keeps W^T, its accumulators and both split operands live: */ \
+    /* 4-wave workgroups (1 wave per SIMD, 512 registers) instead of spilling at 256           */ \
+    constexpr int NWB = (a * b > 128) ? 4 : NWV;                                                 \
+    if (g_fmlp_split_bf16) {                                                                     \
+      gx_ = cap_grid(grid_for_nw(max_rows, (a * b > 128) ? 1 : (big ? ((a * b <= 32) ? 2 : 1) : 4), NWB), NWB); \
+      nwv = NWB;                                                                                 \
+    } else {                                                                                     \
+      gx_ = cap_grid(grid_for_nw(max_rows, big ? ((a * b <= 32) ? 2 : 1) : 4, NWV), NWV);        \
+      nwv = NWV;                                                                                 \
+    }                                                                                            \
+    const dim3 grid((unsigned)gx_, (unsigned)nr);                                                \
+    if (g_fmlp_mode == 3 && gx)                                                                  \
+      bwd_kernel_bf<a, b, true, NWB, false><<<grid, NWB * 64, 0, stream>>>(                      \
+          gy, h, 0, 0, am, scale, bias, slope, c1, c2, c3, xprev, K, pre_am, pre_scale,          \
+          pre_bias, pre_slope, W, gx, gwp, pstp, rt);                                            \
+    else if (g_fmlp_mode == 3)                                                                   \
+      bwd_kernel_bf<a, b, false, NWB, false><<<grid, NWB * 64, 0, stream>>>(                     \
+          gy, h, 0, 0, am, scale, bias, slope, c1, c2, c3, xprev, K, pre_am, pre_scale,          \
+          pre_bias, pre_slope, W, nullptr, gwp, nullptr, rt);                                    \
+    else if (g_fmlp_split_bf16 && gx)                                                            \
+      bwd_kernel_bf<a, b, true, NWB, true><<<grid, NWB * 64, 0, stream>>>(                       \
+          gy, h, 0, 0, am, scale, bias, slope, c1, c2, c3, xprev, K, pre_am, pre_scale,          \
+          pre_bias, pre_slope, W, gx, gwp, pstp, rt);                                            \
+    else if (g_fmlp_split_bf16)                                                                  \
+      bwd_kernel_bf<a, b, false, NWB, true><<<grid, NWB * 64, 0, stream>>>(                      \
+          gy, h, 0, 0, am, scale, bias, slope, c1, c2, c3, xprev, K, pre_am, pre_scale,          \
+          pre_bias, pre_slope, W, nullptr, gwp, nullptr, rt);                                    \
+    else if (gx)                                                                                 \
+      bwd_kernel<a, b, true, NWV, big><<<grid, NWV * 64, 0, stream>>>(                           \
+          gy, h, 0, 0, am, scale, bias, slope, c1, c2, c3, xprev, K, pre_am, pre_scale,          \
+          pre_bias, pre_slope, W, gx, gwp, pstp, rt);                                            \
+    else                                                                                         \
+      bwd_kernel<a, b, false, NWV, big><<<grid, NWV * 64, 0, stream>>>(                          \
+          gy, h, 0, 0, am, scale, bias, slope, c1, c2, c3, xprev, K, pre_am, pre_scale,          \
+          pre_bias, pre_slope, W, nullptr, gwp, nullptr, rt);                                    \
+  }
+  int per_run = 0;                              // wave records per run
+  if (g_fmlp_split_bf16 && gx && fmlp_dma_of(mode) && fmlp_dma_supported(K, N)) {
+    per_run = fmlp_dma_bwd_launch(pooled, g_fmlp_mode != 3, gy, h, rt, max_rows, N, am, scale, bias,
+                                  slope, c1, c2, c3, xprev, K, pre_am, pre_scale, pre_bias, pre_slope,
+                                  W, gx, gwp, pstp, perm, pos_seg, gout, arg, stream);
+  } else if (pooled) {
+    SPT_FMLP_POOLED_SHAPES(XP)
+    per_run = gx_ * nwv;
+  } else {
+    SPT_FMLP_SHAPES(X)
+    per_run = gx_ * nwv;
+  }
 #undef X
-  reduce_tables_kernel<double><<<(2 * N + 1 + 15) / 16, 1024, 0, stream>>>(partial, grid, 2 * N + 1,
-                                                                           total, 0);
+#undef XP
+  SPT_CHECK_ARG(per_run > 0, "no kernel for this shape");
+  reduce_tables_kernel<float><<<(N * K + 15) / 16, 1024, 0, stream>>>(gwp, per_run * nr, N * K, gW,
+                                                                     accumulate);
+  if (prev_total)
+    reduce_tables_groups_kernel<double><<<dim3((2 * K + 1 + 15) / 16, num_graphs), 1024, 0, stream>>>(
+        pst, fmlp_groups(rt, num_graphs, per_run), 2 * K + 1, prev_total);
   SPT_CHECK_LAUNCH();
   return 0;
 }
@@ -1189,49 +1412,30 @@ extern "C" int spt_fused_linear_bwd_pooled_ex_f32(
     const float* xprev, int K, const float* pre_am, const float* pre_scale, const float* pre_bias,
     float pre_slope, const float* W, float* gx, float* gW, int accumulate, double* prev_total,
     int mode, void* ws, size_t ws_bytes, spt_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  const int g_fmlp_mode = fmlp_mode_of(mode);
-  SPT_CHECK_ARG(p1 >= p0 && K >= 1 && N >= 16, "bad shape");
-  SPT_CHECK_ARG(spt_fused_linear_pooled_supported_ex(K, N, g_fmlp_mode), "(K, N) has no pooled kernel in this matrix mode");
-  SPT_CHECK_ARG(gout && arg && perm && pos_seg && h && am && scale && bias && c1 && c2 && c3 &&
-                xprev && W && gW && gx && ws, "null pointer");
-  SPT_CHECK_ARG(ws_bytes >= spt_fused_linear_workspace_bytes(K, N), "workspace too small");
-  SPT_CHECK_ARG(!prev_total || pre_am, "previous-layer statistics need its tables");
-  const int k4 = (K + 3) / 4, nbk = N / 16;
-  int grid = 1, nw = 1;
-  float* gwp = (float*)ws;
-  double* pst = (double*)((char*)ws + align_up((size_t)MAX_BWD_WAVES * N * K * 4, 256));
-#define X(a, b)                                                                                  \
-  if (k4 == a && nbk == b) {                                                                     \
-    /* (the register-prefetch variant PIPE = true measured slower: 7.3 vs 6.7 ms at 64 -> 128; */ \
-    /* at one wave per SIMD nothing overlaps the ~1 450 VALU instructions per tile)            */ \
-    constexpr bool big = (a * b >= 32);                                                          \
-    constexpr int NWB = (a * b > 128) ? 4 : (big ? 8 : 4);                                       \
-    grid = grid_for_nw(p1 - p0, (a * b > 128) ? 1 : (big ? ((a * b <= 32) ? 2 : 1) : 4), NWB);   \
-    nw = grid * NWB;                                                                             \
-    if (g_fmlp_mode == 3)                                                                        \
-      bwd_kernel_bf<a, b, true, NWB, false, true><<<grid, NWB * 64, 0, stream>>>(                \
-          nullptr, h, p0, p1, am, scale, bias, slope, c1, c2, c3, xprev, K, pre_am, pre_scale,   \
-          pre_bias, pre_slope, W, gx, gwp, prev_total ? pst : nullptr, perm, pos_seg, gout, arg); \
-    else                                                                                         \
-      bwd_kernel_bf<a, b, true, NWB, true, true><<<grid, NWB * 64, 0, stream>>>(                 \
-          nullptr, h, p0, p1, am, scale, bias, slope, c1, c2, c3, xprev, K, pre_am, pre_scale,   \
-          pre_bias, pre_slope, W, gx, gwp, prev_total ? pst : nullptr, perm, pos_seg, gout, arg); \
-  }
-  if (fmlp_dma_of(mode) && fmlp_dma_supported(K, N)) {
-    nw = fmlp_dma_bwd_launch(true, g_fmlp_mode != 3, nullptr, h, p0, p1, N, am, scale, bias, slope, c1,
-                             c2, c3, xprev, K, pre_am, pre_scale, pre_bias, pre_slope, W, gx, gwp,
-                             prev_total ? pst : nullptr, perm, pos_seg, gout, arg, stream);
-  } else {
-    SPT_FMLP_POOLED_SHAPES(X)
-  }
-#undef X
-  reduce_tables_kernel<float><<<(N * K + 15) / 16, 1024, 0, stream>>>(gwp, nw, N * K, gW, accumulate);
-  if (prev_total)
-    reduce_tables_kernel<double><<<(2 * K + 1 + 15) / 16, 1024, 0, stream>>>(pst, nw, 2 * K + 1,
-                                                                            prev_total, 0);
-  SPT_CHECK_LAUNCH();
-  return 0;
+  SPT_CHECK_ARG(p1 >= p0, "bad shape");
+  FmlpRuns rt;
+  rt.n = 1; rt.g[0] = 0; rt.r0[0] = p0; rt.r1[0] = p1;
+  return fmlp_bwd_impl(true, nullptr, gout, arg, perm, pos_seg, h, rt, p1 - p0, 1, N, am, scale, bias,
+                       slope, c1, c2, c3, xprev, K, pre_am, pre_scale, pre_bias, pre_slope, W, gx, gW,
+                       accumulate, prev_total, mode, ws, ws_bytes, (hipStream_t)stream_);
+}
+// Same over the CSR position ranges of several graphs in one launch: tables [num_graphs, N] /
+// [num_graphs, K], prev_total [num_graphs, 2K+1]; gW receives the sum over all runs.
+extern "C" int spt_fused_linear_bwd_pooled_runs_f32(
+    const float* gout, const int32_t* arg, const int32_t* perm, const int32_t* pos_seg,
+    const float* h, int nruns, const int64_t* run_p0, const int64_t* run_p1,
+    const int32_t* run_graph, int num_graphs, int N, const float* am, const float* scale,
+    const float* bias, float slope, const float* c1, const float* c2, const float* c3,
+    const float* xprev, int K, const float* pre_am, const float* pre_scale, const float* pre_bias,
+    float pre_slope, const float* W, float* gx, float* gW, double* prev_total, int mode, void* ws,
+    size_t ws_bytes, spt_stream_t stream_) {
+  FmlpRuns rt;
+  int64_t max_rows;
+  const char* err = fmlp_make_runs(nruns, run_p0, run_p1, run_graph, num_graphs, &rt, &max_rows);
+  SPT_CHECK_ARG(!err, err ? err : "");
+  return fmlp_bwd_impl(true, nullptr, gout, arg, perm, pos_seg, h, rt, max_rows, num_graphs, N, am,
+                       scale, bias, slope, c1, c2, c3, xprev, K, pre_am, pre_scale, pre_bias,
+                       pre_slope, W, gx, gW, 0, prev_total, mode, ws, ws_bytes, (hipStream_t)stream_);
 }
 
 // Backward of one layer over the rows [r0, r1) of one graph.
@@ -1261,71 +1465,27 @@ extern "C" int spt_fused_linear_bwd_ex_f32(const float* gy, const float* h, int6
                                            float* gx, float* gW, int accumulate,
                                            double* prev_total, int mode, void* ws, size_t ws_bytes,
                                            spt_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  const int g_fmlp_mode = fmlp_mode_of(mode);
-  const bool g_fmlp_split_bf16 = g_fmlp_mode >= 1;
-  SPT_CHECK_ARG(r1 >= r0 && K >= 1 && N >= 16, "bad shape");
-  SPT_CHECK_ARG(spt_fused_linear_supported(K, N), "(K, N) not built");
-  SPT_CHECK_ARG(gy && h && am && scale && bias && c1 && c2 && c3 && xprev && W && gW && ws,
-                "null pointer");
-  SPT_CHECK_ARG(ws_bytes >= spt_fused_linear_workspace_bytes(K, N), "workspace too small");
-  SPT_CHECK_ARG(!prev_total || (gx && pre_am), "previous-layer statistics need gx and its tables");
-  const int k4 = (K + 3) / 4, nbk = N / 16;
-  int grid = 1, nw = 1;
-  float* gwp = (float*)ws;
-  double* pst = (double*)((char*)ws + align_up((size_t)MAX_BWD_WAVES * N * K * 4, 256));
-#define X(a, b)                                                                                  \
-  if (k4 == a && nbk == b) {                                                                     \
-    constexpr bool big = (a * b >= 32);   /* W as LDS B operands, 8-wave blocks */              \
-    constexpr int NWV = big ? 8 : 4;                                                             \
-    /* workgroups per CU the registers / LDS allow: 4 x 4 waves for the small layers, */         \
-    /* 2 x 8 waves while the LDS tiles stay under 80 KB, else 1 x 8 */                            \
-    grid = grid_for_nw(r1 - r0, big ? ((a * b <= 32) ? 2 : 1) : 4, NWV);                         \
-    nw = grid * NWV;                                                                             \
-    /* split-bf16: the K = 132 layer keeps W^T, its accumulators and both split operands live: */ \
-    /* 4-wave workgroups (1 wave per SIMD, 512 registers) instead of spilling at 256           */ \
-    constexpr int NWB = (a * b > 128) ? 4 : NWV;                                                 \
-    if (g_fmlp_split_bf16) {                                                                     \
-      grid = grid_for_nw(r1 - r0, (a * b > 128) ? 1 : (big ? ((a * b <= 32) ? 2 : 1) : 4), NWB); \
-      nw = grid * NWB;                                                                           \
-    }                                                                                            \
-    if (g_fmlp_mode == 3 && gx)                                                                  \
-      bwd_kernel_bf<a, b, true, NWB, false><<<grid, NWB * 64, 0, stream>>>(                      \
-          gy, h, r0, r1, am, scale, bias, slope, c1, c2, c3, xprev, K, pre_am, pre_scale,        \
-          pre_bias, pre_slope, W, gx, gwp, prev_total ? pst : nullptr);                          \
-    else if (g_fmlp_mode == 3)                                                                   \
-      bwd_kernel_bf<a, b, false, NWB, false><<<grid, NWB * 64, 0, stream>>>(                     \
-          gy, h, r0, r1, am, scale, bias, slope, c1, c2, c3, xprev, K, pre_am, pre_scale,        \
-          pre_bias, pre_slope, W, nullptr, gwp, nullptr);                                        \
-    else if (g_fmlp_split_bf16 && gx)                                                            \
-      bwd_kernel_bf<a, b, true, NWB, true><<<grid, NWB * 64, 0, stream>>>(                       \
-          gy, h, r0, r1, am, scale, bias, slope, c1, c2, c3, xprev, K, pre_am, pre_scale,        \
-          pre_bias, pre_slope, W, gx, gwp, prev_total ? pst : nullptr);                          \
-    else if (g_fmlp_split_bf16)                                                                  \
-      bwd_kernel_bf<a, b, false, NWB, true><<<grid, NWB * 64, 0, stream>>>(                      \
-          gy, h, r0, r1, am, scale, bias, slope, c1, c2, c3, xprev, K, pre_am, pre_scale,        \
-          pre_bias, pre_slope, W, nullptr, gwp, nullptr);                                        \
-    else if (gx)                                                                                 \
-      bwd_kernel<a, b, true, NWV, big><<<grid, NWV * 64, 0, stream>>>(                           \
-          gy, h, r0, r1, am, scale, bias, slope, c1, c2, c3, xprev, K, pre_am, pre_scale,        \
-          pre_bias, pre_slope, W, gx, gwp, prev_total ? pst : nullptr);                          \
-    else                                                                                         \
-      bwd_kernel<a, b, false, NWV, big><<<grid, NWV * 64, 0, stream>>>(                          \
-          gy, h, r0, r1, am, scale, bias, slope, c1, c2, c3, xprev, K, pre_am, pre_scale,        \
-          pre_bias, pre_slope, W, nullptr, gwp, nullptr);                                        \
-  }
-  if (g_fmlp_split_bf16 && gx && fmlp_dma_of(mode) && fmlp_dma_supported(K, N)) {
-    nw = fmlp_dma_bwd_launch(false, g_fmlp_mode != 3, gy, h, r0, r1, N, am, scale, bias, slope, c1, c2,
-                             c3, xprev, K, pre_am, pre_scale, pre_bias, pre_slope, W, gx, gwp,
-                             prev_total ? pst : nullptr, nullptr, nullptr, nullptr, nullptr, stream);
-  } else {
-    SPT_FMLP_SHAPES(X)
-  }
-#undef X
-  reduce_tables_kernel<float><<<(N * K + 15) / 16, 1024, 0, stream>>>(gwp, nw, N * K, gW, accumulate);
-  if (prev_total)
-    reduce_tables_kernel<double><<<(2 * K + 1 + 15) / 16, 1024, 0, stream>>>(pst, nw, 2 * K + 1,
-                                                                            prev_total, 0);
-  SPT_CHECK_LAUNCH();
-  return 0;
+  SPT_CHECK_ARG(r1 >= r0, "bad shape");
+  FmlpRuns rt;
+  rt.n = 1; rt.g[0] = 0; rt.r0[0] = r0; rt.r1[0] = r1;
+  return fmlp_bwd_impl(false, gy, nullptr, nullptr, nullptr, nullptr, h, rt, r1 - r0, 1, N, am, scale,
+                       bias, slope, c1, c2, c3, xprev, K, pre_am, pre_scale, pre_bias, pre_slope, W,
+                       gx, gW, accumulate, prev_total, mode, ws, ws_bytes, (hipStream_t)stream_);
+}
+// Same over the row ranges of several graphs in one launch (tables [num_graphs, .], prev_total
+// [num_graphs, 2K+1], gW = the sum over all runs).
+extern "C" int spt_fused_linear_bwd_runs_f32(
+    const float* gy, const float* h, int nruns, const int64_t* run_r0, const int64_t* run_r1,
+    const int32_t* run_graph, int num_graphs, int N, const float* am, const float* scale,
+    const float* bias, float slope, const float* c1, const float* c2, const float* c3,
+    const float* xprev, int K, const float* pre_am, const float* pre_scale, const float* pre_bias,
+    float pre_slope, const float* W, float* gx, float* gW, double* prev_total, int mode, void* ws,
+    size_t ws_bytes, spt_stream_t stream_) {
+  FmlpRuns rt;
+  int64_t max_rows;
+  const char* err = fmlp_make_runs(nruns, run_r0, run_r1, run_graph, num_graphs, &rt, &max_rows);
+  SPT_CHECK_ARG(!err, err ? err : "");
+  return fmlp_bwd_impl(false, gy, nullptr, nullptr, nullptr, nullptr, h, rt, max_rows, num_graphs, N,
+                       am, scale, bias, slope, c1, c2, c3, xprev, K, pre_am, pre_scale, pre_bias,
+                       pre_slope, W, gx, gW, 0, prev_total, mode, ws, ws_bytes, (hipStream_t)stream_);
 }

@@ -119,8 +119,18 @@ __global__ __launch_bounds__(NW * 64, OCC) void bwd_dma_kernel(
     float pslope, const float* __restrict__ W, float* __restrict__ gx,
     float* __restrict__ gw_partial, double* __restrict__ pstat_partial,
     const int32_t* __restrict__ perm, const int32_t* __restrict__ pos_seg,
-    const float* __restrict__ gout, const int32_t* __restrict__ arg) {
+    const float* __restrict__ gout, const int32_t* __restrict__ arg, FmlpRuns rt) {
   constexpr int NC = N / 4, KC = K / 4, NBK = N / 16, KB = K / 16, NS = N / 32;
+  if (rt.n > 0) {                           // multi-run launch (common.hpp): blockIdx.y = run
+    const int run_ = blockIdx.y, gph_ = rt.g[run_];
+    r0 = rt.r0[run_];
+    r1 = rt.r1[run_];
+    am += (size_t)gph_ * N; sc += (size_t)gph_ * N;
+    c1 += (size_t)gph_ * N; c2 += (size_t)gph_ * N; c3 += (size_t)gph_ * N;
+    if (pam) { pam += (size_t)gph_ * K; psc += (size_t)gph_ * K; }
+    gw_partial += (size_t)run_ * gridDim.x * NW * N * K;
+    if (pstat_partial) pstat_partial += (size_t)run_ * gridDim.x * NW * (2 * K + 1);
+  }
   constexpr int HI = TR * NC / 64, XI = TR * KC / 64;   // DMA instructions per tile (h, x)
   constexpr int RH = 64 / NC;                            // rows of h per DMA instruction
   constexpr int NSEG = RH;                               // segments one (gout | arg) DMA covers
@@ -444,38 +454,43 @@ bool fmlp_dma_supported(int K, int N) {
 
 // Launches the layer's backward; returns the number of per-wave partial tables written
 // (gw_partial: [waves][N x K], pstat_partial: [waves][2 K + 1] or null), 0 if (K, N) is not built.
-int fmlp_dma_bwd_launch(bool pooled, bool lo, const float* gy, const float* h, int64_t r0, int64_t r1,
-                        int N, const float* am, const float* sc, const float* bs, float slope,
-                        const float* c1, const float* c2, const float* c3, const float* xprev, int K,
-                        const float* pam, const float* psc, const float* pbs, float pslope,
-                        const float* W, float* gx, float* gw_partial, double* pstat_partial,
-                        const int32_t* perm, const int32_t* pos_seg, const float* gout,
-                        const int32_t* arg, hipStream_t stream) {
+// returns the number of wave records PER RUN written to the partial tables (0: shape not built)
+int fmlp_dma_bwd_launch(bool pooled, bool lo, const float* gy, const float* h, FmlpRuns rt,
+                        int64_t max_rows, int N, const float* am, const float* sc, const float* bs,
+                        float slope, const float* c1, const float* c2, const float* c3,
+                        const float* xprev, int K, const float* pam, const float* psc,
+                        const float* pbs, float pslope, const float* W, float* gx,
+                        float* gw_partial, double* pstat_partial, const int32_t* perm,
+                        const int32_t* pos_seg, const float* gout, const int32_t* arg,
+                        hipStream_t stream) {
   using namespace fdma;
-  const int64_t tiles = (r1 - r0 + TR - 1) / TR;
+  const int64_t tiles = (max_rows + TR - 1) / TR;
+  const int nr = rt.n < 1 ? 1 : rt.n;
 #define SPT_DMA_CASE(KK, NN, NWV, PER_CU, OCC)                                                        \
   if (K == KK && N == NN) {                                                                        \
     int64_t blocks = (tiles + NWV - 1) / NWV;                                                      \
-    if (blocks > 256 * PER_CU) blocks = 256 * PER_CU;                                              \
+    /* one resident round of workgroups over all runs together */                                  \
+    const int64_t cap = (256 * PER_CU) / nr > 1 ? (256 * PER_CU) / nr : 1;                         \
+    if (blocks > cap) blocks = cap;                                                                \
     if (blocks < 1) blocks = 1;                                                                    \
-    const int grid = (int)blocks;                                                                  \
+    const dim3 grid((unsigned)blocks, (unsigned)nr);                                               \
     if (pooled && lo)                                                                              \
       bwd_dma_kernel<KK, NN, NWV, OCC, true, true><<<grid, NWV * 64, 0, stream>>>(                      \
-          gy, h, r0, r1, am, sc, bs, slope, c1, c2, c3, xprev, pam, psc, pbs, pslope, W, gx,       \
-          gw_partial, pstat_partial, perm, pos_seg, gout, arg);                                    \
+          gy, h, 0, 0, am, sc, bs, slope, c1, c2, c3, xprev, pam, psc, pbs, pslope, W, gx,         \
+          gw_partial, pstat_partial, perm, pos_seg, gout, arg, rt);                                \
     else if (pooled)                                                                               \
       bwd_dma_kernel<KK, NN, NWV, OCC, false, true><<<grid, NWV * 64, 0, stream>>>(                     \
-          gy, h, r0, r1, am, sc, bs, slope, c1, c2, c3, xprev, pam, psc, pbs, pslope, W, gx,       \
-          gw_partial, pstat_partial, perm, pos_seg, gout, arg);                                    \
+          gy, h, 0, 0, am, sc, bs, slope, c1, c2, c3, xprev, pam, psc, pbs, pslope, W, gx,         \
+          gw_partial, pstat_partial, perm, pos_seg, gout, arg, rt);                                \
     else if (lo)                                                                                   \
       bwd_dma_kernel<KK, NN, NWV, OCC, true, false><<<grid, NWV * 64, 0, stream>>>(                     \
-          gy, h, r0, r1, am, sc, bs, slope, c1, c2, c3, xprev, pam, psc, pbs, pslope, W, gx,       \
-          gw_partial, pstat_partial, perm, pos_seg, gout, arg);                                    \
+          gy, h, 0, 0, am, sc, bs, slope, c1, c2, c3, xprev, pam, psc, pbs, pslope, W, gx,         \
+          gw_partial, pstat_partial, perm, pos_seg, gout, arg, rt);                                \
     else                                                                                           \
       bwd_dma_kernel<KK, NN, NWV, OCC, false, false><<<grid, NWV * 64, 0, stream>>>(                    \
-          gy, h, r0, r1, am, sc, bs, slope, c1, c2, c3, xprev, pam, psc, pbs, pslope, W, gx,       \
-          gw_partial, pstat_partial, perm, pos_seg, gout, arg);                                    \
-    return grid * NWV;                                                                             \
+          gy, h, 0, 0, am, sc, bs, slope, c1, c2, c3, xprev, pam, psc, pbs, pslope, W, gx,         \
+          gw_partial, pstat_partial, perm, pos_seg, gout, arg, rt);                                \
+    return (int)blocks * NWV;                                                                      \
   }
   SPT_DMA_CASE(64, 128, 8, 1, 2)
   SPT_DMA_CASE(64, 64, 8, 1, 2)

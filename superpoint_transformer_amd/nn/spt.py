@@ -12,6 +12,7 @@ path and raises."""
 import torch
 from torch import nn
 
+from .. import ops
 from ..csr import adopt_csr
 from .fusion import CatFusion
 from .mlp import MLP
@@ -291,6 +292,9 @@ class SPT(nn.Module):
             if self.h_edge_mlps[i_stage] is not None and ea is not None:   # spt.py:827-835
                 one = B == 1 and self.norm_mode == "graph"              # one cloud: one graph
                 eb = None if (ni is None or one) else ni[ei[0]]
+                if eb is not None and B is not None and self.norm_mode == "graph" and eb.is_cuda:
+                    # sorted inside each third of [i<j | j>i | loops]: a handful of runs
+                    ops.graph_runs_via(eb, B, ei, ei, ni)
                 ea = self.h_edge_mlps[i_stage](ea, batch=eb, batch_size=B)
             node_x[i_level], edge_attrs[i_level] = xh, ea
             # the down stage and, later, the up stage of this level read the same edge_attr:

@@ -1171,13 +1171,114 @@ def graph_ranges(batch, num_graphs, rows):
     return ranges
 
 
+MAX_FUSED_RUNS = 16          # FMLP_MAX_RUNS of csrc/common.hpp
+
+
+class GraphRuns:
+    """Row ranges of constant graph id, sorted by graph: what one launch of the fused layer
+    kernels covers (``spt_fused_linear_*_runs_f32``).  ``sorted_batch``: one run per graph in
+    row order (a batch whose clouds are contiguous)."""
+
+    __slots__ = ("r0", "r1", "g", "B", "rows", "sorted_batch", "_c")
+
+    def __init__(self, runs, B, rows):
+        runs = sorted(runs, key=lambda t: (t[2], t[0]))
+        self.r0 = [int(t[0]) for t in runs]
+        self.r1 = [int(t[1]) for t in runs]
+        self.g = [int(t[2]) for t in runs]
+        self.B, self.rows = int(B), int(rows)
+        self.sorted_batch = (len(runs) <= self.B and
+                             all(self.r1[i] <= self.r0[i + 1] for i in range(len(runs) - 1)))
+        self._c = None
+
+    @property
+    def n(self):
+        return len(self.r0)
+
+    def c_arrays(self):
+        """(nruns, int64[] r0, int64[] r1, int32[] graph) for the C ABI (host arrays)."""
+        if self._c is None:
+            import ctypes
+            n = self.n
+            self._c = (n, (ctypes.c_int64 * n)(*self.r0), (ctypes.c_int64 * n)(*self.r1),
+                       (ctypes.c_int32 * n)(*self.g))
+        return self._c
+
+    def rows_per_graph(self):
+        out = [0] * self.B
+        for a, b, g in zip(self.r0, self.r1, self.g):
+            out[g] += b - a
+        return out
+
+
+def graph_runs(batch, num_graphs, rows):
+    """``GraphRuns`` of a per-row graph index, or None when it has more than 16 runs / graphs
+    (the caller then takes the layer-by-layer route).  ``batch`` may be sorted (one run per
+    cloud) or piecewise sorted (the edge MLP's norm index).  One host sync per batch tensor
+    (memoised on the tensor, like the CSR views)."""
+    if batch is None or (num_graphs is not None and int(num_graphs) == 1):
+        return GraphRuns([(0, rows, 0)], 1, rows)
+    B = int(num_graphs)
+    if B > MAX_FUSED_RUNS:
+        return None
+    memo = getattr(batch, _GRUN_ATTR, None)
+    key = (batch._version, B, batch.data_ptr(), batch.numel())
+    if memo is not None and memo[0] == key:
+        return memo[1]
+    runs = None
+    if batch.numel() == 0:
+        runs = GraphRuns([], B, 0)
+    else:
+        # run starts = positions where the id changes; read back only when there are few
+        change = (batch[1:] != batch[:-1])
+        n_change = int(change.sum())
+        if n_change + 1 <= MAX_FUSED_RUNS:
+            starts = [0] + (torch.nonzero(change).flatten() + 1).tolist()
+            ends = starts[1:] + [int(batch.numel())]
+            ids = batch[torch.tensor(starts, device=batch.device)].tolist()
+            if all(0 <= g < B for g in ids):
+                runs = GraphRuns(list(zip(starts, ends, ids)), B, batch.numel())
+    try:
+        setattr(batch, _GRUN_ATTR, (key, runs))
+    except Exception:
+        pass
+    return runs
+
+
+_GRUN_ATTR = "_spt_graph_runs"
+
+
+def graph_runs_via(batch, num_graphs, holder, *deps):
+    """``graph_runs(batch, ...)`` for a ``batch`` that is DERIVED from longer-lived tensors (the
+    edge MLP's ``norm_index[edge_index[0]]`` is rebuilt every forward): the run table - host
+    knowledge of the batch layout, like the row ranges of ``batch`` itself - is memoised on
+    ``holder`` (the edge_index) keyed by the versions of ``deps``, so only the first forward on a
+    batch pays the read-back."""
+    key = tuple((d._version, d.data_ptr(), d.numel()) for d in deps) + (int(num_graphs),)
+    memo = getattr(holder, _GRUN_ATTR + "_via", None)
+    if memo is not None and memo[0] == key:
+        runs = memo[1]
+    else:
+        runs = graph_runs(batch, num_graphs, batch.numel())
+        try:
+            setattr(holder, _GRUN_ATTR + "_via", (key, runs))
+        except Exception:
+            pass
+    try:
+        setattr(batch, _GRUN_ATTR, ((batch._version, int(num_graphs), batch.data_ptr(), batch.numel()), runs))
+    except Exception:
+        pass
+    return runs
+
+
 def fused_mlp_supported(dims):
     return all(_lib.lib.spt_fused_linear_supported(int(k), int(n))
                for k, n in zip(dims[:-1], dims[1:]))
 
 
-def _fmlp_forward(x, batch, ranges, eps_list, slope_list, params, apply_last=True, fmode=-1):
-    """Forward of the fused layer chain.  Returns (y or None, saved tensors, hs[-1], tables of
+def _fmlp_forward(x, batch, runs, eps_list, slope_list, params, apply_last=True, fmode=-1):
+    """Forward of the fused layer chain (``runs``: a ``GraphRuns``; ONE launch per layer whatever
+    the number of graphs).  Returns (y or None, saved tensors, hs[-1], tables of
     the last GraphNorm): with ``apply_last=False`` the last norm + activation are left to the
     consumer (the fused max-pool)."""
     L = len(eps_list)
@@ -1190,7 +1291,8 @@ def _fmlp_forward(x, batch, ranges, eps_list, slope_list, params, apply_last=Tru
         x2 = x2.float()
     R = x2.shape[0]
     dev = x2.device
-    B = len(ranges) - 1
+    B = runs.B
+    nr, c_r0, c_r1, c_g = runs.c_arrays()
     sp = _lib.stream_ptr(dev)
     hs, tabs = [], []
     cur, pre = x2, None
@@ -1202,17 +1304,16 @@ def _fmlp_forward(x, batch, ranges, eps_list, slope_list, params, apply_last=Tru
             total = torch.empty((B, 2 * N + 1), dtype=torch.float64, device=dev)
             nb = _lib.lib.spt_fused_linear_workspace_bytes(K, N)
             ws = _workspace(nb, dev)
-            for g in range(B):
-                pa = ps = pb = None
-                if pre is not None:
-                    pa, ps, pb = pre[0][g], pre[1][g], pre[2]
-                with _timed(f"fused_linear_fwd:{K}x{N}:{ranges[g + 1] - ranges[g]}"):
-                    st = _lib.lib.spt_fused_linear_fwd_ex_f32(
-                        _lib.ptr(cur), ranges[g], ranges[g + 1], K, _lib.ptr(Ws[l]), N,
-                        _lib.ptr(pa), _lib.ptr(ps), _lib.ptr(pb),
-                        float(slope_list[l - 1]) if l else 1.0, _lib.ptr(h),
-                        _lib.ptr(total[g]), fmode, _lib.ptr(ws), ws.numel(), sp)
-                _lib.check(st, "spt_fused_linear_fwd_ex_f32")
+            pa = ps = pb = None
+            if pre is not None:
+                pa, ps, pb = pre
+            with _timed(f"fused_linear_fwd:{K}x{N}:{R}"):
+                st = _lib.lib.spt_fused_linear_fwd_runs_f32(
+                    _lib.ptr(cur), nr, c_r0, c_r1, c_g, B, K, _lib.ptr(Ws[l]), N,
+                    _lib.ptr(pa), _lib.ptr(ps), _lib.ptr(pb),
+                    float(slope_list[l - 1]) if l else 1.0, _lib.ptr(h),
+                    _lib.ptr(total), fmode, _lib.ptr(ws), ws.numel(), sp)
+            _lib.check(st, "spt_fused_linear_fwd_runs_f32")
             mean = torch.empty((B, N), dtype=torch.float32, device=dev)
             rstd, am, sc = (torch.empty_like(mean) for _ in range(3))
             st = _lib.lib.spt_graphnorm_tables_f32(
@@ -1239,8 +1340,8 @@ def _fmlp_backward(saved, meta, gy, top_total=None, pooled=None):
     ``top_total``: statistics of the top GraphNorm's backward when the caller already has
     them (the max-pool route computes them from the pool's sparse gradient).
     ``pooled = (gout, arg, csr)``: the top layer consumes the pool's gradient directly
-    (``spt_fused_linear_bwd_pooled_f32``), ``gy`` is then None."""
-    L, ranges, slopes, in_dtype, need_gx0 = meta[:5]
+    (``spt_fused_linear_bwd_pooled_runs_f32``), ``gy`` is then None."""
+    L, runs, slopes, in_dtype, need_gx0 = meta[:5]
     fmode = meta[5] if len(meta) > 5 else -1          # the matrix mode the forward ran in
     sv = list(saved)
     x2, batch = sv[0], sv[1]
@@ -1250,7 +1351,8 @@ def _fmlp_backward(saved, meta, gy, top_total=None, pooled=None):
     Ws, gnw, gnb, gms = sv[o:o + L], sv[o + L:o + 2 * L], sv[o + 2 * L:o + 3 * L], sv[o + 3 * L:o + 4 * L]
     R = x2.shape[0]
     dev = x2.device
-    B = len(ranges) - 1
+    B = runs.B
+    nr, c_r0, c_r1, c_g = runs.c_arrays()
     sp = _lib.stream_ptr(dev)
     g_cur = gy.contiguous().float() if gy is not None else None
     grads = [None] * (4 * L)
@@ -1286,33 +1388,30 @@ def _fmlp_backward(saved, meta, gy, top_total=None, pooled=None):
             gW = torch.empty((N, K), dtype=torch.float32, device=dev)
             ptot = torch.empty((B, 2 * K + 1), dtype=torch.float64, device=dev) if l else None
             ws = _workspace(_lib.lib.spt_fused_linear_workspace_bytes(K, N), dev)
-            for g in range(B):
-                pa = ps = pb = None
-                if pre is not None:
-                    pa, ps, pb = pre[2][g], pre[3][g], gnb[l - 1]
-                if pooled is not None and l == L - 1:
-                    p_gout, p_arg, p_csr = pooled
-                    with _timed(f"fused_linear_bwd_pooled:{K}x{N}:{ranges[g + 1] - ranges[g]}"):
-                        st = _lib.lib.spt_fused_linear_bwd_pooled_ex_f32(
-                            _lib.ptr(p_gout), _lib.ptr(p_arg), _lib.ptr(p_csr.perm),
-                            _lib.ptr(p_csr.pos_seg()), _lib.ptr(hs[l]), ranges[g], ranges[g + 1], N,
-                            _lib.ptr(am[g]), _lib.ptr(sc[g]), _lib.ptr(gnb[l]), float(slopes[l]),
-                            _lib.ptr(c1[g]), _lib.ptr(c2[g]), _lib.ptr(c3[g]), _lib.ptr(xprev), K,
-                            _lib.ptr(pa), _lib.ptr(ps), _lib.ptr(pb),
-                            float(slopes[l - 1]) if l else 1.0, _lib.ptr(Ws[l]), _lib.ptr(gx),
-                            _lib.ptr(gW), 1 if g else 0, _lib.ptr(ptot[g]) if l else None,
-                            fmode, _lib.ptr(ws), ws.numel(), sp)
-                    _lib.check(st, "spt_fused_linear_bwd_pooled_ex_f32")
-                    continue
-                st = _lib.lib.spt_fused_linear_bwd_ex_f32(
-                    _lib.ptr(g_cur), _lib.ptr(hs[l]), ranges[g], ranges[g + 1], N,
-                    _lib.ptr(am[g]), _lib.ptr(sc[g]), _lib.ptr(gnb[l]), float(slopes[l]),
-                    _lib.ptr(c1[g]), _lib.ptr(c2[g]), _lib.ptr(c3[g]), _lib.ptr(xprev), K,
+            pa = ps = pb = None
+            if pre is not None:
+                pa, ps, pb = pre[2], pre[3], gnb[l - 1]
+            if pooled is not None and l == L - 1:
+                p_gout, p_arg, p_csr = pooled
+                with _timed(f"fused_linear_bwd_pooled:{K}x{N}:{R}"):
+                    st = _lib.lib.spt_fused_linear_bwd_pooled_runs_f32(
+                        _lib.ptr(p_gout), _lib.ptr(p_arg), _lib.ptr(p_csr.perm),
+                        _lib.ptr(p_csr.pos_seg()), _lib.ptr(hs[l]), nr, c_r0, c_r1, c_g, B, N,
+                        _lib.ptr(am), _lib.ptr(sc), _lib.ptr(gnb[l]), float(slopes[l]),
+                        _lib.ptr(c1), _lib.ptr(c2), _lib.ptr(c3), _lib.ptr(xprev), K,
+                        _lib.ptr(pa), _lib.ptr(ps), _lib.ptr(pb),
+                        float(slopes[l - 1]) if l else 1.0, _lib.ptr(Ws[l]), _lib.ptr(gx),
+                        _lib.ptr(gW), _lib.ptr(ptot), fmode, _lib.ptr(ws), ws.numel(), sp)
+                _lib.check(st, "spt_fused_linear_bwd_pooled_runs_f32")
+            else:
+                st = _lib.lib.spt_fused_linear_bwd_runs_f32(
+                    _lib.ptr(g_cur), _lib.ptr(hs[l]), nr, c_r0, c_r1, c_g, B, N,
+                    _lib.ptr(am), _lib.ptr(sc), _lib.ptr(gnb[l]), float(slopes[l]),
+                    _lib.ptr(c1), _lib.ptr(c2), _lib.ptr(c3), _lib.ptr(xprev), K,
                     _lib.ptr(pa), _lib.ptr(ps), _lib.ptr(pb),
                     float(slopes[l - 1]) if l else 1.0, _lib.ptr(Ws[l]), _lib.ptr(gx),
-                    _lib.ptr(gW), 1 if g else 0, _lib.ptr(ptot[g]) if l else None,
-                    fmode, _lib.ptr(ws), ws.numel(), sp)
-                _lib.check(st, "spt_fused_linear_bwd_ex_f32")
+                    _lib.ptr(gW), _lib.ptr(ptot), fmode, _lib.ptr(ws), ws.numel(), sp)
+                _lib.check(st, "spt_fused_linear_bwd_runs_f32")
             grads[4 * l], grads[4 * l + 1], grads[4 * l + 2], grads[4 * l + 3] = gW, gw_n, gb_n, ga_n
             if l:
                 g_cur, total = gx, ptot
@@ -1327,11 +1426,11 @@ class _FusedMLP(torch.autograd.Function):
     except the final output."""
 
     @staticmethod
-    def forward(ctx, x, batch, ranges, eps_list, slope_list, *params):
+    def forward(ctx, x, batch, runs, eps_list, slope_list, *params):
         fmode = _precision.fused_mode()
-        y, saved, _, _ = _fmlp_forward(x, batch, ranges, eps_list, slope_list, params, fmode=fmode)
+        y, saved, _, _ = _fmlp_forward(x, batch, runs, eps_list, slope_list, params, fmode=fmode)
         ctx.save_for_backward(*saved)
-        ctx.meta = (len(eps_list), ranges, list(slope_list), x.dtype, x.requires_grad, fmode)
+        ctx.meta = (len(eps_list), runs, list(slope_list), x.dtype, x.requires_grad, fmode)
         return y.to(x.dtype)
 
     @staticmethod
@@ -1347,9 +1446,9 @@ class _FusedMLPMaxPool(torch.autograd.Function):
     gradient to the arg rows, then the MLP backward."""
 
     @staticmethod
-    def forward(ctx, x, batch, ranges, eps_list, slope_list, csr, seg_graph, *params):
+    def forward(ctx, x, batch, runs, eps_list, slope_list, csr, seg_graph, *params):
         fmode = _precision.fused_mode()
-        _, saved, h_last, (am, sc, bs) = _fmlp_forward(x, batch, ranges, eps_list, slope_list,
+        _, saved, h_last, (am, sc, bs) = _fmlp_forward(x, batch, runs, eps_list, slope_list,
                                                         params, apply_last=False, fmode=fmode)
         R, N = h_last.shape
         dev = h_last.device
@@ -1365,27 +1464,26 @@ class _FusedMLPMaxPool(torch.autograd.Function):
         ctx.save_for_backward(arg, *saved)
         ctx.csr = csr
         ctx.seg_graph = seg_graph
-        ctx.meta = (len(eps_list), ranges, list(slope_list), x.dtype, x.requires_grad, fmode)
+        ctx.meta = (len(eps_list), runs, list(slope_list), x.dtype, x.requires_grad, fmode)
         return out.to(x.dtype)
 
     @staticmethod
     def backward(ctx, gout):
         arg, saved = ctx.saved_tensors[0], ctx.saved_tensors[1:]
-        L, ranges, slopes = ctx.meta[0], ctx.meta[1], ctx.meta[2]
+        L, runs, slopes = ctx.meta[0], ctx.meta[1], ctx.meta[2]
         h_last = saved[2 + L - 1]
         am, sc = saved[2 + L + 4 * (L - 1) + 2], saved[2 + L + 4 * (L - 1) + 3]
         gnb_last = saved[2 + 5 * L + 2 * L + (L - 1)]
         R, N = h_last.shape
         dev = h_last.device
-        B = len(ranges) - 1
+        B = runs.B
         gout = gout.contiguous().float()
         # statistics of the top GraphNorm's backward from the pool's SPARSE gradient (one
         # non-zero per (segment, channel)) instead of a pass over the dense [R, N] tensors
         total = None
         if N <= 256 and 256 % N == 0:
             total = torch.empty((B, 2 * N + 1), dtype=torch.float64, device=dev)
-            rows = torch.tensor([ranges[g + 1] - ranges[g] for g in range(B)], dtype=torch.int64,
-                                device=dev)
+            rows = torch.tensor(runs.rows_per_graph(), dtype=torch.int64, device=dev)
             nb = _lib.lib.spt_graphnorm_bwd_stats_sparse_workspace_bytes(ctx.csr.num_seg, N, B)
             ws = _workspace(nb, dev)
             with torch.cuda.device(dev):
@@ -1403,6 +1501,7 @@ class _FusedMLPMaxPool(torch.autograd.Function):
         K_top = saved[2 + 5 * L + (L - 1)].shape[1]
         pooled_ok = (total is not None and L > 1
                      and _lib.lib.spt_fused_linear_pooled_supported_ex(int(K_top), int(N), ctx.meta[5]) == 1
+                     and runs.sorted_batch
                      and (B == 1 or graph_ranges(ctx.seg_graph, B, ctx.csr.num_seg) is not None))
         if pooled_ok:
             gx0, grads = _fmlp_backward(saved, ctx.meta, None, top_total=total,
@@ -1415,19 +1514,21 @@ class _FusedMLPMaxPool(torch.autograd.Function):
 
 def fused_mlp(x, batch, num_graphs, layers):
     """``layers``: list of (linear_weight [N,K], gn_weight, gn_bias, gn_mean_scale, eps,
-    act_slope) - ``act_slope = 1`` for a layer without activation.  Returns None when
-    the fused path does not apply (unsorted batch, unbuilt shape): the caller then
-    runs the layer-by-layer HIP path."""
+    act_slope) - ``act_slope = 1`` for a layer without activation.  ``batch`` may be sorted
+    (clouds of a batch) or piecewise sorted (<= 16 runs of constant id: the edge MLP's norm
+    index): every layer is ONE launch per direction over all graphs.  Returns None when
+    the fused path does not apply (more runs / graphs than that, unbuilt shape): the caller
+    then runs the layer-by-layer HIP path."""
     if x.dim() != 2 or not x.is_cuda:
         return None
     dims = [layers[0][0].shape[1]] + [l[0].shape[0] for l in layers]
     if not fused_mlp_supported(dims):
         return None
-    ranges = graph_ranges(batch, num_graphs if batch is not None else 1, x.shape[0])
-    if ranges is None:
+    runs = graph_runs(batch, num_graphs if batch is not None else 1, x.shape[0])
+    if runs is None:
         return None
     params = [t for l in layers for t in l[:4]]
-    return _FusedMLP.apply(x, batch, ranges, [l[4] for l in layers], [l[5] for l in layers], *params)
+    return _FusedMLP.apply(x, batch, runs, [l[4] for l in layers], [l[5] for l in layers], *params)
 
 
 def fused_mlp_maxpool(x, batch, num_graphs, layers, index, num_seg, seg_graph=None):
@@ -1440,11 +1541,11 @@ def fused_mlp_maxpool(x, batch, num_graphs, layers, index, num_seg, seg_graph=No
     dims = [layers[0][0].shape[1]] + [l[0].shape[0] for l in layers]
     if not fused_mlp_supported(dims) or dims[-1] % 4 != 0:
         return None
-    ranges = graph_ranges(batch, num_graphs if batch is not None else 1, x.shape[0])
-    if ranges is None or (len(ranges) > 2 and seg_graph is None):
+    runs = graph_runs(batch, num_graphs if batch is not None else 1, x.shape[0])
+    if runs is None or (runs.B > 1 and seg_graph is None):
         return None
     csr = index if isinstance(index, SegmentCSR) else csr_of(index, num_seg)
-    sg = None if len(ranges) <= 2 else seg_graph.long().contiguous()
+    sg = None if runs.B <= 1 else seg_graph.long().contiguous()
     params = [t for l in layers for t in l[:4]]
-    return _FusedMLPMaxPool.apply(x, batch, ranges, [l[4] for l in layers],
+    return _FusedMLPMaxPool.apply(x, batch, runs, [l[4] for l in layers],
                                   [l[5] for l in layers], csr, sg, *params)

@@ -17,6 +17,10 @@ CASES = [
     ([18, 32, 32], 70_000, 2),           # h_edge_mlp
     ([132, 64, 64], 30_000, 4),          # down / up in_mlp
     ([68, 64, 64], 20_000, 1),
+    # piecewise-sorted index: the edge MLP of a 4-cloud batch, norm_index[edge_index[0]] sorted
+    # inside each third of [i<j | j>i | loops] (src/models/components/spt.py:829-836) = 12 runs
+    ([18, 32, 32], 60_000, -4),
+    ([12, 32, 64], 33_333, -3),
 ]
 
 
@@ -39,7 +43,12 @@ def test_fused_mlp_matches_oracle_and_unfused_path(dims, rows, B, gemm_mode, dev
         for p in mlp.parameters():
             p.add_(0.1 * torch.randn(p.shape, generator=g))
     x = torch.randn(rows, dims[0], generator=g) * 2 + 0.5
-    batch = (torch.arange(rows) * B // rows) if B > 1 else None          # sorted clouds
+    if B < 0:                                                            # three sorted thirds
+        B = -B
+        cuts = [0, rows // 3 + 7, 2 * rows // 3 - 5, rows]
+        batch = torch.cat([torch.arange(b - a) * B // (b - a) for a, b in zip(cuts[:-1], cuts[1:])])
+    else:
+        batch = (torch.arange(rows) * B // rows) if B > 1 else None      # sorted clouds
     gw = torch.randn(rows, dims[-1], generator=g)
 
     ref = copy.deepcopy(mlp).double()
@@ -107,14 +116,26 @@ def test_fused_mlp_matches_oracle_and_unfused_path(dims, rows, B, gemm_mode, dev
     close(gxf, gxu.double(), 1e-4, "gx fused vs unfused", outliers=few)
 
 
-def test_fused_mlp_falls_back_on_unsorted_batch(dev):
+def test_fused_mlp_runs_of_a_piecewise_sorted_batch(dev):
+    """The run table the fused kernels are launched with: one run per cloud of a sorted batch,
+    the runs of every graph together for a piecewise-sorted one, None (-> layer-by-layer route)
+    for an index with more than 16 runs."""
     from superpoint_transformer_amd import nn as N, ops
+    rows = 20000
+    sorted_b = (torch.arange(rows) * 3 // rows).to(dev)
+    r = ops.graph_runs(sorted_b, 3, rows)
+    assert r.sorted_batch and r.n == 3 and r.g == [0, 1, 2] and r.r0[0] == 0 and r.r1[-1] == rows
+    third = torch.arange(rows // 4) * 3 // (rows // 4)
+    piece = torch.cat([third, third, third, third]).to(dev)
+    r = ops.graph_runs(piece, 3, rows)
+    assert r is not None and not r.sorted_batch and r.n == 12 and r.g == sorted(r.g)
+    assert r.rows_per_graph() == [int((piece == g).sum()) for g in range(3)]
     mlp = N.MLP([12, 32, 64], norm=N.GraphNorm).to(dev)
-    x = torch.randn(20000, 12, device=dev)
-    batch = torch.randint(0, 3, (20000,), device=dev)
-    assert ops.graph_ranges(batch, 3, 20000) is None
+    x = torch.randn(rows, 12, device=dev)
+    batch = torch.randint(0, 3, (rows,), device=dev)
+    assert ops.graph_runs(batch, 3, rows) is None
     y = mlp(x, batch=batch, batch_size=3)            # layer-by-layer HIP path
-    assert y.shape == (20000, 64) and bool(torch.isfinite(y).all())
+    assert y.shape == (rows, 64) and bool(torch.isfinite(y).all())
 
 
 @pytest.mark.parametrize("rows,nseg,B", [(50_000, 1500, 1), (40_001, 900, 3)])
