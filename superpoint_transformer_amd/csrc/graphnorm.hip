@@ -518,7 +518,16 @@ struct GnPlan {
 static bool gn_plan(int64_t R, int d, int B, GnPlan* p) {
   if (!gn_shape(d, &p->sh)) return false;
   p->row_len = 2 * d + 1;
-  int64_t nb = ceil_div(R > 0 ? R : 1, (int64_t)p->sh.rpb * GN_UNR);
+  // one partial table per block: the finalize kernels walk them serially (16 slices), so a launch
+  // over few rows gets fewer, fatter blocks - at least four unrolled iterations each unless that
+  // leaves less than 128 blocks (train-batch sizes: 35 000 rows -> 137 tables instead of 547,
+  // the table reduction 26 -> ~8 us); large inputs keep the full grid
+  const int64_t per_iter = (int64_t)p->sh.rpb * GN_UNR;
+  int64_t nb = ceil_div(R > 0 ? R : 1, per_iter * 4);
+  if (nb < 128) {
+    nb = ceil_div(R > 0 ? R : 1, per_iter);
+    if (nb > 128) nb = 128;
+  }
   if (nb > GN_MAX_BLOCKS) nb = GN_MAX_BLOCKS;
   p->nblocks = (int)nb;
   size_t o = 0;

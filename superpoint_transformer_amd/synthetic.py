@@ -62,14 +62,28 @@ def _super_index(gen, n_child, n_parent, kind, device, shuffle):
     return idx
 
 
-def _edges(gen, n, e_target, device):
+def _edges(gen, n, e_target, device, cloud=None):
     """[2,E] directed edges incl. both directions and self loops, in the
     reference's final layout [i<j | j>i | loops] (transforms/graph.py:1268,
     :1442-1446): row 0 (source = softmax group) is unsorted.  Endpoints are drawn
-    UNIFORMLY (Poisson-like degrees around E / n, no spatial locality): the stress case."""
+    UNIFORMLY (Poisson-like degrees around E / n, no spatial locality): the stress case.
+    ``cloud`` [n] (sorted cloud id of every node, batches of several clouds): both endpoints of
+    an edge lie in ONE cloud and the stored (i < j) list is the concatenation of the clouds'
+    lists, as NAGBatch.from_nag_list builds it (src/data/nag.py:878-898) - each third of the
+    final layout is then sorted by cloud."""
     m = max((e_target - n) // 2, 0)
     a = torch.randint(0, n, (m,), generator=gen, device=device)
-    b = torch.randint(0, n, (m,), generator=gen, device=device)
+    if cloud is None:
+        b = torch.randint(0, n, (m,), generator=gen, device=device)
+    else:
+        nb = int(cloud.max()) + 1
+        size = torch.bincount(cloud, minlength=nb)
+        start = torch.cumsum(size, 0) - size
+        ca = cloud[a]
+        u = torch.rand(m, generator=gen, device=device)
+        b = start[ca] + (u * size[ca]).long().clamp_(max=size[ca] - 1)
+        order = torch.argsort(ca, stable=True)
+        a, b = a[order], b[order]
     keep = a != b
     a, b = a[keep], b[keep]
     lo, hi = torch.minimum(a, b), torch.maximum(a, b)
@@ -97,22 +111,28 @@ def _knn_indices(pos, k):
     return out
 
 
-def _edges_local(gen, pos, e_target, device):
+def _edges_local(gen, pos, e_target, device, cloud=None):
     """The superpoint graph of SURVEY 8(d): undirected edges between spatially nearest segment
     centroids (every node proposes its k nearest, mutual proposals merge, a random subset hits
-    the edge budget), then the reference's final layout [i<j | j>i | loops] like ``_edges``."""
+    the edge budget), then the reference's final layout [i<j | j>i | loops] like ``_edges``.
+    ``cloud``: neighbours are searched inside a node's own cloud only (the clouds of a batch are
+    moved 10 km apart for the search) and the (i < j) list is ordered by cloud."""
     n = pos.shape[0]
     m = max((e_target - n) // 2, 0)
     k = max(1, min(45, int(math.ceil(1.6 * m / max(n, 1)))))
-    nb = _knn_indices(pos, k).to(device)
+    spos = pos if cloud is None else pos + torch.stack(
+        [cloud.to(pos.dtype) * 1.0e4, torch.zeros_like(pos[:, 0]), torch.zeros_like(pos[:, 0])], 1)
+    nb = _knn_indices(spos, k).to(device)
     a = torch.arange(n, device=device).repeat_interleave(k)
     b = nb.reshape(-1)
     keep = (b >= 0) & (a != b)
+    if cloud is not None:
+        keep &= cloud[a] == cloud[b.clamp(min=0)]
     a, b = a[keep], b[keep]
     key = torch.unique(torch.minimum(a, b) * n + torch.maximum(a, b))
     if key.numel() > m:
-        key = key[torch.randperm(key.numel(), generator=gen, device=device)[:m]]
-    lo, hi = key // n, key % n
+        key = key[torch.randperm(key.numel(), generator=gen, device=device)[:m]].sort().values
+    lo, hi = key // n, key % n          # ascending lo: by cloud (the nodes of a cloud are contiguous)
     loops = torch.arange(n, device=device)
     return torch.stack([torch.cat([lo, hi, loops]), torch.cat([hi, lo, loops])])
 
@@ -206,12 +226,13 @@ def make_nag(scene="S", seed=1234, device="cpu", sizes=None, point_dim=8,
         raise ValueError("order must be 'storage' or 'morton'")
     ns1 = torch.bincount(si0, minlength=n1)
     ns2 = torch.zeros(n2, dtype=torch.long, device=device).index_add_(0, si1, ns1)
+    c1, c2 = (b1, b2) if b > 1 else (None, None)
     if graph == "local":
-        ei1 = _edges_local(gen, pos1, e1, device)
-        ei2 = _edges_local(gen, pos2, e2, device)
+        ei1 = _edges_local(gen, pos1, e1, device, c1)
+        ei2 = _edges_local(gen, pos2, e2, device, c2)
     elif graph == "random":
-        ei1 = _edges(gen, n1, e1, device)
-        ei2 = _edges(gen, n2, e2, device)
+        ei1 = _edges(gen, n1, e1, device, c1)
+        ei2 = _edges(gen, n2, e2, device, c2)
     else:
         raise ValueError("graph must be 'random' or 'local'")
 
