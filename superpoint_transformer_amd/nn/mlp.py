@@ -55,7 +55,7 @@ class MLP(nn.Module):
                 i += 2
         return out or None
 
-    FUSE_MIN_ROWS = 16384
+    FUSE_MIN_ROWS = 4096      # below that a layer is a few microseconds either way
 
     def forward_max_pooled(self, x, index, num_pool, batch=None, batch_size=None,
                            seg_graph=None):

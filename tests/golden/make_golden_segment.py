@@ -34,6 +34,10 @@ def main():
         G.geometric_features_torch(xyz, nn, k_min=k_min, k_step=k_step, k_min_search=k_min_search)
     gen = torch.Generator().manual_seed(20240607)
     torch.manual_seed(7)
+    # the reference's CPU sampler draws from numpy's GLOBAL generator (sparse_sample ->
+    # fast_randperm -> np.random.shuffle, src/utils/tensor.py:330-339): seed it, or two runs of
+    # this script store different draws
+    np.random.seed(20240607)
 
     out = {}
     # --- 1. sampling counts over a sweep of segment sizes ---------------------------------
