@@ -116,6 +116,13 @@ int spt_segcsr_max_affine_f32(const float* x, const int32_t* perm, const int32_t
                               const float* scale, const float* bias, float act_slope,
                               const int64_t* seg_graph, float* out, int32_t* arg,
                               spt_stream_t stream);
+/* Same with x stored as bf16 [n, c] (SPT_FMLP_H_BF16 below); built for c = 128, n >= 65 536. */
+int spt_segcsr_max_affine_bf16_supported(int c, int64_t n);
+int spt_segcsr_max_affine_bf16(const void* x_bf16, const int32_t* perm, const int32_t* rowptr,
+                               int64_t n, int64_t num_seg, int c, const float* am,
+                               const float* scale, const float* bias, float act_slope,
+                               const int64_t* seg_graph, float* out, int32_t* arg,
+                               spt_stream_t stream);
 int spt_segcsr_reduce_bwd_f32(int op, const float* gout, const int32_t* arg,
                               const int64_t* idx, const int32_t* perm,
                               const int32_t* rowptr, int64_t n, int64_t num_seg,
@@ -654,6 +661,12 @@ int spt_graphnorm_bwd_stats_sparse_f32(const float* x, const float* gout, const 
                                        const float* am, const float* scale, const float* bias,
                                        float act_slope, double* total, void* ws,
                                        size_t ws_bytes, spt_stream_t stream);
+/* x_is_bf16 != 0: x holds bf16 values (SPT_FMLP_H_BF16 below). */
+int spt_graphnorm_bwd_stats_sparse_ex_f32(
+    const void* x, int x_is_bf16, const float* gout, const int32_t* arg, const int64_t* seg_graph,
+    const int64_t* graph_rows, int64_t num_seg, int64_t n, int d, int num_graphs,
+    const float* am, const float* scale, const float* bias, float act_slope, double* total,
+    void* ws, size_t ws_bytes, spt_stream_t stream);
 int spt_graphnorm_bwd_tables_f32(const double* total, int num_graphs, int d, const float* weight,
                                  const float* mean_scale, const float* mean, const float* rstd,
                                  float* c1, float* c2, float* c3, float* gweight, float* gbias,
@@ -709,6 +722,15 @@ int spt_fused_linear_pooled_supported_ex(int K, int N, int mode);
  * inside a tile.  Process-wide: spt_fused_linear_bwd_use_dma(0 | 1) (< 0: query), returns the
  * previous setting; per call: OR SPT_FMLP_BWD_REGISTER_STAGED into the `mode` of the *_ex entries. */
 #define SPT_FMLP_BWD_REGISTER_STAGED 4
+/* bf16 ACTIVATION STORAGE (the reference's `precision: bf16`, configs/trainer/gpu.yaml:7-10: under
+ * autocast the Linear outputs ARE bf16 tensors).  With matrix mode 3 in the mode word of the *_ex /
+ * *_runs entries: SPT_FMLP_H_BF16 = the layer's raw output h is written (forward) / read (backward)
+ * as bf16 [rows, N]; SPT_FMLP_X_BF16 = the layer's input x / xprev holds bf16 values (the previous
+ * layer's h).  Statistics, gradients and tables stay f32 / f64.  spt_fused_linear_storage_supported:
+ * shapes built with this option (the point MLP's). */
+#define SPT_FMLP_H_BF16 8
+#define SPT_FMLP_X_BF16 16
+int spt_fused_linear_storage_supported(int K, int N);
 int spt_fused_linear_bwd_use_dma(int on);
 int spt_fused_linear_fwd_ex_f32(const float* x, int64_t r0, int64_t r1, int K, const float* W,
                                 int N, const float* pre_am, const float* pre_scale,

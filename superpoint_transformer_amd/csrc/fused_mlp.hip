@@ -39,16 +39,34 @@ __device__ __forceinline__ void wave_sync_lds() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// ---- activations stored as bf16 (the `bf16` precision mode's storage option) -------------------
+// four consecutive elements of a row as f32: a 16-byte load of f32 data, or an 8-byte load of
+// bf16 data widened (bf16 -> f32 is a 16-bit shift: exact)
+template <bool B16>
+__device__ __forceinline__ float4 ld4(const float* __restrict__ base, int64_t elem) {
+  if constexpr (B16) {
+    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + elem);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
+                       __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+  } else {
+    return *reinterpret_cast<const float4*>(base + elem);
+  }
+}
+__device__ __forceinline__ unsigned bf16_bits(float v) {       // round to nearest even
+  return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)v);
+}
+
 // Stage a [cnt x K] tile of row-major x into LDS (row stride LD) with the widest
 // aligned vector loads, optionally applying v <- leaky((v - am[k]) * sc[k] + bs[k])
 // with the per-column tables read from LDS (tab = am | sc | bs, KT floats each).
 // Rows >= cnt and columns >= K become 0.  RAW != nullptr also keeps the raw values.
 // IND: the tile's rows are x[rid] with rid held by lane rr of `rid_l` (a gathered tile).
-template <int KP, int LD, int KT, bool IND = false, int GRP = 4>
+// X16: x holds bf16 values (whole-chunk rows only: K == KP).
+template <int KP, int LD, int KT, bool IND = false, int GRP = 4, bool X16 = false>
 __device__ __forceinline__ void stage_tile(const float* __restrict__ x, int64_t row0, int cnt,
                                            int K, bool pre, const float* tab, float slope,
                                            float* lds, float* raw, int lane, int rid_l = 0) {
-  if (K == KP) {
+  if (K == KP || X16) {
     // whole rows of 16-byte chunks, trip count known: the loads of up to four chunks per lane
     // are issued together and consumed afterwards - ONE memory round trip per group instead of
     // one per chunk (in-kernel cycle counts: this loop, load -> use -> ds_write per chunk, was
@@ -63,7 +81,7 @@ __device__ __forceinline__ void stage_tile(const float* __restrict__ x, int64_t 
         v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i0 + j < NIT) {
           const int64_t xr = IND ? (int64_t)__shfl(rid_l, rr < TR ? rr : 0, 64) : row0 + rr;
-          if (q < TR * CH && rr < cnt) v[j] = *reinterpret_cast<const float4*>(x + xr * K + k);
+          if (q < TR * CH && rr < cnt) v[j] = ld4<X16>(x, xr * K + k);
         }
       }
 #pragma unroll
@@ -581,7 +599,12 @@ __device__ __forceinline__ f32x4 mfma3_16(const bf16x4& ah, const bf16x4& al, co
 
 // ---- forward: K padded to KS steps of 32, the weight block W[n][k] as split bf16 B operands
 // (lane (g, c): W[16 nb + c][32 ks + 8 g .. + 7]) resident for the whole launch -----------
-template <int K4, int NBK, bool LO>
+// IN16 / OUT16 (bf16 mode's storage option): x / h hold bf16 values.  The output tile then
+// leaves through the wave's A-tile buffer: values rounded to bf16 (the statistics are taken from
+// the ROUNDED values - what every consumer of h sees), lane pairs (c, c ^ 1) packed into 32-bit
+// words, rows padded by 16 bytes (bank-conflict-free both ways), stored as whole 16-byte chunks of
+// the tile's contiguous 16 x N region.
+template <int K4, int NBK, bool LO, bool IN16 = false, bool OUT16 = false>
 __global__ __launch_bounds__(WAVES * 64, 2) void fwd_kernel_bf(
     const float* __restrict__ x, int64_t r0, int64_t r1, int K, const float* __restrict__ W,
     const float* __restrict__ am, const float* __restrict__ sc, const float* __restrict__ bs,
@@ -626,7 +649,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void fwd_kernel_bf(
     const int64_t row0 = r0 + t * TR;
     const int cnt = (int)((r1 - row0) < TR ? (r1 - row0) : TR);
     wave_sync_lds();
-    stage_tile<KP32, LDA, KP32>(x, row0, cnt, K, pre, tab, slope, al, nullptr, lane);
+    stage_tile<KP32, LDA, KP32, false, 4, IN16>(x, row0, cnt, K, pre, tab, slope, al, nullptr, lane);
     wave_sync_lds();
     f32x4 C[NBK];
 #pragma unroll
@@ -641,17 +664,55 @@ __global__ __launch_bounds__(WAVES * 64, 2) void fwd_kernel_bf(
 #pragma unroll
       for (int nb = 0; nb < NBK; ++nb) C[nb] = mfma3_32<LO>(ah, alo, Bh[nb][ks], Bl[nb][ks], C[nb]);
     }
+    if constexpr (OUT16) {
+      constexpr int ROWB = 2 * N + 16;                    // bytes per row of the packed tile
+      static_assert(TR * ROWB <= TR * LDA * 4, "the packed output tile fits the A-tile buffer");
+      static_assert((TR * N / 8) % 64 == 0 || TR * N / 8 < 64, "whole 16-byte chunks");
+      wave_sync_lds();                                    // every lane has read its A operands
+      char* ob = reinterpret_cast<char*>(al);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int rr = 4 * g + r;
-      if (rr < cnt) {
-        float* hr = h + (row0 + rr) * N + c;
+      for (int r = 0; r < 4; ++r) {
+        const int rr = 4 * g + r;
 #pragma unroll
         for (int nb = 0; nb < NBK; ++nb) {
-          const float v = C[nb][r];
-          hr[16 * nb] = v;
-          s1[nb] += (double)v;
-          s2[nb] += (double)v * (double)v;
+          const unsigned mine = bf16_bits(C[nb][r]);
+          const float vr = __uint_as_float(mine << 16);
+          if (rr < cnt) {
+            s1[nb] += (double)vr;
+            s2[nb] += (double)vr * (double)vr;
+          }
+          // neighbour lane c ^ 1 (DPP quad_perm [1, 0, 3, 2]); the lane whose parity matches the
+          // row's packs the pair: even lanes rows 0 / 2, odd lanes rows 1 / 3
+          const unsigned other = (unsigned)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xF, 0xF, false);
+          if ((c & 1) == (r & 1)) {
+            const unsigned w = (c & 1) ? (other | (mine << 16)) : (mine | (other << 16));
+            *reinterpret_cast<unsigned*>(ob + rr * ROWB + (16 * nb + (c & ~1)) * 2) = w;
+          }
+        }
+      }
+      wave_sync_lds();
+      constexpr int CPR = N / 8;                          // 16-byte chunks per row
+      uint16_t* h16 = reinterpret_cast<uint16_t*>(h);
+#pragma unroll
+      for (int q = lane; q < TR * CPR; q += 64) {
+        const int rr = q / CPR, ch = q - rr * CPR;
+        if (rr < cnt)
+          *reinterpret_cast<uint4*>(h16 + (row0 + rr) * N + ch * 8) =
+              *reinterpret_cast<const uint4*>(ob + rr * ROWB + ch * 16);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rr = 4 * g + r;
+        if (rr < cnt) {
+          float* hr = h + (row0 + rr) * N + c;
+#pragma unroll
+          for (int nb = 0; nb < NBK; ++nb) {
+            const float v = C[nb][r];
+            hr[16 * nb] = v;
+            s1[nb] += (double)v;
+            s2[nb] += (double)v * (double)v;
+          }
         }
       }
     }
@@ -688,7 +749,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void fwd_kernel_bf(
 // is bound by memory LATENCY (937 k tiles x ~14 us / 2 048 waves = 6.4 ms at 64 -> 128), not by
 // bandwidth.  Needs K % 4 == 0 (16-byte row chunks) and one wave per SIMD (the prefetch
 // registers do not fit twice into 256).
-template <int K4, int NBK, bool NEED_GX, int NW, bool LO, bool POOLED = false, bool PIPE = false>
+// H16 / X16 (bf16 mode's storage option): h / xprev hold bf16 values (gy, gx stay f32).
+template <int K4, int NBK, bool NEED_GX, int NW, bool LO, bool POOLED = false, bool PIPE = false,
+          bool H16 = false, bool X16 = false>
 __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_kernel_bf(
     const float* __restrict__ gy, const float* __restrict__ h, int64_t r0, int64_t r1,
     const float* __restrict__ am, const float* __restrict__ sc, const float* __restrict__ bs,
@@ -775,6 +838,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_kernel_bf(
     }
     return make_float4(o4[0], o4[1], o4[2], o4[3]);
   };
+  static_assert(!(PIPE && (H16 || X16)), "the register-prefetch variant reads f32 rows");
   constexpr int CH = N / 4, CHX = KPP / 4;
   constexpr int HN = PIPE ? TR * CH / 64 : 1, XN = PIPE ? TR * CHX / 64 : 1;
   float4 p_h[HN], p_g[HN], p_x[XN];          // PIPE: raw chunks of the tile about to be staged
@@ -870,7 +934,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_kernel_bf(
           if constexpr (POOLED) av[j] = make_int4(-1, -1, -1, -1);
           if (rr < cnt) {
             const int64_t hr = POOLED ? (int64_t)ridv[j] : row0 + rr;
-            hv[j] = *reinterpret_cast<const float4*>(h + hr * N + n);
+            hv[j] = ld4<H16>(h, hr * N + n);
             if constexpr (POOLED) {
               av[j] = *reinterpret_cast<const int4*>(arg + sg * N + n);
               gv[j] = *reinterpret_cast<const float4*>(gout + sg * N + n);
@@ -896,8 +960,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_kernel_bf(
         }
       }
       FM_PROBE(0)
-      stage_tile<KPP, LDX, KPP, POOLED, (POOLED && NBK >= 8) ? 2 : 4>(xprev, row0, cnt, K, false, pt, pslope, xl,
-                                                                        nullptr, lane, rid_l);
+      stage_tile<KPP, LDX, KPP, POOLED, (POOLED && NBK >= 8) ? 2 : 4, X16>(xprev, row0, cnt, K, false, pt,
+                                                                             pslope, xl, nullptr, lane, rid_l);
       FM_PROBE(1)
     }
     const int rid_cur = rid_l;                 // the gx scatter below needs this tile's row ids
@@ -1144,6 +1208,20 @@ extern "C" int spt_fused_linear_pooled_supported_ex(int K, int N, int mode) {
   return 0;
 }
 
+// bf16 ACTIVATION STORAGE (precision mode 3 only): bit 3 of the mode word = h is read / written as
+// bf16, bit 4 = x / xprev holds bf16 values.  Built for the point MLP's shapes (the level-0 chain
+// carries ~90 % of a step's activation bytes); register-staged backward.
+#define SPT_FMLP_ST_SHAPES(X) X(3, 2) X(8, 4) X(16, 8) X(16, 4)
+#define SPT_FMLP_ST_POOLED_SHAPES(X) X(16, 8) X(16, 4) X(8, 4)
+extern "C" int spt_fused_linear_storage_supported(int K, int N) {
+  const int k4 = (K + 3) / 4, nbk = N / 16;
+  if (N % 16) return 0;
+#define X(a, b) if (k4 == a && nbk == b) return 1;
+  SPT_FMLP_ST_SHAPES(X)
+#undef X
+  return 0;
+}
+
 extern "C" int spt_fused_linear_supported(int K, int N) {
   const int k4 = (K + 3) / 4, nbk = N / 16;
   if (N % 16) return 0;
@@ -1214,6 +1292,27 @@ static int fmlp_fwd_impl(const char* fn, const float* x, const FmlpRuns& rt, int
   if (gx_ > cap) gx_ = cap;
   const dim3 grid((unsigned)gx_, (unsigned)rt.n);
   double* partial = (double*)ws;
+  const bool h16 = mode >= 0 && (mode & SPT_FMLP_H_BF16), x16 = mode >= 0 && (mode & SPT_FMLP_X_BF16);
+  if (h16 || x16) {
+    SPT_CHECK_ARG(g_fmlp_mode == 3 && h16 && spt_fused_linear_storage_supported(K, N) &&
+                  (!x16 || K % 32 == 0),
+                  "bf16 activation storage: bf16 matrix mode, a built shape, h stored as bf16");
+#define XS(a, b)                                                                                   \
+  if (k4 == a && nbk == b) {                                                                       \
+    if (x16)                                                                                       \
+      fwd_kernel_bf<a, b, false, true, true><<<grid, WAVES * 64, 0, stream>>>(                     \
+          x, 0, 0, K, W, pre_am, pre_scale, pre_bias, pre_slope, h, partial, rt);                  \
+    else                                                                                           \
+      fwd_kernel_bf<a, b, false, false, true><<<grid, WAVES * 64, 0, stream>>>(                    \
+          x, 0, 0, K, W, pre_am, pre_scale, pre_bias, pre_slope, h, partial, rt);                  \
+  }
+    SPT_FMLP_ST_SHAPES(XS)
+#undef XS
+    reduce_tables_groups_kernel<double><<<dim3((2 * N + 1 + 15) / 16, num_graphs), 1024, 0, stream>>>(
+        partial, fmlp_groups(rt, num_graphs, gx_), 2 * N + 1, total);
+    SPT_CHECK_LAUNCH();
+    return 0;
+  }
 #define X(a, b)                                                                        \
   if (k4 == a && nbk == b) {                                                           \
     if (g_fmlp_mode == 3)                                                              \
@@ -1367,7 +1466,58 @@ static int fmlp_bwd_impl(bool pooled, const float* gy, const float* gout, const 
           pre_bias, pre_slope, W, nullptr, gwp, nullptr, rt);                                    \
   }
   int per_run = 0;                              // wave records per run
-  if (g_fmlp_split_bf16 && gx && fmlp_dma_of(mode) && fmlp_dma_supported(K, N)) {
+  const bool h16 = mode >= 0 && (mode & SPT_FMLP_H_BF16), x16 = mode >= 0 && (mode & SPT_FMLP_X_BF16);
+  if (h16 || x16) {
+    SPT_CHECK_ARG(g_fmlp_mode == 3 && h16 && spt_fused_linear_storage_supported(K, N) &&
+                  (!x16 || K % 16 == 0),
+                  "bf16 activation storage: bf16 matrix mode, a built shape, h stored as bf16");
+#define XSP(a, b)                                                                                \
+  if (pooled && k4 == a && nbk == b) {                                                           \
+    constexpr bool big = (a * b >= 32);                                                          \
+    constexpr int NWB = (a * b > 128) ? 4 : (big ? 8 : 4);                                       \
+    gx_ = cap_grid(grid_for_nw(max_rows, (a * b > 128) ? 1 : (big ? ((a * b <= 32) ? 2 : 1) : 4), NWB), NWB); \
+    nwv = NWB;                                                                                   \
+    const dim3 grid((unsigned)gx_, (unsigned)nr);                                                \
+    if (x16)                                                                                     \
+      bwd_kernel_bf<a, b, true, NWB, false, true, false, true, true><<<grid, NWB * 64, 0, stream>>>( \
+          nullptr, h, 0, 0, am, scale, bias, slope, c1, c2, c3, xprev, K, pre_am, pre_scale,     \
+          pre_bias, pre_slope, W, gx, gwp, pstp, rt, perm, pos_seg, gout, arg);                  \
+    else                                                                                         \
+      bwd_kernel_bf<a, b, true, NWB, false, true, false, true, false><<<grid, NWB * 64, 0, stream>>>( \
+          nullptr, h, 0, 0, am, scale, bias, slope, c1, c2, c3, xprev, K, pre_am, pre_scale,     \
+          pre_bias, pre_slope, W, gx, gwp, pstp, rt, perm, pos_seg, gout, arg);                  \
+  }
+#define XSD(a, b)                                                                                \
+  if (!pooled && k4 == a && nbk == b) {                                                          \
+    constexpr bool big = (a * b >= 32);                                                          \
+    constexpr int NWV = big ? 8 : 4;                                                             \
+    constexpr int NWB = (a * b > 128) ? 4 : NWV;                                                 \
+    gx_ = cap_grid(grid_for_nw(max_rows, (a * b > 128) ? 1 : (big ? ((a * b <= 32) ? 2 : 1) : 4), NWB), NWB); \
+    nwv = NWB;                                                                                   \
+    const dim3 grid((unsigned)gx_, (unsigned)nr);                                                \
+    if (gx && x16)                                                                               \
+      bwd_kernel_bf<a, b, true, NWB, false, false, false, true, true><<<grid, NWB * 64, 0, stream>>>( \
+          gy, h, 0, 0, am, scale, bias, slope, c1, c2, c3, xprev, K, pre_am, pre_scale,          \
+          pre_bias, pre_slope, W, gx, gwp, pstp, rt);                                            \
+    else if (gx)                                                                                 \
+      bwd_kernel_bf<a, b, true, NWB, false, false, false, true, false><<<grid, NWB * 64, 0, stream>>>( \
+          gy, h, 0, 0, am, scale, bias, slope, c1, c2, c3, xprev, K, pre_am, pre_scale,          \
+          pre_bias, pre_slope, W, gx, gwp, pstp, rt);                                            \
+    else if (x16)                                                                                \
+      bwd_kernel_bf<a, b, false, NWB, false, false, false, true, true><<<grid, NWB * 64, 0, stream>>>( \
+          gy, h, 0, 0, am, scale, bias, slope, c1, c2, c3, xprev, K, pre_am, pre_scale,          \
+          pre_bias, pre_slope, W, nullptr, gwp, nullptr, rt);                                    \
+    else                                                                                         \
+      bwd_kernel_bf<a, b, false, NWB, false, false, false, true, false><<<grid, NWB * 64, 0, stream>>>( \
+          gy, h, 0, 0, am, scale, bias, slope, c1, c2, c3, xprev, K, pre_am, pre_scale,          \
+          pre_bias, pre_slope, W, nullptr, gwp, nullptr, rt);                                    \
+  }
+    SPT_FMLP_ST_POOLED_SHAPES(XSP)
+    SPT_FMLP_ST_SHAPES(XSD)
+#undef XSP
+#undef XSD
+    per_run = gx_ * nwv;
+  } else if (g_fmlp_split_bf16 && gx && fmlp_dma_of(mode) && fmlp_dma_supported(K, N)) {
     per_run = fmlp_dma_bwd_launch(pooled, g_fmlp_mode != 3, gy, h, rt, max_rows, N, am, scale, bias,
                                   slope, c1, c2, c3, xprev, K, pre_am, pre_scale, pre_bias, pre_slope,
                                   W, gx, gwp, pstp, perm, pos_seg, gout, arg, stream);

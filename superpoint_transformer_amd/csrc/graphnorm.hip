@@ -764,6 +764,7 @@ extern "C" int spt_graphnorm_bwd_stats_f32(const float* x, const float* gy, cons
 // from (gout, arg) and a gather of the raw rows - num_seg*d elements instead of a pass over
 // the [r, d] tensors (15.4 GB at scene S).  Layout and meaning of `total` as above; the row
 // count of graph b is graph_rows[b].
+template <bool X16>
 __global__ __launch_bounds__(256) void gn_bwd_stats_sparse_kernel(
     const float* __restrict__ x, const float* __restrict__ gout,
     const int32_t* __restrict__ arg, const int64_t* __restrict__ seg_graph, int64_t num_seg,
@@ -796,7 +797,9 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_sparse_kernel(
     }
     const int64_t i = arg[s * d + c];
     if (i < 0 || i >= n) continue;         // empty segment: sentinel n
-    const float o = x[i * d + c] - t_am;
+    const float xv = X16 ? __uint_as_float((unsigned)reinterpret_cast<const uint16_t*>(x)[i * d + c] << 16)
+                         : x[i * d + c];
+    const float o = xv - t_am;
     float g = gout[s * d + c];
     if (slope != 1.f) {
       const float y = fmaf(o, t_sc, t_bs);
@@ -828,6 +831,17 @@ extern "C" int spt_graphnorm_bwd_stats_sparse_f32(
     const int64_t* graph_rows, int64_t num_seg, int64_t n, int d, int num_graphs,
     const float* am, const float* scale, const float* bias, float act_slope, double* total,
     void* ws, size_t ws_bytes, spt_stream_t stream_) {
+  return spt_graphnorm_bwd_stats_sparse_ex_f32(x, 0, gout, arg, seg_graph, graph_rows, num_seg, n, d,
+                                               num_graphs, am, scale, bias, act_slope, total, ws,
+                                               ws_bytes, stream_);
+}
+// x_is_bf16 != 0: x holds bf16 values (the fused layers' activation storage option)
+extern "C" int spt_graphnorm_bwd_stats_sparse_ex_f32(
+    const void* x_, int x_is_bf16, const float* gout, const int32_t* arg, const int64_t* seg_graph,
+    const int64_t* graph_rows, int64_t num_seg, int64_t n, int d, int num_graphs,
+    const float* am, const float* scale, const float* bias, float act_slope, double* total,
+    void* ws, size_t ws_bytes, spt_stream_t stream_) {
+  const float* x = reinterpret_cast<const float*>(x_);
   hipStream_t stream = (hipStream_t)stream_;
   const int B = num_graphs;
   SPT_CHECK_ARG(num_seg >= 0 && n >= 0 && B >= 1, "bad shape");
@@ -843,8 +857,12 @@ extern "C" int spt_graphnorm_bwd_stats_sparse_f32(
   const int cap = gn_graphs_per_launch(row_len);
   for (int b_lo = 0; b_lo < B; b_lo += cap) {
     const int Bc = (B - b_lo < cap) ? B - b_lo : cap;
-    gn_bwd_stats_sparse_kernel<<<(int)nb, 256, (size_t)Bc * row_len * 8, stream>>>(
-        x, gout, arg, seg_graph, num_seg, n, d, B, am, scale, bias, act_slope, partial, b_lo, Bc);
+    if (x_is_bf16)
+      gn_bwd_stats_sparse_kernel<true><<<(int)nb, 256, (size_t)Bc * row_len * 8, stream>>>(
+          x, gout, arg, seg_graph, num_seg, n, d, B, am, scale, bias, act_slope, partial, b_lo, Bc);
+    else
+      gn_bwd_stats_sparse_kernel<false><<<(int)nb, 256, (size_t)Bc * row_len * 8, stream>>>(
+          x, gout, arg, seg_graph, num_seg, n, d, B, am, scale, bias, act_slope, partial, b_lo, Bc);
   }
   gn_reduce_partials_kernel<<<dim3(B, (row_len + 15) / 16), 256, 0, stream>>>(partial, (int)nb, B,
                                                                            row_len, total);

@@ -350,7 +350,9 @@ __global__ __launch_bounds__(256) void segcsr_reduce_kernel(
 // lanes).  Same combine rule, same affine expression, bit-identical results.
 // segments [sa, sb) of one graph (one set of coefficient rows): their rows are the contiguous
 // CSR positions [rowptr[sa], rowptr[sb])
-template <bool AFF>
+// X16: the rows hold bf16 values (the bf16 mode's activation storage): 8-byte loads widened
+// to f32 on the way in (exact), everything else unchanged.
+template <bool AFF, bool X16 = false>
 __device__ __forceinline__ void segmax_stream_range(
     const float* __restrict__ x, const int32_t* __restrict__ perm,
     const int32_t* __restrict__ rowptr, int64_t n, int64_t num_seg, float* __restrict__ out,
@@ -450,7 +452,18 @@ __device__ __forceinline__ void segmax_stream_range(
     // a load under a per-lane condition is followed by a wait and a select, which serialises the
     // eight loads of the chunk
 #pragma unroll
-    for (int q = 0; q < CHK / 2; ++q) v[q] = ldv<V>(x + (int64_t)row_of(q) * C + c0);
+    for (int q = 0; q < CHK / 2; ++q) {
+      if constexpr (X16) {
+        const uint2 u = *reinterpret_cast<const uint2*>(
+            reinterpret_cast<const uint16_t*>(x) + (int64_t)row_of(q) * C + c0);
+        v[q].v[0] = __uint_as_float(u.x << 16);
+        v[q].v[1] = __uint_as_float(u.x & 0xffff0000u);
+        v[q].v[2] = __uint_as_float(u.y << 16);
+        v[q].v[3] = __uint_as_float(u.y & 0xffff0000u);
+      } else {
+        v[q] = ldv<V>(x + (int64_t)row_of(q) * C + c0);
+      }
+    }
 #pragma unroll
     for (int q = 0; q < CHK / 2; ++q) {
       const int64_t p0 = j + 2 * q;
@@ -472,7 +485,7 @@ __device__ __forceinline__ void segmax_stream_range(
   }
 }
 
-template <bool AFF>
+template <bool AFF, bool X16 = false>
 __global__ __launch_bounds__(256, 5) void segmax_stream_kernel(
     const float* __restrict__ x, const int32_t* __restrict__ perm,
     const int32_t* __restrict__ rowptr, int64_t n, int64_t num_seg, float* __restrict__ out,
@@ -520,8 +533,8 @@ __global__ __launch_bounds__(256, 5) void segmax_stream_kernel(
         t_bs[k] = af.bs[c0 + k];
       }
     }
-    segmax_stream_range<AFF>(x, perm, rowptr, n, num_seg, out, arg, s_lo, s_hi, t_am, t_sc, t_bs,
-                             af.slope, lane);
+    segmax_stream_range<AFF, X16>(x, perm, rowptr, n, num_seg, out, arg, s_lo, s_hi, t_am, t_sc, t_bs,
+                                  af.slope, lane);
     s_lo = s_hi;
   }
 }
@@ -546,7 +559,7 @@ static bool seg_stream_on() {
 static bool seg_stream_shape(int c, int64_t n, bool want_arg) {
   return seg_stream_on() && c == 128 && want_arg && n >= (1 << 16);
 }
-template <bool AFF>
+template <bool AFF, bool X16 = false>
 static void launch_stream(const float* x, const int32_t* perm, const int32_t* rowptr, int64_t n,
                           int64_t num_seg, float* out, int32_t* arg, const Affine& af,
                           hipStream_t stream) {
@@ -562,8 +575,8 @@ static void launch_stream(const float* x, const int32_t* perm, const int32_t* ro
   if (waves * 256 > n) waves = n / 256 > 4 ? n / 256 : 4;
   const int grid = (int)ceil_div(waves, (int64_t)4);
   const int64_t rows_per_wave = n / ((int64_t)grid * 4) + 1;
-  segmax_stream_kernel<AFF><<<grid, 256, 0, stream>>>(x, perm, rowptr, n, num_seg, out, arg, af,
-                                                      rows_per_wave);
+  segmax_stream_kernel<AFF, X16><<<grid, 256, 0, stream>>>(x, perm, rowptr, n, num_seg, out, arg, af,
+                                                           rows_per_wave);
 }
 
 // Row-parallel "gather with modifier":
@@ -894,6 +907,30 @@ extern "C" int spt_segcsr_max_affine_f32(const float* x, const int32_t* perm,
   else
     segcsr_reduce_kernel<SPT_MAX, 4, true, true><<<grid, 256, 0, stream>>>(
         x, perm, rowptr, n, num_seg, c, rs.lpr_log2, rpg_log2, out, arg, af);
+  SPT_CHECK_LAUNCH();
+  return 0;
+}
+
+// Same with x stored as bf16 [n, c] (the fused layers' activation storage option): the streaming
+// kernel only - c = 128, n >= 65 536, as spt_segcsr_max_affine_bf16_supported reports.
+extern "C" int spt_segcsr_max_affine_bf16_supported(int c, int64_t n) {
+  return seg_stream_shape(c, n, true) ? 1 : 0;
+}
+extern "C" int spt_segcsr_max_affine_bf16(const void* x_bf16, const int32_t* perm,
+                                          const int32_t* rowptr, int64_t n, int64_t num_seg,
+                                          int c, const float* am, const float* scale,
+                                          const float* bias, float act_slope,
+                                          const int64_t* seg_graph, float* out, int32_t* arg,
+                                          spt_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPT_CHECK_ARG(n >= 0 && num_seg >= 0, "bad shape");
+  SPT_CHECK_ARG(spt_segcsr_max_affine_bf16_supported(c, n), "bf16 rows: c = 128 and n >= 65536 only");
+  SPT_CHECK_ARG(rowptr && out && arg && am && scale && bias && x_bf16, "null pointer");
+  if (num_seg == 0) return 0;
+  Affine af;
+  af.am = am; af.sc = scale; af.bs = bias; af.seg_graph = seg_graph; af.slope = act_slope;
+  launch_stream<true, true>(reinterpret_cast<const float*>(x_bf16), perm, rowptr, n, num_seg, out, arg,
+                            af, stream);
   SPT_CHECK_LAUNCH();
   return 0;
 }

@@ -1276,7 +1276,11 @@ def fused_mlp_supported(dims):
                for k, n in zip(dims[:-1], dims[1:]))
 
 
-def _fmlp_forward(x, batch, runs, eps_list, slope_list, params, apply_last=True, fmode=-1):
+_ST_H, _ST_X = 8, 16          # SPT_FMLP_H_BF16 / SPT_FMLP_X_BF16 of include/spt_hip.h
+
+
+def _fmlp_forward(x, batch, runs, eps_list, slope_list, params, apply_last=True, fmode=-1,
+                  store16=False):
     """Forward of the fused layer chain (``runs``: a ``GraphRuns``; ONE launch per layer whatever
     the number of graphs).  Returns (y or None, saved tensors, hs[-1], tables of
     the last GraphNorm): with ``apply_last=False`` the last norm + activation are left to the
@@ -1300,7 +1304,10 @@ def _fmlp_forward(x, batch, runs, eps_list, slope_list, params, apply_last=True,
     with torch.cuda.device(dev):
         for l in range(L):
             N, K = Ws[l].shape
-            h = torch.empty((R, N), dtype=torch.float32, device=dev)
+            # store16: raw layer outputs kept as bf16 (bf16 matrix mode: 3), read as bf16 by the
+            # next layer (its x), the pool and the backward
+            h = torch.empty((R, N), dtype=torch.bfloat16 if store16 else torch.float32, device=dev)
+            lmode = (3 | _ST_H | (_ST_X if l else 0)) if store16 else fmode
             total = torch.empty((B, 2 * N + 1), dtype=torch.float64, device=dev)
             nb = _lib.lib.spt_fused_linear_workspace_bytes(K, N)
             ws = _workspace(nb, dev)
@@ -1312,7 +1319,7 @@ def _fmlp_forward(x, batch, runs, eps_list, slope_list, params, apply_last=True,
                     _lib.ptr(cur), nr, c_r0, c_r1, c_g, B, K, _lib.ptr(Ws[l]), N,
                     _lib.ptr(pa), _lib.ptr(ps), _lib.ptr(pb),
                     float(slope_list[l - 1]) if l else 1.0, _lib.ptr(h),
-                    _lib.ptr(total), fmode, _lib.ptr(ws), ws.numel(), sp)
+                    _lib.ptr(total), lmode, _lib.ptr(ws), ws.numel(), sp)
             _lib.check(st, "spt_fused_linear_fwd_runs_f32")
             mean = torch.empty((B, N), dtype=torch.float32, device=dev)
             rstd, am, sc = (torch.empty_like(mean) for _ in range(3))
@@ -1324,6 +1331,7 @@ def _fmlp_forward(x, batch, runs, eps_list, slope_list, params, apply_last=True,
             tabs.append((mean, rstd, am, sc))
             cur, pre = h, (am, sc, gnb[l])
         if apply_last:
+            assert not store16, "bf16 storage: the last norm is applied by the consumer (the pool)"
             N = Ws[-1].shape[0]
             y = torch.empty((R, N), dtype=torch.float32, device=dev)
             st = _lib.lib.spt_graphnorm_apply_f32(
@@ -1343,6 +1351,7 @@ def _fmlp_backward(saved, meta, gy, top_total=None, pooled=None):
     (``spt_fused_linear_bwd_pooled_runs_f32``), ``gy`` is then None."""
     L, runs, slopes, in_dtype, need_gx0 = meta[:5]
     fmode = meta[5] if len(meta) > 5 else -1          # the matrix mode the forward ran in
+    store16 = bool(meta[6]) if len(meta) > 6 else False   # layer outputs stored as bf16
     sv = list(saved)
     x2, batch = sv[0], sv[1]
     hs = sv[2:2 + L]
@@ -1364,6 +1373,7 @@ def _fmlp_backward(saved, meta, gy, top_total=None, pooled=None):
         if top_total is not None:
             total = top_total
         else:
+            assert not store16, "bf16 storage: the top statistics come from the sparse route"
             total = torch.empty((B, 2 * N + 1), dtype=torch.float64, device=dev)
             ws = _workspace(_lib.lib.spt_graphnorm_workspace_bytes(R, N, B), dev)
             st = _lib.lib.spt_graphnorm_bwd_stats_f32(
@@ -1391,6 +1401,7 @@ def _fmlp_backward(saved, meta, gy, top_total=None, pooled=None):
             pa = ps = pb = None
             if pre is not None:
                 pa, ps, pb = pre[2], pre[3], gnb[l - 1]
+            lmode = (3 | _ST_H | (_ST_X if l else 0)) if store16 else fmode
             if pooled is not None and l == L - 1:
                 p_gout, p_arg, p_csr = pooled
                 with _timed(f"fused_linear_bwd_pooled:{K}x{N}:{R}"):
@@ -1401,7 +1412,7 @@ def _fmlp_backward(saved, meta, gy, top_total=None, pooled=None):
                         _lib.ptr(c1), _lib.ptr(c2), _lib.ptr(c3), _lib.ptr(xprev), K,
                         _lib.ptr(pa), _lib.ptr(ps), _lib.ptr(pb),
                         float(slopes[l - 1]) if l else 1.0, _lib.ptr(Ws[l]), _lib.ptr(gx),
-                        _lib.ptr(gW), _lib.ptr(ptot), fmode, _lib.ptr(ws), ws.numel(), sp)
+                        _lib.ptr(gW), _lib.ptr(ptot), lmode, _lib.ptr(ws), ws.numel(), sp)
                 _lib.check(st, "spt_fused_linear_bwd_pooled_runs_f32")
             else:
                 st = _lib.lib.spt_fused_linear_bwd_runs_f32(
@@ -1410,7 +1421,7 @@ def _fmlp_backward(saved, meta, gy, top_total=None, pooled=None):
                     _lib.ptr(c1), _lib.ptr(c2), _lib.ptr(c3), _lib.ptr(xprev), K,
                     _lib.ptr(pa), _lib.ptr(ps), _lib.ptr(pb),
                     float(slopes[l - 1]) if l else 1.0, _lib.ptr(Ws[l]), _lib.ptr(gx),
-                    _lib.ptr(gW), _lib.ptr(ptot), fmode, _lib.ptr(ws), ws.numel(), sp)
+                    _lib.ptr(gW), _lib.ptr(ptot), lmode, _lib.ptr(ws), ws.numel(), sp)
                 _lib.check(st, "spt_fused_linear_bwd_runs_f32")
             grads[4 * l], grads[4 * l + 1], grads[4 * l + 2], grads[4 * l + 3] = gW, gw_n, gb_n, ga_n
             if l:
@@ -1448,23 +1459,38 @@ class _FusedMLPMaxPool(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, batch, runs, eps_list, slope_list, csr, seg_graph, *params):
         fmode = _precision.fused_mode()
+        # bf16 mode: the raw layer outputs are STORED as bf16 where every kernel of the chain is
+        # built for it (the point MLP in front of the L0 -> L1 pool)
+        L = len(eps_list)
+        dims = [params[0].shape[1]] + [params[4 * i].shape[0] for i in range(L)]
+        store16 = bool(
+            _precision.bf16_activation_storage()
+            and all(_lib.lib.spt_fused_linear_storage_supported(int(k), int(n))
+                    for k, n in zip(dims[:-1], dims[1:]))
+            and all(int(k) % 32 == 0 for k in dims[1:-1])
+            and 256 % int(dims[-1]) == 0
+            and _lib.lib.spt_segcsr_max_affine_bf16_supported(int(dims[-1]), x.shape[0]))
         _, saved, h_last, (am, sc, bs) = _fmlp_forward(x, batch, runs, eps_list, slope_list,
-                                                        params, apply_last=False, fmode=fmode)
+                                                        params, apply_last=False, fmode=fmode,
+                                                        store16=store16)
         R, N = h_last.shape
         dev = h_last.device
         out = torch.empty((csr.num_seg, N), dtype=torch.float32, device=dev)
         arg = torch.empty((csr.num_seg, N), dtype=torch.int32, device=dev)
         # same timer key as the plain segment-max: this IS the L0 -> L1 pool launch
+        seg_max = (_lib.lib.spt_segcsr_max_affine_bf16 if store16
+                   else _lib.lib.spt_segcsr_max_affine_f32)
         with torch.cuda.device(dev), _timed(f"segcsr_reduce_fwd:3:{R}x{N}"):
-            st = _lib.lib.spt_segcsr_max_affine_f32(
+            st = seg_max(
                 _lib.ptr(h_last), _lib.ptr(csr.perm), _lib.ptr(csr.rowptr), R, csr.num_seg, N,
                 _lib.ptr(am), _lib.ptr(sc), _lib.ptr(bs), float(slope_list[-1]),
                 _lib.ptr(seg_graph), _lib.ptr(out), _lib.ptr(arg), _lib.stream_ptr(dev))
-        _lib.check(st, "spt_segcsr_max_affine_f32")
+        _lib.check(st, "spt_segcsr_max_affine")
         ctx.save_for_backward(arg, *saved)
         ctx.csr = csr
         ctx.seg_graph = seg_graph
-        ctx.meta = (len(eps_list), runs, list(slope_list), x.dtype, x.requires_grad, fmode)
+        ctx.meta = (len(eps_list), runs, list(slope_list), x.dtype, x.requires_grad,
+                    3 if store16 else fmode, store16)
         return out.to(x.dtype)
 
     @staticmethod
@@ -1487,12 +1513,13 @@ class _FusedMLPMaxPool(torch.autograd.Function):
             nb = _lib.lib.spt_graphnorm_bwd_stats_sparse_workspace_bytes(ctx.csr.num_seg, N, B)
             ws = _workspace(nb, dev)
             with torch.cuda.device(dev):
-                st = _lib.lib.spt_graphnorm_bwd_stats_sparse_f32(
-                    _lib.ptr(h_last), _lib.ptr(gout), _lib.ptr(arg), _lib.ptr(ctx.seg_graph),
+                st = _lib.lib.spt_graphnorm_bwd_stats_sparse_ex_f32(
+                    _lib.ptr(h_last), 1 if h_last.dtype == torch.bfloat16 else 0, _lib.ptr(gout),
+                    _lib.ptr(arg), _lib.ptr(ctx.seg_graph),
                     _lib.ptr(rows), ctx.csr.num_seg, R, N, B, _lib.ptr(am), _lib.ptr(sc),
                     _lib.ptr(gnb_last), float(slopes[-1]), _lib.ptr(total), _lib.ptr(ws), nb,
                     _lib.stream_ptr(dev))
-            _lib.check(st, "spt_graphnorm_bwd_stats_sparse_f32")
+            _lib.check(st, "spt_graphnorm_bwd_stats_sparse_ex_f32")
         # The pool's gradient has one non-zero per (segment, channel): the top layer's backward
         # reads (gout, arg) through the pool's CSR order instead of a dense [R, N] tensor.  Needs
         # the top GraphNorm's statistics from the sparse route above, an input gradient (L > 1),

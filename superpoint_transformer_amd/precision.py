@@ -5,9 +5,12 @@ switch, configs/trainer/gpu.yaml:7-10).
                      fused MLP layers: forward on the f32 matrix pipe (bitwise an fmaf chain),
                      backward split-bf16.  Every f32 parity bar of tests/ holds in this mode.
 ``"bf16"``           what ``torch.autocast(bfloat16)`` does to the reference's Linear layers:
-                     operands rounded to bf16, f32 accumulate; parameters, activations, norm
-                     statistics, softmax and segment reductions stay f32 (master weights in f32,
-                     like Lightning's bf16-mixed).  Tested at rtol 2e-2.
+                     operands rounded to bf16, f32 accumulate, and - for the point MLP, whose
+                     [N0, 32..128] layer outputs are most of a step's activation bytes - the raw
+                     layer outputs STORED as bf16 (read back by the next layer, the segment
+                     max-pool and the backward); parameters, norm statistics, gradients, softmax
+                     and segment reductions stay f32 (master weights in f32, like Lightning's
+                     bf16-mixed).  Tested at rtol 2e-2.
 ``"f32-exact"``      f32 matrix pipe everywhere (1/16 of the bf16 pipe's rate).
 
 The mode travels PER CALL: ``matrix_precision(mode)`` (a context manager on a ``contextvars``
@@ -20,6 +23,7 @@ it applies wherever no per-call mode is active.
 """
 import contextlib
 import contextvars
+import os
 
 from . import _lib
 
@@ -58,6 +62,24 @@ def fused_mode():
     """Mode word for ``spt_fused_linear_*_ex_f32``."""
     mode = _active.get()
     return -1 if mode is None else _MODES[mode][1]
+
+
+_bf16_storage = os.environ.get("SPT_BF16_STORAGE", "1") != "0"
+
+
+def set_bf16_activation_storage(on):
+    """In the ``"bf16"`` mode the raw outputs of the point MLP's fused layers are STORED as bf16
+    (what ``torch.autocast(bfloat16)`` makes of the reference's Linear outputs,
+    configs/trainer/gpu.yaml:7-10): on by default (``SPT_BF16_STORAGE=0`` in the environment or
+    this switch turn it off, leaving operand rounding only).  Returns the previous setting."""
+    global _bf16_storage
+    prev, _bf16_storage = _bf16_storage, bool(on)
+    return prev
+
+
+def bf16_activation_storage():
+    """True when fused layers launched now should store their activations as bf16."""
+    return _bf16_storage and get_matrix_precision() == "bf16"
 
 
 @contextlib.contextmanager

@@ -161,6 +161,85 @@ def test_bf16_matrix_precision_mode(dev):
     assert precision.get_matrix_precision() == "f32"
 
 
+@pytest.mark.parametrize("B", [1, 3])
+def test_bf16_activation_storage_of_the_point_mlp(dev, B):
+    """The `bf16` mode's STORAGE half (configs/trainer/gpu.yaml:7-10: under autocast the Linear
+    outputs are bf16 tensors): the point MLP's raw layer outputs are written as bf16 by the fused
+    forward, read as bf16 by the next layer, the L0 -> L1 streaming segment-max and the backward
+    (csrc/fused_mlp.hip IN16 / OUT16 / H16 / X16, segmax_stream_kernel<.., X16>).  Pooled values
+    and every gradient against the f64 oracle of MLP -> max-pool at rtol 2e-2 of the tensor scale
+    (SURVEY 8c), against the same mode WITHOUT storage at the same bar, and the saved activations
+    really are bf16; the f32 default never takes this route."""
+    from superpoint_transformer_amd import nn as N, ops, precision
+    from oracle import spt_oracle as O
+    g = torch.Generator().manual_seed(31 + B)
+    rows, nseg = 70_001, 2_300                      # >= 65 536 rows: the streaming pool; ragged tail
+    mlp = N.MLP([12, 32, 64, 128], norm=N.GraphNorm).to(dev)
+    with torch.no_grad():
+        for p in mlp.parameters():
+            p.add_(0.1 * torch.randn(p.shape, generator=g).to(dev))
+    x = torch.randn(rows, 12, generator=g) * 2 + 0.5
+    batch = (torch.arange(rows) * B // rows) if B > 1 else None
+    # segments never straddle two graphs; unsorted membership inside a graph
+    seg_of_graph = torch.arange(nseg) * B // nseg
+    si = torch.empty(rows, dtype=torch.long)
+    for b in range(B):
+        rmask = (batch == b) if batch is not None else torch.ones(rows, dtype=torch.bool)
+        segs = torch.nonzero(seg_of_graph == b).flatten()
+        si[rmask] = segs[torch.randint(0, segs.numel(), (int(rmask.sum()),), generator=g)]
+    gw = torch.randn(nseg, 128, generator=g)
+
+    def run(storage):
+        prev = precision.set_bf16_activation_storage(storage)
+        try:
+            with precision.matrix_precision("bf16"):
+                m = copy.deepcopy(mlp)
+                xd = x.to(dev).requires_grad_()
+                out = m.forward_max_pooled(xd, si.to(dev), nseg,
+                                           batch=None if batch is None else batch.to(dev),
+                                           batch_size=B, seg_graph=seg_of_graph.to(dev))
+                assert out is not None
+                saved = [t for t in out.grad_fn.saved_tensors if t.dim() == 2 and t.shape[0] == rows]
+                (out * gw.to(dev)).sum().backward()
+                return out.detach().cpu(), xd.grad.cpu(), [p.grad.cpu() for p in m.parameters()], saved
+        finally:
+            precision.set_bf16_activation_storage(prev)
+
+    o1, gx1, gp1, saved1 = run(True)
+    o0, gx0, gp0, saved0 = run(False)
+    assert sum(t.dtype == torch.bfloat16 for t in saved1) == 3       # h1, h2, h3 stored as bf16
+    assert all(t.dtype == torch.float32 for t in saved0)
+
+    ref = copy.deepcopy(mlp).double().cpu()
+    x64 = x.double().requires_grad_()
+    from oracle import spt_model as OM2
+    OM2.KEEP_GRAPH = True
+    y64 = OM2.mlp(ref, x64, batch, torch.float64)
+    OM2.KEEP_GRAPH = False
+    p64, _ = O.scatter_max(y64, si, dim_size=nseg)
+    (p64 * gw.double()).sum().backward()
+
+    def rel(a, r):
+        return float((a.double() - r).abs().max() / r.abs().max().clamp_min(1e-30))
+    assert rel(o1, p64.detach()) < 2e-2 and rel(o0, p64.detach()) < 2e-2
+    assert rel(o1, p64.detach()) > 1e-5                               # not secretly f32
+    # bf16 rounding reorders near-ties of the max-pool: a flipped arg moves a gradient value to
+    # another row, so the input gradient is judged as a whole (most entries within the bar, small
+    # L2 distance) and the parameter gradients - sums over 70 k rows - entry by entry; storage on
+    # must not be worse than operand rounding alone by more than the bar
+    def frac_within(a, r, tol):
+        return float(((a.double() - r).abs() <= tol * r.abs().max()).double().mean())
+
+    def l2(a, r):
+        return float((a.double() - r).norm() / r.norm())
+    assert frac_within(gx1, x64.grad, 2e-2) > 0.97, frac_within(gx1, x64.grad, 2e-2)
+    assert l2(gx1, x64.grad) < max(0.25, 1.5 * l2(gx0, x64.grad)), (l2(gx1, x64.grad), l2(gx0, x64.grad))
+    for a, b, p in zip(gp1, gp0, ref.parameters()):
+        assert rel(a, p.grad) < max(2e-2, 2.0 * rel(b, p.grad)), (rel(a, p.grad), rel(b, p.grad))
+    with precision.matrix_precision("f32"):
+        assert not precision.bf16_activation_storage()
+
+
 def test_two_models_at_different_precisions_interleaved_on_two_streams(dev):
     """the C ABI holds no global state.  Two SPT-64 models pinned to different
     matrix precisions (`SPT(matrix_precision=...)` -> the per-call mode word of the *_ex entries)
