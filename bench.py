@@ -384,7 +384,10 @@ def main():
             "dtype": {"f32": "f32 (bf16x3 matrix operands: hi*hi + lo*hi + hi*lo per f32 product, f32 "
                              "accumulate, storage and statistics)",
                       "f32-exact": "f32 (f32 matrix pipe)",
-                      "bf16": "bf16 (matrix operands; f32 accumulate, storage and statistics)"}[args.dtype],
+                      "bf16": ("bf16 (matrix operands and the point MLP's stored layer outputs; f32 "
+                               "accumulate, statistics, gradients, segment / attention tensors)"
+                               if precision.bf16_activation_storage() else
+                               "bf16 (matrix operands; f32 accumulate, storage and statistics)")}[args.dtype],
             "ms_per_step_f32_exact": round(exact_ms, 4) if exact_ms else None,
             "data": "synthetic",
             "config": {

@@ -1157,7 +1157,7 @@ int fmlp_dma_bwd_launch(bool pooled, bool lo, const float* gy, const float* h, F
                         const float* pbs, float pslope, const float* W, float* gx,
                         float* gw_partial, double* pstat_partial, const int32_t* perm,
                         const int32_t* pos_seg, const float* gout, const int32_t* arg,
-                        hipStream_t stream);
+                        hipStream_t stream, bool s16 = false);
 }  // namespace spt
 
 using namespace spt;
@@ -1512,11 +1512,17 @@ static int fmlp_bwd_impl(bool pooled, const float* gy, const float* gout, const 
           gy, h, 0, 0, am, scale, bias, slope, c1, c2, c3, xprev, K, pre_am, pre_scale,          \
           pre_bias, pre_slope, W, nullptr, gwp, nullptr, rt);                                    \
   }
-    SPT_FMLP_ST_POOLED_SHAPES(XSP)
-    SPT_FMLP_ST_SHAPES(XSD)
+    if (x16 && gx && fmlp_dma_of(mode) && fmlp_dma_supported(K, N)) {
+      per_run = fmlp_dma_bwd_launch(pooled, false, gy, h, rt, max_rows, N, am, scale, bias, slope, c1,
+                                    c2, c3, xprev, K, pre_am, pre_scale, pre_bias, pre_slope, W, gx,
+                                    gwp, pstp, perm, pos_seg, gout, arg, stream, true);
+    } else {
+      SPT_FMLP_ST_POOLED_SHAPES(XSP)
+      SPT_FMLP_ST_SHAPES(XSD)
+      per_run = gx_ * nwv;
+    }
 #undef XSP
 #undef XSD
-    per_run = gx_ * nwv;
   } else if (g_fmlp_split_bf16 && gx && fmlp_dma_of(mode) && fmlp_dma_supported(K, N)) {
     per_run = fmlp_dma_bwd_launch(pooled, g_fmlp_mode != 3, gy, h, rt, max_rows, N, am, scale, bias,
                                   slope, c1, c2, c3, xprev, K, pre_am, pre_scale, pre_bias, pre_slope,

@@ -107,9 +107,25 @@ __device__ __forceinline__ f32x4 mfma3_16(const bf16x4& ah, const bf16x4& al, co
   return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(AH, BH, c, 0, 0, 0);
 }
 
+// value of lane (base + sel) of v, sel in [0, R), base wave-uniform: readlane + select
+template <int R>
+__device__ __forceinline__ int pick_lane(int v, int base, int sel) {
+  int r = __builtin_amdgcn_readlane(v, base);
+#pragma unroll
+  for (int j = 1; j < R; ++j) r = (sel == j) ? __builtin_amdgcn_readlane(v, base + j) : r;
+  return r;
+}
+
 // Arguments as fused_mlp.hip's bwd_kernel_bf (K, N compile-time: whole 16-byte row chunks and
 // whole 32-column MFMA steps).  POOLED: the rows walk positions [r0, r1) of the pool's CSR order.
-template <int K, int N, int NW, int OCC, bool LO, bool POOLED>
+// S16 (bf16 mode's activation storage): h and xprev hold bf16 rows.  The DMA lands the raw bf16
+// rows (half the bytes, half the DMA instructions) in the UPPER HALF of the wave's h / x buffers;
+// the GraphNorm-backward transform reads its four h values from there (8 bytes) and writes gh as
+// f32 into the usual swizzled slot, a short pass widens the x rows the same way - row blocks are
+// visited in ascending order, so an f32 block never overwrites bf16 rows that are still to be read
+// (block i ends at byte 1024 (i + 1) <= the first unread bf16 row).  Everything downstream (the two
+// GEMMs, the statistics, gx as f32 rows) is unchanged.
+template <int K, int N, int NW, int OCC, bool LO, bool POOLED, bool S16 = false>
 __global__ __launch_bounds__(NW * 64, OCC) void bwd_dma_kernel(
     const float* __restrict__ gy, const float* __restrict__ h, int64_t r0, int64_t r1,
     const float* __restrict__ am, const float* __restrict__ sc, const float* __restrict__ bs,
@@ -236,15 +252,27 @@ __global__ __launch_bounds__(NW * 64, OCC) void bwd_dma_kernel(
       if (t < ntiles && lane < TR) rid_n = (rowf + lane < r1) ? lane : 0;   // row offset in the tile
     }
   };
+  constexpr int NC16 = N / 8, RH16 = 64 / NC16, HI16 = TR / RH16;     // bf16 rows: 8 values per chunk
+  constexpr int KC16 = K / 8, RX16 = 64 / KC16, XI16 = (TR + RX16 - 1) / RX16;
+  static_assert(!S16 || (TR % RH16 == 0 && RX16 <= TR), "bf16 rows: whole DMA instructions per tile");
   auto issue_h = [&](int64_t t, int rid_l, int seg_l) {
     if (t >= ntiles) return;
     const int64_t row0 = r0 + t * TR;
-    const float* hb = POOLED ? h : h + row0 * N;
     const int hi = ln / NC, n4 = ln % NC;
+    if constexpr (S16) {
+      const uint16_t* hb = reinterpret_cast<const uint16_t*>(h) + (POOLED ? 0 : row0 * N);
+      const int h16 = ln / NC16, p16 = ln % NC16;
 #pragma unroll
-    for (int i = 0; i < HI; ++i) {
-      const int rr7 = (hi + RH * i) & 7;
-      lds_dma16(hb + (int64_t)pick(rid_l, RH * i) * N + 4 * (n4 ^ rr7), HB + 256 * i);
+      for (int i = 0; i < HI16; ++i)
+        lds_dma16(hb + (int64_t)pick_lane<RH16>(rid_l, RH16 * i, h16) * N + 8 * p16,
+                  HB + W_H / 2 + 256 * i);
+    } else {
+      const float* hb = POOLED ? h : h + row0 * N;
+#pragma unroll
+      for (int i = 0; i < HI; ++i) {
+        const int rr7 = (hi + RH * i) & 7;
+        lds_dma16(hb + (int64_t)pick(rid_l, RH * i) * N + 4 * (n4 ^ rr7), HB + 256 * i);
+      }
     }
     if constexpr (POOLED) {
       const int cnt = (int)((r1 - row0) < TR ? (r1 - row0) : TR);
@@ -258,12 +286,21 @@ __global__ __launch_bounds__(NW * 64, OCC) void bwd_dma_kernel(
   auto issue_x = [&](int64_t t, int rid_l) {
     if (t >= ntiles) return;
     const int64_t row0 = r0 + t * TR;
-    const float* xb = POOLED ? xprev : xprev + row0 * K;
-    const int hx = ln / KC, px = ln % KC;
+    if constexpr (S16) {
+      const uint16_t* xb = reinterpret_cast<const uint16_t*>(xprev) + (POOLED ? 0 : row0 * K);
+      const int x16 = ln / KC16, q16 = ln % KC16;
 #pragma unroll
-    for (int i = 0; i < XI; ++i) {
-      const int rr = hx + RX * i;
-      lds_dma16(xb + (int64_t)pickx(rid_l, RX * i) * K + 4 * (px ^ (4 * ((rr >> 2) & 1))), XB + 256 * i);
+      for (int i = 0; i < XI16; ++i)
+        lds_dma16(xb + (int64_t)pick_lane<RX16>(rid_l, RX16 * i, x16) * K + 8 * q16,
+                  XB + W_X / 2 + 256 * i);
+    } else {
+      const float* xb = POOLED ? xprev : xprev + row0 * K;
+      const int hx = ln / KC, px = ln % KC;
+#pragma unroll
+      for (int i = 0; i < XI; ++i) {
+        const int rr = hx + RX * i;
+        lds_dma16(xb + (int64_t)pickx(rid_l, RX * i) * K + 4 * (px ^ (4 * ((rr >> 2) & 1))), XB + 256 * i);
+      }
     }
   };
 
@@ -289,6 +326,20 @@ __global__ __launch_bounds__(NW * 64, OCC) void bwd_dma_kernel(
     }
     wait_vm0();
     lds_order();
+    if constexpr (S16) {
+      // widen the x rows: lane (rr, px) owns the f32 slot at position px of row rr, which holds
+      // column chunk px ^ swizzle(rr) (the layout the f32 DMA produces)
+#pragma unroll
+      for (int i = 0; i < XI; ++i) {
+        const int rr = hx + RX * i;
+        const int cx = px ^ (4 * ((rr >> 2) & 1));
+        const uint2 u = *reinterpret_cast<const uint2*>(
+            reinterpret_cast<const uint16_t*>(XB + W_X / 2) + rr * K + 4 * cx);
+        *reinterpret_cast<float4*>(XB + rr * K + 4 * px) =
+            make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
+                        __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+      }
+    }
     // ---- gh = GraphNorm-backward(gy, h), in place --------------------------------------------
     if constexpr (!(SPT_FDMA_SKIP & 1)) {
       const int s0 = POOLED ? __builtin_amdgcn_readlane(seg_l, 0) : 0;
@@ -298,7 +349,15 @@ __global__ __launch_bounds__(NW * 64, OCC) void bwd_dma_kernel(
       for (int i = 0; i < HI; ++i) {
         const int rr = hi + RH * i;
         float* slot = HB + rr * N + 4 * (n4 ^ (rr & 7));
-        const float4 hv = *reinterpret_cast<const float4*>(slot);
+        float4 hv;
+        if constexpr (S16) {                       // the row's bf16 values, upper half of the buffer
+          const uint2 u = *reinterpret_cast<const uint2*>(
+              reinterpret_cast<const uint16_t*>(HB + W_H / 2) + rr * N + 4 * n4);
+          hv = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
+                           __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+        } else {
+          hv = *reinterpret_cast<const float4*>(slot);
+        }
         float4 gv;
         if constexpr (POOLED) {
           const int rid = pick(rid_l, RH * i);
@@ -462,7 +521,7 @@ int fmlp_dma_bwd_launch(bool pooled, bool lo, const float* gy, const float* h, F
                         const float* pbs, float pslope, const float* W, float* gx,
                         float* gw_partial, double* pstat_partial, const int32_t* perm,
                         const int32_t* pos_seg, const float* gout, const int32_t* arg,
-                        hipStream_t stream) {
+                        hipStream_t stream, bool s16) {
   using namespace fdma;
   const int64_t tiles = (max_rows + TR - 1) / TR;
   const int nr = rt.n < 1 ? 1 : rt.n;
@@ -474,7 +533,15 @@ int fmlp_dma_bwd_launch(bool pooled, bool lo, const float* gy, const float* h, F
     if (blocks > cap) blocks = cap;                                                                \
     if (blocks < 1) blocks = 1;                                                                    \
     const dim3 grid((unsigned)blocks, (unsigned)nr);                                               \
-    if (pooled && lo)                                                                              \
+    if (s16 && pooled)                                                                             \
+      bwd_dma_kernel<KK, NN, NWV, OCC, false, true, true><<<grid, NWV * 64, 0, stream>>>(          \
+          gy, h, 0, 0, am, sc, bs, slope, c1, c2, c3, xprev, pam, psc, pbs, pslope, W, gx,         \
+          gw_partial, pstat_partial, perm, pos_seg, gout, arg, rt);                                \
+    else if (s16)                                                                                  \
+      bwd_dma_kernel<KK, NN, NWV, OCC, false, false, true><<<grid, NWV * 64, 0, stream>>>(         \
+          gy, h, 0, 0, am, sc, bs, slope, c1, c2, c3, xprev, pam, psc, pbs, pslope, W, gx,         \
+          gw_partial, pstat_partial, perm, pos_seg, gout, arg, rt);                                \
+    else if (pooled && lo)                                                                              \
       bwd_dma_kernel<KK, NN, NWV, OCC, true, true><<<grid, NWV * 64, 0, stream>>>(                      \
           gy, h, 0, 0, am, sc, bs, slope, c1, c2, c3, xprev, pam, psc, pbs, pslope, W, gx,         \
           gw_partial, pstat_partial, perm, pos_seg, gout, arg, rt);                                \

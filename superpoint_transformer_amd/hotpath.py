@@ -94,12 +94,15 @@ def _kernel_names(mode):
                 "mlp_fwd": "spt::fmlp::fwd_kernel<16, 8> (f32 matrix pipe)"}
     p = 3 if mode == "f32" else 1
     lo = "true" if mode == "f32" else "false"
+    from . import precision
+    st = mode == "bf16" and precision.bf16_activation_storage()   # layer outputs stored as bf16
     return {"attn_bwd": f"spt::el::attn_bwd_prep_kernel + spt::el::attn_bwd_el_kernel<{p}> + "
                         "spt::el::attn_kv_reduce_kernel + spt::attn_reduce_partials_kernel",
             "attn_fwd": f"spt::mfma::attn_fwd_mfma_kernel<{p}>",
-            "mlp_bwd_pooled": f"spt::fdma::bwd_dma_kernel<64, 128, 8, 2, {lo}, true>",
+            "mlp_bwd_pooled": f"spt::fdma::bwd_dma_kernel<64, 128, 8, 2, {lo}, true" + (", true>" if st else ">"),
             "mlp_fwd": "spt::fmlp::fwd_kernel<16, 8>" if mode == "f32"
-                       else "spt::fmlp::fwd_kernel_bf<16, 8, false>"}
+                       else ("spt::fmlp::fwd_kernel_bf<16, 8, false, true, true>" if st
+                             else "spt::fmlp::fwd_kernel_bf<16, 8, false>")}
 
 
 class SPTSegmenter(nn.Module):
@@ -249,12 +252,16 @@ class SPTTrainStep:
         from . import precision
         n0, n1 = self.n[0], self.n[1]
         c = getattr(self, "pool_c", 128)
-        bytes_ = n0 * (4 * c + 4) + n1 * (8 * c + 4)
+        st16 = (precision.get_matrix_precision() == "bf16" and precision.bf16_activation_storage()
+                and c == 128 and n0 >= 65536)
+        bytes_ = n0 * ((2 if st16 else 4) * c + 4) + n1 * (8 * c + 4)
         ms = ops.timer_mean_ms(self.tname)
         ach = bytes_ / (ms * 1e-3) / 1e9 if ms else None
         traffic = _pmc_traffic("segmax", self.workload)
         roof = {"bound": "hbm",
-                "kernel": "spt::segmax_stream_kernel<true> (L0->L1 segment max + arg, C=%d, the point MLP's "
+                "kernel": ("spt::segmax_stream_kernel<true, true> (bf16 rows; " if st16 else
+                           "spt::segmax_stream_kernel<true> (") +
+                          "L0->L1 segment max + arg, C=%d, the point MLP's "
                           "last GraphNorm + LeakyReLU applied on the fly)" % c
                 if c == 128 and n0 >= 65536 else "spt::segcsr_reduce_kernel<3, 4, true> (L0->L1 segment max + arg)",
                 "achieved": round(ach, 1) if ach else None, "peak": peak_gbs,
@@ -267,6 +274,8 @@ class SPTTrainStep:
         if getattr(self, "k_timers", None):
             n1, e1 = self.level1
             names = _kernel_names(precision.get_matrix_precision())
+            ab = 2 if (precision.get_matrix_precision() == "bf16"
+                       and precision.bf16_activation_storage()) else 4
             rows = n0
             steps = max(self._timed_steps, 1)
             # bytes / FLOPs of the op PER STEP (all launches of the op in one step together):
@@ -278,11 +287,13 @@ class SPTTrainStep:
                 "attn_bwd": ("one level-1 attention backward: all kernels of the call",
                              264 * e1 + 2176 * n1, 37.4e3 * e1, True),
                 "attn_fwd": ("one level-1 attention forward", 136 * e1 + 1156 * n1, 12.6e3 * e1, True),
+                # (ab = bytes per stored activation value: 2 with the bf16 mode's storage option)
                 "mlp_bwd_pooled": ("64 -> 128 backward of the point MLP's top layer with the L0->L1 "
                                    "pool's backward inside",
-                                   rows * (4 * 128 + 8 * 64) + n1 * 1024, 2 * 2 * 64 * 128 * rows, False),
+                                   rows * (ab * 128 + ab * 64 + 4 * 64) + n1 * 1024,
+                                   2 * 2 * 64 * 128 * rows, False),
                 "mlp_fwd": ("64 -> 128 forward of the point MLP's top layer",
-                            rows * 4 * (64 + 128), 2 * 64 * 128 * rows, False),
+                            rows * ab * (64 + 128), 2 * 64 * 128 * rows, False),
             }
             for key, (what, kbytes, kflops, per_call) in spec.items():
                 tms = ops.timer_mean_ms(self.k_timers[key])

@@ -238,3 +238,154 @@ def test_dma_staged_backward_is_bitwise_the_register_staged_one(K, N, rows, nseg
         assert bool(torch.isfinite(a[0]).all())                 # every row of gx was written
         for u, v in zip(a, b):
             assert torch.equal(u, v)
+
+
+@pytest.mark.parametrize("K,N,pooled", [(64, 128, True), (32, 64, False), (32, 64, True), (12, 32, False),
+                                        (64, 64, True)])
+@pytest.mark.parametrize("rows,nseg,B", [(10_007, 300, 1), (20_011, 700, 3)])
+def test_bf16_storage_kernels_are_bitwise_their_f32_storage_siblings(K, N, pooled, rows, nseg, B, dev):
+    """The bf16 mode's activation storage (mode-word bits SPT_FMLP_H_BF16 / SPT_FMLP_X_BF16): fed
+    bf16-REPRESENTABLE activations, the storage kernels (bf16 rows in HBM: fused forward with the
+    packed output tile, DMA-staged backward with in-LDS widening, register-staged backward) and
+    the f32-storage kernels of the same matrix mode see the same numbers - every output must agree
+    BIT FOR BIT (h: the f32 kernel's output rounded to bf16).  Several graphs per launch (run
+    tables), a ragged last tile."""
+    import ctypes
+    from superpoint_transformer_amd import _lib
+    g = torch.Generator().manual_seed(rows + K + N + B)
+    bf = lambda t: t.to(torch.bfloat16)
+    P = _lib.ptr
+    sp = _lib.stream_ptr(dev)
+    first = K == 12                                           # the chain's first layer reads f32 input
+    x32 = (torch.randn(rows, K, generator=g) * 2).to(dev)
+    if not first:
+        x32 = bf(x32).float()
+    x16 = bf(x32)
+    W = (torch.randn(N, K, generator=g) * 0.2).to(dev)
+    tabK = [(torch.rand(B, K, generator=g) + 0.5).to(dev) for _ in range(2)] + \
+           [(torch.rand(K, generator=g) + 0.5).to(dev)]
+    cuts = [rows * b // B for b in range(B + 1)]
+    n = B
+    r0 = (ctypes.c_int64 * n)(*cuts[:-1]); r1 = (ctypes.c_int64 * n)(*cuts[1:])
+    gg = (ctypes.c_int32 * n)(*range(B))
+    ws = torch.empty(_lib.lib.spt_fused_linear_workspace_bytes(K, N), dtype=torch.uint8, device=dev)
+    H, X = 8, 16
+
+    # ---- forward --------------------------------------------------------------------------------
+    def fwd(store):
+        h = torch.empty((rows, N), dtype=torch.bfloat16 if store else torch.float32, device=dev)
+        tot = torch.empty((B, 2 * N + 1), dtype=torch.float64, device=dev)
+        mode = 3 | ((H | (0 if first else X)) if store else 0)
+        xin = x16 if (store and not first) else x32
+        pre = (None, None, None) if first else tuple(P(t) for t in tabK)
+        st = _lib.lib.spt_fused_linear_fwd_runs_f32(
+            P(xin), n, r0, r1, gg, B, K, P(W), N, pre[0], pre[1], pre[2], 0.2, P(h), P(tot), mode,
+            P(ws), ws.numel(), sp)
+        _lib.check(st, "fwd")
+        torch.cuda.synchronize()
+        return h, tot
+    h16, tot16 = fwd(True)
+    h32, tot32 = fwd(False)
+    assert torch.equal(h16, bf(h32))
+    hd = h16.double()
+    for b in range(B):                                        # statistics of the ROUNDED values
+        seg = hd[cuts[b]:cuts[b + 1]]
+        ref = torch.cat([seg.sum(0), (seg * seg).sum(0), torch.tensor([float(seg.shape[0])], device=dev, dtype=torch.float64)])
+        assert torch.allclose(tot16[b], ref, rtol=1e-12, atol=1e-9)
+
+    # ---- backward -------------------------------------------------------------------------------
+    hq32 = h16.float()                                        # bf16-representable h for both kernels
+    tabN = [(torch.rand(B, N, generator=g) + 0.5).to(dev) for _ in range(2)] + \
+           [(torch.rand(N, generator=g) + 0.5).to(dev)] + \
+           [(torch.rand(B, N, generator=g) + 0.5).to(dev) for _ in range(3)]
+    gy = torch.randn(rows, N, generator=g).to(dev)
+    # pooled: segments numbered graph by graph, CSR positions of a graph contiguous
+    seg_of_row = torch.empty(rows, dtype=torch.long)
+    for b in range(B):
+        lo, hi = nseg * b // B, nseg * (b + 1) // B
+        seg_of_row[cuts[b]:cuts[b + 1]] = torch.randint(lo, hi, (cuts[b + 1] - cuts[b],), generator=g)
+        seg_of_row[cuts[b]:cuts[b] + (hi - lo)] = torch.arange(lo, hi)
+    perm = torch.argsort(seg_of_row, stable=True)
+    pos_seg = seg_of_row[perm]
+    rowptr = torch.zeros(nseg + 1, dtype=torch.long)
+    rowptr[1:] = torch.cumsum(torch.bincount(seg_of_row, minlength=nseg), 0)
+    off = (torch.rand(nseg, N, generator=g) * (rowptr[1:] - rowptr[:-1]).view(-1, 1)).long()
+    arg = perm[rowptr[:-1].view(-1, 1) + off].int().contiguous().to(dev)
+    gout = torch.randn(nseg, N, generator=g).to(dev)
+    perm_d, seg_d = perm.int().to(dev), pos_seg.int().to(dev)
+
+    def bwd(store, extra=0):
+        gx = torch.full((rows, K), float("nan"), device=dev)
+        gW = torch.empty(N, K, device=dev)
+        prev = None if first else torch.empty((B, 2 * K + 1), dtype=torch.float64, device=dev)
+        mode = 3 | extra | ((H | (0 if first else X)) if store else 0)
+        hin = h16 if store else hq32
+        xin = x16 if (store and not first) else x32
+        pre = (None, None, None) if first else tuple(P(t) for t in tabK)
+        if pooled:
+            st = _lib.lib.spt_fused_linear_bwd_pooled_runs_f32(
+                P(gout), P(arg), P(perm_d), P(seg_d), P(hin), n, r0, r1, gg, B, N, P(tabN[0]), P(tabN[1]),
+                P(tabN[2]), 0.01, P(tabN[3]), P(tabN[4]), P(tabN[5]), P(xin), K, pre[0], pre[1], pre[2],
+                0.2, P(W), P(gx), P(gW), P(prev), mode, P(ws), ws.numel(), sp)
+        else:
+            st = _lib.lib.spt_fused_linear_bwd_runs_f32(
+                P(gy), P(hin), n, r0, r1, gg, B, N, P(tabN[0]), P(tabN[1]), P(tabN[2]), 0.01, P(tabN[3]),
+                P(tabN[4]), P(tabN[5]), P(xin), K, pre[0], pre[1], pre[2], 0.2, P(W), P(gx), P(gW),
+                P(prev), mode, P(ws), ws.numel(), sp)
+        _lib.check(st, "bwd")
+        torch.cuda.synchronize()
+        return gx, gW, prev
+    if pooled and first:
+        return
+    ref = bwd(False)
+    for extra in (0, 4):                                      # DMA-staged where built / register-staged
+        got = bwd(True, extra)
+        assert bool(torch.isfinite(got[0]).all())
+        for u, v in zip(got, ref):
+            if u is not None:
+                assert torch.equal(u, v)
+
+
+def test_bf16_rows_in_the_streaming_segment_max_and_the_sparse_statistics(dev):
+    """spt_segcsr_max_affine_bf16 / spt_graphnorm_bwd_stats_sparse_ex_f32(x_is_bf16) on bf16 rows
+    against the f32 entries on the same (bf16-representable) values: bit-identical outputs."""
+    from superpoint_transformer_amd import _lib
+    from superpoint_transformer_amd.csr import build_csr
+    g = torch.Generator().manual_seed(77)
+    rows, nseg, C, B = 70_003, 2_100, 128, 2
+    h16 = torch.randn(rows, C, generator=g).to(torch.bfloat16).to(dev)
+    h32 = h16.float()
+    si = torch.randint(0, nseg, (rows,), generator=g)
+    si[:nseg] = torch.arange(nseg)
+    si = si.sort().values[torch.randperm(rows, generator=g)]                 # unsorted membership
+    seg_graph = (torch.arange(nseg) * B // nseg).to(dev)
+    csr = build_csr(si.to(dev), nseg)
+    am, sc = ((torch.rand(B, C, generator=g) - 0.3).to(dev) for _ in range(2))
+    bs = torch.rand(C, generator=g).to(dev)
+    P, sp = _lib.ptr, _lib.stream_ptr(dev)
+
+    def pool(fn, x):
+        out = torch.empty((nseg, C), device=dev)
+        arg = torch.empty((nseg, C), dtype=torch.int32, device=dev)
+        st = fn(P(x), P(csr.perm), P(csr.rowptr), rows, nseg, C, P(am), P(sc), P(bs), 0.01,
+                P(seg_graph), P(out), P(arg), sp)
+        _lib.check(st, "segmax")
+        return out, arg
+    assert _lib.lib.spt_segcsr_max_affine_bf16_supported(C, rows) == 1
+    o16, a16 = pool(_lib.lib.spt_segcsr_max_affine_bf16, h16)
+    o32, a32 = pool(_lib.lib.spt_segcsr_max_affine_f32, h32)
+    assert torch.equal(o16, o32) and torch.equal(a16, a32)
+
+    gout = torch.randn(nseg, C, generator=g).to(dev)
+    grows = torch.tensor([int((seg_graph[si.to(dev)] == b).sum()) for b in range(B)], device=dev)
+    nb = _lib.lib.spt_graphnorm_bwd_stats_sparse_workspace_bytes(nseg, C, B)
+    ws = torch.empty(max(nb, 1), dtype=torch.uint8, device=dev)
+
+    def stats(x, is16):
+        tot = torch.empty((B, 2 * C + 1), dtype=torch.float64, device=dev)
+        st = _lib.lib.spt_graphnorm_bwd_stats_sparse_ex_f32(
+            P(x), is16, P(gout), P(a32), P(seg_graph), P(grows), nseg, rows, C, B, P(am), P(sc), P(bs),
+            0.01, P(tot), P(ws), nb, sp)
+        _lib.check(st, "sparse stats")
+        return tot
+    assert torch.equal(stats(h16, 1), stats(h32, 0))
