@@ -381,8 +381,9 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": {"f32": "f32 (bf16x3 matrix operands: hi*hi + lo*hi + hi*lo per f32 product, f32 "
-                             "accumulate, storage and statistics)",
+            "dtype": {"f32": "f32 (matrix products on the bf16 pipe with split operands: attention and the "
+                             "fused layers' backward hi*hi + lo*hi + hi*lo, the fused layers' forward the "
+                             "f32-exact 3-way split with 6 products; f32 accumulate, storage and statistics)",
                       "f32-exact": "f32 (f32 matrix pipe)",
                       "bf16": ("bf16 (matrix operands and the point MLP's stored layer outputs; f32 "
                                "accumulate, statistics, gradients, segment / attention tensors)"

@@ -732,6 +732,10 @@ int spt_fused_linear_pooled_supported_ex(int K, int N, int mode);
 #define SPT_FMLP_X_BF16 16
 int spt_fused_linear_storage_supported(int K, int N);
 int spt_fused_linear_bwd_use_dma(int on);
+/* Forward of matrix mode 1 (the default "f32"): 1 (default) = the f32 product as SIX bf16 products
+ * of 3-way split operands on the bf16 matrix pipe (f32-exact: every dropped term is below 2^-24 of
+ * its product), 0 = the f32 matrix pipe.  Process-wide; < 0 queries; returns the previous setting. */
+int spt_fused_linear_fwd_use_x3(int on);
 int spt_fused_linear_fwd_ex_f32(const float* x, int64_t r0, int64_t r1, int K, const float* W,
                                 int N, const float* pre_am, const float* pre_scale,
                                 const float* pre_bias, float pre_slope, float* h, double* total,

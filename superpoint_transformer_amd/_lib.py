@@ -103,6 +103,7 @@ SIGNATURES = {
     "spt_fused_linear_supported": (_int, [_int, _int]),
     "spt_fused_linear_use_split_bf16": (_int, [_int]),
     "spt_fused_linear_bwd_use_dma": (_int, [_int]),
+    "spt_fused_linear_fwd_use_x3": (_int, [_int]),
     "spt_fused_linear_pooled_supported": (_int, [_int, _int]),
     "spt_fused_linear_bwd_pooled_f32": (_int, [_p, _p, _p, _p, _p, _i64, _i64, _int, _p, _p, _p, _f32,
                                                _p, _p, _p, _p, _int, _p, _p, _p, _f32, _p, _p, _p,

@@ -16,6 +16,7 @@
 // One launch covers the rows of one graph (statistics are per graph; a batch of B
 // clouds = B launches over contiguous row ranges, described by a host `gptr`).
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.hpp"
 
@@ -732,6 +733,136 @@ __global__ __launch_bounds__(WAVES * 64, 2) void fwd_kernel_bf(
   if (threadIdx.x == 0) out[2 * N] = (blockIdx.x == 0) ? (double)(r1 - r0) : 0.0;
 }
 
+// ---- forward, f32-EXACT on the bf16 matrix pipe: 3-way split, 6 products ------------------------
+// An f32 value is exactly the sum of three bf16 values (8 + 8 + 8 mantissa bits):
+//   x = x1 + x2 + x3,  w = w1 + w2 + w3,
+//   x w = x1 w1 + (x1 w2 + x2 w1) + (x1 w3 + x3 w1 + x2 w2) + [x2 w3 + x3 w2 + x3 w3 <= 3 * 2^-24 |x w|]
+// Every bf16 x bf16 product is exact in f32, so six v_mfma_f32_16x16x32_bf16 per (k-step, column
+// block) give the f32 product to within one unit in the last place of the TERM (the dropped terms)
+// plus the same f32 accumulation error class as an fmaf chain - the 2e-5 bar the 2-way split (3
+// products, ~2^-16 per term) misses after three normalised layers holds.  Matrix-pipe time per
+// 16-row tile at 64 -> 128: 96 instructions x 16 cycles against 128 x 32 on the f32 pipe.
+// W lives in LDS as three bf16 planes (rows padded by 8 values: conflict-free 16-byte reads),
+// shared by the 8 waves of the workgroup; smallest terms are accumulated first.
+constexpr int WAVES_X3 = 8;
+template <int NV, typename V>
+__device__ __forceinline__ void split3_bf16(const float (&x)[NV], V& h, V& m, V& l) {
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const __bf16 a = (__bf16)x[i];
+    const float r1 = x[i] - (float)a;              // exact
+    const __bf16 b = (__bf16)r1;
+    const float r2 = r1 - (float)b;                // exact, |r2| <= 2^-17 |x|: fits bf16 exactly
+    h[i] = a;
+    m[i] = b;
+    l[i] = (__bf16)r2;
+  }
+}
+template <int K4, int NBK>
+__global__ __launch_bounds__(WAVES_X3 * 64, 2) void fwd_kernel_x3(
+    const float* __restrict__ x, int64_t r0, int64_t r1, int K, const float* __restrict__ W,
+    const float* __restrict__ am, const float* __restrict__ sc, const float* __restrict__ bs,
+    float slope, float* __restrict__ h, double* __restrict__ partial, FmlpRuns rt) {
+  constexpr int KP = K4 * 4, KS = (KP + 31) / 32, KP32 = KS * 32, LDA = KP32 + 4, N = NBK * 16;
+  constexpr int LDW = KP32 + 8;                      // bf16 values per padded W row
+  SPT_FMLP_RUN_FWD(N)
+  __shared__ __attribute__((aligned(16))) float a_lds[WAVES_X3][TR * LDA];
+  __shared__ __attribute__((aligned(16))) float tab[3 * KP32];
+  __shared__ __attribute__((aligned(16))) __bf16 wpl[3][N * LDW];   // W = wpl[0] + wpl[1] + wpl[2]
+  __shared__ double red[WAVES_X3][2 * N];
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, c = lane & 15;
+  float* al = a_lds[wid];
+  const bool pre = am != nullptr;
+  load_table(tab, am, K, KP32);
+  load_table(tab + KP32, sc, K, KP32);
+  load_table(tab + 2 * KP32, bs, K, KP32);
+  for (int i = lane; i < TR * LDA; i += 64) al[i] = 0.f;   // padding columns stay zero
+  for (int i = threadIdx.x; i < N * KP32; i += WAVES_X3 * 64) {
+    const int n = i / KP32, k = i - n * KP32;
+    const float w1[1] = {(k < K) ? W[(size_t)n * K + k] : 0.f};
+    __bf16 a[1], b[1], cc[1];
+    split3_bf16<1>(w1, a, b, cc);
+    wpl[0][n * LDW + k] = a[0];
+    wpl[1][n * LDW + k] = b[0];
+    wpl[2][n * LDW + k] = cc[0];
+  }
+  __syncthreads();
+
+  double s1[NBK], s2[NBK];
+#pragma unroll
+  for (int nb = 0; nb < NBK; ++nb) s1[nb] = s2[nb] = 0.0;
+
+  const int64_t ntiles = (r1 - r0 + TR - 1) / TR;
+  const int64_t wave = (int64_t)blockIdx.x * WAVES_X3 + wid;
+  const int64_t nwaves = (int64_t)gridDim.x * WAVES_X3;
+  for (int64_t t = wave; t < ntiles; t += nwaves) {
+    const int64_t row0 = r0 + t * TR;
+    const int cnt = (int)((r1 - row0) < TR ? (r1 - row0) : TR);
+    wave_sync_lds();
+    stage_tile<KP32, LDA, KP32>(x, row0, cnt, K, pre, tab, slope, al, nullptr, lane);
+    wave_sync_lds();
+    f32x4 C[NBK];
+#pragma unroll
+    for (int nb = 0; nb < NBK; ++nb) C[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const float4 a0 = *reinterpret_cast<const float4*>(al + c * LDA + 32 * ks + 8 * g);
+      const float4 a1 = *reinterpret_cast<const float4*>(al + c * LDA + 32 * ks + 8 * g + 4);
+      const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+      bf16x8 x1, x2, x3;
+      split3_bf16<8>(av, x1, x2, x3);
+#pragma unroll
+      for (int nb = 0; nb < NBK; ++nb) {
+        const int wo = (16 * nb + c) * LDW + 32 * ks + 8 * g;
+        const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(&wpl[0][wo]);
+        const bf16x8 w2 = *reinterpret_cast<const bf16x8*>(&wpl[1][wo]);
+        const bf16x8 w3 = *reinterpret_cast<const bf16x8*>(&wpl[2][wo]);
+        f32x4 acc = C[nb];
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x3, w1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1, w3, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x2, w2, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x2, w1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1, w2, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1, w1, acc, 0, 0, 0);
+        C[nb] = acc;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int rr = 4 * g + r;
+      if (rr < cnt) {
+        float* hr = h + (row0 + rr) * N + c;
+#pragma unroll
+        for (int nb = 0; nb < NBK; ++nb) {
+          const float v = C[nb][r];
+          hr[16 * nb] = v;
+          s1[nb] += (double)v;
+          s2[nb] += (double)v * (double)v;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int nb = 0; nb < NBK; ++nb) {
+    const double a = xg_sum_d(s1[nb]), b = xg_sum_d(s2[nb]);
+    if (g == 0) {
+      red[wid][nb * 16 + c] = a;
+      red[wid][N + nb * 16 + c] = b;
+    }
+  }
+  __syncthreads();
+  double* out = partial + (size_t)blockIdx.x * (2 * N + 1);
+  for (int i = threadIdx.x; i < 2 * N; i += WAVES_X3 * 64) {
+    double t2 = 0.0;
+#pragma unroll
+    for (int w = 0; w < WAVES_X3; ++w) t2 += red[w][i];       // fixed order: deterministic
+    out[i] = t2;
+  }
+  if (threadIdx.x == 0) out[2 * N] = (blockIdx.x == 0) ? (double)(r1 - r0) : 0.0;
+}
+
 // ---- backward: gW += gh^T y_prev as 16x16x16 products (contraction = the 16 rows of the
 // tile: the 4 rows a lane group holds are one packed operand), gx = gh W as 16x16x32
 // products with W^T as split bf16 rows in LDS (wt[k][n], n contiguous: lane (g, c) reads the 8
@@ -1169,8 +1300,10 @@ using namespace spt::fmlp;
 // 0: f32-in / f32-accumulate MFMA everywhere (bitwise an fmaf chain);
 // 1 (default): the BACKWARD GEMMs (gW, gx) on the bf16 matrix pipe with split operands - the
 //    gradients' parity bars are 1e-4 of the tensor's scale, ten times the split's error; the
-//    forward stays exact f32 because its outputs feed GraphNorm statistics and are held to
-//    2e-5 (measured with the split forward: 1e-4 after three normalised layers);
+//    forward's outputs feed GraphNorm statistics and are held to 2e-5 (measured with the 2-way
+//    split forward: 1e-4 after three normalised layers): it runs the 3-way split (6 products,
+//    f32-exact, fwd_kernel_x3) where that is enabled (spt_fused_linear_fwd_use_x3, default on),
+//    else the f32 matrix pipe;
 // 2: forward too;  3: plain bf16 operands (hi halves only) in both directions - the bf16
 //    precision mode.  Process-wide, returns the previous setting.
 static int g_fmlp_mode = 1;
@@ -1180,6 +1313,13 @@ static inline int fmlp_mode_of(int mode) { return mode < 0 ? g_fmlp_mode : (mode
 // (fused_mlp_dma.hip) where the shape is built, 0 = register-staged everywhere (the process-wide
 // switch holds under a per-call precision too, like the attention's formulation default).  Per
 // call: bit 2 of the mode word (SPT_FMLP_BWD_REGISTER_STAGED) forces the register-staged kernels.
+// forward of mode 1: 1 (default) = 3-way split on the bf16 pipe (fwd_kernel_x3), 0 = f32 matrix pipe
+static int g_fmlp_x3 = [] { const char* e = getenv("SPT_FMLP_X3"); return e ? (atoi(e) != 0) : 1; }();
+extern "C" int spt_fused_linear_fwd_use_x3(int on) {
+  const int prev = g_fmlp_x3;
+  if (on >= 0) g_fmlp_x3 = on != 0;
+  return prev;
+}
 static int g_fmlp_dma = 1;
 static inline bool fmlp_dma_of(int mode) { return g_fmlp_dma != 0 && !(mode >= 0 && (mode & 4)); }
 extern "C" int spt_fused_linear_bwd_use_dma(int on) {
@@ -1290,7 +1430,18 @@ static int fmlp_fwd_impl(const char* fn, const float* x, const FmlpRuns& rt, int
   int gx_ = grid_for(max_rows, per_cu);
   const int cap = MAX_BLOCKS / rt.n;
   if (gx_ > cap) gx_ = cap;
+  const bool x3 = g_fmlp_mode == 1 && g_fmlp_x3 && !(mode >= 0 && (mode & (SPT_FMLP_H_BF16 | SPT_FMLP_X_BF16)));
+  if (x3) {
+    // 8-wave workgroups (the W planes are shared through LDS): one or two per CU
+    const int64_t tiles = (max_rows + TR - 1) / TR;
+    int64_t blocks = (tiles + WAVES_X3 - 1) / WAVES_X3;
+    const int64_t cap8 = 256 * ((k4 * nbk <= 32) ? 2 : 1);
+    if (blocks > cap8) blocks = cap8;
+    if (blocks > cap) blocks = cap;
+    gx_ = (int)(blocks < 1 ? 1 : blocks);
+  }
   const dim3 grid((unsigned)gx_, (unsigned)rt.n);
+  const dim3 grid8 = grid;
   double* partial = (double*)ws;
   const bool h16 = mode >= 0 && (mode & SPT_FMLP_H_BF16), x16 = mode >= 0 && (mode & SPT_FMLP_X_BF16);
   if (h16 || x16) {
@@ -1321,6 +1472,9 @@ static int fmlp_fwd_impl(const char* fn, const float* x, const FmlpRuns& rt, int
     else if (g_fmlp_mode == 2)                                                         \
       fwd_kernel_bf<a, b, true><<<grid, WAVES * 64, 0, stream>>>(x, 0, 0, K, W, pre_am, pre_scale, \
                                                                  pre_bias, pre_slope, h, partial, rt);  \
+    else if (g_fmlp_mode == 1 && g_fmlp_x3)                                            \
+      fwd_kernel_x3<a, b><<<grid8, WAVES_X3 * 64, 0, stream>>>(x, 0, 0, K, W, pre_am, pre_scale, \
+                                                               pre_bias, pre_slope, h, partial, rt); \
     else                                                                               \
       fwd_kernel<a, b><<<grid, WAVES * 64, 0, stream>>>(x, 0, 0, K, W, pre_am, pre_scale, \
                                                         pre_bias, pre_slope, h, partial, rt);  \

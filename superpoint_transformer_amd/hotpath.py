@@ -16,6 +16,7 @@ import os
 import torch
 from torch import nn
 
+from . import _lib
 from . import csr as _csr
 from . import ops, parallel
 from .nn import SPT, Classifier, GraphNorm
@@ -100,7 +101,9 @@ def _kernel_names(mode):
                         "spt::el::attn_kv_reduce_kernel + spt::attn_reduce_partials_kernel",
             "attn_fwd": f"spt::mfma::attn_fwd_mfma_kernel<{p}>",
             "mlp_bwd_pooled": f"spt::fdma::bwd_dma_kernel<64, 128, 8, 2, {lo}, true" + (", true>" if st else ">"),
-            "mlp_fwd": "spt::fmlp::fwd_kernel<16, 8>" if mode == "f32"
+            "mlp_fwd": ("spt::fmlp::fwd_kernel_x3<16, 8> (f32 product as 6 bf16 products of 3-way split operands)"
+                        if _lib.lib.spt_fused_linear_fwd_use_x3(-1) else "spt::fmlp::fwd_kernel<16, 8>")
+                       if mode == "f32"
                        else ("spt::fmlp::fwd_kernel_bf<16, 8, false, true, true>" if st
                              else "spt::fmlp::fwd_kernel_bf<16, 8, false>")}
 
