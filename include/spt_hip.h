@@ -265,6 +265,10 @@ int spt_attn_use_mfma(int mode);
  * node may be cut between two waves); 0 = one tile set per source node (62-69 % full at mean
  * degree 16).  Same results up to f32 summation order.  Returns the previous setting. */
 int spt_attn_bwd_packed(int on);
+/* Request shape of the edge-lane backward's k / v gathers and [dk | dv] stores: 1 (default) = whole
+ * 128-byte lines per instruction, 0 = the 64-byte pieces of the MFMA layout.  Results are bit-identical;
+ * process-wide measurement switch (< 0: query), returns the previous setting. */
+int spt_attn_bwd_el_full_line(int on);
 int spt_edge_attn_bwd_f32(const float* qkv, int64_t n, int H, int D, int Dv,
                           const int32_t* erowptr, const int32_t* eperm,
                           const int32_t* tgt_sorted, int64_t e,

@@ -52,6 +52,7 @@ SIGNATURES = {
     "spt_edge_attn_bwd_workspace_bytes": (_sz, [_int, _int, _int, _int]),
     "spt_attn_use_mfma": (_int, [_int]),
     "spt_attn_bwd_packed": (_int, [_int]),
+    "spt_attn_bwd_el_full_line": (_int, [_int]),
     "spt_edge_attn_bwd_f32": (_int, [_p, _i64, _int, _int, _int, _p, _p, _p, _i64, _p, _int,
                                      _p, _p, _p, _p, _p, _p, _int, _f32, _p, _p, _p, _p,
                                      _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),

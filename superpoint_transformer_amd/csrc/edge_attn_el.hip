@@ -39,6 +39,7 @@
 // the bf16 matrix pipe, f32 accumulate (~10 ulp of f32 per product).  PREC = 1: hi only (bf16
 // matrix-precision mode).
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.hpp"
 
@@ -292,7 +293,16 @@ __global__ __launch_bounds__(256) void attn_kv_reduce_kernel(
 #define SPT_PROBE(i)
 #endif
 
-template <int PREC>
+// FL ("full line"): the gathered k / v rows and the streamed [dk | dv] rows move as WHOLE 128-byte
+// lines.  The MFMA layout gives lane (g, c) 16 bytes of edge c per request, so an instruction of
+// the plain mapping touches 16 rows x 64 bytes - every 128-byte line of the traffic is split over
+// two instructions.  With FL an instruction covers 4 edges x 256 bytes (lane l: edge 4 j + l / 16,
+// 16-byte chunk l % 16 of the wave's [k (128 B) | v (128 B)] half of the row): for the gathers the
+// DMA lands that as [edge][chunk] with the chunk position XOR-swizzled by the edge (the lane's own
+// (k, v) chunks are then conflict-free 16-byte LDS reads); for the stores the per-edge results go
+// through the same buffer (free once the rows are consumed) the other way round.  Same values, same
+// instruction counts - only the shape of each request changes.
+template <int PREC, bool FL>
 __global__ __launch_bounds__(WAVES * 64, 2) void attn_bwd_el_kernel(
     const float* __restrict__ qkv, int64_t E, const int32_t* __restrict__ ids3, int64_t ntiles,
     int64_t tpw, const float* __restrict__ ea, const float* __restrict__ Wk,
@@ -394,13 +404,25 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_bwd_el_kernel(
     };
     auto issue_gather = [&](int slot) {
       const int* ids = ids_ring + slot * 48;
-      const int64_t tc = ids[16 + c];
-      const float* kv = qkv + tc * LD + 32 * hh + 4 * g;
       float* G = L + L_G;
+      if constexpr (FL) {
+        // chunk ch of the wave's half row: ch < 8 -> k columns 64 + 32 hh + 4 ch, else v columns
+        // 128 + 32 hh + 4 (ch - 8); lane l fetches chunk (l % 16) ^ (edge % 16) of edge 4 j + l / 16
 #pragma unroll
-      for (int bl = 0; bl < NBW; ++bl) {
-        lds_dma16(kv + 64 + 16 * bl, G + (2 * bl + 0) * 256);
-        lds_dma16(kv + 128 + 16 * bl, G + (2 * bl + 1) * 256);
+        for (int j = 0; j < 4; ++j) {
+          const int e = 4 * j + g;
+          const int ch = c ^ e;
+          const int64_t tc = ids[16 + e];
+          lds_dma16(qkv + tc * LD + 64 + 32 * hh + 4 * ch + ((ch & 8) ? 32 : 0), G + j * 256);
+        }
+      } else {
+        const int64_t tc = ids[16 + c];
+        const float* kv = qkv + tc * LD + 32 * hh + 4 * g;
+#pragma unroll
+        for (int bl = 0; bl < NBW; ++bl) {
+          lds_dma16(kv + 64 + 16 * bl, G + (2 * bl + 0) * 256);
+          lds_dma16(kv + 128 + 16 * bl, G + (2 * bl + 1) * 256);
+        }
       }
     };
     // node rows of the tile's edges, straight into registers (asm: invisible to the compiler's
@@ -566,8 +588,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_bwd_el_kernel(
         }
 #pragma unroll
         for (int bl = 0; bl < NBW; ++bl) {
-          const f32x4 kt = *reinterpret_cast<const f32x4*>(Gb + (2 * bl + 0) * 256);
-          const f32x4 vt = *reinterpret_cast<const f32x4*>(Gb + (2 * bl + 1) * 256);
+          // FL: chunk 4 bl + g (k) / 8 + 4 bl + g (v) of edge c sits at position chunk ^ c
+          const f32x4 kt = FL ? *reinterpret_cast<const f32x4*>(L + L_G + c * 64 + 4 * ((4 * bl + g) ^ c))
+                              : *reinterpret_cast<const f32x4*>(Gb + (2 * bl + 0) * 256);
+          const f32x4 vt = FL ? *reinterpret_cast<const f32x4*>(L + L_G + c * 64 + 4 * ((8 + 4 * bl + g) ^ c))
+                              : *reinterpret_cast<const f32x4*>(Gb + (2 * bl + 1) * 256);
           const f32x4 qr = nq[bl];
           const f32x4 gs = ng[bl];
           float kk[4], q[4], v[4];
@@ -590,12 +615,37 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_bwd_el_kernel(
         }
         // dk / dv rows of the tile's edges, CSR order: row j = [dk (64) | dv (64)], this lane's four
         // dims of head 4 b + g of edge c - 16-byte non-temporal stores, summed per target later
-        float* drow = dkv + (t * TE + c) * 128 + 32 * hh + 4 * g;
-        if (valid) {                              // rows beyond the edge list own no row
+        if constexpr (FL) {
+          // through the (consumed) gather buffer: [edge c][position chunk ^ c] <- the lane's four
+          // chunks, read back as [edge 4 j + l / 16][position l % 16] = whole 128-byte lines
+          wait_lds();                             // the gathered rows are consumed
+          float* G = L + L_G;
 #pragma unroll
           for (int bl = 0; bl < NBW; ++bl) {
-            __builtin_nontemporal_store(Ck[bl], reinterpret_cast<f32x4*>(drow + 16 * bl));
-            __builtin_nontemporal_store(Cv[bl], reinterpret_cast<f32x4*>(drow + 64 + 16 * bl));
+            *reinterpret_cast<f32x4*>(G + c * 64 + 4 * ((4 * bl + g) ^ c)) = Ck[bl];
+            *reinterpret_cast<f32x4*>(G + c * 64 + 4 * ((8 + 4 * bl + g) ^ c)) = Cv[bl];
+          }
+          lds_order();
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int e = 4 * j + g;
+            const int ch = c ^ e;
+            const f32x4 v4 = *reinterpret_cast<const f32x4*>(G + j * 256 + lane * 4);
+            // rows beyond the edge list own no row (masked per lane: the instruction still issues,
+            // which keeps the counted waits valid - unless a whole instruction's edges are past the
+            // end, which only the LAST tile of the edge list can have: nothing is counted after it)
+            if (t * TE + e < E)
+              __builtin_nontemporal_store(
+                  v4, reinterpret_cast<f32x4*>(dkv + (t * TE + e) * 128 + 32 * hh + 4 * (ch & 7) + ((ch & 8) ? 64 : 0)));
+          }
+        } else {
+          float* drow = dkv + (t * TE + c) * 128 + 32 * hh + 4 * g;
+          if (valid) {                              // rows beyond the edge list own no row
+#pragma unroll
+            for (int bl = 0; bl < NBW; ++bl) {
+              __builtin_nontemporal_store(Ck[bl], reinterpret_cast<f32x4*>(drow + 16 * bl));
+              __builtin_nontemporal_store(Cv[bl], reinterpret_cast<f32x4*>(drow + 64 + 16 * bl));
+            }
           }
         }
       }
@@ -751,6 +801,15 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_bwd_el_kernel(
 
 }  // namespace el
 
+// request shape of the edge-lane backward's k / v gathers and [dk | dv] stores: 1 = whole 128-byte
+// lines per instruction (FL), 0 = the MFMA layout's own 64-byte pieces.  Same results bit for bit.
+static int g_attn_el_full_line = [] { const char* e = getenv("SPT_EL_FULL_LINE"); return e ? (atoi(e) != 0) : 1; }();
+extern "C" int spt_attn_bwd_el_full_line(int on) {
+  const int prev = g_attn_el_full_line;
+  if (on >= 0) g_attn_el_full_line = on != 0;
+  return prev;
+}
+
 // ---- launcher called from edge_attn.hip's C entry points ------------------------------------
 constexpr int ATTN_EL_MAX_PAIRS = 1024;     // 256 workgroups of 4 pairs: one workgroup per CU
 
@@ -808,14 +867,16 @@ int attn_bwd_el_launch(const float* qkv, int64_t n, const int32_t* erowptr, cons
   const int64_t tpw = ceil_div(ntiles, pairs);
   pairs = ceil_div(ntiles, tpw);
   const int grid = (int)ceil_div(pairs, el::WAVES / 2);
-  if (prec == 3)
-    el::attn_bwd_el_kernel<3><<<grid, el::WAVES * 64, 0, stream>>>(
-        qkv, e, tile_ids, ntiles, tpw, ea, Wk, bk, Wq, bq, Wv, bv, dm, qs, gout, gqkv, gea, gea_acc,
-        dkv, partial);
-  else
-    el::attn_bwd_el_kernel<1><<<grid, el::WAVES * 64, 0, stream>>>(
-        qkv, e, tile_ids, ntiles, tpw, ea, Wk, bk, Wq, bq, Wv, bv, dm, qs, gout, gqkv, gea, gea_acc,
-        dkv, partial);
+#define SPT_EL_LAUNCH(P, F)                                                                      \
+  el::attn_bwd_el_kernel<P, F><<<grid, el::WAVES * 64, 0, stream>>>(                             \
+      qkv, e, tile_ids, ntiles, tpw, ea, Wk, bk, Wq, bq, Wv, bv, dm, qs, gout, gqkv, gea, gea_acc, \
+      dkv, partial)
+  if (prec == 3) {
+    if (g_attn_el_full_line) SPT_EL_LAUNCH(3, true); else SPT_EL_LAUNCH(3, false);
+  } else {
+    if (g_attn_el_full_line) SPT_EL_LAUNCH(1, true); else SPT_EL_LAUNCH(1, false);
+  }
+#undef SPT_EL_LAUNCH
   const int64_t rblocks = ceil_div(n, (int64_t)8);
   el::attn_kv_reduce_kernel<<<(int)(rblocks < 256 * 16 ? rblocks : 256 * 16), 256, 0, stream>>>(
       dkv, tperm, trowptr, scl, n, gqkv);
