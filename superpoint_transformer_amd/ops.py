@@ -608,6 +608,15 @@ def edge_attention(qkv, edge_index, edge_attr=None, k_rpe=None, q_rpe=None, v_rp
     share = ea_grad if torch.is_grad_enabled() else None
     split = _matrix_pipe_split(qkv, edge_attr, Wk, Wq, Wv, H, D)
     if split is None:
+        padded = _matrix_pipe_pad(qkv, ecsr, edge_attr, Wk, bk, Wq, bq, Wv, bv, H, D)
+        if padded is not None:
+            # narrower head layouts (nano: 16 heads of qk_dim 2, value dim 1, 16-D edge encodings)
+            # zero-padded to the built (16, 4, 4, 32) shape: the matrix-pipe kernels instead of
+            # the generic VALU ones; plain torch ops do the padding, autograd their backward
+            qp, eap, wk, bkp, wq, bqp, wv, bvp, dv = padded
+            out = _EdgeAttention.apply(qp, ecsr, eap, wk, bkp, wq, bqp, wv, bvp, 16, 4,
+                                       int(scale_mode), float(scale_a), None)
+            return out.view(out.shape[0], 16, 4)[:, :, :dv].reshape(out.shape[0], 16 * dv)
         return _EdgeAttention.apply(qkv, ecsr, edge_attr, Wk, bk, Wq, bq, Wv, bv, H, D,
                                     int(scale_mode), float(scale_a), share)
     # wider head layouts (SPT-128: 16 heads of value dim 8; 32 heads) on the matrix-pipe kernels
@@ -777,6 +786,50 @@ class _EdgeAttentionSplit(torch.autograd.Function):
 
 
 _SPLIT_COLS = {}
+
+
+PAD_MIN_EDGES = 1 << 16        # below that the generic kernels are a few microseconds anyway
+
+
+def _matrix_pipe_pad(qkv, ecsr, edge_attr, Wk, bk, Wq, bq, Wv, bv, H, D):
+    """Operands of a head layout NARROWER than the built (16, 4, 4, 32) one, zero-padded to it
+    (H = 16, qk_dim <= 4, value dim <= 4, in_rpe_dim <= 32, all three RPE encoders, a
+    matrix-pipe precision active, enough edges to matter); None otherwise.  Exact: padded q / k
+    dims add zero to every dot product, padded value dims and edge-encoding columns meet zero
+    weights, the padded output dims are dropped."""
+    if H != 16 or D > 4 or edge_attr is None or Wk is None or Wq is None or Wv is None:
+        return None
+    F = edge_attr.shape[1]
+    C = qkv.shape[1] - 2 * H * D
+    if C <= 0 or C % H or F > 32 or ecsr.e < PAD_MIN_EDGES:
+        return None
+    Dv = C // H
+    if Dv > 4 or (D == 4 and Dv == 4 and F == 32):
+        return None
+    if qkv.dtype != torch.float32 or edge_attr.dtype != torch.float32:
+        return None
+    mode = _precision.attention_mode()
+    if mode < 0:
+        mode = _lib.lib.spt_attn_use_mfma(-2)
+    if (mode & 3) == 0:
+        return None
+    n, e = qkv.shape[0], edge_attr.shape[0]
+    pad = torch.nn.functional.pad
+
+    def heads(t, d):                                 # [rows, H * d] -> [rows, H * 4]
+        return t if d == 4 else pad(t.reshape(t.shape[0], H, d), (0, 4 - d)).reshape(t.shape[0], H * 4)
+
+    def enc(w, b, d):                                # ([H d, F], [H d]) -> ([H 4, 32], [H 4])
+        w = pad(w.reshape(H, d, F), (0, 32 - F, 0, 4 - d)).reshape(H * 4, 32)
+        b = None if b is None else pad(b.reshape(H, d), (0, 4 - d)).reshape(H * 4)
+        return w.contiguous(), b
+    q, k, v = qkv[:, :H * D], qkv[:, H * D:2 * H * D], qkv[:, 2 * H * D:]
+    qp = torch.cat([heads(q, D), heads(k, D), heads(v, Dv)], dim=1)
+    eap = edge_attr if F == 32 else pad(edge_attr, (0, 32 - F))
+    wk, bkp = enc(Wk, bk, D)
+    wq, bqp = enc(Wq, bq, D)
+    wv, bvp = enc(Wv, bv, Dv)
+    return qp, eap, wk, bkp, wq, bqp, wv, bvp, Dv
 
 
 def _matrix_pipe_split(qkv, edge_attr, Wk, Wq, Wv, H, D):

@@ -461,3 +461,47 @@ def test_wider_head_layouts_decompose_onto_the_matrix_pipe_kernels(H, Dv, dev):
     got = run("f32")
     for a, r in zip(got, ref):
         assert (a - r).abs().max().item() <= 1e-5 + 2e-4 * r.abs().max().item()
+
+
+@pytest.mark.parametrize("D,Dv,F", [(2, 1, 16), (4, 2, 32), (2, 4, 18)])
+def test_narrower_head_layouts_are_zero_padded_onto_the_matrix_pipe_kernels(D, Dv, F, dev):
+    """The nano family (configs/model/semantic/nano-2.yaml: 16 heads of qk_dim 2, value dim 1,
+    16-D edge encodings) and other layouts NARROWER than the built (16, 4, 4, 32) one run on the
+    matrix-pipe kernels with zero-padded operands (ops._matrix_pipe_pad: padded q / k dims add
+    zero to the dot products, padded value dims and encoding columns meet zero weights, padded
+    outputs are dropped - exact).  Against the generic VALU kernels of the same call, forward and
+    every gradient."""
+    from superpoint_transformer_amd import _lib, ops, precision
+    gen = torch.Generator().manual_seed(D * 100 + Dv * 10 + F)
+    n, H = 500, 16
+    ei = _rand_graph(gen, n, 12.0)
+    E = ei.shape[1]
+    qkv = torch.randn(n, 2 * H * D + H * Dv, generator=gen)
+    ea = torch.randn(E, F, generator=gen) * 0.4
+    W = [(torch.randn(c, F, generator=gen) * 0.1, torch.randn(c, generator=gen) * 0.1)
+         for c in (H * D, H * D, H * Dv)]
+    gw = torch.randn(n, H * Dv, generator=gen)
+    old_min = ops.PAD_MIN_EDGES
+
+    def run(padded):
+        q = qkv.to(dev).requires_grad_()
+        e = ea.to(dev).requires_grad_()
+        ps = [(w.to(dev).requires_grad_(), b.to(dev).requires_grad_()) for w, b in W]
+        ops.PAD_MIN_EDGES = 0 if padded else 1 << 60
+        try:
+            with precision.matrix_precision("f32"):
+                ecsr = ops.edge_csr_of(ei.to(dev), n)
+                took = ops._matrix_pipe_pad(q, ecsr, e, ps[0][0], ps[0][1], ps[1][0], ps[1][1],
+                                            ps[2][0], ps[2][1], H, D) is not None
+                assert took == padded
+                out = ops.edge_attention(q, ei.to(dev), e, *ps, num_heads=H, qk_dim=D, scale_a=0.7)
+                (out * gw.to(dev)).sum().backward()
+        finally:
+            ops.PAD_MIN_EDGES = old_min
+        return [out.detach(), q.grad, e.grad] + [t.grad for p in ps for t in p]
+
+    ref = run(False)
+    got = run(True)
+    assert got[0].shape == (n, H * Dv)
+    for a, r in zip(got, ref):
+        assert (a - r).abs().max().item() <= 1e-5 + 2e-4 * r.abs().max().item()

@@ -3,7 +3,7 @@
 # scenes S and T (rocprofv3 --kernel-trace of the same command), PMC traffic of the roofline kernels.
 #   tools/round_profiles.sh <tag>      -> gpurun_out/<tag>_*
 cd $GRAFT_REPO_ROOT
-TAG=${1:-r03x}
+TAG=${1:-r04x}
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 python bench.py 2>/dev/null | grep '^{"metric' > gpurun_out/${TAG}_bench_sceneS.json
