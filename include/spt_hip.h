@@ -172,6 +172,19 @@ int spt_unit_sphere_assemble_f32(const float* pos, const int64_t* idx,
                                  const float* w_f32, const int64_t* w_i64,
                                  int64_t n, int64_t num_seg, const float* x, int cx,
                                  float* xcat, float* diam, float* center, spt_stream_t stream);
+/* Both entries with a caller workspace of spt_unit_sphere_workspace_bytes(n, num_seg) bytes:
+ * segments of thousands of rows (idx = NULL: the whole top level is one segment, norm.py:86-110)
+ * are reduced by several workgroups each and merged in a fixed order instead of by one. */
+size_t spt_unit_sphere_workspace_bytes(int64_t n, int64_t num_seg);
+int spt_unit_sphere_norm_ws_f32(const float* pos, const int64_t* idx, const int32_t* perm,
+                                const int32_t* rowptr, const float* w_f32, const int64_t* w_i64,
+                                int64_t n, int64_t num_seg, float* pos_out, float* diam,
+                                float* center, void* ws, size_t ws_bytes, spt_stream_t stream);
+int spt_unit_sphere_assemble_ws_f32(const float* pos, const int64_t* idx, const int32_t* perm,
+                                    const int32_t* rowptr, const float* w_f32, const int64_t* w_i64,
+                                    int64_t n, int64_t num_seg, const float* x, int cx, float* xcat,
+                                    float* diam, float* center, void* ws, size_t ws_bytes,
+                                    spt_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * GraphNorm forward / backward, optionally fused with LeakyReLU      (a5)

@@ -134,6 +134,10 @@ SIGNATURES = {
                                         _sz, _p]),
     "spt_unit_sphere_norm_f32": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _p, _p, _p, _p]),
     "spt_unit_sphere_assemble_f32": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _p, _int, _p, _p, _p, _p]),
+    "spt_unit_sphere_workspace_bytes": (_sz, [_i64, _i64]),
+    "spt_unit_sphere_norm_ws_f32": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _p, _p, _p, _p, _sz, _p]),
+    "spt_unit_sphere_assemble_ws_f32": (_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _p, _int, _p, _p, _p,
+                                               _p, _sz, _p]),
     "spt_sparse_sample_workspace_bytes": (_sz, [_i64, _i64]),
     "spt_sparse_sample": (_int, [_p, _i64, _i64, _p, _int, _int, _c.c_uint64, _p, _p, _p, _sz, _p]),
     "spt_segment_std_f32": (_int, [_p, _p, _p, _i64, _int, _p, _p]),

@@ -132,6 +132,61 @@ __global__ __launch_bounds__(256) void usn_stats_block_kernel(
   }
 }
 
+// Few, HUGE segments (idx = None at the top level: one segment of 178 571 nodes at scene S) with a
+// caller workspace: blockIdx.x = slice of the segment, blockIdx.y = segment; every block writes its
+// partial box, a second kernel merges the P partials of a segment in slice order (deterministic).
+// The one-block-per-segment kernel above walks such a segment with 256 threads: 0.40 ms at scene S.
+__global__ __launch_bounds__(256) void usn_stats_split_kernel(
+    const float* __restrict__ pos, const int32_t* __restrict__ perm,
+    const int32_t* __restrict__ rowptr, const float* __restrict__ wf,
+    const int64_t* __restrict__ wi, int P, Box* __restrict__ part_out) {
+  __shared__ Box part[4];
+  const int64_t s = blockIdx.y;
+  const int64_t start = rowptr[s], end = rowptr[s + 1];
+  const int64_t chunk = (end - start + P - 1) / P;
+  const int64_t a = start + (int64_t)blockIdx.x * chunk;
+  const int64_t b_end = (a + chunk < end) ? a + chunk : end;
+  Box b;
+  box_init(b);
+  for (int64_t j = a + threadIdx.x; j < b_end; j += blockDim.x) {
+    const int64_t r = perm ? perm[j] : j;
+    box_add(b, pos[r * 3], pos[r * 3 + 1], pos[r * 3 + 2], row_weight(wf, wi, r));
+  }
+  for (int o = 1; o < 64; o <<= 1) box_merge_xor(b, o);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = b;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        b.mn[k] = fminf(b.mn[k], part[w].mn[k]);
+        b.mx[k] = fmaxf(b.mx[k], part[w].mx[k]);
+        b.sx[k] += part[w].sx[k];
+      }
+      b.sw += part[w].sw;
+    }
+    part_out[s * P + blockIdx.x] = b;
+  }
+}
+__global__ __launch_bounds__(256) void usn_stats_merge_kernel(
+    const Box* __restrict__ part, const int32_t* __restrict__ rowptr, int64_t num_seg, int P,
+    float* __restrict__ center, float* __restrict__ diam) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= num_seg) return;
+  Box b = part[s * P];
+  for (int p = 1; p < P; ++p) {
+    const Box q = part[s * P + p];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      b.mn[k] = fminf(b.mn[k], q.mn[k]);
+      b.mx[k] = fmaxf(b.mx[k], q.mx[k]);
+      b.sx[k] += q.sx[k];
+    }
+    b.sw += q.sw;
+  }
+  box_finish(b, rowptr[s + 1] - rowptr[s], center + s * 3, diam + s);
+}
+
 // out[i] = (pos[i] - center[idx[i]]) / (diam[idx[i]] + 1e-2)    norm.py:132-136
 __global__ __launch_bounds__(256) void usn_apply_kernel(
     const float* __restrict__ pos, const int64_t* __restrict__ idx,
@@ -184,10 +239,25 @@ __global__ __launch_bounds__(256) void usn_assemble_kernel(
 
 using namespace spt;
 
+// slices per segment of the split statistics (few huge segments): ~2 048 rows per block, the whole
+// launch within 4 096 blocks and 65 535 segments
+static int usn_slices(int64_t n, int64_t num_seg) {
+  if (num_seg < 1 || num_seg > 65535) return 1;
+  const int64_t avg = n / num_seg;
+  int64_t p = ceil_div(avg, (int64_t)2048);
+  const int64_t cap = 4096 / num_seg > 1 ? 4096 / num_seg : 1;
+  if (p > cap) p = cap;
+  return (int)(p < 1 ? 1 : p);
+}
+extern "C" size_t spt_unit_sphere_workspace_bytes(int64_t n, int64_t num_seg) {
+  return (size_t)(num_seg > 0 ? num_seg : 1) * usn_slices(n, num_seg) * sizeof(Box) + 256;
+}
+
 static int usn_launch(const float* pos, const int64_t* idx, const int32_t* perm,
                       const int32_t* rowptr, const float* w_f32, const int64_t* w_i64, int64_t n,
                       int64_t num_seg, float* pos_out, const float* x, int cx, float* xcat,
-                      float* diam, float* center, hipStream_t stream);
+                      float* diam, float* center, hipStream_t stream, void* ws = nullptr,
+                      size_t ws_bytes = 0);
 
 extern "C" int spt_unit_sphere_norm_f32(const float* pos, const int64_t* idx,
                                         const int32_t* perm, const int32_t* rowptr,
@@ -214,17 +284,49 @@ extern "C" int spt_unit_sphere_assemble_f32(const float* pos, const int64_t* idx
                     center, (hipStream_t)stream_);
 }
 
+// The two entries above with a caller workspace (spt_unit_sphere_workspace_bytes): segments of
+// thousands of rows (idx = NULL at the top level of a scene) are reduced by several workgroups
+// each - partial boxes in the workspace, merged in a fixed order - instead of one.
+extern "C" int spt_unit_sphere_norm_ws_f32(const float* pos, const int64_t* idx,
+                                           const int32_t* perm, const int32_t* rowptr,
+                                           const float* w_f32, const int64_t* w_i64, int64_t n,
+                                           int64_t num_seg, float* pos_out, float* diam,
+                                           float* center, void* ws, size_t ws_bytes,
+                                           spt_stream_t stream_) {
+  SPT_CHECK_ARG(n == 0 || pos_out, "null pos_out");
+  return usn_launch(pos, idx, perm, rowptr, w_f32, w_i64, n, num_seg, pos_out, nullptr, 0, nullptr,
+                    diam, center, (hipStream_t)stream_, ws, ws_bytes);
+}
+extern "C" int spt_unit_sphere_assemble_ws_f32(const float* pos, const int64_t* idx,
+                                               const int32_t* perm, const int32_t* rowptr,
+                                               const float* w_f32, const int64_t* w_i64, int64_t n,
+                                               int64_t num_seg, const float* x, int cx, float* xcat,
+                                               float* diam, float* center, void* ws,
+                                               size_t ws_bytes, spt_stream_t stream_) {
+  SPT_CHECK_ARG(cx >= 4 && cx % 4 == 0, "x needs a multiple of 4 columns");
+  SPT_CHECK_ARG(n == 0 || (x && xcat), "null x / xcat");
+  SPT_CHECK_ARG(((uintptr_t)x | (uintptr_t)xcat) % 16 == 0, "x / xcat must be 16-byte aligned");
+  return usn_launch(pos, idx, perm, rowptr, w_f32, w_i64, n, num_seg, nullptr, x, cx, xcat, diam,
+                    center, (hipStream_t)stream_, ws, ws_bytes);
+}
+
 static int usn_launch(const float* pos, const int64_t* idx, const int32_t* perm,
                       const int32_t* rowptr, const float* w_f32, const int64_t* w_i64, int64_t n,
                       int64_t num_seg, float* pos_out, const float* x, int cx, float* xcat,
-                      float* diam, float* center, hipStream_t stream) {
+                      float* diam, float* center, hipStream_t stream, void* ws, size_t ws_bytes) {
   SPT_CHECK_ARG(n >= 0 && num_seg >= 1, "bad shape");
   SPT_CHECK_ARG(rowptr && diam && center, "null pointer");
   SPT_CHECK_ARG(n == 0 || pos, "null pos");
   SPT_CHECK_ARG(!(w_f32 && w_i64), "pass at most one weight array");
   SPT_CHECK_ARG(idx || num_seg == 1, "idx may be null only for a single segment");
   const int64_t avg = n / num_seg;
-  if (avg >= 2048) {
+  const int P = usn_slices(n, num_seg);
+  if (avg >= 2048 && P > 1 && ws && ws_bytes >= (size_t)num_seg * P * sizeof(Box)) {
+    usn_stats_split_kernel<<<dim3(P, (unsigned)num_seg), 256, 0, stream>>>(
+        pos, perm, rowptr, w_f32, w_i64, P, (Box*)ws);
+    usn_stats_merge_kernel<<<(int)ceil_div(num_seg, 256), 256, 0, stream>>>(
+        (const Box*)ws, rowptr, num_seg, P, center, diam);
+  } else if (avg >= 2048) {
     const int grid = (int)(num_seg < 4096 ? num_seg : 4096);
     usn_stats_block_kernel<<<grid, 256, 0, stream>>>(pos, perm, rowptr, w_f32, w_i64,
                                                      num_seg, center, diam);

@@ -285,12 +285,14 @@ def unit_sphere_norm(pos, idx, w=None, num_super=None):
     out = torch.empty_like(pos)
     diam = torch.empty(num_seg, dtype=torch.float32, device=dev)
     center = torch.empty((num_seg, 3), dtype=torch.float32, device=dev)
+    nb = _lib.lib.spt_unit_sphere_workspace_bytes(n, num_seg)
+    ws = _workspace(nb, dev)
     with torch.cuda.device(dev):
-        st = _lib.lib.spt_unit_sphere_norm_f32(
+        st = _lib.lib.spt_unit_sphere_norm_ws_f32(
             _lib.ptr(pos), _lib.ptr(idx_t), _lib.ptr(perm), _lib.ptr(rowptr),
             _lib.ptr(wf), _lib.ptr(wi), n, num_seg, _lib.ptr(out), _lib.ptr(diam),
-            _lib.ptr(center), _lib.stream_ptr(dev))
-    _lib.check(st, "spt_unit_sphere_norm_f32")
+            _lib.ptr(center), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+    _lib.check(st, "spt_unit_sphere_norm_ws_f32")
     return out, diam.view(-1, 1)
 
 
@@ -303,12 +305,14 @@ class _UnitSphereAssemble(torch.autograd.Function):
         out = torch.empty((n, 4 + cx), dtype=torch.float32, device=dev)
         diam = torch.empty(num_seg, dtype=torch.float32, device=dev)
         center = torch.empty((num_seg, 3), dtype=torch.float32, device=dev)
+        nb = _lib.lib.spt_unit_sphere_workspace_bytes(n, num_seg)
+        ws = _workspace(nb, dev)
         with torch.cuda.device(dev):
-            st = _lib.lib.spt_unit_sphere_assemble_f32(
+            st = _lib.lib.spt_unit_sphere_assemble_ws_f32(
                 _lib.ptr(pos), _lib.ptr(idx_t), _lib.ptr(perm), _lib.ptr(rowptr), _lib.ptr(wf),
                 _lib.ptr(wi), n, num_seg, _lib.ptr(x2), cx, _lib.ptr(out), _lib.ptr(diam),
-                _lib.ptr(center), _lib.stream_ptr(dev))
-        _lib.check(st, "spt_unit_sphere_assemble_f32")
+                _lib.ptr(center), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+        _lib.check(st, "spt_unit_sphere_assemble_ws_f32")
         diam = diam.view(-1, 1)
         ctx.mark_non_differentiable(diam)
         ctx.x_dtype = x.dtype
