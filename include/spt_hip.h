@@ -282,6 +282,18 @@ int spt_attn_bwd_packed(int on);
  * 128-byte lines per instruction, 0 = the 64-byte pieces of the MFMA layout.  Results are bit-identical;
  * process-wide measurement switch (< 0: query), returns the previous setting. */
 int spt_attn_bwd_el_full_line(int on);
+/* Edge order of the edge-lane backward: 1 (default) = the edge stream sorted by TARGET node
+ * (csrc/edge_attn_to.hip: k / v of the target are L1 hits, dk / dv are reduced inside the tile, the
+ * streamed per-edge quantity is dq - half the bytes of [dk | dv]), 0 = by source
+ * (csrc/edge_attn_el.hip).  Process-wide (< 0: query), returns the previous setting.  The tile
+ * records a caller builds once per batch and level differ between the two:
+ * spt_attn_pack_tile_ids_ex writes the format of the current setting, spt_attn_tile_record_ints()
+ * ints per 16-edge tile (64 / 48). */
+int spt_attn_bwd_el_target_order(int on);
+int spt_attn_tile_record_ints(void);
+int spt_attn_pack_tile_ids_ex(const int32_t* eperm, const int32_t* tgt_sorted,
+                              const int32_t* src_sorted, const int32_t* tperm, int64_t e,
+                              int32_t* tile_ids, spt_stream_t stream);
 int spt_edge_attn_bwd_f32(const float* qkv, int64_t n, int H, int D, int Dv,
                           const int32_t* erowptr, const int32_t* eperm,
                           const int32_t* tgt_sorted, int64_t e,

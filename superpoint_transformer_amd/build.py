@@ -32,6 +32,7 @@ FLAGS = [
 PER_FILE_FLAGS = {
     "edge_attn_mfma.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
     "edge_attn_el.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+    "edge_attn_to.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
     "fused_mlp.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
     "fused_mlp_dma.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
 }

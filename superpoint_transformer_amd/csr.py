@@ -159,18 +159,22 @@ class EdgeCSR:
         self._tile_ids = None
 
     def tile_ids(self):
-        """int32 [ceil(e / 16), 48]: the edge-lane attention backward's tile records (edge rows |
-        targets | sources of 16 consecutive CSR positions), built on first use."""
-        if self._tile_ids is None:
+        """int32 [ceil(e / 16), 48 | 64]: the edge-lane attention backward's tile records, built on
+        first use in the format of the current process setting: 16 consecutive positions of the
+        edge stream in TARGET order (edge rows | targets | sources | source-order positions), or in
+        source (CSR) order (edge rows | targets | sources)."""
+        ints = int(_lib.lib.spt_attn_tile_record_ints())     # 64: target order, 48: source order
+        if self._tile_ids is None or self._tile_ids.shape[1] != ints:
             dev = self.tgt_sorted.device
             nt = (self.e + 15) // 16
-            out = torch.empty((max(nt, 1), 48), dtype=torch.int32, device=dev)
+            out = torch.empty((max(nt, 1), ints), dtype=torch.int32, device=dev)
             src = self.src_sorted()
+            tperm = self.target_view().perm if ints == 64 else None
             with torch.cuda.device(dev):
-                st = _lib.lib.spt_attn_pack_tile_ids(
-                    _lib.ptr(self.eperm), _lib.ptr(self.tgt_sorted), _lib.ptr(src), self.e,
-                    _lib.ptr(out), _lib.stream_ptr(dev))
-            _lib.check(st, "spt_attn_pack_tile_ids")
+                st = _lib.lib.spt_attn_pack_tile_ids_ex(
+                    _lib.ptr(self.eperm), _lib.ptr(self.tgt_sorted), _lib.ptr(src), _lib.ptr(tperm),
+                    self.e, _lib.ptr(out), _lib.stream_ptr(dev))
+            _lib.check(st, "spt_attn_pack_tile_ids_ex")
             self._tile_ids = out
         return self._tile_ids
 

@@ -770,6 +770,18 @@ int attn_bwd_mfma_launch(const float* qkv, int64_t n, const int32_t* erowptr,
 size_t attn_bwd_el_workspace_bytes(int64_t n, int64_t e);
 void attn_pack_tile_ids_launch(const int32_t* eperm, const int32_t* tgt, const int32_t* src,
                                int64_t e, int32_t* ids3, hipStream_t stream);
+// edge_attn_to.hip: the same backward over the edge stream in TARGET order
+bool attn_bwd_to_enabled();
+size_t attn_bwd_to_workspace_bytes(int64_t n, int64_t e);
+void attn_pack_tile_ids_to_launch(const int32_t* eperm, const int32_t* tgt, const int32_t* src,
+                                  const int32_t* tperm, int64_t e, int32_t* ids4, hipStream_t stream);
+int attn_bwd_to_launch(const float* qkv, int64_t n, const int32_t* erowptr, const int32_t* eperm,
+                       const int32_t* tgt, const int32_t* src, const int32_t* tile_ids,
+                       const int32_t* tperm, int64_t e, const float* ea, const float* Wk,
+                       const float* bk, const float* Wq, const float* bq, const float* Wv,
+                       const float* bv, int scale_mode, float scale_a, const float* out,
+                       const float* m, const float* z, const float* gout, float* gqkv, float* gea,
+                       int gea_acc, float* partial, void* ws, int prec, hipStream_t stream);
 int attn_bwd_el_launch(const float* qkv, int64_t n, const int32_t* erowptr, const int32_t* eperm,
                        const int32_t* tgt, const int32_t* src, const int32_t* tile_ids,
                        const int32_t* tperm, const int32_t* trowptr, int64_t e, const float* ea,
@@ -956,6 +968,25 @@ extern "C" int spt_attn_pack_tile_ids(const int32_t* eperm, const int32_t* tgt_s
   return 0;
 }
 
+// Tile records in the format the edge-lane backward of the current process setting reads
+// (spt_attn_bwd_el_target_order): 64 ints per tile in TARGET order when it is on (needs `tperm`,
+// the CSR view of the targets over the CSR positions, and `src_sorted`), else the 48-int
+// source-order records of spt_attn_pack_tile_ids.  spt_attn_tile_record_ints() = ints per tile.
+extern "C" int spt_attn_tile_record_ints(void) { return attn_bwd_to_enabled() ? 64 : 48; }
+extern "C" int spt_attn_pack_tile_ids_ex(const int32_t* eperm, const int32_t* tgt_sorted,
+                                         const int32_t* src_sorted, const int32_t* tperm, int64_t e,
+                                         int32_t* tile_ids, spt_stream_t stream_) {
+  SPT_CHECK_ARG(e >= 0 && (e == 0 || (tgt_sorted && src_sorted && tile_ids)), "null pointer");
+  if (attn_bwd_to_enabled()) {
+    SPT_CHECK_ARG(e == 0 || tperm, "target-order tile records need the target view (tperm)");
+    attn_pack_tile_ids_to_launch(eperm, tgt_sorted, src_sorted, tperm, e, tile_ids, (hipStream_t)stream_);
+  } else {
+    attn_pack_tile_ids_launch(eperm, tgt_sorted, src_sorted, e, tile_ids, (hipStream_t)stream_);
+  }
+  SPT_CHECK_LAUNCH();
+  return 0;
+}
+
 // The general entry: `src_sorted` (nullable) = source node of every CSR position (edge_index[0]
 // in CSR order); `tile_ids` (nullable) = spt_attn_pack_tile_ids of the graph; `tperm` / `trowptr`
 // (nullable, both or none) = CSR view of tgt_sorted over the
@@ -1008,7 +1039,15 @@ extern "C" int spt_edge_attn_bwd_ex_f32(const float* qkv, int64_t n, int H, int 
                     "edge-lane backward: workspace of spt_edge_attn_bwd_ex_workspace_bytes, the "
                     "target CSR view and a bf16-pipe precision are required");
     SPT_CHECK_ARG((tperm == nullptr) == (trowptr == nullptr), "pass both tperm and trowptr or neither");
-    if (form == 2 && prec >= 2 && e > 0 && ws_bytes >= need_el && tperm) {
+    if (form == 2 && prec >= 2 && e > 0 && ws_bytes >= need_el && tperm && src_sorted &&
+        attn_bwd_to_enabled()) {
+      // edge stream in target order (edge_attn_to.hip); `tile_ids`, when given, are the 64-int
+      // records of spt_attn_pack_tile_ids_ex
+      ntab = attn_bwd_to_launch(qkv, n, erowptr, eperm, tgt_sorted, src_sorted, tile_ids, tperm, e,
+                                edge_attr, Wk, bk, Wq, bq, Wv, bv, scale_mode, scale_a, out, m, z,
+                                gout, gqkv, gedge_attr, gea_acc, partial, (char*)ws + need,
+                                prec == 2 ? 3 : 1, stream);
+    } else if (form == 2 && prec >= 2 && e > 0 && ws_bytes >= need_el && tperm) {
       ntab = attn_bwd_el_launch(qkv, n, erowptr, eperm, tgt_sorted, src_sorted, tile_ids, tperm,
                                 trowptr, e, edge_attr, Wk,
                                 bk, Wq, bq, Wv, bv, scale_mode, scale_a, out, m, z, gout, gqkv,

@@ -97,8 +97,11 @@ def _kernel_names(mode):
     lo = "true" if mode == "f32" else "false"
     from . import precision
     st = mode == "bf16" and precision.bf16_activation_storage()   # layer outputs stored as bf16
-    return {"attn_bwd": f"spt::el::attn_bwd_prep_kernel + spt::el::attn_bwd_el_kernel<{p}> + "
-                        "spt::el::attn_kv_reduce_kernel + spt::attn_reduce_partials_kernel",
+    to = bool(_lib.lib.spt_attn_bwd_el_target_order(-1))           # edge stream by target / by source
+    return {"attn_bwd": (f"spt::to::attn_bwd_to_prep_kernel + spt::to::attn_bwd_to_kernel<{p}> + "
+                         "spt::to::attn_q_reduce_kernel + spt::attn_reduce_partials_kernel" if to else
+                         f"spt::el::attn_bwd_prep_kernel + spt::el::attn_bwd_el_kernel<{p}> + "
+                         "spt::el::attn_kv_reduce_kernel + spt::attn_reduce_partials_kernel"),
             "attn_fwd": f"spt::mfma::attn_fwd_mfma_kernel<{p}>",
             "mlp_bwd_pooled": f"spt::fdma::bwd_dma_kernel<64, 128, 8, 2, {lo}, true" + (", true>" if st else ">"),
             "mlp_fwd": ("spt::fmlp::fwd_kernel_x3<16, 8> (f32 product as 6 bf16 products of 3-way split operands)"

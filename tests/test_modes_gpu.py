@@ -284,6 +284,11 @@ def test_two_models_at_different_precisions_interleaved_on_two_streams(dev):
         outs["b"] = run(mb, s2)
     torch.cuda.synchronize()
     assert torch.equal(outs["a"][0], ref_a[0]) and torch.equal(outs["b"][0], ref_b[0])
-    for got, ref in ((outs["a"][1], ref_a[1]), (outs["b"][1], ref_b[1])):
-        assert (got - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+    # gradients: equal up to the order of the attention backward's atomic sums (dk / dv per target
+    # in the target-order kernel).  In the bf16 mode that ~1e-7 noise decides bf16 roundings of
+    # the next backward's operands one way or the other (2^-9 per flipped value): 1e-3 there
+    for name, got, ref, tol in (("f32-exact", outs["a"][1], ref_a[1], 1e-4),
+                                ("bf16", outs["b"][1], ref_b[1], 1e-3)):
+        err = (got - ref).abs().max().item() / ref.abs().max().item()
+        assert err <= tol, (name, err)
     assert (ref_a[0] - ref_b[0]).abs().max().item() > 1e-5 * ref_a[0].abs().max().item()

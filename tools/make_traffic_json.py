@@ -31,8 +31,15 @@ def find(sub, counter, col):
 
 
 def entry(label, kernels, col):
-    f = [find(k, "FETCH_SIZE", col) for k in kernels]
-    w = [find(k, "WRITE_SIZE", col) for k in kernels]
+    # a kernel may be given as alternatives "a|b": the first one the capture holds
+    def pick(k, counter):
+        for alt in k.split("|"):
+            v = find(alt, counter, col)
+            if v is not None:
+                return v
+        return None
+    f = [pick(k, "FETCH_SIZE") for k in kernels]
+    w = [pick(k, "WRITE_SIZE") for k in kernels]
     if any(v is None for v in f + w):
         return None
     fetch, write = sum(f), sum(w)
@@ -48,11 +55,13 @@ out = {"_comment": "HBM bytes per launch from rocprofv3 PMC passes over the trai
                    "(<op>@<scene>/<net>): no entry, no traffic figure"}
 spec = {
     "segmax": ("spt::segmax_stream_kernel<true>", ["segmax_stream_kernel"], "avg"),
-    "attn_bwd": ("spt::el::attn_bwd_el_kernel + spt::el::attn_kv_reduce_kernel, level-1 launches",
-                 ["attn_bwd_el_kernel", "attn_kv_reduce_kernel"], "hi"),
+    "attn_bwd": ("main kernel + per-node reduction of the edge-lane attention backward "
+                 "(spt::to::attn_bwd_to_kernel + attn_q_reduce_kernel, or spt::el::attn_bwd_el_kernel + "
+                 "attn_kv_reduce_kernel), level-1 launches",
+                 ["attn_bwd_to_kernel|attn_bwd_el_kernel", "attn_q_reduce_kernel|attn_kv_reduce_kernel"], "hi"),
     "attn_fwd": ("spt::mfma::attn_fwd_mfma_kernel, level-1 launches", ["attn_fwd_mfma_kernel"], "hi"),
     "mlp_bwd_pooled": ("spt::fdma::bwd_dma_kernel<64, 128, 8, 2, true, true>", ["bwd_dma_kernel<64, 128"], "avg"),
-    "mlp_fwd": ("spt::fmlp::fwd_kernel<16, 8>", ["fwd_kernel<16, 8>"], "avg"),
+    "mlp_fwd": ("spt::fmlp::fwd_kernel_x3<16, 8> (or fwd_kernel<16, 8>)", ["fwd_kernel_x3<16, 8>|fwd_kernel<16, 8>"], "avg"),
 }
 try:                                   # keep the entries of other workloads / legs
     import os
