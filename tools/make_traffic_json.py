@@ -55,10 +55,11 @@ out = {"_comment": "HBM bytes per launch from rocprofv3 PMC passes over the trai
                    "(<op>@<scene>/<net>): no entry, no traffic figure"}
 spec = {
     "segmax": ("spt::segmax_stream_kernel<true>", ["segmax_stream_kernel"], "avg"),
-    "attn_bwd": ("main kernel + per-node reduction of the edge-lane attention backward "
+    "attn_bwd": ("prep + main kernel + per-node reduction of the edge-lane attention backward "
                  "(spt::to::attn_bwd_to_kernel + attn_q_reduce_kernel, or spt::el::attn_bwd_el_kernel + "
                  "attn_kv_reduce_kernel), level-1 launches",
-                 ["attn_bwd_to_kernel|attn_bwd_el_kernel", "attn_q_reduce_kernel|attn_kv_reduce_kernel"], "hi"),
+                 ["attn_bwd_to_kernel|attn_bwd_el_kernel", "attn_q_reduce_kernel|attn_kv_reduce_kernel",
+                  "attn_bwd_to_prep_kernel|attn_bwd_prep_kernel"], "hi"),
     "attn_fwd": ("spt::mfma::attn_fwd_mfma_kernel, level-1 launches", ["attn_fwd_mfma_kernel"], "hi"),
     "mlp_bwd_pooled": ("spt::fdma::bwd_dma_kernel<64, 128, 8, 2, true, true>", ["bwd_dma_kernel<64, 128"], "avg"),
     "mlp_fwd": ("spt::fmlp::fwd_kernel_x3<16, 8> (or fwd_kernel<16, 8>)", ["fwd_kernel_x3<16, 8>|fwd_kernel<16, 8>"], "avg"),
