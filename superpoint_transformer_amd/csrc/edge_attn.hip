@@ -963,6 +963,11 @@ extern "C" int spt_attn_pack_tile_ids(const int32_t* eperm, const int32_t* tgt_s
                                       const int32_t* src_sorted, int64_t e, int32_t* tile_ids,
                                       spt_stream_t stream_) {
   SPT_CHECK_ARG(e >= 0 && (e == 0 || (tgt_sorted && src_sorted && tile_ids)), "null pointer");
+  // the 48-int source-order records: the target-order backward (the default) reads another format
+  // and would silently walk garbage - refuse instead of writing records nobody can use
+  SPT_CHECK_ARG(!attn_bwd_to_enabled(),
+                "the target-order backward is on: build the tile records with spt_attn_pack_tile_ids_ex "
+                "(or switch it off with spt_attn_bwd_el_target_order(0))");
   attn_pack_tile_ids_launch(eperm, tgt_sorted, src_sorted, e, tile_ids, (hipStream_t)stream_);
   SPT_CHECK_LAUNCH();
   return 0;
