@@ -36,7 +36,7 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-preprocess", action="store_true")
     p.add_argument("--no-f32-exact", action="store_true",
-                   help="skip the 5 extra steps that time the f32-matrix-pipe variant of the step")
+                   help="skip the extra steps that time the f32-matrix-pipe and the bf16 variants of the step")
     p.add_argument("--cpu-scale", type=float, default=None)
     p.add_argument("--stages", default="all")
     p.add_argument("--mode", default="train", choices=["train", "infer", "panoptic"],
@@ -350,6 +350,20 @@ def main():
         torch.cuda.synchronize()
         exact_ms = (time.perf_counter() - t1) / 3 * 1e3
         precision.set_matrix_precision(args.dtype)
+    # ... and under the reference's other trainer setting (`precision: bf16`, BASELINE config #2's
+    # wording): bf16 matrix operands + bf16 storage of the point MLP's layer outputs
+    bf16_ms = None
+    if args.dtype == "f32" and world == 1 and args.mode == "train" and not args.no_f32_exact:
+        precision.set_matrix_precision("bf16")
+        for _ in range(2):
+            path.step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            path.step()
+        torch.cuda.synchronize()
+        bf16_ms = (time.perf_counter() - t1) / 5 * 1e3
+        precision.set_matrix_precision(args.dtype)
 
     cpu = None
     pre = None
@@ -390,6 +404,7 @@ def main():
                                if precision.bf16_activation_storage() else
                                "bf16 (matrix operands; f32 accumulate, storage and statistics)")}[args.dtype],
             "ms_per_step_f32_exact": round(exact_ms, 4) if exact_ms else None,
+            "ms_per_step_bf16": round(bf16_ms, 4) if bf16_ms else None,
             "data": "synthetic",
             "config": {
                 "workload": workload,

@@ -60,21 +60,23 @@ __global__ void knn_gather_sorted_kernel(const float* __restrict__ pos,
   }
 }
 
-// lane ^ J exchange without the LDS crossbar: DPP row operations inside a 16-lane row,
-// gfx950's v_permlane16_swap / v_permlane32_swap across rows.
+// lane ^ J exchange without the LDS crossbar: DPP row operations inside a 16-lane row (every lane
+// has a source: no `old` value, no register initialisation), gfx950's v_permlane16_swap /
+// v_permlane32_swap across rows.
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_all(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xF, 0xF, true);
+}
 template <int J>
 __device__ __forceinline__ uint32_t xor_lane_u32(uint32_t v) {
-  const int x = (int)v;
   if constexpr (J == 1) {
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, false);      // quad [1,0,3,2]
+    return dpp_all<0xB1>(v);                      // quad [1,0,3,2]
   } else if constexpr (J == 2) {
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, false);      // quad [2,3,0,1]
-  } else if constexpr (J == 4) {                                                     // ^3 then ^7
-    const int t = __builtin_amdgcn_update_dpp(0, x, 0x1B, 0xF, 0xF, false);         // quad [3,2,1,0]
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, t, 0x141, 0xF, 0xF, false);     // row_half_mirror
-  } else if constexpr (J == 8) {                                                     // ^7 then ^15
-    const int t = __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, false);        // row_half_mirror
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, t, 0x140, 0xF, 0xF, false);     // row_mirror
+    return dpp_all<0x4E>(v);                      // quad [2,3,0,1]
+  } else if constexpr (J == 4) {
+    return dpp_all<0x141>(dpp_all<0x1B>(v));      // ^3 (quad [3,2,1,0]) then ^7 (row_half_mirror)
+  } else if constexpr (J == 8) {
+    return dpp_all<0x128>(v);                     // row_ror:8
   } else if constexpr (J == 16) {
     const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);   // {[v0 v0 v2 v2], [v1 v1 v3 v3]}
     return (threadIdx.x & 16) ? r[0] : r[1];
@@ -89,9 +91,7 @@ __device__ __forceinline__ uint64_t xor_lane_u64(uint64_t v) {
 }
 
 __device__ __forceinline__ uint64_t row_mirror_u64(uint64_t v) {
-  const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, 0x140, 0xF, 0xF, false);
-  const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), 0x140, 0xF, 0xF, false);
-  return ((uint64_t)hi << 32) | lo;
+  return ((uint64_t)dpp_all<0x140>((uint32_t)(v >> 32)) << 32) | dpp_all<0x140>((uint32_t)v);
 }
 // value of a wave-uniform lane index (v_readlane, no LDS permute)
 __device__ __forceinline__ uint64_t read_lane_u64(uint64_t v, int src) {
@@ -100,14 +100,35 @@ __device__ __forceinline__ uint64_t read_lane_u64(uint64_t v, int src) {
   return ((uint64_t)hi << 32) | lo;
 }
 
+// One compare-exchange of the bitonic network: the lane keeps min or max of (its key, the key of
+// lane ^ J).  ONE 64-bit compare; which side a lane keeps is a compile-time lane mask combined
+// with the compare's mask on the scalar unit: 5 vector instructions per step inside a row (two
+// DPP moves, the compare, two selects), 7 for J = 4 and across rows.
+//   across rows: the swap instruction leaves (A, B) = (key, partner) in even rows / row halves and
+//   (partner, key) in odd ones, and the lane's result is `(A < B) == wants_min ? A : B` in both
+//   (an odd lane that wants the minimum takes A = its partner exactly when A < B).
 template <int K, int J>
 __device__ __forceinline__ uint64_t bitonic_step(uint64_t key, int lane) {
-  const uint64_t other = xor_lane_u64<J>(key);
-  const bool asc = (lane & K) == 0;
-  const bool lower = (lane & J) == 0;
-  const uint64_t mn = key < other ? key : other;
-  const uint64_t mx = key < other ? other : key;
-  return (lower == asc) ? mn : mx;
+  const bool want_min = ((lane & K) == 0) == ((lane & J) == 0);
+  if constexpr (J >= 16) {
+    const uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
+    uint64_t A, B;
+    if constexpr (J == 16) {
+      const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+      const auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+      A = ((uint64_t)rh[0] << 32) | rl[0];
+      B = ((uint64_t)rh[1] << 32) | rl[1];
+    } else {
+      const auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+      const auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+      A = ((uint64_t)rh[0] << 32) | rl[0];
+      B = ((uint64_t)rh[1] << 32) | rl[1];
+    }
+    return ((A < B) == want_min) ? A : B;
+  } else {
+    const uint64_t other = xor_lane_u64<J>(key);
+    return ((key < other) == want_min) ? key : other;
+  }
 }
 template <int K, int J>
 __device__ __forceinline__ uint64_t bitonic_merge_steps(uint64_t key, int lane) {
@@ -324,20 +345,54 @@ __global__ __launch_bounds__(KNN_WAVES * 64) void knn_search_kernel(
 //           read back as broadcasts: every lane evaluates ITS distance to the same candidate;
 //   pass A: per-lane histogram (KC_NBINS bins of d2 over [0, B2], B2 = min(guaranteed radius^2
 //           of ring 1, r^2)) -> smallest bin edge holding >= K candidates;
-//   pass B: candidates at or below that bin are appended to the lane's list (<= 64 entries);
+//   pass B: candidates at or below that bin are appended to the lane's list (<= 64 entries) -
+//           one comparison per candidate against the largest d2 of that bin (found once per
+//           round by one-ulp steps around bin edge / scale, so that it is EXACTLY pass A's set);
 //   sort  : per query one 64-lane bitonic sort of its list, K results written.
+// The kernel is bound by its vector instruction count (PMC: ~0.8 VALU busy at 2 waves per SIMD):
+// round 4 halved it - candidates staged per coordinate (packed f32 arithmetic on candidate pairs,
+// no register shuffles), 5-7 instructions per compare-exchange of the sort network instead of
+// 12-16, the row of a list entry by one table read instead of a 9-range search.
 // A lane whose ring-1 neighbourhood does not guarantee its K-th neighbour (fewer than K
 // candidates within B2 while r reaches further; a bin so dense that the list would overflow)
 // is appended to `todo` and finished by knn_search_kernel afterwards: same exact contract.
 constexpr int KC_WAVES = 4;
 constexpr int KC_NBINS = 16;
 constexpr int KC_CAP = 64;
-constexpr int KC_W = 3;
+// measurement builds (tools/build_variant.sh ... -DSPT_KC_W=<cells> -DSPT_KC_MAXBLK=<blocks>)
+#ifndef SPT_KC_W
+#define SPT_KC_W 3
+#endif
+#ifndef SPT_KC_G
+#define SPT_KC_G 4
+#endif
+#ifndef SPT_KC_MASKED_ADD
+#define SPT_KC_MASKED_ADD 0
+#endif
+#ifndef SPT_KC_SKIP     /* 1: no sort stage, 2: no pass B and no sort, 4: no distance work in pass A */
+#define SPT_KC_SKIP 0
+#endif
+#ifndef SPT_KC_MAXBLK
+#define SPT_KC_MAXBLK 256
+#endif
+constexpr int KC_W = SPT_KC_W;
+// 64-candidate blocks per round (16 384 candidates; denser rounds go to the wave-per-query kernel).
+// A wave's LDS is 14.3 KB: two workgroups per CU - three (a shorter table) measured 3 % slower,
+// the candidate passes are bound by the LDS pipe (broadcast reads + histogram atomics), not by
+// latency
+constexpr int KC_MAXBLK = SPT_KC_MAXBLK;
 
 struct KcLds {
   uint32_t hist[KC_NBINS][64];
   uint16_t list[KC_CAP + 1][64];   // + 1: the branch-free append always stores, then maybe advances
-  float4 stage[64];
+  // the staged candidates, one array per coordinate: a 16-byte broadcast read hands every lane the
+  // same coordinate of FOUR candidates in adjacent registers - the operand pairs of the packed f32
+  // instructions as they come, no register shuffles in front of the distance arithmetic
+  float sx[64], sy[64], sz[64];
+  // the round's candidate stream as blocks of <= 64 consecutive positions of the cell order: first
+  // position and length; a list entry is 64 * block + slot, a candidate's row one table read away
+  int32_t blk[KC_MAXBLK];
+  uint8_t blkm[KC_MAXBLK];
 };
 
 __device__ __forceinline__ void kc_wave_sync() {
@@ -356,13 +411,23 @@ __device__ __forceinline__ float kc_d2(const float4& q, const float4& p) {
   return (ddx * ddx + ddy * ddy) + ddz * ddz;       // the contract's rounding order
 }
 
-// 64 candidates of one range into the wave's staging tile; slots beyond m hold a point
-// that is out of every radius, so the consumers run whole groups of 4 without a tail
-__device__ __forceinline__ void kc_stage(KcLds& L, const float4* __restrict__ sorted, int first,
-                                         int m, int lane) {
-  kc_wave_sync();
-  L.stage[lane] = lane < m ? sorted[first + lane] : make_float4(1e30f, 1e30f, 1e30f, 0.f);
-  kc_wave_sync();
+// squared distances of the query to staged candidates t .. t + 3 (the contract's rounding order),
+// two candidates per packed f32 instruction
+typedef float kc_f32x2 __attribute__((ext_vector_type(2)));
+typedef float kc_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void kc_d2x4(const KcLds& L, int t, const float4& q, float (&d2)[4]) {
+  const kc_f32x4 X = *reinterpret_cast<const kc_f32x4*>(&L.sx[t]);
+  const kc_f32x4 Y = *reinterpret_cast<const kc_f32x4*>(&L.sy[t]);
+  const kc_f32x4 Z = *reinterpret_cast<const kc_f32x4*>(&L.sz[t]);
+  const kc_f32x2 qx = {q.x, q.x}, qy = {q.y, q.y}, qz = {q.z, q.z};
+  const kc_f32x2 ax = qx - X.xy, ay = qy - Y.xy, az = qz - Z.xy;
+  const kc_f32x2 bx = qx - X.zw, by = qy - Y.zw, bz = qz - Z.zw;
+  const kc_f32x2 a = (ax * ax + ay * ay) + az * az;
+  const kc_f32x2 b = (bx * bx + by * by) + bz * bz;
+  d2[0] = a.x;
+  d2[1] = a.y;
+  d2[2] = b.x;
+  d2[3] = b.y;
 }
 
 __global__ __launch_bounds__(KC_WAVES * 64) void knn_cell_kernel(
@@ -399,7 +464,7 @@ __global__ __launch_bounds__(KC_WAVES * 64) void knn_cell_kernel(
       const bool mine = ((pending >> lane) & 1) && cy == ly && cz == lz && cx >= lx &&
                         cx < lx + KC_W;
       pending &= ~__ballot(mine);
-      // the 9 candidate ranges (lanes 0..8), their prefix bases and the total
+      // the 9 candidate ranges (lanes 0..8)
       int rs = 0, rl = 0;
       if (lane < 9) {
         const int z = lz + lane / 3 - 1, y = ly + lane % 3 - 1;
@@ -411,39 +476,60 @@ __global__ __launch_bounds__(KC_WAVES * 64) void knn_cell_kernel(
           rl = rowptr[rb + x1 + 1] - rs;
         }
       }
-      const int rbase = (int)wave_inclusive_scan((uint32_t)rl) - rl;   // exclusive prefix
-      int rs_u[9], rl_u[9], rb_u[9];                                   // wave-uniform copies
-#pragma unroll
-      for (int ri = 0; ri < 9; ++ri) {
-        rs_u[ri] = __builtin_amdgcn_readlane(rs, ri);
-        rl_u[ri] = __builtin_amdgcn_readlane(rl, ri);
-        rb_u[ri] = __builtin_amdgcn_readlane(rbase, ri);
-      }
-      const int ncand = rb_u[8] + rl_u[8];
+      // the round's candidate stream as a table of <= 64-candidate blocks (first position in
+      // `sorted`, length): lanes 0..8 write the blocks of their range at its prefix offset
+      const int nbk = (rl + 63) >> 6;
+      const int bpre = (int)wave_inclusive_scan((uint32_t)nbk) - nbk;
+      const int nblk = __builtin_amdgcn_readlane(bpre + nbk, 8);
       bool ok = false;
       int bK = KC_NBINS - 1, len = 0;
-      if (ncand <= 65535) {
+      // candidate rows of block bi, one per lane (slots past the block's end hold a point that is
+      // out of every radius: the consumers run whole groups of 4 without a tail)
+      auto fetch_blk = [&](int bi) -> float4 {
+        float4 p = make_float4(1e30f, 1e30f, 1e30f, 0.f);
+        if (bi < nblk) {
+          const int base = L.blk[bi], m = (int)L.blkm[bi];
+          if (lane < m) p = sorted[base + lane];
+        }
+        return p;
+      };
+      // block bi into the staging arrays (its rows were requested one block earlier and travelled
+      // while the previous block was evaluated); returns its length
+      auto stage_blk = [&](int bi, const float4& p) -> int {
+        kc_wave_sync();                                   // every lane is done with the previous block
+        L.sx[lane] = p.x;
+        L.sy[lane] = p.y;
+        L.sz[lane] = p.z;
+        kc_wave_sync();
+        return __builtin_amdgcn_readfirstlane((int)L.blkm[bi]);
+      };
+      if (nblk <= KC_MAXBLK) {
+        kc_wave_sync();                                   // (the previous round's table readers)
+        for (int jb = 0; jb < nbk; ++jb) {
+          L.blk[bpre + jb] = rs + 64 * jb;
+          L.blkm[bpre + jb] = (uint8_t)(rl - 64 * jb < 64 ? rl - 64 * jb : 64);
+        }
         // ---- pass A: per-lane histogram of d2 (lanes outside the group count too: their
         //      columns are simply not read) --------------------------------------------------
 #pragma unroll
         for (int b = 0; b < KC_NBINS; ++b) L.hist[b][lane] = 0u;
+        kc_wave_sync();
+        float4 nxt = fetch_blk(0);
+        for (int bi = 0; bi < nblk; ++bi) {
+          const int m = stage_blk(bi, nxt);
+          nxt = fetch_blk(bi + 1);
+          for (int t = 0; t < ((SPT_KC_SKIP & 4) ? 0 : m); t += 4) {
+            float d2[4];
+            kc_d2x4(L, t, q, d2);
+            const kc_f32x2 s01 = (kc_f32x2){d2[0], d2[1]} * bin_scale;     // packed: d2 * bin_scale
+            const kc_f32x2 s23 = (kc_f32x2){d2[2], d2[3]} * bin_scale;
+            const float sc[4] = {s01.x, s01.y, s23.x, s23.y};
 #pragma unroll
-        for (int ri = 0; ri < 9; ++ri) {
-          for (int b0 = 0; b0 < rl_u[ri]; b0 += 64) {
-            const int m = rl_u[ri] - b0 < 64 ? rl_u[ri] - b0 : 64;
-            kc_stage(L, sorted, rs_u[ri] + b0, m, lane);
-            for (int t = 0; t < m; t += 4) {
-              float4 p[4];
-#pragma unroll
-              for (int u = 0; u < 4; ++u) p[u] = L.stage[t + u];
-#pragma unroll
-              for (int u = 0; u < 4; ++u) {
-                const float d2 = kc_d2(q, p[u]);
-                int bin = (int)(d2 * bin_scale);
-                bin = bin > KC_NBINS - 1 ? KC_NBINS - 1 : bin;
-                __hip_atomic_fetch_add(&L.hist[bin][lane], d2 <= lim ? 1u : 0u, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_WAVEFRONT);
-              }
+            for (int u = 0; u < 4; ++u) {
+              int bin = (int)sc[u];
+              bin = bin > KC_NBINS - 1 ? KC_NBINS - 1 : bin;
+              __hip_atomic_fetch_add(&L.hist[bin][lane], d2[u] <= lim ? 1u : 0u, __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_WAVEFRONT);
             }
           }
         }
@@ -466,6 +552,9 @@ __global__ __launch_bounds__(KC_WAVES * 64) void knn_cell_kernel(
         }
       }
       ok = ok && mine;
+#if SPT_KC_SKIP & 4
+      ok = mine;
+#endif
       // ---- lanes the fast path cannot finish ----------------------------------------------
       const uint64_t fb = __ballot(mine && !ok);
       if (fb) {
@@ -476,35 +565,52 @@ __global__ __launch_bounds__(KC_WAVES * 64) void knn_cell_kernel(
       }
       uint64_t todo_sort = __ballot(ok);
       if (todo_sort == 0) continue;
-      // ---- pass B: the candidates at or below the lane's bin, as positions in the round's
-      //      candidate enumeration (branch-free append: store, then advance if taken) --------
-      const int bKe = ok ? bK : -1;
+#if SPT_KC_SKIP & 2     /* measurement: rounds end after pass A */
+      continue;
+#endif
+      // ---- pass B: the candidates at or below the lane's bin, as 64 * block + slot
+      //      (branch-free append: store, then advance if taken) --------------------------------
+      // take <=> d2 <= lim and bin(d2) <= bK, with bin(d2) = min(int(d2 * bin_scale), NBINS - 1) as
+      // in pass A.  bin is monotone in d2, so the second condition is d2 <= D for the largest float
+      // D with fl(D * bin_scale) < bK + 1: found once per round (a division and one-ulp steps), and
+      // the per-candidate test is ONE comparison against min(lim, D)
+      float dlim = -1.0f;                                  // lanes not in the round take nothing
+      if (ok) {
+        dlim = lim;
+        if (bK < KC_NBINS - 1) {
+          const float thr = (float)(bK + 1);
+          float D = thr / bin_scale;
+          while (D * bin_scale >= thr) D = __uint_as_float(__float_as_uint(D) - 1u);
+          while (__uint_as_float(__float_as_uint(D) + 1u) * bin_scale < thr)
+            D = __uint_as_float(__float_as_uint(D) + 1u);
+          dlim = D < lim ? D : lim;
+        }
+      }
       int nl = 0;
-#pragma unroll
-      for (int ri = 0; ri < 9; ++ri) {
-        for (int b0 = 0; b0 < rl_u[ri]; b0 += 64) {
-          const int m = rl_u[ri] - b0 < 64 ? rl_u[ri] - b0 : 64;
-          kc_stage(L, sorted, rs_u[ri] + b0, m, lane);
-          const int pb = rb_u[ri] + b0;
+      {
+        float4 nxt = fetch_blk(0);
+        for (int bi = 0; bi < nblk; ++bi) {
+          const int m = stage_blk(bi, nxt);
+          nxt = fetch_blk(bi + 1);
+          const int pb = 64 * bi;
           for (int t = 0; t < m; t += 4) {
-            float4 p[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) p[u] = L.stage[t + u];
+            float d2[4];
+            kc_d2x4(L, t, q, d2);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-              const float d2 = kc_d2(q, p[u]);
-              int bin = (int)(d2 * bin_scale);
-              bin = bin > KC_NBINS - 1 ? KC_NBINS - 1 : bin;
-              const bool take = d2 <= lim && bin <= bKe;
               L.list[nl][lane] = (uint16_t)(pb + t + u);
-              nl += take ? 1 : 0;
+              nl += d2[u] <= dlim ? 1 : 0;
             }
           }
         }
       }
       kc_wave_sync();
-      // ---- per query: 64-lane sort of its list, K results; the candidate rows of the next
-      //      query are in flight while the current one sorts ---------------------------------
+#if SPT_KC_SKIP & 1     /* measurement: no per-query sort / output */
+      continue;
+#endif
+      // ---- per query: 64-lane sort of its list, K results.  The candidate rows of a query are a
+      //      64-lane gather (L2 latency >> one sort): the rows of the NEXT four queries (pairs of
+      //      queries) are in flight while the current four sort ---------------------------------
       // lists of <= 32 candidates (K <= 32: the DALES setting k = 25) are sorted two queries at a
       // time, one per half wave
 #ifdef SPT_KNN_NO_PAIR   /* measurement builds only */
@@ -514,76 +620,86 @@ __global__ __launch_bounds__(KC_WAVES * 64) void knn_cell_kernel(
 #endif
       uint64_t big = todo_sort & ~small;
       uint64_t pairs = small;
-      auto gidx = [&](int pos) {
-        int gi = 0;
+      auto gidx = [&](int pos) { return L.blk[pos >> 6] + (pos & 63); };
+      constexpr int KC_G = SPT_KC_G;                        // queries (pairs) per prefetch group
+      if (pairs) {
+        auto next_pair = [&](int& qa, int& qb) {
+          qa = qb = -1;
+          if (!pairs) return;
+          qa = __ffsll((unsigned long long)pairs) - 1;
+          pairs &= pairs - 1;
+          qb = pairs ? __ffsll((unsigned long long)pairs) - 1 : qa;            // odd one out: alone
+          pairs &= pairs - 1;
+        };
+        auto fetch2 = [&](int qa, int qb) -> float4 {
+          float4 pc = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (qa < 0) return pc;
+          const int qh = (lane < 32) ? qa : qb;                                // the query of this half
+          const int n = __shfl(len, qh, 64);
+          if ((lane & 31) < n && (lane < 32 || qb != qa)) pc = sorted[gidx((int)L.list[lane & 31][qh])];
+          return pc;
+        };
+        auto sort2 = [&](int qa, int qb, const float4& pc2) {
+          const int qh = (lane < 32) ? qa : qb;
+          const int hl = lane & 31;
+          const bool live = lane < 32 || qb != qa;
+          const int n = __shfl(len, qh, 64);
+          float4 qq;
+          qq.x = __shfl(q.x, qh, 64);
+          qq.y = __shfl(q.y, qh, 64);
+          qq.z = __shfl(q.z, qh, 64);
+          const int64_t qi = (int64_t)(uint32_t)__shfl(__float_as_int(q.w), qh, 64);
+          uint64_t key = KNN_EMPTY;
+          if (hl < n && live)
+            key = ((uint64_t)__float_as_uint(kc_d2(qq, pc2)) << 32) | (uint32_t)__float_as_int(pc2.w);
+          key = wave_sort_halves(key, lane);
+          if (hl < K && live) {
+            const bool okk = key != KNN_EMPTY;
+            float d = __uint_as_float((uint32_t)(key >> 32));
+            if (!squared) d = sqrtf(d);
+            out_idx[qi * K + hl] = okk ? (int64_t)(uint32_t)(key & 0xffffffffu) : -1;
+            out_dist[qi * K + hl] = okk ? d : -1.0f;
+          }
+        };
+        int qa[KC_G], qb[KC_G];
+        float4 pc2[KC_G];
 #pragma unroll
-        for (int ri = 0; ri < 9; ++ri) gi = pos >= rb_u[ri] ? rs_u[ri] + (pos - rb_u[ri]) : gi;
-        return gi;
-      };
-      // (the candidate rows of the next pair are in flight while the current one sorts)
-      auto next_pair = [&](int& qa, int& qb) {
-        qa = qb = -1;
-        if (!pairs) return;
-        qa = __ffsll((unsigned long long)pairs) - 1;
-        pairs &= pairs - 1;
-        qb = pairs ? __ffsll((unsigned long long)pairs) - 1 : qa;              // odd one out: alone
-        pairs &= pairs - 1;
-      };
-      auto fetch2 = [&](int qa, int qb) -> float4 {
-        float4 pc = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (qa < 0) return pc;
-        const int qh = (lane < 32) ? qa : qb;                                  // the query of this half
-        const int n = __shfl(len, qh, 64);
-        if ((lane & 31) < n && (lane < 32 || qb != qa)) pc = sorted[gidx((int)L.list[lane & 31][qh])];
-        return pc;
-      };
-      int qa, qb;
-      next_pair(qa, qb);
-      float4 pc2 = fetch2(qa, qb);
-      while (qa >= 0) {
-        int na, nb2;
-        next_pair(na, nb2);
-        const float4 pn2 = fetch2(na, nb2);
-        const int qh = (lane < 32) ? qa : qb;
-        const int hl = lane & 31;
-        const bool live = lane < 32 || qb != qa;
-        const int n = __shfl(len, qh, 64);
-        float4 qq;
-        qq.x = __shfl(q.x, qh, 64);
-        qq.y = __shfl(q.y, qh, 64);
-        qq.z = __shfl(q.z, qh, 64);
-        const int64_t qi = (int64_t)(uint32_t)__shfl(__float_as_int(q.w), qh, 64);
-        uint64_t key = KNN_EMPTY;
-        if (hl < n && live)
-          key = ((uint64_t)__float_as_uint(kc_d2(qq, pc2)) << 32) | (uint32_t)__float_as_int(pc2.w);
-        key = wave_sort_halves(key, lane);
-        if (hl < K && live) {
-          const bool okk = key != KNN_EMPTY;
-          float d = __uint_as_float((uint32_t)(key >> 32));
-          if (!squared) d = sqrtf(d);
-          out_idx[qi * K + hl] = okk ? (int64_t)(uint32_t)(key & 0xffffffffu) : -1;
-          out_dist[qi * K + hl] = okk ? d : -1.0f;
+        for (int gq = 0; gq < KC_G; ++gq) next_pair(qa[gq], qb[gq]);
+#pragma unroll
+        for (int gq = 0; gq < KC_G; ++gq) pc2[gq] = fetch2(qa[gq], qb[gq]);
+        while (qa[0] >= 0) {
+          int na[KC_G], nb2[KC_G];
+          float4 pn2[KC_G];
+#pragma unroll
+          for (int gq = 0; gq < KC_G; ++gq) next_pair(na[gq], nb2[gq]);
+#pragma unroll
+          for (int gq = 0; gq < KC_G; ++gq) pn2[gq] = fetch2(na[gq], nb2[gq]);
+#pragma unroll
+          for (int gq = 0; gq < KC_G; ++gq)
+            if (qa[gq] >= 0) sort2(qa[gq], qb[gq], pc2[gq]);
+#pragma unroll
+          for (int gq = 0; gq < KC_G; ++gq) {
+            qa[gq] = na[gq];
+            qb[gq] = nb2[gq];
+            pc2[gq] = pn2[gq];
+          }
         }
-        qa = na;
-        qb = nb2;
-        pc2 = pn2;
       }
       todo_sort = big;
       if (todo_sort == 0) continue;
+      auto next_q = [&]() {
+        const int ql = todo_sort ? __ffsll((unsigned long long)todo_sort) - 1 : -1;
+        todo_sort &= todo_sort - 1;
+        return ql;
+      };
       auto fetch = [&](int ql) -> float4 {
         float4 pc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ql < 0) return pc;
         const int n = __builtin_amdgcn_readlane(len, ql);
         if (lane < n) pc = sorted[gidx((int)L.list[lane][ql])];
         return pc;
       };
-      int ql = __ffsll((unsigned long long)todo_sort) - 1;
-      todo_sort &= todo_sort - 1;
-      float4 pc = fetch(ql);
-      while (true) {
-        const int qn = todo_sort ? __ffsll((unsigned long long)todo_sort) - 1 : -1;
-        todo_sort &= todo_sort - 1;
-        float4 pn = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (qn >= 0) pn = fetch(qn);
+      auto sort1 = [&](int ql, const float4& pc) {
         const int n = __builtin_amdgcn_readlane(len, ql);
         float4 qq;
         qq.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.x), ql));
@@ -601,9 +717,28 @@ __global__ __launch_bounds__(KC_WAVES * 64) void knn_cell_kernel(
           out_idx[qi * K + lane] = okk ? (int64_t)(uint32_t)(key & 0xffffffffu) : -1;
           out_dist[qi * K + lane] = okk ? d : -1.0f;
         }
-        if (qn < 0) break;
-        ql = qn;
-        pc = pn;
+      };
+      int qc[KC_G];
+      float4 pc[KC_G];
+#pragma unroll
+      for (int gq = 0; gq < KC_G; ++gq) qc[gq] = next_q();
+#pragma unroll
+      for (int gq = 0; gq < KC_G; ++gq) pc[gq] = fetch(qc[gq]);
+      while (qc[0] >= 0) {
+        int qn[KC_G];
+        float4 pn[KC_G];
+#pragma unroll
+        for (int gq = 0; gq < KC_G; ++gq) qn[gq] = next_q();
+#pragma unroll
+        for (int gq = 0; gq < KC_G; ++gq) pn[gq] = fetch(qn[gq]);
+#pragma unroll
+        for (int gq = 0; gq < KC_G; ++gq)
+          if (qc[gq] >= 0) sort1(qc[gq], pc[gq]);
+#pragma unroll
+        for (int gq = 0; gq < KC_G; ++gq) {
+          qc[gq] = qn[gq];
+          pc[gq] = pn[gq];
+        }
       }
     }
   }
