@@ -349,10 +349,12 @@ __global__ __launch_bounds__(KNN_WAVES * 64) void knn_search_kernel(
 //           one comparison per candidate against the largest d2 of that bin (found once per
 //           round by one-ulp steps around bin edge / scale, so that it is EXACTLY pass A's set);
 //   sort  : per query one 64-lane bitonic sort of its list, K results written.
-// The kernel is bound by its vector instruction count (PMC: ~0.8 VALU busy at 2 waves per SIMD):
-// round 4 halved it - candidates staged per coordinate (packed f32 arithmetic on candidate pairs,
-// no register shuffles), 5-7 instructions per compare-exchange of the sort network instead of
-// 12-16, the row of a list entry by one table read instead of a 9-range search.
+// Round 4 halved the vector instruction count - candidates staged per coordinate (packed f32
+// arithmetic on candidate pairs, no register shuffles), 5-7 instructions per compare-exchange of
+// the sort network instead of 12-16, the row of a list entry by one table read instead of a
+// 9-range search - and keeps four queries' candidate rows in flight per group of sorts: the sort
+// stage went from 8.5 to 6.0 ms at scene S, the two candidate passes stayed at ~13 ms: they are
+// bound by the LDS pipe (broadcast reads + per-lane atomics / stores), DESIGN.md 7.3 item 8.
 // A lane whose ring-1 neighbourhood does not guarantee its K-th neighbour (fewer than K
 // candidates within B2 while r reaches further; a bin so dense that the list would overflow)
 // is appended to `todo` and finished by knn_search_kernel afterwards: same exact contract.
