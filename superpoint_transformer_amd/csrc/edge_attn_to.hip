@@ -73,7 +73,7 @@ constexpr int WB_ELEMS = 192 * WB_LD;
 //   follower: [top] k / v rows (4), old d edge_attr rows of tile k (2)
 //             [core] dq rows (2)  [mid] source records of tile k+1 (5)
 //             [tail] d edge_attr rows (2), dk / dv atomics (0..16)
-constexpr int N_DQ = 2;
+constexpr int N_DQ = 2;                 // dq stores per tile and wave (f32 rows; bf16 rows: 1)
 constexpr int N_GATHER = 5;
 
 __device__ __forceinline__ void lds_dma16(const float* g, float* lds) {
@@ -203,6 +203,20 @@ __global__ __launch_bounds__(256) void pack_tile_ids_to_kernel(
 // source are the contiguous run [erowptr[s], erowptr[s + 1]) of the temporary (the main kernel
 // writes every edge's row at its source-order position), summed in ascending order (deterministic).
 // A quarter wave per node: 16 lanes x 16 bytes = one 256-byte row per load, eight rows in flight.
+// B16 (the bf16 mode): the rows hold bf16 values (128 bytes per edge), 8 bytes per lane.
+template <bool B16>
+__device__ __forceinline__ f32x4 dq_row_chunk(const float* __restrict__ dqt, int64_t row, int l16) {
+  if constexpr (B16) {
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 u = __builtin_nontemporal_load(
+        reinterpret_cast<const u32x2*>(reinterpret_cast<const uint16_t*>(dqt) + row * 64 + 4 * l16));
+    return (f32x4){__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
+                   __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+  } else {
+    return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(dqt + row * 64 + 4 * l16));
+  }
+}
+template <bool B16>
 __global__ __launch_bounds__(256) void attn_q_reduce_kernel(
     const float* __restrict__ dqt, const int32_t* __restrict__ erowptr,
     const float* __restrict__ scl, int64_t N, float* __restrict__ gqkv) {
@@ -216,8 +230,7 @@ __global__ __launch_bounds__(256) void attn_q_reduce_kernel(
     for (; u + 8 <= b; u += 8) {
       f32x4 v[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
-        v[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(dqt + (int64_t)(u + i) * 64 + 4 * l16));
+      for (int i = 0; i < 8; ++i) v[i] = dq_row_chunk<B16>(dqt, (int64_t)(u + i), l16);
 #pragma unroll
       for (int i = 0; i < 8; ++i) acc += v[i];
     }
@@ -226,7 +239,7 @@ __global__ __launch_bounds__(256) void attn_q_reduce_kernel(
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int64_t j = u + i < b ? u + i : b - 1;
-        v[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(dqt + j * 64 + 4 * l16));
+        v[i] = dq_row_chunk<B16>(dqt, j, l16);
       }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -247,6 +260,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_bwd_to_kernel(
     float* __restrict__ partial) {
   static_assert(PREC == 1 || PREC == 3, "bf16 matrix pipe only");
   constexpr bool LO = PREC == 3;
+  // the bf16 mode streams its dq rows as bf16: 64 bytes per edge and wave, ONE store per tile
+  constexpr bool DQ16 = PREC == 1;
+  constexpr int NDQ = DQ16 ? 1 : N_DQ;
   __shared__ __attribute__((aligned(16))) float lds_wave[WAVES][L_END];
   __shared__ __attribute__((aligned(16))) float lds_pair[WAVES / 2][P_END];
   __shared__ __attribute__((aligned(16))) __bf16 wb_hi[WB_ELEMS];
@@ -386,7 +402,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_bwd_to_kernel(
       if (leader) {
         // edge_attr rows of tile k and the ids of tile k + 1 have landed; behind them in the queue:
         // the dq rows of tile k - 1, the gathers of tile k, dk / dv atomics
-        wait_vm<N_DQ + N_GATHER>();
+        wait_vm<NDQ + N_GATHER>();
         flag_set(flg + F_EA, k + 1);
       } else {
         flag_wait(flg + F_EA, k + 1);
@@ -522,15 +538,33 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_bwd_to_kernel(
         for (int bl = 0; bl < NBW; ++bl)
           *reinterpret_cast<f32x4*>(Gq + c * 32 + 4 * ((4 * bl + g) ^ ((c >> 1) & 7))) = Cq[bl];
         lds_order();
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int e = 8 * j + (lane >> 3);
-          const int x = (lane & 7) ^ ((e >> 1) & 7);
-          const f32x4 v4 = *reinterpret_cast<const f32x4*>(Gq + j * 256 + lane * 4);
+        if constexpr (DQ16) {
+          // lane -> edge lane / 4, columns 8 (lane % 4) .. + 7 of the wave's half row, rounded to bf16
+          typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+          const int e = lane >> 2, cp = lane & 3, sw = (e >> 1) & 7;
+          const f32x4 v0 = *reinterpret_cast<const f32x4*>(Gq + e * 32 + 4 * ((2 * cp) ^ sw));
+          const f32x4 v1 = *reinterpret_cast<const f32x4*>(Gq + e * 32 + 4 * ((2 * cp + 1) ^ sw));
+          auto pk = [](float a, float b) {
+            const __bf16 ha = (__bf16)a, hb = (__bf16)b;
+            return (unsigned int)__builtin_bit_cast(unsigned short, ha) |
+                   ((unsigned int)__builtin_bit_cast(unsigned short, hb) << 16);
+          };
+          const u32x4 w4 = {pk(v0[0], v0[1]), pk(v0[2], v0[3]), pk(v1[0], v1[1]), pk(v1[2], v1[3])};
           const int64_t sp = ids[48 + e];
-          // rows beyond the edge list own no row (masked per lane: the instruction still issues)
           if (t * TE + e < E)
-            __builtin_nontemporal_store(v4, reinterpret_cast<f32x4*>(dqt + sp * 64 + 32 * hh + 4 * x));
+            __builtin_nontemporal_store(
+                w4, reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(dqt) + sp * 64 + 32 * hh + 8 * cp));
+        } else {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int e = 8 * j + (lane >> 3);
+            const int x = (lane & 7) ^ ((e >> 1) & 7);
+            const f32x4 v4 = *reinterpret_cast<const f32x4*>(Gq + j * 256 + lane * 4);
+            const int64_t sp = ids[48 + e];
+            // rows beyond the edge list own no row (masked per lane: the instruction still issues)
+            if (t * TE + e < E)
+              __builtin_nontemporal_store(v4, reinterpret_cast<f32x4*>(dqt + sp * 64 + 32 * hh + 4 * x));
+          }
         }
       }
       wait_lds();                                 // the transposition buffer is free again
@@ -622,7 +656,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_bwd_to_kernel(
         C2[0] += *reinterpret_cast<const f32x4*>(P + P_MB + lane * 8);
         C2[1] += *reinterpret_cast<const f32x4*>(P + P_MB + lane * 8 + 4);
         flag_set(flg + F_MBFREE, k + 1);
-        wait_vm<N_DQ + N_GATHER>();               // the old rows (issued at the top) have landed
+        wait_vm<NDQ + N_GATHER>();               // the old rows (issued at the top) have landed
         if (acc) {
           C2[0] += *reinterpret_cast<const f32x4*>(P + P_GEA + lane * 4);
           C2[1] += *reinterpret_cast<const f32x4*>(P + P_GEA + 256 + lane * 4);
@@ -734,8 +768,12 @@ int attn_bwd_to_launch(const float* qkv, int64_t n, const int32_t* erowptr, cons
     to::attn_bwd_to_kernel<1><<<grid, to::WAVES * 64, 0, stream>>>(
         qkv, e, tile_ids, ntiles, tpw, ea, Wk, bk, Wq, bq, Wv, bv, rec, gqkv, gea, gea_acc, dqt, partial);
   const int64_t rblocks = ceil_div(n, (int64_t)16);
-  to::attn_q_reduce_kernel<<<(int)(rblocks < 256 * 16 ? rblocks : 256 * 16), 256, 0, stream>>>(
-      dqt, erowptr, scl, n, gqkv);
+  if (prec == 3)
+    to::attn_q_reduce_kernel<false><<<(int)(rblocks < 256 * 16 ? rblocks : 256 * 16), 256, 0, stream>>>(
+        dqt, erowptr, scl, n, gqkv);
+  else
+    to::attn_q_reduce_kernel<true><<<(int)(rblocks < 256 * 16 ? rblocks : 256 * 16), 256, 0, stream>>>(
+        dqt, erowptr, scl, n, gqkv);
   return grid * (to::WAVES / 2);
 }
 
