@@ -152,7 +152,9 @@ def preprocess_leg(scene, n_points, dev, reps=5):
     knn_gbs = knn_b / (med(t_knn) * 1e-3) / 1e9
     geof_gbs = geof_b / (med(t_geof) * 1e-3) / 1e9
     pmc = _preprocess_pmc(scene)
-    roof = {"knn": {"kernel": "spt::knn_cell_kernel (+ grid build, leftovers)", "bound": "valu",
+    roof = {"knn": {"kernel": "spt::knn_cell_kernel (+ grid build, leftovers)", "bound": "valu+lds",
+                    "bound_note": "per-wave VALU share of a PMC capture x 2 waves per SIMD; the two "
+                                  "candidate passes saturate the CU's LDS pipe (DESIGN 7.3 item 8)",
                     "bytes_per_launch": int(knn_b), "achieved": round(knn_gbs, 1), "unit": "GB/s",
                     "frac_hbm": round(knn_gbs / HBM_PEAK_GBS, 4),
                     "valu_busy": pmc.get("knn_valu_busy") if pmc else None,
