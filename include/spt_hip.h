@@ -123,6 +123,16 @@ int spt_segcsr_max_affine_bf16(const void* x_bf16, const int32_t* perm, const in
                                const float* scale, const float* bias, float act_slope,
                                const int64_t* seg_graph, float* out, int32_t* arg,
                                spt_stream_t stream);
+/* Same pool (x f32, or bf16 rows with x_is_bf16 != 0) with a third output raw [num_seg, c] f32 =
+ * x[arg[s, c], c], the winner's value BEFORE the map (0 for an empty segment): what the top
+ * GraphNorm's backward statistics of a max-pooled layer need (spt_graphnorm_bwd_stats_sparse_raw_f32
+ * reads it as a stream instead of gathering).  Built for c = 128, n >= 65 536. */
+int spt_segcsr_max_affine_raw_supported(int c, int64_t n);
+int spt_segcsr_max_affine_raw_f32(const void* x, int x_is_bf16, const int32_t* perm,
+                                  const int32_t* rowptr, int64_t n, int64_t num_seg, int c,
+                                  const float* am, const float* scale, const float* bias,
+                                  float act_slope, const int64_t* seg_graph, float* out,
+                                  int32_t* arg, float* raw, spt_stream_t stream);
 int spt_segcsr_reduce_bwd_f32(int op, const float* gout, const int32_t* arg,
                               const int64_t* idx, const int32_t* perm,
                               const int32_t* rowptr, int64_t n, int64_t num_seg,
@@ -690,9 +700,16 @@ int spt_graphnorm_bwd_stats_sparse_f32(const float* x, const float* gout, const 
                                        const float* am, const float* scale, const float* bias,
                                        float act_slope, double* total, void* ws,
                                        size_t ws_bytes, spt_stream_t stream);
-/* x_is_bf16 != 0: x holds bf16 values (SPT_FMLP_H_BF16 below). */
+/* x_is_bf16 = 1: x holds bf16 values (SPT_FMLP_H_BF16 below); 2: x is raw [num_seg, d] f32. */
 int spt_graphnorm_bwd_stats_sparse_ex_f32(
     const void* x, int x_is_bf16, const float* gout, const int32_t* arg, const int64_t* seg_graph,
+    const int64_t* graph_rows, int64_t num_seg, int64_t n, int d, int num_graphs,
+    const float* am, const float* scale, const float* bias, float act_slope, double* total,
+    void* ws, size_t ws_bytes, spt_stream_t stream);
+/* The same totals from raw [num_seg, d] = the layer output at the arg rows as the pool wrote it
+ * (spt_segcsr_max_affine_raw_f32): a stream, no gather.  n = rows of the layer (arg's sentinel). */
+int spt_graphnorm_bwd_stats_sparse_raw_f32(
+    const float* raw, const float* gout, const int32_t* arg, const int64_t* seg_graph,
     const int64_t* graph_rows, int64_t num_seg, int64_t n, int d, int num_graphs,
     const float* am, const float* scale, const float* bias, float act_slope, double* total,
     void* ws, size_t ws_bytes, spt_stream_t stream);

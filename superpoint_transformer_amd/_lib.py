@@ -32,6 +32,11 @@ SIGNATURES = {
     "spt_segcsr_max_affine_f32": (_int, [_p, _p, _p, _i64, _i64, _int, _p, _p, _p, _f32, _p, _p, _p, _p]),
     "spt_segcsr_max_affine_bf16_supported": (_int, [_int, _i64]),
     "spt_segcsr_max_affine_bf16": (_int, [_p, _p, _p, _i64, _i64, _int, _p, _p, _p, _f32, _p, _p, _p, _p]),
+    "spt_segcsr_max_affine_raw_supported": (_int, [_int, _i64]),
+    "spt_segcsr_max_affine_raw_f32": (_int, [_p, _int, _p, _p, _i64, _i64, _int, _p, _p, _p, _f32, _p, _p, _p,
+                                             _p, _p]),
+    "spt_graphnorm_bwd_stats_sparse_raw_f32": (_int, [_p, _p, _p, _p, _p, _i64, _i64, _int, _int, _p, _p, _p,
+                                                      _f32, _p, _p, _sz, _p]),
     "spt_fused_linear_storage_supported": (_int, [_int, _int]),
     "spt_graphnorm_bwd_stats_sparse_ex_f32": (_int, [_p, _int, _p, _p, _p, _p, _i64, _i64, _int, _int, _p, _p,
                                                      _p, _f32, _p, _p, _sz, _p]),

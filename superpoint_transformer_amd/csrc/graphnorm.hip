@@ -764,7 +764,10 @@ extern "C" int spt_graphnorm_bwd_stats_f32(const float* x, const float* gy, cons
 // from (gout, arg) and a gather of the raw rows - num_seg*d elements instead of a pass over
 // the [r, d] tensors (15.4 GB at scene S).  Layout and meaning of `total` as above; the row
 // count of graph b is graph_rows[b].
-template <bool X16>
+// RAWV: x is not the [n, d] layer output but raw[num_seg, d] = its value at the arg row (the
+// pool's third output, spt_segcsr_max_affine_raw_f32): a stream instead of a 4-byte gather per
+// (segment, channel); the same values, the same sums.
+template <bool X16, bool RAWV = false>
 __global__ __launch_bounds__(256) void gn_bwd_stats_sparse_kernel(
     const float* __restrict__ x, const float* __restrict__ gout,
     const int32_t* __restrict__ arg, const int64_t* __restrict__ seg_graph, int64_t num_seg,
@@ -797,8 +800,9 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_sparse_kernel(
     }
     const int64_t i = arg[s * d + c];
     if (i < 0 || i >= n) continue;         // empty segment: sentinel n
-    const float xv = X16 ? __uint_as_float((unsigned)reinterpret_cast<const uint16_t*>(x)[i * d + c] << 16)
-                         : x[i * d + c];
+    const float xv = RAWV ? x[s * d + c]
+                     : (X16 ? __uint_as_float((unsigned)reinterpret_cast<const uint16_t*>(x)[i * d + c] << 16)
+                            : x[i * d + c]);
     const float o = xv - t_am;
     float g = gout[s * d + c];
     if (slope != 1.f) {
@@ -835,7 +839,8 @@ extern "C" int spt_graphnorm_bwd_stats_sparse_f32(
                                                num_graphs, am, scale, bias, act_slope, total, ws,
                                                ws_bytes, stream_);
 }
-// x_is_bf16 != 0: x holds bf16 values (the fused layers' activation storage option)
+// x_is_bf16 = 1: x holds bf16 values (the fused layers' activation storage option); 2: x is the
+// pool's raw output [num_seg, d] (f32)
 extern "C" int spt_graphnorm_bwd_stats_sparse_ex_f32(
     const void* x_, int x_is_bf16, const float* gout, const int32_t* arg, const int64_t* seg_graph,
     const int64_t* graph_rows, int64_t num_seg, int64_t n, int d, int num_graphs,
@@ -857,7 +862,10 @@ extern "C" int spt_graphnorm_bwd_stats_sparse_ex_f32(
   const int cap = gn_graphs_per_launch(row_len);
   for (int b_lo = 0; b_lo < B; b_lo += cap) {
     const int Bc = (B - b_lo < cap) ? B - b_lo : cap;
-    if (x_is_bf16)
+    if (x_is_bf16 == 2)         // x = raw[num_seg, d] (spt_graphnorm_bwd_stats_sparse_raw_f32)
+      gn_bwd_stats_sparse_kernel<false, true><<<(int)nb, 256, (size_t)Bc * row_len * 8, stream>>>(
+          x, gout, arg, seg_graph, num_seg, n, d, B, am, scale, bias, act_slope, partial, b_lo, Bc);
+    else if (x_is_bf16)
       gn_bwd_stats_sparse_kernel<true><<<(int)nb, 256, (size_t)Bc * row_len * 8, stream>>>(
           x, gout, arg, seg_graph, num_seg, n, d, B, am, scale, bias, act_slope, partial, b_lo, Bc);
     else
@@ -869,6 +877,19 @@ extern "C" int spt_graphnorm_bwd_stats_sparse_ex_f32(
   gn_set_row_counts_kernel<<<(B + 63) / 64, 64, 0, stream>>>(total, B, row_len, graph_rows);
   SPT_CHECK_LAUNCH();
   return 0;
+}
+
+// The same totals from raw[num_seg, d] = the layer output at the arg rows, as the pool wrote it
+// (spt_segcsr_max_affine_raw_f32): no gather.  n = rows of the layer (arg's sentinel for an empty
+// segment).
+extern "C" int spt_graphnorm_bwd_stats_sparse_raw_f32(
+    const float* raw, const float* gout, const int32_t* arg, const int64_t* seg_graph,
+    const int64_t* graph_rows, int64_t num_seg, int64_t n, int d, int num_graphs,
+    const float* am, const float* scale, const float* bias, float act_slope, double* total,
+    void* ws, size_t ws_bytes, spt_stream_t stream_) {
+  return spt_graphnorm_bwd_stats_sparse_ex_f32(raw, 2, gout, arg, seg_graph, graph_rows, num_seg, n, d,
+                                               num_graphs, am, scale, bias, act_slope, total, ws,
+                                               ws_bytes, stream_);
 }
 
 // backward coefficient rows (gx = c1*g - c2*o - c3) and the three parameter gradients

@@ -352,12 +352,15 @@ __global__ __launch_bounds__(256) void segcsr_reduce_kernel(
 // CSR positions [rowptr[sa], rowptr[sb])
 // X16: the rows hold bf16 values (the bf16 mode's activation storage): 8-byte loads widened
 // to f32 on the way in (exact), everything else unchanged.
-template <bool AFF, bool X16 = false>
+// RAW (with AFF): raw[s, c] = the value BEFORE the map of the element that won (0 for an empty
+// segment) - what the sparse GraphNorm-backward statistics of the pooled layer need, read there as
+// a stream instead of one 4-byte gather per (segment, channel).
+template <bool AFF, bool X16 = false, bool RAW = false>
 __device__ __forceinline__ void segmax_stream_range(
     const float* __restrict__ x, const int32_t* __restrict__ perm,
     const int32_t* __restrict__ rowptr, int64_t n, int64_t num_seg, float* __restrict__ out,
-    int32_t* __restrict__ arg, int64_t sa, int64_t sb, const float (&t_am)[4],
-    const float (&t_sc)[4], const float (&t_bs)[4], float slope, int lane) {
+    int32_t* __restrict__ arg, float* __restrict__ raw, int64_t sa, int64_t sb,
+    const float (&t_am)[4], const float (&t_sc)[4], const float (&t_bs)[4], float slope, int lane) {
   // a row = 32 lanes x 4 channels; the two half-waves take the even / odd positions of the
   // stream (2 rows per load instruction, 4 channels per combine: half the instructions per byte
   // of a 64-lane x 2-channel row).  Both halves work on the same segment unless a boundary falls
@@ -365,34 +368,46 @@ __device__ __forceinline__ void segmax_stream_range(
   // position at a time.
   // (12 rows per chunk with the affine map: its 12 coefficient registers then still leave room
   // for 5 waves per SIMD)
-  constexpr int C = 128, CHK = AFF ? 12 : 16, V = 4;
+  constexpr int C = 128, CHK = AFF ? (RAW && !X16 ? 10 : 12) : 16, V = 4;   // (RAW: 4 more registers)
   const int hf = lane >> 5;                               // 0: even positions, 1: odd positions
   const int c0 = (lane & 31) * V;
   const bool leaky01 = AFF && slope >= 0.f && slope <= 1.f;
   float acc[V];
   int32_t ar[V];
+  float hb[RAW ? V : 1];                                  // RAW: the winner's value before the map
 #pragma unroll
   for (int k = 0; k < V; ++k) {
     acc[k] = op_identity<SPT_MAX>();
     ar[k] = 0x7fffffff;
+    if constexpr (RAW) hb[k] = 0.f;
   }
   // result of segment s: the odd half's partial joins the even half's, which writes the row
   auto emit = [&](int64_t s, bool empty) {
-    Vec<V> o;
+    Vec<V> o, oh;
     int32_t oa[V];
 #pragma unroll
     for (int k = 0; k < V; ++k) {
       const float ov = __shfl_xor(acc[k], 32, 64);
       const int32_t orr = __shfl_xor(ar[k], 32, 64);
+      if constexpr (RAW) {
+        const float ohv = __shfl_xor(hb[k], 32, 64);
+        const bool other = (ov > acc[k]) || (ov == acc[k] && orr < ar[k]);   // combine's rule
+        hb[k] = other ? ohv : hb[k];
+      }
       combine<SPT_MAX, true, float>(acc[k], ar[k], ov, orr);
       o.v[k] = empty ? 0.f : acc[k];
       oa[k] = (!empty && ar[k] != 0x7fffffff) ? ar[k] : (int32_t)n;
+      if constexpr (RAW) {
+        oh.v[k] = (!empty && ar[k] != 0x7fffffff) ? hb[k] : 0.f;
+        hb[k] = 0.f;
+      }
       acc[k] = op_identity<SPT_MAX>();
       ar[k] = 0x7fffffff;
     }
     if (hf == 0) {
       stv<V>(out + s * C + c0, o);
       sti<V>(arg + s * C + c0, oa);
+      if constexpr (RAW) stv<V>(raw + s * C + c0, oh);
     }
   };
   int64_t s = sa;
@@ -434,6 +449,10 @@ __device__ __forceinline__ void segmax_stream_range(
       if constexpr (AFF) {
         a = fmaf(a - t_am[k], t_sc[k], t_bs[k]);           // same expression as gn_apply
         a = leaky01 ? fmaxf(a, a * slope) : (a > 0.f ? a : a * slope);
+      }
+      if constexpr (RAW) {
+        const bool win = (a > acc[k]) || (a == acc[k] && r < ar[k]);         // combine's rule
+        hb[k] = win ? v.v[k] : hb[k];
       }
       combine<SPT_MAX, true, float>(acc[k], ar[k], a, r);
     }
@@ -485,11 +504,11 @@ __device__ __forceinline__ void segmax_stream_range(
   }
 }
 
-template <bool AFF, bool X16 = false>
+template <bool AFF, bool X16 = false, bool RAW = false>
 __global__ __launch_bounds__(256, 5) void segmax_stream_kernel(
     const float* __restrict__ x, const int32_t* __restrict__ perm,
     const int32_t* __restrict__ rowptr, int64_t n, int64_t num_seg, float* __restrict__ out,
-    int32_t* __restrict__ arg, Affine af, int64_t rows_per_wave) {
+    int32_t* __restrict__ arg, float* __restrict__ raw, Affine af, int64_t rows_per_wave) {
   constexpr int C = 128;
   const int lane = threadIdx.x & 63;
   const int c0 = (lane & 31) * 4;
@@ -533,8 +552,8 @@ __global__ __launch_bounds__(256, 5) void segmax_stream_kernel(
         t_bs[k] = af.bs[c0 + k];
       }
     }
-    segmax_stream_range<AFF, X16>(x, perm, rowptr, n, num_seg, out, arg, s_lo, s_hi, t_am, t_sc, t_bs,
-                                  af.slope, lane);
+    segmax_stream_range<AFF, X16, RAW>(x, perm, rowptr, n, num_seg, out, arg, raw, s_lo, s_hi, t_am,
+                                       t_sc, t_bs, af.slope, lane);
     s_lo = s_hi;
   }
 }
@@ -562,7 +581,7 @@ static bool seg_stream_shape(int c, int64_t n, bool want_arg) {
 template <bool AFF, bool X16 = false>
 static void launch_stream(const float* x, const int32_t* perm, const int32_t* rowptr, int64_t n,
                           int64_t num_seg, float* out, int32_t* arg, const Affine& af,
-                          hipStream_t stream) {
+                          hipStream_t stream, float* raw = nullptr) {
   // 8 waves per SIMD over the whole chip, at least 256 rows per wave
   // one resident round: 5 waves per SIMD (96 registers) over the whole chip - with more waves
   // than fit at once the last partial round costs more than finer ranges balance (measured:
@@ -575,8 +594,15 @@ static void launch_stream(const float* x, const int32_t* perm, const int32_t* ro
   if (waves * 256 > n) waves = n / 256 > 4 ? n / 256 : 4;
   const int grid = (int)ceil_div(waves, (int64_t)4);
   const int64_t rows_per_wave = n / ((int64_t)grid * 4) + 1;
-  segmax_stream_kernel<AFF, X16><<<grid, 256, 0, stream>>>(x, perm, rowptr, n, num_seg, out, arg, af,
-                                                           rows_per_wave);
+  if constexpr (AFF) {
+    if (raw) {
+      segmax_stream_kernel<AFF, X16, true><<<grid, 256, 0, stream>>>(x, perm, rowptr, n, num_seg, out,
+                                                                     arg, raw, af, rows_per_wave);
+      return;
+    }
+  }
+  segmax_stream_kernel<AFF, X16><<<grid, 256, 0, stream>>>(x, perm, rowptr, n, num_seg, out, arg,
+                                                           nullptr, af, rows_per_wave);
 }
 
 // Row-parallel "gather with modifier":
@@ -931,6 +957,37 @@ extern "C" int spt_segcsr_max_affine_bf16(const void* x_bf16, const int32_t* per
   af.am = am; af.sc = scale; af.bs = bias; af.seg_graph = seg_graph; af.slope = act_slope;
   launch_stream<true, true>(reinterpret_cast<const float*>(x_bf16), perm, rowptr, n, num_seg, out, arg,
                             af, stream);
+  SPT_CHECK_LAUNCH();
+  return 0;
+}
+
+// The same pool (x f32 or - x_is_bf16 - bf16 rows) with a third output, raw[s, c] = the value
+// BEFORE the map of the element that won (0 for an empty segment): the sparse GraphNorm-backward
+// statistics of the pooled layer (spt_graphnorm_bwd_stats_sparse_raw_f32) then read a stream
+// instead of gathering x[arg[s, c], c].  The streaming kernel only (c = 128, n >= 65 536, as
+// spt_segcsr_max_affine_raw_supported reports).
+extern "C" int spt_segcsr_max_affine_raw_supported(int c, int64_t n) {
+  return seg_stream_shape(c, n, true) ? 1 : 0;
+}
+extern "C" int spt_segcsr_max_affine_raw_f32(const void* x, int x_is_bf16, const int32_t* perm,
+                                             const int32_t* rowptr, int64_t n, int64_t num_seg,
+                                             int c, const float* am, const float* scale,
+                                             const float* bias, float act_slope,
+                                             const int64_t* seg_graph, float* out, int32_t* arg,
+                                             float* raw, spt_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPT_CHECK_ARG(n >= 0 && num_seg >= 0, "bad shape");
+  SPT_CHECK_ARG(spt_segcsr_max_affine_raw_supported(c, n), "raw output: c = 128 and n >= 65536 only");
+  SPT_CHECK_ARG(rowptr && out && arg && raw && am && scale && bias && x, "null pointer");
+  if (num_seg == 0) return 0;
+  Affine af;
+  af.am = am; af.sc = scale; af.bs = bias; af.seg_graph = seg_graph; af.slope = act_slope;
+  if (x_is_bf16)
+    launch_stream<true, true>(reinterpret_cast<const float*>(x), perm, rowptr, n, num_seg, out, arg, af,
+                              stream, raw);
+  else
+    launch_stream<true, false>(reinterpret_cast<const float*>(x), perm, rowptr, n, num_seg, out, arg,
+                               af, stream, raw);
   SPT_CHECK_LAUNCH();
   return 0;
 }

@@ -1507,6 +1507,11 @@ class _FusedMLP(torch.autograd.Function):
         return (gx0, None, None, None, None, *grads)
 
 
+# the fused MLP + max-pool node lets the pool write the winners' raw values for its backward
+# (tests switch it off to pin the two routes on each other)
+POOL_RAW_OUTPUT = True
+
+
 class _FusedMLPMaxPool(torch.autograd.Function):
     """The fused MLP followed by a max-pool over segments, as ONE node: the last
     GraphNorm-apply + LeakyReLU run inside the pool's read of the raw h_L (the normalised
@@ -1534,16 +1539,33 @@ class _FusedMLPMaxPool(torch.autograd.Function):
         dev = h_last.device
         out = torch.empty((csr.num_seg, N), dtype=torch.float32, device=dev)
         arg = torch.empty((csr.num_seg, N), dtype=torch.int32, device=dev)
+        # a backward will follow: the pool also writes the winners' raw values, which the top
+        # GraphNorm's backward statistics then read as a stream instead of gathering h[arg]
+        raw = None
+        if (POOL_RAW_OUTPUT and any(ctx.needs_input_grad) and N <= 256 and 256 % N == 0
+                and _lib.lib.spt_segcsr_max_affine_raw_supported(int(N), R)):
+            raw = torch.empty((csr.num_seg, N), dtype=torch.float32, device=dev)
         # same timer key as the plain segment-max: this IS the L0 -> L1 pool launch
-        seg_max = (_lib.lib.spt_segcsr_max_affine_bf16 if store16
-                   else _lib.lib.spt_segcsr_max_affine_f32)
         with torch.cuda.device(dev), _timed(f"segcsr_reduce_fwd:3:{R}x{N}"):
-            st = seg_max(
-                _lib.ptr(h_last), _lib.ptr(csr.perm), _lib.ptr(csr.rowptr), R, csr.num_seg, N,
-                _lib.ptr(am), _lib.ptr(sc), _lib.ptr(bs), float(slope_list[-1]),
-                _lib.ptr(seg_graph), _lib.ptr(out), _lib.ptr(arg), _lib.stream_ptr(dev))
+            if raw is not None:
+                st = _lib.lib.spt_segcsr_max_affine_raw_f32(
+                    _lib.ptr(h_last), 1 if store16 else 0, _lib.ptr(csr.perm), _lib.ptr(csr.rowptr),
+                    R, csr.num_seg, N, _lib.ptr(am), _lib.ptr(sc), _lib.ptr(bs),
+                    float(slope_list[-1]), _lib.ptr(seg_graph), _lib.ptr(out), _lib.ptr(arg),
+                    _lib.ptr(raw), _lib.stream_ptr(dev))
+            else:
+                seg_max = (_lib.lib.spt_segcsr_max_affine_bf16 if store16
+                           else _lib.lib.spt_segcsr_max_affine_f32)
+                st = seg_max(
+                    _lib.ptr(h_last), _lib.ptr(csr.perm), _lib.ptr(csr.rowptr), R, csr.num_seg, N,
+                    _lib.ptr(am), _lib.ptr(sc), _lib.ptr(bs), float(slope_list[-1]),
+                    _lib.ptr(seg_graph), _lib.ptr(out), _lib.ptr(arg), _lib.stream_ptr(dev))
         _lib.check(st, "spt_segcsr_max_affine")
-        ctx.save_for_backward(arg, *saved)
+        ctx.has_raw = raw is not None
+        if raw is not None:
+            ctx.save_for_backward(arg, *saved, raw)
+        else:
+            ctx.save_for_backward(arg, *saved)
         ctx.csr = csr
         ctx.seg_graph = seg_graph
         ctx.meta = (len(eps_list), runs, list(slope_list), x.dtype, x.requires_grad,
@@ -1552,7 +1574,9 @@ class _FusedMLPMaxPool(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gout):
-        arg, saved = ctx.saved_tensors[0], ctx.saved_tensors[1:]
+        arg, saved, raw = ctx.saved_tensors[0], ctx.saved_tensors[1:], None
+        if ctx.has_raw:
+            saved, raw = saved[:-1], saved[-1]
         L, runs, slopes = ctx.meta[0], ctx.meta[1], ctx.meta[2]
         h_last = saved[2 + L - 1]
         am, sc = saved[2 + L + 4 * (L - 1) + 2], saved[2 + L + 4 * (L - 1) + 3]
@@ -1570,13 +1594,20 @@ class _FusedMLPMaxPool(torch.autograd.Function):
             nb = _lib.lib.spt_graphnorm_bwd_stats_sparse_workspace_bytes(ctx.csr.num_seg, N, B)
             ws = _workspace(nb, dev)
             with torch.cuda.device(dev):
-                st = _lib.lib.spt_graphnorm_bwd_stats_sparse_ex_f32(
-                    _lib.ptr(h_last), 1 if h_last.dtype == torch.bfloat16 else 0, _lib.ptr(gout),
-                    _lib.ptr(arg), _lib.ptr(ctx.seg_graph),
-                    _lib.ptr(rows), ctx.csr.num_seg, R, N, B, _lib.ptr(am), _lib.ptr(sc),
-                    _lib.ptr(gnb_last), float(slopes[-1]), _lib.ptr(total), _lib.ptr(ws), nb,
-                    _lib.stream_ptr(dev))
-            _lib.check(st, "spt_graphnorm_bwd_stats_sparse_ex_f32")
+                if raw is not None:
+                    st = _lib.lib.spt_graphnorm_bwd_stats_sparse_raw_f32(
+                        _lib.ptr(raw), _lib.ptr(gout), _lib.ptr(arg), _lib.ptr(ctx.seg_graph),
+                        _lib.ptr(rows), ctx.csr.num_seg, R, N, B, _lib.ptr(am), _lib.ptr(sc),
+                        _lib.ptr(gnb_last), float(slopes[-1]), _lib.ptr(total), _lib.ptr(ws), nb,
+                        _lib.stream_ptr(dev))
+                else:
+                    st = _lib.lib.spt_graphnorm_bwd_stats_sparse_ex_f32(
+                        _lib.ptr(h_last), 1 if h_last.dtype == torch.bfloat16 else 0, _lib.ptr(gout),
+                        _lib.ptr(arg), _lib.ptr(ctx.seg_graph),
+                        _lib.ptr(rows), ctx.csr.num_seg, R, N, B, _lib.ptr(am), _lib.ptr(sc),
+                        _lib.ptr(gnb_last), float(slopes[-1]), _lib.ptr(total), _lib.ptr(ws), nb,
+                        _lib.stream_ptr(dev))
+            _lib.check(st, "spt_graphnorm_bwd_stats_sparse")
         # The pool's gradient has one non-zero per (segment, channel): the top layer's backward
         # reads (gout, arg) through the pool's CSR order instead of a dense [R, N] tensor.  Needs
         # the top GraphNorm's statistics from the sparse route above, an input gradient (L > 1),

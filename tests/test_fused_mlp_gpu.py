@@ -389,3 +389,104 @@ def test_bf16_rows_in_the_streaming_segment_max_and_the_sparse_statistics(dev):
         _lib.check(st, "sparse stats")
         return tot
     assert torch.equal(stats(h16, 1), stats(h32, 0))
+
+
+def test_raw_output_of_the_pool_feeds_the_sparse_statistics(dev):
+    """spt_segcsr_max_affine_raw_f32: same (out, arg) as the two-output entries, raw = x[arg] (0 for
+    an empty segment), f32 and bf16 rows; spt_graphnorm_bwd_stats_sparse_raw_f32 on it = the
+    gathering entry, bit for bit."""
+    from superpoint_transformer_amd import _lib
+    from superpoint_transformer_amd.csr import build_csr
+    g = torch.Generator().manual_seed(78)
+    rows, nseg, C, B = 70_011, 2_300, 128, 2
+    h16 = torch.randn(rows, C, generator=g).to(torch.bfloat16).to(dev)
+    h32 = h16.float()
+    si = torch.randint(0, nseg, (rows,), generator=g)
+    si[si % 17 == 3] = 5                                                     # empty segments
+    si = si.sort().values[torch.randperm(rows, generator=g)]                 # unsorted membership
+    seg_graph = (torch.arange(nseg) * B // nseg).to(dev)
+    csr = build_csr(si.to(dev), nseg)
+    am, sc = ((torch.rand(B, C, generator=g) - 0.3).to(dev) for _ in range(2))
+    bs = torch.rand(C, generator=g).to(dev)
+    P, sp = _lib.ptr, _lib.stream_ptr(dev)
+    assert _lib.lib.spt_segcsr_max_affine_raw_supported(C, rows) == 1
+
+    def pool(x, is16, want_raw):
+        out = torch.empty((nseg, C), device=dev)
+        arg = torch.empty((nseg, C), dtype=torch.int32, device=dev)
+        raw = torch.full((nseg, C), float("nan"), device=dev)
+        if want_raw:
+            st = _lib.lib.spt_segcsr_max_affine_raw_f32(
+                P(x), is16, P(csr.perm), P(csr.rowptr), rows, nseg, C, P(am), P(sc), P(bs), 0.01,
+                P(seg_graph), P(out), P(arg), P(raw), sp)
+        else:
+            fn = _lib.lib.spt_segcsr_max_affine_bf16 if is16 else _lib.lib.spt_segcsr_max_affine_f32
+            st = fn(P(x), P(csr.perm), P(csr.rowptr), rows, nseg, C, P(am), P(sc), P(bs), 0.01,
+                    P(seg_graph), P(out), P(arg), sp)
+        _lib.check(st, "segmax")
+        return out, arg, raw
+    o_ref, a_ref, _ = pool(h32, 0, False)
+    empty = a_ref[:, 0] == rows
+    assert int(empty.sum()) > 50
+    expect = torch.gather(h32, 0, a_ref.long().clamp(max=rows - 1))
+    expect[empty] = 0.0
+    for x, is16 in ((h32, 0), (h16, 1)):
+        o, a, raw = pool(x, is16, True)
+        assert torch.equal(o, o_ref) and torch.equal(a, a_ref)
+        assert torch.equal(raw, expect)
+
+    gout = torch.randn(nseg, C, generator=g).to(dev)
+    grows = torch.tensor([int((seg_graph[si.to(dev)] == b).sum()) for b in range(B)], device=dev)
+    nb = _lib.lib.spt_graphnorm_bwd_stats_sparse_workspace_bytes(nseg, C, B)
+    ws = torch.empty(max(nb, 1), dtype=torch.uint8, device=dev)
+    t_gather = torch.empty((B, 2 * C + 1), dtype=torch.float64, device=dev)
+    st = _lib.lib.spt_graphnorm_bwd_stats_sparse_ex_f32(
+        P(h32), 0, P(gout), P(a_ref), P(seg_graph), P(grows), nseg, rows, C, B, P(am), P(sc), P(bs),
+        0.01, P(t_gather), P(ws), nb, sp)
+    _lib.check(st, "sparse stats")
+    t_raw = torch.empty_like(t_gather)
+    st = _lib.lib.spt_graphnorm_bwd_stats_sparse_raw_f32(
+        P(expect), P(gout), P(a_ref), P(seg_graph), P(grows), nseg, rows, C, B, P(am), P(sc), P(bs),
+        0.01, P(t_raw), P(ws), nb, sp)
+    _lib.check(st, "sparse stats (raw)")
+    assert torch.allclose(t_raw, t_gather, rtol=1e-13, atol=1e-13)
+
+
+def test_fused_mlp_max_pool_with_and_without_the_raw_output(dev):
+    """MLP.forward_max_pooled at a size where the pool's raw output is built (128 channels,
+    >= 65 536 rows): same pooled values, gradients equal up to the f64 summation order of the top
+    statistics, with the raw output feeding them (default) and with the gathering statistics."""
+    from superpoint_transformer_amd import nn as N, ops
+    g = torch.Generator().manual_seed(79)
+    rows, nseg, B = 70_000, 2_000, 2
+    mlp = N.MLP([12, 32, 64, 128], norm=N.GraphNorm).to(dev)
+    with torch.no_grad():
+        for p in mlp.parameters():
+            p.add_(0.1 * torch.randn(p.shape, generator=g).to(dev))
+    x = (torch.randn(rows, 12, generator=g) * 2 + 0.5).to(dev)
+    batch = (torch.arange(rows) * B // rows).to(dev)
+    seg_graph = (torch.arange(nseg) * B // nseg).to(dev)
+    idx = torch.empty(rows, dtype=torch.long, device=dev)
+    for b in range(B):
+        rows_b = torch.where(batch == b)[0]
+        segs_b = torch.where(seg_graph == b)[0][3:]                          # a few empty segments
+        idx[rows_b] = segs_b[torch.randint(0, segs_b.numel(), (rows_b.numel(),), generator=g).to(dev)]
+    gout = torch.randn(nseg, 128, generator=g).to(dev)
+
+    def run(flag):
+        old, ops.POOL_RAW_OUTPUT = ops.POOL_RAW_OUTPUT, flag
+        try:
+            m = copy.deepcopy(mlp)
+            xd = x.clone().requires_grad_()
+            out = m.forward_max_pooled(xd, idx, nseg, batch=batch, batch_size=B, seg_graph=seg_graph)
+            assert out is not None
+            (out * gout).sum().backward()
+            return out.detach(), xd.grad, [p.grad for p in m.parameters()]
+        finally:
+            ops.POOL_RAW_OUTPUT = old
+    o1, gx1, gp1 = run(True)
+    o0, gx0, gp0 = run(False)
+    assert torch.equal(o1, o0)
+    assert torch.allclose(gx1, gx0, rtol=1e-6, atol=1e-7 * float(gx0.abs().max()))
+    for a, b in zip(gp1, gp0):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6 * float(b.abs().max()))
