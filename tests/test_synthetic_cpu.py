@@ -1,0 +1,123 @@
+"""Host-side pieces the GPU path leans on, runnable without a GPU: the synthetic NAG generator
+(bench.py's scenes: the stored cluster CSR ``sub`` of every level, multi-cloud batches, the
+``--graph local`` / ``--order morton`` variants) and the ``Cluster`` / ``Data`` behaviour the
+CSR adoption of round 4 relies on (src/data/cluster.py:19-77, src/data/nag.py:878-898)."""
+import pytest
+import torch
+
+from superpoint_transformer_amd import synthetic
+from superpoint_transformer_amd.data import Cluster, Data
+
+SIZES = (6_000, 400, 150, 3_000, 1_800, 1)
+SIZES_B3 = (9_000, 600, 210, 4_500, 2_700, 3)
+
+
+def _check_sub(levels):
+    for lo, hi in zip(levels[:-1], levels[1:]):
+        si, sub = lo["super_index"], hi["sub"]
+        n_parent = hi["pos"].shape[0]
+        assert sub.pointers.numel() == n_parent + 1 and int(sub.pointers[-1]) == si.numel()
+        # the same partition: the children listed for cluster c all point at c ...
+        owner = torch.repeat_interleave(torch.arange(n_parent), sub.pointers[1:] - sub.pointers[:-1])
+        assert torch.equal(si[sub.points], owner)
+        # ... every child exactly once, ascending inside a cluster (= the stable sort of super_index)
+        assert torch.equal(sub.points, torch.argsort(si, stable=True))
+        assert sub.ascending
+
+
+@pytest.mark.parametrize("graph,order", [("random", "storage"), ("local", "storage"),
+                                         ("random", "morton"), ("local", "morton")])
+def test_synthetic_nag_levels_are_consistent(graph, order):
+    nag = synthetic.make_nag(sizes=SIZES, seed=5, graph=graph, order=order)
+    lv = nag.levels
+    n0, n1, n2 = SIZES[:3]
+    assert [l["pos"].shape[0] for l in lv] == [n0, n1, n2]
+    _check_sub(lv)
+    # node_size = points below every node (NodeSize, src/transforms/graph.py:1475-1498)
+    assert torch.equal(lv[1]["node_size"], torch.bincount(lv[0]["super_index"], minlength=n1))
+    assert int(lv[2]["node_size"].sum()) == n0
+    for l, n in ((lv[1], n1), (lv[2], n2)):
+        ei = l["edge_index"]
+        assert ei.shape[0] == 2 and int(ei.min()) >= 0 and int(ei.max()) < n
+        assert l["edge_attr"].shape[0] == ei.shape[1]
+        # both directions and every self-loop are present (the doubled graph + NAGAddSelfLoops)
+        key = set((ei[0] * n + ei[1]).tolist())
+        assert all(int(s) * n + int(s) in key for s in range(0, n, max(n // 50, 1)))
+        assert all((int(t) * n + int(s)) in key for s, t in ei[:, :200].t().tolist())
+    # children jitter around their parents: positions survive any relabelling
+    d = (lv[0]["pos"] - lv[1]["pos"][lv[0]["super_index"]]).norm(dim=1)
+    assert float(d.mean()) < 1.0
+
+
+def test_default_scene_is_the_same_scene_as_before():
+    """The default generator (random graph, storage order) is what every committed bench line was
+    measured on: same seed -> same arrays, with or without the optional arguments spelled out."""
+    a = synthetic.make_nag(sizes=SIZES, seed=1234)
+    b = synthetic.make_nag(sizes=SIZES, seed=1234, graph="random", order="storage")
+    for la, lb in zip(a.levels, b.levels):
+        for k in ("pos", "super_index", "edge_index", "edge_attr", "batch"):
+            if la.get(k) is not None:
+                assert torch.equal(la[k], lb[k])
+    c = synthetic.make_nag(sizes=SIZES, seed=1235)
+    assert not torch.equal(a.levels[1]["edge_index"], c.levels[1]["edge_index"])
+
+
+def test_morton_order_puts_graph_neighbours_close_in_memory():
+    far = synthetic.make_nag(sizes=SIZES, seed=7, graph="local", order="storage").levels[1]["edge_index"]
+    near = synthetic.make_nag(sizes=SIZES, seed=7, graph="local", order="morton").levels[1]["edge_index"]
+    gap = lambda ei: float((ei[0] - ei[1]).abs().double().median())
+    assert gap(near) < 0.25 * gap(far)
+
+
+@pytest.mark.parametrize("graph", ["random", "local"])
+def test_multi_cloud_batch_keeps_clouds_contiguous_and_edges_inside_them(graph):
+    nag = synthetic.make_nag(sizes=SIZES_B3, seed=11, graph=graph)
+    assert nag.num_clouds == 3
+    lv = nag.levels
+    _check_sub(lv)
+    for l in lv:
+        b = l["batch"]
+        assert bool((b[1:] >= b[:-1]).all()) and int(b.max()) == 2          # NAGBatch.from_nag_list
+    assert torch.equal(lv[0]["batch"], lv[1]["batch"][lv[0]["super_index"]])
+    for l in lv[1:]:
+        ei, b = l["edge_index"], l["batch"]
+        assert torch.equal(b[ei[0]], b[ei[1]])                              # no edge between clouds
+        eb = b[ei[0]]
+        # the edge MLP's norm index: a few sorted runs (the fused layers' run table holds 16)
+        runs = 1 + int((eb[1:] != eb[:-1]).sum())
+        assert runs <= 16
+
+
+def test_cluster_ascending_flag():
+    ptr = torch.tensor([0, 2, 2, 5])
+    asc = Cluster(ptr, torch.tensor([4, 7, 0, 1, 9]))
+    assert asc.ascending                                  # worked out on first use
+    assert not Cluster(ptr, torch.tensor([7, 4, 0, 1, 9])).ascending
+    assert Cluster(ptr, torch.tensor([7, 4, 0, 1, 9]), ascending=True).ascending   # the caller vouches
+    # empty clusters and the boundary between clusters do not count as descents
+    assert Cluster(torch.tensor([0, 0, 1, 1, 3]), torch.tensor([5, 0, 2])).ascending
+    assert asc.clone().ascending and asc.to("cpu").ascending
+
+
+def test_data_item_access_is_strict():
+    d = Data(pos=torch.zeros(3, 3), x=torch.ones(3, 2))
+    assert d["pos"].shape == (3, 3) and d.get("x") is not None
+    assert d.get("nope") is None and d.get("nope", 7) == 7
+    with pytest.raises(KeyError):
+        d["nope"]
+
+
+def test_bf16_storage_switch_round_trips():
+    from superpoint_transformer_amd import precision
+    prev = precision.set_bf16_activation_storage(False)
+    try:
+        with precision.matrix_precision("bf16"):
+            assert precision.bf16_activation_storage() is False
+            assert precision.set_bf16_activation_storage(True) is False
+            assert precision.bf16_activation_storage() is True          # bf16 mode + the switch
+        with precision.matrix_precision("f32"):
+            assert precision.bf16_activation_storage() is False         # f32 storage in the f32 modes
+    finally:
+        precision.set_bf16_activation_storage(prev)
+    with pytest.raises(ValueError):
+        precision.set_matrix_precision("fp8")
