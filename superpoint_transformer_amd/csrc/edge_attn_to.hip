@@ -656,7 +656,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_bwd_to_kernel(
         C2[0] += *reinterpret_cast<const f32x4*>(P + P_MB + lane * 8);
         C2[1] += *reinterpret_cast<const f32x4*>(P + P_MB + lane * 8 + 4);
         flag_set(flg + F_MBFREE, k + 1);
-        wait_vm<NDQ + N_GATHER>();               // the old rows (issued at the top) have landed
+        // the old rows (issued at the top) have landed.  Behind them in the queue: this tile's dq
+        // stores and the next tile's gathers - but the compiler branches around a dq store whose
+        // lanes are all masked (f32 rows: the second store of a last tile with <= 8 edges), so
+        // only NDQ - 1 of them are counted on there (the bf16 row store always has live lanes)
+        wait_vm<N_GATHER + (DQ16 ? NDQ : NDQ - 1)>();
         if (acc) {
           C2[0] += *reinterpret_cast<const f32x4*>(P + P_GEA + lane * 4);
           C2[1] += *reinterpret_cast<const f32x4*>(P + P_GEA + 256 + lane * 4);
