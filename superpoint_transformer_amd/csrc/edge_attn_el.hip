@@ -631,9 +631,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_bwd_el_kernel(
             const int e = 4 * j + g;
             const int ch = c ^ e;
             const f32x4 v4 = *reinterpret_cast<const f32x4*>(G + j * 256 + lane * 4);
-            // rows beyond the edge list own no row (masked per lane: the instruction still issues,
-            // which keeps the counted waits valid - unless a whole instruction's edges are past the
-            // end, which only the LAST tile of the edge list can have: nothing is counted after it)
+            // rows beyond the edge list own no row (masked per lane: the instruction still issues
+            // - unless a whole instruction's edges are past the end, which only the LAST tile of the
+            // edge list can have: the one counted wait behind it in that tile allows for it)
             if (t * TE + e < E)
               __builtin_nontemporal_store(
                   v4, reinterpret_cast<f32x4*>(dkv + (t * TE + e) * 128 + 32 * hh + 4 * (ch & 7) + ((ch & 8) ? 64 : 0)));
@@ -746,7 +746,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_bwd_el_kernel(
         C2[0] += *reinterpret_cast<const f32x4*>(P + P_MB + lane * 8);
         C2[1] += *reinterpret_cast<const f32x4*>(P + P_MB + lane * 8 + 4);
         flag_set(flg + F_MBFREE, k + 1);
-        wait_vm<N_KV + N_GATHER>();               // the old rows (issued at the top) have landed
+        // the old rows (issued at the top) have landed.  Behind them in the queue: the next tile's
+        // gathers and this tile's dk / dv row stores - of which the full-line form may lose all but
+        // one (the compiler branches around a store whose edges are all past the end of the edge
+        // list: the last tile), so it counts on one only
+        wait_vm<N_GATHER + (FL ? 1 : N_KV)>();
         if (acc) {
           C2[0] += *reinterpret_cast<const f32x4*>(P + P_GEA + lane * 4);
           C2[1] += *reinterpret_cast<const f32x4*>(P + P_GEA + 256 + lane * 4);
