@@ -1,4 +1,4 @@
-"""Host-side pieces the GPU path leans on, runnable without a GPU: the synthetic NAG generator
+"""Host-side pieces the GPU path leans on, runnable without a GPU: the fused layers' run tables, the synthetic NAG generator
 (bench.py's scenes: the stored cluster CSR ``sub`` of every level, multi-cloud batches, the
 ``--graph local`` / ``--order morton`` variants) and the ``Cluster`` / ``Data`` behaviour the
 CSR adoption of round 4 relies on (src/data/cluster.py:19-77, src/data/nag.py:878-898)."""
@@ -121,3 +121,39 @@ def test_bf16_storage_switch_round_trips():
         precision.set_bf16_activation_storage(prev)
     with pytest.raises(ValueError):
         precision.set_matrix_precision("fp8")
+
+
+def test_graph_runs_of_sorted_and_piecewise_sorted_indices():
+    """``ops.graph_runs``: the run table one launch of the fused layer kernels covers - pure host
+    logic over the batch index (the GPU tests launch with it; here its shape is pinned)."""
+    from superpoint_transformer_amd import ops
+    rows = 1200
+    one = ops.graph_runs(None, None, rows)
+    assert one.n == 1 and one.sorted_batch and one.rows_per_graph() == [rows]
+    b = torch.arange(rows) * 3 // rows
+    r = ops.graph_runs(b, 3, rows)
+    assert r.sorted_batch and r.g == [0, 1, 2] and r.r0[0] == 0 and r.r1[-1] == rows
+    assert r.r1[:-1] == r.r0[1:] and r.rows_per_graph() == [400, 400, 400]
+    assert ops.graph_runs(b, 3, rows) is r                              # memoised on the tensor
+    n, r0, r1, g = r.c_arrays()
+    assert n == 3 and list(r0) == r.r0 and list(r1) == r.r1 and list(g) == r.g
+    # the edge MLP's norm index of a 4-cloud batch: sorted inside each third of [i<j | j>i | loops]
+    third = torch.arange(rows // 3) * 4 // (rows // 3)
+    p = torch.cat([third, third, third])
+    r = ops.graph_runs(p, 4, rows)
+    assert r is not None and not r.sorted_batch and r.n == 12
+    assert r.g == sorted(r.g)                                           # runs grouped by graph
+    assert r.rows_per_graph() == [int((p == k).sum()) for k in range(4)]
+    # more runs than the kernels' table holds, an id outside [0, B): no table (layer-by-layer route)
+    assert ops.graph_runs(torch.randint(0, 3, (rows,), generator=torch.Generator().manual_seed(1)),
+                          3, rows) is None
+    assert ops.graph_runs(torch.arange(rows) * 3 // rows + 1, 3, rows) is None
+    assert ops.graph_runs(b.clone(), ops.MAX_FUSED_RUNS + 1, rows) is None
+    # a derived index (norm_index[edge_index[0]]): the table is remembered on the holder
+    holder = torch.zeros(2, rows, dtype=torch.long)
+    d1 = p.clone()
+    r1 = ops.graph_runs_via(d1, 4, holder, holder, p)
+    d2 = p.clone()                                                      # rebuilt every forward
+    assert ops.graph_runs_via(d2, 4, holder, holder, p) is r1
+    holder.add_(0)                                                      # in-place change: new version
+    assert ops.graph_runs_via(p.clone(), 4, holder, holder, p) is not r1
