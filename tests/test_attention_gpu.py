@@ -240,11 +240,14 @@ def _degree_graph(gen, degrees):
     [15, 17] * 8 + [1, 100, 1, 3],                        # boundaries drifting through the tiles
     [0] * 5 + [9] + [0] * 5,                              # a single node with edges
 ])
-@pytest.mark.parametrize("packed", [1, 0])
-def test_attention_backward_tilings_match_oracle(degrees, packed, dev):
-    """The packed backward (16-edge tiles over the edge stream, two node contexts per pass,
-    extra passes when a tile holds more nodes) and the per-node tiling, against the f64
-    oracle on graphs built to hit the tile / node boundary cases."""
+@pytest.mark.parametrize("packed,target_order", [(2, 1), (2, 0), (1, None), (0, None)],
+                         ids=["edge-lane-target-order", "edge-lane-source-order", "packed", "per-node"])
+def test_attention_backward_tilings_match_oracle(degrees, packed, target_order, dev):
+    """The edge-lane backward over the edge stream in target order (the default) and in source
+    order, the packed backward (16-edge tiles over the edge stream, two node contexts per pass,
+    extra passes when a tile holds more nodes) and the per-node tiling, against the f64 oracle
+    on graphs built to hit the tile / node boundary cases (short last tiles included: the
+    edge counts are 160, 144, 192, 361 and 9)."""
     from superpoint_transformer_amd import _lib, nn as N
     gen = torch.Generator().manual_seed(sum(degrees) + len(degrees))
     n, H, D, dim, F = len(degrees), 16, 4, 64, 32
@@ -256,6 +259,7 @@ def test_attention_backward_tilings_match_oracle(degrees, packed, dev):
     ea = torch.randn(E, F, generator=gen) * 0.5
     gw = torch.randn(n, dim, generator=gen)
     prev = _lib.lib.spt_attn_bwd_packed(packed)
+    prev_to = _lib.lib.spt_attn_bwd_el_target_order(target_order) if target_order is not None else None
     try:
         xd = x.to(dev).requires_grad_()
         ead = ea.to(dev).requires_grad_()
@@ -263,6 +267,8 @@ def test_attention_backward_tilings_match_oracle(degrees, packed, dev):
         (out * gw.to(dev)).sum().backward()
     finally:
         _lib.lib.spt_attn_bwd_packed(prev)
+        if prev_to is not None:
+            _lib.lib.spt_attn_bwd_el_target_order(prev_to)
     p = {k: v.detach().cpu().double().requires_grad_() for k, v in blk.named_parameters()}
     x64, ea64 = x.double().requires_grad_(), ea.double().requires_grad_()
     deg = torch.tensor(degrees).double().clamp(min=1)
