@@ -338,7 +338,7 @@ def main():
                       "allreduce_us": round(us, 1) if us is not None else None}
 
     # The default "f32" mode runs the attention GEMMs and the fused layers' backward GEMMs as three
-    # bf16 products per f32 product (~10 ulp of f32; every f32 parity bar holds): print what the
+    # bf16 products per f32 product (~2^-17 relative per product: 17 of f32's 24 bits; every f32 parity bar holds): print what the
     # same step costs on the f32 matrix pipe everywhere next to it (untimed for `value`).
     exact_ms = None
     if args.dtype == "f32" and world == 1 and args.mode == "train" and not args.no_f32_exact:

@@ -13,8 +13,15 @@
  *     Scratch comes from a caller-provided workspace (ws, ws_bytes) whose size
  *     is returned by the paired *_workspace_bytes() query;
  *   - every function is asynchronous on `stream` (a hipStream_t passed as
- *     void*), re-entrant, and holds no global state besides the thread-local
- *     last-error string;
+ *     void*) and re-entrant.  State held by the library: the thread-local
+ *     last-error string, and a handful of process-wide FORMULATION DEFAULTS
+ *     (std::atomic<int>, set by the spt_*_use_* / spt_attn_bwd_* setters below or
+ *     read once from SPT_* environment variables: matrix-pipe precision, backward
+ *     tiling, edge order, LDS-DMA staging, streaming segment-max, cell-centric
+ *     kNN).  They select between implementations of the SAME result and apply
+ *     only where a call passes no choice of its own: every op they govern has a
+ *     *_ex / *_m entry whose `mode` word carries the choice per call, so two
+ *     callers (threads, streams, models) never change each other's arithmetic;
  *   - return value: 0 = ok, <0 = error (see spt_last_error()).  Nothing throws
  *     across the boundary;
  *   - row-major, contiguous tensors; f32 features; int64 indices as the
@@ -276,7 +283,8 @@ size_t spt_edge_attn_bwd_workspace_bytes(int H, int D, int Dv, int F);
 /* Three formulations exist for the SPT-64 head layout (H=16, D=Dv=4, F=32):
  *   2 (default)  matrix pipe, split-bf16: every f32 product of the three RPE GEMMs (and of
  *                the two gradient GEMMs) is hi*hi + lo*hi + hi*lo of bf16 halves on the bf16
- *                MFMA (16x the f32 pipe's rate), f32 accumulate: ~10 ulp of f32 per product;
+ *                MFMA (16x the f32 pipe's rate), f32 accumulate: the dropped lo*lo term and the
+ *                halves' rounding leave ~2^-17 relative per product (17 of f32's 24 bits);
  *   1            matrix pipe, f32 in / f32 accumulate (bitwise an fmaf chain);
  *   0            generic lane-per-output VALU kernels (every other shape uses these).
  * spt_attn_use_mfma(mode) selects process-wide and returns the previous mode (mode < -1: query
@@ -304,6 +312,17 @@ int spt_attn_tile_record_ints(void);
 int spt_attn_pack_tile_ids_ex(const int32_t* eperm, const int32_t* tgt_sorted,
                               const int32_t* src_sorted, const int32_t* tperm, int64_t e,
                               int32_t* tile_ids, spt_stream_t stream);
+/* The same two with the edge order taken from bits 6-7 of a per-call `mode` word (< 0 or 0 in
+ * those bits: the process default) - the word later handed to spt_edge_attn_bwd_ex_f32.
+ * ABI note (round 4 -> 5): spt_attn_pack_tile_ids (48-int records, declared further down) REFUSES
+ * while the process default is the target order, because records of the wrong width would be read
+ * as garbage; callers of the older pair (spt_attn_pack_tile_ids + spt_edge_attn_bwd_ex_f32) either
+ * move to the _m entries or pin SPT_ATTN_BWD_SOURCE_ORDER in their mode word and call
+ * spt_attn_pack_tile_ids_m with it. */
+int spt_attn_tile_record_ints_m(int mode);
+int spt_attn_pack_tile_ids_m(const int32_t* eperm, const int32_t* tgt_sorted,
+                             const int32_t* src_sorted, const int32_t* tperm, int64_t e, int mode,
+                             int32_t* tile_ids, spt_stream_t stream);
 int spt_edge_attn_bwd_f32(const float* qkv, int64_t n, int H, int D, int Dv,
                           const int32_t* erowptr, const int32_t* eperm,
                           const int32_t* tgt_sorted, int64_t e,
@@ -337,7 +356,17 @@ int spt_edge_attn_bwd_acc_f32(const float* qkv, int64_t n, int H, int D, int Dv,
  *   bits 0-1  precision: SPT_ATTN_VALU 0, SPT_ATTN_F32 1 (f32 matrix pipe), SPT_ATTN_SPLIT_BF16 2,
  *             SPT_ATTN_BF16 3 (operands rounded to bf16);
  *   bits 4-5  backward tiling of the bf16-pipe precisions: 0 auto (edge-lane when the workspace
- *             allows), SPT_ATTN_BWD_PER_NODE, SPT_ATTN_BWD_PACKED, SPT_ATTN_BWD_EDGE_LANE.
+ *             allows), SPT_ATTN_BWD_PER_NODE, SPT_ATTN_BWD_PACKED, SPT_ATTN_BWD_EDGE_LANE;
+ *   bits 6-7  edge order of the edge-lane backward: 0 = the process default
+ *             (spt_attn_bwd_el_target_order), SPT_ATTN_BWD_TARGET_ORDER (csrc/edge_attn_to.hip:
+ *             dk / dv reduced per target inside the tile, a few float atomics per node - the
+ *             sums' order, not their value, varies run to run), SPT_ATTN_BWD_SOURCE_ORDER
+ *             (csrc/edge_attn_el.hip: no atomics, every gradient bitwise reproducible).  The
+ *             tile records a caller pre-builds must come from spt_attn_pack_tile_ids_m with the
+ *             SAME word (64 ints per tile in target order, 48 in source order); when a call
+ *             cannot run the selected target order (src_sorted NULL or a workspace below
+ *             spt_edge_attn_bwd_ex_workspace_bytes) it falls back to the source order and
+ *             rebuilds the records itself - it never reads records of the other format.
  * Edge-lane backward (csrc/edge_attn_el.hip; H=16, D=Dv=4, F=32): 16-edge tiles over the CSR edge
  * stream, a wave owns half of the heads; the recompute GEMM runs transposed so that a lane holds
  * whole heads of ONE edge (no redundant softmax math, per-edge node rows fetched by LDS-DMA, any
@@ -360,6 +389,8 @@ int spt_edge_attn_bwd_acc_f32(const float* qkv, int64_t n, int H, int D, int Dv,
 #define SPT_ATTN_BWD_PER_NODE (1 << 4)
 #define SPT_ATTN_BWD_PACKED (2 << 4)
 #define SPT_ATTN_BWD_EDGE_LANE (3 << 4)
+#define SPT_ATTN_BWD_TARGET_ORDER (1 << 6)
+#define SPT_ATTN_BWD_SOURCE_ORDER (2 << 6)
 int spt_edge_attn_fwd_ex_f32(const float* qkv, int64_t n, int H, int D, int Dv,
                              const int32_t* erowptr, const int32_t* eperm,
                              const int32_t* tgt_sorted, int64_t e,
@@ -368,6 +399,9 @@ int spt_edge_attn_fwd_ex_f32(const float* qkv, int64_t n, int H, int D, int Dv,
                              const float* Wv, const float* bv, int scale_mode,
                              float scale_a, float* out, float* m, float* z, int mode,
                              spt_stream_t stream);
+/* Scratch for either edge order of the edge-lane backward (the larger of the two layouts: the
+ * target order needs 644 B per node + 256 B per edge + 16 B per tile id, the source order
+ * 388 B per node + 516 B per edge + 12 B per tile id) on top of the weight-gradient tables. */
 size_t spt_edge_attn_bwd_ex_workspace_bytes(int64_t n, int64_t e, int H, int D, int Dv, int F);
 /* 1 when the edge-lane backward is built for this head layout AND `mode` (< 0: the process
  * defaults) selects it (a caller uses it to decide whether to build the target view). */
@@ -734,7 +768,7 @@ int spt_graphnorm_bwd_tables_f32(const double* total, int num_graphs, int d, con
 int spt_fused_linear_supported(int K, int N);
 /* Matrix pipe of the fused layers' GEMMs.  0: f32 in / f32 accumulate everywhere (bitwise an
  * fmaf chain).  1 (default): the backward GEMMs (gW, gx) on the bf16 pipe with split operands
- * (each f32 product = hi*hi + lo*hi + hi*lo of bf16 halves, f32 accumulate, ~10 ulp of f32 -
+ * (each f32 product = hi*hi + lo*hi + hi*lo of bf16 halves, f32 accumulate, ~2^-17 relative per product: 17 of f32's 24 bits -
  * a tenth of the gradients' parity bar); the forward stays exact f32 (its outputs feed
  * GraphNorm statistics, bar 2e-5).  2: forward too.  Returns the previous setting. */
 int spt_fused_linear_use_split_bf16(int mode);

@@ -61,6 +61,8 @@ SIGNATURES = {
     "spt_attn_bwd_el_target_order": (_int, [_int]),
     "spt_attn_tile_record_ints": (_int, []),
     "spt_attn_pack_tile_ids_ex": (_int, [_p, _p, _p, _p, _i64, _p, _p]),
+    "spt_attn_tile_record_ints_m": (_int, [_int]),
+    "spt_attn_pack_tile_ids_m": (_int, [_p, _p, _p, _p, _i64, _int, _p, _p]),
     "spt_edge_attn_bwd_f32": (_int, [_p, _i64, _int, _int, _int, _p, _p, _p, _i64, _p, _int,
                                      _p, _p, _p, _p, _p, _p, _int, _f32, _p, _p, _p, _p,
                                      _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),

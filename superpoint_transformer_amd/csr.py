@@ -14,6 +14,7 @@ import torch
 from . import _lib
 
 _ATTR = "_spt_csr_memo"
+_ATTR_BAD = "_spt_csr_rejected"     # a (sub, super_index) pair that failed adopt_csr's check
 
 
 class SegmentCSR:
@@ -108,16 +109,24 @@ def use_sub_views(on=True):
     return old
 
 
-def adopt_csr(idx, num_seg, pointers, points):
+def adopt_csr(idx, num_seg, pointers, points, ascending=None):
     """Install ``(pointers, points)`` as the memoised CSR view of ``idx`` - no sort.
 
     The reference's NAG stores, next to every ``super_index``, the same partition as a CSR:
     ``nag[i+1].sub`` with ``sub.points[sub.pointers[c]:sub.pointers[c+1]]`` the children of
     cluster ``c`` (src/data/cluster.py:19-77; kept consistent by ``NAG.select``,
     src/data/nag.py:306-399).  With the children of a cluster in ascending order - what the
-    stable sort of ``build_csr`` produces; the caller vouches for it (``Cluster.ascending``)
-    - the two views are the same arrays, so the per-batch sort of the level is skipped.
-    Only the int32 casts run (one pass over the level's ids)."""
+    stable sort of ``build_csr`` produces - the two views are the same arrays, so the per-batch
+    sort of the level is skipped: only the int32 casts run (one pass over the level's ids).
+
+    Nothing is taken on trust: the view is adopted only for a contiguous int64 ``idx`` (what
+    ``build_csr`` normalises to and the kernels read), and only after ONE memoised device check
+    per (idx, sub) pair - ``pointers`` starts at 0, ends at ``n`` and never decreases,
+    ``idx[points[j]]`` is the cluster of position ``j`` for every ``j`` (membership; with
+    ``points.numel() == n`` this also makes ``points`` a permutation), and, unless the caller
+    already knows it (``ascending=True``, e.g. ``Cluster.ascending``), the points of every cluster
+    ascend.  A stale or hand-built ``sub`` fails the check and the level falls back to the sort
+    (``None`` is returned)."""
     if not _USE_SUB_VIEWS or idx is None:
         return None
     n = idx.numel()
@@ -125,11 +134,36 @@ def adopt_csr(idx, num_seg, pointers, points):
     if (points.numel() != n or pointers.numel() != num_seg + 1
             or points.device != idx.device or pointers.device != idx.device):
         return None                     # not the same partition / not resident: leave it to the sort
+    if idx.dtype != torch.int64 or not idx.is_contiguous() or idx.dim() != 1:
+        return None                     # build_csr normalises these; an adopted view cannot
     _lib.require_cuda(idx)
     memo = getattr(idx, _ATTR, None)
     key = (idx._version, num_seg, idx.data_ptr(), n)
     if memo is not None and key in memo:
         return memo[key]
+    bad = getattr(idx, _ATTR_BAD, None)
+    vkey = key + (points.data_ptr(), points._version, pointers.data_ptr(), pointers._version)
+    if bad == vkey:
+        return None                     # this very pair failed the check before
+    if n:
+        pl, ql = points.long(), pointers.long()
+        sizes = ql[1:] - ql[:-1]
+        ok = (ql[0] == 0) & (ql[-1] == n) & (sizes >= 0).all()
+        ok = ok & (pl >= 0).all() & (pl < n).all()
+        if bool(ok):                    # (the gathers below need in-range ids)
+            seg_of_pos = torch.repeat_interleave(
+                torch.arange(num_seg, device=idx.device, dtype=torch.int64), sizes)
+            ok = (idx[pl] == seg_of_pos).all()
+            if ascending is not True and n > 1:
+                inc = pl[1:] > pl[:-1]
+                inc = inc | (seg_of_pos[1:] != seg_of_pos[:-1])
+                ok = ok & inc.all()
+        if not bool(ok):
+            try:
+                setattr(idx, _ATTR_BAD, vkey)
+            except Exception:
+                pass
+            return None
     csr = SegmentCSR(idx.detach(), points.to(torch.int32), pointers.to(torch.int32), n, num_seg)
     if memo is None or any(k[0] != idx._version for k in memo):
         memo = {}
@@ -158,25 +192,29 @@ class EdgeCSR:
         self._tview = None
         self._tile_ids = None
 
-    def tile_ids(self):
+    def tile_ids(self, mode=-1):
         """int32 [ceil(e / 16), 48 | 64]: the edge-lane attention backward's tile records, built on
-        first use in the format of the current process setting: 16 consecutive positions of the
-        edge stream in TARGET order (edge rows | targets | sources | source-order positions), or in
-        source (CSR) order (edge rows | targets | sources)."""
-        ints = int(_lib.lib.spt_attn_tile_record_ints())     # 64: target order, 48: source order
-        if self._tile_ids is None or self._tile_ids.shape[1] != ints:
+        first use in the format the call's ``mode`` word selects (bits 6-7; the process setting
+        when it carries no choice): 16 consecutive positions of the edge stream in TARGET order
+        (edge rows | targets | sources | source-order positions), or in source (CSR) order
+        (edge rows | targets | sources).  One set per format is kept."""
+        ints = int(_lib.lib.spt_attn_tile_record_ints_m(int(mode)))   # 64: target order, 48: source order
+        if self._tile_ids is None:
+            self._tile_ids = {}
+        if ints not in self._tile_ids:
             dev = self.tgt_sorted.device
             nt = (self.e + 15) // 16
             out = torch.empty((max(nt, 1), ints), dtype=torch.int32, device=dev)
             src = self.src_sorted()
             tperm = self.target_view().perm if ints == 64 else None
+            order = (1 << 6) if ints == 64 else (2 << 6)
             with torch.cuda.device(dev):
-                st = _lib.lib.spt_attn_pack_tile_ids_ex(
+                st = _lib.lib.spt_attn_pack_tile_ids_m(
                     _lib.ptr(self.eperm), _lib.ptr(self.tgt_sorted), _lib.ptr(src), _lib.ptr(tperm),
-                    self.e, _lib.ptr(out), _lib.stream_ptr(dev))
-            _lib.check(st, "spt_attn_pack_tile_ids_ex")
-            self._tile_ids = out
-        return self._tile_ids
+                    self.e, order, _lib.ptr(out), _lib.stream_ptr(dev))
+            _lib.check(st, "spt_attn_pack_tile_ids_m")
+            self._tile_ids[ints] = out
+        return self._tile_ids[ints]
 
     def target_view(self):
         """CSR view of ``tgt_sorted`` over the CSR positions (which positions point INTO node t,
@@ -235,8 +273,14 @@ def forget(*tensors):
     carry new tensors; benchmarks reusing one batch call this every step so
     that the per-batch sort stays inside the timed region)."""
     for t in tensors:
-        if t is not None and hasattr(t, _ATTR):
-            try:
-                delattr(t, _ATTR)
-            except Exception:
-                pass
+        if t is None:
+            continue
+        # the CSR views AND the run tables / row ranges ops.graph_runs(_via) / graph_ranges
+        # memoise on batch vectors and edge indices: a fresh batch pays their read-backs too
+        for a in (_ATTR, _ATTR_BAD, "_spt_graph_runs", "_spt_graph_runs_via", "_spt_graph_ranges",
+                  "_spt_batch_checked"):
+            if hasattr(t, a):
+                try:
+                    delattr(t, a)
+                except Exception:
+                    pass

@@ -791,9 +791,9 @@ int attn_bwd_el_launch(const float* qkv, int64_t n, const int32_t* erowptr, cons
                        float* gqkv, float* gea, int gea_acc, float* partial, void* ws, int prec,
                        hipStream_t stream);
 // 0: lane-per-output VALU kernels, 1: f32 matrix pipe (bitwise an fmaf chain), 2 (default):
-// split-bf16 on the bf16 matrix pipe (3 products per f32 product, ~10 ulp of f32), 3: plain
+// split-bf16 on the bf16 matrix pipe (3 products per f32 product, ~2^-17 relative per product: 17 of f32's 24 bits), 3: plain
 // bf16 operands, f32 accumulate (the bf16 precision mode)
-static int g_attn_mfma = -1;  // -1: decide from the environment on first use
+static std::atomic<int> g_attn_mfma{-1};  // -1: decide from the environment on first use
 static int mfma_mode() {
   if (g_attn_mfma < 0) g_attn_mfma = getenv("SPT_ATTN_VALU_ONLY") == nullptr ? 2 : 0;
   return g_attn_mfma;
@@ -802,12 +802,18 @@ static bool use_mfma() { return mfma_mode() != 0; }
 // backward of the bf16-pipe modes: 2 (default) edge-lane kernel (edge_attn_el.hip; needs the
 // larger workspace of spt_edge_attn_bwd_ex_workspace_bytes, else 1 is used), 1 packed tiles over
 // the edge stream, 0 one tile set per source node
-static int g_attn_bwd_packed = 2;
+static std::atomic<int> g_attn_bwd_packed{2};
 // per-call mode word (include/spt_hip.h): < 0 = the process defaults above
 static int mode_precision(int mode) { return mode < 0 ? mfma_mode() : (mode & 3); }
 static int mode_bwd_form(int mode) {
   const int f = mode < 0 ? 0 : ((mode >> 4) & 3);
-  return f == 0 ? g_attn_bwd_packed : f - 1;
+  return f == 0 ? (int)g_attn_bwd_packed : f - 1;
+}
+// bits 6-7 of the mode word: edge order of the edge-lane backward (0 = the process default of
+// spt_attn_bwd_el_target_order, SPT_ATTN_BWD_TARGET_ORDER, SPT_ATTN_BWD_SOURCE_ORDER)
+static bool mode_target_order(int mode) {
+  const int o = mode < 0 ? 0 : ((mode >> 6) & 3);
+  return o == 0 ? attn_bwd_to_enabled() : o == 1;
 }
 }  // namespace spt
 
@@ -912,7 +918,10 @@ extern "C" int spt_edge_attn_bwd_el_supported(int H, int D, int Dv, int F, int m
 
 extern "C" size_t spt_edge_attn_bwd_ex_workspace_bytes(int64_t n, int64_t e, int H, int D, int Dv,
                                                        int F) {
-  return attn_tables_bytes(H, D, Dv, F) + attn_bwd_el_workspace_bytes(n, e);
+  // enough for EITHER edge order of the edge-lane backward: the target-order layout (640 B of
+  // records per node + 256 B of dq rows per edge) is the larger one on graphs with e < ~1.4 n
+  const size_t el = attn_bwd_el_workspace_bytes(n, e), to = attn_bwd_to_workspace_bytes(n, e);
+  return attn_tables_bytes(H, D, Dv, F) + (el > to ? el : to);
 }
 
 extern "C" int spt_edge_attn_bwd_f32(const float* qkv, int64_t n, int H, int D, int Dv,
@@ -966,8 +975,8 @@ extern "C" int spt_attn_pack_tile_ids(const int32_t* eperm, const int32_t* tgt_s
   // the 48-int source-order records: the target-order backward (the default) reads another format
   // and would silently walk garbage - refuse instead of writing records nobody can use
   SPT_CHECK_ARG(!attn_bwd_to_enabled(),
-                "the target-order backward is on: build the tile records with spt_attn_pack_tile_ids_ex "
-                "(or switch it off with spt_attn_bwd_el_target_order(0))");
+                "the target-order backward is on: build the tile records with spt_attn_pack_tile_ids_ex / "
+                "_m (or switch it off with spt_attn_bwd_el_target_order(0))");
   attn_pack_tile_ids_launch(eperm, tgt_sorted, src_sorted, e, tile_ids, (hipStream_t)stream_);
   SPT_CHECK_LAUNCH();
   return 0;
@@ -978,11 +987,19 @@ extern "C" int spt_attn_pack_tile_ids(const int32_t* eperm, const int32_t* tgt_s
 // the CSR view of the targets over the CSR positions, and `src_sorted`), else the 48-int
 // source-order records of spt_attn_pack_tile_ids.  spt_attn_tile_record_ints() = ints per tile.
 extern "C" int spt_attn_tile_record_ints(void) { return attn_bwd_to_enabled() ? 64 : 48; }
+extern "C" int spt_attn_tile_record_ints_m(int mode) { return mode_target_order(mode) ? 64 : 48; }
 extern "C" int spt_attn_pack_tile_ids_ex(const int32_t* eperm, const int32_t* tgt_sorted,
                                          const int32_t* src_sorted, const int32_t* tperm, int64_t e,
                                          int32_t* tile_ids, spt_stream_t stream_) {
+  return spt_attn_pack_tile_ids_m(eperm, tgt_sorted, src_sorted, tperm, e, -1, tile_ids, stream_);
+}
+// Same with the edge order taken from bits 6-7 of a per-call `mode` word (the word handed to
+// spt_edge_attn_bwd_ex_f32 afterwards): the records' format follows the call, not the process.
+extern "C" int spt_attn_pack_tile_ids_m(const int32_t* eperm, const int32_t* tgt_sorted,
+                                        const int32_t* src_sorted, const int32_t* tperm, int64_t e,
+                                        int mode, int32_t* tile_ids, spt_stream_t stream_) {
   SPT_CHECK_ARG(e >= 0 && (e == 0 || (tgt_sorted && src_sorted && tile_ids)), "null pointer");
-  if (attn_bwd_to_enabled()) {
+  if (mode_target_order(mode)) {
     SPT_CHECK_ARG(e == 0 || tperm, "target-order tile records need the target view (tperm)");
     attn_pack_tile_ids_to_launch(eperm, tgt_sorted, src_sorted, tperm, e, tile_ids, (hipStream_t)stream_);
   } else {
@@ -1031,28 +1048,39 @@ extern "C" int spt_edge_attn_bwd_ex_f32(const float* qkv, int64_t n, int H, int 
   const size_t partial_bytes = align_up((size_t)EA_BWD_BLOCKS * EA_WAVES * len * 4, 256);
   float* total = has_rpe ? (float*)((char*)ws + partial_bytes) : nullptr;
   const int grid = (int)(ceil_div(n, EA_WAVES) < EA_BWD_BLOCKS ? ceil_div(n, EA_WAVES) : EA_BWD_BLOCKS);
-  const bool el_ok = prec >= 2 && e > 0 && tperm &&
+  const bool el_ok = form == 2 && prec >= 2 && e > 0 && tperm &&
                      attn_mfma_shape_ok(H, D, Dv, F, edge_attr, Wk, Wq, Wv);
-  // gqkv receives atomics: start from zero (the edge-lane path initialises it itself)
-  if (!(form == 2 && el_ok && ws_bytes >= need + attn_bwd_el_workspace_bytes(n, e)))
-    hipMemsetAsync(gqkv, 0, (size_t)n * ld * 4, stream);
+  // The edge-lane route is decided ONCE, from the mode word and from what the caller handed over;
+  // each edge order has its own scratch layout, and a route only runs inside the bytes it needs
+  // (spt_edge_attn_bwd_ex_workspace_bytes covers both).
+  const bool to_sel = mode_target_order(mode);
+  const size_t need_el = need + attn_bwd_el_workspace_bytes(n, e);
+  const size_t need_to = need + attn_bwd_to_workspace_bytes(n, e);
+  const bool run_to = el_ok && to_sel && src_sorted && ws_bytes >= need_to;
+  const bool run_el = el_ok && !run_to && ws_bytes >= need_el;
+  // records built for the target order (64 ints) must not reach the source-order kernel (48 ints):
+  // when the call falls back from the selected target order, the ids are rebuilt in the workspace
+  if (run_el && to_sel) tile_ids = nullptr;
+  // gqkv receives atomics: start from zero (the edge-lane paths initialise it themselves)
+  if (!(run_to || run_el)) hipMemsetAsync(gqkv, 0, (size_t)n * ld * 4, stream);
   if (prec != 0 && attn_mfma_shape_ok(H, D, Dv, F, edge_attr, Wk, Wq, Wv)) {
     int ntab;
-    const size_t need_el = need + attn_bwd_el_workspace_bytes(n, e);
     if (form == 2 && mode >= 0 && ((mode >> 4) & 3) == 3)
-      SPT_CHECK_ARG(ws_bytes >= need_el && prec >= 2 && tperm && trowptr,
+      SPT_CHECK_ARG((run_to || run_el) && trowptr,
                     "edge-lane backward: workspace of spt_edge_attn_bwd_ex_workspace_bytes, the "
                     "target CSR view and a bf16-pipe precision are required");
+    if (mode >= 0 && ((mode >> 6) & 3) == 1 && el_ok)
+      SPT_CHECK_ARG(run_to, "target-order backward: src_sorted and the workspace of "
+                            "spt_edge_attn_bwd_ex_workspace_bytes are required");
     SPT_CHECK_ARG((tperm == nullptr) == (trowptr == nullptr), "pass both tperm and trowptr or neither");
-    if (form == 2 && prec >= 2 && e > 0 && ws_bytes >= need_el && tperm && src_sorted &&
-        attn_bwd_to_enabled()) {
+    if (run_to) {
       // edge stream in target order (edge_attn_to.hip); `tile_ids`, when given, are the 64-int
       // records of spt_attn_pack_tile_ids_ex
       ntab = attn_bwd_to_launch(qkv, n, erowptr, eperm, tgt_sorted, src_sorted, tile_ids, tperm, e,
                                 edge_attr, Wk, bk, Wq, bq, Wv, bv, scale_mode, scale_a, out, m, z,
                                 gout, gqkv, gedge_attr, gea_acc, partial, (char*)ws + need,
                                 prec == 2 ? 3 : 1, stream);
-    } else if (form == 2 && prec >= 2 && e > 0 && ws_bytes >= need_el && tperm) {
+    } else if (run_el) {
       ntab = attn_bwd_el_launch(qkv, n, erowptr, eperm, tgt_sorted, src_sorted, tile_ids, tperm,
                                 trowptr, e, edge_attr, Wk,
                                 bk, Wq, bq, Wv, bv, scale_mode, scale_a, out, m, z, gout, gqkv,

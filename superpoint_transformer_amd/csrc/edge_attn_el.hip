@@ -36,7 +36,7 @@
 //     counted vmcnt so the tile's own atomics never stall the next tile.
 //
 // Split-bf16 arithmetic as in edge_attn_mfma.hip: x = hi + lo, products hi*hi + lo*hi + hi*lo on
-// the bf16 matrix pipe, f32 accumulate (~10 ulp of f32 per product).  PREC = 1: hi only (bf16
+// the bf16 matrix pipe, f32 accumulate (~2^-17 relative per product: 17 of f32's 24 bits).  PREC = 1: hi only (bf16
 // matrix-precision mode).
 #include <math.h>
 #include <stdlib.h>
@@ -807,7 +807,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_bwd_el_kernel(
 
 // request shape of the edge-lane backward's k / v gathers and [dk | dv] stores: 1 = whole 128-byte
 // lines per instruction (FL), 0 = the MFMA layout's own 64-byte pieces.  Same results bit for bit.
-static int g_attn_el_full_line = [] { const char* e = getenv("SPT_EL_FULL_LINE"); return e ? (atoi(e) != 0) : 1; }();
+static std::atomic<int> g_attn_el_full_line{[] { const char* e = getenv("SPT_EL_FULL_LINE"); return e ? (atoi(e) != 0) : 1; }()};
 extern "C" int spt_attn_bwd_el_full_line(int on) {
   const int prev = g_attn_el_full_line;
   if (on >= 0) g_attn_el_full_line = on != 0;

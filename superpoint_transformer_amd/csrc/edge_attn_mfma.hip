@@ -197,7 +197,7 @@ __device__ __forceinline__ void load_a(const float* slab, int g, int c, float (&
 // ---- split-bf16 operands: x = hi + lo (+ 2^-18 |x|), both bf16 (RNE).  A product of two
 // f32 numbers is taken as hi*hi + lo*hi + hi*lo on the bf16 matrix pipe (16x the f32 pipe's
 // rate, exact bf16 x bf16 products, f32 accumulate): relative error <= ~3 * 2^-18 per product,
-// i.e. ~10 ulp of f32 - inside the attention parity bar (1e-5 + 1e-4 |ref|).
+// i.e. ~2^-17 relative per product: 17 of f32's 24 bits - inside the attention parity bar (1e-5 + 1e-4 |ref|).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 

@@ -713,7 +713,7 @@ constexpr int ATTN_TO_MAX_PAIRS = 1024;     // 256 workgroups of 4 pairs: one wo
 
 // edge order of the edge-lane backward: 1 = by TARGET (this file; default), 0 = by source
 // (edge_attn_el.hip).  Process-wide measurement / fallback switch.
-static int g_attn_el_target_order = [] { const char* e = getenv("SPT_EL_TARGET_ORDER"); return e ? (atoi(e) != 0) : 1; }();
+static std::atomic<int> g_attn_el_target_order{[] { const char* e = getenv("SPT_EL_TARGET_ORDER"); return e ? (atoi(e) != 0) : 1; }()};
 extern "C" int spt_attn_bwd_el_target_order(int on) {
   const int prev = g_attn_el_target_order;
   if (on >= 0) g_attn_el_target_order = on != 0;

@@ -1306,21 +1306,21 @@ using namespace spt::fmlp;
 //    else the f32 matrix pipe;
 // 2: forward too;  3: plain bf16 operands (hi halves only) in both directions - the bf16
 //    precision mode.  Process-wide, returns the previous setting.
-static int g_fmlp_mode = 1;
+static std::atomic<int> g_fmlp_mode{1};
 // per-call mode word of the *_ex entries: < 0 = the process default above, else 0..3
-static inline int fmlp_mode_of(int mode) { return mode < 0 ? g_fmlp_mode : (mode & 3); }
+static inline int fmlp_mode_of(int mode) { return mode < 0 ? (int)g_fmlp_mode : (mode & 3); }
 // Backward formulation of the split-bf16 / bf16 modes: 1 (default) = tiles staged by LDS-DMA
 // (fused_mlp_dma.hip) where the shape is built, 0 = register-staged everywhere (the process-wide
 // switch holds under a per-call precision too, like the attention's formulation default).  Per
 // call: bit 2 of the mode word (SPT_FMLP_BWD_REGISTER_STAGED) forces the register-staged kernels.
 // forward of mode 1: 1 (default) = 3-way split on the bf16 pipe (fwd_kernel_x3), 0 = f32 matrix pipe
-static int g_fmlp_x3 = [] { const char* e = getenv("SPT_FMLP_X3"); return e ? (atoi(e) != 0) : 1; }();
+static std::atomic<int> g_fmlp_x3{[] { const char* e = getenv("SPT_FMLP_X3"); return e ? (atoi(e) != 0) : 1; }()};
 extern "C" int spt_fused_linear_fwd_use_x3(int on) {
   const int prev = g_fmlp_x3;
   if (on >= 0) g_fmlp_x3 = on != 0;
   return prev;
 }
-static int g_fmlp_dma = 1;
+static std::atomic<int> g_fmlp_dma{1};
 static inline bool fmlp_dma_of(int mode) { return g_fmlp_dma != 0 && !(mode >= 0 && (mode & 4)); }
 extern "C" int spt_fused_linear_bwd_use_dma(int on) {
   const int prev = g_fmlp_dma;

@@ -877,7 +877,7 @@ extern "C" int spt_spatial_order(const float* xyz, int64_t n, float cell_size, c
 
 // process-wide switch between the two self-search kernels (tests cross-check them; 1 = shared
 // candidate streams, 0 = wave per query); returns the previous setting
-static int g_knn_cell_path = 1;
+static std::atomic<int> g_knn_cell_path{1};
 static thread_local int tl_knn_cell_path = -1;   // per-call choice of spt_grid_knn_ex_f32
 static bool knn_cell_path_enabled() {
   return tl_knn_cell_path >= 0 ? tl_knn_cell_path != 0 : g_knn_cell_path != 0;

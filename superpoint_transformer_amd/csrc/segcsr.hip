@@ -558,7 +558,7 @@ __global__ __launch_bounds__(256, 5) void segmax_stream_kernel(
   }
 }
 
-static int g_seg_stream = -1;   // -1: from the environment (SPT_SEG_STREAM=0 turns it off)
+static std::atomic<int> g_seg_stream{-1};   // -1: from the environment (SPT_SEG_STREAM=0 turns it off)
 // per-call choice of the *_ex entries (thread-local, set for the duration of one call)
 static thread_local int tl_seg_stream = -1;
 struct SegStreamScope {

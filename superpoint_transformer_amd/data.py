@@ -468,6 +468,9 @@ class NAG:
             d.batch = torch.repeat_interleave(
                 torch.arange(len(nag_list), device=dev),
                 torch.tensor(counts[l], device=dev))
+            # host knowledge of the batch layout (Batch.ptr in the reference): the fused layers'
+            # run tables come from it without reading the device tensor back (ops.graph_runs)
+            d.batch._spt_host_ptr = list(off)
             d.num_nodes = off[-1]
             out.append(d)
         return cls(out)

@@ -91,8 +91,10 @@ def _adopt_sub_views(levels):
         pointers, points = getattr(sub, "pointers", None), getattr(sub, "points", None)
         if pointers is None or points is None or points.device != si.device:
             continue
-        if getattr(sub, "ascending", False):
-            adopt_csr(si, pointers.numel() - 1, pointers, points)
+        # (adopt_csr verifies membership - and the ascending order unless the Cluster already
+        # knows it - in one memoised device check; a stale `sub` falls back to the sort)
+        adopt_csr(si, pointers.numel() - 1, pointers, points,
+                  ascending=getattr(sub, "_ascending", None))
 
 
 class SPT(nn.Module):

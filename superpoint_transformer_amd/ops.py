@@ -567,7 +567,7 @@ class _EdgeAttention(torch.autograd.Function):
         src = tids = tperm = trowptr = None
         if el:
             src = ecsr.src_sorted()
-            tids = ecsr.tile_ids()
+            tids = ecsr.tile_ids(ctx.mode)
             tv = ecsr.target_view()
             tperm, trowptr = tv.perm, tv.rowptr
         with torch.cuda.device(dev), _timed(f"edge_attn_bwd:{n}:{ecsr.e}"):
@@ -738,7 +738,7 @@ class _EdgeAttentionSplit(torch.autograd.Function):
         ws = _workspace(nb, dev)
         src = tids = tperm = trowptr = None
         if el:
-            src, tids, tv = ecsr.src_sorted(), ecsr.tile_ids(), ecsr.target_view()
+            src, tids, tv = ecsr.src_sorted(), ecsr.tile_ids(ctx.mode), ecsr.target_view()
             tperm, trowptr = tv.perm, tv.rowptr
         with torch.cuda.device(dev):
             for gi in range(G):
@@ -1092,12 +1092,17 @@ class _NormLinear(torch.autograd.Function):
         _lib.check(st, "spt_skinny_linear_pre_f32")
         ctx.save_for_backward(xd, batch, w, b, a, mean, rstd, am, sc, wd)
         ctx.meta = (B, bias is not None)
+        # an unused output arrives as None in the backward instead of a dense zero [rows, C]
+        # tensor that the norm's backward kernel would read for nothing
+        ctx.set_materialize_grads(False)
         return y, x
 
     @staticmethod
     def backward(ctx, gy, gres):
         xd, batch, w, b, a, mean, rstd, am, sc, wd = ctx.saved_tensors
         B, has_bias = ctx.meta
+        if gy is None:                       # only the residual branch was used
+            return gres, None, None, None, None, None, None, None, None
         rows, d = xd.shape
         n = wd.shape[0]
         dev = xd.device
@@ -1142,10 +1147,33 @@ def norm_linear_ok(x, batch, num_graphs, weight):
                 and _lib.lib.spt_skinny_dw_supported(x.shape[1], weight.shape[0]))
 
 
+_BCHK_ATTR = "_spt_batch_checked"
+
+
+def _check_batch_ids(batch, B):
+    """The folded pre-norm kernels index LDS tables by ``batch[row]``: ids outside [0, B) must fail
+    here, as they do on the unfused ``graph_norm`` route, not read tables out of range.  One
+    memoised device reduction per batch vector (none when its maker left the host ranges)."""
+    if batch is None or _host_ptr(batch, B) is not None:
+        return
+    key = (batch._version, int(B), batch.data_ptr(), batch.numel())
+    if getattr(batch, _BCHK_ATTR, None) == key:
+        return
+    if batch.numel():
+        lo, hi = torch.aminmax(batch)
+        if int(lo) < 0 or int(hi) >= int(B):
+            raise ValueError(f"graph ids of `batch` must lie in [0, {int(B)}): found [{int(lo)}, {int(hi)}]")
+    try:
+        setattr(batch, _BCHK_ATTR, key)
+    except Exception:
+        pass
+
+
 def norm_linear(x, batch, num_graphs, gn_weight, gn_bias, gn_mean_scale, eps, weight, bias):
     """``(linear(graph_norm(x, batch), weight, bias), x_res)`` - see ``_NormLinear``.  Callers
     check ``norm_linear_ok`` first."""
     B = 1 if batch is None else int(num_graphs)
+    _check_batch_ids(batch, B)
     return _NormLinear.apply(x, batch, B, gn_weight, gn_bias, gn_mean_scale, float(eps), weight, bias)
 
 
@@ -1204,6 +1232,17 @@ def cross_entropy(logits, target, ignore_index=-100):
 _GPTR_ATTR = "_spt_graph_ranges"
 
 
+def _host_ptr(batch, num_graphs):
+    """Row ranges [B+1] of the clouds of a batch vector when its maker left them on the tensor
+    (``NAG.from_nag_list`` / the synthetic batches: ``Batch.ptr`` of the reference) - host
+    knowledge, no device read-back - else None."""
+    hp = getattr(batch, "_spt_host_ptr", None)
+    if (hp is None or len(hp) != int(num_graphs) + 1 or hp[0] != 0 or hp[-1] != batch.numel()
+            or batch._version != 0):
+        return None
+    return list(hp)
+
+
 def graph_ranges(batch, num_graphs, rows):
     """Host row ranges [B+1] of the graphs when ``batch`` is sorted (clouds of a
     NAGBatch are contiguous), else None.  One host sync per batch tensor (memoised
@@ -1214,6 +1253,9 @@ def graph_ranges(batch, num_graphs, rows):
     key = (batch._version, int(num_graphs), batch.data_ptr(), batch.numel())
     if memo is not None and memo[0] == key:
         return memo[1]
+    hp = _host_ptr(batch, num_graphs)
+    if hp is not None:
+        return hp
     if batch.numel() and not bool((batch[1:] >= batch[:-1]).all()):
         ranges = None
     else:
@@ -1283,8 +1325,12 @@ def graph_runs(batch, num_graphs, rows):
     if memo is not None and memo[0] == key:
         return memo[1]
     runs = None
+    hp = _host_ptr(batch, B)
     if batch.numel() == 0:
         runs = GraphRuns([], B, 0)
+    elif hp is not None:
+        runs = GraphRuns([(hp[g], hp[g + 1], g) for g in range(B) if hp[g + 1] > hp[g]], B,
+                         batch.numel())
     else:
         # run starts = positions where the id changes; read back only when there are few
         change = (batch[1:] != batch[:-1])

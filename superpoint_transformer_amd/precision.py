@@ -1,7 +1,7 @@
 """Matrix-pipe precision of the hot path's GEMMs (the reference's ``precision: 32 | bf16``
 switch, configs/trainer/gpu.yaml:7-10).
 
-``"f32"`` (default)  attention: split-bf16 (3 bf16 products per f32 product, ~10 ulp of f32);
+``"f32"`` (default)  attention: split-bf16 (3 bf16 products per f32 product, ~2^-17 relative per product: 17 of f32's 24 bits);
                      fused MLP layers: forward on the f32 matrix pipe (bitwise an fmaf chain),
                      backward split-bf16.  Every f32 parity bar of tests/ holds in this mode.
 ``"bf16"``           what ``torch.autocast(bfloat16)`` does to the reference's Linear layers:
@@ -52,10 +52,35 @@ def get_matrix_precision():
     return _active.get() or _default
 
 
+_ORDERS = {"target": 1 << 6, "source": 2 << 6}       # SPT_ATTN_BWD_TARGET_ORDER / _SOURCE_ORDER
+_order = contextvars.ContextVar("spt_attn_bwd_order", default=None)
+
+
 def attention_mode():
-    """Mode word for ``spt_edge_attn_*_ex_f32``: -1 (library default) unless a per-call mode is active."""
-    mode = _active.get()
-    return -1 if mode is None else _MODES[mode][0]
+    """Mode word for ``spt_edge_attn_*_ex_f32``: -1 (library defaults) unless a per-call precision
+    or a per-call edge order of the attention backward is active (bits 0-1 precision, bits 6-7
+    edge order; include/spt_hip.h)."""
+    mode, order = _active.get(), _order.get()
+    if mode is None and order is None:
+        return -1
+    prec = _MODES[mode][0] if mode is not None else int(_lib.lib.spt_attn_use_mfma(-2))
+    return prec | (_ORDERS[order] if order is not None else 0)
+
+
+@contextlib.contextmanager
+def attention_backward_order(order):
+    """Per-call edge order of the edge-lane attention backward for everything launched inside the
+    block (this thread / task only; the backward of an op runs in the order its forward saw):
+    ``"target"`` - dk / dv reduced per target inside the tile, a few float atomics per node (the
+    default of the library); ``"source"`` - no atomics, every gradient bitwise reproducible run to
+    run (the deterministic option; +25 % on the level-1 backward).  ``None``: the process default."""
+    if order is not None and order not in _ORDERS:
+        raise ValueError(f"order must be one of {sorted(_ORDERS)} or None")
+    token = _order.set(order)
+    try:
+        yield
+    finally:
+        _order.reset(token)
 
 
 def fused_mode():

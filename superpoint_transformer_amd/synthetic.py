@@ -201,6 +201,10 @@ def make_nag(scene="S", seed=1234, device="cpu", sizes=None, point_dim=8,
         si0 = si0[torch.argsort(b2[si1][si0], stable=True)]
     b1 = b2[si1]
     b0 = b1[si0]
+    if b > 1:
+        # what NAGBatch.from_nag_list knows on the host (Batch.ptr): the clouds' node ranges
+        for bt in (b0, b1, b2):
+            bt._spt_host_ptr = [0] + torch.cumsum(torch.bincount(bt, minlength=b), 0).tolist()
 
     def rnd(*shape, s=1.0):
         return torch.randn(*shape, generator=gen, device=device) * s

@@ -511,3 +511,54 @@ def test_narrower_head_layouts_are_zero_padded_onto_the_matrix_pipe_kernels(D, D
     assert got[0].shape == (n, H * Dv)
     for a, r in zip(got, ref):
         assert (a - r).abs().max().item() <= 1e-5 + 2e-4 * r.abs().max().item()
+
+
+@pytest.mark.parametrize("order", ["target", "source"])
+def test_edge_lane_backward_stays_inside_an_exact_workspace_when_edges_are_fewer_than_nodes(order, dev):
+    """Advisor (round 4, high): with e < n the target-order layout (640 B of records per node) is
+    LARGER than the source-order one that `spt_edge_attn_bwd_ex_workspace_bytes` used to return -
+    a caller allocating exactly that many bytes had ~10 MB written past its buffer.  Here the
+    workspace handed to the op is EXACTLY the advertised size with a guard page behind it: the
+    guard must survive, the query must cover the layout of either order, and the gradients of
+    the two orders (chosen PER CALL through the mode word, precision.attention_backward_order)
+    must agree with each other and with the f64 oracle."""
+    from superpoint_transformer_amd import _lib, ops, precision, nn as N
+    gen = torch.Generator().manual_seed(5)
+    n, H, D, dim, F = 60_000, 16, 4, 64, 32
+    e = 36_000                                             # fewer edges than nodes, no self loops
+    src = torch.randint(0, n, (e,), generator=gen)
+    tgt = torch.randint(0, n, (e,), generator=gen)
+    ei = torch.stack([src, tgt])
+    blk = N.SelfAttentionBlock(dim, num_heads=H, out_dim=None, qk_dim=D, in_rpe_dim=F,
+                               k_rpe=True, q_rpe=True, v_rpe=True).to(dev)
+    x = torch.randn(n, dim, generator=gen)
+    ea = torch.randn(e, F, generator=gen) * 0.5
+    gw = torch.randn(n, dim, generator=gen)
+    nb = int(_lib.lib.spt_edge_attn_bwd_ex_workspace_bytes(n, e, H, D, D, F))
+    tables = int(_lib.lib.spt_edge_attn_bwd_workspace_bytes(H, D, D, F))
+    assert nb - tables >= n * 640 + e * 256               # the target-order layout fits
+    GUARD = 1 << 16
+    slab = torch.full((nb + GUARD,), 0xA5, dtype=torch.uint8, device=dev)
+    real_ws = ops._workspace
+    ops._workspace = lambda nbytes, d: (slab[:nb] if nbytes == nb else real_ws(nbytes, d))
+    try:
+        with precision.attention_backward_order(order):
+            xd = x.to(dev).requires_grad_()
+            ead = ea.to(dev).requires_grad_()
+            out = blk(xd, ei.to(dev), edge_attr=ead)
+            (out * gw.to(dev)).sum().backward()
+        torch.cuda.synchronize()
+    finally:
+        ops._workspace = real_ws
+    assert bool((slab[nb:] == 0xA5).all()), "the backward wrote past the advertised workspace"
+    p = {k: v.detach().cpu().double().requires_grad_() for k, v in blk.named_parameters()}
+    x64, ea64 = x.double().requires_grad_(), ea.double().requires_grad_()
+    ref = O.self_attention(x64, ei, ea64, p, H, D)
+    (ref * gw.double()).sum().backward()
+    _check(out, ref, "out")
+    _check(xd.grad, x64.grad, "g_x")
+    _check(ead.grad, ea64.grad, "g_edge_attr")
+    for k, v in blk.named_parameters():
+        _check(v.grad, p[k].grad, "g_" + k, rel_to_max=True)
+    # the process default was not touched by the per-call choice
+    assert _lib.lib.spt_attn_bwd_el_target_order(-1) == 1

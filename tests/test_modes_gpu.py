@@ -292,3 +292,51 @@ def test_two_models_at_different_precisions_interleaved_on_two_streams(dev):
         err = (got - ref).abs().max().item() / ref.abs().max().item()
         assert err <= tol, (name, err)
     assert (ref_a[0] - ref_b[0]).abs().max().item() > 1e-5 * ref_a[0].abs().max().item()
+
+
+def test_two_attention_backward_formulations_interleaved_on_two_streams(dev):
+    """Verdict (round 4, #7): the edge order of the edge-lane attention backward travels in the
+    per-call mode word (bits 6-7) - two callers choose per call.  One attention block run in the
+    TARGET order on one stream and in the SOURCE order on another, interleaved: each reproduces
+    its own stand-alone gradients (the source order bit for bit - it has no atomics; the target
+    order up to the order of its dk / dv atomics), both agree with each other to f32 round-off,
+    and the process default is never touched."""
+    from superpoint_transformer_amd import _lib, precision, nn as N
+    gen = torch.Generator().manual_seed(17)
+    n, H, D, dim, F = 20_000, 16, 4, 64, 32
+    e = 300_000
+    ei = torch.stack([torch.randint(0, n, (e,), generator=gen),
+                      torch.randint(0, n, (e,), generator=gen)]).to(dev)
+    blk = N.SelfAttentionBlock(dim, num_heads=H, out_dim=None, qk_dim=D, in_rpe_dim=F,
+                               k_rpe=True, q_rpe=True, v_rpe=True).to(dev)
+    x = torch.randn(n, dim, generator=gen).to(dev)
+    ea = (torch.randn(e, F, generator=gen) * 0.5).to(dev)
+    gw = torch.randn(n, dim, generator=gen).to(dev)
+
+    def run(order, stream):
+        with torch.cuda.stream(stream), precision.attention_backward_order(order):
+            xd, ead = x.clone().requires_grad_(), ea.clone().requires_grad_()
+            blk.zero_grad(set_to_none=True)
+            out = blk(xd, ei, edge_attr=ead)
+            (out * gw).sum().backward()
+            return xd.grad.clone(), ead.grad.clone(), blk.sa.qkv.weight.grad.clone()
+
+    before = _lib.lib.spt_attn_bwd_el_target_order(-1)
+    main = torch.cuda.current_stream()
+    ref_t, ref_s = run("target", main), run("source", main)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    s1.wait_stream(main), s2.wait_stream(main)
+    got = {}
+    for rep in range(3):
+        got["t"] = run("target", s1)
+        torch.cuda.synchronize()          # (the block's .grad buffers are shared by the two runs)
+        got["s"] = run("source", s2)
+        torch.cuda.synchronize()
+    for a, b in zip(got["s"], ref_s):
+        assert torch.equal(a, b), "the source-order backward is not reproducible bit for bit"
+    for a, b in zip(got["t"], ref_t):
+        assert (a - b).abs().max().item() <= 1e-5 * b.abs().max().item()
+    for a, b in zip(ref_t, ref_s):
+        assert (a - b).abs().max().item() <= 1e-4 * b.abs().max().item()
+    assert _lib.lib.spt_attn_bwd_el_target_order(-1) == before

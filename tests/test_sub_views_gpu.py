@@ -36,6 +36,44 @@ def test_adopted_view_is_the_sorted_view(dev):
         assert bad.ascending is False and sub.ascending is True
 
 
+def test_adoption_checks_the_stored_csr_against_the_index(dev):
+    """``adopt_csr`` takes nothing on trust (advisor, round 4): a ``sub`` whose sizes match but whose
+    membership is stale, whose clusters do not ascend, whose pointers do not end at n, or an
+    ``int32`` / strided ``super_index`` are all refused (the level then falls back to the device
+    sort), and the refusal is memoised for that very pair."""
+    from superpoint_transformer_amd import csr
+    nag = _nag(dev)
+    si, sub = nag[0]["super_index"], nag[1]["sub"]
+    n_par = nag[1]["pos"].shape[0]
+    ref = csr.build_csr(si, n_par)
+    csr.forget(si)
+    # 1. membership: swap two points that belong to DIFFERENT clusters (sizes unchanged)
+    pts = sub.points.clone()
+    a, b = int(sub.pointers[1]) - 1, int(sub.pointers[1])          # last of cluster 0, first of 1
+    pts[a], pts[b] = sub.points[b].clone(), sub.points[a].clone()
+    assert csr.adopt_csr(si, n_par, sub.pointers, pts, ascending=True) is None
+    assert csr.adopt_csr(si, n_par, sub.pointers, pts, ascending=True) is None   # memoised verdict
+    # 2. order inside a cluster (membership intact): refused unless the caller vouches for it
+    pts = sub.points.clone()
+    sizes = sub.pointers[1:] - sub.pointers[:-1]
+    c = int(torch.nonzero(sizes >= 2)[0])
+    a = int(sub.pointers[c])
+    pts[a], pts[a + 1] = sub.points[a + 1].clone(), sub.points[a].clone()
+    assert csr.adopt_csr(si, n_par, sub.pointers, pts) is None
+    # 3. pointers that do not cover the level
+    ptr = sub.pointers.clone()
+    ptr[-1] -= 1
+    assert csr.adopt_csr(si, n_par, ptr, sub.points) is None
+    # 4. an index the kernels cannot read as contiguous int64
+    assert csr.adopt_csr(si.int(), n_par, sub.pointers, sub.points) is None
+    wide = torch.stack([si, si], 1)[:, 0]
+    assert not wide.is_contiguous() and csr.adopt_csr(wide, n_par, sub.pointers, sub.points) is None
+    # the genuine pair is still adopted afterwards, and is the sorted view
+    got = csr.adopt_csr(si, n_par, sub.pointers, sub.points)
+    assert got is not None and torch.equal(got.perm, ref.perm) and torch.equal(got.rowptr, ref.rowptr)
+    csr.forget(si)
+
+
 def test_select_keeps_clusters_ascending(dev):
     from superpoint_transformer_amd.synthetic import make_raw_nag
     nag = make_raw_nag("R", seed=3, device=dev, sizes=(20_000, 600, 250, 5_000, 4_000, 1))
