@@ -873,6 +873,57 @@ int spt_fused_linear_bwd_pooled_runs_f32(
     size_t ws_bytes, spt_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * The point MLP's TOP layer and the max-pool behind it as one unit     (a1 + a2 + a5, round 5)
+ * Replaces, for the layer whose output feeds only the level-0 -> level-1 max-pool
+ * (src/nn/stage.py:413-431: PointStage MLP -> pool; layer = bias-free Linear -> GraphNorm ->
+ * LeakyReLU, src/nn/mlp.py:43-56; pool = MaxPool, src/nn/pool.py:61-82), the sequence
+ * spt_fused_linear_fwd_* -> spt_graphnorm_tables_f32 -> spt_segcsr_max_affine_* (forward) and
+ * spt_fused_linear_bwd_pooled_* (backward): the layer's [rows, N] output is never written, read
+ * or recomputed (csrc/fused_pool.hip explains the three identities used).
+ *   forward : out [num_seg, N] = max over the segment's rows of leaky(GraphNorm(x_act W^T)), bitwise
+ *             the value of norm-then-pool evaluated with THESE statistics; arg [num_seg, N] int32 =
+ *             first row attaining the raw extremum (n_rows for an empty segment, like
+ *             spt_segcsr_reduce_f32; the reference's arg except on ties of y between rows of
+ *             different h); raw [num_seg, N] = h of the arg row; gram [num_graphs, K K + K + 1] f64
+ *             = (sum_i y_i y_i^T | sum_i y_i | rows) of the layer's activated INPUT per graph, from
+ *             which the norm's statistics are evaluated (total [num_graphs, 2N+1], nullable, receives
+ *             them in spt_fused_linear_fwd_*'s layout) and its tables mean / rstd / am / scale
+ *             [num_graphs, N] are written (spt_graphnorm_tables_f32's formulas).
+ *             x [n_rows, K]: RAW output of the previous layer (f32, or bf16 with SPT_FMLP_X_BF16 in
+ *             `mode`), pre_* its norm tables ([num_graphs, K], [num_graphs, K], [K]) and slope;
+ *             (perm, pos_seg, rowptr): the pool's CSR view and the segment of every CSR position;
+ *             runs: the graphs' CSR position ranges (contiguous, tiling [0, n_rows)); seg_graph
+ *             [num_seg] int64 (NULL with one graph).
+ *   backward: from gout [num_seg, N] and the GraphNorm-backward coefficient rows c1 / c2 / c3
+ *             (spt_graphnorm_bwd_stats_sparse_raw_f32 -> spt_graphnorm_bwd_tables_f32) to gx
+ *             [n_rows, K] (gradient of the previous layer's normalised output), gW [N, K] and
+ *             prev_total [num_graphs, 2K+1] (statistics of the previous norm's backward);
+ *             gm [num_seg, N] f32: scratch of the call.
+ *   mode    : the fused layers' mode word; built for matrix modes 1 (f32-exact 3-way split forward),
+ *             2 and 3, K in {32, 64}, N in {64, 128} (spt_fused_linear_pool_supported).
+ *   ws      : spt_fused_linear_pool_workspace_bytes(K, N). */
+int spt_fused_linear_pool_supported(int K, int N, int mode);
+size_t spt_fused_linear_pool_gram_len(int K);
+size_t spt_fused_linear_pool_workspace_bytes(int K, int N);
+int spt_fused_linear_fwd_pool_runs_f32(
+    const void* x, const int32_t* perm, const int32_t* pos_seg, const int32_t* rowptr,
+    const int64_t* seg_graph, int64_t num_seg, int64_t n_rows, int nruns, const int64_t* run_p0,
+    const int64_t* run_p1, const int32_t* run_graph, int num_graphs, int K, const float* W, int N,
+    const float* gn_weight, const float* gn_bias, const float* gn_mean_scale, float eps, float slope,
+    const float* pre_am, const float* pre_scale, const float* pre_bias, float pre_slope, float* out,
+    int32_t* arg, float* raw, double* gram, double* total, float* mean, float* rstd, float* am,
+    float* scale, int mode, void* ws, size_t ws_bytes, spt_stream_t stream);
+int spt_fused_linear_bwd_pool_runs_f32(
+    const float* gout, const float* raw, const int32_t* arg, const int32_t* perm,
+    const int32_t* pos_seg, const int64_t* seg_graph, int64_t num_seg, int nruns,
+    const int64_t* run_p0, const int64_t* run_p1, const int32_t* run_graph, int num_graphs, int N,
+    const float* am, const float* scale, const float* bias, float slope, const float* c1,
+    const float* c2, const float* c3, const void* xprev, int K, const float* pre_am,
+    const float* pre_scale, const float* pre_bias, float pre_slope, const float* W,
+    const double* gram, float* gm, float* gx, float* gW, double* prev_total, int mode, void* ws,
+    size_t ws_bytes, spt_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * Cross-entropy of the classifier heads' logits                (train step)
  * torch.nn.CrossEntropyLoss(ignore_index=...) of configs/model/semantic/default.yaml:47-49 as
  * src/models/semantic.py applies it per output level: mean over the rows whose target is not

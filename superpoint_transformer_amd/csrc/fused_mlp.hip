@@ -1799,3 +1799,133 @@ extern "C" int spt_fused_linear_bwd_runs_f32(
                        am, scale, bias, slope, c1, c2, c3, xprev, K, pre_am, pre_scale, pre_bias,
                        pre_slope, W, gx, gW, 0, prev_total, mode, ws, ws_bytes, (hipStream_t)stream_);
 }
+
+// ---- the top layer fused with the max-pool behind it (fused_pool.hip) -----------------------------
+namespace spt {
+bool fpool_supported(int K, int N);
+int fpool_gram_len(int K);
+int fpool_fwd_launch(int prec, bool in16, const float* x, const int32_t* perm, const int32_t* pos_seg,
+                     const int32_t* rowptr, const FmlpRuns& rt, int64_t max_rows, int K, int N,
+                     const float* W, const float* gnw, const float* pam, const float* psc,
+                     const float* pbs, float pslope, float* raw, int32_t* arg, double* partial,
+                     hipStream_t stream);
+void fpool_tables_launch(int K, const double* gram, int B, const float* W, int N, int bfw,
+                         const float* weight, const float* mean_scale, float eps, double* total,
+                         float* mean, float* rstd, float* am, float* scale, hipStream_t stream);
+void fpool_apply_launch(int K, bool in16, const int32_t* rowptr, const int32_t* perm,
+                        const int64_t* seg_graph, int64_t num_seg, int N, int64_t n_rows,
+                        const float* am, const float* sc, const float* bs, float slope,
+                        const float* gnw, const float* x, const float* W, const float* pam,
+                        const float* psc, const float* pbs, float pslope, int bfw, float* raw,
+                        int32_t* arg, float* out, hipStream_t stream);
+int fpool_bwd_launch(bool lo, bool x16, const float* gout, const float* raw, const int32_t* arg,
+                     const int32_t* perm, const int32_t* pos_seg, const int64_t* seg_graph,
+                     int64_t num_seg, const FmlpRuns& rt, int64_t max_rows, int num_graphs, int K,
+                     int N, const float* am, const float* sc, const float* bs, float slope,
+                     const float* c1, const float* c2, const float* c3, const float* xprev,
+                     const float* pam, const float* psc, const float* pbs, float pslope,
+                     const float* W, float* gm, float* Mbuf, float* c0buf, float* gx,
+                     float* gw_partial, double* pstat_partial, int max_waves, hipStream_t stream);
+void fpool_gw_dense_launch(int K, const double* gram, int B, const float* W, int N, int bfw,
+                           const float* am, const float* c2, const float* c3, float* gW,
+                           hipStream_t stream);
+}  // namespace spt
+
+// matrix mode of the pool-fused top layer: forward 3 = f32-exact (3-way split), 2 = 2-way split,
+// 1 = plain bf16; 0 = not built (the f32 matrix pipe keeps the materialised route)
+static int fpool_prec_of(int mode) {
+  const int m = fmlp_mode_of(mode);
+  if (m == 1) return g_fmlp_x3 ? 3 : 0;
+  return m == 2 ? 2 : (m == 3 ? 1 : 0);
+}
+extern "C" int spt_fused_linear_pool_supported(int K, int N, int mode) {
+  return fpool_supported(K, N) && fpool_prec_of(mode) != 0;
+}
+extern "C" size_t spt_fused_linear_pool_gram_len(int K) { return (size_t)fpool_gram_len(K); }
+extern "C" size_t spt_fused_linear_pool_workspace_bytes(int K, int N) {
+  return align_up(spt_fused_linear_workspace_bytes(K, N), 256) +
+         align_up((size_t)FMLP_MAX_RUNS * (K * K + K) * 4, 256) + 256;
+}
+
+extern "C" int spt_fused_linear_fwd_pool_runs_f32(
+    const void* x, const int32_t* perm, const int32_t* pos_seg, const int32_t* rowptr,
+    const int64_t* seg_graph, int64_t num_seg, int64_t n_rows, int nruns, const int64_t* run_p0,
+    const int64_t* run_p1, const int32_t* run_graph, int num_graphs, int K, const float* W, int N,
+    const float* gn_weight, const float* gn_bias, const float* gn_mean_scale, float eps, float slope,
+    const float* pre_am, const float* pre_scale, const float* pre_bias, float pre_slope, float* out,
+    int32_t* arg, float* raw, double* gram, double* total, float* mean, float* rstd, float* am,
+    float* scale, int mode, void* ws, size_t ws_bytes, spt_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  FmlpRuns rt;
+  int64_t max_rows;
+  const char* err = fmlp_make_runs(nruns, run_p0, run_p1, run_graph, num_graphs, &rt, &max_rows);
+  SPT_CHECK_ARG(!err, err ? err : "");
+  const int prec = fpool_prec_of(mode);
+  const bool in16 = mode >= 0 && (mode & SPT_FMLP_X_BF16);
+  SPT_CHECK_ARG(fpool_supported(K, N) && prec != 0 && (!in16 || prec == 1),
+                "(K, N) has no pool-fused kernel in this matrix mode");
+  SPT_CHECK_ARG(x && pos_seg && rowptr && W && gn_weight && gn_bias && gn_mean_scale && pre_am &&
+                pre_scale && pre_bias && out && arg && raw && gram && mean && rstd && am && scale && ws,
+                "null pointer");
+  SPT_CHECK_ARG(num_seg >= 0 && n_rows >= 0 && (num_graphs == 1 || seg_graph), "bad shape");
+  SPT_CHECK_ARG(ws_bytes >= spt_fused_linear_pool_workspace_bytes(K, N), "workspace too small");
+  // the runs are the graphs' CSR position ranges: contiguous, starting at 0, ending at n_rows
+  for (int r = 0; r < rt.n; ++r)
+    SPT_CHECK_ARG(rt.r0[r] == (r ? rt.r1[r - 1] : 0), "runs must tile the CSR positions");
+  SPT_CHECK_ARG(rt.r1[rt.n - 1] == n_rows, "runs must tile the CSR positions");
+  double* partial = (double*)ws;
+  const int glen = fpool_gram_len(K);
+  const int gx_ = fpool_fwd_launch(prec, in16, (const float*)x, perm, pos_seg, rowptr, rt, max_rows, K, N,
+                                   W, gn_weight, pre_am, pre_scale, pre_bias, pre_slope, raw, arg,
+                                   partial, stream);
+  SPT_CHECK_ARG(gx_ > 0, "no kernel for this variant");
+  reduce_tables_groups_kernel<double><<<dim3((glen + 15) / 16, num_graphs), 1024, 0, stream>>>(
+      partial, fmlp_groups(rt, num_graphs, gx_), glen, gram);
+  fpool_tables_launch(K, gram, num_graphs, W, N, prec == 1, gn_weight, gn_mean_scale, eps, total, mean,
+                      rstd, am, scale, stream);
+  fpool_apply_launch(K, in16, rowptr, perm, seg_graph, num_seg, N, n_rows, am, scale, gn_bias, slope,
+                     gn_weight, (const float*)x, W, pre_am, pre_scale, pre_bias, pre_slope, prec == 1,
+                     raw, arg, out, stream);
+  SPT_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int spt_fused_linear_bwd_pool_runs_f32(
+    const float* gout, const float* raw, const int32_t* arg, const int32_t* perm,
+    const int32_t* pos_seg, const int64_t* seg_graph, int64_t num_seg, int nruns,
+    const int64_t* run_p0, const int64_t* run_p1, const int32_t* run_graph, int num_graphs, int N,
+    const float* am, const float* scale, const float* bias, float slope, const float* c1,
+    const float* c2, const float* c3, const void* xprev, int K, const float* pre_am,
+    const float* pre_scale, const float* pre_bias, float pre_slope, const float* W,
+    const double* gram, float* gm, float* gx, float* gW, double* prev_total, int mode, void* ws,
+    size_t ws_bytes, spt_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  FmlpRuns rt;
+  int64_t max_rows;
+  const char* err = fmlp_make_runs(nruns, run_p0, run_p1, run_graph, num_graphs, &rt, &max_rows);
+  SPT_CHECK_ARG(!err, err ? err : "");
+  const int prec = fpool_prec_of(mode);
+  const bool x16 = mode >= 0 && (mode & SPT_FMLP_X_BF16);
+  SPT_CHECK_ARG(fpool_supported(K, N) && prec != 0 && (!x16 || prec == 1),
+                "(K, N) has no pool-fused kernel in this matrix mode");
+  SPT_CHECK_ARG(gout && raw && arg && pos_seg && am && scale && bias && c1 && c2 && c3 && xprev &&
+                pre_am && pre_scale && pre_bias && W && gram && gm && gx && gW && prev_total && ws,
+                "null pointer");
+  SPT_CHECK_ARG(num_seg >= 0 && (num_graphs == 1 || seg_graph), "bad shape");
+  SPT_CHECK_ARG(ws_bytes >= spt_fused_linear_pool_workspace_bytes(K, N), "workspace too small");
+  float* gwp = (float*)ws;
+  double* pst = (double*)((char*)ws + align_up((size_t)MAX_BWD_WAVES * N * K * 4, 256));
+  float* Mbuf = (float*)((char*)ws + align_up(spt_fused_linear_workspace_bytes(K, N), 256));
+  float* c0buf = Mbuf + (size_t)FMLP_MAX_RUNS * K * K;
+  const int per_run = fpool_bwd_launch(prec != 1, x16, gout, raw, arg, perm, pos_seg, seg_graph, num_seg,
+                                       rt, max_rows, num_graphs, K, N, am, scale, bias, slope, c1, c2, c3,
+                                       (const float*)xprev, pre_am, pre_scale, pre_bias, pre_slope, W, gm,
+                                       Mbuf, c0buf, gx, gwp, pst, MAX_BWD_WAVES, stream);
+  SPT_CHECK_ARG(per_run > 0, "no kernel for this variant");
+  reduce_tables_kernel<float><<<(N * K + 15) / 16, 1024, 0, stream>>>(gwp, per_run * rt.n, N * K, gW, 0);
+  reduce_tables_groups_kernel<double><<<dim3((2 * K + 1 + 15) / 16, num_graphs), 1024, 0, stream>>>(
+      pst, fmlp_groups(rt, num_graphs, per_run), 2 * K + 1, prev_total);
+  fpool_gw_dense_launch(K, gram, num_graphs, W, N, prec == 1, am, c2, c3, gW, stream);
+  SPT_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,1051 @@
+// The point MLP's TOP layer and the level-0 -> level-1 max-pool as one algebraic unit
+// (src/nn/mlp.py:43-56 bias-free Linear -> GraphNorm -> LeakyReLU, src/nn/stage.py:413-431,
+// src/nn/pool.py:61-82 max over the children of a superpoint): the layer's [rows, N] output is
+// consumed by nothing but the pool, so it is never written, read or recomputed.
+//
+// Three exact identities (h = y_prev W^T raw, y = leaky(sc (h - am) + bs), out[s] = max_i y_i):
+//  (i)  y is a per-channel MONOTONE function of h - non-decreasing for GraphNorm weight w_c >= 0,
+//       non-increasing for w_c < 0, and every rounding of its f32 evaluation is monotone - so
+//       max_i y_ic = y(max_i h_ic) (w_c >= 0) or y(min_i h_ic) (w_c < 0), bit for bit.  The
+//       forward pools the RAW tile out of the MFMA accumulators (the sign of w_c folded into W's
+//       row, so it is always a max) while walking the rows in the pool's CSR order, and writes
+//       one (raw value, arg row) pair per (segment, channel).  The arg is the first row
+//       attaining the raw extremum: the reference's arg (first row attaining max y) except where
+//       two rows with DIFFERENT h round to the same y - there both rows hold the maximum and the
+//       reference's own choice hangs on the last bit of its norm (tests/test_fused_pool_gpu.py).
+//       w_c == 0 (y constant: every row ties, the reference takes the first): arg = first row of
+//       the segment and its true h, restored by pool_apply_kernel.
+//  (ii) the norm's statistics come from the layer's INPUT: sum_i h_ic = w_c . sum_i y_prev_i,
+//       sum_i h_ic^2 = w_c^T G w_c with G = sum_i y_prev_i y_prev_i^T (K x K, per graph),
+//       accumulated on the matrix pipe (contraction = the tile's 16 rows) next to the product,
+//       reduced and evaluated in f64.
+//  (iii) backward: dL/dh_i = S_i + A + B o h_i with S the pool's sparse gradient (one non-zero per
+//       (segment, channel), already times c1 and the activation's slope), A = c2 am - c3,
+//       B = -c2 (the GraphNorm-backward coefficient rows), hence
+//         g(y_prev)_i = S_i W + y_prev_i (W^T diag(B) W) + A W          (two GEMMs over the tile)
+//         gW          = S^T y_prev + diag(B) W G + A (x) sum_i y_prev_i   (GEMM + closed form)
+//       - h is neither read nor rebuilt; forming the dense GraphNorm backward of a 16 x N tile
+//       becomes an `arg == row` select.
+//
+// Bytes at the S3DIS-scale scene (15 M rows, K = 64, N = 128): forward 3.84 GB (x) + 0.06 (ids) +
+// 0.44 (raw, arg) instead of 11.5 GB + 8.2 GB for layer + pool; backward 3.84 (x) + 3.84 (gx) +
+// 0.12 (ids) + 0.66 (gm, arg, raw) instead of 15.8 GB.
+#include <math.h>
+
+#include "common.hpp"
+
+namespace spt {
+namespace fpool {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+constexpr int TR = 16;           // rows per MFMA tile
+constexpr int NWF = 8;           // waves per workgroup (the W planes are shared through LDS)
+constexpr int ARG_NONE = 0x7fffffff;
+
+__device__ __forceinline__ double xg_sum_d(double v) {
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+__device__ __forceinline__ float xg_sum_f(float v) {
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+__device__ __forceinline__ void wave_sync_lds() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// four consecutive elements of a row as f32 (f32 storage: 16-byte load; bf16 storage: 8-byte
+// load widened - exact)
+template <bool B16>
+__device__ __forceinline__ float4 ld4(const float* __restrict__ base, int64_t elem) {
+  if constexpr (B16) {
+    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + elem);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
+                       __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+  } else {
+    return *reinterpret_cast<const float4*>(base + elem);
+  }
+}
+template <int NV, typename V>
+__device__ __forceinline__ void split2(const float (&x)[NV], V& hi, V& lo) {
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const __bf16 h = (__bf16)x[i];
+    hi[i] = h;
+    lo[i] = (__bf16)(x[i] - (float)h);
+  }
+}
+template <int NV, typename V>
+__device__ __forceinline__ void split3(const float (&x)[NV], V& h, V& m, V& l) {
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const __bf16 a = (__bf16)x[i];
+    const float r1 = x[i] - (float)a;              // exact
+    const __bf16 b = (__bf16)r1;
+    const float r2 = r1 - (float)b;                // exact, fits bf16
+    h[i] = a;
+    m[i] = b;
+    l[i] = (__bf16)r2;
+  }
+}
+__device__ __forceinline__ f32x4 mfma16(const bf16x4& a, const bf16x4& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a),
+                                                   __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
+}
+
+// Stage the 16 gathered rows x[rid] (rid of tile row rr in lane rr of `rid_l`) of K f32 / bf16
+// values into LDS (row stride LD floats), applying y = leaky((v - am) sc + bs) on the way in
+// (tab = am | sc | bs, K floats each; the expression of gn_apply_fwd_kernel).  Rows >= cnt
+// become 0.  All loads of the tile are issued before the first is used: one round trip.
+template <int K, int LD, bool X16>
+__device__ __forceinline__ void stage_rows(const float* __restrict__ x, int rid_l, int cnt,
+                                           const float* tab, float slope, float* lds, int lane) {
+  constexpr int CH = K / 4, NIT = TR * CH / 64;
+  static_assert(TR * CH % 64 == 0, "whole waves of chunks");
+  float4 v[NIT];
+#pragma unroll
+  for (int j = 0; j < NIT; ++j) {
+    const int q = lane + 64 * j, rr = q / CH, k = (q - rr * CH) << 2;
+    const int64_t xr = (int64_t)__shfl(rid_l, rr, 64);
+    v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (rr < cnt) v[j] = ld4<X16>(x, xr * K + k);
+  }
+#pragma unroll
+  for (int j = 0; j < NIT; ++j) {
+    const int q = lane + 64 * j, rr = q / CH, k = (q - rr * CH) << 2;
+    float4 w = v[j];
+    if (rr < cnt) {
+      const float4 a = *reinterpret_cast<const float4*>(tab + k);
+      const float4 s = *reinterpret_cast<const float4*>(tab + K + k);
+      const float4 b = *reinterpret_cast<const float4*>(tab + 2 * K + k);
+      w.x = fmaf(w.x - a.x, s.x, b.x); w.y = fmaf(w.y - a.y, s.y, b.y);
+      w.z = fmaf(w.z - a.z, s.z, b.z); w.w = fmaf(w.w - a.w, s.w, b.w);
+      w.x = w.x > 0.f ? w.x : w.x * slope; w.y = w.y > 0.f ? w.y : w.y * slope;
+      w.z = w.z > 0.f ? w.z : w.z * slope; w.w = w.w > 0.f ? w.w : w.w * slope;
+    }
+    *reinterpret_cast<float4*>(lds + rr * LD + k) = w;
+  }
+}
+
+// first position of a segment at or after p inside [r0, r1] (r0, r1 are segment boundaries)
+__device__ __forceinline__ int64_t cut_at(int64_t p, int64_t r0, int64_t r1,
+                                          const int32_t* __restrict__ pos_seg,
+                                          const int32_t* __restrict__ rowptr) {
+  if (p <= r0) return r0;
+  if (p >= r1) return r1;
+  const int s = __builtin_amdgcn_readfirstlane(pos_seg[p]);
+  const int64_t b = (int64_t)__builtin_amdgcn_readfirstlane(rowptr[s]);
+  if (b == p) return p;
+  const int64_t e = (int64_t)__builtin_amdgcn_readfirstlane(rowptr[s + 1]);
+  return e < r1 ? e : r1;
+}
+
+// ---- forward: product + Gram matrix + segment max of the raw tile ---------------------------------
+// PREC 3: f32-exact product (3-way split operands, 6 bf16 products; the default `f32` mode);
+//      2: 2-way split (3 products);  1: plain bf16 operands (the bf16 mode).
+// IN16: x holds bf16 values (bf16 activation storage).
+// One workgroup = 8 waves sharing W's bf16 planes in LDS; a wave owns a contiguous range of CSR
+// positions cut at segment boundaries (no segment is shared between waves, nothing is merged).
+// Multi-graph launches: blockIdx.y = run (a graph's contiguous CSR positions).
+template <int K, int N, int PREC, bool IN16>
+__global__ __launch_bounds__(NWF * 64, 2) void fwd_pool_kernel(
+    const float* __restrict__ x, const int32_t* __restrict__ perm,
+    const int32_t* __restrict__ pos_seg, const int32_t* __restrict__ rowptr,
+    const float* __restrict__ W, const float* __restrict__ gnw, const float* __restrict__ pam,
+    const float* __restrict__ psc, const float* __restrict__ pbs, float pslope,
+    float* __restrict__ raw, int32_t* __restrict__ arg, double* __restrict__ partial, FmlpRuns rt) {
+  constexpr int KS = K / 32, KB = K / 16, NBK = N / 16, LDA = K + 4, LDW = K + 8;
+  constexpr int NPL = PREC == 3 ? 3 : (PREC == 2 ? 2 : 1);
+  constexpr int NGB = KB * (KB + 1) / 2;                 // upper-triangular 16 x 16 blocks of G
+  constexpr int GLEN = K * K + K + 1;
+  static_assert(K % 32 == 0 && N % 16 == 0, "shape");
+  __shared__ __attribute__((aligned(16))) float a_lds[NWF][TR * LDA];
+  __shared__ __attribute__((aligned(16))) float tab[3 * K];
+  __shared__ __attribute__((aligned(16))) float sgn_l[N];
+  __shared__ __attribute__((aligned(16))) __bf16 wpl[NPL][N * LDW];
+  __shared__ double gred[K * K + K];
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, c = lane & 15;
+  const int run = blockIdx.y, gph = rt.g[run];
+  const int64_t r0 = rt.r0[run], r1 = rt.r1[run];
+  pam += (size_t)gph * K;
+  psc += (size_t)gph * K;
+  partial += ((size_t)run * gridDim.x + blockIdx.x) * GLEN;
+  float* al = a_lds[wid];
+  for (int i = threadIdx.x; i < K; i += NWF * 64) {
+    tab[i] = pam[i];
+    tab[K + i] = psc[i];
+    tab[2 * K + i] = pbs[i];
+  }
+  for (int i = threadIdx.x; i < N; i += NWF * 64) sgn_l[i] = gnw[i] < 0.f ? -1.f : 1.f;
+  // W with the sign of the norm's weight folded into its rows (h' = sgn h: the pool is a max for
+  // every channel; the Gram statistics do not see the sign), split into bf16 planes
+  for (int i = threadIdx.x; i < N * K; i += NWF * 64) {
+    const int n = i / K, k = i - n * K;
+    const float w = gnw[n] < 0.f ? -W[i] : W[i];
+    if constexpr (PREC == 3) {
+      const float w1[1] = {w};
+      __bf16 a[1], b[1], cc[1];
+      split3<1>(w1, a, b, cc);
+      wpl[0][n * LDW + k] = a[0];
+      wpl[1][n * LDW + k] = b[0];
+      wpl[2][n * LDW + k] = cc[0];
+    } else if constexpr (PREC == 2) {
+      const __bf16 hh = (__bf16)w;
+      wpl[0][n * LDW + k] = hh;
+      wpl[1][n * LDW + k] = (__bf16)(w - (float)hh);
+    } else {
+      wpl[0][n * LDW + k] = (__bf16)w;
+    }
+  }
+  __syncthreads();
+
+  f32x4 GA[NGB];
+#pragma unroll
+  for (int i = 0; i < NGB; ++i) GA[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float sy[KB];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) sy[kb] = 0.f;
+  // the wave's partial maximum of the open segment: its own rows (4 g + r of every tile) only;
+  // the four lane groups meet when the segment closes
+  float pm[NBK];
+  int pa[NBK];
+#pragma unroll
+  for (int nb = 0; nb < NBK; ++nb) {
+    pm[nb] = -INFINITY;
+    pa[nb] = ARG_NONE;
+  }
+  int cur_seg = -1;
+  auto flush = [&](int seg) {
+#pragma unroll
+    for (int nb = 0; nb < NBK; ++nb) {
+      float m = pm[nb];
+      int a = pa[nb];
+#pragma unroll
+      for (int off = 16; off <= 32; off <<= 1) {
+        const float om = __shfl_xor(m, off, 64);
+        const int oa = __shfl_xor(a, off, 64);
+        const bool t = (om > m) || (om == m && oa < a);      // segcsr's combine rule
+        m = t ? om : m;
+        a = t ? oa : a;
+      }
+      if ((nb & 3) == g) {                                   // the four groups share the stores
+        const size_t o = (size_t)seg * N + 16 * nb + c;
+        raw[o] = m * sgn_l[16 * nb + c];
+        arg[o] = a;
+      }
+      pm[nb] = -INFINITY;
+      pa[nb] = ARG_NONE;
+    }
+  };
+
+  const int64_t nw = (int64_t)gridDim.x * NWF, w = (int64_t)blockIdx.x * NWF + wid;
+  const int64_t per = (((r1 - r0 + nw - 1) / nw) + TR - 1) / TR * TR;
+  const int64_t pa0 = cut_at(r0 + w * per, r0, r1, pos_seg, rowptr);
+  const int64_t pb0 = (w == nw - 1) ? r1 : cut_at(r0 + (w + 1) * per, r0, r1, pos_seg, rowptr);
+  auto ids_of = [&](int64_t p, int& rid, int& sg) {
+    rid = 0;
+    sg = -1;
+    if (lane < TR && p + lane < pb0) {
+      rid = perm ? perm[p + lane] : (int)(p + lane);
+      sg = pos_seg[p + lane];
+    }
+  };
+  int rid_l, seg_l, rid_n, seg_n;
+  ids_of(pa0, rid_l, seg_l);
+  for (int64_t p = pa0; p < pb0; p += TR) {
+    const int cnt = (int)((pb0 - p) < TR ? (pb0 - p) : TR);
+    ids_of(p + TR, rid_n, seg_n);
+    wave_sync_lds();
+    stage_rows<K, LDA, IN16>(x, rid_l, cnt, tab, pslope, al, lane);
+    wave_sync_lds();
+    // ---- h' = y_prev W'^T ------------------------------------------------------------------
+    f32x4 C[NBK];
+#pragma unroll
+    for (int nb = 0; nb < NBK; ++nb) C[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const float4 a0 = *reinterpret_cast<const float4*>(al + c * LDA + 32 * ks + 8 * g);
+      const float4 a1 = *reinterpret_cast<const float4*>(al + c * LDA + 32 * ks + 8 * g + 4);
+      const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+      bf16x8 x1, x2, x3;
+      if constexpr (PREC == 3) {
+        split3<8>(av, x1, x2, x3);
+      } else if constexpr (PREC == 2) {
+        split2<8>(av, x1, x2);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x1[i] = (__bf16)av[i];
+      }
+#pragma unroll
+      for (int nb = 0; nb < NBK; ++nb) {
+        const int wo = (16 * nb + c) * LDW + 32 * ks + 8 * g;
+        const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(&wpl[0][wo]);
+        f32x4 acc = C[nb];
+        if constexpr (PREC == 3) {
+          const bf16x8 w2 = *reinterpret_cast<const bf16x8*>(&wpl[1][wo]);
+          const bf16x8 w3 = *reinterpret_cast<const bf16x8*>(&wpl[NPL - 1][wo]);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x3, w1, acc, 0, 0, 0);   // smallest terms first
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1, w3, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x2, w2, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x2, w1, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1, w2, acc, 0, 0, 0);
+        } else if constexpr (PREC == 2) {
+          const bf16x8 w2 = *reinterpret_cast<const bf16x8*>(&wpl[NPL - 1][wo]);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x2, w1, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1, w2, acc, 0, 0, 0);
+        }
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1, w1, acc, 0, 0, 0);
+        C[nb] = acc;
+      }
+    }
+    // ---- G += y_prev^T y_prev (contraction = the tile's rows: the 4 rows a lane group holds of
+    // one column are one packed operand), column sums of y_prev ---------------------------------
+    {
+      bf16x4 Yh[KB], Yl[KB];
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        float yv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) yv[r] = al[(4 * g + r) * LDA + 16 * kb + c];
+        if constexpr (PREC == 1) {
+          // the product above saw bf16(y): the statistics are those of what it computed
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            Yh[kb][r] = (__bf16)yv[r];
+            yv[r] = (float)Yh[kb][r];
+          }
+        } else {
+          split2<4>(yv, Yh[kb], Yl[kb]);
+        }
+        sy[kb] += (yv[0] + yv[1]) + (yv[2] + yv[3]);
+      }
+      int gi = 0;
+#pragma unroll
+      for (int mi = 0; mi < KB; ++mi)
+#pragma unroll
+        for (int ni = mi; ni < KB; ++ni) {
+          f32x4 acc = GA[gi];
+          if constexpr (PREC != 1) {
+            acc = mfma16(Yl[mi], Yh[ni], acc);
+            acc = mfma16(Yh[mi], Yl[ni], acc);
+          }
+          GA[gi] = mfma16(Yh[mi], Yh[ni], acc);
+          ++gi;
+        }
+    }
+    // ---- segment max of the raw tile ---------------------------------------------------------
+    {
+      int rid4[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) rid4[r] = __shfl(rid_l, 4 * g + r, 64);
+      int row = 0;
+      while (row < cnt) {
+        const int s = __builtin_amdgcn_readlane(seg_l, row);
+        const uint64_t diff = __ballot(lane < cnt && lane > row && seg_l != s);
+        const int e = diff ? (int)__builtin_ctzll(diff) : cnt;   // rows [row, e) belong to s
+        if (s != cur_seg) {
+          if (cur_seg >= 0) flush(cur_seg);
+          cur_seg = s;
+        }
+        if (row == 0 && e == TR) {                                // the whole tile: no masks
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int nb = 0; nb < NBK; ++nb) {
+              const float v = C[nb][r];
+              const bool win = v > pm[nb];
+              pm[nb] = win ? v : pm[nb];
+              pa[nb] = win ? rid4[r] : pa[nb];
+            }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int rr = 4 * g + r;
+            const bool in = rr >= row && rr < e;
+#pragma unroll
+            for (int nb = 0; nb < NBK; ++nb) {
+              const float v = in ? C[nb][r] : -INFINITY;
+              const bool win = v > pm[nb];
+              pm[nb] = win ? v : pm[nb];
+              pa[nb] = win ? rid4[r] : pa[nb];
+            }
+          }
+        }
+        row = e;
+      }
+    }
+    rid_l = rid_n;
+    seg_l = seg_n;
+  }
+  if (cur_seg >= 0) flush(cur_seg);
+
+  // ---- the workgroup's Gram partial: waves in a fixed order, f64 -----------------------------
+  for (int i = threadIdx.x; i < K * K + K; i += NWF * 64) gred[i] = 0.0;
+  __syncthreads();
+  for (int ww = 0; ww < NWF; ++ww) {
+    if (wid == ww) {
+      int gi = 0;
+#pragma unroll
+      for (int mi = 0; mi < KB; ++mi)
+#pragma unroll
+        for (int ni = mi; ni < KB; ++ni) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            gred[(16 * mi + 4 * g + r) * K + 16 * ni + c] += (double)GA[gi][r];
+          ++gi;
+        }
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        const double t = xg_sum_d((double)sy[kb]);
+        if (g == 0) gred[K * K + 16 * kb + c] += t;
+      }
+    }
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < K * K; i += NWF * 64) {
+    const int rr = i / K, cc = i - rr * K;
+    partial[i] = (rr / 16 <= cc / 16) ? gred[i] : gred[cc * K + rr];   // lower blocks: the mirror
+  }
+  for (int i = threadIdx.x; i < K; i += NWF * 64) partial[K * K + i] = gred[K * K + i];
+  if (threadIdx.x == 0) partial[K * K + K] = (blockIdx.x == 0) ? (double)(r1 - r0) : 0.0;
+}
+
+// ---- statistics and coefficient rows of the norm from the Gram totals ----------------------------
+// gram [B][K K + K + 1] (G | column sums | row count); one block per graph, one thread per
+// channel.  Same formulas and roundings as gn_fwd_tables_kernel (graphnorm.hip).
+// BFW: the product ran on bf16(W) (the bf16 mode) - the statistics are those of what it computed.
+template <int K>
+__global__ __launch_bounds__(256) void gram_tables_kernel(
+    const double* __restrict__ gram, const float* __restrict__ W, int N, int bfw,
+    const float* __restrict__ weight, const float* __restrict__ mean_scale, float eps,
+    double* __restrict__ total, float* __restrict__ mean, float* __restrict__ rstd,
+    float* __restrict__ am, float* __restrict__ scale) {
+  constexpr int GLEN = K * K + K + 1;
+  __shared__ double gl[K * K + K];
+  extern __shared__ float wl[];                          // W [N, K] as the product saw it
+  const int b = blockIdx.x;
+  const double* gr = gram + (size_t)b * GLEN;
+  for (int i = threadIdx.x; i < K * K + K; i += blockDim.x) gl[i] = gr[i];
+  for (int i = threadIdx.x; i < N * K; i += blockDim.x) {
+    const float w = W[i];
+    wl[i] = bfw ? (float)(__bf16)w : w;
+  }
+  __syncthreads();
+  double n = gr[K * K + K];
+  const double nraw = n;
+  if (n < 1.0) n = 1.0;
+  for (int c = threadIdx.x; c < N; c += blockDim.x) {
+    const float* wv = wl + (size_t)c * K;
+    double s1 = 0.0, s2 = 0.0;
+    for (int j = 0; j < K; ++j) {
+      double t = 0.0;
+#pragma unroll 8
+      for (int k = 0; k < K; ++k) t += gl[j * K + k] * (double)wv[k];
+      s2 += (double)wv[j] * t;
+      s1 += (double)wv[j] * gl[K * K + j];
+    }
+    if (s2 < 0.0) s2 = 0.0;
+    if (total) {
+      double* tr = total + (size_t)b * (2 * N + 1);
+      tr[c] = s1;
+      tr[N + c] = s2;
+      if (c == 0) tr[2 * N] = nraw;
+    }
+    const double mu = s1 / n;
+    const double a = (double)mean_scale[c];
+    double var = s2 / n - (2.0 * a - a * a) * mu * mu;
+    if (var < 0.0) var = 0.0;
+    const double rs = 1.0 / sqrt(var + (double)eps);
+    const float mu32 = (float)mu, rs32 = (float)rs;
+    const int t = b * N + c;
+    mean[t] = mu32;
+    rstd[t] = rs32;
+    am[t] = (float)(a * (double)mu32);
+    scale[t] = (float)((double)weight[c] * (double)rs32);
+  }
+}
+
+// ---- out = y(raw); empty segments; channels whose norm weight is exactly 0 ------------------------
+// one thread per (segment, channel).  w_c == 0: y is the constant leaky(bias_c) - every row ties and
+// the reference's arg is the segment's first row; its raw value (the norm's weight gradient needs
+// the true h of the arg row) is rebuilt from that row of x.
+template <int K, bool IN16>
+__global__ __launch_bounds__(256) void pool_apply_kernel(
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ perm,
+    const int64_t* __restrict__ seg_graph, int64_t num_seg, int N, int64_t n_rows,
+    const float* __restrict__ am, const float* __restrict__ sc, const float* __restrict__ bs,
+    float slope, const float* __restrict__ gnw, const float* __restrict__ x,
+    const float* __restrict__ W, const float* __restrict__ pam, const float* __restrict__ psc,
+    const float* __restrict__ pbs, float pslope, int bfw, float* __restrict__ raw,
+    int32_t* __restrict__ arg, float* __restrict__ out) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= num_seg * N) return;
+  const int64_t s = t / N;
+  const int c = (int)(t - s * N);
+  const int a0 = rowptr[s], a1 = rowptr[s + 1];
+  if (a1 <= a0) {                                        // empty: segcsr's convention
+    out[t] = 0.f;
+    raw[t] = 0.f;
+    arg[t] = (int32_t)n_rows;
+    return;
+  }
+  const int64_t gph = seg_graph ? seg_graph[s] : 0;
+  float h = raw[t];
+  if (gnw[c] == 0.f) {
+    const int row = perm ? perm[a0] : a0;
+    double acc = 0.0;
+    for (int k = 0; k < K; ++k) {
+      float v = IN16 ? __uint_as_float((unsigned)reinterpret_cast<const uint16_t*>(x)[(int64_t)row * K + k] << 16)
+                     : x[(int64_t)row * K + k];
+      v = fmaf(v - pam[gph * K + k], psc[gph * K + k], pbs[k]);
+      v = v > 0.f ? v : v * pslope;
+      float w = W[(size_t)c * K + k];
+      if (bfw) {
+        w = (float)(__bf16)w;
+        v = (float)(__bf16)v;
+      }
+      acc += (double)v * (double)w;
+    }
+    h = (float)acc;
+    raw[t] = h;
+    arg[t] = row;
+  }
+  float y = fmaf(h - am[gph * N + c], sc[gph * N + c], bs[c]);   // gn_apply_fwd_kernel's expression
+  y = y > 0.f ? y : y * slope;
+  out[t] = y;
+}
+
+// ---- backward, preparation ------------------------------------------------------------------------
+// gm[s, c] = c1[g, c] gout[s, c] leaky'(y(raw[s, c])): the pool's gradient as the GraphNorm
+// backward's c1 g term, one non-zero per (segment, channel) at row arg[s, c].
+__global__ __launch_bounds__(256) void pool_bwd_gm_kernel(
+    const float* __restrict__ gout, const float* __restrict__ raw,
+    const int64_t* __restrict__ seg_graph, int64_t num_seg, int N, const float* __restrict__ am,
+    const float* __restrict__ sc, const float* __restrict__ bs, float slope,
+    const float* __restrict__ c1, float* __restrict__ gm) {
+  const int64_t t4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (t4 >= num_seg * N) return;
+  const int64_t s = t4 / N;
+  const int c = (int)(t4 - s * N);
+  const int64_t gph = seg_graph ? seg_graph[s] : 0;
+  const float4 go = *reinterpret_cast<const float4*>(gout + t4);
+  const float4 hv = *reinterpret_cast<const float4*>(raw + t4);
+  const float4 a = *reinterpret_cast<const float4*>(am + gph * N + c);
+  const float4 sv = *reinterpret_cast<const float4*>(sc + gph * N + c);
+  const float4 b = *reinterpret_cast<const float4*>(bs + c);
+  const float4 k1 = *reinterpret_cast<const float4*>(c1 + gph * N + c);
+  const float gg[4] = {go.x, go.y, go.z, go.w}, hh[4] = {hv.x, hv.y, hv.z, hv.w};
+  const float aa[4] = {a.x, a.y, a.z, a.w}, ss[4] = {sv.x, sv.y, sv.z, sv.w};
+  const float bb[4] = {b.x, b.y, b.z, b.w}, q1[4] = {k1.x, k1.y, k1.z, k1.w};
+  float o[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float g_ = gg[e];
+    if (slope != 1.f) {
+      const float y = fmaf(hh[e] - aa[e], ss[e], bb[e]);
+      g_ = (y > 0.f) ? g_ : g_ * slope;
+    }
+    o[e] = q1[e] * g_;
+  }
+  *reinterpret_cast<float4*>(gm + t4) = make_float4(o[0], o[1], o[2], o[3]);
+}
+
+// per graph: Bc = -c2, Ac = c2 am - c3;  M = W^T diag(Bc) W  [K, K] (symmetric),  c0 = Ac W  [K]
+template <int K>
+__global__ __launch_bounds__(256) void pool_bwd_coef_kernel(
+    const float* __restrict__ W, int N, const float* __restrict__ am, const float* __restrict__ c2,
+    const float* __restrict__ c3, float* __restrict__ M, float* __restrict__ c0) {
+  const int b = blockIdx.x;
+  extern __shared__ float sm[];                          // Bc [N] | Ac [N]
+  float* Bc = sm;
+  float* Ac = sm + N;
+  for (int i = threadIdx.x; i < N; i += blockDim.x) {
+    const float k2 = c2[b * N + i];
+    Bc[i] = -k2;
+    Ac[i] = fmaf(k2, am[b * N + i], -c3[b * N + i]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < K * K + K; i += blockDim.x) {
+    double acc = 0.0;
+    if (i < K * K) {
+      const int j = i / K, k = i - j * K;
+      for (int c = 0; c < N; ++c)
+        acc += (double)W[(size_t)c * K + j] * (double)Bc[c] * (double)W[(size_t)c * K + k];
+      M[(size_t)b * K * K + i] = (float)acc;
+    } else {
+      const int k = i - K * K;
+      for (int c = 0; c < N; ++c) acc += (double)Ac[c] * (double)W[(size_t)c * K + k];
+      c0[(size_t)b * K + k] = (float)acc;
+    }
+  }
+}
+
+// gW[c, k] += sum_b ( Bc[b, c] sum_j W[c, j] G[b][j, k] + Ac[b, c] sy[b][k] ): the dense part of
+// the GraphNorm backward in closed form (f64), added to the sparse part the main kernel summed.
+// BFW: the operands the forward saw (bf16 mode).
+template <int K>
+__global__ __launch_bounds__(256) void pool_bwd_gw_dense_kernel(
+    const double* __restrict__ gram, int B, const float* __restrict__ W, int N, int bfw,
+    const float* __restrict__ am, const float* __restrict__ c2, const float* __restrict__ c3,
+    float* __restrict__ gW) {
+  constexpr int GLEN = K * K + K + 1;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= N * K) return;
+  const int c = t / K, k = t - c * K;
+  double acc = 0.0;
+  for (int b = 0; b < B; ++b) {
+    const double* gr = gram + (size_t)b * GLEN;
+    const double k2 = (double)c2[b * N + c];
+    const double Ac = (double)fmaf(c2[b * N + c], am[b * N + c], -c3[b * N + c]);
+    double t1 = 0.0;
+    for (int j = 0; j < K; ++j) {
+      float w = W[(size_t)c * K + j];
+      if (bfw) w = (float)(__bf16)w;
+      t1 += (double)w * gr[j * K + k];
+    }
+    acc += -k2 * t1 + Ac * gr[K * K + k];
+  }
+  gW[t] = (float)((double)gW[t] + acc);
+}
+
+// ---- backward, main kernel ------------------------------------------------------------------------
+// Tiles walk the rows in the pool's CSR order.  S tile (f32, LDS) = gm where arg == row else 0;
+// gW += S^T y_prev (16x16x16, contraction = the tile's rows), gy = S W + y_prev M + c0
+// (16x16x32, W^T and M as split-bf16 rows in LDS), then - as every fused layer's backward - the
+// rows leave as the gradient of the previous layer's normalised output and the two sums its
+// GraphNorm backward needs (sum g', sum g' o') fall out of the same registers.
+// LO: split operands (hi + lo, 3 products);  X16: xprev holds bf16 values.
+template <int K, int N, bool LO, bool X16, int NW>
+__global__ __launch_bounds__(NW * 64, NW / 4) void bwd_pool_kernel(
+    const float* __restrict__ gm, const int32_t* __restrict__ arg,
+    const int32_t* __restrict__ perm, const int32_t* __restrict__ pos_seg,
+    const float* __restrict__ xprev, const float* __restrict__ pam,
+    const float* __restrict__ psc, const float* __restrict__ pbs, float pslope,
+    const float* __restrict__ W, const float* __restrict__ Mg, const float* __restrict__ c0g,
+    float* __restrict__ gx, float* __restrict__ gw_partial, double* __restrict__ pstat_partial,
+    FmlpRuns rt) {
+  constexpr int KB = K / 16, NBK = N / 16, NS = N / 32, KS = K / 32;
+  constexpr int LDG = N + 4, LDX = K + 4, LDT = N + 8, LDM = K + 8;
+  static_assert(K % 32 == 0 && N % 32 == 0, "shape");
+  __shared__ __attribute__((aligned(16))) float g_lds[NW][TR * LDG];   // S tile
+  __shared__ __attribute__((aligned(16))) float x_lds[NW][TR * LDX];   // RAW xprev tile
+  __shared__ __attribute__((aligned(16))) __bf16 wt_hi[K * LDT];       // wt[k][n] = W[n][k]
+  __shared__ __attribute__((aligned(16))) __bf16 wt_lo[LO ? K * LDT : 8];
+  __shared__ __attribute__((aligned(16))) __bf16 mt_hi[K * LDM];       // mt[k][j] = M[j][k] (= M[k][j])
+  __shared__ __attribute__((aligned(16))) __bf16 mt_lo[LO ? K * LDM : 8];
+  __shared__ __attribute__((aligned(16))) float pt[3 * K];             // previous norm: am | sc | bs
+  __shared__ __attribute__((aligned(16))) float c0l[K];
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, c = lane & 15;
+  const int run = blockIdx.y, gph = rt.g[run];
+  const int64_t r0 = rt.r0[run], r1 = rt.r1[run];
+  pam += (size_t)gph * K;
+  psc += (size_t)gph * K;
+  Mg += (size_t)gph * K * K;
+  c0g += (size_t)gph * K;
+  gw_partial += (size_t)run * gridDim.x * NW * N * K;
+  pstat_partial += (size_t)run * gridDim.x * NW * (2 * K + 1);
+  float* gl = g_lds[wid];
+  float* xl = x_lds[wid];
+  for (int i = threadIdx.x; i < K * N; i += NW * 64) {
+    const int k = i / N, n = i - k * N;
+    const float w = W[(size_t)n * K + k];
+    const __bf16 hh = (__bf16)w;
+    wt_hi[k * LDT + n] = hh;
+    if constexpr (LO) wt_lo[k * LDT + n] = (__bf16)(w - (float)hh);
+  }
+  for (int i = threadIdx.x; i < K * K; i += NW * 64) {
+    const int k = i / K, j = i - k * K;
+    const float m = Mg[(size_t)j * K + k];
+    const __bf16 hh = (__bf16)m;
+    mt_hi[k * LDM + j] = hh;
+    if constexpr (LO) mt_lo[k * LDM + j] = (__bf16)(m - (float)hh);
+  }
+  for (int i = threadIdx.x; i < K; i += NW * 64) {
+    pt[i] = pam[i];
+    pt[K + i] = psc[i];
+    pt[2 * K + i] = pbs[i];
+    c0l[i] = c0g[i];
+  }
+  __syncthreads();
+
+  f32x4 C3[NBK][KB];       // C3[nb][kb][r] = gW[16 nb + 4 g + r][16 kb + c]
+#pragma unroll
+  for (int nb = 0; nb < NBK; ++nb)
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) C3[nb][kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  double p1[KB], p2[KB];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) p1[kb] = p2[kb] = 0.0;
+
+  const int64_t ntiles = (r1 - r0 + TR - 1) / TR;
+  const int64_t wave = (int64_t)blockIdx.x * NW + wid;
+  const int64_t nwaves = (int64_t)gridDim.x * NW;
+  int rid_n = 0, seg_n = 0;
+  auto load_ids = [&](int64_t t) {
+    rid_n = seg_n = 0;
+    const int64_t rowf = r0 + t * TR;
+    if (t < ntiles && rowf + lane < r1 && lane < TR) {
+      rid_n = perm ? perm[rowf + lane] : (int)(rowf + lane);
+      seg_n = pos_seg[rowf + lane];
+    }
+  };
+  load_ids(wave);
+  int rid_l = rid_n, seg_l = seg_n;
+  load_ids(wave + nwaves);
+  for (int64_t t = wave; t < ntiles; t += nwaves) {
+    const int64_t row0 = r0 + t * TR;
+    const int cnt = (int)((r1 - row0) < TR ? (r1 - row0) : TR);
+    wave_sync_lds();
+    // ---- S tile: (gm, arg) rows of the segments this tile touches, out of L1 / L2 --------------
+    {
+      constexpr int CH = N / 4, NIT = TR * CH / 64, GS = NIT < 4 ? NIT : 4;
+      static_assert(TR * CH % 64 == 0 && NIT % GS == 0, "whole groups of chunks");
+#pragma unroll 1
+      for (int i0 = 0; i0 < NIT; i0 += GS) {
+        float4 gv[GS];
+        int4 av[GS];
+        int ridv[GS];
+#pragma unroll
+        for (int j = 0; j < GS; ++j) {
+          const int q = lane + 64 * (i0 + j), rr = q / CH, n = (q - rr * CH) << 2;
+          ridv[j] = __shfl(rid_l, rr, 64);
+          const int64_t sg = (int64_t)__shfl(seg_l, rr, 64);
+          gv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+          av[j] = make_int4(-1, -1, -1, -1);
+          if (rr < cnt) {
+            av[j] = *reinterpret_cast<const int4*>(arg + sg * N + n);
+            gv[j] = *reinterpret_cast<const float4*>(gm + sg * N + n);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < GS; ++j) {
+          const int q = lane + 64 * (i0 + j), rr = q / CH, n = (q - rr * CH) << 2;
+          const int rid = ridv[j];
+          const float4 v = make_float4(av[j].x == rid ? gv[j].x : 0.f, av[j].y == rid ? gv[j].y : 0.f,
+                                       av[j].z == rid ? gv[j].z : 0.f, av[j].w == rid ? gv[j].w : 0.f);
+          *reinterpret_cast<float4*>(gl + rr * LDG + n) = v;
+        }
+      }
+    }
+    // ---- RAW xprev tile (gathered rows; rows >= cnt zero) ---------------------------------------
+    {
+      constexpr int CHX = K / 4, NITX = TR * CHX / 64;
+      float4 v[NITX];
+#pragma unroll
+      for (int j = 0; j < NITX; ++j) {
+        const int q = lane + 64 * j, rr = q / CHX, k = (q - rr * CHX) << 2;
+        const int64_t xr = (int64_t)__shfl(rid_l, rr, 64);
+        v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rr < cnt) v[j] = ld4<X16>(xprev, xr * K + k);
+      }
+#pragma unroll
+      for (int j = 0; j < NITX; ++j) {
+        const int q = lane + 64 * j, rr = q / CHX, k = (q - rr * CHX) << 2;
+        *reinterpret_cast<float4*>(xl + rr * LDX + k) = v[j];
+      }
+    }
+    const int rid_cur = rid_l;                 // the gx scatter below needs this tile's row ids
+    rid_l = rid_n;
+    seg_l = seg_n;
+    load_ids(t + 2 * nwaves);
+    wave_sync_lds();
+    // y_prev of one raw value (rows >= cnt: 0)
+    auto ynorm = [&](float v, int k, bool ok) {
+      v = fmaf(v - pt[k], pt[K + k], pt[2 * K + k]);
+      v = (v > 0.f) ? v : v * pslope;
+      return ok ? v : 0.f;
+    };
+    // ---- gW += S^T y_prev ----------------------------------------------------------------------
+    {
+      bf16x4 Xh[KB], Xl[KB];
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        const int k = 16 * kb + c;
+        float xv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xv[r] = ynorm(xl[(4 * g + r) * LDX + k], k, 4 * g + r < cnt);
+        if constexpr (LO) {
+          split2<4>(xv, Xh[kb], Xl[kb]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Xh[kb][r] = (__bf16)xv[r];
+        }
+      }
+#pragma unroll
+      for (int nb = 0; nb < NBK; ++nb) {
+        float sv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sv[r] = gl[(4 * g + r) * LDG + 16 * nb + c];
+        bf16x4 sh, sl;
+        if constexpr (LO) {
+          split2<4>(sv, sh, sl);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sh[r] = (__bf16)sv[r];
+        }
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+          f32x4 acc = C3[nb][kb];
+          if constexpr (LO) {
+            acc = mfma16(sl, Xh[kb], acc);
+            acc = mfma16(sh, Xl[kb], acc);
+          }
+          C3[nb][kb] = mfma16(sh, Xh[kb], acc);
+        }
+      }
+    }
+    // ---- gy = c0 + S W + y_prev M (+ statistics for the previous GraphNorm's backward) ----------
+    {
+      f32x4 CX[KB];
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        const float z = c0l[16 * kb + c];
+        CX[kb] = (f32x4){z, z, z, z};
+      }
+#pragma unroll
+      for (int sg = 0; sg < NS; ++sg) {
+        const float4 a0 = *reinterpret_cast<const float4*>(gl + c * LDG + 32 * sg + 8 * g);
+        const float4 a1 = *reinterpret_cast<const float4*>(gl + c * LDG + 32 * sg + 8 * g + 4);
+        const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        bf16x8 ah, alo;
+        if constexpr (LO) {
+          split2<8>(av, ah, alo);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) ah[i] = (__bf16)av[i];
+        }
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+          const bf16x8 bh = *reinterpret_cast<const bf16x8*>(wt_hi + (16 * kb + c) * LDT + 32 * sg + 8 * g);
+          f32x4 acc = CX[kb];
+          if constexpr (LO) {
+            const bf16x8 bl = *reinterpret_cast<const bf16x8*>(wt_lo + (16 * kb + c) * LDT + 32 * sg + 8 * g);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo, bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc, 0, 0, 0);
+          }
+          CX[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const float4 a0 = *reinterpret_cast<const float4*>(xl + c * LDX + 32 * ks + 8 * g);
+        const float4 a1 = *reinterpret_cast<const float4*>(xl + c * LDX + 32 * ks + 8 * g + 4);
+        const float rv[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        float av[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) av[i] = ynorm(rv[i], 32 * ks + 8 * g + i, c < cnt);
+        bf16x8 ah, alo;
+        if constexpr (LO) {
+          split2<8>(av, ah, alo);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) ah[i] = (__bf16)av[i];
+        }
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+          const bf16x8 bh = *reinterpret_cast<const bf16x8*>(mt_hi + (16 * kb + c) * LDM + 32 * ks + 8 * g);
+          f32x4 acc = CX[kb];
+          if constexpr (LO) {
+            const bf16x8 bl = *reinterpret_cast<const bf16x8*>(mt_lo + (16 * kb + c) * LDM + 32 * ks + 8 * g);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo, bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc, 0, 0, 0);
+          }
+          CX[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rr = 4 * g + r;
+        const int64_t orow = (int64_t)__shfl(rid_cur, rr, 64);
+        if (rr < cnt) {
+#pragma unroll
+          for (int kb = 0; kb < KB; ++kb) {
+            const int k = 16 * kb + c;
+            const float v = CX[kb][r];
+            gx[orow * K + k] = v;
+            const float o = xl[rr * LDX + k] - pt[k];
+            float gg = v;
+            if (pslope != 1.f) {
+              const float y = fmaf(o, pt[K + k], pt[2 * K + k]);
+              gg = (y > 0.f) ? gg : gg * pslope;
+            }
+            p1[kb] += (double)gg;
+            p2[kb] += (double)gg * (double)o;
+          }
+        }
+      }
+    }
+  }
+  float* gwp = gw_partial + (size_t)wave * N * K;
+#pragma unroll
+  for (int nb = 0; nb < NBK; ++nb)
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        gwp[(size_t)(16 * nb + 4 * g + r) * K + 16 * kb + c] = C3[nb][kb][r];
+  double* pp = pstat_partial + (size_t)wave * (2 * K + 1);
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) {
+    const double a = xg_sum_d(p1[kb]), b = xg_sum_d(p2[kb]);
+    const int k = 16 * kb + c;
+    if (g == 0) {
+      pp[k] = a;
+      pp[K + k] = b;
+    }
+  }
+  if (lane == 0) pp[2 * K] = (wave == 0) ? (double)(r1 - r0) : 0.0;
+}
+
+}  // namespace fpool
+
+// ---- launchers (called from fused_mlp.hip's C entry points) -------------------------------------
+// shapes built: the top layers that sit in front of a max-pool (64 -> 128 semantic, 64 -> 64
+// panoptic, 32 -> 64 small MLPs)
+#define SPT_FPOOL_SHAPES(X) X(64, 128) X(64, 64) X(32, 64)
+
+bool fpool_supported(int K, int N) {
+#define X(k, n) if (K == k && N == n) return true;
+  SPT_FPOOL_SHAPES(X)
+#undef X
+  return false;
+}
+int fpool_gram_len(int K) { return K * K + K + 1; }
+
+// workgroups of the forward per run (its partial Gram records)
+int fpool_fwd_blocks(int64_t max_rows, int nruns) {
+  int64_t blocks = (max_rows + fpool::TR * fpool::NWF * 4 - 1) / (fpool::TR * fpool::NWF * 4);
+  int64_t cap = 256 / nruns;
+  if (cap < 1) cap = 1;
+  if (blocks > cap) blocks = cap;
+  return (int)(blocks < 1 ? 1 : blocks);
+}
+
+// prec: 3 = f32-exact (3-way split), 2 = 2-way split, 1 = plain bf16.  Returns blocks per run.
+int fpool_fwd_launch(int prec, bool in16, const float* x, const int32_t* perm, const int32_t* pos_seg,
+                     const int32_t* rowptr, const FmlpRuns& rt, int64_t max_rows, int K, int N,
+                     const float* W, const float* gnw, const float* pam, const float* psc,
+                     const float* pbs, float pslope, float* raw, int32_t* arg, double* partial,
+                     hipStream_t stream) {
+  const int gx_ = fpool_fwd_blocks(max_rows, rt.n);
+  const dim3 grid((unsigned)gx_, (unsigned)rt.n);
+#define X(k, n)                                                                                   \
+  if (K == k && N == n) {                                                                         \
+    if (prec == 3 && !in16)                                                                       \
+      fpool::fwd_pool_kernel<k, n, 3, false><<<grid, fpool::NWF * 64, 0, stream>>>(               \
+          x, perm, pos_seg, rowptr, W, gnw, pam, psc, pbs, pslope, raw, arg, partial, rt);        \
+    else if (prec == 2 && !in16)                                                                  \
+      fpool::fwd_pool_kernel<k, n, 2, false><<<grid, fpool::NWF * 64, 0, stream>>>(               \
+          x, perm, pos_seg, rowptr, W, gnw, pam, psc, pbs, pslope, raw, arg, partial, rt);        \
+    else if (prec == 1 && !in16)                                                                  \
+      fpool::fwd_pool_kernel<k, n, 1, false><<<grid, fpool::NWF * 64, 0, stream>>>(               \
+          x, perm, pos_seg, rowptr, W, gnw, pam, psc, pbs, pslope, raw, arg, partial, rt);        \
+    else if (prec == 1 && in16)                                                                   \
+      fpool::fwd_pool_kernel<k, n, 1, true><<<grid, fpool::NWF * 64, 0, stream>>>(                \
+          x, perm, pos_seg, rowptr, W, gnw, pam, psc, pbs, pslope, raw, arg, partial, rt);        \
+    else                                                                                          \
+      return -1;                                                                                  \
+  }
+  SPT_FPOOL_SHAPES(X)
+#undef X
+  return gx_;
+}
+
+void fpool_tables_launch(int K, const double* gram, int B, const float* W, int N, int bfw,
+                         const float* weight, const float* mean_scale, float eps, double* total,
+                         float* mean, float* rstd, float* am, float* scale, hipStream_t stream) {
+  if (K == 64)
+    fpool::gram_tables_kernel<64><<<B, 128, (size_t)N * K * 4, stream>>>(gram, W, N, bfw, weight, mean_scale, eps,
+                                                         total, mean, rstd, am, scale);
+  else
+    fpool::gram_tables_kernel<32><<<B, 128, (size_t)N * K * 4, stream>>>(gram, W, N, bfw, weight, mean_scale, eps,
+                                                         total, mean, rstd, am, scale);
+}
+
+void fpool_apply_launch(int K, bool in16, const int32_t* rowptr, const int32_t* perm,
+                        const int64_t* seg_graph, int64_t num_seg, int N, int64_t n_rows,
+                        const float* am, const float* sc, const float* bs, float slope,
+                        const float* gnw, const float* x, const float* W, const float* pam,
+                        const float* psc, const float* pbs, float pslope, int bfw, float* raw,
+                        int32_t* arg, float* out, hipStream_t stream) {
+  const int64_t total = num_seg * N;
+  if (total <= 0) return;
+  const int grid = (int)ceil_div(total, 256);
+#define XA(k, i16)                                                                                 \
+  fpool::pool_apply_kernel<k, i16><<<grid, 256, 0, stream>>>(rowptr, perm, seg_graph, num_seg, N,  \
+                                                             n_rows, am, sc, bs, slope, gnw, x, W, \
+                                                             pam, psc, pbs, pslope, bfw, raw, arg, out)
+  if (K == 64) { if (in16) XA(64, true); else XA(64, false); }
+  else { if (in16) XA(32, true); else XA(32, false); }
+#undef XA
+}
+
+// backward: gm, coefficient matrices, main kernel.  Returns wave records per run (gW / statistics
+// partial tables), or -1 for an unbuilt variant.
+int fpool_bwd_launch(bool lo, bool x16, const float* gout, const float* raw, const int32_t* arg,
+                     const int32_t* perm, const int32_t* pos_seg, const int64_t* seg_graph,
+                     int64_t num_seg, const FmlpRuns& rt, int64_t max_rows, int num_graphs, int K,
+                     int N, const float* am, const float* sc, const float* bs, float slope,
+                     const float* c1, const float* c2, const float* c3, const float* xprev,
+                     const float* pam, const float* psc, const float* pbs, float pslope,
+                     const float* W, float* gm, float* Mbuf, float* c0buf, float* gx,
+                     float* gw_partial, double* pstat_partial, int max_waves, hipStream_t stream) {
+  if (num_seg > 0)
+    fpool::pool_bwd_gm_kernel<<<(int)ceil_div(num_seg * N / 4, 256), 256, 0, stream>>>(
+        gout, raw, seg_graph, num_seg, N, am, sc, bs, slope, c1, gm);
+  if (K == 64)
+    fpool::pool_bwd_coef_kernel<64><<<num_graphs, 256, 2 * N * sizeof(float), stream>>>(W, N, am, c2, c3, Mbuf, c0buf);
+  else
+    fpool::pool_bwd_coef_kernel<32><<<num_graphs, 256, 2 * N * sizeof(float), stream>>>(W, N, am, c2, c3, Mbuf, c0buf);
+  constexpr int NW = 8;
+  const int64_t tiles = (max_rows + fpool::TR - 1) / fpool::TR;
+  int64_t blocks = (tiles + NW - 1) / NW;
+  int64_t cap = (K * N > 4096) ? 256 : 512;               // 64 -> 128: one 8-wave workgroup per CU
+  const int64_t cap_ws = max_waves / (NW * rt.n);
+  if (cap > cap_ws) cap = cap_ws;
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  const dim3 grid((unsigned)blocks, (unsigned)rt.n);
+#define X(k, n)                                                                                   \
+  if (K == k && N == n) {                                                                         \
+    if (lo && !x16)                                                                               \
+      fpool::bwd_pool_kernel<k, n, true, false, NW><<<grid, NW * 64, 0, stream>>>(                \
+          gm, arg, perm, pos_seg, xprev, pam, psc, pbs, pslope, W, Mbuf, c0buf, gx, gw_partial,   \
+          pstat_partial, rt);                                                                     \
+    else if (!lo && !x16)                                                                         \
+      fpool::bwd_pool_kernel<k, n, false, false, NW><<<grid, NW * 64, 0, stream>>>(               \
+          gm, arg, perm, pos_seg, xprev, pam, psc, pbs, pslope, W, Mbuf, c0buf, gx, gw_partial,   \
+          pstat_partial, rt);                                                                     \
+    else if (!lo && x16)                                                                          \
+      fpool::bwd_pool_kernel<k, n, false, true, NW><<<grid, NW * 64, 0, stream>>>(                \
+          gm, arg, perm, pos_seg, xprev, pam, psc, pbs, pslope, W, Mbuf, c0buf, gx, gw_partial,   \
+          pstat_partial, rt);                                                                     \
+    else                                                                                          \
+      return -1;                                                                                  \
+  }
+  SPT_FPOOL_SHAPES(X)
+#undef X
+  return (int)blocks * NW;
+}
+
+void fpool_gw_dense_launch(int K, const double* gram, int B, const float* W, int N, int bfw,
+                           const float* am, const float* c2, const float* c3, float* gW,
+                           hipStream_t stream) {
+  const int grid = (N * K + 255) / 256;
+  if (K == 64)
+    fpool::pool_bwd_gw_dense_kernel<64><<<grid, 256, 0, stream>>>(gram, B, W, N, bfw, am, c2, c3, gW);
+  else
+    fpool::pool_bwd_gw_dense_kernel<32><<<grid, 256, 0, stream>>>(gram, B, W, N, bfw, am, c2, c3, gW);
+}
+
+}  // namespace spt

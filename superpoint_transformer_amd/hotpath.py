@@ -104,6 +104,11 @@ def _kernel_names(mode):
                          "spt::el::attn_kv_reduce_kernel + spt::attn_reduce_partials_kernel"),
             "attn_fwd": f"spt::mfma::attn_fwd_mfma_kernel<{p}>",
             "mlp_bwd_pooled": f"spt::fdma::bwd_dma_kernel<64, 128, 8, 2, {lo}, true" + (", true>" if st else ">"),
+            "mlp_fwd_pool": (f"spt::fpool::fwd_pool_kernel<64, 128, {3 if mode == 'f32' else 1}, "
+                             f"{'true' if st else 'false'}> + gram_tables_kernel + pool_apply_kernel"),
+            "mlp_bwd_pool": (f"spt::fpool::pool_bwd_gm_kernel + pool_bwd_coef_kernel + "
+                             f"bwd_pool_kernel<64, 128, {lo}, {'true' if st else 'false'}, 8> + "
+                             "reduce_tables + pool_bwd_gw_dense_kernel"),
             "mlp_fwd": ("spt::fmlp::fwd_kernel_x3<16, 8> (f32 product as 6 bf16 products of 3-way split operands)"
                         if _lib.lib.spt_fused_linear_fwd_use_x3(-1) else "spt::fmlp::fwd_kernel<16, 8>")
                        if mode == "f32"
@@ -221,6 +226,9 @@ class SPTTrainStep:
             "attn_fwd": f"edge_attn_fwd:{n1}:{e1}",
             "mlp_bwd_pooled": "fused_linear_bwd_pooled:64x128:",
             "mlp_fwd": "fused_linear_fwd:64x128:",
+            # round 5: the top layer with the pool inside (no [rows, 128] tensor)
+            "mlp_fwd_pool": "fused_linear_fwd_pool:64x128:",
+            "mlp_bwd_pool": "fused_linear_bwd_pool:64x128:",
         }
         for key, name in self.k_timers.items():
             ops.enable_timer(name, prefix=key.startswith("mlp"))
@@ -300,6 +308,19 @@ class SPTTrainStep:
                                    2 * 2 * 64 * 128 * rows, False),
                 "mlp_fwd": ("64 -> 128 forward of the point MLP's top layer",
                             rows * ab * (64 + 128), 2 * 64 * 128 * rows, False),
+                # pool-fused top layer (csrc/fused_pool.hip): forward reads x (ab K) + the row id and
+                # the segment id (8) per row, writes (raw, arg) and reads / writes (raw, out) per
+                # (segment, channel): 5 x 4 N per segment; backward reads x (ab K) + ids (8), writes
+                # gx (4 K) per row, and moves (gout, raw | gm | gm, arg) = 5 x 4 N per segment
+                "mlp_fwd_pool": ("64 -> 128 forward of the point MLP's top layer WITH the L0->L1 max-pool, "
+                                 "the norm's statistics from the input's Gram matrix: product + pool + "
+                                 "tables + apply, all kernels of the call",
+                                 rows * (ab * 64 + 8) + n1 * 5 * 4 * 128,
+                                 2 * (64 * 128 + 64 * 64 // 2) * rows, False),
+                "mlp_bwd_pool": ("64 -> 128 backward of the same unit from (gout, arg, raw): gm + "
+                                 "coefficients + main kernel + reductions, all kernels of the call",
+                                 rows * (ab * 64 + 8 + 4 * 64) + n1 * 5 * 4 * 128,
+                                 2 * (2 * 64 * 128 + 64 * 64) * rows, False),
             }
             for key, (what, kbytes, kflops, per_call) in spec.items():
                 tms = ops.timer_mean_ms(self.k_timers[key])

@@ -1557,6 +1557,23 @@ class _FusedMLP(torch.autograd.Function):
 # (tests switch it off to pin the two routes on each other)
 POOL_RAW_OUTPUT = True
 
+# Round 5: the top layer and the max-pool behind it as ONE algebraic unit (csrc/fused_pool.hip) -
+# the layer's [rows, N] output is never written, read or recomputed: the forward pools the raw
+# tile out of the matrix-pipe accumulators, the norm's statistics come from the Gram matrix of the
+# layer's input, the backward needs (gout, arg, raw) and that input only.  Off: the round-4 route
+# (layer output materialised, streaming segment-max, LDS-DMA backward); tests pin one on the other.
+POOL_IN_FORWARD = os.environ.get("SPT_POOL_IN_FORWARD", "1") != "0"
+
+
+def pool_in_forward(on=None):
+    """Switch of the pool-fused top layer (default on; ``SPT_POOL_IN_FORWARD=0`` turns it off).
+    Returns the previous setting."""
+    global POOL_IN_FORWARD
+    prev = POOL_IN_FORWARD
+    if on is not None:
+        POOL_IN_FORWARD = bool(on)
+    return prev
+
 
 class _FusedMLPMaxPool(torch.autograd.Function):
     """The fused MLP followed by a max-pool over segments, as ONE node: the last
@@ -1578,6 +1595,13 @@ class _FusedMLPMaxPool(torch.autograd.Function):
             and all(int(k) % 32 == 0 for k in dims[1:-1])
             and 256 % int(dims[-1]) == 0
             and _lib.lib.spt_segcsr_max_affine_bf16_supported(int(dims[-1]), x.shape[0]))
+        ctx.pool_fused = False
+        mode_top = (3 | _ST_X) if store16 else fmode
+        if (POOL_IN_FORWARD and L > 1 and runs.sorted_batch
+                and _lib.lib.spt_fused_linear_pool_supported(int(dims[-2]), int(dims[-1]), mode_top)
+                and (runs.B == 1 or graph_ranges(seg_graph, runs.B, csr.num_seg) is not None)):
+            return _FusedMLPMaxPool._forward_pooled(ctx, x, batch, runs, eps_list, slope_list, csr,
+                                                    seg_graph, params, fmode, store16, mode_top)
         _, saved, h_last, (am, sc, bs) = _fmlp_forward(x, batch, runs, eps_list, slope_list,
                                                         params, apply_last=False, fmode=fmode,
                                                         store16=store16)
@@ -1619,7 +1643,114 @@ class _FusedMLPMaxPool(torch.autograd.Function):
         return out.to(x.dtype)
 
     @staticmethod
+    def _forward_pooled(ctx, x, batch, runs, eps_list, slope_list, csr, seg_graph, params, fmode,
+                        store16, mode_top):
+        """Layers 0 .. L-2 as a fused chain (their last norm + activation are applied inside the top
+        layer's read), then the top layer with the pool in its epilogue
+        (``spt_fused_linear_fwd_pool_runs_f32``): out, arg, raw per (segment, channel), the Gram
+        totals and the norm's tables - no [rows, N] tensor."""
+        L = len(eps_list)
+        _, saved_sub, h_prev, (pam, psc, pbs) = _fmlp_forward(
+            x, batch, runs, eps_list[:L - 1], slope_list[:L - 1], params[:4 * (L - 1)],
+            apply_last=False, fmode=fmode, store16=store16)
+        W = params[4 * (L - 1)].detach().float().contiguous()
+        gnw, gnb, gms = (params[4 * (L - 1) + i].detach().float().contiguous() for i in (1, 2, 3))
+        N, K = W.shape
+        R = h_prev.shape[0]
+        dev = h_prev.device
+        B = runs.B
+        S = csr.num_seg
+        nr, c_r0, c_r1, c_g = runs.c_arrays()
+        out = torch.empty((S, N), dtype=torch.float32, device=dev)
+        arg = torch.empty((S, N), dtype=torch.int32, device=dev)
+        raw = torch.empty((S, N), dtype=torch.float32, device=dev)
+        glen = int(_lib.lib.spt_fused_linear_pool_gram_len(K))
+        gram = torch.empty((B, glen), dtype=torch.float64, device=dev)
+        mean, rstd, am, sc = (torch.empty((B, N), dtype=torch.float32, device=dev) for _ in range(4))
+        nb = _lib.lib.spt_fused_linear_pool_workspace_bytes(K, N)
+        ws = _workspace(nb, dev)
+        # same timer key as the segment-max it replaces: this IS the L0 -> L1 pool of the step
+        with torch.cuda.device(dev), _timed(f"fused_linear_fwd_pool:{K}x{N}:{R}"):
+            st = _lib.lib.spt_fused_linear_fwd_pool_runs_f32(
+                _lib.ptr(h_prev), _lib.ptr(csr.perm), _lib.ptr(csr.pos_seg()), _lib.ptr(csr.rowptr),
+                _lib.ptr(seg_graph), S, R, nr, c_r0, c_r1, c_g, B, K, _lib.ptr(W), N,
+                _lib.ptr(gnw), _lib.ptr(gnb), _lib.ptr(gms), float(eps_list[-1]),
+                float(slope_list[-1]), _lib.ptr(pam), _lib.ptr(psc), _lib.ptr(pbs),
+                float(slope_list[-2]), _lib.ptr(out), _lib.ptr(arg), _lib.ptr(raw), _lib.ptr(gram),
+                None, _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(am), _lib.ptr(sc), mode_top,
+                _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+        _lib.check(st, "spt_fused_linear_fwd_pool_runs_f32")
+        ctx.pool_fused = True
+        ctx.n_sub = len(saved_sub)
+        ctx.save_for_backward(arg, raw, gram, mean, rstd, am, sc, W, gnw, gnb, gms, h_prev, pam, psc,
+                              pbs, *saved_sub)
+        ctx.csr = csr
+        ctx.seg_graph = seg_graph
+        ctx.meta = (L, runs, list(slope_list), x.dtype, x.requires_grad,
+                    3 if store16 else fmode, store16)
+        ctx.mode_top = mode_top
+        return out.to(x.dtype)
+
+    @staticmethod
+    def _backward_pooled(ctx, gout):
+        (arg, raw, gram, mean, rstd, am, sc, W, gnw, gnb, gms, h_prev, pam, psc,
+         pbs) = ctx.saved_tensors[:15]
+        saved_sub = ctx.saved_tensors[15:]
+        L, runs, slopes, in_dtype, need_gx0, fmode, store16 = ctx.meta
+        N, K = W.shape
+        R = h_prev.shape[0]
+        dev = h_prev.device
+        B = runs.B
+        csr = ctx.csr
+        S = csr.num_seg
+        nr, c_r0, c_r1, c_g = runs.c_arrays()
+        sp = _lib.stream_ptr(dev)
+        gout = gout.contiguous().float()
+        with torch.cuda.device(dev):
+            # statistics of the top GraphNorm's backward from the pool's sparse gradient
+            total = torch.empty((B, 2 * N + 1), dtype=torch.float64, device=dev)
+            rows = torch.tensor(runs.rows_per_graph(), dtype=torch.int64, device=dev)
+            nbs = _lib.lib.spt_graphnorm_bwd_stats_sparse_workspace_bytes(S, N, B)
+            ws = _workspace(nbs, dev)
+            st = _lib.lib.spt_graphnorm_bwd_stats_sparse_raw_f32(
+                _lib.ptr(raw), _lib.ptr(gout), _lib.ptr(arg), _lib.ptr(ctx.seg_graph),
+                _lib.ptr(rows), S, R, N, B, _lib.ptr(am), _lib.ptr(sc), _lib.ptr(gnb),
+                float(slopes[-1]), _lib.ptr(total), _lib.ptr(ws), nbs, sp)
+            _lib.check(st, "spt_graphnorm_bwd_stats_sparse_raw_f32")
+            c1, c2, c3 = (torch.empty((B, N), dtype=torch.float32, device=dev) for _ in range(3))
+            gw_n, gb_n, ga_n = (torch.empty(N, dtype=torch.float32, device=dev) for _ in range(3))
+            st = _lib.lib.spt_graphnorm_bwd_tables_f32(
+                _lib.ptr(total), B, N, _lib.ptr(gnw), _lib.ptr(gms), _lib.ptr(mean), _lib.ptr(rstd),
+                _lib.ptr(c1), _lib.ptr(c2), _lib.ptr(c3), _lib.ptr(gw_n), _lib.ptr(gb_n),
+                _lib.ptr(ga_n), sp)
+            _lib.check(st, "spt_graphnorm_bwd_tables_f32")
+            gm = torch.empty((S, N), dtype=torch.float32, device=dev)
+            gx = torch.empty((R, K), dtype=torch.float32, device=dev)
+            gW = torch.empty((N, K), dtype=torch.float32, device=dev)
+            ptot = torch.empty((B, 2 * K + 1), dtype=torch.float64, device=dev)
+            nb = _lib.lib.spt_fused_linear_pool_workspace_bytes(K, N)
+            ws = _workspace(nb, dev)
+            with _timed(f"fused_linear_bwd_pool:{K}x{N}:{R}"):
+                st = _lib.lib.spt_fused_linear_bwd_pool_runs_f32(
+                    _lib.ptr(gout), _lib.ptr(raw), _lib.ptr(arg), _lib.ptr(csr.perm),
+                    _lib.ptr(csr.pos_seg()), _lib.ptr(ctx.seg_graph), S, nr, c_r0, c_r1, c_g, B, N,
+                    _lib.ptr(am), _lib.ptr(sc), _lib.ptr(gnb), float(slopes[-1]), _lib.ptr(c1),
+                    _lib.ptr(c2), _lib.ptr(c3), _lib.ptr(h_prev), K, _lib.ptr(pam), _lib.ptr(psc),
+                    _lib.ptr(pbs), float(slopes[-2]), _lib.ptr(W), _lib.ptr(gram), _lib.ptr(gm),
+                    _lib.ptr(gx), _lib.ptr(gW), _lib.ptr(ptot), ctx.mode_top, _lib.ptr(ws),
+                    ws.numel(), sp)
+            _lib.check(st, "spt_fused_linear_bwd_pool_runs_f32")
+        # layers L-2 .. 0: the fused chain's own backward, entered with the gradient of its
+        # normalised output and the statistics of its top norm's backward
+        meta_sub = (L - 1, runs, list(slopes[:L - 1]), in_dtype, need_gx0, fmode, store16)
+        gx0, grads = _fmlp_backward(saved_sub, meta_sub, gx, top_total=ptot)
+        grads = list(grads) + [gW, gw_n, gb_n, ga_n]
+        return (gx0, None, None, None, None, None, None, *grads)
+
+    @staticmethod
     def backward(ctx, gout):
+        if ctx.pool_fused:
+            return _FusedMLPMaxPool._backward_pooled(ctx, gout)
         arg, saved, raw = ctx.saved_tensors[0], ctx.saved_tensors[1:], None
         if ctx.has_raw:
             saved, raw = saved[:-1], saved[-1]

@@ -68,3 +68,15 @@ def demo_nag():
             lv["sub_points"] = d[f"level_{i}___cluster___sub__value_0"]
         levels.append(lv)
     return levels
+
+
+@pytest.fixture
+def materialised_pool_route():
+    """Tests that pin the ROUND-4 route of MLP -> max-pool (the top layer's output written, the
+    streaming segment-max with the folded norm, the pooled LDS-DMA backward) bit for bit on
+    norm-then-pool: switch the round-5 pool-fused top layer off for their duration.  The fused
+    route has its own file (tests/test_fused_pool_gpu.py)."""
+    from superpoint_transformer_amd import ops
+    prev = ops.pool_in_forward(False)
+    yield
+    ops.pool_in_forward(prev)

@@ -139,7 +139,7 @@ def test_fused_mlp_runs_of_a_piecewise_sorted_batch(dev):
 
 
 @pytest.mark.parametrize("rows,nseg,B", [(50_000, 1500, 1), (40_001, 900, 3)])
-def test_mlp_folded_into_the_max_pool_equals_mlp_then_pool(rows, nseg, B, dev):
+def test_mlp_folded_into_the_max_pool_equals_mlp_then_pool(rows, nseg, B, dev, materialised_pool_route):
     """MLP.forward_max_pooled (last GraphNorm + LeakyReLU applied inside the pool's read of
     the raw activations) against the same MLP followed by the segment max-pool: pooled
     values bit-identical (same expression per element, hence the same arg rows); gradients
@@ -452,7 +452,7 @@ def test_raw_output_of_the_pool_feeds_the_sparse_statistics(dev):
     assert torch.allclose(t_raw, t_gather, rtol=1e-13, atol=1e-13)
 
 
-def test_fused_mlp_max_pool_with_and_without_the_raw_output(dev):
+def test_fused_mlp_max_pool_with_and_without_the_raw_output(dev, materialised_pool_route):
     """MLP.forward_max_pooled at a size where the pool's raw output is built (128 channels,
     >= 65 536 rows): same pooled values, gradients equal up to the f64 summation order of the top
     statistics, with the raw output feeding them (default) and with the gathering statistics."""

@@ -1,0 +1,286 @@
+"""GPU parity of the pool-fused top layer (csrc/fused_pool.hip; round 5): the point MLP's last
+Linear -> GraphNorm -> LeakyReLU and the max-pool behind it as ONE unit that never materialises
+the layer's [rows, N] output - against the float64 oracle of MLP -> scatter_max
+(src/nn/mlp.py:43-56, src/nn/stage.py:413-431, src/nn/pool.py:61-82 restated in oracle/) and
+against the round-4 route it replaces (layer output written, streaming segment-max, LDS-DMA
+backward), which stays in the library and is pinned bitwise on norm-then-pool elsewhere.
+
+What "same result" means here:
+  * pooled VALUES: the expression per element is the one of gn_apply / the streaming pool; the
+    norm's statistics come from the Gram matrix of the layer's input instead of sums over its
+    output - equal to ~1e-7 relative, so values agree to f32 round-off, not bit for bit;
+  * ARG rows: the first row attaining the raw extremum.  Equal to the reference's arg except
+    where two rows with different h round to the SAME y: both are maxima of y, the tests check
+    exactly that for every mismatch;
+  * gradients: another algebraic form of the same sums (f32 round-off)."""
+import copy
+
+import pytest
+import torch
+
+from oracle import spt_model as OM
+from oracle import spt_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem(gen, rows, nseg, B, dims, dev, empty=0, neg=0, zero=0, seg_sizes=None):
+    """MLP with perturbed parameters (``neg`` / ``zero``: channels of the TOP norm whose weight is
+    made negative / exactly 0), rows, a sorted batch vector and an UNSORTED super index whose
+    segments never straddle two graphs (``empty`` unused segments per graph)."""
+    from superpoint_transformer_amd import nn as N
+    mlp = N.MLP(dims, norm=N.GraphNorm)
+    with torch.no_grad():
+        for p in mlp.parameters():
+            p.add_(0.1 * torch.randn(p.shape, generator=gen))
+        top = [m for m in mlp.mlp if isinstance(m, N.GraphNorm)][-1]
+        C = dims[-1]
+        pick = torch.randperm(C, generator=gen)
+        top.weight[pick[:neg]] = -top.weight[pick[:neg]].abs() - 0.05
+        top.weight[pick[neg:neg + zero]] = 0.0
+    x = torch.randn(rows, dims[0], generator=gen) * 2 + 0.5
+    batch = (torch.arange(rows) * B // rows) if B > 1 else None
+    seg_graph = torch.arange(nseg) * B // nseg
+    si = torch.empty(rows, dtype=torch.long)
+    for b in range(B):
+        rmask = (batch == b) if batch is not None else torch.ones(rows, dtype=torch.bool)
+        segs = torch.nonzero(seg_graph == b).flatten()[empty:]
+        nb = int(rmask.sum())
+        if seg_sizes == "one-row":          # as many segments of a single row as possible
+            k = min(nb, segs.numel())
+            pick = torch.cat([segs[:k], segs[torch.randint(0, k, (nb - k,), generator=gen)]])
+            si[rmask] = pick[torch.randperm(nb, generator=gen)]
+        elif seg_sizes == "giant":          # one segment owns half of the graph's rows
+            r = segs[torch.randint(0, segs.numel(), (nb,), generator=gen)]
+            r[torch.rand(nb, generator=gen) < 0.5] = segs[0]
+            si[rmask] = r
+        else:
+            si[rmask] = segs[torch.randint(0, segs.numel(), (nb,), generator=gen)]
+    gout = torch.randn(nseg, dims[-1], generator=gen)
+    return mlp, x, batch, seg_graph, si, gout
+
+
+def _run(mlp, x, batch, seg_graph, si, gout, nseg, B, dev, fused):
+    from superpoint_transformer_amd import ops
+    prev = ops.pool_in_forward(fused)
+    try:
+        m = copy.deepcopy(mlp).to(dev)
+        m.FUSE_MIN_ROWS = 0
+        xd = x.to(dev).requires_grad_()
+        out = m.forward_max_pooled(xd, si.to(dev), nseg, batch=None if batch is None else batch.to(dev),
+                                   batch_size=B, seg_graph=seg_graph.to(dev) if B > 1 else None)
+        assert out is not None
+        node = out.grad_fn
+        (out * gout.to(dev)).sum().backward()
+        arg = None
+        if fused:
+            assert getattr(node, "pool_fused", False), "the pool-fused route did not run"
+            arg = node.saved_tensors[0].cpu().long()
+            big = [t for t in node.saved_tensors if t.dim() == 2 and t.shape[0] == x.shape[0]]
+            assert all(t.shape[1] < mlp_out_dim(mlp) for t in big), \
+                "a [rows, N] tensor of the top layer was saved: its output is supposed never to exist"
+        return out.detach().cpu(), xd.grad.cpu(), {k: p.grad.cpu() for k, p in m.named_parameters()}, arg
+    finally:
+        ops.pool_in_forward(prev)
+
+
+def mlp_out_dim(mlp):
+    return [p for p in mlp.parameters() if p.dim() == 2][-1].shape[0]
+
+
+def _oracle(mlp, x, batch, si, gout, nseg):
+    ref = copy.deepcopy(mlp).double()
+    x64 = x.double().requires_grad_()
+    OM.KEEP_GRAPH = True
+    y64 = OM.mlp(ref, x64, batch, torch.float64)
+    OM.KEEP_GRAPH = False
+    p64, a64 = O.scatter_max(y64, si, dim_size=nseg)
+    (p64 * gout.double()).sum().backward()
+    return y64.detach(), p64.detach(), a64, x64.grad, dict(ref.named_parameters())
+
+
+def _rel(a, r):
+    return float((a.double() - r.double()).abs().max() / r.double().abs().max().clamp_min(1e-30))
+
+
+def _check_args(arg, a64, y64, nrows):
+    """Every arg row either IS the oracle's or holds the same maximum of y (a tie of the f32 / f64
+    evaluation between rows of different h); empty segments carry the sentinel."""
+    empty = a64 >= nrows
+    assert bool((arg[empty] == nrows).all())
+    ok = ~empty
+    mism = ok & (arg != a64)
+    frac = float(mism.sum()) / max(int(ok.sum()), 1)
+    assert frac < 2e-3, f"{frac:.2e} of the arg rows differ from the oracle's"
+    s_idx, c_idx = torch.nonzero(mism, as_tuple=True)
+    if s_idx.numel():
+        ya = y64[arg[s_idx, c_idx], c_idx]
+        yr = y64[a64[s_idx, c_idx], c_idx]
+        # a different arg must hold (to f32 resolution) the same maximum
+        assert bool(((ya - yr).abs() <= 4e-7 * yr.abs().clamp(min=1e-3)).all()), \
+            float(((ya - yr).abs() / yr.abs().clamp(min=1e-3)).max())
+    return frac
+
+
+CASES = [
+    # dims, rows, nseg, B, kwargs
+    ([12, 32, 64, 128], 50_000, 1500, 1, {}),
+    ([12, 32, 64, 128], 40_001, 900, 3, dict(empty=2)),
+    ([12, 32, 64, 128], 30_011, 700, 2, dict(neg=40, zero=3, empty=1)),     # min-pooled / constant channels
+    ([12, 32, 64, 128], 9_000, 6_000, 1, dict(seg_sizes="one-row")),        # up to 16 segments per tile
+    ([12, 32, 64, 128], 20_003, 300, 2, dict(seg_sizes="giant", neg=5)),    # a segment spanning many waves' ranges
+    ([12, 32, 64], 25_000, 800, 1, dict(neg=7)),                            # 32 -> 64 top layer
+    ([12, 64, 64], 18_017, 500, 2, dict(zero=1)),                           # 64 -> 64 (panoptic)
+    ([12, 32, 64, 128], 17, 2, 1, {}),                                      # fewer rows than one wave's tile pair
+]
+
+
+@pytest.mark.parametrize("dims,rows,nseg,B,kw", CASES)
+def test_pool_fused_top_layer_matches_oracle_and_materialised_route(dims, rows, nseg, B, kw, dev):
+    gen = torch.Generator().manual_seed(rows + nseg)
+    mlp, x, batch, seg_graph, si, gout = _problem(gen, rows, nseg, B, dims, dev, **kw)
+    of, gxf, gpf, arg = _run(mlp, x, batch, seg_graph, si, gout, nseg, B, dev, True)
+    om, gxm, gpm, _ = _run(mlp, x, batch, seg_graph, si, gout, nseg, B, dev, False)
+    y64, p64, a64, gx64, p64p = _oracle(mlp, x, batch, si, gout, nseg)
+    # values: the f32 forward bar of the fused layers (2e-5 of max(1, |ref|)) and round-off against
+    # the materialised route
+    err = ((of.double() - p64).abs() / p64.abs().clamp(min=1)).max().item()
+    assert err < 2e-5, err
+    assert ((of - om).abs() / om.abs().clamp(min=1)).max().item() < 4e-6
+    _check_args(arg, a64, y64, rows)
+    # gradients: no further from the oracle than the materialised route (same tolerance family as
+    # tests/test_fused_mlp_gpu.py) and close to it
+    def scaled(a, r):
+        return float((a.double() - r).abs().max() / r.abs().max().clamp(min=1e-6))
+    ef, em = scaled(gxf, gx64), scaled(gxm, gx64)
+    assert ef <= max(2e-4, 3 * em), (ef, em)
+    for k in gpf:
+        r = p64p[k].grad
+        ef, em = scaled(gpf[k], r), scaled(gpm[k], r)
+        assert ef <= max(2e-4, 3 * em), (k, ef, em)
+        assert scaled(gpf[k], gpm[k].double()) < 5e-4, k
+
+
+def test_exact_ties_take_the_first_row(dev):
+    """Duplicated input rows give bitwise equal h: the arg is the FIRST of them in the original
+    row order (torch_scatter's rule, the stable CSR view's order) - on the fused route exactly as
+    on the materialised one, for max-pooled, min-pooled (negative weight) and constant (zero
+    weight) channels."""
+    gen = torch.Generator().manual_seed(4)
+    dims, rows, nseg, B = [12, 32, 64, 128], 12_000, 500, 1
+    mlp, x, batch, seg_graph, si, gout = _problem(gen, rows, nseg, B, dims, dev, neg=30, zero=4)
+    half = rows // 2
+    x[half:] = x[:half]                         # every row twice ...
+    si[half:] = si[:half]                       # ... in the same segment
+    of, gxf, gpf, arg = _run(mlp, x, batch, seg_graph, si, gout, nseg, B, dev, True)
+    om, gxm, gpm, _ = _run(mlp, x, batch, seg_graph, si, gout, nseg, B, dev, False)
+    assert bool((arg[arg < rows] < half).all()), "a duplicate won over its first occurrence"
+    y64, p64, a64, gx64, _ = _oracle(mlp, x, batch, si, gout, nseg)
+    _check_args(arg, a64, y64, rows)
+    assert _rel(of, om) < 4e-6
+    assert bool((gxf[half:] == 0).all()), "gradient reached a second occurrence"
+    assert _rel(gxf, gxm) < 2e-4
+
+
+def test_zero_weight_channels_report_the_first_row_and_its_true_value(dev):
+    """GraphNorm weight exactly 0: y is the constant leaky(bias) - every row ties, the reference's
+    arg is the segment's first row, and the norm's WEIGHT gradient (sum g h_hat at the arg rows)
+    needs that row's true h: pool_apply_kernel restores both."""
+    gen = torch.Generator().manual_seed(9)
+    dims, rows, nseg, B = [12, 32, 64, 128], 20_000, 600, 2
+    mlp, x, batch, seg_graph, si, gout = _problem(gen, rows, nseg, B, dims, dev, zero=16, empty=1)
+    of, gxf, gpf, arg = _run(mlp, x, batch, seg_graph, si, gout, nseg, B, dev, True)
+    y64, p64, a64, gx64, p64p = _oracle(mlp, x, batch, si, gout, nseg)
+    top_w = [p for k, p in mlp.named_parameters() if p.dim() == 1][-3]       # weight | bias | mean_scale
+    zero = torch.nonzero(top_w == 0).flatten()
+    assert zero.numel() == 16
+    assert torch.equal(arg[:, zero], a64[:, zero])
+    names = [k for k, p in mlp.named_parameters() if p.dim() == 1][-3:]
+    for k in names:
+        r = p64p[k].grad
+        assert float((gpf[k].double() - r).abs().max() / r.abs().max().clamp(min=1e-6)) < 2e-4, k
+
+
+@pytest.mark.parametrize("B", [1, 3])
+def test_pool_fused_route_in_the_bf16_mode(dev, B):
+    """`bf16` precision (configs/trainer/gpu.yaml:7-10) with activation storage: the fused route
+    reads the previous layer's bf16 rows, rounds its operands to bf16 and pools the UNROUNDED f32
+    accumulators (the materialised route rounds the layer's output to bf16 first).  Against the f64
+    oracle at the mode's 2e-2 bar, per element (|err| <= 2e-2 max(|ref|, rms))."""
+    from superpoint_transformer_amd import precision
+    gen = torch.Generator().manual_seed(77 + B)
+    dims, rows, nseg = [12, 32, 64, 128], 70_001, 2_300
+    mlp, x, batch, seg_graph, si, gout = _problem(gen, rows, nseg, B, dims, dev, neg=9)
+    with precision.matrix_precision("bf16"):
+        assert precision.bf16_activation_storage()
+        of, gxf, gpf, arg = _run(mlp, x, batch, seg_graph, si, gout, nseg, B, dev, True)
+        om, gxm, gpm, _ = _run(mlp, x, batch, seg_graph, si, gout, nseg, B, dev, False)
+    y64, p64, a64, gx64, p64p = _oracle(mlp, x, batch, si, gout, nseg)
+    rms = p64.pow(2).mean().sqrt()
+    bar = 2e-2 * torch.maximum(p64.abs(), rms)
+    assert bool(((of.double() - p64).abs() <= bar).all()), \
+        float(((of.double() - p64).abs() / torch.maximum(p64.abs(), rms)).max())
+    assert _rel(of, p64) > 1e-5                                   # not secretly f32
+    # gradients: bf16 rounding reorders near-ties of the pool (tests/test_modes_gpu.py explains);
+    # the fused route is no further from the oracle than the materialised one
+    def l2(a, r):
+        return float((a.double() - r).norm() / r.norm())
+    assert l2(gxf, gx64) < 1.5 * l2(gxm, gx64) + 0.05, (l2(gxf, gx64), l2(gxm, gx64))
+    for k in gpf:
+        assert l2(gpf[k], p64p[k].grad) < 1.5 * l2(gpm[k], p64p[k].grad) + 0.05, k
+
+
+def test_gram_statistics_equal_the_sums_over_the_output(dev):
+    """Identity (ii) on its own, through the C ABI: `total` of spt_fused_linear_fwd_pool_runs_f32
+    (w . sum y, w^T G w) against the f64 sums over the materialised h = y W^T of the same rows."""
+    from superpoint_transformer_amd import _lib, csr as C
+    gen = torch.Generator().manual_seed(12)
+    rows, K, N, nseg = 33_333, 64, 128, 1000
+    x = torch.randn(rows, K, generator=gen) * 1.5 + 0.3
+    W = torch.randn(N, K, generator=gen) * 0.2
+    gnw = torch.randn(N, generator=gen)
+    gnb, gms = torch.randn(N, generator=gen) * 0.1, torch.rand(N, generator=gen)
+    pam, psc, pbs = torch.randn(1, K, generator=gen) * 0.1, torch.rand(1, K, generator=gen) + 0.5, \
+        torch.randn(K, generator=gen) * 0.1
+    si = torch.randint(0, nseg, (rows,), generator=gen)
+    view = C.build_csr(si.to(dev), nseg)
+    d = lambda t: t.to(dev).contiguous()
+    xd, Wd, gnwd, gnbd, gmsd, pamd, pscd, pbsd = map(d, (x, W, gnw, gnb, gms, pam, psc, pbs))
+    out = torch.empty(nseg, N, device=dev)
+    raw = torch.empty(nseg, N, device=dev)
+    arg = torch.empty(nseg, N, dtype=torch.int32, device=dev)
+    glen = int(_lib.lib.spt_fused_linear_pool_gram_len(K))
+    gram = torch.empty(1, glen, dtype=torch.float64, device=dev)
+    total = torch.empty(1, 2 * N + 1, dtype=torch.float64, device=dev)
+    mean, rstd, am, sc = (torch.empty(1, N, device=dev) for _ in range(4))
+    ws = torch.empty(_lib.lib.spt_fused_linear_pool_workspace_bytes(K, N), dtype=torch.uint8, device=dev)
+    import ctypes
+    r0, r1, g0 = (ctypes.c_int64 * 1)(0), (ctypes.c_int64 * 1)(rows), (ctypes.c_int32 * 1)(0)
+    P = _lib.ptr
+    st = _lib.lib.spt_fused_linear_fwd_pool_runs_f32(
+        P(xd), P(view.perm), P(view.pos_seg()), P(view.rowptr), None, nseg, rows, 1, r0, r1, g0, 1, K,
+        P(Wd), N, P(gnwd), P(gnbd), P(gmsd), 1e-5, 0.01, P(pamd), P(pscd), P(pbsd), 0.2, P(out), P(arg),
+        P(raw), P(gram), P(total), P(mean), P(rstd), P(am), P(sc), 1, P(ws), ws.numel(),
+        _lib.stream_ptr(dev))
+    _lib.check(st, "spt_fused_linear_fwd_pool_runs_f32")
+    torch.cuda.synchronize()
+    y = (x.double() - pam.double()) * psc.double() + pbs.double()
+    y = torch.where(y > 0, y, 0.2 * y)
+    # the kernel's y is the f32 evaluation: compare against f64 sums of the f32-evaluated y
+    y32 = torch.nn.functional.leaky_relu(torch.addcmul(pbs, x - pam, psc), 0.2).double()
+    h = y32 @ W.double().t()
+    G = gram[0, :K * K].view(K, K).cpu()
+    assert float((G - y32.t() @ y32).abs().max() / (y32.t() @ y32).abs().max()) < 2e-6
+    assert float((gram[0, K * K:K * K + K].cpu() - y32.sum(0)).abs().max() / y32.sum(0).abs().max()) < 2e-6
+    assert float(gram[0, -1]) == rows
+    t = total[0].cpu()
+    assert float((t[:N] - h.sum(0)).abs().max() / h.sum(0).abs().max()) < 2e-6
+    assert float((t[N:2 * N] - h.pow(2).sum(0)).abs().max() / h.pow(2).sum(0).abs().max()) < 2e-6
+    # raw / arg against a plain max (min for negative weights) of the f64 h, ties excluded
+    hs = h * torch.where(gnw < 0, -1.0, 1.0).double()
+    pm, pa = O.scatter_max(hs, si, dim_size=nseg)
+    got = raw.cpu().double() * torch.where(gnw < 0, -1.0, 1.0).double()
+    assert float((got - pm).abs().max() / pm.abs().max()) < 2e-6
+    same = (arg.cpu().long() == pa)
+    assert float(same.float().mean()) > 0.999
+    assert bool(torch.isfinite(y).all())

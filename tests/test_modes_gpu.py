@@ -162,7 +162,7 @@ def test_bf16_matrix_precision_mode(dev):
 
 
 @pytest.mark.parametrize("B", [1, 3])
-def test_bf16_activation_storage_of_the_point_mlp(dev, B):
+def test_bf16_activation_storage_of_the_point_mlp(dev, B, materialised_pool_route):
     """The `bf16` mode's STORAGE half (configs/trainer/gpu.yaml:7-10: under autocast the Linear
     outputs are bf16 tensors): the point MLP's raw layer outputs are written as bf16 by the fused
     forward, read as bf16 by the next layer, the L0 -> L1 streaming segment-max and the backward

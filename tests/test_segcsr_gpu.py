@@ -224,7 +224,7 @@ def test_row_streaming_max_equals_lane_group_kernel_and_oracle(kind, n, dev):
 
 
 @pytest.mark.parametrize("rows,B", [(150_000, 1), (200_003, 3)])
-def test_row_streaming_max_with_the_fused_norm_equals_lane_group_kernel(rows, B, dev):
+def test_row_streaming_max_with_the_fused_norm_equals_lane_group_kernel(rows, B, dev, materialised_pool_route):
     """The pool that evaluates the point MLP's last GraphNorm + LeakyReLU on the fly
     (spt_segcsr_max_affine_f32), row-streaming vs lane-group kernel: pooled values, arg rows and
     therefore every gradient bit-identical; several graphs (the coefficient rows change with the
