@@ -884,7 +884,8 @@ int spt_fused_linear_bwd_pooled_runs_f32(
  *             the value of norm-then-pool evaluated with THESE statistics; arg [num_seg, N] int32 =
  *             first row attaining the raw extremum (n_rows for an empty segment, like
  *             spt_segcsr_reduce_f32; the reference's arg except on ties of y between rows of
- *             different h); raw [num_seg, N] = h of the arg row; gram [num_graphs, K K + K + 1] f64
+ *             different h); argpos [num_seg, N] int32 = the CSR position of that row (arg =
+ *             perm[argpos]: what the backward scatters by); raw [num_seg, N] = h of the arg row; gram [num_graphs, K K + K + 1] f64
  *             = (sum_i y_i y_i^T | sum_i y_i | rows) of the layer's activated INPUT per graph, from
  *             which the norm's statistics are evaluated (total [num_graphs, 2N+1], nullable, receives
  *             them in spt_fused_linear_fwd_*'s layout) and its tables mean / rstd / am / scale
@@ -894,7 +895,7 @@ int spt_fused_linear_bwd_pooled_runs_f32(
  *             (perm, pos_seg, rowptr): the pool's CSR view and the segment of every CSR position;
  *             runs: the graphs' CSR position ranges (contiguous, tiling [0, n_rows)); seg_graph
  *             [num_seg] int64 (NULL with one graph).
- *   backward: from gout [num_seg, N] and the GraphNorm-backward coefficient rows c1 / c2 / c3
+ *   backward: from gout, raw, argpos [num_seg, N] and the GraphNorm-backward coefficient rows c1 / c2 / c3
  *             (spt_graphnorm_bwd_stats_sparse_raw_f32 -> spt_graphnorm_bwd_tables_f32) to gx
  *             [n_rows, K] (gradient of the previous layer's normalised output), gW [N, K] and
  *             prev_total [num_graphs, 2K+1] (statistics of the previous norm's backward);
@@ -911,10 +912,10 @@ int spt_fused_linear_fwd_pool_runs_f32(
     const int64_t* run_p1, const int32_t* run_graph, int num_graphs, int K, const float* W, int N,
     const float* gn_weight, const float* gn_bias, const float* gn_mean_scale, float eps, float slope,
     const float* pre_am, const float* pre_scale, const float* pre_bias, float pre_slope, float* out,
-    int32_t* arg, float* raw, double* gram, double* total, float* mean, float* rstd, float* am,
-    float* scale, int mode, void* ws, size_t ws_bytes, spt_stream_t stream);
+    int32_t* arg, int32_t* argpos, float* raw, double* gram, double* total, float* mean, float* rstd,
+    float* am, float* scale, int mode, void* ws, size_t ws_bytes, spt_stream_t stream);
 int spt_fused_linear_bwd_pool_runs_f32(
-    const float* gout, const float* raw, const int32_t* arg, const int32_t* perm,
+    const float* gout, const float* raw, const int32_t* argpos, const int32_t* perm,
     const int32_t* pos_seg, const int64_t* seg_graph, int64_t num_seg, int nruns,
     const int64_t* run_p0, const int64_t* run_p1, const int32_t* run_graph, int num_graphs, int N,
     const float* am, const float* scale, const float* bias, float slope, const float* c1,

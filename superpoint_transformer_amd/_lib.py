@@ -142,7 +142,7 @@ SIGNATURES = {
     "spt_fused_linear_pool_workspace_bytes": (_sz, [_int, _int]),
     "spt_fused_linear_fwd_pool_runs_f32": (_int, [_p, _p, _p, _p, _p, _i64, _i64, _int, _p, _p, _p, _int,
                                                   _int, _p, _int, _p, _p, _p, _f32, _f32, _p, _p, _p,
-                                                  _f32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _int, _p,
+                                                  _f32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _int, _p,
                                                   _sz, _p]),
     "spt_fused_linear_bwd_pool_runs_f32": (_int, [_p, _p, _p, _p, _p, _p, _i64, _int, _p, _p, _p, _int,
                                                   _int, _p, _p, _p, _f32, _p, _p, _p, _p, _int, _p, _p,

@@ -1807,7 +1807,7 @@ int fpool_gram_len(int K);
 int fpool_fwd_launch(int prec, bool in16, const float* x, const int32_t* perm, const int32_t* pos_seg,
                      const int32_t* rowptr, const FmlpRuns& rt, int64_t max_rows, int K, int N,
                      const float* W, const float* gnw, const float* pam, const float* psc,
-                     const float* pbs, float pslope, float* raw, int32_t* arg, double* partial,
+                     const float* pbs, float pslope, float* raw, int32_t* argpos, double* partial,
                      hipStream_t stream);
 void fpool_tables_launch(int K, const double* gram, int B, const float* W, int N, int bfw,
                          const float* weight, const float* mean_scale, float eps, double* total,
@@ -1817,8 +1817,8 @@ void fpool_apply_launch(int K, bool in16, const int32_t* rowptr, const int32_t* 
                         const float* am, const float* sc, const float* bs, float slope,
                         const float* gnw, const float* x, const float* W, const float* pam,
                         const float* psc, const float* pbs, float pslope, int bfw, float* raw,
-                        int32_t* arg, float* out, hipStream_t stream);
-int fpool_bwd_launch(bool lo, bool x16, const float* gout, const float* raw, const int32_t* arg,
+                        int32_t* argpos, int32_t* arg, float* out, hipStream_t stream);
+int fpool_bwd_launch(bool lo, bool x16, const float* gout, const float* raw, const int32_t* argpos,
                      const int32_t* perm, const int32_t* pos_seg, const int64_t* seg_graph,
                      int64_t num_seg, const FmlpRuns& rt, int64_t max_rows, int num_graphs, int K,
                      int N, const float* am, const float* sc, const float* bs, float slope,
@@ -1853,8 +1853,8 @@ extern "C" int spt_fused_linear_fwd_pool_runs_f32(
     const int64_t* run_p1, const int32_t* run_graph, int num_graphs, int K, const float* W, int N,
     const float* gn_weight, const float* gn_bias, const float* gn_mean_scale, float eps, float slope,
     const float* pre_am, const float* pre_scale, const float* pre_bias, float pre_slope, float* out,
-    int32_t* arg, float* raw, double* gram, double* total, float* mean, float* rstd, float* am,
-    float* scale, int mode, void* ws, size_t ws_bytes, spt_stream_t stream_) {
+    int32_t* arg, int32_t* argpos, float* raw, double* gram, double* total, float* mean, float* rstd,
+    float* am, float* scale, int mode, void* ws, size_t ws_bytes, spt_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   FmlpRuns rt;
   int64_t max_rows;
@@ -1865,7 +1865,7 @@ extern "C" int spt_fused_linear_fwd_pool_runs_f32(
   SPT_CHECK_ARG(fpool_supported(K, N) && prec != 0 && (!in16 || prec == 1),
                 "(K, N) has no pool-fused kernel in this matrix mode");
   SPT_CHECK_ARG(x && pos_seg && rowptr && W && gn_weight && gn_bias && gn_mean_scale && pre_am &&
-                pre_scale && pre_bias && out && arg && raw && gram && mean && rstd && am && scale && ws,
+                pre_scale && pre_bias && out && arg && argpos && raw && gram && mean && rstd && am && scale && ws,
                 "null pointer");
   SPT_CHECK_ARG(num_seg >= 0 && n_rows >= 0 && (num_graphs == 1 || seg_graph), "bad shape");
   SPT_CHECK_ARG(ws_bytes >= spt_fused_linear_pool_workspace_bytes(K, N), "workspace too small");
@@ -1876,7 +1876,7 @@ extern "C" int spt_fused_linear_fwd_pool_runs_f32(
   double* partial = (double*)ws;
   const int glen = fpool_gram_len(K);
   const int gx_ = fpool_fwd_launch(prec, in16, (const float*)x, perm, pos_seg, rowptr, rt, max_rows, K, N,
-                                   W, gn_weight, pre_am, pre_scale, pre_bias, pre_slope, raw, arg,
+                                   W, gn_weight, pre_am, pre_scale, pre_bias, pre_slope, raw, argpos,
                                    partial, stream);
   SPT_CHECK_ARG(gx_ > 0, "no kernel for this variant");
   reduce_tables_groups_kernel<double><<<dim3((glen + 15) / 16, num_graphs), 1024, 0, stream>>>(
@@ -1885,13 +1885,13 @@ extern "C" int spt_fused_linear_fwd_pool_runs_f32(
                       rstd, am, scale, stream);
   fpool_apply_launch(K, in16, rowptr, perm, seg_graph, num_seg, N, n_rows, am, scale, gn_bias, slope,
                      gn_weight, (const float*)x, W, pre_am, pre_scale, pre_bias, pre_slope, prec == 1,
-                     raw, arg, out, stream);
+                     raw, argpos, arg, out, stream);
   SPT_CHECK_LAUNCH();
   return 0;
 }
 
 extern "C" int spt_fused_linear_bwd_pool_runs_f32(
-    const float* gout, const float* raw, const int32_t* arg, const int32_t* perm,
+    const float* gout, const float* raw, const int32_t* argpos, const int32_t* perm,
     const int32_t* pos_seg, const int64_t* seg_graph, int64_t num_seg, int nruns,
     const int64_t* run_p0, const int64_t* run_p1, const int32_t* run_graph, int num_graphs, int N,
     const float* am, const float* scale, const float* bias, float slope, const float* c1,
@@ -1908,7 +1908,7 @@ extern "C" int spt_fused_linear_bwd_pool_runs_f32(
   const bool x16 = mode >= 0 && (mode & SPT_FMLP_X_BF16);
   SPT_CHECK_ARG(fpool_supported(K, N) && prec != 0 && (!x16 || prec == 1),
                 "(K, N) has no pool-fused kernel in this matrix mode");
-  SPT_CHECK_ARG(gout && raw && arg && pos_seg && am && scale && bias && c1 && c2 && c3 && xprev &&
+  SPT_CHECK_ARG(gout && raw && argpos && pos_seg && am && scale && bias && c1 && c2 && c3 && xprev &&
                 pre_am && pre_scale && pre_bias && W && gram && gm && gx && gW && prev_total && ws,
                 "null pointer");
   SPT_CHECK_ARG(num_seg >= 0 && (num_graphs == 1 || seg_graph), "bad shape");
@@ -1917,7 +1917,7 @@ extern "C" int spt_fused_linear_bwd_pool_runs_f32(
   double* pst = (double*)((char*)ws + align_up((size_t)MAX_BWD_WAVES * N * K * 4, 256));
   float* Mbuf = (float*)((char*)ws + align_up(spt_fused_linear_workspace_bytes(K, N), 256));
   float* c0buf = Mbuf + (size_t)FMLP_MAX_RUNS * K * K;
-  const int per_run = fpool_bwd_launch(prec != 1, x16, gout, raw, arg, perm, pos_seg, seg_graph, num_seg,
+  const int per_run = fpool_bwd_launch(prec != 1, x16, gout, raw, argpos, perm, pos_seg, seg_graph, num_seg,
                                        rt, max_rows, num_graphs, K, N, am, scale, bias, slope, c1, c2, c3,
                                        (const float*)xprev, pre_am, pre_scale, pre_bias, pre_slope, W, gm,
                                        Mbuf, c0buf, gx, gwp, pst, MAX_BWD_WAVES, stream);

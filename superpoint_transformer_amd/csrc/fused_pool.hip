@@ -99,16 +99,16 @@ __device__ __forceinline__ f32x4 mfma16(const bf16x4& a, const bf16x4& b, f32x4 
                                                    __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
 }
 
-// Stage the 16 gathered rows x[rid] (rid of tile row rr in lane rr of `rid_l`) of K f32 / bf16
-// values into LDS (row stride LD floats), applying y = leaky((v - am) sc + bs) on the way in
-// (tab = am | sc | bs, K floats each; the expression of gn_apply_fwd_kernel).  Rows >= cnt
-// become 0.  All loads of the tile are issued before the first is used: one round trip.
-template <int K, int LD, bool X16>
-__device__ __forceinline__ void stage_rows(const float* __restrict__ x, int rid_l, int cnt,
-                                           const float* tab, float slope, float* lds, int lane) {
+// The 16 gathered rows x[rid] (rid of tile row rr in lane rr of `rid_l`) of K f32 / bf16 values:
+// load_rows requests them into registers (all loads of the tile back to back: one round trip, and
+// - issued a tile ahead - the trip runs under the previous tile's arithmetic), store_rows writes
+// them to LDS (row stride LD floats), applying y = leaky((v - am) sc + bs) on the way when PRE
+// (tab = am | sc | bs, K floats each; the expression of gn_apply_fwd_kernel).  Rows >= cnt are 0.
+template <int K, bool X16>
+__device__ __forceinline__ void load_rows(const float* __restrict__ x, int rid_l, int cnt,
+                                          float4 (&v)[TR * (K / 4) / 64], int lane) {
   constexpr int CH = K / 4, NIT = TR * CH / 64;
   static_assert(TR * CH % 64 == 0, "whole waves of chunks");
-  float4 v[NIT];
 #pragma unroll
   for (int j = 0; j < NIT; ++j) {
     const int q = lane + 64 * j, rr = q / CH, k = (q - rr * CH) << 2;
@@ -116,11 +116,16 @@ __device__ __forceinline__ void stage_rows(const float* __restrict__ x, int rid_
     v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (rr < cnt) v[j] = ld4<X16>(x, xr * K + k);
   }
+}
+template <int K, int LD, bool PRE>
+__device__ __forceinline__ void store_rows(const float4 (&v)[TR * (K / 4) / 64], int cnt,
+                                           const float* tab, float slope, float* lds, int lane) {
+  constexpr int CH = K / 4, NIT = TR * CH / 64;
 #pragma unroll
   for (int j = 0; j < NIT; ++j) {
     const int q = lane + 64 * j, rr = q / CH, k = (q - rr * CH) << 2;
     float4 w = v[j];
-    if (rr < cnt) {
+    if (PRE && rr < cnt) {
       const float4 a = *reinterpret_cast<const float4*>(tab + k);
       const float4 s = *reinterpret_cast<const float4*>(tab + K + k);
       const float4 b = *reinterpret_cast<const float4*>(tab + 2 * K + k);
@@ -159,7 +164,7 @@ __global__ __launch_bounds__(NWF * 64, 2) void fwd_pool_kernel(
     const int32_t* __restrict__ pos_seg, const int32_t* __restrict__ rowptr,
     const float* __restrict__ W, const float* __restrict__ gnw, const float* __restrict__ pam,
     const float* __restrict__ psc, const float* __restrict__ pbs, float pslope,
-    float* __restrict__ raw, int32_t* __restrict__ arg, double* __restrict__ partial, FmlpRuns rt) {
+    float* __restrict__ raw, int32_t* __restrict__ argpos, double* __restrict__ partial, FmlpRuns rt) {
   constexpr int KS = K / 32, KB = K / 16, NBK = N / 16, LDA = K + 4, LDW = K + 8;
   constexpr int NPL = PREC == 3 ? 3 : (PREC == 2 ? 2 : 1);
   constexpr int NGB = KB * (KB + 1) / 2;                 // upper-triangular 16 x 16 blocks of G
@@ -213,21 +218,23 @@ __global__ __launch_bounds__(NWF * 64, 2) void fwd_pool_kernel(
   float sy[KB];
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb) sy[kb] = 0.f;
-  // the wave's partial maximum of the open segment: its own rows (4 g + r of every tile) only;
-  // the four lane groups meet when the segment closes
+  // the wave's partial maximum of the open segment: its own rows (4 g + r of every tile) only,
+  // with the CSR POSITION of the winner (inside a segment the positions ascend with the original
+  // row ids - the view is a stable sort - so "first occurrence" is "smallest position"); the four
+  // lane groups meet when the segment closes
   float pm[NBK];
-  int pa[NBK];
+  int pp[NBK];
 #pragma unroll
   for (int nb = 0; nb < NBK; ++nb) {
     pm[nb] = -INFINITY;
-    pa[nb] = ARG_NONE;
+    pp[nb] = ARG_NONE;
   }
   int cur_seg = -1;
   auto flush = [&](int seg) {
 #pragma unroll
     for (int nb = 0; nb < NBK; ++nb) {
       float m = pm[nb];
-      int a = pa[nb];
+      int a = pp[nb];
 #pragma unroll
       for (int off = 16; off <= 32; off <<= 1) {
         const float om = __shfl_xor(m, off, 64);
@@ -239,10 +246,10 @@ __global__ __launch_bounds__(NWF * 64, 2) void fwd_pool_kernel(
       if ((nb & 3) == g) {                                   // the four groups share the stores
         const size_t o = (size_t)seg * N + 16 * nb + c;
         raw[o] = m * sgn_l[16 * nb + c];
-        arg[o] = a;
+        argpos[o] = a;
       }
       pm[nb] = -INFINITY;
-      pa[nb] = ARG_NONE;
+      pp[nb] = ARG_NONE;
     }
   };
 
@@ -260,11 +267,20 @@ __global__ __launch_bounds__(NWF * 64, 2) void fwd_pool_kernel(
   };
   int rid_l, seg_l, rid_n, seg_n;
   ids_of(pa0, rid_l, seg_l);
+  float4 xv[TR * (K / 4) / 64];                 // raw rows of the tile about to be staged
+  if (pa0 < pb0) load_rows<K, IN16>(x, rid_l, (int)((pb0 - pa0) < TR ? (pb0 - pa0) : TR), xv, lane);
+  ids_of(pa0 + TR, rid_n, seg_n);
   for (int64_t p = pa0; p < pb0; p += TR) {
     const int cnt = (int)((pb0 - p) < TR ? (pb0 - p) : TR);
-    ids_of(p + TR, rid_n, seg_n);
     wave_sync_lds();
-    stage_rows<K, LDA, IN16>(x, rid_l, cnt, tab, pslope, al, lane);
+    store_rows<K, LDA, true>(xv, cnt, tab, pslope, al, lane);
+    // the NEXT tile's rows travel while this one is multiplied; the ids of the tile after it too
+    int rid_nn, seg_nn;
+    {
+      const int64_t pn = p + TR;
+      if (pn < pb0) load_rows<K, IN16>(x, rid_n, (int)((pb0 - pn) < TR ? (pb0 - pn) : TR), xv, lane);
+      ids_of(pn + TR, rid_nn, seg_nn);
+    }
     wave_sync_lds();
     // ---- h' = y_prev W'^T ------------------------------------------------------------------
     f32x4 C[NBK];
@@ -334,6 +350,9 @@ __global__ __launch_bounds__(NWF * 64, 2) void fwd_pool_kernel(
         for (int ni = mi; ni < KB; ++ni) {
           f32x4 acc = GA[gi];
           if constexpr (PREC != 1) {
+            // (lo lo too: on the diagonal it is a sum of squares - dropped, E[h^2] would sit a
+            // systematic 1.3e-6 low; with it the split's error is zero-mean)
+            acc = mfma16(Yl[mi], Yl[ni], acc);
             acc = mfma16(Yl[mi], Yh[ni], acc);
             acc = mfma16(Yh[mi], Yl[ni], acc);
           }
@@ -343,9 +362,7 @@ __global__ __launch_bounds__(NWF * 64, 2) void fwd_pool_kernel(
     }
     // ---- segment max of the raw tile ---------------------------------------------------------
     {
-      int rid4[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) rid4[r] = __shfl(rid_l, 4 * g + r, 64);
+      const int pos0 = (int)p + 4 * g;                            // position of the lane's row r = 0
       int row = 0;
       while (row < cnt) {
         const int s = __builtin_amdgcn_readlane(seg_l, row);
@@ -363,7 +380,7 @@ __global__ __launch_bounds__(NWF * 64, 2) void fwd_pool_kernel(
               const float v = C[nb][r];
               const bool win = v > pm[nb];
               pm[nb] = win ? v : pm[nb];
-              pa[nb] = win ? rid4[r] : pa[nb];
+              pp[nb] = win ? pos0 + r : pp[nb];
             }
         } else {
 #pragma unroll
@@ -375,7 +392,7 @@ __global__ __launch_bounds__(NWF * 64, 2) void fwd_pool_kernel(
               const float v = in ? C[nb][r] : -INFINITY;
               const bool win = v > pm[nb];
               pm[nb] = win ? v : pm[nb];
-              pa[nb] = win ? rid4[r] : pa[nb];
+              pp[nb] = win ? pos0 + r : pp[nb];
             }
           }
         }
@@ -384,6 +401,8 @@ __global__ __launch_bounds__(NWF * 64, 2) void fwd_pool_kernel(
     }
     rid_l = rid_n;
     seg_l = seg_n;
+    rid_n = rid_nn;
+    seg_n = seg_nn;
   }
   if (cur_seg >= 0) flush(cur_seg);
 
@@ -419,8 +438,9 @@ __global__ __launch_bounds__(NWF * 64, 2) void fwd_pool_kernel(
 }
 
 // ---- statistics and coefficient rows of the norm from the Gram totals ----------------------------
-// gram [B][K K + K + 1] (G | column sums | row count); one block per graph, one thread per
-// channel.  Same formulas and roundings as gn_fwd_tables_kernel (graphnorm.hip).
+// gram [B][K K + K + 1] (G | column sums | row count).  grid = (ceil(N / CPB), B); a block of
+// CPB x K threads: thread (c, j) forms w_j (G w)_j and w_j sy_j of channel c, a tree over j sums
+// them (f64, fixed order).  Same formulas and roundings as gn_fwd_tables_kernel (graphnorm.hip).
 // BFW: the product ran on bf16(W) (the bf16 mode) - the statistics are those of what it computed.
 template <int K>
 __global__ __launch_bounds__(256) void gram_tables_kernel(
@@ -428,55 +448,65 @@ __global__ __launch_bounds__(256) void gram_tables_kernel(
     const float* __restrict__ weight, const float* __restrict__ mean_scale, float eps,
     double* __restrict__ total, float* __restrict__ mean, float* __restrict__ rstd,
     float* __restrict__ am, float* __restrict__ scale) {
-  constexpr int GLEN = K * K + K + 1;
+  constexpr int GLEN = K * K + K + 1, CPB = 256 / K;
   __shared__ double gl[K * K + K];
-  extern __shared__ float wl[];                          // W [N, K] as the product saw it
-  const int b = blockIdx.x;
+  __shared__ double wl[CPB][K];
+  __shared__ double r1[CPB][K], r2[CPB][K];
+  const int b = blockIdx.y;
   const double* gr = gram + (size_t)b * GLEN;
-  for (int i = threadIdx.x; i < K * K + K; i += blockDim.x) gl[i] = gr[i];
-  for (int i = threadIdx.x; i < N * K; i += blockDim.x) {
-    const float w = W[i];
-    wl[i] = bfw ? (float)(__bf16)w : w;
+  for (int i = threadIdx.x; i < K * K + K; i += 256) gl[i] = gr[i];
+  const int cl = threadIdx.x / K, j = threadIdx.x - cl * K;
+  const int c = blockIdx.x * CPB + cl;
+  {
+    float w = c < N ? W[(size_t)c * K + j] : 0.f;
+    if (bfw) w = (float)(__bf16)w;
+    wl[cl][j] = (double)w;
   }
   __syncthreads();
+  double t = 0.0;
+#pragma unroll 8
+  for (int k = 0; k < K; ++k) t += gl[j * K + k] * wl[cl][k];
+  r2[cl][j] = wl[cl][j] * t;
+  r1[cl][j] = wl[cl][j] * gl[K * K + j];
+  __syncthreads();
+  for (int st = K / 2; st > 0; st >>= 1) {
+    if (j < st) {
+      r1[cl][j] += r1[cl][j + st];
+      r2[cl][j] += r2[cl][j + st];
+    }
+    __syncthreads();
+  }
+  if (j != 0 || c >= N) return;
   double n = gr[K * K + K];
   const double nraw = n;
   if (n < 1.0) n = 1.0;
-  for (int c = threadIdx.x; c < N; c += blockDim.x) {
-    const float* wv = wl + (size_t)c * K;
-    double s1 = 0.0, s2 = 0.0;
-    for (int j = 0; j < K; ++j) {
-      double t = 0.0;
-#pragma unroll 8
-      for (int k = 0; k < K; ++k) t += gl[j * K + k] * (double)wv[k];
-      s2 += (double)wv[j] * t;
-      s1 += (double)wv[j] * gl[K * K + j];
-    }
-    if (s2 < 0.0) s2 = 0.0;
-    if (total) {
-      double* tr = total + (size_t)b * (2 * N + 1);
-      tr[c] = s1;
-      tr[N + c] = s2;
-      if (c == 0) tr[2 * N] = nraw;
-    }
-    const double mu = s1 / n;
-    const double a = (double)mean_scale[c];
-    double var = s2 / n - (2.0 * a - a * a) * mu * mu;
-    if (var < 0.0) var = 0.0;
-    const double rs = 1.0 / sqrt(var + (double)eps);
-    const float mu32 = (float)mu, rs32 = (float)rs;
-    const int t = b * N + c;
-    mean[t] = mu32;
-    rstd[t] = rs32;
-    am[t] = (float)(a * (double)mu32);
-    scale[t] = (float)((double)weight[c] * (double)rs32);
+  const double s1 = r1[cl][0];
+  double s2 = r2[cl][0];
+  if (s2 < 0.0) s2 = 0.0;
+  if (total) {
+    double* tr = total + (size_t)b * (2 * N + 1);
+    tr[c] = s1;
+    tr[N + c] = s2;
+    if (c == 0) tr[2 * N] = nraw;
   }
+  const double mu = s1 / n;
+  const double a = (double)mean_scale[c];
+  double var = s2 / n - (2.0 * a - a * a) * mu * mu;
+  if (var < 0.0) var = 0.0;
+  const double rs = 1.0 / sqrt(var + (double)eps);
+  const float mu32 = (float)mu, rs32 = (float)rs;
+  const int o = b * N + c;
+  mean[o] = mu32;
+  rstd[o] = rs32;
+  am[o] = (float)(a * (double)mu32);
+  scale[o] = (float)((double)weight[c] * (double)rs32);
 }
 
 // ---- out = y(raw); empty segments; channels whose norm weight is exactly 0 ------------------------
-// one thread per (segment, channel).  w_c == 0: y is the constant leaky(bias_c) - every row ties and
-// the reference's arg is the segment's first row; its raw value (the norm's weight gradient needs
-// the true h of the arg row) is rebuilt from that row of x.
+// one thread per (segment, channel): arg = the original row of the winner's CSR position.
+// w_c == 0: y is the constant leaky(bias_c) - every row ties and the reference's arg is the
+// segment's first row; its raw value (the norm's weight gradient needs the true h of the arg row)
+// is rebuilt from that row of x.
 template <int K, bool IN16>
 __global__ __launch_bounds__(256) void pool_apply_kernel(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ perm,
@@ -485,7 +515,7 @@ __global__ __launch_bounds__(256) void pool_apply_kernel(
     float slope, const float* __restrict__ gnw, const float* __restrict__ x,
     const float* __restrict__ W, const float* __restrict__ pam, const float* __restrict__ psc,
     const float* __restrict__ pbs, float pslope, int bfw, float* __restrict__ raw,
-    int32_t* __restrict__ arg, float* __restrict__ out) {
+    int32_t* __restrict__ argpos, int32_t* __restrict__ arg, float* __restrict__ out) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= num_seg * N) return;
   const int64_t s = t / N;
@@ -495,11 +525,14 @@ __global__ __launch_bounds__(256) void pool_apply_kernel(
     out[t] = 0.f;
     raw[t] = 0.f;
     arg[t] = (int32_t)n_rows;
+    argpos[t] = (int32_t)n_rows;
     return;
   }
   const int64_t gph = seg_graph ? seg_graph[s] : 0;
   float h = raw[t];
+  int pos = argpos[t];
   if (gnw[c] == 0.f) {
+    pos = a0;
     const int row = perm ? perm[a0] : a0;
     double acc = 0.0;
     for (int k = 0; k < K; ++k) {
@@ -516,8 +549,10 @@ __global__ __launch_bounds__(256) void pool_apply_kernel(
     }
     h = (float)acc;
     raw[t] = h;
-    arg[t] = row;
+    argpos[t] = pos;
   }
+  // (no row won - every value NaN: the sentinel of an empty segment)
+  arg[t] = (pos >= a0 && pos < a1) ? (perm ? perm[pos] : pos) : (int32_t)n_rows;
   float y = fmaf(h - am[gph * N + c], sc[gph * N + c], bs[c]);   // gn_apply_fwd_kernel's expression
   y = y > 0.f ? y : y * slope;
   out[t] = y;
@@ -617,15 +652,25 @@ __global__ __launch_bounds__(256) void pool_bwd_gw_dense_kernel(
 }
 
 // ---- backward, main kernel ------------------------------------------------------------------------
-// Tiles walk the rows in the pool's CSR order.  S tile (f32, LDS) = gm where arg == row else 0;
-// gW += S^T y_prev (16x16x16, contraction = the tile's rows), gy = S W + y_prev M + c0
-// (16x16x32, W^T and M as split-bf16 rows in LDS), then - as every fused layer's backward - the
-// rows leave as the gradient of the previous layer's normalised output and the two sums its
-// GraphNorm backward needs (sum g', sum g' o') fall out of the same registers.
+// Tiles walk the rows in the pool's CSR order.  S tile (f32, LDS) = gm where the winner's CSR
+// position is this row, else 0: the tile is zero-filled and the (gm, argpos) rows of the segments
+// it touches - one or two at 35 rows per segment - are SCATTERED into it (a lane owns N / 64
+// channels; no search, no compare per (row, channel)).  gW += S^T y_prev (16x16x16, contraction =
+// the tile's rows), gy = S W + y_prev M + c0 (16x16x32, W^T and M as split-bf16 rows in LDS), then
+// - as every fused layer's backward - the rows leave as the gradient of the previous layer's
+// normalised output and the two sums its GraphNorm backward needs (sum g', sum g' o') fall out of
+// the same registers.  The gathered x rows of the NEXT tile are requested before this tile's
+// GEMMs (one HBM round trip per tile, under the arithmetic).
+// WAVE PAIRS: the 128 x 64 weight-gradient accumulators are 128 registers per lane - with them a
+// wave has no room for the next tile's rows in flight and spills (measured: 78 % of the wave
+// cycles parked on memory).  Two waves of a pair therefore walk the SAME tiles: each stages the
+// tile into its own LDS buffers (the second read of a row is an L2 hit; no hand-shake between
+// the two is needed) and owns HALF of the output - the gW rows of N / 2 channels and K / 2 columns
+// of gy.  Per wave: 64 + 8 accumulators, ~150 registers, nothing spilled.
 // LO: split operands (hi + lo, 3 products);  X16: xprev holds bf16 values.
 template <int K, int N, bool LO, bool X16, int NW>
 __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_pool_kernel(
-    const float* __restrict__ gm, const int32_t* __restrict__ arg,
+    const float* __restrict__ gm, const int32_t* __restrict__ argpos,
     const int32_t* __restrict__ perm, const int32_t* __restrict__ pos_seg,
     const float* __restrict__ xprev, const float* __restrict__ pam,
     const float* __restrict__ psc, const float* __restrict__ pbs, float pslope,
@@ -633,8 +678,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_pool_kernel(
     float* __restrict__ gx, float* __restrict__ gw_partial, double* __restrict__ pstat_partial,
     FmlpRuns rt) {
   constexpr int KB = K / 16, NBK = N / 16, NS = N / 32, KS = K / 32;
+  constexpr int NBH = NBK / 2, KBH = KB / 2;             // a wave's half of the outputs
   constexpr int LDG = N + 4, LDX = K + 4, LDT = N + 8, LDM = K + 8;
-  static_assert(K % 32 == 0 && N % 32 == 0, "shape");
+  constexpr int CPL = N / 64;                            // channels a lane scatters per segment
+  static_assert(K % 32 == 0 && N % 64 == 0 && NW % 2 == 0, "shape");
   __shared__ __attribute__((aligned(16))) float g_lds[NW][TR * LDG];   // S tile
   __shared__ __attribute__((aligned(16))) float x_lds[NW][TR * LDX];   // RAW xprev tile
   __shared__ __attribute__((aligned(16))) __bf16 wt_hi[K * LDT];       // wt[k][n] = W[n][k]
@@ -645,6 +692,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_pool_kernel(
   __shared__ __attribute__((aligned(16))) float c0l[K];
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int hf = wid & 1;                                // which half of the outputs
+  const int nb0 = hf * NBH, kb0 = hf * KBH;
   const int g = lane >> 4, c = lane & 15;
   const int run = blockIdx.y, gph = rt.g[run];
   const int64_t r0 = rt.r0[run], r1 = rt.r1[run];
@@ -652,8 +701,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_pool_kernel(
   psc += (size_t)gph * K;
   Mg += (size_t)gph * K * K;
   c0g += (size_t)gph * K;
-  gw_partial += (size_t)run * gridDim.x * NW * N * K;
-  pstat_partial += (size_t)run * gridDim.x * NW * (2 * K + 1);
+  gw_partial += (size_t)run * gridDim.x * (NW / 2) * N * K;
+  pstat_partial += (size_t)run * gridDim.x * (NW / 2) * (2 * K + 1);
   float* gl = g_lds[wid];
   float* xl = x_lds[wid];
   for (int i = threadIdx.x; i < K * N; i += NW * 64) {
@@ -678,86 +727,79 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_pool_kernel(
   }
   __syncthreads();
 
-  f32x4 C3[NBK][KB];       // C3[nb][kb][r] = gW[16 nb + 4 g + r][16 kb + c]
+  f32x4 C3[NBH][KB];       // C3[j][kb][r] = gW[16 (nb0 + j) + 4 g + r][16 kb + c]
 #pragma unroll
-  for (int nb = 0; nb < NBK; ++nb)
+  for (int nb = 0; nb < NBH; ++nb)
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) C3[nb][kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  double p1[KB], p2[KB];
+  double p1[KBH], p2[KBH];
 #pragma unroll
-  for (int kb = 0; kb < KB; ++kb) p1[kb] = p2[kb] = 0.0;
+  for (int kb = 0; kb < KBH; ++kb) p1[kb] = p2[kb] = 0.0;
 
   const int64_t ntiles = (r1 - r0 + TR - 1) / TR;
-  const int64_t wave = (int64_t)blockIdx.x * NW + wid;
-  const int64_t nwaves = (int64_t)gridDim.x * NW;
-  int rid_n = 0, seg_n = 0;
-  auto load_ids = [&](int64_t t) {
-    rid_n = seg_n = 0;
+  const int64_t pair = (int64_t)blockIdx.x * (NW / 2) + (wid >> 1);
+  const int64_t npairs = (int64_t)gridDim.x * (NW / 2);
+  auto cnt_of = [&](int64_t t) {
+    const int64_t row0 = r0 + t * TR;
+    return (t < ntiles) ? (int)((r1 - row0) < TR ? (r1 - row0) : TR) : 0;
+  };
+  auto load_ids = [&](int64_t t, int& rid, int& sg) {
+    rid = 0;
+    sg = -1;
     const int64_t rowf = r0 + t * TR;
     if (t < ntiles && rowf + lane < r1 && lane < TR) {
-      rid_n = perm ? perm[rowf + lane] : (int)(rowf + lane);
-      seg_n = pos_seg[rowf + lane];
+      rid = perm ? perm[rowf + lane] : (int)(rowf + lane);
+      sg = pos_seg[rowf + lane];
     }
   };
-  load_ids(wave);
-  int rid_l = rid_n, seg_l = seg_n;
-  load_ids(wave + nwaves);
-  for (int64_t t = wave; t < ntiles; t += nwaves) {
+  int rid_l, seg_l, rid_n, seg_n;
+  load_ids(pair, rid_l, seg_l);
+  float4 xv[TR * (K / 4) / 64];                 // raw rows of the tile about to be staged
+  if (pair < ntiles) load_rows<K, X16>(xprev, rid_l, cnt_of(pair), xv, lane);
+  load_ids(pair + npairs, rid_n, seg_n);
+  for (int64_t t = pair; t < ntiles; t += npairs) {
     const int64_t row0 = r0 + t * TR;
-    const int cnt = (int)((r1 - row0) < TR ? (r1 - row0) : TR);
+    const int cnt = cnt_of(t);
     wave_sync_lds();
-    // ---- S tile: (gm, arg) rows of the segments this tile touches, out of L1 / L2 --------------
+    // ---- S tile: zero, then the (gm, argpos) rows of the tile's segments scattered into it ------
     {
-      constexpr int CH = N / 4, NIT = TR * CH / 64, GS = NIT < 4 ? NIT : 4;
-      static_assert(TR * CH % 64 == 0 && NIT % GS == 0, "whole groups of chunks");
-#pragma unroll 1
-      for (int i0 = 0; i0 < NIT; i0 += GS) {
-        float4 gv[GS];
-        int4 av[GS];
-        int ridv[GS];
+      constexpr int NZ = TR * (N / 4) / 64;
 #pragma unroll
-        for (int j = 0; j < GS; ++j) {
-          const int q = lane + 64 * (i0 + j), rr = q / CH, n = (q - rr * CH) << 2;
-          ridv[j] = __shfl(rid_l, rr, 64);
-          const int64_t sg = (int64_t)__shfl(seg_l, rr, 64);
-          gv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-          av[j] = make_int4(-1, -1, -1, -1);
-          if (rr < cnt) {
-            av[j] = *reinterpret_cast<const int4*>(arg + sg * N + n);
-            gv[j] = *reinterpret_cast<const float4*>(gm + sg * N + n);
-          }
+      for (int j = 0; j < NZ; ++j) {
+        const int q = lane + 64 * j, rr = q / (N / 4), n = (q - rr * (N / 4)) << 2;
+        *reinterpret_cast<float4*>(gl + rr * LDG + n) = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      int row = 0;
+      while (row < cnt) {
+        const int sgm = __builtin_amdgcn_readlane(seg_l, row);
+        const uint64_t diff = __ballot(lane < cnt && lane > row && seg_l != sgm);
+        const int e = diff ? (int)__builtin_ctzll(diff) : cnt;   // rows [row, e) belong to sgm
+        const size_t o = (size_t)sgm * N + CPL * lane;
+        int ap[CPL];
+        float gv[CPL];
+        if constexpr (CPL == 2) {
+          const int2 a2 = *reinterpret_cast<const int2*>(argpos + o);
+          const float2 g2 = *reinterpret_cast<const float2*>(gm + o);
+          ap[0] = a2.x; ap[1] = a2.y;
+          gv[0] = g2.x; gv[1] = g2.y;
+        } else {
+          ap[0] = argpos[o];
+          gv[0] = gm[o];
         }
 #pragma unroll
-        for (int j = 0; j < GS; ++j) {
-          const int q = lane + 64 * (i0 + j), rr = q / CH, n = (q - rr * CH) << 2;
-          const int rid = ridv[j];
-          const float4 v = make_float4(av[j].x == rid ? gv[j].x : 0.f, av[j].y == rid ? gv[j].y : 0.f,
-                                       av[j].z == rid ? gv[j].z : 0.f, av[j].w == rid ? gv[j].w : 0.f);
-          *reinterpret_cast<float4*>(gl + rr * LDG + n) = v;
+        for (int q = 0; q < CPL; ++q) {
+          const int rr = ap[q] - (int)row0;
+          if (rr >= row && rr < e) gl[rr * LDG + CPL * lane + q] = gv[q];
         }
+        row = e;
       }
     }
     // ---- RAW xprev tile (gathered rows; rows >= cnt zero) ---------------------------------------
-    {
-      constexpr int CHX = K / 4, NITX = TR * CHX / 64;
-      float4 v[NITX];
-#pragma unroll
-      for (int j = 0; j < NITX; ++j) {
-        const int q = lane + 64 * j, rr = q / CHX, k = (q - rr * CHX) << 2;
-        const int64_t xr = (int64_t)__shfl(rid_l, rr, 64);
-        v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (rr < cnt) v[j] = ld4<X16>(xprev, xr * K + k);
-      }
-#pragma unroll
-      for (int j = 0; j < NITX; ++j) {
-        const int q = lane + 64 * j, rr = q / CHX, k = (q - rr * CHX) << 2;
-        *reinterpret_cast<float4*>(xl + rr * LDX + k) = v[j];
-      }
-    }
+    store_rows<K, LDX, false>(xv, cnt, nullptr, 1.f, xl, lane);
     const int rid_cur = rid_l;                 // the gx scatter below needs this tile's row ids
-    rid_l = rid_n;
-    seg_l = seg_n;
-    load_ids(t + 2 * nwaves);
+    int rid_nn, seg_nn;
+    if (t + npairs < ntiles) load_rows<K, X16>(xprev, rid_n, cnt_of(t + npairs), xv, lane);
+    load_ids(t + 2 * npairs, rid_nn, seg_nn);
     wave_sync_lds();
     // y_prev of one raw value (rows >= cnt: 0)
     auto ynorm = [&](float v, int k, bool ok) {
@@ -765,27 +807,27 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_pool_kernel(
       v = (v > 0.f) ? v : v * pslope;
       return ok ? v : 0.f;
     };
-    // ---- gW += S^T y_prev ----------------------------------------------------------------------
+    // ---- gW[this half's rows] += S^T y_prev -------------------------------------------------------
     {
       bf16x4 Xh[KB], Xl[KB];
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb) {
         const int k = 16 * kb + c;
-        float xv[4];
+        float xr4[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) xv[r] = ynorm(xl[(4 * g + r) * LDX + k], k, 4 * g + r < cnt);
+        for (int r = 0; r < 4; ++r) xr4[r] = ynorm(xl[(4 * g + r) * LDX + k], k, 4 * g + r < cnt);
         if constexpr (LO) {
-          split2<4>(xv, Xh[kb], Xl[kb]);
+          split2<4>(xr4, Xh[kb], Xl[kb]);
         } else {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) Xh[kb][r] = (__bf16)xv[r];
+          for (int r = 0; r < 4; ++r) Xh[kb][r] = (__bf16)xr4[r];
         }
       }
 #pragma unroll
-      for (int nb = 0; nb < NBK; ++nb) {
+      for (int nb = 0; nb < NBH; ++nb) {
         float sv[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sv[r] = gl[(4 * g + r) * LDG + 16 * nb + c];
+        for (int r = 0; r < 4; ++r) sv[r] = gl[(4 * g + r) * LDG + 16 * (nb0 + nb) + c];
         bf16x4 sh, sl;
         if constexpr (LO) {
           split2<4>(sv, sh, sl);
@@ -804,12 +846,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_pool_kernel(
         }
       }
     }
-    // ---- gy = c0 + S W + y_prev M (+ statistics for the previous GraphNorm's backward) ----------
+    // ---- gy[this half's columns] = c0 + S W + y_prev M (+ statistics for the previous norm) ------
     {
-      f32x4 CX[KB];
+      f32x4 CX[KBH];
 #pragma unroll
-      for (int kb = 0; kb < KB; ++kb) {
-        const float z = c0l[16 * kb + c];
+      for (int kb = 0; kb < KBH; ++kb) {
+        const float z = c0l[16 * (kb0 + kb) + c];
         CX[kb] = (f32x4){z, z, z, z};
       }
 #pragma unroll
@@ -825,11 +867,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_pool_kernel(
           for (int i = 0; i < 8; ++i) ah[i] = (__bf16)av[i];
         }
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {
-          const bf16x8 bh = *reinterpret_cast<const bf16x8*>(wt_hi + (16 * kb + c) * LDT + 32 * sg + 8 * g);
+        for (int kb = 0; kb < KBH; ++kb) {
+          const int wo = (16 * (kb0 + kb) + c) * LDT + 32 * sg + 8 * g;
+          const bf16x8 bh = *reinterpret_cast<const bf16x8*>(wt_hi + wo);
           f32x4 acc = CX[kb];
           if constexpr (LO) {
-            const bf16x8 bl = *reinterpret_cast<const bf16x8*>(wt_lo + (16 * kb + c) * LDT + 32 * sg + 8 * g);
+            const bf16x8 bl = *reinterpret_cast<const bf16x8*>(wt_lo + wo);
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo, bh, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc, 0, 0, 0);
           }
@@ -852,11 +895,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_pool_kernel(
           for (int i = 0; i < 8; ++i) ah[i] = (__bf16)av[i];
         }
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {
-          const bf16x8 bh = *reinterpret_cast<const bf16x8*>(mt_hi + (16 * kb + c) * LDM + 32 * ks + 8 * g);
+        for (int kb = 0; kb < KBH; ++kb) {
+          const int mo = (16 * (kb0 + kb) + c) * LDM + 32 * ks + 8 * g;
+          const bf16x8 bh = *reinterpret_cast<const bf16x8*>(mt_hi + mo);
           f32x4 acc = CX[kb];
           if constexpr (LO) {
-            const bf16x8 bl = *reinterpret_cast<const bf16x8*>(mt_lo + (16 * kb + c) * LDM + 32 * ks + 8 * g);
+            const bf16x8 bl = *reinterpret_cast<const bf16x8*>(mt_lo + mo);
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo, bh, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc, 0, 0, 0);
           }
@@ -869,8 +913,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_pool_kernel(
         const int64_t orow = (int64_t)__shfl(rid_cur, rr, 64);
         if (rr < cnt) {
 #pragma unroll
-          for (int kb = 0; kb < KB; ++kb) {
-            const int k = 16 * kb + c;
+          for (int kb = 0; kb < KBH; ++kb) {
+            const int k = 16 * (kb0 + kb) + c;
             const float v = CX[kb][r];
             gx[orow * K + k] = v;
             const float o = xl[rr * LDX + k] - pt[k];
@@ -885,26 +929,31 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_pool_kernel(
         }
       }
     }
+    rid_l = rid_n;
+    seg_l = seg_n;
+    rid_n = rid_nn;
+    seg_n = seg_nn;
   }
-  float* gwp = gw_partial + (size_t)wave * N * K;
+  // one record per PAIR: each wave writes its rows of gW and its columns of the statistics
+  float* gwp = gw_partial + (size_t)pair * N * K;
 #pragma unroll
-  for (int nb = 0; nb < NBK; ++nb)
+  for (int nb = 0; nb < NBH; ++nb)
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        gwp[(size_t)(16 * nb + 4 * g + r) * K + 16 * kb + c] = C3[nb][kb][r];
-  double* pp = pstat_partial + (size_t)wave * (2 * K + 1);
+        gwp[(size_t)(16 * (nb0 + nb) + 4 * g + r) * K + 16 * kb + c] = C3[nb][kb][r];
+  double* pp = pstat_partial + (size_t)pair * (2 * K + 1);
 #pragma unroll
-  for (int kb = 0; kb < KB; ++kb) {
+  for (int kb = 0; kb < KBH; ++kb) {
     const double a = xg_sum_d(p1[kb]), b = xg_sum_d(p2[kb]);
-    const int k = 16 * kb + c;
+    const int k = 16 * (kb0 + kb) + c;
     if (g == 0) {
       pp[k] = a;
       pp[K + k] = b;
     }
   }
-  if (lane == 0) pp[2 * K] = (wave == 0) ? (double)(r1 - r0) : 0.0;
+  if (lane == 0 && hf == 0) pp[2 * K] = (pair == 0) ? (double)(r1 - r0) : 0.0;
 }
 
 }  // namespace fpool
@@ -935,7 +984,7 @@ int fpool_fwd_blocks(int64_t max_rows, int nruns) {
 int fpool_fwd_launch(int prec, bool in16, const float* x, const int32_t* perm, const int32_t* pos_seg,
                      const int32_t* rowptr, const FmlpRuns& rt, int64_t max_rows, int K, int N,
                      const float* W, const float* gnw, const float* pam, const float* psc,
-                     const float* pbs, float pslope, float* raw, int32_t* arg, double* partial,
+                     const float* pbs, float pslope, float* raw, int32_t* argpos, double* partial,
                      hipStream_t stream) {
   const int gx_ = fpool_fwd_blocks(max_rows, rt.n);
   const dim3 grid((unsigned)gx_, (unsigned)rt.n);
@@ -943,16 +992,16 @@ int fpool_fwd_launch(int prec, bool in16, const float* x, const int32_t* perm, c
   if (K == k && N == n) {                                                                         \
     if (prec == 3 && !in16)                                                                       \
       fpool::fwd_pool_kernel<k, n, 3, false><<<grid, fpool::NWF * 64, 0, stream>>>(               \
-          x, perm, pos_seg, rowptr, W, gnw, pam, psc, pbs, pslope, raw, arg, partial, rt);        \
+          x, perm, pos_seg, rowptr, W, gnw, pam, psc, pbs, pslope, raw, argpos, partial, rt);        \
     else if (prec == 2 && !in16)                                                                  \
       fpool::fwd_pool_kernel<k, n, 2, false><<<grid, fpool::NWF * 64, 0, stream>>>(               \
-          x, perm, pos_seg, rowptr, W, gnw, pam, psc, pbs, pslope, raw, arg, partial, rt);        \
+          x, perm, pos_seg, rowptr, W, gnw, pam, psc, pbs, pslope, raw, argpos, partial, rt);        \
     else if (prec == 1 && !in16)                                                                  \
       fpool::fwd_pool_kernel<k, n, 1, false><<<grid, fpool::NWF * 64, 0, stream>>>(               \
-          x, perm, pos_seg, rowptr, W, gnw, pam, psc, pbs, pslope, raw, arg, partial, rt);        \
+          x, perm, pos_seg, rowptr, W, gnw, pam, psc, pbs, pslope, raw, argpos, partial, rt);        \
     else if (prec == 1 && in16)                                                                   \
       fpool::fwd_pool_kernel<k, n, 1, true><<<grid, fpool::NWF * 64, 0, stream>>>(                \
-          x, perm, pos_seg, rowptr, W, gnw, pam, psc, pbs, pslope, raw, arg, partial, rt);        \
+          x, perm, pos_seg, rowptr, W, gnw, pam, psc, pbs, pslope, raw, argpos, partial, rt);        \
     else                                                                                          \
       return -1;                                                                                  \
   }
@@ -965,10 +1014,10 @@ void fpool_tables_launch(int K, const double* gram, int B, const float* W, int N
                          const float* weight, const float* mean_scale, float eps, double* total,
                          float* mean, float* rstd, float* am, float* scale, hipStream_t stream) {
   if (K == 64)
-    fpool::gram_tables_kernel<64><<<B, 128, (size_t)N * K * 4, stream>>>(gram, W, N, bfw, weight, mean_scale, eps,
+    fpool::gram_tables_kernel<64><<<dim3((N + 3) / 4, B), 256, 0, stream>>>(gram, W, N, bfw, weight, mean_scale, eps,
                                                          total, mean, rstd, am, scale);
   else
-    fpool::gram_tables_kernel<32><<<B, 128, (size_t)N * K * 4, stream>>>(gram, W, N, bfw, weight, mean_scale, eps,
+    fpool::gram_tables_kernel<32><<<dim3((N + 7) / 8, B), 256, 0, stream>>>(gram, W, N, bfw, weight, mean_scale, eps,
                                                          total, mean, rstd, am, scale);
 }
 
@@ -977,14 +1026,14 @@ void fpool_apply_launch(int K, bool in16, const int32_t* rowptr, const int32_t* 
                         const float* am, const float* sc, const float* bs, float slope,
                         const float* gnw, const float* x, const float* W, const float* pam,
                         const float* psc, const float* pbs, float pslope, int bfw, float* raw,
-                        int32_t* arg, float* out, hipStream_t stream) {
+                        int32_t* argpos, int32_t* arg, float* out, hipStream_t stream) {
   const int64_t total = num_seg * N;
   if (total <= 0) return;
   const int grid = (int)ceil_div(total, 256);
 #define XA(k, i16)                                                                                 \
   fpool::pool_apply_kernel<k, i16><<<grid, 256, 0, stream>>>(rowptr, perm, seg_graph, num_seg, N,  \
                                                              n_rows, am, sc, bs, slope, gnw, x, W, \
-                                                             pam, psc, pbs, pslope, bfw, raw, arg, out)
+                                                             pam, psc, pbs, pslope, bfw, raw, argpos, arg, out)
   if (K == 64) { if (in16) XA(64, true); else XA(64, false); }
   else { if (in16) XA(32, true); else XA(32, false); }
 #undef XA
@@ -992,7 +1041,7 @@ void fpool_apply_launch(int K, bool in16, const int32_t* rowptr, const int32_t* 
 
 // backward: gm, coefficient matrices, main kernel.  Returns wave records per run (gW / statistics
 // partial tables), or -1 for an unbuilt variant.
-int fpool_bwd_launch(bool lo, bool x16, const float* gout, const float* raw, const int32_t* arg,
+int fpool_bwd_launch(bool lo, bool x16, const float* gout, const float* raw, const int32_t* argpos,
                      const int32_t* perm, const int32_t* pos_seg, const int64_t* seg_graph,
                      int64_t num_seg, const FmlpRuns& rt, int64_t max_rows, int num_graphs, int K,
                      int N, const float* am, const float* sc, const float* bs, float slope,
@@ -1009,9 +1058,9 @@ int fpool_bwd_launch(bool lo, bool x16, const float* gout, const float* raw, con
     fpool::pool_bwd_coef_kernel<32><<<num_graphs, 256, 2 * N * sizeof(float), stream>>>(W, N, am, c2, c3, Mbuf, c0buf);
   constexpr int NW = 8;
   const int64_t tiles = (max_rows + fpool::TR - 1) / fpool::TR;
-  int64_t blocks = (tiles + NW - 1) / NW;
+  int64_t blocks = (tiles + NW / 2 - 1) / (NW / 2);         // a tile is walked by a pair of waves
   int64_t cap = (K * N > 4096) ? 256 : 512;               // 64 -> 128: one 8-wave workgroup per CU
-  const int64_t cap_ws = max_waves / (NW * rt.n);
+  const int64_t cap_ws = max_waves / ((NW / 2) * rt.n);    // one record per wave PAIR
   if (cap > cap_ws) cap = cap_ws;
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
@@ -1020,22 +1069,22 @@ int fpool_bwd_launch(bool lo, bool x16, const float* gout, const float* raw, con
   if (K == k && N == n) {                                                                         \
     if (lo && !x16)                                                                               \
       fpool::bwd_pool_kernel<k, n, true, false, NW><<<grid, NW * 64, 0, stream>>>(                \
-          gm, arg, perm, pos_seg, xprev, pam, psc, pbs, pslope, W, Mbuf, c0buf, gx, gw_partial,   \
+          gm, argpos, perm, pos_seg, xprev, pam, psc, pbs, pslope, W, Mbuf, c0buf, gx, gw_partial,   \
           pstat_partial, rt);                                                                     \
     else if (!lo && !x16)                                                                         \
       fpool::bwd_pool_kernel<k, n, false, false, NW><<<grid, NW * 64, 0, stream>>>(               \
-          gm, arg, perm, pos_seg, xprev, pam, psc, pbs, pslope, W, Mbuf, c0buf, gx, gw_partial,   \
+          gm, argpos, perm, pos_seg, xprev, pam, psc, pbs, pslope, W, Mbuf, c0buf, gx, gw_partial,   \
           pstat_partial, rt);                                                                     \
     else if (!lo && x16)                                                                          \
       fpool::bwd_pool_kernel<k, n, false, true, NW><<<grid, NW * 64, 0, stream>>>(                \
-          gm, arg, perm, pos_seg, xprev, pam, psc, pbs, pslope, W, Mbuf, c0buf, gx, gw_partial,   \
+          gm, argpos, perm, pos_seg, xprev, pam, psc, pbs, pslope, W, Mbuf, c0buf, gx, gw_partial,   \
           pstat_partial, rt);                                                                     \
     else                                                                                          \
       return -1;                                                                                  \
   }
   SPT_FPOOL_SHAPES(X)
 #undef X
-  return (int)blocks * NW;
+  return (int)blocks * (NW / 2);
 }
 
 void fpool_gw_dense_launch(int K, const double* gram, int B, const float* W, int N, int bfw,

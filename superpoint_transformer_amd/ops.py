@@ -1663,6 +1663,7 @@ class _FusedMLPMaxPool(torch.autograd.Function):
         nr, c_r0, c_r1, c_g = runs.c_arrays()
         out = torch.empty((S, N), dtype=torch.float32, device=dev)
         arg = torch.empty((S, N), dtype=torch.int32, device=dev)
+        argpos = torch.empty((S, N), dtype=torch.int32, device=dev)
         raw = torch.empty((S, N), dtype=torch.float32, device=dev)
         glen = int(_lib.lib.spt_fused_linear_pool_gram_len(K))
         gram = torch.empty((B, glen), dtype=torch.float64, device=dev)
@@ -1676,14 +1677,15 @@ class _FusedMLPMaxPool(torch.autograd.Function):
                 _lib.ptr(seg_graph), S, R, nr, c_r0, c_r1, c_g, B, K, _lib.ptr(W), N,
                 _lib.ptr(gnw), _lib.ptr(gnb), _lib.ptr(gms), float(eps_list[-1]),
                 float(slope_list[-1]), _lib.ptr(pam), _lib.ptr(psc), _lib.ptr(pbs),
-                float(slope_list[-2]), _lib.ptr(out), _lib.ptr(arg), _lib.ptr(raw), _lib.ptr(gram),
+                float(slope_list[-2]), _lib.ptr(out), _lib.ptr(arg), _lib.ptr(argpos), _lib.ptr(raw),
+                _lib.ptr(gram),
                 None, _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(am), _lib.ptr(sc), mode_top,
                 _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
         _lib.check(st, "spt_fused_linear_fwd_pool_runs_f32")
         ctx.pool_fused = True
         ctx.n_sub = len(saved_sub)
         ctx.save_for_backward(arg, raw, gram, mean, rstd, am, sc, W, gnw, gnb, gms, h_prev, pam, psc,
-                              pbs, *saved_sub)
+                              pbs, argpos, *saved_sub)
         ctx.csr = csr
         ctx.seg_graph = seg_graph
         ctx.meta = (L, runs, list(slope_list), x.dtype, x.requires_grad,
@@ -1694,8 +1696,8 @@ class _FusedMLPMaxPool(torch.autograd.Function):
     @staticmethod
     def _backward_pooled(ctx, gout):
         (arg, raw, gram, mean, rstd, am, sc, W, gnw, gnb, gms, h_prev, pam, psc,
-         pbs) = ctx.saved_tensors[:15]
-        saved_sub = ctx.saved_tensors[15:]
+         pbs, argpos) = ctx.saved_tensors[:16]
+        saved_sub = ctx.saved_tensors[16:]
         L, runs, slopes, in_dtype, need_gx0, fmode, store16 = ctx.meta
         N, K = W.shape
         R = h_prev.shape[0]
@@ -1732,7 +1734,7 @@ class _FusedMLPMaxPool(torch.autograd.Function):
             ws = _workspace(nb, dev)
             with _timed(f"fused_linear_bwd_pool:{K}x{N}:{R}"):
                 st = _lib.lib.spt_fused_linear_bwd_pool_runs_f32(
-                    _lib.ptr(gout), _lib.ptr(raw), _lib.ptr(arg), _lib.ptr(csr.perm),
+                    _lib.ptr(gout), _lib.ptr(raw), _lib.ptr(argpos), _lib.ptr(csr.perm),
                     _lib.ptr(csr.pos_seg()), _lib.ptr(ctx.seg_graph), S, nr, c_r0, c_r1, c_g, B, N,
                     _lib.ptr(am), _lib.ptr(sc), _lib.ptr(gnb), float(slopes[-1]), _lib.ptr(c1),
                     _lib.ptr(c2), _lib.ptr(c3), _lib.ptr(h_prev), K, _lib.ptr(pam), _lib.ptr(psc),

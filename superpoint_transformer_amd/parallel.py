@@ -101,8 +101,14 @@ class FlatGradAllReduce:
         (norm logging, clipping on one buffer)."""
         if self.world > 1 or (self.always and dist.is_initialized()):
             self.pack()
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-            self.flat.div_(self.world)
+            # RCCL averages inside the collective (ReduceOp.AVG: no separate divide launch); gloo
+            # (the CPU tests' backend) has no AVG: sum, then one divide
+            backend = dist.get_backend(self.group)
+            if backend == "nccl":
+                dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=self.group)
+            else:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+                self.flat.div_(self.world)
         return self.flat if self._packed else None
 
     def time_allreduce_us(self, reps=20):

@@ -319,7 +319,7 @@ def test_two_attention_backward_formulations_interleaved_on_two_streams(dev):
             blk.zero_grad(set_to_none=True)
             out = blk(xd, ei, edge_attr=ead)
             (out * gw).sum().backward()
-            return xd.grad.clone(), ead.grad.clone(), blk.sa.qkv.weight.grad.clone()
+            return xd.grad.clone(), ead.grad.clone(), blk.qkv.weight.grad.clone()
 
     before = _lib.lib.spt_attn_bwd_el_target_order(-1)
     main = torch.cuda.current_stream()
