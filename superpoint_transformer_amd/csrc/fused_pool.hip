@@ -32,6 +32,8 @@
 // 0.12 (ids) + 0.66 (gm, arg, raw) instead of 15.8 GB.
 #include <math.h>
 
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace spt {
@@ -105,16 +107,18 @@ __device__ __forceinline__ f32x4 mfma16(const bf16x4& a, const bf16x4& b, f32x4 
 // them to LDS (row stride LD floats), applying y = leaky((v - am) sc + bs) on the way when PRE
 // (tab = am | sc | bs, K floats each; the expression of gn_apply_fwd_kernel).  Rows >= cnt are 0.
 template <int K, bool X16>
-__device__ __forceinline__ void load_rows(const float* __restrict__ x, int rid_l, int cnt,
+__device__ __forceinline__ void load_rows(const float* __restrict__ x, int rid_l,
                                           float4 (&v)[TR * (K / 4) / 64], int lane) {
   constexpr int CH = K / 4, NIT = TR * CH / 64;
   static_assert(TR * CH % 64 == 0, "whole waves of chunks");
+  // UNCONDITIONAL loads (tile rows past the end carry the id of a valid row and are zeroed by
+  // store_rows): a load under a per-lane condition is followed by a wait and a select, which
+  // serialises the tile's loads and defeats issuing them a tile ahead
 #pragma unroll
   for (int j = 0; j < NIT; ++j) {
     const int q = lane + 64 * j, rr = q / CH, k = (q - rr * CH) << 2;
     const int64_t xr = (int64_t)__shfl(rid_l, rr, 64);
-    v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (rr < cnt) v[j] = ld4<X16>(x, xr * K + k);
+    v[j] = ld4<X16>(x, xr * K + k);
   }
 }
 template <int K, int LD, bool PRE>
@@ -125,7 +129,7 @@ __device__ __forceinline__ void store_rows(const float4 (&v)[TR * (K / 4) / 64],
   for (int j = 0; j < NIT; ++j) {
     const int q = lane + 64 * j, rr = q / CH, k = (q - rr * CH) << 2;
     float4 w = v[j];
-    if (PRE && rr < cnt) {
+    if constexpr (PRE) {
       const float4 a = *reinterpret_cast<const float4*>(tab + k);
       const float4 s = *reinterpret_cast<const float4*>(tab + K + k);
       const float4 b = *reinterpret_cast<const float4*>(tab + 2 * K + k);
@@ -134,6 +138,7 @@ __device__ __forceinline__ void store_rows(const float4 (&v)[TR * (K / 4) / 64],
       w.x = w.x > 0.f ? w.x : w.x * slope; w.y = w.y > 0.f ? w.y : w.y * slope;
       w.z = w.z > 0.f ? w.z : w.z * slope; w.w = w.w > 0.f ? w.w : w.w * slope;
     }
+    if (rr >= cnt) w = make_float4(0.f, 0.f, 0.f, 0.f);
     *reinterpret_cast<float4*>(lds + rr * LD + k) = w;
   }
 }
@@ -257,30 +262,35 @@ __global__ __launch_bounds__(NWF * 64, 2) void fwd_pool_kernel(
   const int64_t per = (((r1 - r0 + nw - 1) / nw) + TR - 1) / TR * TR;
   const int64_t pa0 = cut_at(r0 + w * per, r0, r1, pos_seg, rowptr);
   const int64_t pb0 = (w == nw - 1) ? r1 : cut_at(r0 + (w + 1) * per, r0, r1, pos_seg, rowptr);
+  const bool has_rows = pa0 < pb0;            // (an empty range skips the loop; it still joins the
+                                              //  workgroup's reduction below)
+  // ids of the 16 positions from p (lanes past the wave's range read its last position: a valid
+  // row that store_rows zeroes and the epilogue never looks at) - unconditional loads
+  const int64_t plast = pb0 - 1;
   auto ids_of = [&](int64_t p, int& rid, int& sg) {
-    rid = 0;
-    sg = -1;
-    if (lane < TR && p + lane < pb0) {
-      rid = perm ? perm[p + lane] : (int)(p + lane);
-      sg = pos_seg[p + lane];
-    }
+    int64_t q = p + (lane & (TR - 1));
+    q = q < plast ? q : plast;
+    rid = perm ? perm[q] : (int)q;
+    sg = pos_seg[q];
   };
+  if (has_rows) {
   int rid_l, seg_l, rid_n, seg_n;
   ids_of(pa0, rid_l, seg_l);
   float4 xv[TR * (K / 4) / 64];                 // raw rows of the tile about to be staged
-  if (pa0 < pb0) load_rows<K, IN16>(x, rid_l, (int)((pb0 - pa0) < TR ? (pb0 - pa0) : TR), xv, lane);
+  load_rows<K, IN16>(x, rid_l, xv, lane);
   ids_of(pa0 + TR, rid_n, seg_n);
   for (int64_t p = pa0; p < pb0; p += TR) {
     const int cnt = (int)((pb0 - p) < TR ? (pb0 - p) : TR);
     wave_sync_lds();
     store_rows<K, LDA, true>(xv, cnt, tab, pslope, al, lane);
-    // the NEXT tile's rows travel while this one is multiplied; the ids of the tile after it too
-    int rid_nn, seg_nn;
-    {
-      const int64_t pn = p + TR;
-      if (pn < pb0) load_rows<K, IN16>(x, rid_n, (int)((pb0 - pn) < TR ? (pb0 - pn) : TR), xv, lane);
-      ids_of(pn + TR, rid_nn, seg_nn);
-    }
+    // the NEXT tile's rows travel while this one is multiplied; the ids of the tile after it too.
+    // The id registers rotate HERE, on values that have arrived (at the loop's end the rotation
+    // would wait for the ids just requested): this tile's segment ids stay in seg_c
+    const int seg_c = seg_l;
+    load_rows<K, IN16>(x, rid_n, xv, lane);
+    rid_l = rid_n;
+    seg_l = seg_n;
+    ids_of(p + 2 * TR, rid_n, seg_n);
     wave_sync_lds();
     // ---- h' = y_prev W'^T ------------------------------------------------------------------
     f32x4 C[NBK];
@@ -365,8 +375,8 @@ __global__ __launch_bounds__(NWF * 64, 2) void fwd_pool_kernel(
       const int pos0 = (int)p + 4 * g;                            // position of the lane's row r = 0
       int row = 0;
       while (row < cnt) {
-        const int s = __builtin_amdgcn_readlane(seg_l, row);
-        const uint64_t diff = __ballot(lane < cnt && lane > row && seg_l != s);
+        const int s = __builtin_amdgcn_readlane(seg_c, row);
+        const uint64_t diff = __ballot(lane < cnt && lane > row && seg_c != s);
         const int e = diff ? (int)__builtin_ctzll(diff) : cnt;   // rows [row, e) belong to s
         if (s != cur_seg) {
           if (cur_seg >= 0) flush(cur_seg);
@@ -399,10 +409,7 @@ __global__ __launch_bounds__(NWF * 64, 2) void fwd_pool_kernel(
         row = e;
       }
     }
-    rid_l = rid_n;
-    seg_l = seg_n;
-    rid_n = rid_nn;
-    seg_n = seg_nn;
+  }
   }
   if (cur_seg >= 0) flush(cur_seg);
 
@@ -743,25 +750,79 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_pool_kernel(
     const int64_t row0 = r0 + t * TR;
     return (t < ntiles) ? (int)((r1 - row0) < TR ? (r1 - row0) : TR) : 0;
   };
+  // ids of tile t's 16 positions - UNCONDITIONAL loads (see load_rows): a tile past the end reads
+  // the run's last tile again, positions past r1 its last position; nothing of it is used
   auto load_ids = [&](int64_t t, int& rid, int& sg) {
-    rid = 0;
-    sg = -1;
-    const int64_t rowf = r0 + t * TR;
-    if (t < ntiles && rowf + lane < r1 && lane < TR) {
-      rid = perm ? perm[rowf + lane] : (int)(rowf + lane);
-      sg = pos_seg[rowf + lane];
+    const int64_t tt = t < ntiles ? t : ntiles - 1;
+    int64_t q = r0 + tt * TR + (lane & (TR - 1));
+    q = q < r1 - 1 ? q : r1 - 1;
+    rid = perm ? perm[q] : (int)q;
+    sg = pos_seg[q];
+  };
+  // (gm, argpos) of the lane's CPL channels of segment sgm
+  auto load_seg = [&](int sgm, int (&ap)[CPL], float (&gv)[CPL]) {
+    const size_t o = (size_t)sgm * N + CPL * lane;
+    if constexpr (CPL == 2) {
+      const int2 a2 = *reinterpret_cast<const int2*>(argpos + o);
+      const float2 g2 = *reinterpret_cast<const float2*>(gm + o);
+      ap[0] = a2.x; ap[1] = a2.y;
+      gv[0] = g2.x; gv[1] = g2.y;
+    } else {
+      ap[0] = argpos[o];
+      gv[0] = gm[o];
     }
   };
+  // winners of one segment whose tile rows are [lo, hi): S[row][channel] = gm.  Branch-free: a
+  // lane whose winner lies outside writes a pad column of row 0 instead (never read)
+  auto scatter = [&](const int (&ap)[CPL], const float (&gv)[CPL], int row0i, int lo, int hi) {
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) {
+      const int rr = ap[q] - row0i;
+      const bool ok = rr >= lo && rr < hi;
+      gl[ok ? rr * LDG + CPL * lane + q : N + q] = gv[q];
+    }
+  };
+  if (ntiles > 0) {                             // (an empty run still writes its zero records below)
   int rid_l, seg_l, rid_n, seg_n;
   load_ids(pair, rid_l, seg_l);
   float4 xv[TR * (K / 4) / 64];                 // raw rows of the tile about to be staged
-  if (pair < ntiles) load_rows<K, X16>(xprev, rid_l, cnt_of(pair), xv, lane);
+  load_rows<K, X16>(xprev, rid_l, xv, lane);
+  // the tile's FIRST and LAST segment (at 35 rows per segment a tile touches one or two): their
+  // (gm, argpos) rows travel a tile ahead like the x rows; further segments are fetched in place
+  int apA[CPL], apB[CPL];
+  float gvA[CPL], gvB[CPL];
+  {
+    const int c0 = cnt_of(pair < ntiles ? pair : ntiles - 1);
+    load_seg(__builtin_amdgcn_readlane(seg_l, 0), apA, gvA);
+    load_seg(__builtin_amdgcn_readlane(seg_l, c0 - 1), apB, gvB);
+  }
   load_ids(pair + npairs, rid_n, seg_n);
-  for (int64_t t = pair; t < ntiles; t += npairs) {
+  // The loop's memory operations are waited for by COUNT (s_waitcnt vmcnt(n): at most n younger
+  // operations outstanding), and the compiler merges the counts of the loop's entry with those of
+  // its back edge: entering with the same sequence in flight as an iteration leaves behind - the
+  // requests above, then as many stores as a tile's gx - keeps every count in the loop exact
+  // (otherwise each wait for a prefetched row also drains the previous tile's 4 KBH stores).
+  // The stores go to this pair's own gW record, which is written for real at the end.
+  {
+    float* scratch = gw_partial + (size_t)pair * N * K + (size_t)hf * (N / 2) * K;
+#pragma unroll
+    for (int i = 0; i < 4 * KBH; ++i) scratch[lane + 64 * i] = 0.f;
+  }
+  // One tile.  FULL (every tile but a run's last): 16 rows, so no per-row condition anywhere -
+  // in particular the gx stores are unconditional, and the compiler's count of memory operations
+  // in flight stays EXACT across the loop: the waits for the rows requested a tile ahead then do
+  // not drain the stores issued after them (vmcnt counts in order; a store under a per-lane
+  // condition is assumed not to have been issued, and every later wait over-waits by that much).
+  auto tile = [&](auto full_c, int64_t t) {
+    constexpr bool FULL = decltype(full_c)::value;
     const int64_t row0 = r0 + t * TR;
-    const int cnt = cnt_of(t);
+    const int cnt = FULL ? TR : cnt_of(t);
     wave_sync_lds();
-    // ---- S tile: zero, then the (gm, argpos) rows of the tile's segments scattered into it ------
+    // ---- RAW xprev tile (gathered rows; rows >= cnt zero).  FIRST: the rows were requested
+    // before everything else of this tile, and the rare 3+-segment loop below contains loads of
+    // its own - whatever is waited for behind it is waited for with vmcnt(0)
+    store_rows<K, LDX, false>(xv, cnt, nullptr, 1.f, xl, lane);
+    // ---- S tile: zero, then the winners of the tile's segments scattered into it ---------------
     {
       constexpr int NZ = TR * (N / 4) / 64;
 #pragma unroll
@@ -769,37 +830,39 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_pool_kernel(
         const int q = lane + 64 * j, rr = q / (N / 4), n = (q - rr * (N / 4)) << 2;
         *reinterpret_cast<float4*>(gl + rr * LDG + n) = make_float4(0.f, 0.f, 0.f, 0.f);
       }
-      int row = 0;
-      while (row < cnt) {
+      const int sA = __builtin_amdgcn_readlane(seg_l, 0);
+      const int sB = __builtin_amdgcn_readlane(seg_l, cnt - 1);
+      const uint64_t notA = __ballot(lane < cnt && seg_l != sA);
+      const int eA = notA ? (int)__builtin_ctzll(notA) : cnt;       // rows [0, eA): segment sA
+      const uint64_t isB = __ballot(lane < cnt && seg_l == sB);
+      const int bB = (int)__builtin_ctzll(isB);                     // rows [bB, cnt): segment sB
+      scatter(apA, gvA, (int)row0, 0, eA);
+      if (sB != sA) scatter(apB, gvB, (int)row0, bB, cnt);
+      int row = eA;
+      while (row < bB) {                                           // 3+ segments in the tile (rare)
         const int sgm = __builtin_amdgcn_readlane(seg_l, row);
         const uint64_t diff = __ballot(lane < cnt && lane > row && seg_l != sgm);
-        const int e = diff ? (int)__builtin_ctzll(diff) : cnt;   // rows [row, e) belong to sgm
-        const size_t o = (size_t)sgm * N + CPL * lane;
+        const int e = diff ? (int)__builtin_ctzll(diff) : cnt;
         int ap[CPL];
         float gv[CPL];
-        if constexpr (CPL == 2) {
-          const int2 a2 = *reinterpret_cast<const int2*>(argpos + o);
-          const float2 g2 = *reinterpret_cast<const float2*>(gm + o);
-          ap[0] = a2.x; ap[1] = a2.y;
-          gv[0] = g2.x; gv[1] = g2.y;
-        } else {
-          ap[0] = argpos[o];
-          gv[0] = gm[o];
-        }
-#pragma unroll
-        for (int q = 0; q < CPL; ++q) {
-          const int rr = ap[q] - (int)row0;
-          if (rr >= row && rr < e) gl[rr * LDG + CPL * lane + q] = gv[q];
-        }
+        load_seg(sgm, ap, gv);
+        scatter(ap, gv, (int)row0, row, e);
         row = e;
       }
     }
-    // ---- RAW xprev tile (gathered rows; rows >= cnt zero) ---------------------------------------
-    store_rows<K, LDX, false>(xv, cnt, nullptr, 1.f, xl, lane);
     const int rid_cur = rid_l;                 // the gx scatter below needs this tile's row ids
-    int rid_nn, seg_nn;
-    if (t + npairs < ntiles) load_rows<K, X16>(xprev, rid_n, cnt_of(t + npairs), xv, lane);
-    load_ids(t + 2 * npairs, rid_nn, seg_nn);
+    // everything the NEXT tile needs from memory is requested here, before this tile's GEMMs;
+    // the id registers rotate HERE, on values that have arrived (a rotation at the loop's end
+    // would have to wait for the ids just requested)
+    load_rows<K, X16>(xprev, rid_n, xv, lane);
+    {
+      const int64_t tn = t + npairs < ntiles ? t + npairs : ntiles - 1;
+      load_seg(__builtin_amdgcn_readlane(seg_n, 0), apA, gvA);
+      load_seg(__builtin_amdgcn_readlane(seg_n, cnt_of(tn) - 1), apB, gvB);
+    }
+    rid_l = rid_n;
+    seg_l = seg_n;
+    load_ids(t + 2 * npairs, rid_n, seg_n);
     wave_sync_lds();
     // y_prev of one raw value (rows >= cnt: 0)
     auto ynorm = [&](float v, int k, bool ok) {
@@ -911,7 +974,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_pool_kernel(
       for (int r = 0; r < 4; ++r) {
         const int rr = 4 * g + r;
         const int64_t orow = (int64_t)__shfl(rid_cur, rr, 64);
-        if (rr < cnt) {
+        if (FULL || rr < cnt) {
 #pragma unroll
           for (int kb = 0; kb < KBH; ++kb) {
             const int k = 16 * (kb0 + kb) + c;
@@ -929,10 +992,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_pool_kernel(
         }
       }
     }
-    rid_l = rid_n;
-    seg_l = seg_n;
-    rid_n = rid_nn;
-    seg_n = seg_nn;
+  };
+  const int64_t nfull = (r1 - r0) / TR;         // complete tiles; at most one partial tile follows
+  int64_t t = pair;
+  for (; t < nfull; t += npairs) tile(std::true_type{}, t);
+  if (t < ntiles) tile(std::false_type{}, t);
   }
   // one record per PAIR: each wave writes its rows of gW and its columns of the statistics
   float* gwp = gw_partial + (size_t)pair * N * K;
