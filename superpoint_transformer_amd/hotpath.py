@@ -348,6 +348,49 @@ class SPTTrainStep:
         roof["kernels"] = kernels
         return roof
 
+    def northstar(self, peak_gbs, reps=5):
+        """The north-star segment-CSR scatter kernel on its own: ``MaxPool.__call__`` of the
+        level-0 -> level-1 pool (src/nn/pool.py:61-82) = ``ops.segment_reduce(x, super_index, max,
+        arg)`` on a [N0, 128] f32 tensor through the scene's own CSR view, timed with HIP events on
+        the launch stream.  Since round 5 the TRAINING STEP no longer launches this kernel (the
+        pool runs inside the top layer's product, csrc/fused_pool.hip): the operator stays on the
+        boundary (nn.MaxPool, shims.scatter_shim.scatter_max) and is measured here, in the same
+        process, on the same index.  Returns the fields of the bench line's ``roofline`` object,
+        or None when the step did launch the kernel (its in-step timer is the figure then)."""
+        if ops.timer_mean_ms(self.tname):
+            return None
+        n0, n1 = self.n[0], self.n[1]
+        c = 128
+        si = self.nag.levels[0].get("super_index")
+        if si is None or n0 < 65536:
+            return None
+        x = torch.randn(n0, c, device=self.dev)
+        for _ in range(2):
+            ops.segment_reduce(x, si, n1, "max", return_arg=True)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            ops.segment_reduce(x, si, n1, "max", return_arg=True)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        del x
+        # row 4 C + 4 (its position's row id), parent 4 C (max) + 4 C (arg, int32) + 4 (range)
+        bytes_ = n0 * (4 * c + 4) + n1 * (8 * c + 4)
+        ach = bytes_ / (ms * 1e-3) / 1e9
+        tr = _pmc_traffic("segmax_standalone", self.workload)
+        return {"bound": "hbm",
+                "kernel": "spt::segmax_stream_kernel<false> (L0->L1 segment max + arg of [N0, 128] f32 rows "
+                          "through the level's CSR view: nn.MaxPool / scatter_max on its own - the step "
+                          "runs the pool inside spt::fpool::fwd_pool_kernel, see `kernels`)",
+                "achieved": round(ach, 1), "peak": peak_gbs, "unit": "GB/s",
+                "frac": round(ach / peak_gbs, 4),
+                "traffic": tr.get("bytes") if tr else None,
+                "traffic_source": tr.get("source") if tr else None,
+                "bytes_per_launch": bytes_, "ms_per_launch": round(ms, 4),
+                "measured": f"{reps} stand-alone launches after the timed region, HIP events on the launch stream"}
+
     def describe(self, scene, sizes, graph="random"):
         views = ("level CSR views taken from the NAG's stored `sub` (nag[i+1].sub), edge views sorted per step"
                  if _csr._USE_SUB_VIEWS and self.nag.levels[1].get("sub") is not None
