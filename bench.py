@@ -41,9 +41,10 @@ def parse():
     p.add_argument("--cpu-all-cores", action="store_true",
                    help="also probe the CPU baseline with one thread per core (minutes on a 256-core box)")
     p.add_argument("--stages", default="all")
-    p.add_argument("--mode", default="train", choices=["train", "infer", "panoptic"],
+    p.add_argument("--mode", default="train", choices=["train", "infer", "panoptic", "iteration"],
                    help="train: fwd+loss+bwd+AdamW (default, BASELINE cfg #2); infer: forward only "
-                        "(cfg #3, use --scene D); panoptic: + edge-affinity head and loss (cfg #5)")
+                        "(cfg #3, use --scene D); panoptic: + edge-affinity head and loss (cfg #5); iteration: "
+                        "the on-device transform chain on a raw NAG + the train step, timed together (use --scene T)")
     p.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f32-exact"],
                    help="matrix-pipe precision (superpoint_transformer_amd.precision); f32 = the "
                         "reference's shipped `precision: 32`, bf16 = its bf16 option (cfg #2)")
@@ -326,8 +327,12 @@ def main():
     from superpoint_transformer_amd import csr as _csr
     _csr.use_sub_views(not args.rebuild_csr)
     mix = [SCENE_MIX[r % len(SCENE_MIX)] if (args.scene_mix and world > 1) else 1.0 for r in range(world)]
-    nag = make_nag(args.scene, seed=1234 + rank, device=dev, graph=args.graph, order=args.order,
-                   scale=mix[rank])
+    if args.mode == "iteration":
+        from superpoint_transformer_amd.synthetic import make_raw_nag
+        nag = make_raw_nag(args.scene, seed=1234 + rank, device=dev)
+    else:
+        nag = make_nag(args.scene, seed=1234 + rank, device=dev, graph=args.graph, order=args.order,
+                       scale=mix[rank])
     path = hotpath.build(nag, dev, world=world, stages=args.stages, mode=args.mode, model=args.model,
                          kernel_timers=True)
     if args.graph == "random" and args.order == "storage":

@@ -506,6 +506,90 @@ class ScatterChain:
         return f"{self.name}; scene {scene} {sizes}"
 
 
+class SPTIterationStep(SPTTrainStep):
+    """A training ITERATION as the reference runs it (src/datamodules/base.py:341-380:
+    ``on_after_batch_transfer`` applies ``on_device_train_transform`` to the batch, then the model
+    steps): the per-batch on-device transform chain of configs/datamodule/semantic/default.yaml:
+    206-290 - NodeSize -> SampleSubNodes -> SampleSegments -> OnTheFlyHorizontalEdgeFeatures
+    (+ self loops) -> SampleEdges - on a RAW NAG as it sits on disk (trimmed edges with the 7
+    stored attributes, no node sizes, ``superpoint_transformer_amd.synthetic.make_raw_nag``), then
+    forward + CE loss + backward + AdamW on what the chain produced.  Every step starts from a
+    fresh copy of the raw batch, so the chain, every CSR view and every run table are rebuilt:
+    nothing of the batch is prepared outside the timed region."""
+    name = ("one training iteration: on-device transform chain (NodeSize, SampleSubNodes, SampleSegments, "
+            "OnTheFlyHorizontalEdgeFeatures, SampleEdges) + SPT-64 fwd + CE loss + bwd + AdamW")
+
+    def __init__(self, raw_nag, dev, world=1, seed=0, model="spt64", kernel_timers=False):
+        from . import transforms as T
+        self.raw, self.dev, self.world = raw_nag, dev, world
+        self.n = raw_nag.num_points
+        self.net_name, self.workload, self.k_timers = model, None, None
+        self.chain = [T.NodeSize(0), T.SampleSubNodes(1, 0, n_max=32, n_min=8),
+                      T.SampleSegments(ratio=0.2), T.OnTheFlyHorizontalEdgeFeatures(),
+                      T.SampleEdges(levels=(1, 2), n_min=4, n_max=16)]
+        torch.manual_seed(seed)
+        probe = self._prepare()
+        self.model = SPTSegmenter(**MODEL_CONFIGS[model](probe[0].x.shape[1],
+                                                         probe[1].edge_attr.shape[1])).to(dev)
+        self.params = [p for p in self.model.parameters()]
+        parallel.broadcast_parameters(self.params, src=0)
+        self.bucket = parallel.FlatGradAllReduce(
+            self.params, always=os.environ.get("SPT_FORCE_COLLECTIVES") == "1")
+        self.opt = torch.optim.AdamW(self.params, lr=1e-3, weight_decay=1e-4, fused=dev.type == "cuda")
+        self.lambdas = [1.0, 50.0]
+        self.loss_fn = ops.cross_entropy
+        self.tname = "unused"
+        self.last_loss = None
+        self.last_sizes = probe.num_points
+        self.ms_chain = []
+
+    def _prepare(self):
+        nag = self.raw.clone()
+        for t in self.chain:
+            nag = t(nag)
+        return nag
+
+    def step(self):
+        self._timed_steps += 1
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        nag = self._prepare()
+        e1.record()
+        self.ms_chain.append((e0, e1))
+        n = nag.num_points
+        # labels of the sampled nodes (the reference carries them through the selection; random
+        # here: synthetic data has none)
+        labels = [torch.randint(0, NUM_CLASSES, (n[i],), device=self.dev) for i in (1, 2)]
+        logits = self.model(nag)
+        loss = sum(l * self.loss_fn(lg, y) for l, lg, y in zip(self.lambdas, logits, labels))
+        self.bucket.zero()
+        loss.backward()
+        self.bucket.reduce()
+        self.opt.step()
+        self.last_loss, self.last_sizes = loss, n
+        return loss
+
+    def reset_kernel_timers(self):
+        self.ms_chain = []
+        self._timed_steps = 0
+
+    def roofline(self, peak_gbs):
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(b) for a, b in self.ms_chain]
+        return {"bound": "hbm", "kernel": "n/a (iteration line: see ms_transform_chain)", "achieved": None,
+                "peak": peak_gbs, "unit": "GB/s", "frac": None, "traffic": None,
+                "ms_transform_chain": round(sum(ms) / len(ms), 4) if ms else None,
+                "sizes_after_chain": list(self.last_sizes), "kernels": []}
+
+    def northstar(self, peak_gbs, reps=5):
+        return None
+
+    def describe(self, scene, sizes, graph="random"):
+        return (f"{self.name}; raw synthetic NAG scene {scene} (N0,N1,N2,E1,E2,clouds)={sizes} -> "
+                f"{list(self.last_sizes)} nodes per level after the chain; every step re-runs the chain on a "
+                "fresh copy of the raw batch")
+
+
 def build(nag, dev, world=1, stages="all", mode="train", model="spt64", kernel_timers=False):
     if stages == "scatter":
         return ScatterChain(nag, dev, world)
@@ -513,4 +597,6 @@ def build(nag, dev, world=1, stages="all", mode="train", model="spt64", kernel_t
         return SPTInferStep(nag, dev, world, model=model, kernel_timers=kernel_timers)
     if mode == "panoptic":
         return SPTPanopticStep(nag, dev, world, model=model, kernel_timers=kernel_timers)
+    if mode == "iteration":
+        return SPTIterationStep(nag, dev, world, model=model, kernel_timers=kernel_timers)
     return SPTTrainStep(nag, dev, world, model=model, kernel_timers=kernel_timers)

@@ -10,7 +10,7 @@ from . import _lib
 __all__ = ["horizontal_edge_features", "EDGE_FEATURE_COLUMNS", "NodeSize", "SampleSubNodes",
            "SampleSegments", "SampleEdges", "OnTheFlyHorizontalEdgeFeatures",
            "SampleRadiusSubgraphs", "OnTheFlyInstanceGraph", "segment_sampling_weights",
-           "NAGRestrictSize"]
+           "NAGRestrictSize", "MortonOrder", "morton_code"]
 
 EDGE_FEATURE_COLUMNS = [
     "mean_off_x", "mean_off_y", "mean_off_z", "std_off_x", "std_off_y", "std_off_z",
@@ -388,3 +388,65 @@ class OnTheFlyInstanceGraph:
         dense = _consecutive(joint)[0]
         data.obj_pos = obj_pos[dense[:sp_obj_idx.numel()]]
         return nag
+
+
+def morton_code(pos, bits=10):
+    """``bits``-per-axis Morton (Z-order) code of [n, 3] positions inside their bounding box (int64)."""
+    lo, hi = pos.min(0).values, pos.max(0).values
+    top = (1 << bits) - 1
+    q = ((pos - lo) / (hi - lo).clamp_min(1e-9) * float(top)).long().clamp_(0, top)
+    code = torch.zeros(pos.shape[0], dtype=torch.int64, device=pos.device)
+    for b in range(bits):
+        for a in range(3):
+            code |= ((q[:, a] >> b) & 1) << (3 * b + a)
+    return code
+
+
+class MortonOrder:
+    """Load-time re-ordering of a NAG for MEMORY LOCALITY (round 5; not a transform of the
+    reference - its datasets store nodes in the order the partition emitted them, spatial neighbours
+    ~0.23 N apart in the demo room).  The top level is sorted by (cloud, Morton code of its
+    position); every level below is re-grouped by its parent in the parent's new order - what
+    ``NAG.select`` does to the descendants of a re-ordered level (src/data/nag.py:306-399) - and,
+    inside a parent, sorted by its own Morton code.  Afterwards the nodes a superpoint-graph edge
+    joins (built by radius search, src/transforms/graph.py:193-321: spatial neighbours) are close
+    in memory at every level, the children of a superpoint are contiguous (the pool's CSR view is
+    the identity: coalesced streams instead of gathers), and the attention's k / v / record gathers
+    hit rows that are still in L2.
+
+    Purely a renumbering: edges, ``super_index``, ``sub`` and every per-node attribute follow.
+    ``nag[i].morton_origin`` [n_i] = the ORIGINAL index of every node, so per-node outputs go
+    back with ``MortonOrder.restore`` (``out_original[origin] = out``); results are those of the
+    un-ordered NAG up to the summation order of segment / attention reductions."""
+
+    KEY = "morton_origin"
+
+    def __init__(self, bits=10):
+        self.bits = int(bits)
+
+    def __call__(self, nag):
+        nag = nag.clone()
+        L = nag.num_levels
+        for i in range(L):
+            n = nag[i].num_nodes
+            nag[i][self.KEY] = torch.arange(n, device=nag.device)
+        top = L - 1
+        d = nag[top]
+        key = morton_code(d.pos, self.bits)
+        if d.batch is not None:
+            key = key + (d.batch.long() << (3 * self.bits))
+        nag = nag.select(top, torch.argsort(key, stable=True))
+        for i in range(top - 1, 0, -1):
+            d = nag[i]
+            key = morton_code(d.pos, self.bits) + (d.super_index.long() << (3 * self.bits))
+            nag = nag.select(i, torch.argsort(key, stable=True))
+        return nag
+
+    @classmethod
+    def restore(cls, nag, out, i_level):
+        """Per-node tensor ``out`` [n_i, ...] of the re-ordered level ``i_level`` back in the
+        original node order."""
+        origin = nag[i_level][cls.KEY]
+        back = torch.empty_like(out)
+        back[origin] = out
+        return back

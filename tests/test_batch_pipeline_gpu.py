@@ -193,3 +193,42 @@ def test_restrict_size_caps_nodes_and_edges_of_the_upper_levels(dev):
         assert out[i].edge_attr.shape[0] == out[i].num_edges
     same = NAGRestrictSize(level="1+", num_nodes=10 ** 9, num_edges=10 ** 9)(out)
     assert same.num_points == out.num_points and same[1].num_edges == out[1].num_edges
+
+
+def test_morton_order_is_a_renumbering_the_model_cannot_see(dev):
+    """``transforms.MortonOrder`` (round 5): levels re-ordered along a Morton curve, children
+    re-grouped under their parents - the hierarchy stays consistent, the children of every
+    superpoint become contiguous, spatial neighbours move close in memory, and the model's logits,
+    put back in the original node order, are those of the un-ordered NAG (same sums, another
+    order: f32 round-off)."""
+    from superpoint_transformer_amd.hotpath import SPTSegmenter, spt64_config
+    from superpoint_transformer_amd.synthetic import make_raw_nag
+    from superpoint_transformer_amd import transforms as T
+    torch.manual_seed(0)
+    nag = make_raw_nag("R", device=dev)
+    for t in (T.NodeSize(0), T.OnTheFlyHorizontalEdgeFeatures()):
+        nag = t(nag)
+    mo = T.MortonOrder()(nag)
+    check_hierarchy(mo)
+    assert mo.num_points == nag.num_points
+    for i in range(nag.num_levels):
+        origin = mo[i].morton_origin
+        assert torch.equal(torch.sort(origin).values, torch.arange(nag.num_points[i], device=dev))
+        assert torch.equal(mo[i].pos, nag[i].pos[origin])                  # a pure renumbering
+        if i + 1 < nag.num_levels:                                         # parents follow their children
+            assert torch.equal(mo[i + 1].morton_origin[mo[i].super_index], nag[i].super_index[origin])
+            assert bool((mo[i].super_index[1:] >= mo[i].super_index[:-1]).all())   # children contiguous
+    # edges join the same pairs of nodes
+    e_new = mo[1].morton_origin[mo[1].edge_index]
+    key = lambda e: torch.sort(e[0] * nag.num_points[1] + e[1]).values
+    assert torch.equal(key(e_new), key(nag[1].edge_index))
+    # locality: the median index distance of an edge's endpoints shrinks
+    span = lambda e: float((e[0] - e[1]).abs().float().median())
+    assert span(mo[1].edge_index) < 0.5 * span(nag[1].edge_index)
+    model = SPTSegmenter(**spt64_config(nag[0].x.shape[1], 18)).to(dev).eval()
+    with torch.no_grad():
+        ref = model(nag)
+        got = model(mo)
+    for i, (a, b) in enumerate(zip(ref, got)):
+        back = T.MortonOrder.restore(mo, b, i + 1)
+        assert torch.allclose(back, a, rtol=1e-4, atol=1e-5 * float(a.abs().max())), i
