@@ -337,7 +337,9 @@ def main():
                          kernel_timers=True)
     if args.graph == "random" and args.order == "storage":
         # PMC captures (profiles/traffic.json) exist per (scene, net) of the default generator only
-        path.workload = f"{args.scene}/{args.model}" + ("" if args.mode == "train" else f"/{args.mode}")
+        # (keyed by dtype too: a bf16 line never prints traffic fractions off the f32 capture's bytes)
+        path.workload = (f"{args.scene}/{args.model}" + ("" if args.mode == "train" else f"/{args.mode}")
+                         + ("" if args.dtype == "f32" else f"/{args.dtype}"))
 
     # A process that is the first to touch a box's GPU runs its first seconds ~10 % slow (clock
     # ramp; measured: the same binary 74.6 ms/step in the first process of a fresh box, 67.3 in

@@ -1,6 +1,6 @@
 """profiles/<tag>_pmc_step_traffic.txt (tools/pmc_step.sh) -> profiles/traffic.json.
 
-    python tools/make_traffic_json.py profiles/r04x_pmc_step_traffic.txt S spt64 > profiles/traffic.json
+    python tools/make_traffic_json.py profiles/r05x_pmc_step_traffic.txt S spt64 [dtype] > profiles/traffic.json
 
 One entry per roofline op of `hotpath.SPTTrainStep.roofline`, keyed by op AND workload shape
 (`<op>@<scene>/<net>`): a bench line of another scene / model finds no entry and prints
@@ -13,6 +13,8 @@ import re
 import sys
 
 path, scene, net = sys.argv[1], sys.argv[2], sys.argv[3]
+dtype = sys.argv[4] if len(sys.argv) > 4 else "f32"          # keys of non-f32 captures end in /<dtype>
+suffix = "" if dtype == "f32" else f"/{dtype}"
 rows = {}
 for line in open(path):
     m = re.match(r"(.{48}) (\S+)\s+avg\s+([\d.]+)\s+max\s+([\d.]+)\s+n=(\d+)(?:\s+hi\s+([\d.]+)\s+nhi=(\d+))?", line)
@@ -63,6 +65,11 @@ spec = {
     "attn_fwd": ("spt::mfma::attn_fwd_mfma_kernel, level-1 launches", ["attn_fwd_mfma_kernel"], "hi"),
     "mlp_bwd_pooled": ("spt::fdma::bwd_dma_kernel<64, 128, 8, 2, true, true>", ["bwd_dma_kernel<64, 128"], "avg"),
     "mlp_fwd": ("spt::fmlp::fwd_kernel_x3<16, 8> (or fwd_kernel<16, 8>)", ["fwd_kernel_x3<16, 8>|fwd_kernel<16, 8>"], "avg"),
+    # round 5: the top layer with the pool inside (csrc/fused_pool.hip)
+    "mlp_fwd_pool": ("spt::fpool::fwd_pool_kernel + pool_apply_kernel", ["fwd_pool_kernel", "pool_apply_kernel"], "avg"),
+    "mlp_bwd_pool": ("spt::fpool::pool_bwd_gm_kernel + bwd_pool_kernel", ["pool_bwd_gm_kernel", "bwd_pool_kernel"], "avg"),
+    # the north-star kernel on its own (tools/pmc_segmax.sh capture)
+    "segmax_standalone": ("spt::segmax_stream_kernel<false>", ["segmax_stream_kernel<false"], "avg"),
 }
 try:                                   # keep the entries of other workloads / legs
     import os
@@ -74,5 +81,5 @@ except (OSError, ValueError):
 for op, (label, kernels, col) in spec.items():
     e = entry(label, kernels, col)
     if e is not None:
-        out[f"{op}@{scene}/{net}"] = e
+        out[f"{op}@{scene}/{net}{suffix}"] = e
 print(json.dumps(out, indent=1))
