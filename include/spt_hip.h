@@ -669,13 +669,18 @@ int spt_edge_affinity_features_bwd_f32(const float* x, const float* gout, int64_
  * Tall-skinny Linear: y [rows, N] = x [rows, K] W[N, K]^T (+ bias [N] or NULL), f32 in /
  * f32 accumulate.  The qkv / out_proj nn.Linear of SelfAttentionBlock
  * (src/nn/attention.py:202-215, 311-313) and, on (gy, W^T), their input gradients.
- * K in {32, 64, 128, 192}, N a multiple of 64; x, W, y contiguous.
+ * K in {32, 64, 128, 192} and - round 5 - 132 / 260: the first Linear of the KITTI-360 width's
+ * node MLPs ([4 + 128, 128, 128] / [4 + 256, 128, 128], configs/experiment/semantic/kitti360.yaml:
+ * 22-27, src/nn/mlp.py:43-56), which ran on the vendor GEMM before.  N any width from 64 up (a last
+ * slab of fewer than 64 columns - the dX of a 132 / 260-wide input - reads the missing weight rows
+ * as zero and stores nothing for them), or N <= 16 (the heads); x, W, y contiguous.
  * ---------------------------------------------------------------------- */
 int spt_skinny_linear_supported(int K, int N);
 int spt_skinny_linear_f32(const float* x, int64_t rows, int K, const float* W, const float* bias,
                           int N, float* y, spt_stream_t stream);
 /* Weight gradient of the same Linear: gw[N,K] = gy[rows,N]^T x[rows,K] (src/nn/attention.py's qkv /
- * out_proj under autograd), a reduction over 10^5..10^7 rows.  K in {32, 64}, N a multiple of 64;
+ * out_proj under autograd), a reduction over 10^5..10^7 rows.  K in {32, 64, 128, 132, 260} (above
+ * 64: 64-column slabs of x, the last one narrower), N a multiple of 64;
  * f32 in / f32 accumulate on the matrix pipe, per-wave partials summed in a fixed order
  * (deterministic).  gb[N] (nullable) receives the column sums of gy - the bias gradient - from the
  * same pass.  ws: spt_skinny_dw_workspace_bytes(K, N) bytes of device scratch. */

@@ -121,8 +121,7 @@ __global__ __launch_bounds__(WAVES * 64, (K4 <= 32) ? 2 : 1) void skinny_linear_
         const int64_t row = t * TR + 4 * g + r;
 #pragma unroll
         for (int nb = 0; nb < NBS; ++nb)
-          rv[nb][r] = (row < rows && (NBS == 4 || n0 + 16 * nb + c < N))
-                          ? res[row * N + n0 + c + 16 * nb] : 0.f;
+          rv[nb][r] = (row < rows && n0 + 16 * nb + c < N) ? res[row * N + n0 + c + 16 * nb] : 0.f;
       }
     }
     wave_sync_lds();
@@ -161,7 +160,7 @@ __global__ __launch_bounds__(WAVES * 64, (K4 <= 32) ? 2 : 1) void skinny_linear_
         float* yr = y + row * N + n0 + c;
 #pragma unroll
         for (int nb = 0; nb < NBS; ++nb)
-          if (NBS == 4 || n0 + 16 * nb + c < N)
+          if (n0 + 16 * nb + c < N)                       // (the last slab of an N % 64 != 0 output)
             __builtin_nontemporal_store(RES ? C[nb][r] + rv[nb][r] : C[nb][r], yr + 16 * nb);
       }
     }
@@ -172,32 +171,37 @@ __global__ __launch_bounds__(WAVES * 64, (K4 <= 32) ? 2 : 1) void skinny_linear_
 // stays in LDS for the whole launch and every MFMA takes its B operand from there (one 4-byte
 // LDS read per 32-cycle MFMA), 8-wave workgroups share the slab: two waves per SIMD.
 constexpr int WAVES_L = 8;
-template <int K4>
-__global__ __launch_bounds__(WAVES_L * 64, 2) void skinny_linear_wlds_kernel(
+// Also the kernel of the WIDE inputs (K = 132 / 260: [diameter | pos | x] and [.. | x_up | x_skip] of
+// the KITTI-360 width's node MLPs, configs/experiment/semantic/kitti360.yaml:22-27 - 264 B-operand
+// registers otherwise): any K a multiple of 4 (a tile is TR K / 4 16-byte chunks, the last wave-load
+// of a tile partly idle), NWL waves per workgroup so that slab + tiles fit the LDS.
+template <int K4, int NWL = WAVES_L>
+__global__ __launch_bounds__(NWL * 64, NWL / 4) void skinny_linear_wlds_kernel(
     const float* __restrict__ x, int64_t rows, const float* __restrict__ W,
     const float* __restrict__ bias, int N, float* __restrict__ y) {
-  constexpr int K = 4 * K4, LDA = K + 4, V = K4 / 4, NBS = 4;
+  constexpr int K = 4 * K4, LDA = K + 4, NCH = TR * K4, V = (NCH + 63) / 64, NBS = 4;
   __shared__ __attribute__((aligned(16))) float w_lds[16 * NBS * LDA];
-  __shared__ __attribute__((aligned(16))) float a_lds[WAVES_L][TR * LDA];
+  __shared__ __attribute__((aligned(16))) float a_lds[NWL][TR * LDA];
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, c = lane & 15;
   const int n0 = blockIdx.y * (16 * NBS);
   float* al = a_lds[wid];
-  for (int q = threadIdx.x; q < 16 * NBS * K4; q += WAVES_L * 64) {
+  for (int q = threadIdx.x; q < 16 * NBS * K4; q += NWL * 64) {
     const int rr = q / K4, k4 = q - rr * K4;
     *reinterpret_cast<float4*>(w_lds + rr * LDA + 4 * k4) =
-        *reinterpret_cast<const float4*>(W + (size_t)(n0 + rr) * K + 4 * k4);
+        (n0 + rr < N) ? *reinterpret_cast<const float4*>(W + (size_t)(n0 + rr) * K + 4 * k4)
+                      : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   float bb[NBS];
 #pragma unroll
-  for (int nb = 0; nb < NBS; ++nb) bb[nb] = bias ? bias[n0 + 16 * nb + c] : 0.f;
+  for (int nb = 0; nb < NBS; ++nb) bb[nb] = (bias && n0 + 16 * nb + c < N) ? bias[n0 + 16 * nb + c] : 0.f;
   __syncthreads();
   const float* wl = w_lds + c * LDA + g;                // + 16 nb LDA + 4 st
 
   const int64_t ntiles = (rows + TR - 1) / TR;
-  const int64_t wave = (int64_t)blockIdx.x * WAVES_L + wid;
-  const int64_t nwaves = (int64_t)gridDim.x * WAVES_L;
+  const int64_t wave = (int64_t)blockIdx.x * NWL + wid;
+  const int64_t nwaves = (int64_t)gridDim.x * NWL;
   float4 nx[V];
   auto fetch = [&](int64_t t) {
     const int64_t base = t * TR * (int64_t)K;
@@ -205,8 +209,8 @@ __global__ __launch_bounds__(WAVES_L * 64, 2) void skinny_linear_wlds_kernel(
 #pragma unroll
     for (int v = 0; v < V; ++v) {
       const int64_t e = base + (int64_t)(v * 64 + lane) * 4;
-      nx[v] = (e < lim) ? *reinterpret_cast<const float4*>(x + e)
-                        : make_float4(0.f, 0.f, 0.f, 0.f);
+      nx[v] = (v * 64 + lane < NCH && e < lim) ? *reinterpret_cast<const float4*>(x + e)
+                                               : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   if (wave < ntiles) fetch(wave);
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(WAVES_L * 64, 2) void skinny_linear_wlds_kernel(
     for (int v = 0; v < V; ++v) {
       const int q = (v * 64 + lane) * 4;
       const int rr = q / K, k = q - rr * K;
-      *reinterpret_cast<float4*>(al + rr * LDA + k) = nx[v];
+      if (v * 64 + lane < NCH) *reinterpret_cast<float4*>(al + rr * LDA + k) = nx[v];
     }
     wave_sync_lds();
     if (t + nwaves < ntiles) fetch(t + nwaves);         // in flight during the MFMAs
@@ -237,7 +241,8 @@ __global__ __launch_bounds__(WAVES_L * 64, 2) void skinny_linear_wlds_kernel(
       if (row < rows) {
         float* yr = y + row * N + n0 + c;
 #pragma unroll
-        for (int nb = 0; nb < NBS; ++nb) __builtin_nontemporal_store(C[nb][r], yr + 16 * nb);
+        for (int nb = 0; nb < NBS; ++nb)
+          if (n0 + 16 * nb + c < N) __builtin_nontemporal_store(C[nb][r], yr + 16 * nb);
       }
     }
   }
@@ -302,8 +307,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void skinny_dw_kernel(
     for (int v = 0; v < VX; ++v) {
       const int q = v * 64 + lane, rr = q / K4, ch = q - rr * K4;
       const int64_t row = t * TR + rr;
-      nx[v] = (row < rows) ? *reinterpret_cast<const float4*>(x + row * KF + k0 + ch * 4)
-                           : make_float4(0.f, 0.f, 0.f, 0.f);
+      nx[v] = (row < rows && k0 + ch * 4 < KF)            // (columns past KF: the last, narrower slab)
+                  ? *reinterpret_cast<const float4*>(x + row * KF + k0 + ch * 4)
+                  : make_float4(0.f, 0.f, 0.f, 0.f);
       if constexpr (PRE) xg[v] = (row < rows) ? (batch ? (int)batch[row] : 0) : -1;
     }
   };
@@ -363,7 +369,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void skinny_dw_kernel(
     for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        pw[(size_t)(n0 + 16 * nb + 4 * g + r) * KF + k0 + 16 * kb + c] = C[nb][kb][r];
+        if (k0 + 16 * kb + c < KF)
+          pw[(size_t)(n0 + 16 * nb + 4 * g + r) * KF + k0 + 16 * kb + c] = C[nb][kb][r];
 }
 
 // sums of per-wave records [ntab][len], fixed order: 16 columns x 64 slices per 1024-thread block
@@ -487,7 +494,8 @@ using namespace spt::skinny;
 constexpr int DW_BLOCKS = 256;                          // x 4 waves: partial tables per slab
 
 extern "C" int spt_skinny_dw_supported(int K, int N) {
-  return (K == 32 || K == 64 || K == 128) && N >= SLAB && N % SLAB == 0 && N <= 1024;
+  // K > 64 runs as 64-column slabs of x (the last one narrower: 132 = 64 + 64 + 4, 260 = 4 x 64 + 4)
+  return (K == 32 || K == 64 || K == 128 || K == 132 || K == 260) && N >= SLAB && N % SLAB == 0 && N <= 1024;
 }
 extern "C" size_t spt_skinny_dw_workspace_bytes(int K, int N) {
   return (size_t)DW_BLOCKS * WAVES * N * (K + 1) * sizeof(float);
@@ -528,7 +536,7 @@ extern "C" int spt_skinny_dw_pre_f32(const float* gy, const float* x, int64_t ro
   }
   const int64_t tiles = ceil_div(rows, TR);
   int64_t bx = ceil_div(tiles, WAVES);
-  const int kslabs = K > 64 ? K / 64 : 1;
+  const int kslabs = K > 64 ? (K + 63) / 64 : 1;            // the last slab may be narrower (132, 260)
   const int64_t cap = DW_BLOCKS / (slabs * kslabs) > 1 ? DW_BLOCKS / (slabs * kslabs) : 1;
   if (bx > cap) bx = cap;
   const dim3 grid((unsigned)bx, (unsigned)slabs, (unsigned)kslabs);
@@ -552,8 +560,10 @@ extern "C" int spt_skinny_dw_pre_f32(const float* gy, const float* x, int64_t ro
 }
 
 extern "C" int spt_skinny_linear_supported(int K, int N) {
-  const bool kok = K == 32 || K == 64 || K == 128 || K == 192;
-  return kok && ((N >= SLAB && N % SLAB == 0 && N <= 1024) || (N >= 1 && N <= 16 && K <= 128));
+  const bool kok = K == 32 || K == 64 || K == 128 || K == 192 || K == 132 || K == 260;
+  // N: whole 64-column slabs, or (the dX of a 132 / 260-wide input) any width from 64 up - the
+  // last slab's missing columns are read as zero and not stored -, or the narrow heads (<= 16)
+  return kok && ((N >= SLAB && N <= 1024) || (N >= 1 && N <= 16 && K <= 128));
 }
 
 extern "C" int spt_skinny_linear_f32(const float* x, int64_t rows, int K, const float* W,
@@ -582,7 +592,7 @@ extern "C" int spt_skinny_linear_pre_f32(const float* x, int64_t rows, int K, co
                 "pre-normalisation: incomplete tables, unbuilt shape or num_graphs * K too large");
   SPT_CHECK_ARG(!resid || spt_skinny_pre_supported(K, N, 1), "residual epilogue: unbuilt shape");
   const bool narrow = N <= 16;
-  const int slabs = narrow ? 1 : N / SLAB;
+  const int slabs = narrow ? 1 : (N + SLAB - 1) / SLAB;
   const int64_t tiles = ceil_div(rows, TR);
   int64_t bx = ceil_div(tiles, WAVES);
   const int64_t cap = (int64_t)256 * 8 / slabs > 1 ? (int64_t)256 * 8 / slabs : 1;
@@ -621,12 +631,24 @@ extern "C" int spt_skinny_linear_pre_f32(const float* x, int64_t rows, int K, co
     case 32:  skinny_linear_kernel<8><<<grid, WAVES * 64, 0, stream>>>(x, rows, W, bias, N, y); break;
     case 64:  skinny_linear_kernel<16><<<grid, WAVES * 64, 0, stream>>>(x, rows, W, bias, N, y); break;
     case 128: skinny_linear_kernel<32><<<grid, WAVES * 64, 0, stream>>>(x, rows, W, bias, N, y); break;
+    case 260: {                                          // 4-wave workgroups: slab + tiles = 135 KB of LDS
+      int64_t b4 = ceil_div(tiles, (int64_t)4);
+      const int64_t cap4 = (int64_t)256 / slabs > 1 ? (int64_t)256 / slabs : 1;
+      if (b4 > cap4) b4 = cap4;
+      skinny_linear_wlds_kernel<65, 4><<<dim3((unsigned)b4, (unsigned)slabs), 4 * 64, 0, stream>>>(
+          x, rows, W, bias, N, y);
+      break;
+    }
     default: {
       int64_t b8 = ceil_div(tiles, WAVES_L);
-      const int64_t cap8 = (int64_t)256 * 2 / slabs > 1 ? (int64_t)256 * 2 / slabs : 1;
+      const int64_t cap8 = (int64_t)256 * (K == 192 ? 2 : 1) / slabs > 1 ? (int64_t)256 * (K == 192 ? 2 : 1) / slabs : 1;
       if (b8 > cap8) b8 = cap8;
-      skinny_linear_wlds_kernel<48><<<dim3((unsigned)b8, (unsigned)slabs), WAVES_L * 64, 0, stream>>>(
-          x, rows, W, bias, N, y);
+      if (K == 132)
+        skinny_linear_wlds_kernel<33><<<dim3((unsigned)b8, (unsigned)slabs), WAVES_L * 64, 0, stream>>>(
+            x, rows, W, bias, N, y);
+      else
+        skinny_linear_wlds_kernel<48><<<dim3((unsigned)b8, (unsigned)slabs), WAVES_L * 64, 0, stream>>>(
+            x, rows, W, bias, N, y);
       break;
     }
   }

@@ -8,7 +8,10 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("rows", [1, 15, 16, 17, 4099, 70001])
-@pytest.mark.parametrize("K,N", [(64, 192), (64, 64), (192, 64), (32, 64), (128, 128), (192, 192)])
+@pytest.mark.parametrize("K,N", [(64, 192), (64, 64), (192, 64), (32, 64), (128, 128), (192, 192),
+                                 # the KITTI-360 width's node MLPs ([132, 128, 128], [260, 128, 128],
+                                 # kitti360.yaml:22-27): wide inputs, and their dX (132 / 260 OUTPUT columns)
+                                 (132, 128), (260, 128), (128, 132), (128, 260)])
 @pytest.mark.parametrize("bias", [True, False])
 def test_forward_matches_float64(rows, K, N, bias, dev):
     from superpoint_transformer_amd import ops
@@ -25,7 +28,8 @@ def test_forward_matches_float64(rows, K, N, bias, dev):
 def test_linear_autograd_matches_torch(dev):
     from superpoint_transformer_amd import ops
     g = torch.Generator().manual_seed(0)
-    for rows, K, N in ((5000, 64, 192), (140000, 64, 64), (9000, 48, 64)):   # last: library path
+    for rows, K, N in ((5000, 64, 192), (140000, 64, 64), (9000, 48, 64),   # (48, 64): library path
+                       (35000, 132, 128), (14500, 260, 128)):               # the SPT-128 node MLPs
         x = torch.randn(rows, K, generator=g).to(dev).requires_grad_()
         w = (torch.randn(N, K, generator=g) * 0.2).to(dev).requires_grad_()
         b = torch.randn(N, generator=g).to(dev).requires_grad_()
@@ -43,6 +47,8 @@ def test_unsupported_shapes_and_small_inputs_use_the_library(dev):
     from superpoint_transformer_amd import ops, _lib
     assert not _lib.lib.spt_skinny_linear_supported(48, 64)
     assert not _lib.lib.spt_skinny_linear_supported(64, 40)
+    assert _lib.lib.spt_skinny_linear_supported(132, 128) and _lib.lib.spt_skinny_linear_supported(128, 260)
+    assert _lib.lib.spt_skinny_dw_supported(260, 128) and not _lib.lib.spt_skinny_dw_supported(260, 132)
     assert _lib.lib.spt_skinny_linear_supported(64, 13)        # narrow heads are built
     x = torch.randn(100, 64, device=dev)
     w = torch.randn(192, 64, device=dev)
@@ -52,7 +58,8 @@ def test_unsupported_shapes_and_small_inputs_use_the_library(dev):
 
 
 @pytest.mark.parametrize("rows", [1, 15, 16, 17, 4099, 70001, 428_571])
-@pytest.mark.parametrize("K,N", [(64, 192), (64, 64), (32, 64), (32, 128), (128, 128), (128, 256)])
+@pytest.mark.parametrize("K,N", [(64, 192), (64, 64), (32, 64), (32, 128), (128, 128), (128, 256),
+                                 (132, 128), (260, 128)])
 def test_weight_gradient_kernel_matches_float64(rows, K, N, dev):
     """dW = G^T X on the skinny dW kernel (f32 MFMA, per-wave partials, fixed-order sum) against
     float64: the error is that of an f32 sum over `rows` terms - bar 1e-6 * sqrt(rows) of the
