@@ -88,10 +88,31 @@ __global__ __launch_bounds__(256) void usn_stats_group_kernel(
     const int end = sv ? rowptr[s + 1] : 0;
     Box b;
     box_init(b);
-    for (int j = start + lg; j < end; j += g) {
-      const int64_t r = perm ? perm[j] : j;
-      const float x = pos[r * 3], y = pos[r * 3 + 1], z = pos[r * 3 + 2];
-      box_add(b, x, y, z, row_weight(wf, wi, r));
+    // four rows of the lane's stride per trip: the four row ids are requested together, then the
+    // twelve coordinates (round 5: the loop was perm -> pos one row at a time, two dependent
+    // round trips per row with ~2 rows per lane - pure latency; same rows, same order of adds)
+    for (int j0 = start + lg; j0 < end; j0 += 4 * g) {
+      int64_t r[4];
+      bool ok[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = j0 + u * g;
+        ok[u] = j < end;
+        const int jc = ok[u] ? j : start;                     // (a valid position: unconditional load)
+        r[u] = perm ? perm[jc] : jc;
+      }
+      float px[4], py[4], pz[4];
+      double pw[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        px[u] = pos[r[u] * 3];
+        py[u] = pos[r[u] * 3 + 1];
+        pz[u] = pos[r[u] * 3 + 2];
+        pw[u] = row_weight(wf, wi, r[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (ok[u]) box_add(b, px[u], py[u], pz[u], pw[u]);
     }
     for (int o = 1; o < g; o <<= 1) box_merge_xor(b, o);
     if (sv && lg == 0) box_finish(b, end - start, center + s * 3, diam + s);
@@ -210,12 +231,15 @@ __global__ __launch_bounds__(256) void usn_apply_kernel(
 // are copies of x.  (A wave-per-64-rows variant with all header loads in one lane group measured
 // slower: two dependent round trips per block with nothing else in flight.)
 struct f3 { float x, y, z; };
-template <typename I>
+// CC4 > 0: the row's chunk count 1 + cx / 4 as a compile-time constant (3: the 8 point features of
+// level 0, 17 / 33: 64 / 128 segment features) - the chunk -> (row, chunk of row) split is then a
+// multiply-shift instead of a 20-instruction integer division per thread.
+template <typename I, int CC4 = 0>
 __global__ __launch_bounds__(256) void usn_assemble_kernel(
     const float* __restrict__ pos, const int64_t* __restrict__ idx,
     const float* __restrict__ center, const float* __restrict__ diam,
     const float* __restrict__ x, int cx4, int64_t n, float* __restrict__ out) {
-  const I c4 = (I)(cx4 + 1);
+  const I c4 = CC4 > 0 ? (I)CC4 : (I)(cx4 + 1);
   const I total = (I)n * c4;
   const I stride = (I)gridDim.x * blockDim.x;
   for (I q = (I)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += stride) {
@@ -341,7 +365,17 @@ static int usn_launch(const float* pos, const int64_t* idx, const int32_t* perm,
   if (n > 0 && xcat)
   {
     const int64_t chunks = n * (cx / 4 + 1);
-    if (chunks + (int64_t)256 * 4096 < ((int64_t)1 << 32))          // 32-bit index arithmetic
+    const bool i32 = chunks + (int64_t)256 * 4096 < ((int64_t)1 << 32);   // 32-bit index arithmetic
+    if (i32 && cx == 8)
+      usn_assemble_kernel<uint32_t, 3><<<stream_grid(chunks, 256), 256, 0, stream>>>(
+          pos, idx, center, diam, x, cx / 4, n, xcat);
+    else if (i32 && cx == 64)
+      usn_assemble_kernel<uint32_t, 17><<<stream_grid(chunks, 256), 256, 0, stream>>>(
+          pos, idx, center, diam, x, cx / 4, n, xcat);
+    else if (i32 && cx == 128)
+      usn_assemble_kernel<uint32_t, 33><<<stream_grid(chunks, 256), 256, 0, stream>>>(
+          pos, idx, center, diam, x, cx / 4, n, xcat);
+    else if (i32)
       usn_assemble_kernel<uint32_t><<<stream_grid(chunks, 256), 256, 0, stream>>>(
           pos, idx, center, diam, x, cx / 4, n, xcat);
     else
