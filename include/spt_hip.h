@@ -877,6 +877,15 @@ int spt_fused_linear_bwd_pooled_runs_f32(
     float pre_slope, const float* W, float* gx, float* gW, double* prev_total, int mode, void* ws,
     size_t ws_bytes, spt_stream_t stream);
 
+/* Consistency check of a stored segment CSR (pointers [num_seg + 1], points [n], int64 as the
+ * reference's Cluster keeps them, src/data/cluster.py:19-77) against the index it is to be adopted
+ * as the view of (idx [n] int64): ORs into *flag (int32, device; the caller clears it) bit 0 =
+ * pointers not 0 .. n / decreasing, bit 1 = a point outside [0, n), bit 2 = idx[points[j]] is not
+ * the segment holding position j, bit 3 (check_ascending) = a segment's points not ascending.
+ * One launch, no host round trip. */
+int spt_csr_check_i64(const int64_t* idx, const int64_t* points, const int64_t* pointers, int64_t n,
+                      int64_t num_seg, int check_ascending, int32_t* flag, spt_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * The point MLP's TOP layer and the max-pool behind it as one unit     (a1 + a2 + a5, round 5)
  * Replaces, for the layer whose output feeds only the level-0 -> level-1 max-pool

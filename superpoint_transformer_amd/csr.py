@@ -109,7 +109,43 @@ def use_sub_views(on=True):
     return old
 
 
-def adopt_csr(idx, num_seg, pointers, points, ascending=None):
+class StaleCSRError(RuntimeError):
+    """A stored ``sub`` adopted as the CSR view of a ``super_index`` turned out not to describe it."""
+
+
+_PENDING = []          # deferred verdicts: (event, pinned flag, description)
+_CHECK_BITS = {1: "pointers do not run 0 .. n monotonically", 2: "a point id outside [0, n)",
+               4: "membership: idx[points[j]] is not the cluster holding position j",
+               8: "the points of a cluster are not in ascending order"}
+
+
+def _flag_text(v):
+    return "; ".join(t for b, t in _CHECK_BITS.items() if v & b) or "ok"
+
+
+def verify_adopted(block=False):
+    """Read the verdicts of the deferred ``adopt_csr`` checks that have COMPLETED (``block``: wait
+    for all of them) and raise ``StaleCSRError`` for a view that failed.  Never waits on the device
+    unless asked to: the flag travels to pinned host memory behind its check kernel, an event
+    tells when it has arrived."""
+    keep = []
+    for ev, host, what in _PENDING:
+        if block:
+            ev.synchronize()
+        if not ev.query():
+            keep.append((ev, host, what))
+            continue
+        v = int(host[0])
+        if v:
+            _PENDING[:] = []
+            raise StaleCSRError(
+                f"the stored CSR adopted as the view of {what} does not describe it ({_flag_text(v)}): the "
+                "segment kernels grouped wrong rows since that batch - rebuild the NAG's `sub` or call "
+                "csr.use_sub_views(False)")
+    _PENDING[:] = keep
+
+
+def adopt_csr(idx, num_seg, pointers, points, ascending=None, verify="now"):
     """Install ``(pointers, points)`` as the memoised CSR view of ``idx`` - no sort.
 
     The reference's NAG stores, next to every ``super_index``, the same partition as a CSR:
@@ -119,14 +155,21 @@ def adopt_csr(idx, num_seg, pointers, points, ascending=None):
     stable sort of ``build_csr`` produces - the two views are the same arrays, so the per-batch
     sort of the level is skipped: only the int32 casts run (one pass over the level's ids).
 
-    Nothing is taken on trust: the view is adopted only for a contiguous int64 ``idx`` (what
-    ``build_csr`` normalises to and the kernels read), and only after ONE memoised device check
-    per (idx, sub) pair - ``pointers`` starts at 0, ends at ``n`` and never decreases,
-    ``idx[points[j]]`` is the cluster of position ``j`` for every ``j`` (membership; with
-    ``points.numel() == n`` this also makes ``points`` a permutation), and, unless the caller
-    already knows it (``ascending=True``, e.g. ``Cluster.ascending``), the points of every cluster
-    ascend.  A stale or hand-built ``sub`` fails the check and the level falls back to the sort
-    (``None`` is returned)."""
+    Nothing is taken on trust.  The view is adopted only for a contiguous int64 ``idx`` (what
+    ``build_csr`` normalises to and the kernels read), and ONE device kernel per (idx, sub) pair
+    (``spt_csr_check_i64``) checks that ``pointers`` runs 0 .. n without decreasing, that every
+    point id is in range, that ``idx[points[j]]`` is the cluster holding position ``j``
+    (membership; with ``points.numel() == n`` this also makes ``points`` a permutation) and -
+    unless the caller already knows it (``ascending=True``: ``Cluster.ascending``) - that the
+    points of every cluster ascend.
+
+    ``verify``: ``"now"`` (default) reads the verdict before answering - a failing pair returns
+    ``None`` (the level falls back to the sort) and is remembered; ``"deferred"`` (the model's
+    per-batch hook) adopts at once and lets the verdict travel to pinned host memory behind the
+    check kernel: it is read - without ever waiting for the device - by a later ``adopt_csr`` /
+    ``verify_adopted()`` call, which raises ``StaleCSRError`` for a view that failed.  A training
+    step so never pays a host round trip for the check, and a stale ``sub`` stops the run within
+    a step or two instead of silently grouping wrong rows."""
     if not _USE_SUB_VIEWS or idx is None:
         return None
     n = idx.numel()
@@ -137,6 +180,8 @@ def adopt_csr(idx, num_seg, pointers, points, ascending=None):
     if idx.dtype != torch.int64 or not idx.is_contiguous() or idx.dim() != 1:
         return None                     # build_csr normalises these; an adopted view cannot
     _lib.require_cuda(idx)
+    if _PENDING:
+        verify_adopted()
     memo = getattr(idx, _ATTR, None)
     key = (idx._version, num_seg, idx.data_ptr(), n)
     if memo is not None and key in memo:
@@ -145,25 +190,28 @@ def adopt_csr(idx, num_seg, pointers, points, ascending=None):
     vkey = key + (points.data_ptr(), points._version, pointers.data_ptr(), pointers._version)
     if bad == vkey:
         return None                     # this very pair failed the check before
-    if n:
-        pl, ql = points.long(), pointers.long()
-        sizes = ql[1:] - ql[:-1]
-        ok = (ql[0] == 0) & (ql[-1] == n) & (sizes >= 0).all()
-        ok = ok & (pl >= 0).all() & (pl < n).all()
-        if bool(ok):                    # (the gathers below need in-range ids)
-            seg_of_pos = torch.repeat_interleave(
-                torch.arange(num_seg, device=idx.device, dtype=torch.int64), sizes)
-            ok = (idx[pl] == seg_of_pos).all()
-            if ascending is not True and n > 1:
-                inc = pl[1:] > pl[:-1]
-                inc = inc | (seg_of_pos[1:] != seg_of_pos[:-1])
-                ok = ok & inc.all()
-        if not bool(ok):
-            try:
-                setattr(idx, _ATTR_BAD, vkey)
-            except Exception:
-                pass
-            return None
+    dev = idx.device
+    pl = points if points.dtype == torch.int64 else points.long()
+    ql = pointers if pointers.dtype == torch.int64 else pointers.long()
+    pl, ql = pl.contiguous(), ql.contiguous()
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        st = _lib.lib.spt_csr_check_i64(_lib.ptr(idx), _lib.ptr(pl), _lib.ptr(ql), n, num_seg,
+                                        0 if ascending is True else 1, _lib.ptr(flag),
+                                        _lib.stream_ptr(dev))
+    _lib.check(st, "spt_csr_check_i64")
+    if verify == "deferred":
+        host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        host.copy_(flag, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        _PENDING.append((ev, host, f"an index of {n} rows / {num_seg} segments"))
+    elif int(flag.item()):
+        try:
+            setattr(idx, _ATTR_BAD, vkey)
+        except Exception:
+            pass
+        return None
     csr = SegmentCSR(idx.detach(), points.to(torch.int32), pointers.to(torch.int32), n, num_seg)
     if memo is None or any(k[0] != idx._version for k in memo):
         memo = {}

@@ -92,9 +92,10 @@ def _adopt_sub_views(levels):
         if pointers is None or points is None or points.device != si.device:
             continue
         # (adopt_csr verifies membership - and the ascending order unless the Cluster already
-        # knows it - in one memoised device check; a stale `sub` falls back to the sort)
+        # knows it - with one device kernel; the verdict is read a step later without a host
+        # round trip: a stale `sub` raises csr.StaleCSRError then)
         adopt_csr(si, pointers.numel() - 1, pointers, points,
-                  ascending=getattr(sub, "_ascending", None))
+                  ascending=getattr(sub, "_ascending", None), verify="deferred")
 
 
 class SPT(nn.Module):

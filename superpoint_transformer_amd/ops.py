@@ -1359,8 +1359,14 @@ def graph_runs_via(batch, num_graphs, holder, *deps):
     batch pays the read-back."""
     key = tuple((d._version, d.data_ptr(), d.numel()) for d in deps) + (int(num_graphs),)
     memo = getattr(holder, _GRUN_ATTR + "_via", None)
+    host = getattr(holder, "_spt_host_runs", None)
     if memo is not None and memo[0] == key:
         runs = memo[1]
+    elif (host is not None and holder._version == 0 and host[0] == (int(num_graphs), batch.numel())
+          and len(host[1]) <= MAX_FUSED_RUNS):
+        # the batch's maker left the runs on the edge index (host knowledge of the batch layout,
+        # like Batch.ptr: per-cloud edge counts are known where the clouds are concatenated)
+        runs = GraphRuns(list(host[1]), int(num_graphs), batch.numel())
     else:
         runs = graph_runs(batch, num_graphs, batch.numel())
         try:

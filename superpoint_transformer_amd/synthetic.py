@@ -240,6 +240,17 @@ def make_nag(scene="S", seed=1234, device="cpu", sizes=None, point_dim=8,
     else:
         raise ValueError("graph must be 'random' or 'local'")
 
+    if b > 1:
+        # host knowledge of the batch layout, like the node ranges above: the runs of constant cloud
+        # id along every edge index (sorted inside each third of [i<j | j>i | loops]) - what the
+        # edge MLP's run table is built from without reading the device back (ops.graph_runs_via)
+        for ei_, b_ in ((ei1, b1), (ei2, b2)):
+            eb = b_[ei_[0]]
+            starts = [0] + (torch.nonzero(eb[1:] != eb[:-1]).flatten() + 1).tolist()
+            ends = starts[1:] + [int(eb.numel())]
+            ids = eb[torch.tensor(starts, device=device)].tolist()
+            ei_._spt_host_runs = ((b, int(eb.numel())), list(zip(starts, ends, ids)))
+
     def sub_of(si, n_parent):
         """The level's cluster CSR as a stored NAG carries it next to ``super_index``
         (``nag[i+1].sub``, src/data/cluster.py:19-77): children of every cluster ascending."""

@@ -74,6 +74,28 @@ def test_adoption_checks_the_stored_csr_against_the_index(dev):
     csr.forget(si)
 
 
+def test_deferred_verdict_of_an_adopted_view(dev):
+    """The model's per-batch hook adopts with ``verify="deferred"``: no host round trip in the step,
+    the check kernel's verdict travels to pinned memory and is read by a later call - a genuine
+    pair passes silently, a stale one raises ``StaleCSRError`` (here forced with ``block=True``)."""
+    from superpoint_transformer_amd import csr
+    nag = _nag(dev)
+    si, sub = nag[0]["super_index"], nag[1]["sub"]
+    n_par = nag[1]["pos"].shape[0]
+    csr.forget(si)
+    assert csr.adopt_csr(si, n_par, sub.pointers, sub.points, verify="deferred") is not None
+    csr.verify_adopted(block=True)                                   # genuine: nothing happens
+    csr.forget(si)
+    pts = sub.points.clone()
+    a, b = int(sub.pointers[1]) - 1, int(sub.pointers[1])
+    pts[a], pts[b] = sub.points[b].clone(), sub.points[a].clone()    # stale membership
+    assert csr.adopt_csr(si, n_par, sub.pointers, pts, ascending=True, verify="deferred") is not None
+    with pytest.raises(csr.StaleCSRError, match="membership"):
+        csr.verify_adopted(block=True)
+    csr.verify_adopted(block=True)                                   # the queue was cleared
+    csr.forget(si)
+
+
 def test_select_keeps_clusters_ascending(dev):
     from superpoint_transformer_amd.synthetic import make_raw_nag
     nag = make_raw_nag("R", seed=3, device=dev, sizes=(20_000, 600, 250, 5_000, 4_000, 1))
