@@ -274,23 +274,28 @@ __global__ __launch_bounds__(NWF * 64, 2) void fwd_pool_kernel(
     sg = pos_seg[q];
   };
   if (has_rows) {
-  int rid_l, seg_l, rid_n, seg_n;
-  ids_of(pa0, rid_l, seg_l);
-  float4 xv[TR * (K / 4) / 64];                 // raw rows of the tile about to be staged
-  load_rows<K, IN16>(x, rid_l, xv, lane);
-  ids_of(pa0 + TR, rid_n, seg_n);
+  // Software pipeline over the wave's tiles.  Memory operations are waited for by COUNT
+  // (s_waitcnt vmcnt(n): at most n YOUNGER operations outstanding) and the results of a closing
+  // segment are stored from data-dependent control flow, i.e. the compiler has to assume that
+  // none of those stores was issued: any wait placed behind them drains them.  The order below
+  // keeps every wait in front of the stores of its own iteration:
+  //   multiply tile p | stage tile p+1 (its rows were requested before the multiplication) |
+  //   take over the ids of tile p+2 (requested an iteration ago) | pool tile p, STORES |
+  //   request the rows of tile p+2 and the ids of tile p+3.
+  int seg_a, seg_b, rid_c, seg_c;               // segment ids of tile p, p+1; ids of tile p+2
+  float4 xv[TR * (K / 4) / 64];                 // raw rows of the tile to be staged next
+  {
+    int rid0, rid1;
+    ids_of(pa0, rid0, seg_a);
+    load_rows<K, IN16>(x, rid0, xv, lane);
+    ids_of(pa0 + TR, rid1, seg_b);
+    ids_of(pa0 + 2 * TR, rid_c, seg_c);
+    wave_sync_lds();
+    store_rows<K, LDA, true>(xv, (int)((pb0 - pa0) < TR ? (pb0 - pa0) : TR), tab, pslope, al, lane);
+    load_rows<K, IN16>(x, rid1, xv, lane);
+  }
   for (int64_t p = pa0; p < pb0; p += TR) {
     const int cnt = (int)((pb0 - p) < TR ? (pb0 - p) : TR);
-    wave_sync_lds();
-    store_rows<K, LDA, true>(xv, cnt, tab, pslope, al, lane);
-    // the NEXT tile's rows travel while this one is multiplied; the ids of the tile after it too.
-    // The id registers rotate HERE, on values that have arrived (at the loop's end the rotation
-    // would wait for the ids just requested): this tile's segment ids stay in seg_c
-    const int seg_c = seg_l;
-    load_rows<K, IN16>(x, rid_n, xv, lane);
-    rid_l = rid_n;
-    seg_l = seg_n;
-    ids_of(p + 2 * TR, rid_n, seg_n);
     wave_sync_lds();
     // ---- h' = y_prev W'^T ------------------------------------------------------------------
     f32x4 C[NBK];
@@ -370,13 +375,21 @@ __global__ __launch_bounds__(NWF * 64, 2) void fwd_pool_kernel(
           ++gi;
         }
     }
+    // ---- tile p+1 into LDS (every lane has read its operands of tile p), ids of tile p+2 -------
+    wave_sync_lds();
+    {
+      const int64_t left = pb0 - (p + TR);
+      store_rows<K, LDA, true>(xv, (int)(left < 0 ? 0 : (left < TR ? left : TR)), tab, pslope, al, lane);
+      asm volatile("" : "+v"(rid_c), "+v"(seg_c));                 // (the wait for them belongs HERE)
+    }
+    const int seg_cur = seg_a;
     // ---- segment max of the raw tile ---------------------------------------------------------
     {
       const int pos0 = (int)p + 4 * g;                            // position of the lane's row r = 0
       int row = 0;
       while (row < cnt) {
-        const int s = __builtin_amdgcn_readlane(seg_c, row);
-        const uint64_t diff = __ballot(lane < cnt && lane > row && seg_c != s);
+        const int s = __builtin_amdgcn_readlane(seg_cur, row);
+        const uint64_t diff = __ballot(lane < cnt && lane > row && seg_cur != s);
         const int e = diff ? (int)__builtin_ctzll(diff) : cnt;   // rows [row, e) belong to s
         if (s != cur_seg) {
           if (cur_seg >= 0) flush(cur_seg);
@@ -409,6 +422,11 @@ __global__ __launch_bounds__(NWF * 64, 2) void fwd_pool_kernel(
         row = e;
       }
     }
+    // ---- requests for the tiles ahead (behind this tile's stores) -------------------------------
+    load_rows<K, IN16>(x, rid_c, xv, lane);                       // rows of tile p+2
+    seg_a = seg_b;
+    seg_b = seg_c;
+    ids_of(p + 3 * TR, rid_c, seg_c);
   }
   }
   if (cur_seg >= 0) flush(cur_seg);

@@ -152,12 +152,23 @@ def test_bf16_matrix_precision_mode(dev):
         assert max(errs.values()) < 2e-2, errs
         assert errs["out"] > 1e-5           # the mode really is bf16: well above f32 round-off
 
+        # ... and PER ELEMENT (SURVEY 8c words the bf16 bar as an rtol): every element of the
+        # forward output within allclose(rtol = 2e-2, atol = 2e-2 x the tensor's rms) of the
+        # reference fixture - not only the worst element against the tensor's maximum
+        def elementwise(a, r, name):
+            a, r = a.detach().cpu().double(), r.double()
+            bar = 2e-2 * r.abs() + 2e-2 * r.pow(2).mean().sqrt()
+            worst = float(((a - r).abs() / bar).max())
+            assert worst <= 1.0, f"{name}: an element at {worst:.2f} x its bar"
+        elementwise(out, t64(g["out"]), "out")
+
         torch.manual_seed(0)
         mlp = N.MLP([12, 32, 64, 128], norm=N.GraphNorm).to(dev)
         xin = torch.randn(40000, 12, device=dev)
         y = mlp(xin)
         ref = OM.mlp(copy.deepcopy(mlp).double().cpu(), xin.cpu().double(), None, torch.float64)
         assert ((y.detach().cpu().double() - ref).abs().max() / ref.abs().max()).item() < 2e-2
+        elementwise(y, ref, "mlp")
     assert precision.get_matrix_precision() == "f32"
 
 
