@@ -406,9 +406,9 @@ class MortonOrder:
     """Load-time re-ordering of a NAG for MEMORY LOCALITY (round 5; not a transform of the
     reference - its datasets store nodes in the order the partition emitted them, spatial neighbours
     ~0.23 N apart in the demo room).  The top level is sorted by (cloud, Morton code of its
-    position); every level below is re-grouped by its parent in the parent's new order - what
-    ``NAG.select`` does to the descendants of a re-ordered level (src/data/nag.py:306-399) - and,
-    inside a parent, sorted by its own Morton code.  Afterwards the nodes a superpoint-graph edge
+    position); every level below is sorted by its parent (in the parent's new numbering) and,
+    inside a parent, by its own Morton code - each step one ``NAG.select`` with a permutation
+    (src/data/nag.py:306-399), which re-indexes edges, ``super_index`` and ``sub`` consistently.  Afterwards the nodes a superpoint-graph edge
     joins (built by radius search, src/transforms/graph.py:193-321: spatial neighbours) are close
     in memory at every level, the children of a superpoint are contiguous (the pool's CSR view is
     the identity: coalesced streams instead of gathers), and the attention's k / v / record gathers
@@ -436,9 +436,14 @@ class MortonOrder:
         if d.batch is not None:
             key = key + (d.batch.long() << (3 * self.bits))
         nag = nag.select(top, torch.argsort(key, stable=True))
-        for i in range(top - 1, 0, -1):
+        # (NAG.select re-indexes the levels below a re-ordered level but leaves their nodes where
+        # they are: every level is sorted explicitly - by parent, then by its own Morton code;
+        # the points of level 0 by parent only, in their stored order)
+        for i in range(top - 1, -1, -1):
             d = nag[i]
-            key = morton_code(d.pos, self.bits) + (d.super_index.long() << (3 * self.bits))
+            key = d.super_index.long() << (3 * self.bits)
+            if i > 0:
+                key = key + morton_code(d.pos, self.bits)
             nag = nag.select(i, torch.argsort(key, stable=True))
         return nag
 
