@@ -53,8 +53,10 @@ def parse():
     p.add_argument("--graph", default="random", choices=["random", "local"],
                    help="superpoint graph of the synthetic NAG: random = uniformly drawn endpoints (no "
                         "locality: the stress case, default); local = kNN on the segment centroids (SURVEY 8d)")
-    p.add_argument("--order", default="storage", choices=["storage", "morton"],
-                   help="node order of levels 1-2: storage = shuffled (default), morton = along a Morton curve")
+    p.add_argument("--order", default="storage", choices=["storage", "morton", "grouped"],
+                   help="node order: storage = shuffled (default); morton = levels 1-2 along a Morton curve; "
+                        "grouped = the layout of transforms.MortonOrder (levels sorted by parent then curve, "
+                        "level-0 points grouped by superpoint)")
     p.add_argument("--scene-mix", action="store_true",
                    help="N > 1: every rank draws its scene size from the S3DIS area distribution (SCENE_MIX) "
                         "instead of all ranks owning scenes of one shape - shows the imbalance loss of "
@@ -390,8 +392,10 @@ def main():
     north_needed = roof.get("achieved") is None      # the step did not launch the stand-alone pool
     workload = (path.describe(args.scene, SCENES.get(args.scene), args.graph)
                 if args.stages == "all" else path.describe(args.scene, SCENES.get(args.scene)))
-    if args.order != "storage":
+    if args.order == "morton":
         workload += "; level-1/2 nodes stored along a Morton curve"
+    elif args.order == "grouped":
+        workload += "; nodes in the layout of transforms.MortonOrder (sorted by parent, then Morton curve)"
 
     # what the step's one collective cost on this run's process group (RCCL over xGMI, or one
     # rank under SPT_FORCE_COLLECTIVES=1); null without a process group
@@ -448,7 +452,7 @@ def main():
         if north is not None:
             roof.update(north)
         _log("stand-alone north-star kernel timed; building the local-graph scene")
-        nag_l = make_nag(args.scene, seed=1234 + rank, device=dev, graph="local", order="morton")
+        nag_l = make_nag(args.scene, seed=1234 + rank, device=dev, graph="local", order="grouped")
         path_l = hotpath.build(nag_l, dev, world=world, stages=args.stages, mode=args.mode,
                                model=args.model, kernel_timers=True)
         for _ in range(2):
@@ -462,7 +466,8 @@ def main():
         roof_l = path_l.roofline(HBM_PEAK_GBS)
         local = {"ms_per_step": round((time.perf_counter() - t1) / 5 * 1e3, 4),
                  "workload": path_l.describe(args.scene, SCENES.get(args.scene), "local")
-                 + "; level-1/2 nodes stored along a Morton curve",
+                 + "; nodes in the layout of the load-time transform transforms.MortonOrder (level 2 along a "
+                 "Morton curve, level 1 by parent then curve, level-0 points grouped by superpoint)",
                  "kernels": [{k: v for k, v in kk.items() if k in
                               ("kernel", "ms_per_launch", "launches_per_step", "bytes_per_launch",
                                "achieved", "frac")}

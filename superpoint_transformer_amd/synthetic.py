@@ -137,8 +137,8 @@ def _edges_local(gen, pos, e_target, device, cloud=None):
     return torch.stack([torch.cat([lo, hi, loops]), torch.cat([hi, lo, loops])])
 
 
-def _morton_order(pos):
-    """argsort of the 30-bit Morton code of ``pos`` (10 bits per axis)."""
+def _morton_code(pos):
+    """30-bit Morton code of ``pos`` (10 bits per axis)."""
     lo, hi = pos.min(0).values, pos.max(0).values
     q = ((pos - lo) / (hi - lo).clamp_min(1e-9) * 1023.0).long().clamp_(0, 1023)
 
@@ -148,7 +148,12 @@ def _morton_order(pos):
         v = (v | (v << 4)) & 0x030C30C3
         return (v | (v << 2)) & 0x09249249
 
-    return torch.argsort(spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2), stable=True)
+    return spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
+
+
+def _morton_order(pos):
+    """argsort of the 30-bit Morton code of ``pos``."""
+    return torch.argsort(_morton_code(pos), stable=True)
 
 
 class SyntheticNAG:
@@ -180,7 +185,9 @@ def make_nag(scene="S", seed=1234, device="cpu", sizes=None, point_dim=8,
     kNN-on-centroids generator of SURVEY 8(d) (``_edges_local``).  ``order``: "storage"
     (default) keeps the nodes of levels 1 and 2 in their shuffled order - spatial neighbours
     are then far apart in memory, like the demo room (median |s - t| ~ 0.23 N); "morton" stores
-    them along a Morton curve (what a spatially sorted dataset would hand over)."""
+    them along a Morton curve (what a spatially sorted dataset would hand over); "grouped" = the
+    layout ``transforms.MortonOrder`` produces at load time (level 2 along the curve, level 1 by
+    parent then curve, level-0 points grouped by superpoint)."""
     n0, n1, n2, e1, e2, b = sizes if sizes is not None else SCENES[scene]
     if scale != 1.0:
         n0, n1, n2 = (max(int(v * scale), 8) for v in (n0, n1, n2))
@@ -201,10 +208,6 @@ def make_nag(scene="S", seed=1234, device="cpu", sizes=None, point_dim=8,
         si0 = si0[torch.argsort(b2[si1][si0], stable=True)]
     b1 = b2[si1]
     b0 = b1[si0]
-    if b > 1:
-        # what NAGBatch.from_nag_list knows on the host (Batch.ptr): the clouds' node ranges
-        for bt in (b0, b1, b2):
-            bt._spt_host_ptr = [0] + torch.cumsum(torch.bincount(bt, minlength=b), 0).tolist()
 
     def rnd(*shape, s=1.0):
         return torch.randn(*shape, generator=gen, device=device) * s
@@ -226,8 +229,27 @@ def make_nag(scene="S", seed=1234, device="cpu", sizes=None, point_dim=8,
         pos2, b2, si1 = pos2[o2], b2[o2], inv2[si1]
         o1, inv1_ = relabel(pos1, b1)
         pos1, b1, si1, si0 = pos1[o1], b1[o1], si1[o1], inv1_[si0]
+    elif order == "grouped":
+        # the layout transforms.MortonOrder produces at load time: level 2 along a Morton curve
+        # (cloud first), level 1 sorted by parent then by its own Morton code, the points of level 0
+        # grouped by their superpoint (the pool's CSR view becomes the identity)
+        def by_key(key):
+            o = torch.argsort(key, stable=True)
+            inv = torch.empty_like(o)
+            inv[o] = torch.arange(o.numel(), device=device)
+            return o, inv
+        o2, inv2 = by_key(_morton_code(pos2) + (b2 << 30))
+        pos2, b2, si1 = pos2[o2], b2[o2], inv2[si1]
+        o1, inv1_ = by_key(_morton_code(pos1) + (si1 << 30))
+        pos1, b1, si1, si0 = pos1[o1], b1[o1], si1[o1], inv1_[si0]
+        o0 = torch.argsort(si0, stable=True)
+        pos0, b0, si0 = pos0[o0], b0[o0], si0[o0]
     elif order != "storage":
-        raise ValueError("order must be 'storage' or 'morton'")
+        raise ValueError("order must be 'storage', 'morton' or 'grouped'")
+    if b > 1:
+        # what NAGBatch.from_nag_list knows on the host (Batch.ptr): the clouds' node ranges
+        for bt in (b0, b1, b2):
+            bt._spt_host_ptr = [0] + torch.cumsum(torch.bincount(bt, minlength=b), 0).tolist()
     ns1 = torch.bincount(si0, minlength=n1)
     ns2 = torch.zeros(n2, dtype=torch.long, device=device).index_add_(0, si1, ns1)
     c1, c2 = (b1, b2) if b > 1 else (None, None)
