@@ -106,9 +106,24 @@ __device__ __forceinline__ f32x4 mfma16(const bf16x4& a, const bf16x4& b, f32x4 
 // - issued a tile ahead - the trip runs under the previous tile's arithmetic), store_rows writes
 // them to LDS (row stride LD floats), applying y = leaky((v - am) sc + bs) on the way when PRE
 // (tab = am | sc | bs, K floats each; the expression of gn_apply_fwd_kernel).  Rows >= cnt are 0.
+// (bf16 rows stay 8-byte register pairs while they travel and are widened when they are stored:
+// widening at the load would put the wait for the load right behind it)
+template <bool X16>
+struct RowChunk { typedef float4 type; };
+template <>
+struct RowChunk<true> { typedef uint2 type; };
+template <bool X16>
+__device__ __forceinline__ float4 widen(const typename RowChunk<X16>::type& u) {
+  if constexpr (X16) {
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
+                       __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+  } else {
+    return u;
+  }
+}
 template <int K, bool X16>
 __device__ __forceinline__ void load_rows(const float* __restrict__ x, int rid_l,
-                                          float4 (&v)[TR * (K / 4) / 64], int lane) {
+                                          typename RowChunk<X16>::type (&v)[TR * (K / 4) / 64], int lane) {
   constexpr int CH = K / 4, NIT = TR * CH / 64;
   static_assert(TR * CH % 64 == 0, "whole waves of chunks");
   // UNCONDITIONAL loads (tile rows past the end carry the id of a valid row and are zeroed by
@@ -118,17 +133,20 @@ __device__ __forceinline__ void load_rows(const float* __restrict__ x, int rid_l
   for (int j = 0; j < NIT; ++j) {
     const int q = lane + 64 * j, rr = q / CH, k = (q - rr * CH) << 2;
     const int64_t xr = (int64_t)__shfl(rid_l, rr, 64);
-    v[j] = ld4<X16>(x, xr * K + k);
+    if constexpr (X16)
+      v[j] = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(x) + xr * K + k);
+    else
+      v[j] = *reinterpret_cast<const float4*>(x + xr * K + k);
   }
 }
-template <int K, int LD, bool PRE>
-__device__ __forceinline__ void store_rows(const float4 (&v)[TR * (K / 4) / 64], int cnt,
-                                           const float* tab, float slope, float* lds, int lane) {
+template <int K, int LD, bool PRE, bool X16>
+__device__ __forceinline__ void store_rows(const typename RowChunk<X16>::type (&v)[TR * (K / 4) / 64],
+                                           int cnt, const float* tab, float slope, float* lds, int lane) {
   constexpr int CH = K / 4, NIT = TR * CH / 64;
 #pragma unroll
   for (int j = 0; j < NIT; ++j) {
     const int q = lane + 64 * j, rr = q / CH, k = (q - rr * CH) << 2;
-    float4 w = v[j];
+    float4 w = widen<X16>(v[j]);
     if constexpr (PRE) {
       const float4 a = *reinterpret_cast<const float4*>(tab + k);
       const float4 s = *reinterpret_cast<const float4*>(tab + K + k);
@@ -283,7 +301,7 @@ __global__ __launch_bounds__(NWF * 64, 2) void fwd_pool_kernel(
   //   take over the ids of tile p+2 (requested an iteration ago) | pool tile p, STORES |
   //   request the rows of tile p+2 and the ids of tile p+3.
   int seg_a, seg_b, rid_c, seg_c;               // segment ids of tile p, p+1; ids of tile p+2
-  float4 xv[TR * (K / 4) / 64];                 // raw rows of the tile to be staged next
+  typename RowChunk<IN16>::type xv[TR * (K / 4) / 64];   // raw rows of the tile to be staged next
   {
     int rid0, rid1;
     ids_of(pa0, rid0, seg_a);
@@ -291,7 +309,7 @@ __global__ __launch_bounds__(NWF * 64, 2) void fwd_pool_kernel(
     ids_of(pa0 + TR, rid1, seg_b);
     ids_of(pa0 + 2 * TR, rid_c, seg_c);
     wave_sync_lds();
-    store_rows<K, LDA, true>(xv, (int)((pb0 - pa0) < TR ? (pb0 - pa0) : TR), tab, pslope, al, lane);
+    store_rows<K, LDA, true, IN16>(xv, (int)((pb0 - pa0) < TR ? (pb0 - pa0) : TR), tab, pslope, al, lane);
     load_rows<K, IN16>(x, rid1, xv, lane);
   }
   for (int64_t p = pa0; p < pb0; p += TR) {
@@ -379,7 +397,7 @@ __global__ __launch_bounds__(NWF * 64, 2) void fwd_pool_kernel(
     wave_sync_lds();
     {
       const int64_t left = pb0 - (p + TR);
-      store_rows<K, LDA, true>(xv, (int)(left < 0 ? 0 : (left < TR ? left : TR)), tab, pslope, al, lane);
+      store_rows<K, LDA, true, IN16>(xv, (int)(left < 0 ? 0 : (left < TR ? left : TR)), tab, pslope, al, lane);
       asm volatile("" : "+v"(rid_c), "+v"(seg_c));                 // (the wait for them belongs HERE)
     }
     const int seg_cur = seg_a;
@@ -803,7 +821,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_pool_kernel(
   if (ntiles > 0) {                             // (an empty run still writes its zero records below)
   int rid_l, seg_l, rid_n, seg_n;
   load_ids(pair, rid_l, seg_l);
-  float4 xv[TR * (K / 4) / 64];                 // raw rows of the tile about to be staged
+  typename RowChunk<X16>::type xv[TR * (K / 4) / 64];   // raw rows of the tile about to be staged
   load_rows<K, X16>(xprev, rid_l, xv, lane);
   // the tile's FIRST and LAST segment (at 35 rows per segment a tile touches one or two): their
   // (gm, argpos) rows travel a tile ahead like the x rows; further segments are fetched in place
@@ -839,7 +857,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_pool_kernel(
     // ---- RAW xprev tile (gathered rows; rows >= cnt zero).  FIRST: the rows were requested
     // before everything else of this tile, and the rare 3+-segment loop below contains loads of
     // its own - whatever is waited for behind it is waited for with vmcnt(0)
-    store_rows<K, LDX, false>(xv, cnt, nullptr, 1.f, xl, lane);
+    store_rows<K, LDX, false, X16>(xv, cnt, nullptr, 1.f, xl, lane);
     // ---- S tile: zero, then the winners of the tile's segments scattered into it ---------------
     {
       constexpr int NZ = TR * (N / 4) / 64;
