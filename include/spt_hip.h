@@ -707,7 +707,8 @@ int spt_skinny_dw_f32(const float* gy, const float* x, int64_t rows, int N, int 
                       float* gb, void* ws, size_t ws_bytes, spt_stream_t stream);
 /* Narrow Linears (N <= 16 outputs: the classifier heads, src/nn/mlp.py:128-142).  Forward: the
  * skinny kernel above accepts N <= 16 with K in {32, 64, 128} (missing columns read as zero, not
- * stored).  Backward in ONE pass over x and gy for K = 64: gx[rows,K] = gy W (nullable),
+ * stored).  Backward in ONE pass over x and gy for K = 64 and (round 5: the KITTI-360 width's heads,
+ * two 64-column slabs) K = 128: gx[rows,K] = gy W (nullable),
  * gw[N,K] = gy^T x, gb[N] = column sums of gy (nullable); per-wave partials, fixed-order sum. */
 int spt_narrow_linear_bwd_supported(int K, int N);
 size_t spt_narrow_linear_bwd_workspace_bytes(int K, int N);

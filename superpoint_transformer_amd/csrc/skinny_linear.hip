@@ -415,9 +415,12 @@ __global__ __launch_bounds__(1024) void sum_tables_kernel(const float* __restric
 template <int NMAX>
 __global__ __launch_bounds__(256) void narrow_linear_bwd_kernel(
     const float* __restrict__ gy, const float* __restrict__ x, const float* __restrict__ W,
-    int64_t rows, int N, float* __restrict__ gx, float* __restrict__ partial) {
-  constexpr int K = 64, RT = 16;                        // rows per step
-  const int lane = threadIdx.x & 63;
+    int64_t rows, int N, float* __restrict__ gx, float* __restrict__ partial, int K) {
+  // K = the layer's input width: blockIdx.y = its 64-column slab (K = 128, the KITTI-360 width's
+  // heads: two slabs, each re-reading the 13 gradient columns); x, W, gx, the partial records are
+  // addressed with the full row stride K
+  constexpr int RT = 16;                                // rows per step
+  const int lane = (threadIdx.x & 63) + 64 * blockIdx.y;   // this lane's input column
   const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
   float w[NMAX], aw[NMAX], ab[NMAX];
@@ -432,9 +435,10 @@ __global__ __launch_bounds__(256) void narrow_linear_bwd_kernel(
     const int cnt = (int)((rows - row0) < RT ? (rows - row0) : RT);
     // the step's gradient values: RT * N <= 256 floats, element e in lane e & 63 of gt[e >> 6]
     float gt[4];
+    const int wl = threadIdx.x & 63;                    // lane inside the wave (lane = input column)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int e = q * 64 + lane;
+      const int e = q * 64 + wl;
       gt[q] = (e < cnt * N) ? gy[row0 * N + e] : 0.f;
     }
     float xr[RT];
@@ -477,7 +481,7 @@ __global__ __launch_bounds__(256) void narrow_linear_bwd_kernel(
 #pragma unroll
   for (int n = 0; n < NMAX; ++n)
     if (n < N) pw[n * K + lane] = aw[n];
-  if (lane < N) {
+  if (lane < N) {                                       // (slab 0's lanes: the bias gradient once)
     float v = 0.f;
 #pragma unroll
     for (int n = 0; n < NMAX; ++n) v = (lane == n) ? ab[n] : v;
@@ -658,7 +662,7 @@ extern "C" int spt_skinny_linear_pre_f32(const float* x, int64_t rows, int K, co
 
 constexpr int NARROW_BLOCKS = 256;                      // x 4 waves of partial (dW, db)
 
-extern "C" int spt_narrow_linear_bwd_supported(int K, int N) { return K == 64 && N >= 1 && N <= 16; }
+extern "C" int spt_narrow_linear_bwd_supported(int K, int N) { return (K == 64 || K == 128) && N >= 1 && N <= 16; }
 extern "C" size_t spt_narrow_linear_bwd_workspace_bytes(int K, int N) {
   return (size_t)NARROW_BLOCKS * 4 * (16 * K + 16) * sizeof(float);
 }
@@ -684,10 +688,10 @@ extern "C" int spt_narrow_linear_bwd_f32(const float* gy, const float* x, const 
   int nmax;
   if (N == 13) {
     nmax = 13;
-    narrow_linear_bwd_kernel<13><<<(int)bx, 256, 0, stream>>>(gy, x, W, rows, N, gx, partial);
+    narrow_linear_bwd_kernel<13><<<dim3((unsigned)bx, K / 64), 256, 0, stream>>>(gy, x, W, rows, N, gx, partial, K);
   } else {
     nmax = 16;
-    narrow_linear_bwd_kernel<16><<<(int)bx, 256, 0, stream>>>(gy, x, W, rows, N, gx, partial);
+    narrow_linear_bwd_kernel<16><<<dim3((unsigned)bx, K / 64), 256, 0, stream>>>(gy, x, W, rows, N, gx, partial, K);
   }
   (void)nmax;
   sum_tables_kernel<<<(N * (K + 1) + 15) / 16, 1024, 0, stream>>>(partial, (int)bx * 4, N * (K + 1), N * K,
