@@ -157,3 +157,70 @@ def test_graph_runs_of_sorted_and_piecewise_sorted_indices():
     assert ops.graph_runs_via(d2, 4, holder, holder, p) is r1
     holder.add_(0)                                                      # in-place change: new version
     assert ops.graph_runs_via(p.clone(), 4, holder, holder, p) is not r1
+
+
+def test_run_tables_from_host_knowledge_and_forget():
+    """Round 5: the run tables of the fused layers are host knowledge of the batch layout (the
+    reference's ``Batch.ptr``): where a batch's maker leaves the clouds' node ranges on the batch
+    vector (`_spt_host_ptr`) and the runs of constant cloud id on the edge index
+    (`_spt_host_runs`), they are built WITHOUT reading the device tensor back - and `csr.forget`
+    (what a benchmark calls every step to stand for a fresh batch) drops the memoised tables, so
+    a batch without that knowledge pays its read-back every step, as real training does."""
+    from superpoint_transformer_amd import csr, ops
+    nag = synthetic.make_nag(sizes=SIZES_B3, seed=2)
+    for lv in nag.levels:
+        b = lv["batch"]
+        hp = b._spt_host_ptr
+        assert hp[0] == 0 and hp[-1] == b.numel() and len(hp) == 4
+        assert hp == [0] + torch.cumsum(torch.bincount(b, minlength=3), 0).tolist()
+        r = ops.graph_runs(b, 3, b.numel())
+        assert r.sorted_batch and r.r0 == hp[:-1] and r.r1 == hp[1:] and r.g == [0, 1, 2]
+        assert ops.graph_ranges(b, 3, b.numel()) == hp
+        assert hasattr(b, "_spt_graph_runs")
+        csr.forget(b)
+        assert not hasattr(b, "_spt_graph_runs") and not hasattr(b, "_spt_graph_ranges")
+        assert hasattr(b, "_spt_host_ptr")                            # knowledge of the batch stays
+    # a poisoned device tensor shows that the host route never looks at the values
+    b = nag.levels[1]["batch"]
+    fake = torch.full_like(b, 7)
+    fake._spt_host_ptr = list(b._spt_host_ptr)
+    assert ops.graph_runs(fake, 3, fake.numel()).g == [0, 1, 2]
+    # ... and a stale pointer list (wrong length / wrong total) is not trusted
+    stale = b.clone()
+    stale._spt_host_ptr = [0, 5, 9]
+    assert ops.graph_runs(stale, 3, stale.numel()).r1[-1] == stale.numel()
+    for i in (1, 2):
+        lv = nag.levels[i]
+        ei, bb = lv["edge_index"], lv["batch"]
+        (B, ne), runs = ei._spt_host_runs
+        assert B == 3 and ne == ei.shape[1] and len(runs) == 9        # 3 clouds x [i<j | j>i | loops]
+        eb = bb[ei[0]]
+        for a, e, g in runs:
+            assert bool((eb[a:e] == g).all())
+        fake = torch.full_like(eb, 9)                                 # never read on the host route
+        r = ops.graph_runs_via(fake, 3, ei, ei, bb)
+        assert r.n == 9 and r.rows_per_graph() == [int((eb == k).sum()) for k in range(3)]
+
+
+def test_grouped_order_is_the_morton_transform_layout():
+    """``order="grouped"`` of the synthetic generator = what ``transforms.MortonOrder`` produces:
+    children contiguous under their parents at every level, clouds contiguous."""
+    from superpoint_transformer_amd.transforms import morton_code
+    nag = synthetic.make_nag(sizes=SIZES_B3, seed=4, graph="local", order="grouped")
+    lv = nag.levels
+    _check_sub(lv)
+    for l in lv[:2]:
+        si = l["super_index"]
+        assert bool((si[1:] >= si[:-1]).all())                        # grouped by parent
+    for l in lv:
+        b = l["batch"]
+        assert bool((b[1:] >= b[:-1]).all())
+    assert torch.equal(lv[1]["sub"].points, torch.arange(SIZES_B3[0]))   # the pool's view: identity
+    code = morton_code(torch.tensor([[0.0, 0.0, 0.0], [1.0, 1.0, 1.0], [1.0, 0.0, 0.0]]), bits=2)
+    assert code.tolist() == [0, 63, 9]                               # x is the lowest bit of a triple
+
+
+def test_scene_mix_table_of_the_bench():
+    import bench
+    assert len(bench.SCENE_MIX) == 6 and abs(sum(bench.SCENE_MIX) / 6 - 1.0) < 0.01
+    assert max(bench.SCENE_MIX) == 1.73                               # Area 5
