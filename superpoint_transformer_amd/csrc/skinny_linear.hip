@@ -176,7 +176,7 @@ constexpr int WAVES_L = 8;
 // registers otherwise): any K a multiple of 4 (a tile is TR K / 4 16-byte chunks, the last wave-load
 // of a tile partly idle), NWL waves per workgroup so that slab + tiles fit the LDS.
 template <int K4, int NWL = WAVES_L>
-__global__ __launch_bounds__(NWL * 64, NWL / 4) void skinny_linear_wlds_kernel(
+__global__ __launch_bounds__(NWL * 64, (NWL >= 4 ? NWL / 4 : 1)) void skinny_linear_wlds_kernel(
     const float* __restrict__ x, int64_t rows, const float* __restrict__ W,
     const float* __restrict__ bias, int N, float* __restrict__ y) {
   constexpr int K = 4 * K4, LDA = K + 4, NCH = TR * K4, V = (NCH + 63) / 64, NBS = 4;
@@ -564,7 +564,7 @@ extern "C" int spt_skinny_dw_pre_f32(const float* gy, const float* x, int64_t ro
 }
 
 extern "C" int spt_skinny_linear_supported(int K, int N) {
-  const bool kok = K == 32 || K == 64 || K == 128 || K == 192 || K == 132 || K == 260;
+  const bool kok = K == 32 || K == 64 || K == 128 || K == 192 || K == 132 || K == 260 || K == 384;
   // N: whole 64-column slabs, or (the dX of a 132 / 260-wide input) any width from 64 up - the
   // last slab's missing columns are read as zero and not stored -, or the narrow heads (<= 16)
   return kok && ((N >= SLAB && N <= 1024) || (N >= 1 && N <= 16 && K <= 128));
@@ -635,6 +635,14 @@ extern "C" int spt_skinny_linear_pre_f32(const float* x, int64_t rows, int K, co
     case 32:  skinny_linear_kernel<8><<<grid, WAVES * 64, 0, stream>>>(x, rows, W, bias, N, y); break;
     case 64:  skinny_linear_kernel<16><<<grid, WAVES * 64, 0, stream>>>(x, rows, W, bias, N, y); break;
     case 128: skinny_linear_kernel<32><<<grid, WAVES * 64, 0, stream>>>(x, rows, W, bias, N, y); break;
+    case 384: {                                          // dX of the 128-wide blocks' qkv Linear (384 -> 128):
+      int64_t b2 = ceil_div(tiles, (int64_t)2);          // 2-wave workgroups, slab + tiles = 149 KB of LDS
+      const int64_t cap2 = (int64_t)256 / slabs > 1 ? (int64_t)256 / slabs : 1;
+      if (b2 > cap2) b2 = cap2;
+      skinny_linear_wlds_kernel<96, 2><<<dim3((unsigned)b2, (unsigned)slabs), 2 * 64, 0, stream>>>(
+          x, rows, W, bias, N, y);
+      break;
+    }
     case 260: {                                          // 4-wave workgroups: slab + tiles = 135 KB of LDS
       int64_t b4 = ceil_div(tiles, (int64_t)4);
       const int64_t cap4 = (int64_t)256 / slabs > 1 ? (int64_t)256 / slabs : 1;
