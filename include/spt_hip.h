@@ -669,7 +669,7 @@ int spt_edge_affinity_features_bwd_f32(const float* x, const float* gout, int64_
  * Tall-skinny Linear: y [rows, N] = x [rows, K] W[N, K]^T (+ bias [N] or NULL), f32 in /
  * f32 accumulate.  The qkv / out_proj nn.Linear of SelfAttentionBlock
  * (src/nn/attention.py:202-215, 311-313) and, on (gy, W^T), their input gradients.
- * K in {32, 64, 128, 192} and - round 5 - 384 (the dX of the 128-wide blocks' qkv Linear) and
+ * K in {32, 64, 128, 192} and - round 5 - 256 (the dX of the 128-wide blocks' qkv Linear) and
  * 132 / 260: the first Linear of the KITTI-360 width's
  * node MLPs ([4 + 128, 128, 128] / [4 + 256, 128, 128], configs/experiment/semantic/kitti360.yaml:
  * 22-27, src/nn/mlp.py:43-56), which ran on the vendor GEMM before.  N any width from 64 up (a last

@@ -564,7 +564,7 @@ extern "C" int spt_skinny_dw_pre_f32(const float* gy, const float* x, int64_t ro
 }
 
 extern "C" int spt_skinny_linear_supported(int K, int N) {
-  const bool kok = K == 32 || K == 64 || K == 128 || K == 192 || K == 132 || K == 260 || K == 384;
+  const bool kok = K == 32 || K == 64 || K == 128 || K == 192 || K == 132 || K == 260 || K == 256;
   // N: whole 64-column slabs, or (the dX of a 132 / 260-wide input) any width from 64 up - the
   // last slab's missing columns are read as zero and not stored -, or the narrow heads (<= 16)
   return kok && ((N >= SLAB && N <= 1024) || (N >= 1 && N <= 16 && K <= 128));
@@ -635,11 +635,11 @@ extern "C" int spt_skinny_linear_pre_f32(const float* x, int64_t rows, int K, co
     case 32:  skinny_linear_kernel<8><<<grid, WAVES * 64, 0, stream>>>(x, rows, W, bias, N, y); break;
     case 64:  skinny_linear_kernel<16><<<grid, WAVES * 64, 0, stream>>>(x, rows, W, bias, N, y); break;
     case 128: skinny_linear_kernel<32><<<grid, WAVES * 64, 0, stream>>>(x, rows, W, bias, N, y); break;
-    case 384: {                                          // dX of the 128-wide blocks' qkv Linear (384 -> 128):
-      int64_t b2 = ceil_div(tiles, (int64_t)2);          // 2-wave workgroups, slab + tiles = 149 KB of LDS
-      const int64_t cap2 = (int64_t)256 / slabs > 1 ? (int64_t)256 / slabs : 1;
-      if (b2 > cap2) b2 = cap2;
-      skinny_linear_wlds_kernel<96, 2><<<dim3((unsigned)b2, (unsigned)slabs), 2 * 64, 0, stream>>>(
+    case 256: {                                          // dX of the 128-wide blocks' qkv Linear (256 -> 128):
+      int64_t b4 = ceil_div(tiles, (int64_t)4);          // 4-wave workgroups, slab + tiles = 133 KB of LDS
+      const int64_t cap4 = (int64_t)256 / slabs > 1 ? (int64_t)256 / slabs : 1;
+      if (b4 > cap4) b4 = cap4;
+      skinny_linear_wlds_kernel<64, 4><<<dim3((unsigned)b4, (unsigned)slabs), 4 * 64, 0, stream>>>(
           x, rows, W, bias, N, y);
       break;
     }

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("K,N", [(64, 192), (64, 64), (192, 64), (32, 64), (128, 128), (192, 192),
                                  # the KITTI-360 width's node MLPs ([132, 128, 128], [260, 128, 128],
                                  # kitti360.yaml:22-27): wide inputs, and their dX (132 / 260 OUTPUT columns)
-                                 (132, 128), (260, 128), (128, 132), (128, 260), (384, 128)])
+                                 (132, 128), (260, 128), (128, 132), (128, 260), (256, 128)])
 @pytest.mark.parametrize("bias", [True, False])
 def test_forward_matches_float64(rows, K, N, bias, dev):
     from superpoint_transformer_amd import ops
