@@ -457,6 +457,39 @@ int spt_grid_knn_ex_f32(const float* query, int64_t nq, const float* search, int
                         const int32_t* dims, int order_queries_by_cell, int inclusive,
                         int squared, int64_t* idx, float* dist, int32_t* cell_order,
                         int formulation, void* ws, size_t ws_bytes, spt_stream_t stream);
+/* KNN + PointFeatures of the reference's preprocessing chain in ONE call (src/transforms/
+ * neighbors.py:11-95 -> src/transforms/point.py:160-180 -> src/utils/geometry.py:80-126): a
+ * self-search of `xyz` [n, 3] for the K nearest of every point (itself included, column 0:
+ * K = k + 1 of knn_1, K <= 64) that also writes feats [n, 11] = the eigenfeatures (pgeof's
+ * column order) of each point's neighbourhood {found points} - what spt_point_geof_dense_f32
+ * returns for (xyz, idx[:, 1:], add_self = 1, k_min, post), without the index rows and the
+ * neighbours' positions coming back from HBM: the kNN kernel sums the f64 moments of the winners
+ * while their rows are still in cache.  The summation order differs from the stand-alone entry:
+ * results are identical whenever the sums are exact in f64 (coordinates of similar magnitude,
+ * the usual case) and within an ulp of the f32 outputs otherwise.  idx / dist / cell_order /
+ * formulation / ws as in spt_grid_knn_ex_f32 (the one-wave-per-query formulation computes the
+ * features from the index rows it wrote). */
+int spt_grid_knn_geof_f32(const float* xyz, int64_t n, int K, float r, float cell_size,
+                          const float* origin, const int32_t* dims, int inclusive, int squared,
+                          int k_min, int post, int64_t* idx, float* dist, float* feats,
+                          int32_t* cell_order, int formulation, void* ws, size_t ws_bytes,
+                          spt_stream_t stream);
+/* Probes of the host-side grid description (which cell size makes the search fastest; the
+ * RESULT of a search never depends on it).  spt_knn_subsample_f32: the points of the coarse cells
+ * (edge `coarse`, origin lo[3] - HOST floats) whose coordinate hash & 0xFFFF is below `thresh`,
+ * compacted into out [<= n, 3] in no particular order, their number in the DEVICE int32 *count.
+ * spt_grid_cell_ids_f32: the linear cell id ((z * dims[1] + y) * dims[0] + x, clamped) of every
+ * point for a grid description as in spt_grid_knn_f32. */
+int spt_knn_subsample_f32(const float* xyz, int64_t n, const float* lo, float coarse, int thresh,
+                          float* out, int32_t* count, spt_stream_t stream);
+int spt_grid_cell_ids_f32(const float* xyz, int64_t n, float cell_size, const float* origin,
+                          const int32_t* dims, int64_t* cell, spt_stream_t stream);
+/* The number of non-empty cells of that grid in the DEVICE int64 *count (exact: one bit per cell,
+ * set by the points, then counted - no sort).  ws: spt_grid_count_cells_workspace_bytes(ncells). */
+size_t spt_grid_count_cells_workspace_bytes(int64_t ncells);
+int spt_grid_count_cells_f32(const float* xyz, int64_t n, float cell_size, const float* origin,
+                             const int32_t* dims, int64_t* count, void* ws, size_t ws_bytes,
+                             spt_stream_t stream);
 /* Bounding box of a cloud, the input of the host-side grid description above
  * (src/utils/neighbors.py has no counterpart: FRNN derives its grid internally).
  * lo_hi: DEVICE float[12]; [0..3) = min, [3..6) = max, [6..12) scratch. */

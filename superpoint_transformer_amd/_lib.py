@@ -85,12 +85,18 @@ SIGNATURES = {
                                             _int, _p]),
     "spt_grid_knn_ex_f32": (_int, [_p, _i64, _p, _i64, _int, _f32, _f32, _p, _p, _int, _int, _int,
                                    _p, _p, _p, _int, _p, _sz, _p]),
+    "spt_grid_knn_geof_f32": (_int, [_p, _i64, _int, _f32, _f32, _p, _p, _int, _int, _int, _int,
+                                     _p, _p, _p, _p, _int, _p, _sz, _p]),
     "spt_grid_knn_after_f32": (_int, [_p, _i64, _p, _i64, _int, _f32, _f32, _p, _p, _int, _int, _p, _p,
                                       _p, _p, _p, _sz, _p]),
     "spt_grid_knn_f32": (_int, [_p, _i64, _p, _i64, _int, _f32, _f32, _p, _p, _int, _int, _int,
                                 _p, _p, _p, _p, _sz, _p]),
     "spt_point_geof_dense_f32": (_int, [_p, _i64, _p, _int, _int, _int, _int, _p, _p, _p]),
     "spt_bbox_f32": (_int, [_p, _i64, _p, _p]),
+    "spt_knn_subsample_f32": (_int, [_p, _i64, _p, _f32, _int, _p, _p, _p]),
+    "spt_grid_cell_ids_f32": (_int, [_p, _i64, _f32, _p, _p, _p, _p]),
+    "spt_grid_count_cells_workspace_bytes": (_sz, [_i64]),
+    "spt_grid_count_cells_f32": (_int, [_p, _i64, _f32, _p, _p, _p, _p, _sz, _p]),
     "spt_spatial_order_workspace_bytes": (_sz, [_i64, _i64]),
     "spt_spatial_order": (_int, [_p, _i64, _f32, _p, _p, _p, _p, _sz, _p]),
     "spt_point_geof_csr_f32": (_int, [_p, _i64, _p, _p, _int, _int, _int, _p, _p]),

@@ -19,6 +19,7 @@
 #include <math.h>
 
 #include "common.hpp"
+#include "geof_core.hpp"
 
 namespace spt {
 
@@ -432,10 +433,20 @@ __device__ __forceinline__ void kc_d2x4(const KcLds& L, int t, const float4& q, 
   d2[3] = b.y;
 }
 
+// GEOF: the eigenfeatures of every finished query's neighbourhood (the K winners = the point
+// itself + its K - 1 nearest: what geometric_features(xyz, knn_1(xyz, K - 1)) describes) leave the
+// kernel with the neighbour lists.  The winners' rows were gathered for the sort a moment ago; a
+// query's lane walks ITS list once more (rows from L1 / L2), keeps the entries at or below the
+// K-th key the sort found, and sums their moments about the query in f64 - the sums
+// point_geof_dense_kernel forms from the stored index rows, without the 8 (K - 1)-byte index row
+// and the K - 1 position gathers per point coming back from HBM.  One Jacobi per lane at the end
+// of the unit.
+template <bool GEOF>
 __global__ __launch_bounds__(KC_WAVES * 64) void knn_cell_kernel(
     const float4* __restrict__ sorted, int64_t ns, const int32_t* __restrict__ rowptr, Grid g,
     int K, float r, int inclusive, int squared, int64_t* __restrict__ out_idx,
-    float* __restrict__ out_dist, int32_t* __restrict__ todo, int32_t* __restrict__ todo_count) {
+    float* __restrict__ out_dist, int32_t* __restrict__ todo, int32_t* __restrict__ todo_count,
+    int k_min, int post, float* __restrict__ feats) {
   __shared__ KcLds lds_all[KC_WAVES];
   const int lane = threadIdx.x & 63;
   const int wid = threadIdx.x >> 6;
@@ -459,6 +470,10 @@ __global__ __launch_bounds__(KC_WAVES * 64) void knn_cell_kernel(
     const int cy = kc_clamped_cell(q.y, g.oy, g.inv_s, g.dy);
     const int cz = kc_clamped_cell(q.z, g.oz, g.inv_s, g.dz);
     uint64_t pending = __ballot(have);
+    // GEOF: moment sums of the lane's query (filled in the one round that finishes it)
+    double s1[3] = {0.0, 0.0, 0.0}, s2[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    int cnt = 0;
+    bool featured = false;
     while (pending) {
       const int leader = __ffsll((unsigned long long)pending) - 1;
       const int lx = __builtin_amdgcn_readlane(cx, leader), ly = __builtin_amdgcn_readlane(cy, leader),
@@ -567,6 +582,7 @@ __global__ __launch_bounds__(KC_WAVES * 64) void knn_cell_kernel(
       }
       uint64_t todo_sort = __ballot(ok);
       if (todo_sort == 0) continue;
+      uint64_t kth = KNN_EMPTY;         // GEOF: the K-th key of the lane's query (lists shorter than K: all)
 #if SPT_KC_SKIP & 2     /* measurement: rounds end after pass A */
       continue;
 #endif
@@ -655,6 +671,14 @@ __global__ __launch_bounds__(KC_WAVES * 64) void knn_cell_kernel(
           if (hl < n && live)
             key = ((uint64_t)__float_as_uint(kc_d2(qq, pc2)) << 32) | (uint32_t)__float_as_int(pc2.w);
           key = wave_sort_halves(key, lane);
+          if constexpr (GEOF) {
+            const uint32_t alo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, K - 1);
+            const uint32_t ahi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), K - 1);
+            const uint32_t blo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, 32 + K - 1);
+            const uint32_t bhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), 32 + K - 1);
+            if (lane == qa) kth = ((uint64_t)ahi << 32) | alo;
+            if (qb != qa && lane == qb) kth = ((uint64_t)bhi << 32) | blo;
+          }
           if (hl < K && live) {
             const bool okk = key != KNN_EMPTY;
             float d = __uint_as_float((uint32_t)(key >> 32));
@@ -688,7 +712,7 @@ __global__ __launch_bounds__(KC_WAVES * 64) void knn_cell_kernel(
         }
       }
       todo_sort = big;
-      if (todo_sort == 0) continue;
+      if (todo_sort != 0) {
       auto next_q = [&]() {
         const int ql = todo_sort ? __ffsll((unsigned long long)todo_sort) - 1 : -1;
         todo_sort &= todo_sort - 1;
@@ -712,6 +736,11 @@ __global__ __launch_bounds__(KC_WAVES * 64) void knn_cell_kernel(
         if (lane < n)
           key = ((uint64_t)__float_as_uint(kc_d2(qq, pc)) << 32) | (uint32_t)__float_as_int(pc.w);
         key = wave_sort(key, lane);
+        if constexpr (GEOF) {
+          const uint32_t klo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, K - 1);
+          const uint32_t khi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), K - 1);
+          if (lane == ql) kth = ((uint64_t)khi << 32) | klo;
+        }
         if (lane < K) {
           const bool okk = key != KNN_EMPTY;
           float d = __uint_as_float((uint32_t)(key >> 32));
@@ -742,7 +771,92 @@ __global__ __launch_bounds__(KC_WAVES * 64) void knn_cell_kernel(
           pc[gq] = pn[gq];
         }
       }
+      }  // big lists
+      if constexpr (GEOF) {
+        // ---- moments of the round's finished queries, one query per lane: list entry -> row
+        //      (four gathers in flight, unconditional: idle lanes read the round's first row and
+        //      take nothing) -> key as the sort formed it -> at or below the K-th: a winner ----------
+        constexpr int GU = 8;                                 // gathers in flight per lane
+        const double qx = (double)q.x, qy = (double)q.y, qz = (double)q.z;
+        // rows of list entries t .. t + GU - 1: every LDS read and every gather unconditional (an idle
+        // lane reads entry 0 of the round's first block), so that the requests leave together
+        auto request = [&](int t, float4 (&row)[GU], bool (&act)[GU]) {
+          int pos[GU], gi[GU];
+#pragma unroll
+          for (int u = 0; u < GU; ++u) pos[u] = (int)L.list[t + u < KC_CAP ? t + u : KC_CAP][lane];
+#pragma unroll
+          for (int u = 0; u < GU; ++u) {
+            act[u] = ok && t + u < len;
+            pos[u] = act[u] ? pos[u] : 0;
+          }
+#pragma unroll
+          for (int u = 0; u < GU; ++u) gi[u] = gidx(pos[u]);
+#pragma unroll
+          for (int u = 0; u < GU; ++u) row[u] = sorted[gi[u]];
+        };
+        float4 row[GU];
+        bool act[GU];
+        request(0, row, act);
+        for (int t = 0; t < KC_CAP; t += GU) {
+          if (__ballot(ok && t < len) == 0) break;
+          float4 nrow[GU];
+          bool nact[GU];
+          request(t + GU, nrow, nact);
+#pragma unroll
+          for (int u = 0; u < GU; ++u) {
+            const uint64_t key = ((uint64_t)__float_as_uint(kc_d2(q, row[u])) << 32) |
+                                 (uint32_t)__float_as_int(row[u].w);
+            const bool take = act[u] && key <= kth;
+            const double dx = take ? (double)row[u].x - qx : 0.0;
+            const double dy = take ? (double)row[u].y - qy : 0.0;
+            const double dz = take ? (double)row[u].z - qz : 0.0;
+            s1[0] += dx; s1[1] += dy; s1[2] += dz;
+            s2[0] += dx * dx; s2[1] += dx * dy; s2[2] += dx * dz;
+            s2[3] += dy * dy; s2[4] += dy * dz; s2[5] += dz * dz;
+            cnt += take ? 1 : 0;
+          }
+#pragma unroll
+          for (int u = 0; u < GU; ++u) {
+            row[u] = nrow[u];
+            act[u] = nact[u];
+          }
+        }
+        featured = featured || ok;
+      }
     }
+    if constexpr (GEOF) {
+      if (featured)
+        finish_features(s1, s2, cnt, k_min, post, feats + (int64_t)(uint32_t)__float_as_int(q.w) * 11);
+    }
+  }
+}
+
+// Eigenfeatures of the queries the cell kernel left to knn_search_kernel (or of all points when the
+// cell kernel did not run): one lane per listed point, its K found neighbours - itself among them,
+// at distance 0 - read back from the index rows just written.  The same sums about the point's own
+// position as in knn_cell_kernel<true>.
+__global__ __launch_bounds__(256) void knn_geof_rows_kernel(
+    const float* __restrict__ xyz, int64_t n_all, const int32_t* __restrict__ list,
+    const int32_t* __restrict__ n_dev, const int64_t* __restrict__ idx, int K, int k_min, int post,
+    float* __restrict__ feats) {
+  const int64_t n = n_dev ? (int64_t)*n_dev : n_all;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int64_t p = list ? (int64_t)list[i] : i;
+    const double px = xyz[p * 3], py = xyz[p * 3 + 1], pz = xyz[p * 3 + 2];
+    double s1[3] = {0.0, 0.0, 0.0}, s2[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    int cnt = 0;
+    for (int c = 0; c < K; ++c) {
+      const int64_t t = idx[p * K + c];
+      if (t < 0) continue;
+      const double dx = (double)xyz[t * 3] - px, dy = (double)xyz[t * 3 + 1] - py,
+                   dz = (double)xyz[t * 3 + 2] - pz;
+      s1[0] += dx; s1[1] += dy; s1[2] += dz;
+      s2[0] += dx * dx; s2[1] += dx * dy; s2[2] += dx * dz;
+      s2[3] += dy * dy; s2[4] += dy * dz; s2[5] += dz * dz;
+      ++cnt;
+    }
+    finish_features(s1, s2, cnt, k_min, post, feats + p * 11);
   }
 }
 
@@ -875,6 +989,132 @@ extern "C" int spt_spatial_order(const float* xyz, int64_t n, float cell_size, c
                        spt_csr_build_workspace_bytes(n, ncells), stream_);
 }
 
+// ---- the host-side grid description's probes (neighbors._grid_for) as two kernels ---------------
+// The cell size is chosen from the occupancy of the non-empty cells on a spatially coherent
+// subsample: whole coarse cells (edge `coarse`) drawn by a hash of their coordinates.  As torch
+// expressions on the full cloud that was ~25 elementwise launches and three [n, 3] int64
+// temporaries per search (2.5 ms of a 25 ms preprocessing call at 15 M points); here one pass
+// compacts the kept points (order irrelevant: they are only counted per cell) ...
+__global__ __launch_bounds__(256) void knn_subsample_kernel(
+    const float* __restrict__ xyz, int64_t n, float lx, float ly, float lz, float coarse,
+    int thresh, float* __restrict__ out, int32_t* __restrict__ count) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int lane = threadIdx.x & 63;
+  for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x; i0 < n; i0 += stride) {
+    const int64_t i = i0 + threadIdx.x;
+    bool keep = false;
+    float x = 0.f, y = 0.f, z = 0.f;
+    if (i < n) {
+      x = xyz[i * 3]; y = xyz[i * 3 + 1]; z = xyz[i * 3 + 2];
+      const int64_t cx = (int64_t)floorf((x - lx) / coarse), cy = (int64_t)floorf((y - ly) / coarse),
+                    cz = (int64_t)floorf((z - lz) / coarse);
+      const int64_t key = (cx * 73856093ll) ^ (cy * 19349663ll) ^ (cz * 83492791ll);
+      keep = (int)(key & 0xFFFF) < thresh;
+    }
+    const uint64_t m = __ballot(keep);
+    if (m == 0) continue;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(count, __popcll(m));
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (keep) {
+      const int64_t o = (int64_t)base + __popcll(m & lanemask_lt());
+      out[o * 3] = x; out[o * 3 + 1] = y; out[o * 3 + 2] = z;
+    }
+  }
+}
+
+extern "C" int spt_knn_subsample_f32(const float* xyz, int64_t n, const float* lo, float coarse,
+                                     int thresh, float* out, int32_t* count, spt_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPT_CHECK_ARG(n >= 0 && lo && coarse > 0.f, "bad arguments");
+  SPT_CHECK_ARG(count, "null pointer");
+  (void)hipMemsetAsync(count, 0, 4, stream);
+  if (n == 0) return 0;
+  SPT_CHECK_ARG(xyz && out, "null pointer");
+  knn_subsample_kernel<<<stream_grid(n, 256), 256, 0, stream>>>(xyz, n, lo[0], lo[1], lo[2], coarse,
+                                                               thresh, out, count);
+  SPT_CHECK_LAUNCH();
+  return 0;
+}
+
+// ... and the linear cell id of every point at a candidate cell size (counted by the caller)
+extern "C" int spt_grid_cell_ids_f32(const float* xyz, int64_t n, float cell_size,
+                                     const float* origin, const int32_t* dims, int64_t* cell,
+                                     spt_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPT_CHECK_ARG(n >= 0 && cell_size > 0.f && origin && dims, "bad arguments");
+  SPT_CHECK_ARG(dims[0] >= 1 && dims[1] >= 1 && dims[2] >= 1, "bad grid dims");
+  if (n == 0) return 0;
+  SPT_CHECK_ARG(xyz && cell, "null pointer");
+  Grid g;
+  g.ox = origin[0]; g.oy = origin[1]; g.oz = origin[2];
+  g.s = cell_size; g.inv_s = 1.0f / cell_size;
+  g.dx = dims[0]; g.dy = dims[1]; g.dz = dims[2];
+  knn_cell_ids_kernel<<<stream_grid(n, 256), 256, 0, stream>>>(xyz, n, g, cell);
+  SPT_CHECK_LAUNCH();
+  return 0;
+}
+
+// ... or, without the sort a `unique` needs, their NUMBER: one bit per cell, set by the points,
+// counted afterwards (exact; the bitmap is ncells / 8 bytes of the caller's workspace)
+__global__ __launch_bounds__(256) void knn_mark_cells_kernel(const float* __restrict__ pos, int64_t n,
+                                                             Grid g, uint32_t* __restrict__ bits) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    int x = cell_coord(pos[i * 3 + 0], g.ox, g.inv_s);
+    int y = cell_coord(pos[i * 3 + 1], g.oy, g.inv_s);
+    int z = cell_coord(pos[i * 3 + 2], g.oz, g.inv_s);
+    x = x < 0 ? 0 : (x >= g.dx ? g.dx - 1 : x);
+    y = y < 0 ? 0 : (y >= g.dy ? g.dy - 1 : y);
+    z = z < 0 ? 0 : (z >= g.dz ? g.dz - 1 : z);
+    const int64_t c = ((int64_t)z * g.dy + y) * g.dx + x;
+    const uint32_t bit = 1u << (c & 31);
+    if (!(bits[c >> 5] & bit)) atomicOr(&bits[c >> 5], bit);
+  }
+}
+
+__global__ __launch_bounds__(256) void knn_count_bits_kernel(const uint32_t* __restrict__ bits,
+                                                             int64_t nwords,
+                                                             unsigned long long* __restrict__ count) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  uint32_t acc = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += stride)
+    acc += (uint32_t)__popc(bits[i]);
+  acc = wave_reduce_sum(acc);
+  if ((threadIdx.x & 63) == 0 && acc) atomicAdd(count, (unsigned long long)acc);
+}
+
+extern "C" size_t spt_grid_count_cells_workspace_bytes(int64_t ncells) {
+  if (ncells < 1) return 0;
+  return align_up((size_t)((ncells + 31) / 32) * 4, 256) + 256;
+}
+
+extern "C" int spt_grid_count_cells_f32(const float* xyz, int64_t n, float cell_size,
+                                        const float* origin, const int32_t* dims, int64_t* count,
+                                        void* ws, size_t ws_bytes, spt_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPT_CHECK_ARG(n >= 0 && cell_size > 0.f && origin && dims && count, "bad arguments");
+  SPT_CHECK_ARG(dims[0] >= 1 && dims[1] >= 1 && dims[2] >= 1, "bad grid dims");
+  const int64_t ncells = (int64_t)dims[0] * dims[1] * dims[2];
+  SPT_CHECK_ARG(ws && ws_bytes >= spt_grid_count_cells_workspace_bytes(ncells), "workspace too small");
+  SPT_CHECK_ARG(xyz || n == 0, "null pointer");
+  Grid g;
+  g.ox = origin[0]; g.oy = origin[1]; g.oz = origin[2];
+  g.s = cell_size; g.inv_s = 1.0f / cell_size;
+  g.dx = dims[0]; g.dy = dims[1]; g.dz = dims[2];
+  const int64_t nwords = (ncells + 31) / 32;
+  uint32_t* bits = (uint32_t*)ws;
+  (void)hipMemsetAsync(bits, 0, (size_t)nwords * 4, stream);
+  (void)hipMemsetAsync(count, 0, 8, stream);
+  if (n > 0) {
+    knn_mark_cells_kernel<<<stream_grid(n, 256), 256, 0, stream>>>(xyz, n, g, bits);
+    knn_count_bits_kernel<<<stream_grid(nwords, 256), 256, 0, stream>>>(
+        bits, nwords, (unsigned long long*)count);
+  }
+  SPT_CHECK_LAUNCH();
+  return 0;
+}
+
 // process-wide switch between the two self-search kernels (tests cross-check them; 1 = shared
 // candidate streams, 0 = wave per query); returns the previous setting
 static std::atomic<int> g_knn_cell_path{1};
@@ -898,7 +1138,7 @@ static int grid_knn_impl(const float* query, int64_t nq, const float* search, in
                          int order_queries_by_cell, int inclusive, int squared,
                          const int64_t* after_idx, const float* after_d2, int64_t* idx,
                          float* dist, int32_t* cell_order, void* ws, size_t ws_bytes,
-                         spt_stream_t stream_);
+                         spt_stream_t stream_, float* feats = nullptr, int k_min = 1, int post = 0);
 
 extern "C" int spt_grid_knn_f32(const float* query, int64_t nq, const float* search,
                                 int64_t ns, int K, float r, float cell_size,
@@ -928,6 +1168,29 @@ extern "C" int spt_grid_knn_ex_f32(const float* query, int64_t nq, const float* 
   return st;
 }
 
+// Self-search WITH the eigenfeatures of what it finds (KNN + PointFeatures of the reference's
+// preprocessing chain in one call: src/transforms/neighbors.py:11-95 -> src/transforms/point.py:
+// 160-180 -> src/utils/geometry.py:80-126).  Every point searches the cloud for its K nearest
+// (itself included, column 0: K = k + 1 of knn_1); feats[i] = the 11 features (pgeof's column order)
+// of the neighbourhood {found points}: exactly geometric_features(xyz, idx[:, 1:], add_self) of
+// spt_point_geof_dense_f32, the moment sums taken in f64 about the point itself (a different
+// summation order: equal whenever the sums are exact, i.e. for coordinates of similar magnitude,
+// and within an ulp of the f32 outputs otherwise).  formulation as in spt_grid_knn_ex_f32.
+extern "C" int spt_grid_knn_geof_f32(const float* xyz, int64_t n, int K, float r, float cell_size,
+                                     const float* origin, const int32_t* dims, int inclusive,
+                                     int squared, int k_min, int post, int64_t* idx, float* dist,
+                                     float* feats, int32_t* cell_order, int formulation, void* ws,
+                                     size_t ws_bytes, spt_stream_t stream_) {
+  if (!feats) return ::spt::fail(-1, "%s: null feature pointer", __func__);
+  const int prev = tl_knn_cell_path;
+  tl_knn_cell_path = formulation < 0 ? -1 : (formulation != 0);
+  const int st = grid_knn_impl(xyz, n, xyz, n, K, r, cell_size, origin, dims, 1, inclusive, squared,
+                               nullptr, nullptr, idx, dist, cell_order, ws, ws_bytes, stream_, feats,
+                               k_min, post);
+  tl_knn_cell_path = prev;
+  return st;
+}
+
 // The K neighbours ranked strictly AFTER (after_d2[q], after_idx[q]) in the (squared distance,
 // index) order of the contract: chained after a K = 64 search it yields neighbours 65..128
 // (k_max = 100 of cluster_radius_nn_graph, src/utils/neighbors.py:491).  after_idx[q] < 0 (the
@@ -948,9 +1211,11 @@ static int grid_knn_impl(const float* query, int64_t nq, const float* search, in
                          int order_queries_by_cell, int inclusive, int squared,
                          const int64_t* after_idx, const float* after_d2, int64_t* idx,
                          float* dist, int32_t* cell_order, void* ws, size_t ws_bytes,
-                         spt_stream_t stream_) {
+                         spt_stream_t stream_, float* feats, int k_min, int post) {
   hipStream_t stream = (hipStream_t)stream_;
   SPT_CHECK_ARG(nq >= 0 && ns >= 0, "bad shape");
+  SPT_CHECK_ARG(!feats || (query == search && nq == ns && !after_idx),
+                "features come with a self-search only");
   SPT_CHECK_ARG(K >= 1 && K <= 64, "K must be in [1, 64]");
   SPT_CHECK_ARG(r > 0.f && cell_size > 0.f && origin && dims, "bad grid");
   SPT_CHECK_ARG(dims[0] >= 1 && dims[1] >= 1 && dims[2] >= 1, "bad grid dims");
@@ -990,14 +1255,23 @@ static int grid_knn_impl(const float* query, int64_t nq, const float* search, in
     (void)hipMemsetAsync(count, 0, 4, stream);
     const int64_t units = ceil_div(ns, 64);
     const int cgrid = (int)(ceil_div(units, KC_WAVES) < 256 * 8 ? ceil_div(units, KC_WAVES) : 256 * 8);
-    knn_cell_kernel<<<cgrid, KC_WAVES * 64, 0, stream>>>(sorted, ns, rowptr, g, K, r, inclusive,
-                                                         squared, idx, dist, todo, count);
+    if (feats)
+      knn_cell_kernel<true><<<cgrid, KC_WAVES * 64, 0, stream>>>(
+          sorted, ns, rowptr, g, K, r, inclusive, squared, idx, dist, todo, count, k_min, post, feats);
+    else
+      knn_cell_kernel<false><<<cgrid, KC_WAVES * 64, 0, stream>>>(
+          sorted, ns, rowptr, g, K, r, inclusive, squared, idx, dist, todo, count, 0, 0, nullptr);
     knn_search_kernel<<<grid, KNN_WAVES * 64, 0, stream>>>(query, nq, todo, sorted, rowptr, g, K, r,
                                                            inclusive, squared, idx, dist, count);
+    if (feats)      // the leftovers' features, from the rows the kernel above just wrote
+      knn_geof_rows_kernel<<<256, 256, 0, stream>>>(search, ns, todo, count, idx, K, k_min, post, feats);
   } else {
     knn_search_kernel<<<grid, KNN_WAVES * 64, 0, stream>>>(query, nq, qorder, sorted, rowptr, g, K,
                                                            r, inclusive, squared, idx, dist, nullptr,
                                                            after_idx, after_d2);
+    if (feats)
+      knn_geof_rows_kernel<<<stream_grid(ns, 256), 256, 0, stream>>>(search, ns, nullptr, nullptr, idx,
+                                                                     K, k_min, post, feats);
   }
   SPT_CHECK_LAUNCH();
   return 0;

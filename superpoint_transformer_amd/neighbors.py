@@ -9,7 +9,7 @@ from . import _lib
 from . import ops
 from .ops import _workspace
 
-__all__ = ["frnn_grid_points", "knn_1", "knn_1_graph", "oversample_partial_neighborhoods", "knn_2", "neighbors_dense_to_csr",
+__all__ = ["frnn_grid_points", "knn_1", "knn_1_features", "knn_1_graph", "oversample_partial_neighborhoods", "knn_2", "neighbors_dense_to_csr",
            "geometric_features", "GEOF_COLUMNS", "cluster_radius_nn_graph",
            "scatter_nearest_neighbor"]
 
@@ -18,23 +18,23 @@ GEOF_COLUMNS = ["linearity", "planarity", "scattering", "verticality", "normal_x
 
 
 def _bbox(xyz):
-    """(min [3], max [3]) of a contiguous f32 cloud on the device."""
+    """[min (3), max (3)] of a contiguous f32 cloud, on the device."""
     buf = torch.empty(12, dtype=torch.float32, device=xyz.device)
     with torch.cuda.device(xyz.device):
         st = _lib.lib.spt_bbox_f32(_lib.ptr(xyz), xyz.shape[0], _lib.ptr(buf),
                                    _lib.stream_ptr(xyz.device))
     _lib.check(st, "spt_bbox_f32")
-    return buf[0:3], buf[3:6]
+    return buf[0:6]
 
 
 def _grid_for(search, r, K, cell_size=None, self_search=False):
-    """Host-side grid description (one sync: the bounding box).  The result
-    does not depend on the cell size, only the speed does: ~1.5 K points per
-    non-empty cell measured fastest (few rings, few row ranges per ring).  The
-    occupancy is estimated on a <=200 k-point subsample at a coarse probe size
-    and scaled as s^2 (points lie on surfaces)."""
-    lo, hi = _bbox(search)
-    lo_h, hi_h = lo.tolist(), hi.tolist()
+    """Host-side grid description.  The result of a search does not depend on the cell size,
+    only the speed does: ~1.5 K points per non-empty cell measured fastest for the
+    wave-per-query kernel, ~0.75 K for the self-search.  Read-backs: the bounding box, the size
+    of the probe subsample, three cell counts (all from small kernels of this library: the
+    probes were 2.5 ms of a 25 ms preprocessing call as torch expressions)."""
+    lo_hi = _bbox(search).tolist()                      # the one read-back of the bounding box
+    lo_h, hi_h = lo_hi[0:3], lo_hi[3:6]
     ext = [max(h - l, 1e-6) for l, h in zip(lo_h, hi_h)]
     n = search.shape[0]
     if cell_size is None:
@@ -43,25 +43,48 @@ def _grid_for(search, r, K, cell_size=None, self_search=False):
         # points per cell scale as s^d
         import math
         import os
+        dev = search.device
+        o3 = (ctypes.c_float * 3)(*lo_h)
         # probe on a SPATIALLY COHERENT subsample (whole coarse cells of size r, ~2 M points):
         # the counts per fine cell are then exact, which a random subsample cannot give at the
-        # scale of the target cell (a few dozen points)
+        # scale of the target cell (a few dozen points).  One kernel compacts it
+        # (spt_knn_subsample_f32; as torch expressions on the full cloud this was 1 ms at 15 M points)
+        sub = search
         if n > 2_000_000:
-            cc = ((search - lo) / float(r)).floor().long()
-            key0 = (cc[:, 0] * 73856093) ^ (cc[:, 1] * 19349663) ^ (cc[:, 2] * 83492791)
-            keep = (key0 & 0xFFFF) < int(65536 * 2_000_000 / n)
-            sub = search[keep]
-            if sub.shape[0] < 1000:
-                sub = search
-        else:
-            sub = search
+            buf = torch.empty((n, 3), dtype=torch.float32, device=dev)
+            cnt = torch.empty(1, dtype=torch.int32, device=dev)
+            with torch.cuda.device(dev):
+                st = _lib.lib.spt_knn_subsample_f32(
+                    _lib.ptr(search), n, ctypes.cast(o3, ctypes.c_void_p), float(r),
+                    int(65536 * 2_000_000 / n), _lib.ptr(buf), _lib.ptr(cnt), _lib.stream_ptr(dev))
+            _lib.check(st, "spt_knn_subsample_f32")
+            m = int(cnt.item())
+            if m >= 1000:
+                sub = buf[:m]
         m = sub.shape[0]
+        cnt64 = torch.empty(1, dtype=torch.int64, device=dev)
 
         def per_cell(sz):
-            d1 = [int(e / sz) + 1 for e in ext]
-            c = ((sub - lo) / sz).floor().long()
-            lin = (c[:, 2] * d1[1] + c[:, 1]) * d1[0] + c[:, 0]
-            return m / max(int(torch.unique(lin).numel()), 1)
+            """Points per non-empty cell of the subsample at cell size ``sz`` (exact count: one
+            bit per cell, no sort; grids too large for a bitmap: cell ids + ``torch.unique``)."""
+            d1 = [min(int(e / sz) + 1, (1 << 31) - 1) for e in ext]
+            d3 = (ctypes.c_int32 * 3)(*d1)
+            ncells = d1[0] * d1[1] * d1[2]
+            with torch.cuda.device(dev):
+                if ncells <= (1 << 31):                      # a bitmap of <= 256 MB
+                    ws = _workspace(_lib.lib.spt_grid_count_cells_workspace_bytes(ncells), dev)
+                    st = _lib.lib.spt_grid_count_cells_f32(
+                        _lib.ptr(sub), m, float(sz), ctypes.cast(o3, ctypes.c_void_p),
+                        ctypes.cast(d3, ctypes.c_void_p), _lib.ptr(cnt64), _lib.ptr(ws), ws.numel(),
+                        _lib.stream_ptr(dev))
+                    _lib.check(st, "spt_grid_count_cells_f32")
+                    return m / max(int(cnt64.item()), 1)
+                ids = torch.empty(m, dtype=torch.int64, device=dev)
+                st = _lib.lib.spt_grid_cell_ids_f32(
+                    _lib.ptr(sub), m, float(sz), ctypes.cast(o3, ctypes.c_void_p),
+                    ctypes.cast(d3, ctypes.c_void_p), _lib.ptr(ids), _lib.stream_ptr(dev))
+            _lib.check(st, "spt_grid_cell_ids_f32")
+            return m / max(int(torch.unique(ids).numel()), 1)
 
         # first guess from a coarse probe assuming surfaces, then the local dimension and the
         # occupancy measured AT that guess (stacked surfaces look volumetric from afar)
@@ -174,6 +197,51 @@ def knn_1(xyz, k, r_max=1, batch=None, oversample=False, self_is_neighbor=False,
     return idx, dist
 
 
+def knn_1_features(xyz, k, r_max=1, k_min=1, raw=False, squared=True, formulation=-1,
+                   cell_size=None):
+    """``knn_1(xyz, k, r_max)`` and ``geometric_features(xyz, neighbors, k_min)`` in one device
+    pass: the ``KNN`` -> ``PointFeatures`` pair of the reference's preprocessing chain
+    (src/transforms/neighbors.py:11-95, src/transforms/point.py:160-180) without the
+    ``[N, k]`` index rows and the neighbours' positions travelling back from HBM for the
+    eigenfeatures - the kNN kernel sums each neighbourhood's moments while the winners' rows are
+    at hand (``spt_grid_knn_geof_f32``).  Returns ``(neighbors [N,k], distances [N,k],
+    features [N,11])``; neighbours / distances are exactly ``knn_1``'s, the features
+    ``geometric_features``'s (same f64 moments about the point, another summation order:
+    identical where the sums are exact, within an ulp of the f32 outputs otherwise).  One cloud
+    (no ``batch``), the point itself excluded from its neighbours, no oversampling, k <= 63;
+    other settings: call the two functions.  ``formulation`` / ``cell_size``: as in
+    ``spt_grid_knn_ex_f32`` / ``frnn_grid_points`` (tests; the results do not depend on them)."""
+    k = int(k)
+    if k + 1 > 64:
+        raise ValueError("knn_1_features: k + 1 <= 64 (call knn_1 and geometric_features for more)")
+    _lib.require_cuda(xyz)
+    p = xyz.detach().float().contiguous()
+    n = p.shape[0]
+    dev = p.device
+    K = k + 1
+    idx = torch.empty((n, K), dtype=torch.int64, device=dev)
+    dist = torch.empty((n, K), dtype=torch.float32, device=dev)
+    feats = torch.empty((n, 11), dtype=torch.float32, device=dev)
+    if n == 0:
+        return idx[:, 1:], dist[:, 1:], feats
+    cs, origin, dims = _grid_for(p, r_max, K, cell_size, self_search=True)
+    order = torch.empty(n, dtype=torch.int32, device=dev) if n >= _ORDER_MIN_POINTS else None
+    ncells = dims[0] * dims[1] * dims[2]
+    ws = _workspace(_lib.lib.spt_grid_knn_workspace_bytes(n, ncells), dev)
+    o3 = (ctypes.c_float * 3)(*origin)
+    d3 = (ctypes.c_int32 * 3)(*dims)
+    with torch.cuda.device(dev):
+        st = _lib.lib.spt_grid_knn_geof_f32(
+            _lib.ptr(p), n, K, float(r_max), cs, ctypes.cast(o3, ctypes.c_void_p),
+            ctypes.cast(d3, ctypes.c_void_p), 0, int(squared), int(k_min), 0 if raw else 1,
+            _lib.ptr(idx), _lib.ptr(dist), _lib.ptr(feats), _lib.ptr(order), int(formulation),
+            _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev))
+    _lib.check(st, "spt_grid_knn_geof_f32")
+    if order is not None:
+        _remember_order(xyz, order)
+    return idx[:, 1:], dist[:, 1:], feats
+
+
 def oversample_partial_neighborhoods(neighbors, distances, k):
     """Fill the missing (-1) entries of every neighbourhood holding 1..k-1 neighbours with
     uniform draws among the neighbours it does hold, distances following (neighbors.py:420-488;
@@ -277,8 +345,8 @@ def spatial_order(xyz, points_per_cell=32):
     _lib.require_cuda(xyz)
     p = xyz.detach().float().contiguous()
     n = p.shape[0]
-    lo, hi = _bbox(p)
-    ext = float((hi - lo).max())
+    box = _bbox(p)
+    ext = float((box[3:6] - box[0:3]).max())
     s, lo_h, dims = _grid_for(p, max(ext, 1e-3) / 64, points_per_cell / 1.5)
     ncells = dims[0] * dims[1] * dims[2]
     order = torch.empty(max(n, 1), dtype=torch.int32, device=p.device)

@@ -131,6 +131,15 @@ def test_knn_and_geof_at_full_size_against_the_cpu_twin(setting, dev):
     cols = [0, 1, 2, 7, 8, 9, 10]
     err = (feats.cpu()[:, cols] - rf[:, cols]).abs().max().item()
     assert err < 1e-4, err
+    # the same tables and features out of ONE call (the kNN kernel sums the moments itself)
+    nb1, d1, f1 = NB.knn_1_features(pos, k, r, k_min=1)
+    assert torch.equal(nb1, nb) and torch.equal(d1, d)
+    del nb1, d1
+    same = (f1 == feats).all(1).float().mean().item()
+    diff = (f1[:, cols] - feats[:, cols]).abs().max().item()
+    print(f"{setting}: fused features equal bit for bit on {100 * same:.4f} % of the rows, "
+          f"eigenvalue columns max |diff| {diff:.2e}")
+    assert diff <= 1e-6 and same >= 0.99, (same, diff)
 
 
 def test_graph_norm_and_usn_at_scene_scale(dev):

@@ -131,6 +131,56 @@ def test_grid_knn_two_sets_and_euclidean_and_inclusive(dev):
     assert (i0[:, 1:] == -1).all()                      # strict: only the point itself
 
 
+def test_grid_probe_kernels_match_their_torch_expressions(dev):
+    """The host-side grid description probes the cloud with two small kernels: the points of
+    hashed coarse cells (a spatially coherent subsample) and the number of non-empty cells at a
+    candidate cell size.  Both against the torch expressions they replaced."""
+    import ctypes
+    from superpoint_transformer_amd import _lib
+    from superpoint_transformer_amd.ops import _workspace
+    g = torch.Generator().manual_seed(5)
+    xyz = (torch.rand(300_000, 3, generator=g) * torch.tensor([40.0, 25.0, 3.0]) - 7.0).to(dev)
+    lo = xyz.min(0).values.tolist()
+    o3 = (ctypes.c_float * 3)(*lo)
+    r, thresh = 2.0, 9000
+    buf = torch.empty_like(xyz)
+    cnt = torch.empty(1, dtype=torch.int32, device=dev)
+    st = _lib.lib.spt_knn_subsample_f32(_lib.ptr(xyz), xyz.shape[0], ctypes.cast(o3, ctypes.c_void_p), r,
+                                        thresh, _lib.ptr(buf), _lib.ptr(cnt), _lib.stream_ptr(dev))
+    _lib.check(st, "spt_knn_subsample_f32")
+    lo_t = torch.tensor(lo, device=dev)
+    cc = ((xyz - lo_t) / r).floor().long()
+    key = (cc[:, 0] * 73856093) ^ (cc[:, 1] * 19349663) ^ (cc[:, 2] * 83492791)
+    keep = (key & 0xFFFF) < thresh
+    m = int(cnt.item())
+    assert m == int(keep.sum()) and 0 < m < xyz.shape[0]
+    got = buf[:m].cpu()
+    ref = xyz[keep].cpu()
+    srt = lambda t: t[torch.from_numpy(np.lexsort((t[:, 2].numpy(), t[:, 1].numpy(), t[:, 0].numpy())))]
+    assert torch.equal(srt(got), srt(ref))                    # the same points, in some order
+    for sz in (0.5, 0.07):
+        ext = (xyz.max(0).values - xyz.min(0).values).tolist()
+        d1 = [int(e / sz) + 1 for e in ext]
+        d3 = (ctypes.c_int32 * 3)(*d1)
+        ids = torch.empty(xyz.shape[0], dtype=torch.int64, device=dev)
+        st = _lib.lib.spt_grid_cell_ids_f32(_lib.ptr(xyz), xyz.shape[0], sz, ctypes.cast(o3, ctypes.c_void_p),
+                                            ctypes.cast(d3, ctypes.c_void_p), _lib.ptr(ids), _lib.stream_ptr(dev))
+        _lib.check(st, "spt_grid_cell_ids_f32")
+        inv = (torch.ones((), device=dev) / torch.tensor(sz, device=dev))      # 1.0f / sz in f32, as the kernel
+        c = ((xyz - lo_t) * inv).floor().long()
+        for q in range(3):
+            c[:, q].clamp_(0, d1[q] - 1)
+        assert torch.equal(ids, (c[:, 2] * d1[1] + c[:, 1]) * d1[0] + c[:, 0])
+        count = torch.empty(1, dtype=torch.int64, device=dev)
+        ncells = d1[0] * d1[1] * d1[2]
+        ws = _workspace(_lib.lib.spt_grid_count_cells_workspace_bytes(ncells), dev)
+        st = _lib.lib.spt_grid_count_cells_f32(_lib.ptr(xyz), xyz.shape[0], sz, ctypes.cast(o3, ctypes.c_void_p),
+                                               ctypes.cast(d3, ctypes.c_void_p), _lib.ptr(count), _lib.ptr(ws),
+                                               ws.numel(), _lib.stream_ptr(dev))
+        _lib.check(st, "spt_grid_count_cells_f32")
+        assert int(count.item()) == int(torch.unique(ids).numel())
+
+
 def test_knn_1_matches_reference_brute_force_fixture(dev):
     """Golden vector = output of the reference's own knn_brute_force."""
     from superpoint_transformer_amd import neighbors as NB
@@ -216,6 +266,78 @@ def test_geometric_features_vs_oracle_with_partial_neighbourhoods(k_min, dev):
     fc = NB.geometric_features_csr(xyz.to(dev), val.to(dev), ptr.to(dev), k_min=k_min,
                                    add_self=False, raw=False).cpu().double()
     assert torch.equal(fc, f)
+
+
+def _same_features(f, f0, xyz, nn, label):
+    """Features out of the kNN kernel vs geometric_features on its stored rows: the same f64
+    moments about the point in another summation order.  Columns built from eigenVALUES within
+    1e-6; rows whose spectrum is well separated: every column within 1e-5; and the bulk of the
+    rows equal bit for bit (printed)."""
+    f, f0 = f.cpu(), f0.cpu()
+    scal = [0, 1, 2, 7, 8, 9, 10]
+    err = (f[:, scal] - f0[:, scal]).abs().max().item() if f.numel() else 0.0
+    same = (f == f0).all(1).float().mean().item() if f.numel() else 1.0
+    print(f"{label}: rows equal bit for bit {100 * same:.3f} %, max |diff| of the eigenvalue columns {err:.2e}")
+    assert err <= 1e-6, (label, err)
+    good = _spectrum_ok(xyz, nn)
+    if good.any():
+        assert (f[good] - f0[good]).abs().max().item() <= 1e-5, label
+    assert same >= 0.9, (label, same)
+
+
+@pytest.mark.parametrize("name,k,r", [("mixed", 45, 2.0), ("mixed", 20, 0.35), ("mixed", 10, 0.3),
+                                      ("mixed", 63, 50.0), ("lattice", 25, 0.6),
+                                      ("lattice", 45, 10.0), ("lattice", 6, 0.25), ("tiny", 4, 1.0)])
+@pytest.mark.parametrize("cell", [None, 0.11, 0.6, 3.7])
+@pytest.mark.parametrize("k_min", [1, 5])
+def test_knn_1_features_is_knn_1_then_geometric_features(name, k, r, cell, k_min, dev):
+    """One call for the reference's KNN -> PointFeatures pair: neighbours and distances are
+    knn_1's bit for bit, the features geometric_features' - from the cell kernel (moments summed
+    next to the sort), from its leftovers (cells far too fine / too coarse push queries there)
+    and from the one-wave-per-query formulation, partial and empty neighbourhoods included."""
+    from superpoint_transformer_amd import neighbors as NB
+    xyz = _clouds()[name]
+    p = xyz.to(dev)
+    nb0, d0 = NB.knn_1(p, k, r)
+    f0 = NB.geometric_features(p, nb0.contiguous(), k_min=k_min, order=False)
+    small = ((nb0 >= 0).sum(1) + 1) < k_min
+    for formulation in (-1, 0):
+        nb, d, f = NB.knn_1_features(p, k, r, k_min=k_min, formulation=formulation, cell_size=cell)
+        assert torch.equal(nb, nb0) and torch.equal(d, d0), formulation
+        assert bool((f[small] == 0).all())
+        _same_features(f, f0, xyz, nb0.cpu(), f"{name} k={k} r={r} cell={cell} formulation={formulation}")
+    # raw = without the tail of geometric_features (verticality * 2, normals flipped to z >= 0)
+    _, _, fr = NB.knn_1_features(p, k, r, k_min=k_min, raw=True, cell_size=cell)
+    fr0 = NB.geometric_features(p, nb0.contiguous(), k_min=k_min, raw=True, order=False)
+    _same_features(fr, fr0, xyz, nb0.cpu(), f"{name} raw")
+
+
+def test_knn_1_features_against_the_f64_oracle(dev):
+    from superpoint_transformer_amd import neighbors as NB
+    xyz = _clouds()["mixed"]
+    nb, d, f = NB.knn_1_features(xyz.to(dev), 20, 0.35, k_min=1)
+    rd, ri = O.frnn_grid_points(xyz, xyz, 21, 0.35)
+    assert torch.equal(nb.cpu(), ri[:, 1:]) and torch.equal(d.cpu(), rd[:, 1:])
+    ref = O.geometric_features(xyz.double(), ri[:, 1:], k_min=1)
+    f = f.cpu().double()
+    scal = [0, 1, 2, 7, 8, 9, 10]
+    assert (f[:, scal] - ref[:, scal]).abs().max().item() <= 1e-4
+    good = _spectrum_ok(xyz, ri[:, 1:]) & ((ri[:, 1:] >= 0).sum(1) + 1 >= 4)
+    assert (f[good][:, 3:7] - ref[good][:, 3:7]).abs().max().item() <= 1e-4
+
+
+def test_knn_1_features_on_demo_room(dev):
+    """Real S3DIS room at the reference's settings (k = 45, r = 2 m), > 200 k points: the cell
+    order is remembered for later gather kernels as knn_1 does."""
+    from superpoint_transformer_amd import neighbors as NB
+    pos = torch.from_numpy(demo_nag()[0]["pos"]).float().to(dev)
+    nb0, d0 = NB.knn_1(pos, 45, 2.0)
+    f0 = NB.geometric_features(pos, nb0, k_min=5)
+    nb, d, f = NB.knn_1_features(pos, 45, 2.0, k_min=5)
+    assert torch.equal(nb, nb0) and torch.equal(d, d0)
+    _same_features(f, f0, pos.cpu(), nb0.cpu(), "demo room")
+    with pytest.raises(ValueError):
+        NB.knn_1_features(pos, 64, 2.0)
 
 
 def test_preprocess_pipeline_on_demo_room_regresses_to_stored_features(dev):
