@@ -535,6 +535,11 @@ int spt_spatial_order(const float* xyz, int64_t n, float cell_size, const float*
 int spt_point_geof_dense_f32(const float* xyz, int64_t n, const int64_t* nn, int k,
                              int add_self, int k_min, int post, const int32_t* order,
                              float* feats, spt_stream_t stream);
+/* The same with a row pitch: nn[i * ld + c], ld >= k - a column slice of a wider table (knn_1's
+ * [N, k] result is columns 1 .. k of a [N, k + 1] search) is read in place. */
+int spt_point_geof_dense_ld_f32(const float* xyz, int64_t n, const int64_t* nn, int k, int64_t ld,
+                                int add_self, int k_min, int post, const int32_t* order,
+                                float* feats, spt_stream_t stream);
 int spt_point_geof_csr_f32(const float* xyz, int64_t n, const int64_t* nn_val,
                            const int64_t* nn_ptr, int add_self, int k_min, int post,
                            float* feats, spt_stream_t stream);

@@ -92,6 +92,7 @@ SIGNATURES = {
     "spt_grid_knn_f32": (_int, [_p, _i64, _p, _i64, _int, _f32, _f32, _p, _p, _int, _int, _int,
                                 _p, _p, _p, _p, _sz, _p]),
     "spt_point_geof_dense_f32": (_int, [_p, _i64, _p, _int, _int, _int, _int, _p, _p, _p]),
+    "spt_point_geof_dense_ld_f32": (_int, [_p, _i64, _p, _int, _i64, _int, _int, _int, _p, _p, _p]),
     "spt_bbox_f32": (_int, [_p, _i64, _p, _p]),
     "spt_knn_subsample_f32": (_int, [_p, _i64, _p, _f32, _int, _p, _p, _p]),
     "spt_grid_cell_ids_f32": (_int, [_p, _i64, _f32, _p, _p, _p, _p]),

@@ -67,7 +67,7 @@ constexpr int GEOF_CH = 8;              // index columns per chunk
 constexpr int GEOF_LD = GEOF_CH + 1;    // padded LDS row (int64 units)
 
 __global__ __launch_bounds__(256) void point_geof_dense_kernel(
-    const float* __restrict__ xyz, int64_t n, const int64_t* __restrict__ nn, int k,
+    const float* __restrict__ xyz, int64_t n, const int64_t* __restrict__ nn, int k, int64_t ld,
     int add_self, int k_min, int post, const int32_t* __restrict__ order,
     float* __restrict__ feats) {
   __shared__ int64_t idx_lds[4][64 * GEOF_LD];
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void point_geof_dense_kernel(
       for (int p = 0; p < 8; ++p) {
         const int64_t ri = __shfl(i, 8 * p + sub, 64);
         const bool ok = ri >= 0 && c0 + cc < k;
-        iv[p] = nn[ok ? ri * k + c0 + cc : 0];
+        iv[p] = nn[ok ? ri * ld + c0 + cc : 0];
         iv[p] = ok ? iv[p] : -1;
       }
 #pragma unroll
@@ -149,18 +149,29 @@ __global__ __launch_bounds__(256) void point_geof_dense_kernel(
 
 using namespace spt;
 
+// ld: elements between the starts of consecutive rows of nn (>= k): the [N, k] table knn_1 hands
+// out is columns 1 .. k of a [N, k + 1] search result - read in place, not copied (5.3 GB each way
+// at 15 M points, k = 45)
+extern "C" int spt_point_geof_dense_ld_f32(const float* xyz, int64_t n, const int64_t* nn,
+                                           int k, int64_t ld, int add_self, int k_min, int post,
+                                           const int32_t* order, float* feats,
+                                           spt_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPT_CHECK_ARG(n >= 0 && k >= 0 && ld >= k, "bad shape");
+  if (n == 0) return 0;
+  SPT_CHECK_ARG(xyz && feats && (nn || k == 0), "null pointer");
+  point_geof_dense_kernel<<<stream_grid(n, 256), 256, 0, stream>>>(
+      xyz, n, nn, k, ld, add_self, k_min, post, order, feats);
+  SPT_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int spt_point_geof_dense_f32(const float* xyz, int64_t n, const int64_t* nn,
                                         int k, int add_self, int k_min, int post,
                                         const int32_t* order, float* feats,
                                         spt_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  SPT_CHECK_ARG(n >= 0 && k >= 0, "bad shape");
-  if (n == 0) return 0;
-  SPT_CHECK_ARG(xyz && feats && (nn || k == 0), "null pointer");
-  point_geof_dense_kernel<<<stream_grid(n, 256), 256, 0, stream>>>(
-      xyz, n, nn, k, add_self, k_min, post, order, feats);
-  SPT_CHECK_LAUNCH();
-  return 0;
+  return spt_point_geof_dense_ld_f32(xyz, n, nn, k, (int64_t)k, add_self, k_min, post, order, feats,
+                                     stream_);
 }
 
 // ---- scatter_pca (src/utils/scatter.py:41-125) as an entry of its own ----------------------

@@ -416,10 +416,14 @@ def geometric_features(xyz, nn, k_min=1, add_self_as_neighbor=True, raw=False, o
                                            bool(add_self_as_neighbor), raw, order)
     _lib.require_cuda(xyz, nn)
     p = xyz.detach().float().contiguous()
-    nn = nn.contiguous()
     if nn.dtype != torch.int64:
         nn = nn.long()
+    # a column slice of a wider row-major table (knn_1's result) is read in place
+    if nn.dim() != 2 or (nn.shape[1] > 0 and nn.stride(1) != 1) or nn.stride(0) < nn.shape[1] \
+            or nn.shape[0] <= 1:
+        nn = nn.contiguous()
     n, k = nn.shape
+    ld = nn.stride(0) if n > 1 and k > 0 else k
     if order is None and n == xyz.shape[0]:
         order = _recall_order(xyz)          # left by a preceding knn_1 on this very tensor
     if order is False:
@@ -428,10 +432,10 @@ def geometric_features(xyz, nn, k_min=1, add_self_as_neighbor=True, raw=False, o
         order = order.to(torch.int32).contiguous()
     feats = torch.empty((n, 11), dtype=torch.float32, device=p.device)
     with torch.cuda.device(p.device):
-        st = _lib.lib.spt_point_geof_dense_f32(
-            _lib.ptr(p), n, _lib.ptr(nn), k, int(add_self_as_neighbor), int(k_min),
+        st = _lib.lib.spt_point_geof_dense_ld_f32(
+            _lib.ptr(p), n, _lib.ptr(nn), k, int(ld), int(add_self_as_neighbor), int(k_min),
             0 if raw else 1, _lib.ptr(order), _lib.ptr(feats), _lib.stream_ptr(p.device))
-    _lib.check(st, "spt_point_geof_dense_f32")
+    _lib.check(st, "spt_point_geof_dense_ld_f32")
     return feats
 
 

@@ -300,6 +300,9 @@ def test_knn_1_features_is_knn_1_then_geometric_features(name, k, r, cell, k_min
     p = xyz.to(dev)
     nb0, d0 = NB.knn_1(p, k, r)
     f0 = NB.geometric_features(p, nb0.contiguous(), k_min=k_min, order=False)
+    # knn_1's table is a column slice of the [N, k + 1] search result: read in place (row pitch)
+    assert not nb0.is_contiguous() or nb0.shape[0] <= 1
+    assert torch.equal(NB.geometric_features(p, nb0, k_min=k_min, order=False), f0)
     small = ((nb0 >= 0).sum(1) + 1) < k_min
     for formulation in (-1, 0):
         nb, d, f = NB.knn_1_features(p, k, r, k_min=k_min, formulation=formulation, cell_size=cell)

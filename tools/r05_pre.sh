@@ -4,7 +4,7 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 T=${1:-r05p}
-timeout 600 python -m pytest tests/test_neighbors_gpu.py -q -x --no-header -p no:cacheprovider -s -k "knn_1_features" > gpurun_out/${T}_pytest_fused.log 2>&1
+timeout 600 python -m pytest tests/test_neighbors_gpu.py -q -x --no-header -p no:cacheprovider -s -k "knn_1_features or probe or geometric" > gpurun_out/${T}_pytest_fused.log 2>&1
 echo "fused tests rc=$?"
 grep -E "passed|failed|^FAILED|^E  " gpurun_out/${T}_pytest_fused.log | cut -c1-200 | head -12
 grep "bit for bit" gpurun_out/${T}_pytest_fused.log | sort | uniq -c | sort -n | head -8
