@@ -220,6 +220,15 @@ def preprocess_leg(scene, n_points, dev, reps=5):
             "geof": {"kernel": "spt::point_geof_dense_kernel", "bound": "hbm",
                      "bytes_per_launch": int(geof_b), "achieved": round(geof_gbs, 1), "unit": "GB/s",
                      "peak": HBM_PEAK_GBS, "frac": round(geof_gbs / HBM_PEAK_GBS, 4)}}
+    fused_b = n_points * (12 + 12 * (k + 1) + 44)
+    roof["knn_geof"] = {"kernel": "spt::knn_cell_kernel<true> (+ grid description, grid build, leftovers): "
+                                  "the one-call entry `value` is quoted on",
+                        "bound": "valu+lds", "bytes_per_launch": int(fused_b),
+                        "achieved": round(fused_b / dt / 1e9, 1), "unit": "GB/s",
+                        "frac_hbm": round(fused_b / dt / 1e9 / HBM_PEAK_GBS, 4),
+                        "bound_note": "as `knn`; the moment sums and the 3 x 3 eigenproblems add f64 "
+                                      "vector work (+2.6 ms at scene S), no HBM traffic beyond the 44 B "
+                                      "feature row per point"}
     return {"value": round(n_points / dt / 1e6, 3), "unit": "Mpoints/s",
             "workload": f"knn_1(k={k}, r={r}) + geometric_features on {n_points} synthetic "
                         f"voxelised-surface points ({voxel} m lattice): neighbours, distances and "
