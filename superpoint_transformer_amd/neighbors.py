@@ -30,7 +30,7 @@ def _bbox(xyz):
 def _grid_for(search, r, K, cell_size=None, self_search=False):
     """Host-side grid description.  The result of a search does not depend on the cell size,
     only the speed does: ~1.5 K points per non-empty cell measured fastest for the
-    wave-per-query kernel, ~0.75 K for the self-search.  Read-backs: the bounding box, the size
+    wave-per-query kernel, ~0.6 K for the self-search.  Read-backs: the bounding box, the size
     of the probe subsample, three cell counts (all from small kernels of this library: the
     probes were 2.5 ms of a 25 ms preprocessing call as torch expressions)."""
     lo_hi = _bbox(search).tolist()                      # the one read-back of the bounding box
@@ -95,7 +95,9 @@ def _grid_for(search, r, K, cell_size=None, self_search=False):
         dim = min(max(math.log2(max(o2 / max(o1, 1e-9), 1.0 + 1e-6)), 1.0), 3.0)
         # self-search (shared candidate streams): the wave scans 5 x 9 cells per 64 queries, so
         # fewer points per cell than the wave-per-query kernel likes (SPT_KNN_OCC: tuning knob)
-        occ_k = float(os.environ.get("SPT_KNN_OCC", "0.75" if self_search else "1.5"))
+        # (0.6: re-measured in round 5 at both preprocessing settings - 0.55 .. 0.65 within 2 %,
+        # 0.75 4 % and 0.9 20 % slower, with or without the eigenfeatures in the kernel)
+        occ_k = float(os.environ.get("SPT_KNN_OCC", "0.6" if self_search else "1.5"))
         target = max(occ_k * K, 8.0)
         s = s1 * (target / max(occ1, 1e-3)) ** (1.0 / dim)
         s = min(max(s, float(r) / 64), float(r))
