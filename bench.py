@@ -224,6 +224,8 @@ def preprocess_leg(scene, n_points, dev, reps=5):
     roof["knn_geof"] = {"kernel": "spt::knn_cell_kernel<true> (+ grid description, grid build, leftovers): "
                                   "the one-call entry `value` is quoted on",
                         "bound": "valu+lds", "bytes_per_launch": int(fused_b),
+                        "valu_busy": pmc.get("knn_geof_valu_busy") if pmc else None,
+                        "valu_busy_source": pmc.get("source_r05") if pmc else None,
                         "achieved": round(fused_b / dt / 1e9, 1), "unit": "GB/s",
                         "frac_hbm": round(fused_b / dt / 1e9 / HBM_PEAK_GBS, 4),
                         "bound_note": "as `knn`; the moment sums and the 3 x 3 eigenproblems add f64 "
