@@ -503,7 +503,9 @@ def main():
                              for kk in roof_l.get("kernels", []) if "attention" in kk["kernel"]]}
         del path_l, nag_l
         _log(f"local-graph steps done: {local['ms_per_step']} ms per step")
-    elif world == 1 and north_needed:
+    elif north_needed and rank == 0:
+        # (N > 1 too: rank 0 times the stand-alone kernel on its own scene - no collective involved -
+        # so that every line of a scaling run carries `roofline.achieved`)
         north = path.northstar(HBM_PEAK_GBS)
         if north is not None:
             roof.update(north)
@@ -567,6 +569,7 @@ def main():
         }
         print(json.dumps(line))
     if world > 1 or force_dist:
+        barrier()                     # the other ranks leave with rank 0, not while it still measures
         dist.destroy_process_group()
 
 

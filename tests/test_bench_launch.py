@@ -32,7 +32,7 @@ def test_gpus_2_spawns_two_ranks_share_gpu():
         env.pop(k, None)
     r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1",
                         "--settle", "1.0",      # the settle phase holds a collective per step too
-                        "--scene", "R", "--no-cpu-baseline", "--no-preprocess"],
+                        "--scene", "T", "--no-cpu-baseline", "--no-preprocess"],
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -41,6 +41,9 @@ def test_gpus_2_spawns_two_ranks_share_gpu():
     assert out["n_gpus"] == 2
     assert out["config"]["parallelism"] == "dp2"
     assert out["value"] > 0
+    # every line of a scaling run carries the north-star kernel's measurement (rank 0, stand-alone)
+    assert out["roofline"]["achieved"] and 0 < out["roofline"]["frac"] <= 1
+    assert out["cpu_baseline"] is None           # N = 1 only, by the bench contract
 
 
 def test_world_size_from_the_launcher_is_taken_when_gpus_is_not_given():
