@@ -392,12 +392,14 @@ def main():
         path.step()
     path.reset_kernel_timers()
 
+    device_index = local              # (`local` is reused for the local-graph companion below)
+
     def barrier():
         if world > 1 or force_dist:
             if share:
                 dist.barrier()
             else:
-                dist.barrier(device_ids=[local])
+                dist.barrier(device_ids=[device_index])
         torch.cuda.synchronize()
 
     _log("warm-up done, timing")
