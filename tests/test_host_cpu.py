@@ -224,3 +224,25 @@ def test_scene_mix_table_of_the_bench():
     import bench
     assert len(bench.SCENE_MIX) == 6 and abs(sum(bench.SCENE_MIX) / 6 - 1.0) < 0.01
     assert max(bench.SCENE_MIX) == 1.73                               # Area 5
+
+
+def test_product_ops_refuse_cpu_tensors_loudly():
+    """There is no CPU fallback anywhere in the product: an op handed a CPU tensor raises at once
+    (the message says so) instead of computing something else somewhere else; argument errors that
+    need no device are reported before that."""
+    import pytest
+    import torch
+    from superpoint_transformer_amd import neighbors as NB
+    from superpoint_transformer_amd import ops
+    xyz = torch.rand(64, 3)
+    nn = torch.randint(0, 64, (64, 5))
+    idx = torch.randint(0, 8, (64,))
+    for call in (lambda: NB.knn_1(xyz, 5, 0.5),
+                 lambda: NB.knn_1_features(xyz, 5, 0.5),
+                 lambda: NB.geometric_features(xyz, nn),
+                 lambda: NB.frnn_grid_points(xyz, xyz, 4, 0.5),
+                 lambda: ops.segment_reduce(torch.rand(64, 8), idx, 8, "max")):
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            call()
+    with pytest.raises(ValueError, match="k \\+ 1 <= 64"):
+        NB.knn_1_features(xyz, 64, 0.5)
