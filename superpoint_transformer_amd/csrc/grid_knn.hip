@@ -774,7 +774,7 @@ __global__ __launch_bounds__(KC_WAVES * 64) void knn_cell_kernel(
       }  // big lists
       if constexpr (GEOF) {
         // ---- moments of the round's finished queries, one query per lane: list entry -> row
-        //      (four gathers in flight, unconditional: idle lanes read the round's first row and
+        //      (GU gathers in flight, unconditional: idle lanes read the round's first row and
         //      take nothing) -> key as the sort formed it -> at or below the K-th: a winner ----------
         constexpr int GU = 8;                                 // gathers in flight per lane
         const double qx = (double)q.x, qy = (double)q.y, qz = (double)q.z;
