@@ -925,6 +925,15 @@ int spt_fused_linear_bwd_pooled_runs_f32(
  * One launch, no host round trip. */
 int spt_csr_check_i64(const int64_t* idx, const int64_t* points, const int64_t* pointers, int64_t n,
                       int64_t num_seg, int check_ascending, int32_t* flag, spt_stream_t stream);
+/* Round 6: the same check AND the int32 view the segment kernels read, in one launch - what
+ * csr.adopt_csr runs when it installs nag[i+1].sub as the view of nag[i].super_index
+ * (src/data/cluster.py:19-77, src/data/nag.py:306-399).  perm32 [n] = points clamped into [0, n),
+ * rowptr32 [num_seg + 1] = pointers clamped into [0, n]: a stored CSR that fails the check cannot
+ * lead a segment kernel outside its buffers before the (deferred) verdict has been read.  The
+ * ascending comparison (bit 3) always runs.  *flag as above (the caller clears it). */
+int spt_csr_adopt_i64(const int64_t* idx, const int64_t* points, const int64_t* pointers, int64_t n,
+                      int64_t num_seg, int32_t* perm32, int32_t* rowptr32, int32_t* flag,
+                      spt_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * The point MLP's TOP layer and the max-pool behind it as one unit     (a1 + a2 + a5, round 5)

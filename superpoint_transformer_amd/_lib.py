@@ -145,6 +145,7 @@ SIGNATURES = {
                                                     _p, _p, _p, _f32, _p, _p, _p, _p, _int, _p, _p,
                                                     _p, _f32, _p, _p, _p, _p, _int, _p, _sz, _p]),
     "spt_csr_check_i64": (_int, [_p, _p, _p, _i64, _i64, _int, _p, _p]),
+    "spt_csr_adopt_i64": (_int, [_p, _p, _p, _i64, _i64, _p, _p, _p, _p]),
     "spt_fused_linear_pool_supported": (_int, [_int, _int, _int]),
     "spt_fused_linear_pool_gram_len": (_sz, [_int]),
     "spt_fused_linear_pool_workspace_bytes": (_sz, [_int, _int]),

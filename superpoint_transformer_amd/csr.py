@@ -9,6 +9,8 @@ the pool, UnitSphereNorm, unpool-backward and softmax-group uses of one
 (``Tensor._version``) and dies with the tensor object - it is never keyed on
 ``data_ptr`` alone (the caching allocator recycles addresses).
 """
+import weakref
+
 import torch
 
 from . import _lib
@@ -113,36 +115,85 @@ class StaleCSRError(RuntimeError):
     """A stored ``sub`` adopted as the CSR view of a ``super_index`` turned out not to describe it."""
 
 
-_PENDING = []          # deferred verdicts: (event, pinned flag, description)
+_PENDING = []          # deferred verdicts: (event | None, host flag | device flag, description, idx weakref, key, vkey)
 _CHECK_BITS = {1: "pointers do not run 0 .. n monotonically", 2: "a point id outside [0, n)",
                4: "membership: idx[points[j]] is not the cluster holding position j",
                8: "the points of a cluster are not in ascending order"}
+_ORDER_ONLY = 8        # a consistent partition whose clusters do not ascend: legitimate, just not the sort's view
+_PINNED = {}           # ring of pinned int32 verdict slots (one hipHostMalloc per process, not per batch)
 
 
 def _flag_text(v):
     return "; ".join(t for b, t in _CHECK_BITS.items() if v & b) or "ok"
 
 
+def _pinned_slot():
+    ring = _PINNED.get("ring")
+    if ring is None:
+        ring = _PINNED["ring"] = torch.zeros(256, dtype=torch.int32).pin_memory()
+        _PINNED["next"] = 0
+    busy = {h.data_ptr() for ev, h, *_ in _PENDING if ev is not None}
+    for _ in range(ring.numel()):
+        i = _PINNED["next"]
+        _PINNED["next"] = (i + 1) % ring.numel()
+        slot = ring[i:i + 1]
+        if slot.data_ptr() not in busy:
+            return slot
+    return torch.zeros(1, dtype=torch.int32).pin_memory()     # > 256 verdicts in flight
+
+
+def _drop_view(ref, key, vkey, remember):
+    """Take a failed pair's view off its index tensor; ``remember``: the next ``adopt_csr`` of the
+    same pair answers None at once (the level goes to the sort)."""
+    idx = ref() if ref is not None else None
+    if idx is None:
+        return
+    memo = getattr(idx, _ATTR, None)
+    if memo is not None:
+        memo.pop(key, None)
+    if remember:
+        try:
+            setattr(idx, _ATTR_BAD, vkey)
+        except Exception:
+            pass
+
+
 def verify_adopted(block=False):
     """Read the verdicts of the deferred ``adopt_csr`` checks that have COMPLETED (``block``: wait
-    for all of them) and raise ``StaleCSRError`` for a view that failed.  Never waits on the device
-    unless asked to: the flag travels to pinned host memory behind its check kernel, an event
-    tells when it has arrived."""
-    keep = []
-    for ev, host, what in _PENDING:
-        if block:
-            ev.synchronize()
-        if not ev.query():
-            keep.append((ev, host, what))
-            continue
-        v = int(host[0])
+    for all of them).  A view that failed on pointers, point range or membership is taken off its
+    index tensor and ``StaleCSRError`` is raised; a consistent partition whose clusters merely do
+    not ascend (a legitimate ``sub``: the reference builds Cluster with a non-stable sort,
+    src/data/cluster.py:19-77) is dropped silently - the level goes to the device sort from the
+    next batch on, the batches it served grouped the right rows (arg-max ties aside).  Never waits
+    on the device unless asked to: the flag travels to pinned host memory behind its check kernel,
+    an event tells when it has arrived.  Call with ``block=True`` where results leave the device
+    (``SPT.forward`` does so outside training) and after the last batch of a training run."""
+    keep, failed = [], None
+    for item in _PENDING:
+        ev, host, what, ref, key, vkey = item
+        if ev is None:                  # recorded under stream capture: a device flag, read only on request
+            if not block:
+                keep.append(item)
+                continue
+            v = int(host.item())
+        else:
+            if block:
+                ev.synchronize()
+            if not ev.query():
+                keep.append(item)
+                continue
+            v = int(host[0])
         if v:
-            _PENDING[:] = []
-            raise StaleCSRError(
-                f"the stored CSR adopted as the view of {what} does not describe it ({_flag_text(v)}): the "
-                "segment kernels grouped wrong rows since that batch - rebuild the NAG's `sub` or call "
-                "csr.use_sub_views(False)")
+            _drop_view(ref, key, vkey, remember=True)
+        if v & ~_ORDER_ONLY and failed is None:
+            failed = (what, v)
     _PENDING[:] = keep
+    if failed is not None:
+        raise StaleCSRError(
+            f"the stored CSR adopted as the view of {failed[0]} does not describe it "
+            f"({_flag_text(failed[1])}): the segment kernels grouped wrong rows since that batch (inside "
+            "their buffers: the adopted view is clamped) - rebuild the NAG's `sub` or call "
+            "csr.use_sub_views(False)")
 
 
 def adopt_csr(idx, num_seg, pointers, points, ascending=None, verify="now"):
@@ -153,24 +204,27 @@ def adopt_csr(idx, num_seg, pointers, points, ascending=None, verify="now"):
     cluster ``c`` (src/data/cluster.py:19-77; kept consistent by ``NAG.select``,
     src/data/nag.py:306-399).  With the children of a cluster in ascending order - what the
     stable sort of ``build_csr`` produces - the two views are the same arrays, so the per-batch
-    sort of the level is skipped: only the int32 casts run (one pass over the level's ids).
+    sort of the level is skipped: ONE kernel (``spt_csr_adopt_i64``) writes the int32 view the
+    segment kernels read and checks it on the way.
 
     Nothing is taken on trust.  The view is adopted only for a contiguous int64 ``idx`` (what
-    ``build_csr`` normalises to and the kernels read), and ONE device kernel per (idx, sub) pair
-    (``spt_csr_check_i64``) checks that ``pointers`` runs 0 .. n without decreasing, that every
-    point id is in range, that ``idx[points[j]]`` is the cluster holding position ``j``
-    (membership; with ``points.numel() == n`` this also makes ``points`` a permutation) and -
-    unless the caller already knows it (``ascending=True``: ``Cluster.ascending``) - that the
-    points of every cluster ascend.
+    ``build_csr`` normalises to and the kernels read), and the kernel checks that ``pointers``
+    runs 0 .. n without decreasing, that every point id is in range, that ``idx[points[j]]`` is
+    the cluster holding position ``j`` (membership) and that the points of every cluster ascend
+    STRICTLY - membership + strict ascent + ``points.numel() == n`` make ``points`` a permutation
+    (a duplicate inside a cluster fails the ascent, one across clusters fails membership).  The
+    ascent is compared whatever ``ascending`` says (one neighbouring load); a ``sub`` known NOT to
+    ascend (``ascending=False``) is not adopted at all.  The int32 view is CLAMPED into the
+    buffers, so a pair that fails cannot send a segment kernel out of bounds before its verdict
+    has been read.
 
     ``verify``: ``"now"`` (default) reads the verdict before answering - a failing pair returns
     ``None`` (the level falls back to the sort) and is remembered; ``"deferred"`` (the model's
     per-batch hook) adopts at once and lets the verdict travel to pinned host memory behind the
-    check kernel: it is read - without ever waiting for the device - by a later ``adopt_csr`` /
-    ``verify_adopted()`` call, which raises ``StaleCSRError`` for a view that failed.  A training
-    step so never pays a host round trip for the check, and a stale ``sub`` stops the run within
-    a step or two instead of silently grouping wrong rows."""
-    if not _USE_SUB_VIEWS or idx is None:
+    kernel: it is read - without ever waiting for the device - by a later ``adopt_csr`` /
+    ``verify_adopted()`` call (``verify_adopted`` says what happens to a view that failed).  A
+    training step so never pays a host round trip for the check."""
+    if not _USE_SUB_VIEWS or idx is None or ascending is False:
         return None
     n = idx.numel()
     num_seg = max(int(num_seg), 1)
@@ -180,7 +234,8 @@ def adopt_csr(idx, num_seg, pointers, points, ascending=None, verify="now"):
     if idx.dtype != torch.int64 or not idx.is_contiguous() or idx.dim() != 1:
         return None                     # build_csr normalises these; an adopted view cannot
     _lib.require_cuda(idx)
-    if _PENDING:
+    capturing = torch.cuda.is_current_stream_capturing()
+    if _PENDING and not capturing:
         verify_adopted()
     memo = getattr(idx, _ATTR, None)
     key = (idx._version, num_seg, idx.data_ptr(), n)
@@ -195,24 +250,35 @@ def adopt_csr(idx, num_seg, pointers, points, ascending=None, verify="now"):
     ql = pointers if pointers.dtype == torch.int64 else pointers.long()
     pl, ql = pl.contiguous(), ql.contiguous()
     flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    perm = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    rowptr = torch.empty(num_seg + 1, dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
-        st = _lib.lib.spt_csr_check_i64(_lib.ptr(idx), _lib.ptr(pl), _lib.ptr(ql), n, num_seg,
-                                        0 if ascending is True else 1, _lib.ptr(flag),
+        st = _lib.lib.spt_csr_adopt_i64(_lib.ptr(idx), _lib.ptr(pl), _lib.ptr(ql), n, num_seg,
+                                        _lib.ptr(perm), _lib.ptr(rowptr), _lib.ptr(flag),
                                         _lib.stream_ptr(dev))
-    _lib.check(st, "spt_csr_check_i64")
-    if verify == "deferred":
-        host = torch.zeros(1, dtype=torch.int32).pin_memory()
+    _lib.check(st, "spt_csr_adopt_i64")
+    what = f"an index of {n} rows / {num_seg} segments"
+    try:
+        ref = weakref.ref(idx)
+    except TypeError:
+        ref = None
+    if verify == "deferred" and capturing:
+        # inside a captured graph no event can be queried: the device flag stays with the graph's
+        # memory and is read by verify_adopted(block=True) whenever the caller asks
+        _PENDING.append((None, flag, what, ref, key, vkey))
+    elif verify == "deferred":
+        host = _pinned_slot()
         host.copy_(flag, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(dev))
-        _PENDING.append((ev, host, f"an index of {n} rows / {num_seg} segments"))
+        _PENDING.append((ev, host, what, ref, key, vkey))
     elif int(flag.item()):
         try:
             setattr(idx, _ATTR_BAD, vkey)
         except Exception:
             pass
         return None
-    csr = SegmentCSR(idx.detach(), points.to(torch.int32), pointers.to(torch.int32), n, num_seg)
+    csr = SegmentCSR(idx.detach(), perm[:n], rowptr, n, num_seg)
     if memo is None or any(k[0] != idx._version for k in memo):
         memo = {}
         try:

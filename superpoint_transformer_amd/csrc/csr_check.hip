@@ -34,12 +34,79 @@ __global__ __launch_bounds__(256) void csr_check_kernel(
       if (pointers[mid] <= j) lo = mid; else hi = mid - 1;
     }
     if (!(pointers[lo] <= j && j < pointers[lo + 1]) || idx[p] != lo) bad |= 4;
-    if (check_ascending && j > pointers[lo] && points[j - 1] >= p) bad |= 8;
+    if (check_ascending && j > 0 && j > pointers[lo] && points[j - 1] >= p) bad |= 8;
+  }
+  if (bad) atomicOr(flag, bad);
+}
+
+// Round 6 (advisor, medium): adopt = check + the int32 casts the segment kernels read, in ONE launch.
+// The casts are CLAMPED (perm into [0, n), rowptr into [0, n] and never ahead of position j's own
+// chunk), so a stored CSR that fails the check cannot send a segment kernel outside its buffers
+// while the verdict is still on its way to the host (csr.adopt_csr(verify="deferred")).  A
+// workgroup owns a contiguous chunk of positions: two searches bound the segments the chunk
+// touches and every position's own search runs inside that window (5 steps instead of 19 at
+// 428 571 segments); the ascending comparison always runs (one neighbouring load).
+constexpr int ADOPT_CHUNK = 2048;
+
+__device__ __forceinline__ int64_t seg_of_pos(const int64_t* __restrict__ pointers, int64_t lo,
+                                              int64_t hi, int64_t j) {
+  while (lo < hi) {
+    const int64_t mid = (lo + hi + 1) >> 1;
+    if (pointers[mid] <= j) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(256) void csr_adopt_kernel(
+    const int64_t* __restrict__ idx, const int64_t* __restrict__ points,
+    const int64_t* __restrict__ pointers, int64_t n, int64_t num_seg,
+    int32_t* __restrict__ perm32, int32_t* __restrict__ rowptr32, int32_t* __restrict__ flag) {
+  int bad = 0;
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t s = tid; s <= num_seg; s += nthreads) {
+    const int64_t p = pointers[s];
+    if (s < num_seg && p > pointers[s + 1]) bad |= 1;
+    if ((s == 0 && p != 0) || (s == num_seg && p != n)) bad |= 1;
+    rowptr32[s] = (int32_t)(p < 0 ? 0 : (p > n ? n : p));
+  }
+  const int64_t nchunks = (n + ADOPT_CHUNK - 1) / ADOPT_CHUNK;
+  for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    const int64_t j0 = c * ADOPT_CHUNK;
+    const int64_t j1 = j0 + ADOPT_CHUNK < n ? j0 + ADOPT_CHUNK : n;
+    // (wave-uniform searches: garbage pointers cannot lead them outside [0, num_seg))
+    const int64_t slo = seg_of_pos(pointers, 0, num_seg - 1, j0);
+    const int64_t shi = seg_of_pos(pointers, slo, num_seg - 1, j1 - 1);
+    for (int64_t j = j0 + threadIdx.x; j < j1; j += blockDim.x) {
+      const int64_t p = points[j];
+      const bool inr = p >= 0 && p < n;
+      perm32[j] = (int32_t)(inr ? p : (p < 0 ? 0 : n - 1));
+      if (!inr) {
+        bad |= 2;
+        continue;
+      }
+      const int64_t s = seg_of_pos(pointers, slo, shi, j);
+      if (!(pointers[s] <= j && j < pointers[s + 1]) || idx[p] != s) bad |= 4;
+      if (j > 0 && j > pointers[s] && points[j - 1] >= p) bad |= 8;
+    }
   }
   if (bad) atomicOr(flag, bad);
 }
 
 }  // namespace spt
+
+extern "C" int spt_csr_adopt_i64(const int64_t* idx, const int64_t* points, const int64_t* pointers,
+                                 int64_t n, int64_t num_seg, int32_t* perm32, int32_t* rowptr32,
+                                 int32_t* flag, spt_stream_t stream_) {
+  SPT_CHECK_ARG(n >= 0 && num_seg >= 1 && n < (int64_t)INT32_MAX, "bad shape");
+  SPT_CHECK_ARG(pointers && flag && rowptr32 && (n == 0 || (idx && points && perm32)), "null pointer");
+  const int64_t chunks = spt::ceil_div(n, spt::ADOPT_CHUNK);
+  const int64_t blocks = chunks > spt::ceil_div(num_seg + 1, 256) ? chunks : spt::ceil_div(num_seg + 1, 256);
+  spt::csr_adopt_kernel<<<(int)(blocks < 1 ? 1 : (blocks > 256 * 32 ? 256 * 32 : blocks)), 256, 0,
+                          (hipStream_t)stream_>>>(idx, points, pointers, n, num_seg, perm32, rowptr32, flag);
+  SPT_CHECK_LAUNCH();
+  return 0;
+}
 
 extern "C" int spt_csr_check_i64(const int64_t* idx, const int64_t* points, const int64_t* pointers,
                                  int64_t n, int64_t num_seg, int check_ascending, int32_t* flag,

@@ -40,7 +40,7 @@ __device__ __forceinline__ void wave_sync_lds() {
 // live in LDS.  RES: y = (x W^T + b) + res (the block's residual `shortcut + out_proj(.)`).
 constexpr int PRE_MAX = 1024;  // floats per coefficient table in LDS (num_graphs x K)
 template <int K4, int NBS = 4, bool PRE = false, bool RES = false>
-__global__ __launch_bounds__(WAVES * 64, (K4 <= 32) ? 2 : 1) void skinny_linear_kernel(
+__global__ __launch_bounds__(WAVES * 64, (K4 < 32 || (K4 == 32 && !PRE)) ? 2 : 1) void skinny_linear_kernel(
     const float* __restrict__ x, int64_t rows, const float* __restrict__ W,
     const float* __restrict__ bias, int N, float* __restrict__ y,
     const float* __restrict__ pam = nullptr, const float* __restrict__ psc = nullptr,

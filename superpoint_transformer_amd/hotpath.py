@@ -348,7 +348,7 @@ class SPTTrainStep:
         roof["kernels"] = kernels
         return roof
 
-    def northstar(self, peak_gbs, reps=5):
+    def northstar(self, peak_gbs, reps=20):
         """The north-star segment-CSR scatter kernel on its own: ``MaxPool.__call__`` of the
         level-0 -> level-1 pool (src/nn/pool.py:61-82) = ``ops.segment_reduce(x, super_index, max,
         arg)`` on a [N0, 128] f32 tensor through the scene's own CSR view, timed with HIP events on

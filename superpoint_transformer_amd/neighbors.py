@@ -71,7 +71,9 @@ def _grid_for(search, r, K, cell_size=None, self_search=False):
             d3 = (ctypes.c_int32 * 3)(*d1)
             ncells = d1[0] * d1[1] * d1[2]
             with torch.cuda.device(dev):
-                if ncells <= (1 << 31):                      # a bitmap of <= 256 MB
+                if ncells <= (1 << 28):
+                    # a bitmap of <= 32 MB (the cached workspace keeps its largest size for the
+                    # life of the process: finer grids take the ids + unique route on temporaries)
                     ws = _workspace(_lib.lib.spt_grid_count_cells_workspace_bytes(ncells), dev)
                     st = _lib.lib.spt_grid_count_cells_f32(
                         _lib.ptr(sub), m, float(sz), ctypes.cast(o3, ctypes.c_void_p),

@@ -13,7 +13,7 @@ import torch
 from torch import nn
 
 from .. import ops
-from ..csr import adopt_csr
+from ..csr import adopt_csr, verify_adopted
 from .fusion import CatFusion
 from .mlp import MLP
 from .norm import GraphNorm
@@ -91,11 +91,17 @@ def _adopt_sub_views(levels):
         pointers, points = getattr(sub, "pointers", None), getattr(sub, "points", None)
         if pointers is None or points is None or points.device != si.device:
             continue
-        # (adopt_csr verifies membership - and the ascending order unless the Cluster already
-        # knows it - with one device kernel; the verdict is read a step later without a host
-        # round trip: a stale `sub` raises csr.StaleCSRError then)
-        adopt_csr(si, pointers.numel() - 1, pointers, points,
-                  ascending=getattr(sub, "_ascending", None), verify="deferred")
+        asc = getattr(sub, "_ascending", None)
+        if asc is False:
+            # a consistent `sub` whose clusters do not ascend (h5io.load_nag of a reference file:
+            # Cluster sorts with a non-stable sort, src/data/cluster.py:19-77): legitimate, but not
+            # the stable sort's view - the level goes to the device sort
+            continue
+        # (adopt_csr checks pointers, point range, membership and the ascending order with the
+        # kernel that writes the clamped int32 view; the verdict is read a step later without a
+        # host round trip - csr.verify_adopted: a stale `sub` raises StaleCSRError and loses its
+        # view, an order-different one just goes back to the sort)
+        adopt_csr(si, pointers.numel() - 1, pointers, points, ascending=asc, verify="deferred")
 
 
 class SPT(nn.Module):
@@ -236,10 +242,18 @@ class SPT(nn.Module):
                 if isinstance(m, GraphNorm):
                     m.generic = True
         if self.matrix_precision is None:
-            return self._forward(nag)
-        from .. import precision
-        with precision.matrix_precision(self.matrix_precision):
-            return self._forward(nag)
+            out = self._forward(nag)
+        else:
+            from .. import precision
+            with precision.matrix_precision(self.matrix_precision):
+                out = self._forward(nag)
+        if not (self.training and torch.is_grad_enabled()) and not torch.cuda.is_current_stream_capturing():
+            # results are about to leave the device (eval / inference / a single forward): the
+            # adopted views' verdicts are read NOW - a stale `sub` raises here, not never.  A
+            # training loop reads them a step later without waiting (csr.verify_adopted) and
+            # calls csr.verify_adopted(block=True) after its last batch.
+            verify_adopted(block=True)
+        return out
 
     def _forward(self, nag):
         """``nag[i]`` exposes pos, x, super_index, node_size, batch, edge_index,

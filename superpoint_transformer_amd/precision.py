@@ -1,9 +1,16 @@
 """Matrix-pipe precision of the hot path's GEMMs (the reference's ``precision: 32 | bf16``
 switch, configs/trainer/gpu.yaml:7-10).
 
-``"f32"`` (default)  attention: split-bf16 (3 bf16 products per f32 product, ~2^-17 relative per product: 17 of f32's 24 bits);
-                     fused MLP layers: forward on the f32 matrix pipe (bitwise an fmaf chain),
-                     backward split-bf16.  Every f32 parity bar of tests/ holds in this mode.
+``"f32"`` (default)  the reference's SHIPPED arithmetic class: configs/train.yaml:60-61 sets
+                     ``float32_matmul_precision: high`` (src/train.py:94 hands it to
+                     ``torch.set_float32_matmul_precision``), i.e. every f32 matmul of the
+                     reference's run may use TF32 or the "bf16x3" scheme - 3 bf16 products per f32
+                     product - next to ``precision: 32`` (configs/trainer/gpu.yaml:7-10).  Here:
+                     attention split-bf16 = that bf16x3 scheme (hi*hi + lo*hi + hi*lo, ~2^-17
+                     relative per product: 17 of f32's 24 bits, 7 more than TF32's 10); fused MLP
+                     layers: forward as the f32-EXACT 3-way split (6 bf16 products: tighter than
+                     "high" asks for), backward split-bf16.  Every f32 parity bar of tests/ holds
+                     in this mode (the bars are set on tolerances, not on this knob).
 ``"bf16"``           what ``torch.autocast(bfloat16)`` does to the reference's Linear layers:
                      operands rounded to bf16, f32 accumulate, and - for the point MLP, whose
                      [N0, 32..128] layer outputs are most of a step's activation bytes - the raw
@@ -11,7 +18,8 @@ switch, configs/trainer/gpu.yaml:7-10).
                      max-pool and the backward); parameters, norm statistics, gradients, softmax
                      and segment reductions stay f32 (master weights in f32, like Lightning's
                      bf16-mixed).  Tested at rtol 2e-2.
-``"f32-exact"``      f32 matrix pipe everywhere (1/16 of the bf16 pipe's rate).
+``"f32-exact"``      f32 matrix pipe everywhere (1/16 of the bf16 pipe's rate): the reference under
+                     ``float32_matmul_precision: highest``, which it does not ship.
 
 The mode travels PER CALL: ``matrix_precision(mode)`` (a context manager on a ``contextvars``
 variable: per thread / task) and ``SPT(..., matrix_precision=...)`` make the autograd wrappers of

@@ -53,33 +53,57 @@ def test_fused_mlp_matches_oracle_and_unfused_path(dims, rows, B, gemm_mode, dev
 
     ref = copy.deepcopy(mlp).double()
     OM.KEEP_GRAPH = True
-    x64 = x.double().requires_grad_()
-    # the oracle layer by layer (same calls as OM.mlp), keeping every pre-activation
-    pre_acts, h = [], x64
-    for layer in ref.mlp:
-        if isinstance(layer, torch.nn.Linear):
-            h = h @ layer.weight.t()
-        elif isinstance(layer, torch.nn.LeakyReLU):
-            pre_acts.append(h.detach())
-            h = torch.nn.functional.leaky_relu(h, layer.negative_slope)
-        else:
-            h = OM.graph_norm(layer, h, batch, torch.float64)
-    yr = h
-    assert torch.equal(yr.detach(), OM.mlp(copy.deepcopy(mlp).double(), x.double(), batch,
-                                           torch.float64).detach())
-    # LeakyReLU kinks: a pre-activation within f32 rounding of 0 takes one slope or the
-    # other depending on the summation order (MFMA vs library vs f64) and moves the
-    # gradients by that row's whole contribution (about 1/sqrt(rows) of the total; at
-    # these sizes ~1 such element per run is EXPECTED: 4.5 M hidden values, density 0.4
-    # per unit, f32 error 3e-7).  Rows holding any pre-activation closer than 1e-4 to a
-    # kink (about 0.5 % of them) get a zero upstream gradient, so the comparison judges
-    # the arithmetic and not the coin flips.
-    safe = torch.ones(rows, dtype=torch.bool)
+    # LeakyReLU kinks: a pre-activation within the forward's own error of 0 takes one slope or the
+    # other depending on the summation order (MFMA vs library vs f64): at these sizes a handful of
+    # such elements per run is EXPECTED (4.5 M hidden values, density 0.4 per unit, f32 error
+    # 3e-7; more in the all-split mode, whose forward bar is 2e-4).  The comparison judges the
+    # arithmetic and not the coin flips - ONE-SIDEDLY, without tolerated outliers:
+    #   * `near` = elements within eps of a kink in the f64 oracle (eps = 5 x the mode's forward bar);
+    #   * rows holding one get a zero upstream gradient (so a flip cannot move the PARAMETER
+    #     gradients by a row's whole contribution) - what still reaches them comes through the
+    #     GraphNorm statistics (~1 / sqrt(rows) of a normal row's gradient) and does see the flip;
+    #   * the oracle runs three times: kinks as f64 saw them (y, parameter gradients, every row
+    #     without a near element) and with every near element on the POSITIVE / NEGATIVE side:
+    #     a row with one near element must match one of the two sides, whole row, to the bar.
+    eps_kink = 1e-4 if gemm_mode < 2 else 1e-3
+
+    def oracle(side, gw_):
+        """side None: leaky_relu as is; +1 / -1: near-kink elements take slope 1 / negative_slope."""
+        m = copy.deepcopy(mlp).double()
+        xx = x.double().requires_grad_()
+        pre, h = [], xx
+        for layer in m.mlp:
+            if isinstance(layer, torch.nn.Linear):
+                h = h @ layer.weight.t()
+            elif isinstance(layer, torch.nn.LeakyReLU):
+                pre.append(h.detach())
+                f64 = lambda v: torch.tensor(v, dtype=torch.float64)
+                sl = torch.where(h.detach() > 0, f64(1.0), f64(layer.negative_slope))
+                if side is not None:
+                    sl = torch.where(h.detach().abs() <= eps_kink,
+                                     f64(1.0 if side > 0 else layer.negative_slope), sl)
+                h = h * sl
+            else:
+                h = OM.graph_norm(layer, h, batch, torch.float64)
+        if gw_ is not None:
+            (h * gw_.double()).sum().backward()
+        return h.detach(), xx.grad, dict(m.named_parameters()), pre
+
+    yr, _, _, pre_acts = oracle(None, None)
+    assert torch.equal(yr, OM.mlp(copy.deepcopy(mlp).double(), x.double(), batch, torch.float64).detach())
+    near = torch.zeros(rows, dtype=torch.long)
     for pa in pre_acts:
-        safe &= (pa.abs() > 1e-4).all(dim=1)
+        near += (pa.abs() <= eps_kink).sum(dim=1)
+    safe, one = near == 0, near == 1
     gw = gw * safe.view(-1, 1).float()
-    (yr * gw.double()).sum().backward()
+    _, gx_ref, refp, _ = oracle(None, gw)
+    _, gx_pos, _, _ = oracle(+1, gw)
+    _, gx_neg, _, _ = oracle(-1, gw)
     OM.KEEP_GRAPH = False
+    n_multi = int((near > 1).sum())
+    print(f"rows with a near-kink element: {int(one.sum())} single, {n_multi} multiple of {rows} "
+          f"(eps {eps_kink})")
+    assert n_multi <= max(2, rows // (500 if gemm_mode < 2 else 20))      # (left out of the row checks)
 
     def run(fused):
         m = copy.deepcopy(mlp).to(dev)
@@ -91,35 +115,41 @@ def test_fused_mlp_matches_oracle_and_unfused_path(dims, rows, B, gemm_mode, dev
 
     yf, gxf, gpf = run(True)
     yu, gxu, gpu_ = run(False)
-    refp = dict(ref.named_parameters())
 
-    def close(a, r, tol, name, outliers=0, cap=None):
-        err = (a.double() - r).abs() / r.abs().clamp(min=1)
-        bad = int((err > tol).sum())
-        if bad:                                  # (the size of the tolerated outliers is on record)
-            print(f"{name}: {bad} of {err.numel()} elements above {tol}, largest {err.max().item():.3e} "
-                  f"(allowed: {outliers})")
-        assert bad <= outliers, f"{name}: {bad} elements above {tol}, max {err.max().item():.3e}"
-        # the tolerated outliers are kink-row leftovers of O(1 / rows) - measured up to 1.4e-2 in the
-        # all-split mode (printed above): bounded, not arbitrary
-        assert cap is None or err.max().item() <= cap, f"{name}: outlier of {err.max().item():.3e} above {cap}"
+    def relerr(a, r):
+        return (a.double() - r).abs() / r.abs().clamp(min=1)
 
-    # kink rows carry no upstream gradient; what reaches them through the GraphNorm
-    # statistics is O(1/rows) - a handful of gx elements may still sit above the bar
-    few = 8 * dims[0]
+    def close(a, r, tol, name):
+        err = relerr(a, r)
+        assert float(err.max()) <= tol, f"{name}: {int((err > tol).sum())} elements above {tol}, max {err.max().item():.3e}"
+
+    def close_gx(a, name, tol=1e-4):
+        """Every row without a near-kink element: the bar, no outliers.  Every row with ONE: the
+        whole row matches the oracle with that element on one side of the kink or on the other."""
+        close(a[safe], gx_ref[safe], tol, name + " (rows away from every kink)")
+        if int(one.sum()):
+            e_pos = relerr(a[one], gx_pos[one]).amax(dim=1)
+            e_neg = relerr(a[one], gx_neg[one]).amax(dim=1)
+            worst = torch.minimum(e_pos, e_neg)
+            took_pos = int((e_pos <= e_neg).sum())
+            print(f"{name}: {int(one.sum())} single-kink rows, {took_pos} on the positive side, "
+                  f"worst one-sided error {worst.max().item():.3e}")
+            assert float(worst.max()) <= tol, (
+                f"{name}: a near-kink row matches NEITHER side of its kink: {worst.max().item():.3e}")
 
     ytol = 2e-5 if gemm_mode < 2 else 2e-4
-    close(yf, yr.detach(), ytol, "y")
-    close(gxf, x64.grad, 1e-4, "gx", outliers=few, cap=5e-2)
+    close(yf, yr, ytol, "y")
+    close_gx(gxf, "gx fused")
+    close_gx(gxu, "gx unfused")
     for k in gpf:
         r = refp[k].grad
         scale = r.abs().max().clamp(min=1e-2)
         err = ((gpf[k].double() - r).abs() / scale).max().item()
         erru = ((gpu_[k].double() - r).abs() / scale).max().item()
         assert err <= max(2e-4, 3 * erru), f"{k}: fused {err:.3e} unfused {erru:.3e}"
-    # fused and unfused HIP paths agree with each other
+    # fused and unfused HIP paths agree with each other (where no kink decides)
     close(yf, yu.double(), ytol, "y fused vs unfused")
-    close(gxf, gxu.double(), 1e-4, "gx fused vs unfused", outliers=few, cap=5e-2)
+    close(gxf[safe], gxu[safe].double(), 1e-4, "gx fused vs unfused (rows away from every kink)")
 
 
 def test_fused_mlp_runs_of_a_piecewise_sorted_batch(dev):

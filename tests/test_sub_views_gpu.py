@@ -27,13 +27,23 @@ def test_adopted_view_is_the_sorted_view(dev):
         assert torch.equal(got.perm, ref.perm) and torch.equal(got.rowptr, ref.rowptr)
         assert torch.equal(got.pos_seg(), ref.pos_seg())
         csr.forget(si)
-    # a Cluster whose clusters are not ascending is refused by the model-side hook
+    # a Cluster whose clusters are not ascending (a legitimate `sub`: the reference's Cluster
+    # sorts with a non-stable sort) is skipped by the model-side hook: the level is sorted
+    from superpoint_transformer_amd.nn.spt import _adopt_sub_views
     sub = nag[1]["sub"]
     bad = type(sub)(sub.pointers.clone(), sub.points.clone())
-    a, b = int(bad.pointers[0]), int(bad.pointers[1])
-    if b - a >= 2:
-        bad.points[a], bad.points[a + 1] = bad.points[a + 1].clone(), bad.points[a].clone()
-        assert bad.ascending is False and sub.ascending is True
+    sizes = bad.pointers[1:] - bad.pointers[:-1]
+    a = int(bad.pointers[int(torch.nonzero(sizes >= 2)[0])])
+    bad.points[a], bad.points[a + 1] = bad.points[a + 1].clone(), bad.points[a].clone()
+    assert bad.ascending is False and sub.ascending is True
+    si = nag[0]["super_index"]
+    csr.forget(si)
+    _adopt_sub_views([{"super_index": si}, {"sub": bad}])
+    assert not getattr(si, "_spt_csr_memo", None)
+    _adopt_sub_views([{"super_index": si}, {"sub": sub}])
+    assert getattr(si, "_spt_csr_memo", None)
+    csr.verify_adopted(block=True)
+    csr.forget(si)
 
 
 def test_adoption_checks_the_stored_csr_against_the_index(dev):
@@ -53,13 +63,20 @@ def test_adoption_checks_the_stored_csr_against_the_index(dev):
     pts[a], pts[b] = sub.points[b].clone(), sub.points[a].clone()
     assert csr.adopt_csr(si, n_par, sub.pointers, pts, ascending=True) is None
     assert csr.adopt_csr(si, n_par, sub.pointers, pts, ascending=True) is None   # memoised verdict
-    # 2. order inside a cluster (membership intact): refused unless the caller vouches for it
+    # 2. order inside a cluster (membership intact): refused whatever the caller vouches for (the
+    #    ascent is always compared), and not even tried for a `sub` known not to ascend
     pts = sub.points.clone()
     sizes = sub.pointers[1:] - sub.pointers[:-1]
     c = int(torch.nonzero(sizes >= 2)[0])
     a = int(sub.pointers[c])
     pts[a], pts[a + 1] = sub.points[a + 1].clone(), sub.points[a].clone()
     assert csr.adopt_csr(si, n_par, sub.pointers, pts) is None
+    assert csr.adopt_csr(si, n_par, sub.pointers, pts.clone(), ascending=True) is None
+    assert csr.adopt_csr(si, n_par, sub.pointers, sub.points, ascending=False) is None
+    # 2b. a duplicate point id inside one cluster (sizes, membership of every listed point intact)
+    pts = sub.points.clone()
+    pts[a + 1] = pts[a]
+    assert csr.adopt_csr(si, n_par, sub.pointers, pts, ascending=True) is None
     # 3. pointers that do not cover the level
     ptr = sub.pointers.clone()
     ptr[-1] -= 1
@@ -93,7 +110,69 @@ def test_deferred_verdict_of_an_adopted_view(dev):
     with pytest.raises(csr.StaleCSRError, match="membership"):
         csr.verify_adopted(block=True)
     csr.verify_adopted(block=True)                                   # the queue was cleared
+    assert not getattr(si, "_spt_csr_memo", None)                    # ... and the bad view is gone
+    assert csr.adopt_csr(si, n_par, sub.pointers, pts, ascending=True, verify="deferred") is None
     csr.forget(si)
+    # a consistent partition whose clusters do not ascend: served the batch, then back to the sort -
+    # no error (advisor, round 5)
+    pts = sub.points.clone()
+    sizes = sub.pointers[1:] - sub.pointers[:-1]
+    a = int(sub.pointers[int(torch.nonzero(sizes >= 2)[0])])
+    pts[a], pts[a + 1] = sub.points[a + 1].clone(), sub.points[a].clone()
+    assert csr.adopt_csr(si, n_par, sub.pointers, pts, verify="deferred") is not None
+    csr.verify_adopted(block=True)
+    assert not getattr(si, "_spt_csr_memo", None)
+    assert csr.adopt_csr(si, n_par, sub.pointers, pts, verify="deferred") is None
+    csr.forget(si)
+
+
+def test_a_failing_deferred_view_stays_inside_its_buffers(dev):
+    """Point ids / pointers outside the level (bits 1 and 0): the adopted int32 view is clamped,
+    so the segment kernels that run BEFORE the verdict is read stay in bounds; the verdict then
+    raises, and an eval forward reads it before returning (advisor, round 5)."""
+    from superpoint_transformer_amd import csr, ops
+    nag = _nag(dev)
+    si, sub = nag[0]["super_index"], nag[1]["sub"]
+    n_par, n = nag[1]["pos"].shape[0], si.numel()
+    csr.forget(si)
+    pts = sub.points.clone()
+    pts[5], pts[n - 3] = 10 * n, -7
+    ptr = sub.pointers.clone()
+    ptr[3] = 2 * n
+    view = csr.adopt_csr(si, n_par, ptr, pts, verify="deferred")
+    assert view is not None
+    assert int(view.perm.min()) >= 0 and int(view.perm.max()) < n
+    assert int(view.rowptr.min()) >= 0 and int(view.rowptr.max()) <= n
+    x = torch.randn(n, 64, device=dev)
+    ops.segment_reduce(x, si, n_par, "max", return_arg=True)       # wrong rows, but inside the buffers
+    ops.segment_reduce(x, si, n_par, "sum")
+    torch.cuda.synchronize()
+    with pytest.raises(csr.StaleCSRError, match="outside"):
+        csr.verify_adopted(block=True)
+    csr.forget(si)
+    # a single eval forward on a stale `sub` raises before its results are used
+    from superpoint_transformer_amd import hotpath
+    torch.manual_seed(0)
+    model = hotpath.SPTSegmenter(**hotpath.spt64_config(8, 18)).to(dev).eval()
+    lv = [dict(l) for l in nag.levels]
+    stale = type(sub)(sub.pointers.clone(), sub.points.clone())
+    a, b = int(sub.pointers[1]) - 1, int(sub.pointers[1])
+    stale.points[a], stale.points[b] = sub.points[b].clone(), sub.points[a].clone()
+    stale._ascending = True
+    lv[1]["sub"] = stale
+
+    class V:
+        levels, num_clouds = lv, nag.num_clouds
+
+        def __getitem__(self, i):
+            return lv[i]
+
+    for l in lv:
+        csr.forget(l.get("super_index"), l.get("edge_index"), l.get("batch"))
+    with torch.no_grad(), pytest.raises(csr.StaleCSRError):
+        model(V())
+    for l in lv:
+        csr.forget(l.get("super_index"), l.get("edge_index"), l.get("batch"))
 
 
 def test_select_keeps_clusters_ascending(dev):
