@@ -63,6 +63,12 @@ def parse():
                         "data-parallel scene sharding (SURVEY 8e); value = all ranks' points / slowest rank")
     p.add_argument("--no-local", action="store_true",
                    help="skip the extra steps on the spatially local superpoint graph (ms_per_step_local)")
+    p.add_argument("--no-train-batch", action="store_true",
+                   help="skip the train-batch companion (scene T: ms_per_step_T eager + captured, "
+                        "ms_per_iteration_T) of the default line")
+    p.add_argument("--capture", action="store_true",
+                   help="replay the step as a captured graph (hipGraph through torch.cuda.CUDAGraph): forward + "
+                        "loss + backward (+ AdamW at N = 1) of the fixed batch, captured once after the warm-up")
     p.add_argument("--rebuild-csr", action="store_true",
                    help="worst case: ignore the NAG's stored level CSR (nag[i+1].sub) and rebuild every "
                         "CSR view with the device sort each step")
@@ -279,6 +285,72 @@ def cpu_preprocess_baseline(scene, n_sample):
                       f"(k={k}, r={r}) + eigenfeatures via oracle/cpu/libspt_cpu.so (OpenMP)"}
 
 
+def train_batch_leg(dev, steps=100):
+    """The regime the reference TRAINS in, next to the 15 M-point headline: scene T = one S3DIS
+    train batch (4 clouds, 1.2 M points after sampling; batch_size / sample caps of
+    configs/datamodule/semantic/s3dis.yaml:101-104, default.yaml:79-80).  Three figures:
+    the eager step (`ms_per_step_T_eager`), the same step replayed as ONE captured graph
+    (`ms_per_step_T`: hotpath.SPTTrainStep.capture - forward + CE + backward + AdamW, per-batch
+    CSR builds inside), and a whole training ITERATION as the reference runs it
+    (`ms_per_iteration_T`: src/datamodules/base.py:341-380 - the on-device transform chain on a raw
+    batch, then the step; dynamic shapes, so eager)."""
+    from superpoint_transformer_amd import csr as _csr, hotpath, ops
+    from superpoint_transformer_amd.synthetic import SCENES, make_nag, make_raw_nag
+    paused = ops.pause_timers(True)               # the headline's timers stay the headline's
+    out = {"scene": "T", "sizes": list(SCENES["T"])}
+    try:
+        nag = make_nag("T", seed=1234, device=dev)
+        path = hotpath.build(nag, dev, mode="train", model="spt64")
+
+        def timed(p, n):
+            for _ in range(10):
+                p.step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                p.step()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n * 1e3
+
+        out["ms_per_step_T_eager"] = round(timed(path, steps), 4)
+        try:
+            path.capture()
+            out["ms_per_step_T"] = round(timed(path, steps), 4)
+            out["captured"] = "forward + CE loss + backward + AdamW of the fixed-cap batch in one graph"
+            _csr.verify_adopted(block=True)       # the captured view checks' verdicts, outside the graph
+        except Exception as e:                    # a capture that fails is reported, not hidden
+            out["ms_per_step_T"] = out["ms_per_step_T_eager"]
+            out["captured"] = f"capture failed ({type(e).__name__}: {str(e)[:200]}): eager figure"
+        out["Mpoints_per_s_T"] = round(nag.num_points[0] / out["ms_per_step_T"] / 1e3, 2)
+        out["workload"] = path.describe("T", SCENES["T"])
+        del path, nag
+        torch.cuda.empty_cache()
+        raw = make_raw_nag("T", seed=1234, device=dev)
+        it = hotpath.build(raw, dev, mode="iteration", model="spt64")
+        for _ in range(5):
+            it.step()
+        it.reset_kernel_timers()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n_it = max(steps // 2, 10)
+        for _ in range(n_it):
+            it.step()
+        torch.cuda.synchronize()
+        out["ms_per_iteration_T"] = round((time.perf_counter() - t0) / n_it * 1e3, 4)
+        r = it.roofline(HBM_PEAK_GBS)
+        out["ms_transform_chain"] = r.get("ms_transform_chain")
+        out["iteration"] = {"raw_points": int(raw.num_points[0]),
+                            "sizes_after_chain": r.get("sizes_after_chain"),
+                            "note": "raw batch of 1.2 M points as stored -> the chain keeps "
+                                    f"{r.get('sizes_after_chain', [None])[0]} level-0 points, which is what the "
+                                    "model steps on; chain + step timed together, eager"}
+        del it, raw
+        torch.cuda.empty_cache()
+    finally:
+        ops.pause_timers(paused)
+    return out
+
+
 def _free_port():
     import socket
     with socket.socket() as s:
@@ -390,6 +462,15 @@ def main():
         torch.cuda.synchronize()
     for _ in range(args.warmup):
         path.step()
+    captured = None
+    if args.capture:
+        if not hasattr(path, "capture") or args.mode != "train":
+            raise SystemExit("bench.py: --capture applies to --mode train")
+        path.capture()
+        captured = ("forward + loss + backward + AdamW in one graph" if path._graph_opt else
+                    "forward + loss + backward in one graph; all-reduce + AdamW eager")
+        for _ in range(2):
+            path.step()
     path.reset_kernel_timers()
 
     device_index = local              # (`local` is reused for the local-graph companion below)
@@ -412,8 +493,13 @@ def main():
     _log(f"timed region done: {dt / args.steps * 1e3:.2f} ms per step")
     from superpoint_transformer_amd import parallel
     dt = parallel.max_over_ranks(dt, dev)
+    # the adopted views' verdicts that are still on their way (a training loop's last batch:
+    # csr.verify_adopted) - outside the timed region, raises on a stale `sub`
+    _csr.verify_adopted(block=True)
 
     n0 = nag.num_points[0]
+    # iteration mode: what the chain left for the model to step on (raw points are `value`'s unit)
+    path_sizes = list(getattr(path, "last_sizes", None) or []) if args.mode == "iteration" else None
     # every rank's point count is host knowledge (same generator, same scale table)
     n0_all = [max(int(SCENES[args.scene][0] * m), 8) if m != 1.0 else SCENES.get(args.scene, (n0,))[0]
               for m in mix] if args.scene in SCENES else [n0] * world
@@ -511,10 +597,19 @@ def main():
         north = path.northstar(HBM_PEAK_GBS)
         if north is not None:
             roof.update(north)
+    train_batch = None
+    if headline and world == 1 and rank == 0 and not args.no_train_batch and args.scene == "S":
+        del path
+        path = None
+        torch.cuda.empty_cache()
+        train_batch = train_batch_leg(dev)
+        _log(f"train-batch companion done: {train_batch.get('ms_per_step_T')} ms captured, "
+             f"{train_batch.get('ms_per_step_T_eager')} eager, iteration {train_batch.get('ms_per_iteration_T')}")
     if rank == 0 and world == 1 and not headline:
         del path                      # other BASELINE configs: the GPU line only
     elif rank == 0 and world == 1:
-        del path
+        if path is not None:
+            del path
         torch.cuda.empty_cache()
         if not args.no_preprocess:
             pre = preprocess_leg(args.scene, n0, dev)
@@ -529,9 +624,13 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "Mpoints/s SPT fwd+bwd on S3DIS-scale NAG" if args.mode != "infer"
-            else "Mpoints/s SPT forward (inference) on a DALES-scale NAG",
+            "metric": {"infer": "Mpoints/s SPT forward (inference) on a DALES-scale NAG",
+                       "iteration": "Mpoints/s of RAW stored points per training iteration (on-device transform "
+                                    "chain + SPT fwd+bwd); the model steps on the SAMPLED subset: see "
+                                    "value_sampled_points"}.get(args.mode, "Mpoints/s SPT fwd+bwd on S3DIS-scale NAG"),
             "value": round(value, 3),
+            "value_sampled_points": (round(int(path_sizes[0]) * args.steps / dt / 1e6 * world, 3)
+                                     if path_sizes else None),
             "unit": "Mpoints/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -554,6 +653,10 @@ def main():
             "ms_per_step_bf16": round(bf16_ms, 4) if bf16_ms else None,
             "ms_per_step_local": local["ms_per_step"] if local else None,
             "local_graph": local,
+            "captured_graph": captured,
+            "ms_per_step_T": train_batch.get("ms_per_step_T") if train_batch else None,
+            "ms_per_iteration_T": train_batch.get("ms_per_iteration_T") if train_batch else None,
+            "train_batch": train_batch,
             "data": "synthetic",
             "config": {
                 "workload": workload,

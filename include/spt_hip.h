@@ -323,6 +323,24 @@ int spt_attn_tile_record_ints_m(int mode);
 int spt_attn_pack_tile_ids_m(const int32_t* eperm, const int32_t* tgt_sorted,
                              const int32_t* src_sorted, const int32_t* tperm, int64_t e, int mode,
                              int32_t* tile_ids, spt_stream_t stream);
+/* Round 6: TARGET-order tile records without a sorted target view, from the MIRROR structure of
+ * the reference's final edge list [i<j | j>i | loops] (src/transforms/graph.py:1268, 1442-1446:
+ * OnTheFlyHorizontalEdgeFeatures appends the flipped copy of the trimmed list, NAGAddSelfLoops the
+ * loops; the shipped S3DIS / DALES / ScanNet configs skip SampleEdges - `sample_edge_n_min: -1`).
+ * `edge_index` = the [2, e] int64 list, `pairs` = M: edge i < M is mirrored at i + M, every edge
+ * from 2 M on is a self loop.  The edges INTO a node are the mirrors of the edges OUT OF it, which
+ * the by-source view (eperm) holds as one run: no second radix sort per level.
+ * spt_attn_mirror_prepare writes inv [e] (int32: the inverse of eperm) and ORs into *flag (int32,
+ * device; the caller clears it) bit 0 = a pair (i, i + M) that is not (s, t) / (t, s), bit 1 = a
+ * loop with s != t - the structure is CHECKED, not trusted.  spt_attn_pack_tile_ids_mirror writes
+ * the 64-int records of spt_attn_pack_tile_ids_m's target order (same fields; the edges into a
+ * node in by-source order of their mirrors instead of ascending source: the same sums).
+ * spt_edge_attn_bwd_ex_f32 accepts them with tperm = trowptr = NULL. */
+int spt_attn_mirror_prepare(const int64_t* edge_index, const int32_t* eperm, int64_t e, int64_t pairs,
+                            int32_t* inv, int32_t* flag, spt_stream_t stream);
+int spt_attn_pack_tile_ids_mirror(const int32_t* eperm, const int32_t* tgt_sorted,
+                                  const int32_t* src_sorted, const int32_t* inv, int64_t e,
+                                  int64_t pairs, int32_t* tile_ids, spt_stream_t stream);
 int spt_edge_attn_bwd_f32(const float* qkv, int64_t n, int H, int D, int Dv,
                           const int32_t* erowptr, const int32_t* eperm,
                           const int32_t* tgt_sorted, int64_t e,

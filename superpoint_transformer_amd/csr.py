@@ -100,6 +100,16 @@ def csr_of(idx, num_seg=None):
 
 
 _USE_SUB_VIEWS = True
+_USE_MIRROR = True
+
+
+def use_mirror_views(on=True):
+    """Whether the attention backward takes its by-target edge stream from the mirror structure
+    an edge list's maker declared (``EdgeCSR``; default) or always sorts the targets.  Returns the
+    old setting."""
+    global _USE_MIRROR
+    old, _USE_MIRROR = _USE_MIRROR, bool(on)
+    return old
 
 
 def use_sub_views(on=True):
@@ -140,6 +150,10 @@ def _pinned_slot():
         if slot.data_ptr() not in busy:
             return slot
     return torch.zeros(1, dtype=torch.int32).pin_memory()     # > 256 verdicts in flight
+
+
+_MIRROR_BITS = {1: "a pair (i, i + M) that is not (s, t) / (t, s)", 2: "a self loop with s != t"}
+MIRROR_ATTR = "_spt_mirror_pairs"   # host knowledge left on an edge_index by its maker: M (see EdgeCSR)
 
 
 def _drop_view(ref, key, vkey, remember):
@@ -183,11 +197,30 @@ def verify_adopted(block=False):
                 keep.append(item)
                 continue
             v = int(host[0])
+        if v and key == "mirror":
+            # the edge list does not have the mirror structure its maker declared: the tile records
+            # of that batch paired wrong edges.  Forget the hint (later batches sort), then raise.
+            ei = ref() if ref is not None else None
+            if ei is not None:
+                for a in (MIRROR_ATTR, _ATTR):
+                    if hasattr(ei, a):
+                        try:
+                            delattr(ei, a)
+                        except Exception:
+                            pass
+            if failed is None:
+                failed = (what, v, "; ".join(t for b, t in _MIRROR_BITS.items() if v & b))
+            continue
         if v:
             _drop_view(ref, key, vkey, remember=True)
         if v & ~_ORDER_ONLY and failed is None:
-            failed = (what, v)
+            failed = (what, v, None)
     _PENDING[:] = keep
+    if failed is not None and failed[2] is not None:
+        raise StaleCSRError(
+            f"{failed[0]} was declared [i<j | j>i | loops] with mirrored halves ({MIRROR_ATTR}) but is not "
+            f"({failed[2]}): the attention backward of that batch paired wrong edges - drop the attribute "
+            "or rebuild the edge list (the hint has been removed: later batches sort by target)")
     if failed is not None:
         raise StaleCSRError(
             f"the stored CSR adopted as the view of {failed[0]} does not describe it "
@@ -296,15 +329,34 @@ class EdgeCSR:
     edge_index[1] in CSR order."""
 
     __slots__ = ("erowptr", "eperm", "tgt_sorted", "n", "e", "_view", "_src_sorted", "_tview",
-                 "_tile_ids")
+                 "_tile_ids", "_ei", "_mirror", "_ei_ref")
 
-    def __init__(self, erowptr, eperm, tgt_sorted, n, e, view=None):
+    def __init__(self, erowptr, eperm, tgt_sorted, n, e, view=None, edge_index=None):
         self.erowptr, self.eperm, self.tgt_sorted, self.n, self.e = \
             erowptr, eperm, tgt_sorted, n, e
         self._view = view
         self._src_sorted = None
         self._tview = None
         self._tile_ids = None
+        # Host knowledge of the list's layout, left on the tensor by whoever built it
+        # (transforms.horizontal_edge_features, the synthetic batches): M = the number of (i < j)
+        # pairs of [i<j | j>i | loops], edge i mirrored at i + M.  The target-order tile records
+        # then come from the by-source view alone (no second sort); the structure is checked on
+        # the device (spt_attn_mirror_prepare) and a wrong hint raises StaleCSRError.
+        self._ei = self._mirror = self._ei_ref = None
+        m = getattr(edge_index, MIRROR_ATTR, None) if edge_index is not None else None
+        if (_USE_MIRROR and m is not None and edge_index._version == 0 and edge_index.dtype == torch.int64
+                and edge_index.is_contiguous() and edge_index.dim() == 2 and 0 <= 2 * int(m) <= e):
+            self._ei, self._mirror = edge_index.detach(), int(m)
+            try:
+                self._ei_ref = weakref.ref(edge_index)
+            except TypeError:
+                pass
+
+    def mirrored(self, mode=-1):
+        """True when the target-order tile records of this graph come from the mirror structure
+        (no sorted target view is needed by the attention backward in that order)."""
+        return self._mirror is not None and int(_lib.lib.spt_attn_tile_record_ints_m(int(mode))) == 64
 
     def tile_ids(self, mode=-1):
         """int32 [ceil(e / 16), 48 | 64]: the edge-lane attention backward's tile records, built on
@@ -320,6 +372,10 @@ class EdgeCSR:
             nt = (self.e + 15) // 16
             out = torch.empty((max(nt, 1), ints), dtype=torch.int32, device=dev)
             src = self.src_sorted()
+            if ints == 64 and self._mirror is not None:
+                self._pack_mirror(out, src, dev)
+                self._tile_ids[ints] = out
+                return out
             tperm = self.target_view().perm if ints == 64 else None
             order = (1 << 6) if ints == 64 else (2 << 6)
             with torch.cuda.device(dev):
@@ -329,6 +385,31 @@ class EdgeCSR:
             _lib.check(st, "spt_attn_pack_tile_ids_m")
             self._tile_ids[ints] = out
         return self._tile_ids[ints]
+
+    def _pack_mirror(self, out, src, dev):
+        """Target-order tile records from the mirror structure: the inverse of ``eperm`` + the
+        structure check in one kernel, the records in a second; the verdict is deferred like an
+        adopted level view's (``verify_adopted``)."""
+        inv = torch.empty(max(self.e, 1), dtype=torch.int32, device=dev)
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        sp = _lib.stream_ptr(dev)
+        with torch.cuda.device(dev):
+            st = _lib.lib.spt_attn_mirror_prepare(_lib.ptr(self._ei), _lib.ptr(self.eperm), self.e,
+                                                  self._mirror, _lib.ptr(inv), _lib.ptr(flag), sp)
+            _lib.check(st, "spt_attn_mirror_prepare")
+            st = _lib.lib.spt_attn_pack_tile_ids_mirror(
+                _lib.ptr(self.eperm), _lib.ptr(self.tgt_sorted), _lib.ptr(src), _lib.ptr(inv), self.e,
+                self._mirror, _lib.ptr(out), sp)
+            _lib.check(st, "spt_attn_pack_tile_ids_mirror")
+        what = f"an edge list of {self.e} edges ({self._mirror} pairs)"
+        if torch.cuda.is_current_stream_capturing():
+            _PENDING.append((None, flag, what, self._ei_ref, "mirror", None))
+        else:
+            host = _pinned_slot()
+            host.copy_(flag, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            _PENDING.append((ev, host, what, self._ei_ref, "mirror", None))
 
     def target_view(self):
         """CSR view of ``tgt_sorted`` over the CSR positions (which positions point INTO node t,
@@ -371,7 +452,10 @@ def edge_csr_of(edge_index, num_nodes):
         st = _lib.lib.spt_csr_gather_i64_i32(_lib.ptr(tgt64), _lib.ptr(view.perm), e,
                                              _lib.ptr(tgt_sorted), _lib.stream_ptr(edge_index.device))
     _lib.check(st, "spt_csr_gather_i64_i32")
-    ecsr = EdgeCSR(view.rowptr, view.perm, tgt_sorted, int(num_nodes), edge_index.shape[1], view)
+    if _PENDING and not torch.cuda.is_current_stream_capturing():
+        verify_adopted()              # (a level without `sub` never reaches adopt_csr's own reading)
+    ecsr = EdgeCSR(view.rowptr, view.perm, tgt_sorted, int(num_nodes), edge_index.shape[1], view,
+                   edge_index=edge_index)
     if memo is None or any(k[0] != edge_index._version for k in memo):
         memo = {}
         try:

@@ -775,6 +775,11 @@ bool attn_bwd_to_enabled();
 size_t attn_bwd_to_workspace_bytes(int64_t n, int64_t e);
 void attn_pack_tile_ids_to_launch(const int32_t* eperm, const int32_t* tgt, const int32_t* src,
                                   const int32_t* tperm, int64_t e, int32_t* ids4, hipStream_t stream);
+int attn_mirror_prepare_launch(const int64_t* ei, const int32_t* eperm, int64_t e, int64_t pairs,
+                               int32_t* inv, int32_t* flag, hipStream_t stream);
+void attn_pack_tile_ids_mirror_launch(const int32_t* eperm, const int32_t* tgt, const int32_t* src,
+                                      const int32_t* inv, int64_t e, int64_t pairs, int32_t* ids4,
+                                      hipStream_t stream);
 int attn_bwd_to_launch(const float* qkv, int64_t n, const int32_t* erowptr, const int32_t* eperm,
                        const int32_t* tgt, const int32_t* src, const int32_t* tile_ids,
                        const int32_t* tperm, int64_t e, const float* ea, const float* Wk,
@@ -1009,6 +1014,34 @@ extern "C" int spt_attn_pack_tile_ids_m(const int32_t* eperm, const int32_t* tgt
   return 0;
 }
 
+// Target-order tile records from the MIRROR structure of the edge list instead of a sorted target
+// view (edge_attn_to.hip): `edge_index` = the [2, e] int64 list as the reference hands it over,
+// `pairs` = M with edge i < M mirrored at i + M and every edge from 2 M on a self loop.
+// spt_attn_mirror_prepare writes inv [e] (the inverse of eperm) and ORs into *flag (int32, device;
+// the caller clears it): bit 0 = a pair that is not (s, t) / (t, s), bit 1 = a loop with s != t.
+// spt_attn_pack_tile_ids_mirror then writes the same 64-int records spt_attn_pack_tile_ids_m
+// writes in target order (the edges into a node in another order: sums of the same terms).
+extern "C" int spt_attn_mirror_prepare(const int64_t* edge_index, const int32_t* eperm, int64_t e,
+                                       int64_t pairs, int32_t* inv, int32_t* flag,
+                                       spt_stream_t stream_) {
+  SPT_CHECK_ARG(e >= 0 && pairs >= 0 && 2 * pairs <= e, "bad shape");
+  SPT_CHECK_ARG(e == 0 || (edge_index && eperm && inv && flag), "null pointer");
+  attn_mirror_prepare_launch(edge_index, eperm, e, pairs, inv, flag, (hipStream_t)stream_);
+  SPT_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int spt_attn_pack_tile_ids_mirror(const int32_t* eperm, const int32_t* tgt_sorted,
+                                             const int32_t* src_sorted, const int32_t* inv,
+                                             int64_t e, int64_t pairs, int32_t* tile_ids,
+                                             spt_stream_t stream_) {
+  SPT_CHECK_ARG(e >= 0 && pairs >= 0 && 2 * pairs <= e, "bad shape");
+  SPT_CHECK_ARG(e == 0 || (eperm && tgt_sorted && src_sorted && inv && tile_ids), "null pointer");
+  attn_pack_tile_ids_mirror_launch(eperm, tgt_sorted, src_sorted, inv, e, pairs, tile_ids,
+                                   (hipStream_t)stream_);
+  SPT_CHECK_LAUNCH();
+  return 0;
+}
+
 // The general entry: `src_sorted` (nullable) = source node of every CSR position (edge_index[0]
 // in CSR order); `tile_ids` (nullable) = spt_attn_pack_tile_ids of the graph; `tperm` / `trowptr`
 // (nullable, both or none) = CSR view of tgt_sorted over the
@@ -1048,7 +1081,10 @@ extern "C" int spt_edge_attn_bwd_ex_f32(const float* qkv, int64_t n, int H, int 
   const size_t partial_bytes = align_up((size_t)EA_BWD_BLOCKS * EA_WAVES * len * 4, 256);
   float* total = has_rpe ? (float*)((char*)ws + partial_bytes) : nullptr;
   const int grid = (int)(ceil_div(n, EA_WAVES) < EA_BWD_BLOCKS ? ceil_div(n, EA_WAVES) : EA_BWD_BLOCKS);
-  const bool el_ok = form == 2 && prec >= 2 && e > 0 && tperm &&
+  // (the target-order route needs either the sorted target view or ready-made tile records -
+  // spt_attn_pack_tile_ids_mirror builds them without a view; the source-order route needs the view)
+  const bool el_ok = form == 2 && prec >= 2 && e > 0 &&
+                     (tperm || (mode_target_order(mode) && tile_ids && src_sorted)) &&
                      attn_mfma_shape_ok(H, D, Dv, F, edge_attr, Wk, Wq, Wv);
   // The edge-lane route is decided ONCE, from the mode word and from what the caller handed over;
   // each edge order has its own scratch layout, and a route only runs inside the bytes it needs
@@ -1057,7 +1093,7 @@ extern "C" int spt_edge_attn_bwd_ex_f32(const float* qkv, int64_t n, int H, int 
   const size_t need_el = need + attn_bwd_el_workspace_bytes(n, e);
   const size_t need_to = need + attn_bwd_to_workspace_bytes(n, e);
   const bool run_to = el_ok && to_sel && src_sorted && ws_bytes >= need_to;
-  const bool run_el = el_ok && !run_to && ws_bytes >= need_el;
+  const bool run_el = el_ok && !run_to && tperm && ws_bytes >= need_el;
   // records built for the target order (64 ints) must not reach the source-order kernel (48 ints):
   // when the call falls back from the selected target order, the ids are rebuilt in the workspace
   if (run_el && to_sel) tile_ids = nullptr;
@@ -1066,9 +1102,9 @@ extern "C" int spt_edge_attn_bwd_ex_f32(const float* qkv, int64_t n, int H, int 
   if (prec != 0 && attn_mfma_shape_ok(H, D, Dv, F, edge_attr, Wk, Wq, Wv)) {
     int ntab;
     if (form == 2 && mode >= 0 && ((mode >> 4) & 3) == 3)
-      SPT_CHECK_ARG((run_to || run_el) && trowptr,
+      SPT_CHECK_ARG((run_to && (trowptr || tile_ids)) || (run_el && trowptr),
                     "edge-lane backward: workspace of spt_edge_attn_bwd_ex_workspace_bytes, the "
-                    "target CSR view and a bf16-pipe precision are required");
+                    "target CSR view (or target-order tile records) and a bf16-pipe precision are required");
     if (mode >= 0 && ((mode >> 6) & 3) == 1 && el_ok)
       SPT_CHECK_ARG(run_to, "target-order backward: src_sorted and the workspace of "
                             "spt_edge_attn_bwd_ex_workspace_bytes are required");

@@ -199,6 +199,61 @@ __global__ __launch_bounds__(256) void pack_tile_ids_to_kernel(
   ids4[i] = f == 0 ? (eperm ? eperm[sp] : sp) : (f == 1 ? tgt[sp] : (f == 2 ? src[sp] : sp));
 }
 
+// ---- the by-target stream WITHOUT a second sort (round 6) ---------------------------------------
+// The reference's final edge list is [i<j | j>i | loops] (src/transforms/graph.py:1268, 1442-1446:
+// OnTheFlyHorizontalEdgeFeatures appends the flipped copy of the trimmed list, NAGAddSelfLoops the
+// loops; the S3DIS / DALES / ScanNet configs ship `sample_edge_n_min: -1`, so nothing thins it
+// afterwards): edge e < M has its mirror at e + M, a loop is its own mirror.  The edges INTO node t
+// are then the mirrors of the edges OUT OF t, which the by-source view already holds as one
+// contiguous run: walking the by-source positions p = 0 .. E - 1 and taking mirror(eperm[p]) IS a
+// stream grouped by target (ascending), with
+//     edge row = mirror(eperm[p]),  target = src_sorted[p],  source = tgt_sorted[p],
+//     source-order position = inv[mirror(eperm[p])]        (inv = inverse of eperm).
+// mirror_prepare_kernel writes inv and CHECKS the structure the caller declared (a flag word:
+// bit 0 = a pair (e, e + M) that is not (s, t) / (t, s), bit 1 = a "loop" with s != t);
+// pack_tile_ids_mirror_kernel writes the 64-int tile records from it.  No radix sort of the
+// targets, no [E] int64 cast, no row-pointer pass.
+__device__ __forceinline__ int64_t mirror_edge(int64_t e, int64_t M) {
+  return e < M ? e + M : (e < 2 * M ? e - M : e);
+}
+
+__global__ __launch_bounds__(256) void mirror_prepare_kernel(
+    const int64_t* __restrict__ ei, const int32_t* __restrict__ eperm, int64_t E, int64_t M,
+    int32_t* __restrict__ inv, int32_t* __restrict__ flag) {
+  int bad = 0;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < E; e += (int64_t)gridDim.x * 256) {
+    inv[eperm[e]] = (int32_t)e;
+    const int64_t s = ei[e], t = ei[E + e];
+    if (e < M) {
+      if (ei[e + M] != t || ei[E + e + M] != s) bad |= 1;
+    } else if (e >= 2 * M) {
+      if (s != t) bad |= 2;
+    }
+  }
+  if (bad) atomicOr(flag, bad);
+}
+
+__global__ __launch_bounds__(256) void pack_tile_ids_mirror_kernel(
+    const int32_t* __restrict__ eperm, const int32_t* __restrict__ tgt,
+    const int32_t* __restrict__ src, const int32_t* __restrict__ inv, int64_t E, int64_t M,
+    int64_t ntiles, int32_t* __restrict__ ids4) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= ntiles * IDS) return;
+  const int64_t tile = i / IDS;
+  const int l = (int)(i - tile * IDS);
+  int64_t p = tile * TE + (l & 15);
+  p = p < E ? p : E - 1;
+  const int f = l >> 4;
+  if (f == 1) {
+    ids4[i] = src[p];                        // the mirror edge points INTO the source of position p
+  } else if (f == 2) {
+    ids4[i] = tgt[p];
+  } else {
+    const int64_t em = mirror_edge(eperm[p], M);
+    ids4[i] = f == 0 ? (int32_t)em : inv[em];
+  }
+}
+
 // gqkv[s][0 .. 63] = qk-scale(s) * sum over the edges OUT OF s of their dq rows: the rows of a
 // source are the contiguous run [erowptr[s], erowptr[s + 1]) of the temporary (the main kernel
 // writes every edge's row at its source-order position), summed in ascending order (deterministic).
@@ -734,6 +789,22 @@ void attn_pack_tile_ids_to_launch(const int32_t* eperm, const int32_t* tgt, cons
   if (ntiles > 0)
     to::pack_tile_ids_to_kernel<<<(int)ceil_div(ntiles * to::IDS, 256), 256, 0, stream>>>(
         eperm, tgt, src, tperm, e, ntiles, ids4);
+}
+
+int attn_mirror_prepare_launch(const int64_t* ei, const int32_t* eperm, int64_t e, int64_t pairs,
+                               int32_t* inv, int32_t* flag, hipStream_t stream) {
+  if (e > 0)
+    to::mirror_prepare_kernel<<<(int)(ceil_div(e, 256) < 256 * 16 ? ceil_div(e, 256) : 256 * 16), 256, 0,
+                                stream>>>(ei, eperm, e, pairs, inv, flag);
+  return 0;
+}
+void attn_pack_tile_ids_mirror_launch(const int32_t* eperm, const int32_t* tgt, const int32_t* src,
+                                      const int32_t* inv, int64_t e, int64_t pairs, int32_t* ids4,
+                                      hipStream_t stream) {
+  const int64_t ntiles = ceil_div(e, (int64_t)to::TE);
+  if (ntiles > 0)
+    to::pack_tile_ids_mirror_kernel<<<(int)ceil_div(ntiles * to::IDS, 256), 256, 0, stream>>>(
+        eperm, tgt, src, inv, e, pairs, ntiles, ids4);
 }
 
 // returns the number of partial tables written (<= ATTN_TO_MAX_PAIRS).  gqkv needs no

@@ -243,18 +243,92 @@ class SPTTrainStep:
             _csr.forget(lv.get("super_index"), lv.get("edge_index"), lv.get("batch"))
 
     _timed_steps = 0
+    graph = None                      # a captured step (capture()): replayed by step()
 
-    def step(self):
+    def _fwd_bwd(self):
+        """Forward + loss + backward of the batch: every CSR view, run table and gradient rebuilt."""
         self._forget_csr()
-        self._timed_steps += 1
         logits = self.model(self.nag)
         loss = sum(l * self.loss_fn(lg, y) for l, lg, y in zip(self.lambdas, logits, self.labels))
         self.bucket.zero()
         loss.backward()
+        return loss
+
+    def step(self):
+        self._timed_steps += 1
+        if self.graph is not None:
+            return self._replay()
+        loss = self._fwd_bwd()
         self.bucket.reduce()          # one RCCL all-reduce of the flat gradient (no-op at N=1)
         self.opt.step()
         self.last_loss = loss
         return loss
+
+    def capture(self, warmup=3):
+        """Capture the step of THIS batch into one graph (hipGraph through ``torch.cuda.CUDAGraph``)
+        and make ``step()`` replay it: the train-batch regime runs ~370 launches of a few
+        microseconds each (reference batches are capped to fixed sizes,
+        configs/datamodule/semantic/default.yaml:79-80 ``max_num_nodes`` / ``max_num_edges``), so
+        the host's ~370 ctypes / autograd round trips per step and their jitter - what a DDP rank
+        shows its peers as skew in front of the all-reduce - leave the step: one graph launch.
+
+        What the graph holds: the per-batch CSR builds and adopted-view checks (their verdict
+        stays a device flag, read by ``csr.verify_adopted(block=True)`` OUTSIDE the graph), the
+        forward, the losses, the backward and - with one rank - the AdamW update.  With more than
+        one rank (or ``SPT_FORCE_COLLECTIVES=1``) the graph ends after the backward; the flat
+        all-reduce and the fused AdamW (6 launches) follow eagerly, so that no collective is
+        captured.  The batch is static by construction: a new batch of the same caps must be
+        COPIED into the captured tensors (``nag`` levels, ``labels``), host-side run tables are
+        those of the captured batch.  Kernel timers are off in a captured step (no timing events
+        inside a capture).  Returns self."""
+        from . import ops as _ops
+        from . import csr as _csr_mod
+        if self.graph is not None:
+            return self
+        dev = self.dev
+        _csr_mod.verify_adopted(block=True)          # nothing pending from eager steps
+        collective = self.bucket.world > 1 or (self.bucket.always and
+                                               torch.distributed.is_initialized())
+        self._graph_opt = not collective
+        if self._graph_opt:
+            for g in self.opt.param_groups:            # the device-side step counter is advanced in-graph
+                g["capturable"] = True
+            if not self.opt.state:
+                warmup = max(warmup, 1)                # AdamW's moments must exist BEFORE the capture
+        paused = _ops.pause_timers(True)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        try:
+            with torch.cuda.stream(side):
+                for _ in range(warmup):                # allocator, workspaces, optimizer state
+                    self._fwd_bwd()
+                    if self._graph_opt:
+                        self.opt.step()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local"):
+                loss = self._fwd_bwd()
+                if self._graph_opt:
+                    self.opt.step()
+            self._graph_loss = loss
+            # the gradient tensors autograd allocated inside the capture: the replay writes THESE
+            self._graph_grads = [p.grad for p in self.params]
+        finally:
+            _ops.pause_timers(paused)
+        torch.cuda.synchronize(dev)
+        return self
+
+    def _replay(self):
+        self.graph.replay()
+        if not self._graph_opt:
+            for p, g in zip(self.params, self._graph_grads):
+                p.grad = g                             # (pack() re-pointed them at the flat buffer)
+            self.bucket._packed = False
+            self.bucket.reduce()
+            self.opt.step()
+        self.last_loss = self._graph_loss
+        return self._graph_loss
 
     def roofline(self, peak_gbs):
         """North-star entry (the L0->L1 segment-CSR max) + `kernels`: the ops leading the step's

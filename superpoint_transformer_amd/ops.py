@@ -45,9 +45,38 @@ def reset_timers():
         _TIMERS[k] = []
 
 
+_TIMERS_PAUSED = False
+
+
+def pause_timers(on=True):
+    """Stop / resume recording event pairs (a stream capture cannot hold timing events; a second
+    workload timed next to the first must not pool into its timers).  Returns the old setting."""
+    global _TIMERS_PAUSED
+    old, _TIMERS_PAUSED = _TIMERS_PAUSED, bool(on)
+    return old
+
+
+_CONST = {}
+
+
+def _const_tensor(vals, dtype, dev):
+    """Small host-known table as a device tensor, uploaded ONCE per (values, dtype, device): a
+    fresh ``torch.tensor(list, device=...)`` is a pageable host-to-device copy - a stall in an
+    eager step and not capturable into a graph."""
+    key = (tuple(vals), dtype, dev.index)
+    t = _CONST.get(key)
+    if t is None:
+        if len(_CONST) > 512:
+            _CONST.clear()
+        t = _CONST[key] = torch.tensor(list(vals), dtype=dtype, device=dev)
+    return t
+
+
 class _timed:
     def __init__(self, name):
-        self.rec = _TIMERS.get(name)
+        self.rec = None if _TIMERS_PAUSED else _TIMERS.get(name)
+        if _TIMERS_PAUSED:
+            return
         if self.rec is None and _TIMER_PREFIXES:
             for p in _TIMER_PREFIXES:
                 if name.startswith(p):
@@ -260,7 +289,7 @@ def _usn_args(pos, idx, w, num_super):
     if idx is None:
         num_seg = 1
         perm = None
-        rowptr = torch.tensor([0, n], dtype=torch.int32, device=dev)
+        rowptr = _const_tensor([0, n], torch.int32, dev)
         idx_t = None
     else:
         csr = csr_of(idx, num_super)
@@ -568,8 +597,10 @@ class _EdgeAttention(torch.autograd.Function):
         if el:
             src = ecsr.src_sorted()
             tids = ecsr.tile_ids(ctx.mode)
-            tv = ecsr.target_view()
-            tperm, trowptr = tv.perm, tv.rowptr
+            if not ecsr.mirrored(ctx.mode):
+                # (a mirrored edge list's target-order records need no sorted target view)
+                tv = ecsr.target_view()
+                tperm, trowptr = tv.perm, tv.rowptr
         with torch.cuda.device(dev), _timed(f"edge_attn_bwd:{n}:{ecsr.e}"):
             st = _lib.lib.spt_edge_attn_bwd_ex_f32(
                 _lib.ptr(q2), n, H, D, Dv, _lib.ptr(ecsr.erowptr), _lib.ptr(ecsr.eperm),
@@ -738,8 +769,10 @@ class _EdgeAttentionSplit(torch.autograd.Function):
         ws = _workspace(nb, dev)
         src = tids = tperm = trowptr = None
         if el:
-            src, tids, tv = ecsr.src_sorted(), ecsr.tile_ids(ctx.mode), ecsr.target_view()
-            tperm, trowptr = tv.perm, tv.rowptr
+            src, tids = ecsr.src_sorted(), ecsr.tile_ids(ctx.mode)
+            if not ecsr.mirrored(ctx.mode):
+                tv = ecsr.target_view()
+                tperm, trowptr = tv.perm, tv.rowptr
         with torch.cuda.device(dev):
             for gi in range(G):
                 cs = slice(64 * gi, 64 * gi + 64)
@@ -1717,7 +1750,7 @@ class _FusedMLPMaxPool(torch.autograd.Function):
         with torch.cuda.device(dev):
             # statistics of the top GraphNorm's backward from the pool's sparse gradient
             total = torch.empty((B, 2 * N + 1), dtype=torch.float64, device=dev)
-            rows = torch.tensor(runs.rows_per_graph(), dtype=torch.int64, device=dev)
+            rows = _const_tensor(runs.rows_per_graph(), torch.int64, dev)
             nbs = _lib.lib.spt_graphnorm_bwd_stats_sparse_workspace_bytes(S, N, B)
             ws = _workspace(nbs, dev)
             st = _lib.lib.spt_graphnorm_bwd_stats_sparse_raw_f32(
@@ -1775,7 +1808,7 @@ class _FusedMLPMaxPool(torch.autograd.Function):
         total = None
         if N <= 256 and 256 % N == 0:
             total = torch.empty((B, 2 * N + 1), dtype=torch.float64, device=dev)
-            rows = torch.tensor(runs.rows_per_graph(), dtype=torch.int64, device=dev)
+            rows = _const_tensor(runs.rows_per_graph(), torch.int64, dev)
             nb = _lib.lib.spt_graphnorm_bwd_stats_sparse_workspace_bytes(ctx.csr.num_seg, N, B)
             ws = _workspace(nb, dev)
             with torch.cuda.device(dev):

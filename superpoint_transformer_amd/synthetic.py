@@ -90,7 +90,9 @@ def _edges(gen, n, e_target, device, cloud=None):
     loops = torch.arange(n, device=device)
     s = torch.cat([lo, hi, loops])
     t = torch.cat([hi, lo, loops])
-    return torch.stack([s, t])
+    ei = torch.stack([s, t])
+    ei._spt_mirror_pairs = int(lo.numel())      # what OnTheFlyHorizontalEdgeFeatures knows: csr.EdgeCSR
+    return ei
 
 
 def _knn_indices(pos, k):
@@ -134,7 +136,9 @@ def _edges_local(gen, pos, e_target, device, cloud=None):
         key = key[torch.randperm(key.numel(), generator=gen, device=device)[:m]].sort().values
     lo, hi = key // n, key % n          # ascending lo: by cloud (the nodes of a cloud are contiguous)
     loops = torch.arange(n, device=device)
-    return torch.stack([torch.cat([lo, hi, loops]), torch.cat([hi, lo, loops])])
+    ei = torch.stack([torch.cat([lo, hi, loops]), torch.cat([hi, lo, loops])])
+    ei._spt_mirror_pairs = int(lo.numel())
+    return ei
 
 
 def _morton_code(pos):

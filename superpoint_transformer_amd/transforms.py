@@ -49,6 +49,11 @@ def horizontal_edge_features(edge_index, edge_attr, pos, normal, log_length, log
             _lib.ptr(se), e, n, _lib.ptr(ea7), *[_lib.ptr(a) for a in args],
             int(add_self_loops), _lib.ptr(ei_out), _lib.ptr(ea_out), _lib.stream_ptr(dev))
     _lib.check(st, "spt_horizontal_edge_features_f32")
+    # host knowledge of the layout just written: [i<j | j>i (| loops)] with edge i mirrored at
+    # i + e - the attention backward takes its by-target stream from it instead of a second sort
+    # (csr.EdgeCSR; checked on the device).  A later transform that thins the list
+    # (SampleEdges with n >= 0, NAGRestrictSize) builds a new tensor without the attribute.
+    ei_out._spt_mirror_pairs = e
     return ei_out, ea_out
 
 

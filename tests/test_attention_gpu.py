@@ -564,3 +564,111 @@ def test_edge_lane_backward_stays_inside_an_exact_workspace_when_edges_are_fewer
         _check(v.grad, p[k].grad, "g_" + k, rel_to_max=True)
     # the process default was not touched by the per-call choice
     assert _lib.lib.spt_attn_bwd_el_target_order(-1) == 1
+
+
+def _mirrored_graph(gen, n, deg, dev, loops=True):
+    """[i<j | j>i | loops] as OnTheFlyHorizontalEdgeFeatures + NAGAddSelfLoops leave it, with the
+    host knowledge their kernel leaves on the tensor (M pairs)."""
+    m = int(n * deg / 2)
+    a = torch.randint(0, n, (m,), generator=gen)
+    b = torch.randint(0, n, (m,), generator=gen)
+    keep = a != b
+    lo, hi = torch.minimum(a[keep], b[keep]), torch.maximum(a[keep], b[keep])
+    lp = torch.arange(n) if loops else torch.zeros(0, dtype=torch.long)
+    ei = torch.stack([torch.cat([lo, hi, lp]), torch.cat([hi, lo, lp])]).to(dev)
+    ei._spt_mirror_pairs = int(lo.numel())
+    return ei
+
+
+@pytest.mark.parametrize("n,deg,loops", [(5000, 16.0, True), (700, 3.0, False), (40, 90.0, True)])
+def test_by_target_stream_from_the_mirror_structure(n, deg, loops, dev):
+    """Round 6: the target-order tile records of a mirrored edge list come from the by-source view
+    alone (spt_attn_mirror_prepare + spt_attn_pack_tile_ids_mirror: no second sort).  The records
+    must describe the SAME edges as the sort-based ones - every stream position one edge with its
+    (row, target, source, source-order position), targets in ascending runs - and the attention
+    backward on them must match the f64 oracle and the sort-based route."""
+    from superpoint_transformer_amd import csr, nn as N
+    gen = torch.Generator().manual_seed(n + int(deg))
+    ei = _mirrored_graph(gen, n, deg, dev, loops)
+    E = ei.shape[1]
+    ec = csr.edge_csr_of(ei, n)
+    assert ec.mirrored(1 << 6) and not ec.mirrored(2 << 6)
+    rec = ec.tile_ids(1 << 6)                                   # target order, mirror route
+    assert ec._tview is None                                    # no target view was sorted
+    csr.verify_adopted(block=True)                              # the structure check passed
+    old = csr.use_mirror_views(False)
+    try:
+        csr.forget(ei)
+        ref = csr.edge_csr_of(ei, n).tile_ids(1 << 6)           # sort-based records
+    finally:
+        csr.use_mirror_views(old)
+
+    def rows(r):
+        r = r.view(-1, 4, 16).permute(0, 2, 1).reshape(-1, 4)[:E].cpu()     # [E, (row, tgt, src, pos)]
+        return r
+    a, b = rows(rec), rows(ref)
+    assert bool((a[1:, 1] >= a[:-1, 1]).all())                  # grouped by target, ascending
+    assert torch.equal(a[:, 1], b[:, 1])                        # the same targets at the same positions
+    key = lambda r: r[torch.argsort(r[:, 0])]                   # one record per edge row: compare as sets
+    assert torch.equal(key(a), key(b))
+    eic = ei.cpu()
+    assert torch.equal(eic[1][a[:, 0].long()], a[:, 1].long()) and torch.equal(eic[0][a[:, 0].long()], a[:, 2].long())
+
+    H, D, dim, F = 16, 4, 64, 32
+    blk = N.SelfAttentionBlock(dim, num_heads=H, out_dim=None, qk_dim=D, in_rpe_dim=F,
+                               k_rpe=True, q_rpe=True, v_rpe=True).to(dev)
+    x = torch.randn(n, dim, generator=gen)
+    ea = torch.randn(E, F, generator=gen) * 0.5
+    gw = torch.randn(n, dim, generator=gen)
+
+    def run(mirror):
+        old = csr.use_mirror_views(mirror)
+        try:
+            csr.forget(ei)
+            xd, ead = x.to(dev).requires_grad_(), ea.to(dev).requires_grad_()
+            for p_ in blk.parameters():
+                p_.grad = None
+            out = blk(xd, ei, edge_attr=ead)
+            (out * gw.to(dev)).sum().backward()
+            torch.cuda.synchronize()
+            return out.detach(), xd.grad, ead.grad, {k: v.grad.clone() for k, v in blk.named_parameters()}
+        finally:
+            csr.use_mirror_views(old)
+
+    om, gxm, gem, gpm = run(True)
+    os_, gxs, ges, gps = run(False)
+    csr.verify_adopted(block=True)
+    p = {k: v.detach().cpu().double().requires_grad_() for k, v in blk.named_parameters()}
+    x64, ea64 = x.double().requires_grad_(), ea.double().requires_grad_()
+    refo = O.self_attention(x64, eic, ea64, p, H, D)
+    (refo * gw.double()).sum().backward()
+    assert torch.equal(om, os_)                                 # the forward does not see the route
+    _check(om, refo, "out")
+    _check(gxm, x64.grad, "g_x (mirror)")
+    _check(gxs, x64.grad, "g_x (sorted)")
+    _check(gem, ea64.grad, "g_edge_attr (mirror)")
+    for k in gpm:
+        _check(gpm[k], p[k].grad, "g_" + k + " (mirror)", rel_to_max=True)
+
+
+def test_a_wrong_mirror_hint_is_caught(dev):
+    """The declared structure is checked on the device: an edge list whose halves are not mirrors
+    raises StaleCSRError when the verdict is read, the hint is removed and the next batch sorts."""
+    from superpoint_transformer_amd import csr, nn as N
+    gen = torch.Generator().manual_seed(9)
+    n = 900
+    ei = _mirrored_graph(gen, n, 8.0, dev)
+    M = ei._spt_mirror_pairs
+    bad = ei.clone()
+    bad[1, M + 5] = (bad[1, M + 5] + 1) % n                     # one flipped edge points elsewhere
+    bad._spt_mirror_pairs = M
+    blk = N.SelfAttentionBlock(64, num_heads=16, out_dim=None, qk_dim=4, in_rpe_dim=32,
+                               k_rpe=True, q_rpe=True, v_rpe=True).to(dev)
+    x = torch.randn(n, 64, device=dev, requires_grad=True)
+    ea = torch.randn(bad.shape[1], 32, device=dev, requires_grad=True)
+    blk(x, bad, edge_attr=ea).sum().backward()
+    with pytest.raises(csr.StaleCSRError, match="mirror"):
+        csr.verify_adopted(block=True)
+    assert not hasattr(bad, "_spt_mirror_pairs")
+    assert not csr.edge_csr_of(bad, n).mirrored(1 << 6)         # sorts from now on
+    csr.verify_adopted(block=True)

@@ -123,6 +123,13 @@ def test_fused_mlp_matches_oracle_and_unfused_path(dims, rows, B, gemm_mode, dev
         err = relerr(a, r)
         assert float(err.max()) <= tol, f"{name}: {int((err > tol).sum())} elements above {tol}, max {err.max().item():.3e}"
 
+    # the two one-sided oracles move ALL near elements at once, which shifts the GraphNorm
+    # backward's statistics for every row of the graph (thousands of rows x their ~1 / sqrt(rows)
+    # gradients in the all-split mode's wide eps): that collective shift is MEASURED on the rows
+    # away from every kink (where it is the only difference between the three oracles) and is
+    # the slack a near-kink row's one-sided comparison gets on top of the bar - derived, not chosen
+    coll = max(float(relerr(gx_pos[safe], gx_ref[safe]).max()), float(relerr(gx_neg[safe], gx_ref[safe]).max()))
+
     def close_gx(a, name, tol=1e-4):
         """Every row without a near-kink element: the bar, no outliers.  Every row with ONE: the
         whole row matches the oracle with that element on one side of the kink or on the other."""
@@ -133,8 +140,8 @@ def test_fused_mlp_matches_oracle_and_unfused_path(dims, rows, B, gemm_mode, dev
             worst = torch.minimum(e_pos, e_neg)
             took_pos = int((e_pos <= e_neg).sum())
             print(f"{name}: {int(one.sum())} single-kink rows, {took_pos} on the positive side, "
-                  f"worst one-sided error {worst.max().item():.3e}")
-            assert float(worst.max()) <= tol, (
+                  f"worst one-sided error {worst.max().item():.3e} (bar {tol:.0e} + collective {coll:.2e})")
+            assert float(worst.max()) <= tol + coll, (
                 f"{name}: a near-kink row matches NEITHER side of its kink: {worst.max().item():.3e}")
 
     ytol = 2e-5 if gemm_mode < 2 else 2e-4
