@@ -66,6 +66,7 @@ def parse():
     p.add_argument("--no-train-batch", action="store_true",
                    help="skip the train-batch companion (scene T: ms_per_step_T eager + captured, "
                         "ms_per_iteration_T) of the default line")
+    p.add_argument("--train-batch-child", action="store_true", help=argparse.SUPPRESS)
     p.add_argument("--capture", action="store_true",
                    help="replay the step as a captured graph (hipGraph through torch.cuda.CUDAGraph): forward + "
                         "loss + backward (+ AdamW at N = 1) of the fixed batch, captured once after the warm-up")
@@ -285,7 +286,24 @@ def cpu_preprocess_baseline(scene, n_sample):
                       f"(k={k}, r={r}) + eigenfeatures via oracle/cpu/libspt_cpu.so (OpenMP)"}
 
 
-def train_batch_leg(dev, steps=100):
+def train_batch_leg(dev):
+    """The train-batch companion in a CHILD process (same GPU, the parent idle): whatever happens
+    in it - a capture the runtime refuses, a crash - costs the default line its `train_batch`
+    object, never the headline."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--train-batch-child"]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    except subprocess.TimeoutExpired:
+        return {"error": "the train-batch child timed out after 900 s"}
+    for ln in reversed(r.stdout.splitlines()):
+        if ln.startswith('{"scene"'):
+            return json.loads(ln)
+    tail = (r.stderr or "").strip().splitlines()[-3:]
+    return {"error": f"the train-batch child exited with {r.returncode}: {' | '.join(tail)[:400]}"}
+
+
+def _train_batch_leg(dev, steps=100):
     """The regime the reference TRAINS in, next to the 15 M-point headline: scene T = one S3DIS
     train batch (4 clouds, 1.2 M points after sampling; batch_size / sample caps of
     configs/datamodule/semantic/s3dis.yaml:101-104, default.yaml:79-80).  Three figures:
@@ -383,6 +401,14 @@ def _log(msg):
 
 def main():
     args = parse()
+    if args.train_batch_child:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X (no CPU fallback path exists)")
+        torch.cuda.set_device(0)
+        from superpoint_transformer_amd import precision
+        precision.set_matrix_precision("f32")
+        print(json.dumps(_train_batch_leg(torch.device("cuda", 0))))
+        return
     if args.gpus is None:
         # under torchrun / an external launcher WORLD_SIZE decides; alone, one GPU
         args.gpus = int(os.environ.get("WORLD_SIZE", "1"))

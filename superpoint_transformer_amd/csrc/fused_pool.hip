@@ -194,7 +194,7 @@ __global__ __launch_bounds__(NWF * 64, 2) void fwd_pool_kernel(
   constexpr int GLEN = K * K + K + 1;
   static_assert(K % 32 == 0 && N % 16 == 0, "shape");
   __shared__ __attribute__((aligned(16))) float a_lds[NWF][TR * LDA];
-  __shared__ __attribute__((aligned(16))) float tab[3 * K];
+  __shared__ __attribute__((aligned(16))) float tab[4 * K];             // am | sc | bs | Gram shift
   __shared__ __attribute__((aligned(16))) float sgn_l[N];
   __shared__ __attribute__((aligned(16))) __bf16 wpl[NPL][N * LDW];
   __shared__ double gred[K * K + K];
@@ -211,6 +211,15 @@ __global__ __launch_bounds__(NWF * 64, 2) void fwd_pool_kernel(
     tab[i] = pam[i];
     tab[K + i] = psc[i];
     tab[2 * K + i] = pbs[i];
+    // Round 6 (advisor): the Gram matrix and the column sums are accumulated of y - shift, with
+    // shift_k = leaky(bias_k) of the previous norm - the value a channel whose |mean| is large
+    // against its spread sits at (the norm's output has mean ~ bias).  var = w^T G w / n - mu^2
+    // cancels mu^2 / var of the f32 accumulation error over a wave's ~7 K rows; around the shift
+    // the accumulated quantities are the spread itself.  The block's partial is un-shifted in f64
+    // (G = G' + s sy'^T + sy' s^T + n s s^T, sy = sy' + n s), so nothing downstream changes.
+    // The bf16 mode keeps shift 0: its statistics are those of the ROUNDED operands, one plane.
+    const float bsv = pbs[i];
+    tab[3 * K + i] = PREC == 1 ? 0.f : (bsv > 0.f ? bsv : pslope * bsv);
   }
   for (int i = threadIdx.x; i < N; i += NWF * 64) sgn_l[i] = gnw[i] < 0.f ? -1.f : 1.f;
   // W with the sign of the norm's weight folded into its rows (h' = sgn h: the pool is a max for
@@ -364,6 +373,12 @@ __global__ __launch_bounds__(NWF * 64, 2) void fwd_pool_kernel(
         float yv[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) yv[r] = al[(4 * g + r) * LDA + 16 * kb + c];
+        if constexpr (PREC != 1) {
+          // around the shift (rows past the wave's range are zero rows of the tile: they stay zero)
+          const float sh = tab[3 * K + 16 * kb + c];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) yv[r] = (4 * g + r < cnt) ? yv[r] - sh : 0.f;
+        }
         if constexpr (PREC == 1) {
           // the product above saw bf16(y): the statistics are those of what it computed
 #pragma unroll
@@ -472,11 +487,19 @@ __global__ __launch_bounds__(NWF * 64, 2) void fwd_pool_kernel(
     }
     __syncthreads();
   }
+  // rows of this workgroup (its waves' ranges are consecutive): the un-shift needs the count
+  const int64_t wfirst = (int64_t)blockIdx.x * NWF, wlast = wfirst + NWF - 1;
+  const int64_t ba = cut_at(r0 + wfirst * per, r0, r1, pos_seg, rowptr);
+  const int64_t bb = (wlast >= nw - 1) ? r1 : cut_at(r0 + (wlast + 1) * per, r0, r1, pos_seg, rowptr);
+  const double nblk = (double)(bb > ba ? bb - ba : 0);
   for (int i = threadIdx.x; i < K * K; i += NWF * 64) {
     const int rr = i / K, cc = i - rr * K;
-    partial[i] = (rr / 16 <= cc / 16) ? gred[i] : gred[cc * K + rr];   // lower blocks: the mirror
+    const double gp = (rr / 16 <= cc / 16) ? gred[i] : gred[cc * K + rr];   // lower blocks: the mirror
+    const double sr = (double)tab[3 * K + rr], sc_ = (double)tab[3 * K + cc];
+    partial[i] = gp + sr * gred[K * K + cc] + gred[K * K + rr] * sc_ + nblk * sr * sc_;
   }
-  for (int i = threadIdx.x; i < K; i += NWF * 64) partial[K * K + i] = gred[K * K + i];
+  for (int i = threadIdx.x; i < K; i += NWF * 64)
+    partial[K * K + i] = gred[K * K + i] + nblk * (double)tab[3 * K + i];
   if (threadIdx.x == 0) partial[K * K + K] = (blockIdx.x == 0) ? (double)(r1 - r0) : 0.0;
 }
 

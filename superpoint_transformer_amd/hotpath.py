@@ -287,6 +287,13 @@ class SPTTrainStep:
             return self
         dev = self.dev
         _csr_mod.verify_adopted(block=True)          # nothing pending from eager steps
+        # An autograd graph of an EAGER step that is still alive (through `last_loss`) keeps the
+        # parameters' AccumulateGrad nodes, which remember the stream they were created on (the
+        # default stream): the backward of the capture would then hop to that stream - outside the
+        # capture.  Drop it; the warm-up below creates the nodes on the capture's own stream.
+        self.last_loss = None
+        import gc
+        gc.collect()
         collective = self.bucket.world > 1 or (self.bucket.always and
                                                torch.distributed.is_initialized())
         self._graph_opt = not collective
