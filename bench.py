@@ -345,7 +345,7 @@ def _train_batch_leg(dev, steps=100):
         torch.cuda.empty_cache()
         raw = make_raw_nag("T", seed=1234, device=dev)
         it = hotpath.build(raw, dev, mode="iteration", model="spt64")
-        for _ in range(5):
+        for _ in range(40):                       # (sampled sizes vary: let the allocator see them)
             it.step()
         it.reset_kernel_timers()
         torch.cuda.synchronize()

@@ -775,6 +775,13 @@ bool attn_bwd_to_enabled();
 size_t attn_bwd_to_workspace_bytes(int64_t n, int64_t e);
 void attn_pack_tile_ids_to_launch(const int32_t* eperm, const int32_t* tgt, const int32_t* src,
                                   const int32_t* tperm, int64_t e, int32_t* ids4, hipStream_t stream);
+// XCD bands of the attention kernels' work distribution (edge_attn_mfma.hip forward, edge_attn_to.hip
+// backward): a SPEED choice between two walks of the same work - read once from the environment
+// (SPT_ATTN_XCD_BANDS=0 restores the plain grid stride / contiguous tile ranges for A/B runs).
+bool attn_xcd_bands() {
+  static const bool on = [] { const char* e = getenv("SPT_ATTN_XCD_BANDS"); return e ? atoi(e) != 0 : true; }();
+  return on;
+}
 int attn_mirror_prepare_launch(const int64_t* ei, const int32_t* eperm, int64_t e, int64_t pairs,
                                int32_t* inv, int32_t* flag, hipStream_t stream);
 void attn_pack_tile_ids_mirror_launch(const int32_t* eperm, const int32_t* tgt, const int32_t* src,

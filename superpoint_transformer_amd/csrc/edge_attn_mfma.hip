@@ -418,7 +418,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_fwd_mfma_kernel(
     const float* __restrict__ ea, const float* __restrict__ Wk, const float* __restrict__ bk,
     const float* __restrict__ Wq, const float* __restrict__ bq, const float* __restrict__ Wv,
     const float* __restrict__ bv, int scale_mode, float scale_a, float* __restrict__ out,
-    float* __restrict__ mbuf, float* __restrict__ zbuf) {
+    float* __restrict__ mbuf, float* __restrict__ zbuf, int bands) {
   constexpr bool BF3 = PREC != 0, LO = PREC == 3;
   __shared__ __attribute__((aligned(16))) float slab_all[WAVES][2][SLAB];
   const int lane = threadIdx.x & 63;
@@ -445,8 +445,21 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_fwd_mfma_kernel(
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
 
-  const int64_t wave = (int64_t)blockIdx.x * WAVES + wid;
-  const int64_t nwaves = (int64_t)gridDim.x * WAVES;
+  int64_t wave = (int64_t)blockIdx.x * WAVES + wid;
+  int64_t nwaves = (int64_t)gridDim.x * WAVES;
+  if (bands) {
+    // Round 6: XCD bands.  Workgroup b runs on XCD b % 8 (observed placement; only speed depends
+    // on it) and every XCD has its own L2: XCD x takes the contiguous EIGHTH [x N / 8, (x + 1) N / 8)
+    // of the nodes and its resident waves walk it node by node, so the k | v rows the band's
+    // nodes gather - their spatial neighbours, a few hundred rows around them in the MortonOrder
+    // layout - are fetched into ONE L2 once instead of into all eight (the plain grid stride
+    // deals consecutive nodes to consecutive XCDs).  Per-node results do not depend on the walk.
+    const int x = blockIdx.x & 7;
+    const int64_t npx = (N + 7) >> 3, lim = (x + 1) * npx < N ? (x + 1) * npx : N;
+    wave = x * npx + (int64_t)(blockIdx.x >> 3) * WAVES + wid;
+    nwaves = (int64_t)(gridDim.x >> 3) * WAVES;
+    N = lim;
+  }
   if (wave >= N) return;
   Pipe P;
   P.init(wave, nwaves, N, erowptr, eperm, tgt, qkv, ld, ea, slab_all[wid][0], slab_all[wid][1], lane);
@@ -1403,6 +1416,7 @@ SPT_PROBE(6)
 }  // namespace mfma
 
 // ---- launchers called from edge_attn.hip's C entry points --------------------
+bool attn_xcd_bands();      // edge_attn.hip: SPT_ATTN_XCD_BANDS (default on)
 bool attn_mfma_shape_ok(int H, int D, int Dv, int F, const void* ea, const void* Wk,
                         const void* Wq, const void* Wv) {
   return H == 16 && D == 4 && Dv == 4 && F == 32 && ea && Wk && Wq && Wv;
@@ -1415,15 +1429,17 @@ void attn_fwd_mfma_launch(const float* qkv, int64_t n, const int32_t* erowptr,
                           float* out, float* m, float* z, int split_bf16, hipStream_t stream) {
   const int64_t blocks = ceil_div(n, mfma::WAVES);
   const int grid = (int)(blocks < 256 * 2 * 4 ? blocks : 256 * 2 * 4);
+  // XCD bands only where the grid is the capped one (a multiple of 8) and a band outlasts a round
+  const int bands = attn_xcd_bands() && grid == 256 * 2 * 4 && n >= 8 * (int64_t)grid * mfma::WAVES;
   if (split_bf16 == 3)
     mfma::attn_fwd_mfma_kernel<3><<<grid, mfma::WAVES * 64, 0, stream>>>(
-        qkv, 192, n, erowptr, eperm, tgt, ea, Wk, bk, Wq, bq, Wv, bv, scale_mode, scale_a, out, m, z);
+        qkv, 192, n, erowptr, eperm, tgt, ea, Wk, bk, Wq, bq, Wv, bv, scale_mode, scale_a, out, m, z, bands);
   else if (split_bf16 == 1)
     mfma::attn_fwd_mfma_kernel<1><<<grid, mfma::WAVES * 64, 0, stream>>>(
-        qkv, 192, n, erowptr, eperm, tgt, ea, Wk, bk, Wq, bq, Wv, bv, scale_mode, scale_a, out, m, z);
+        qkv, 192, n, erowptr, eperm, tgt, ea, Wk, bk, Wq, bq, Wv, bv, scale_mode, scale_a, out, m, z, bands);
   else
     mfma::attn_fwd_mfma_kernel<0><<<grid, mfma::WAVES * 64, 0, stream>>>(
-        qkv, 192, n, erowptr, eperm, tgt, ea, Wk, bk, Wq, bq, Wv, bv, scale_mode, scale_a, out, m, z);
+        qkv, 192, n, erowptr, eperm, tgt, ea, Wk, bk, Wq, bq, Wv, bv, scale_mode, scale_a, out, m, z, bands);
 }
 
 constexpr int ATTN_BWD_MFMA_BLOCKS = 256;  // one 4-wave workgroup per CU (1 wave / SIMD)

@@ -312,7 +312,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_bwd_to_kernel(
     const float* __restrict__ bk, const float* __restrict__ Wq, const float* __restrict__ bq,
     const float* __restrict__ Wv, const float* __restrict__ bv, const float* __restrict__ rec,
     float* __restrict__ gqkv, float* __restrict__ gea, int gea_acc, float* __restrict__ dqt,
-    float* __restrict__ partial) {
+    float* __restrict__ partial, int bands) {
   static_assert(PREC == 1 || PREC == 3, "bf16 matrix pipe only");
   constexpr bool LO = PREC == 3;
   // the bf16 mode streams its dq rows as bf16: 64 bytes per edge and wave, ONE store per tile
@@ -378,11 +378,26 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_bwd_to_kernel(
     gb[q6] = 0.f;
   }
 
-  const int64_t t_begin = pair * tpw;
-  const int64_t t_end = (t_begin + tpw < ntiles) ? t_begin + tpw : ntiles;
+  // The pair's tiles: a contiguous range of the target-order stream (bands == 0), or - round 6,
+  // XCD bands - every (pairs per XCD)-th tile of the contiguous EIGHTH of the stream that belongs
+  // to this workgroup's XCD (workgroup b runs on XCD b % 8: observed placement, only speed depends
+  // on it).  The resident pairs of an XCD then sweep ONE window of consecutive targets together,
+  // and the source records those targets' edges gather (the targets' spatial neighbours in the
+  // MortonOrder layout) are fetched into that XCD's L2 once for all of them; with contiguous
+  // ranges every pair sat in its own far-away part of the graph.  Same tiles, same per-tile
+  // arithmetic; the sums over tiles (weight gradients, atomics) meet in another order.
+  int64_t t_begin = pair * tpw, t_step = 1;
+  int64_t t_end = (t_begin + tpw < ntiles) ? t_begin + tpw : ntiles;
+  if (bands) {
+    const int x = blockIdx.x & 7;
+    const int64_t tpx = (ntiles + 7) >> 3;
+    t_step = (int64_t)(gridDim.x >> 3) * (WAVES / 2);
+    t_begin = x * tpx + (int64_t)(blockIdx.x >> 3) * (WAVES / 2) + (wid >> 1);
+    t_end = (x + 1) * tpx < ntiles ? (x + 1) * tpx : ntiles;
+  }
   if (t_begin < t_end) {
     int* ids_ring = reinterpret_cast<int*>(P + P_IDS);
-    const int64_t t_last = t_end - 1;
+    const int64_t t_last = t_begin + (t_end - 1 - t_begin) / t_step * t_step;
     auto issue_ids = [&](int64_t t, int slot) {        // one 256-byte record: 64 lanes x 4 bytes
       t = t < t_last ? t : t_last;
       lds_dma4(ids4 + t * IDS + lane, P + P_IDS + slot * IDS);
@@ -440,7 +455,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_bwd_to_kernel(
     // ---- prologue ------------------------------------------------------------------------------
     if (leader) {
       issue_ids(t_begin, 0);
-      issue_ids(t_begin + 1, 1);
+      issue_ids(t_begin + t_step, 1);
       wait_vm<0>();
       issue_ea(0, 0);
       wait_vm<0>();
@@ -452,7 +467,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_bwd_to_kernel(
     wait_vm<0>();
 
     int k = 0;                                    // tile index within the pair's range
-    for (int64_t t = t_begin; t < t_end; ++t, ++k) {
+    for (int64_t t = t_begin; t < t_end; t += t_step, ++k) {
       const int s0 = k & 3, s1 = (k + 1) & 3, s2 = (k + 2) & 3;   // id ring slots of tiles k, k+1, k+2
       if (leader) {
         // edge_attr rows of tile k and the ids of tile k + 1 have landed; behind them in the queue:
@@ -492,7 +507,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_bwd_to_kernel(
       // counted wait serves both
       if (leader) {
         flag_wait(flg + F_DONE, k - 1);
-        issue_ids(t + 2, s2);
+        issue_ids(t + 2 * t_step, s2);
         issue_node(s0);
         flag_wait(flg + F_TOP, k);
         issue_ea(s1, (k + 1) & 1);
@@ -791,6 +806,7 @@ void attn_pack_tile_ids_to_launch(const int32_t* eperm, const int32_t* tgt, cons
         eperm, tgt, src, tperm, e, ntiles, ids4);
 }
 
+bool attn_xcd_bands();      // edge_attn.hip: SPT_ATTN_XCD_BANDS (default on)
 int attn_mirror_prepare_launch(const int64_t* ei, const int32_t* eperm, int64_t e, int64_t pairs,
                                int32_t* inv, int32_t* flag, hipStream_t stream) {
   if (e > 0)
@@ -836,12 +852,14 @@ int attn_bwd_to_launch(const float* qkv, int64_t n, const int32_t* erowptr, cons
   const int64_t tpw = ceil_div(ntiles, pairs);
   pairs = ceil_div(ntiles, tpw);
   const int grid = (int)ceil_div(pairs, to::WAVES / 2);
+  // XCD bands where the grid is the full one (a multiple of 8) and a band outlasts a few sweeps
+  const int bands = attn_xcd_bands() && grid % 8 == 0 && ntiles >= 8 * pairs;
   if (prec == 3)
     to::attn_bwd_to_kernel<3><<<grid, to::WAVES * 64, 0, stream>>>(
-        qkv, e, tile_ids, ntiles, tpw, ea, Wk, bk, Wq, bq, Wv, bv, rec, gqkv, gea, gea_acc, dqt, partial);
+        qkv, e, tile_ids, ntiles, tpw, ea, Wk, bk, Wq, bq, Wv, bv, rec, gqkv, gea, gea_acc, dqt, partial, bands);
   else
     to::attn_bwd_to_kernel<1><<<grid, to::WAVES * 64, 0, stream>>>(
-        qkv, e, tile_ids, ntiles, tpw, ea, Wk, bk, Wq, bq, Wv, bv, rec, gqkv, gea, gea_acc, dqt, partial);
+        qkv, e, tile_ids, ntiles, tpw, ea, Wk, bk, Wq, bq, Wv, bv, rec, gqkv, gea, gea_acc, dqt, partial, bands);
   const int64_t rblocks = ceil_div(n, (int64_t)16);
   if (prec == 3)
     to::attn_q_reduce_kernel<false><<<(int)(rblocks < 256 * 16 ? rblocks : 256 * 16), 256, 0, stream>>>(

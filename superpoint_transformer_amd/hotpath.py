@@ -471,9 +471,14 @@ class SPTTrainStep:
                 "measured": f"{reps} stand-alone launches after the timed region, HIP events on the launch stream"}
 
     def describe(self, scene, sizes, graph="random"):
-        views = ("level CSR views taken from the NAG's stored `sub` (nag[i+1].sub), edge views sorted per step"
+        mirror = (_csr._USE_MIRROR and getattr(self.nag.levels[1].get("edge_index"), _csr.MIRROR_ATTR, None)
+                  is not None)
+        edges = ("by-source edge views sorted per step, the by-target stream taken from the lists' mirror "
+                 "structure [i<j | j>i | loops] (checked on the device)" if mirror
+                 else "edge views (by source, by target) sorted per step")
+        views = (f"level CSR views taken from the NAG's stored `sub` (nag[i+1].sub), {edges}"
                  if _csr._USE_SUB_VIEWS and self.nag.levels[1].get("sub") is not None
-                 else "every CSR view rebuilt by the device sort per step (--rebuild-csr: a NAG without `sub`)")
+                 else f"every level CSR view rebuilt by the device sort per step (--rebuild-csr: a NAG without `sub`), {edges}")
         kind = {"random": "uniformly random superpoint graph = no locality, the worst case for the "
                           "attention's k / v gathers (stress case)",
                 "local": "kNN-on-centroids superpoint graph (SURVEY 8d), nodes in storage order"}[graph]
