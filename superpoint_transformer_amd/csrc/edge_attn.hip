@@ -692,8 +692,13 @@ __global__ __launch_bounds__(EA_WAVES * 64, 1) void edge_attn_bwd_kernel(
 }
 
 // fixed-order sum of the per-wave partial tables: 16 columns x 16 slices per block
+// Fixed-order sum of the per-wave partial tables [rows][F + 1] and the split of the result into
+// the six gradient tensors, in ONE launch (round 6: the sum and the split were two kernels, 14
+// launches of ~5 us per train-batch step).  Same slices, same order of adds as before.
 __global__ __launch_bounds__(256) void attn_reduce_partials_kernel(
-    const float* __restrict__ partial, int nwaves, int len, float* __restrict__ total) {
+    const float* __restrict__ partial, int nwaves, int len, int QK, int C, int F,
+    float* __restrict__ gWk, float* __restrict__ gbk, float* __restrict__ gWq,
+    float* __restrict__ gbq, float* __restrict__ gWv, float* __restrict__ gbv) {
   __shared__ float sl[16][17];
   const int cl = threadIdx.x & 15;
   const int col = blockIdx.x * 16 + cl;
@@ -710,29 +715,16 @@ __global__ __launch_bounds__(256) void attn_reduce_partials_kernel(
     float t = 0.f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) t += sl[k][cl];
-    total[col] = t;
+    const int r = col / (F + 1), f = col - r * (F + 1);
+    float* W;
+    float* b;
+    int rr;
+    if (r < QK) { W = gWk; b = gbk; rr = r; }
+    else if (r < 2 * QK) { W = gWq; b = gbq; rr = r - QK; }
+    else { W = gWv; b = gbv; rr = r - 2 * QK; }
+    if (f < F) { if (W) W[(size_t)rr * F + f] = t; }
+    else if (b) b[rr] = t;
   }
-}
-
-// split the reduced [rows][F+1] table into the six gradient tensors
-__global__ void attn_unpack_grads_kernel(const float* __restrict__ total, int QK, int C,
-                                         int F, float* __restrict__ gWk,
-                                         float* __restrict__ gbk, float* __restrict__ gWq,
-                                         float* __restrict__ gbq, float* __restrict__ gWv,
-                                         float* __restrict__ gbv) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int rows = 2 * QK + C;
-  if (t >= rows * (F + 1)) return;
-  const int r = t / (F + 1), f = t - r * (F + 1);
-  const float v = total[t];
-  float* W;
-  float* b;
-  int rr;
-  if (r < QK) { W = gWk; b = gbk; rr = r; }
-  else if (r < 2 * QK) { W = gWq; b = gbq; rr = r - QK; }
-  else { W = gWv; b = gbv; rr = r - 2 * QK; }
-  if (f < F) { if (W) W[(size_t)rr * F + f] = v; }
-  else if (b) b[rr] = v;
 }
 
 static bool attn_shape(int H, int D, int Dv, int qpl, int vpl, AttnShape* sh) {
@@ -1086,7 +1078,7 @@ extern "C" int spt_edge_attn_bwd_ex_f32(const float* qkv, int64_t n, int H, int 
   SPT_CHECK_ARG(!has_rpe || (ws && ws_bytes >= need), "workspace too small");
   float* partial = has_rpe ? (float*)ws : nullptr;
   const size_t partial_bytes = align_up((size_t)EA_BWD_BLOCKS * EA_WAVES * len * 4, 256);
-  float* total = has_rpe ? (float*)((char*)ws + partial_bytes) : nullptr;
+  (void)partial_bytes;   // (the reduced table used to live behind the partials: written in place now)
   const int grid = (int)(ceil_div(n, EA_WAVES) < EA_BWD_BLOCKS ? ceil_div(n, EA_WAVES) : EA_BWD_BLOCKS);
   // (the target-order route needs either the sorted target view or ready-made tile records -
   // spt_attn_pack_tile_ids_mirror builds them without a view; the source-order route needs the view)
@@ -1136,9 +1128,7 @@ extern "C" int spt_edge_attn_bwd_ex_f32(const float* qkv, int64_t n, int H, int 
                                   prec == 2 ? 3 : (prec == 3 ? 1 : 0), e, form != 0, stream);
     }
     attn_reduce_partials_kernel<<<(int)ceil_div((int64_t)len, 16), 256, 0, stream>>>(
-        partial, ntab, (int)len, total);
-    attn_unpack_grads_kernel<<<(int)ceil_div((int64_t)len, 256), 256, 0, stream>>>(
-        total, H * D, H * Dv, F, gWk, gbk, gWq, gbq, gWv, gbv);
+        partial, ntab, (int)len, H * D, H * Dv, F, gWk, gbk, gWq, gbq, gWv, gbv);
     SPT_CHECK_LAUNCH();
     return 0;
   }
@@ -1156,9 +1146,7 @@ extern "C" int spt_edge_attn_bwd_ex_f32(const float* qkv, int64_t n, int H, int 
 #undef SPT_ATTN_CASE
   if (has_rpe) {
     attn_reduce_partials_kernel<<<(int)ceil_div((int64_t)len, 16), 256, 0, stream>>>(
-        partial, grid * EA_WAVES, (int)len, total);
-    attn_unpack_grads_kernel<<<(int)ceil_div((int64_t)len, 256), 256, 0, stream>>>(
-        total, H * D, H * Dv, F, gWk, gbk, gWq, gbq, gWv, gbv);
+        partial, grid * EA_WAVES, (int)len, H * D, H * Dv, F, gWk, gbk, gWq, gbq, gWv, gbv);
   }
   SPT_CHECK_LAUNCH();
   return 0;

@@ -59,14 +59,17 @@ def _same_parameters(pe, pc, n_steps, pe2=None):
                          ids=["one-cloud", "three-clouds"])
 def test_captured_step_is_the_eager_step(dev, sizes):
     le, pe = _steps(dev, sizes, capture=False, n_steps=5)
-    _, pe2 = _steps(dev, sizes, capture=False, n_steps=5)
+    le2, pe2 = _steps(dev, sizes, capture=False, n_steps=5)
     lc, pc = _steps(dev, sizes, capture=True, n_steps=5)
-    le = le[1:]                                # (the captured run's first step was its eager warm-up)
+    le, le2 = le[1:], le2[1:]                  # (the captured run's first step was its eager warm-up)
     # (the backward's dk / dv sums use hardware atomics: run-to-run differences of ~1e-6 of a
-    # tensor's scale between ANY two runs, eager or not; AdamW's first steps are sign-like, so the
-    # parameters are compared on the step size 1e-3)
-    for a, b in zip(le, lc):
-        assert abs(a - b) <= 2e-4 * max(abs(a), 1.0), (le, lc)
+    # tensor's scale between ANY two runs, eager or not; AdamW's first steps are sign-like, so a
+    # noise-gradient parameter walks +-lr per step and the losses of two runs drift apart by a few
+    # 1e-4 within a handful of steps: the yardstick is a SECOND EAGER run)
+    print("losses eager", le, "eager again", le2, "captured", lc)
+    for a, a2, b in zip(le, le2, lc):
+        assert abs(a - b) <= max(2e-4 * max(abs(a), 1.0), 4 * abs(a - a2)), (le, le2, lc)
+    assert abs(le[0] - lc[0]) <= 2e-4 * max(abs(le[0]), 1.0)      # one update in: still tight
     assert le[-1] < le[0]                      # it trains
     _same_parameters(pe, pc, n_steps=5, pe2=pe2)
 
@@ -88,7 +91,9 @@ def test_captured_forward_backward_with_the_optimizer_outside(dev):
     lc = [float(path.step()) for _ in range(4)]
     # one warm-up step ran before the capture (fwd + bwd only: no update), so the replays start
     # from the same parameters as the eager run
-    for a, b in zip(le, lc):
-        assert abs(a - b) <= 2e-4 * max(abs(a), 1.0), (le, lc)
+    for k, (a, b) in enumerate(zip(le, lc)):
+        # (first replay: the same parameters as the eager run's first step; later ones drift like
+        # any two runs do - see test_captured_step_is_the_eager_step)
+        assert abs(a - b) <= (2e-5 if k == 0 else 1.5e-3) * max(abs(a), 1.0), (le, lc)
     assert path.bucket.check_views()
     _same_parameters(pe, [p.detach() for p in path.params], n_steps=4)
