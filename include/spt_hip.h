@@ -51,6 +51,35 @@ enum spt_reduce_op {
   SPT_MAX = 3
 };
 
+/* Round 6: a GraphNorm whose tables a fused layer call writes from the statistics it has just
+ * summed, instead of the caller making a second call for them (spt_graphnorm_tables_f32 /
+ * spt_graphnorm_bwd_tables_f32: same formulas, same bits).  HOST structs of DEVICE pointers, passed
+ * by address and copied into the launch: weight / mean_scale [d] are the norm's parameters
+ * (PyG GraphNorm, src/nn/mlp.py:85-94); the forward tables mean / rstd / am / scale are
+ * [num_graphs, d]; the backward tables c1 / c2 / c3 [num_graphs, d] and the parameter gradients
+ * gweight / gbias / gmean_scale [d]. */
+typedef struct spt_gn_fwd_tables {
+  const float* weight;
+  const float* mean_scale;
+  float eps;
+  float* mean;
+  float* rstd;
+  float* am;
+  float* scale;
+} spt_gn_fwd_tables;
+typedef struct spt_gn_bwd_tables {
+  const float* weight;
+  const float* mean_scale;
+  const float* mean;
+  const float* rstd;
+  float* c1;
+  float* c2;
+  float* c3;
+  float* gweight;
+  float* gbias;
+  float* gmean_scale;
+} spt_gn_bwd_tables;
+
 /* Library ABI version (major*1000 + minor). */
 int spt_version(void);
 /* Thread-local description of the last error returned by this library. */
@@ -934,6 +963,34 @@ int spt_fused_linear_bwd_pooled_runs_f32(
     const float* xprev, int K, const float* pre_am, const float* pre_scale, const float* pre_bias,
     float pre_slope, const float* W, float* gx, float* gW, double* prev_total, int mode, void* ws,
     size_t ws_bytes, spt_stream_t stream);
+/* Round 6: the same three calls with a GraphNorm descriptor - the layer's own norm (forward: its
+ * tables mean / rstd / am / scale come out of the call, spt_graphnorm_tables_f32 is not needed;
+ * `total` may be NULL) or the PREVIOUS layer's norm (backward: its c1 / c2 / c3 and parameter
+ * gradients come out of the call, spt_graphnorm_bwd_tables_f32 is not needed; `prev_total` may be
+ * NULL).  One "post" launch per call sums the partial tables and writes the norm's tables: a fused
+ * layer costs 2 launches per direction instead of 3 (forward) / 4 (backward) - what a train-batch
+ * step, ~360 launches of a few microseconds, is made of. */
+int spt_fused_linear_fwd_runs_gn_f32(const float* x, int nruns, const int64_t* run_r0,
+                                     const int64_t* run_r1, const int32_t* run_graph, int num_graphs,
+                                     int K, const float* W, int N, const float* pre_am,
+                                     const float* pre_scale, const float* pre_bias, float pre_slope,
+                                     float* h, double* total, int mode, void* ws, size_t ws_bytes,
+                                     const spt_gn_fwd_tables* norm, spt_stream_t stream);
+int spt_fused_linear_bwd_runs_gn_f32(
+    const float* gy, const float* h, int nruns, const int64_t* run_r0, const int64_t* run_r1,
+    const int32_t* run_graph, int num_graphs, int N, const float* am, const float* scale,
+    const float* bias, float slope, const float* c1, const float* c2, const float* c3,
+    const float* xprev, int K, const float* pre_am, const float* pre_scale, const float* pre_bias,
+    float pre_slope, const float* W, float* gx, float* gW, double* prev_total, int mode, void* ws,
+    size_t ws_bytes, const spt_gn_bwd_tables* prev_norm, spt_stream_t stream);
+int spt_fused_linear_bwd_pooled_runs_gn_f32(
+    const float* gout, const int32_t* arg, const int32_t* perm, const int32_t* pos_seg,
+    const float* h, int nruns, const int64_t* run_p0, const int64_t* run_p1,
+    const int32_t* run_graph, int num_graphs, int N, const float* am, const float* scale,
+    const float* bias, float slope, const float* c1, const float* c2, const float* c3,
+    const float* xprev, int K, const float* pre_am, const float* pre_scale, const float* pre_bias,
+    float pre_slope, const float* W, float* gx, float* gW, double* prev_total, int mode, void* ws,
+    size_t ws_bytes, const spt_gn_bwd_tables* prev_norm, spt_stream_t stream);
 
 /* Consistency check of a stored segment CSR (pointers [num_seg + 1], points [n], int64 as the
  * reference's Cluster keeps them, src/data/cluster.py:19-77) against the index it is to be adopted
@@ -1004,6 +1061,17 @@ int spt_fused_linear_bwd_pool_runs_f32(
     const float* pre_scale, const float* pre_bias, float pre_slope, const float* W,
     const double* gram, float* gm, float* gx, float* gW, double* prev_total, int mode, void* ws,
     size_t ws_bytes, spt_stream_t stream);
+/* ... with the previous layer's GraphNorm-backward tables written by the call (round 6, see
+ * spt_fused_linear_bwd_runs_gn_f32; prev_total may be NULL). */
+int spt_fused_linear_bwd_pool_runs_gn_f32(
+    const float* gout, const float* raw, const int32_t* argpos, const int32_t* perm,
+    const int32_t* pos_seg, const int64_t* seg_graph, int64_t num_seg, int nruns,
+    const int64_t* run_p0, const int64_t* run_p1, const int32_t* run_graph, int num_graphs, int N,
+    const float* am, const float* scale, const float* bias, float slope, const float* c1,
+    const float* c2, const float* c3, const void* xprev, int K, const float* pre_am,
+    const float* pre_scale, const float* pre_bias, float pre_slope, const float* W,
+    const double* gram, float* gm, float* gx, float* gW, double* prev_total, int mode, void* ws,
+    size_t ws_bytes, const spt_gn_bwd_tables* prev_norm, spt_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Cross-entropy of the classifier heads' logits                (train step)

@@ -146,6 +146,17 @@ SIGNATURES = {
     "spt_fused_linear_bwd_pooled_runs_f32": (_int, [_p, _p, _p, _p, _p, _int, _p, _p, _p, _int, _int,
                                                     _p, _p, _p, _f32, _p, _p, _p, _p, _int, _p, _p,
                                                     _p, _f32, _p, _p, _p, _p, _int, _p, _sz, _p]),
+    "spt_fused_linear_fwd_runs_gn_f32": (_int, [_p, _int, _p, _p, _p, _int, _int, _p, _int, _p, _p, _p,
+                                                _f32, _p, _p, _int, _p, _sz, _p, _p]),
+    "spt_fused_linear_bwd_runs_gn_f32": (_int, [_p, _p, _int, _p, _p, _p, _int, _int, _p, _p, _p, _f32,
+                                                _p, _p, _p, _p, _int, _p, _p, _p, _f32, _p, _p, _p, _p,
+                                                _int, _p, _sz, _p, _p]),
+    "spt_fused_linear_bwd_pooled_runs_gn_f32": (_int, [_p, _p, _p, _p, _p, _int, _p, _p, _p, _int, _int,
+                                                       _p, _p, _p, _f32, _p, _p, _p, _p, _int, _p, _p,
+                                                       _p, _f32, _p, _p, _p, _p, _int, _p, _sz, _p, _p]),
+    "spt_fused_linear_bwd_pool_runs_gn_f32": (_int, [_p, _p, _p, _p, _p, _p, _i64, _int, _p, _p, _p, _int,
+                                                     _int, _p, _p, _p, _f32, _p, _p, _p, _p, _int, _p, _p,
+                                                     _p, _f32, _p, _p, _p, _p, _p, _p, _int, _p, _sz, _p, _p]),
     "spt_csr_check_i64": (_int, [_p, _p, _p, _i64, _i64, _int, _p, _p]),
     "spt_csr_adopt_i64": (_int, [_p, _p, _p, _i64, _i64, _p, _p, _p, _p]),
     "spt_fused_linear_pool_supported": (_int, [_int, _int, _int]),
@@ -200,6 +211,18 @@ SIGNATURES = {
     "spt_radius_ball_f32": (_int, [_p, _i64, _p, _f32, _int, _p, _i64, _p, _p, _p, _sz, _p]),
     "spt_cluster_pair_anchors_f32": (_int, [_p, _p, _p, _p, _p, _i64, _i64, _int, _int, _p, _p, _p]),
 }
+
+
+class GnFwdTables(ctypes.Structure):
+    """``spt_gn_fwd_tables`` of include/spt_hip.h (host struct of device pointers)."""
+    _fields_ = [("weight", _p), ("mean_scale", _p), ("eps", _f32), ("mean", _p), ("rstd", _p),
+                ("am", _p), ("scale", _p)]
+
+
+class GnBwdTables(ctypes.Structure):
+    """``spt_gn_bwd_tables`` of include/spt_hip.h."""
+    _fields_ = [("weight", _p), ("mean_scale", _p), ("mean", _p), ("rstd", _p), ("c1", _p), ("c2", _p),
+                ("c3", _p), ("gweight", _p), ("gbias", _p), ("gmean_scale", _p)]
 
 
 def _load():

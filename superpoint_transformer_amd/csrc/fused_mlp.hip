@@ -1217,10 +1217,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_kernel_bf(
 // 16-slice shape took 35-60 us per call, ~70 calls per train step at batch size)
 template <typename T>
 __device__ __forceinline__ void reduce_tables_body(const T* __restrict__ partial, int ntab, int len,
-                                                   T* __restrict__ total, int accumulate) {
+                                                   T* __restrict__ total, int accumulate,
+                                                   int bx = -1) {
   __shared__ T sl[64][17];
   const int cl = threadIdx.x & 15;
-  const int col = blockIdx.x * 16 + cl;
+  const int col = (bx < 0 ? (int)blockIdx.x : bx) * 16 + cl;
   const int slice = threadIdx.x >> 4;
   T acc = 0;
   if (col < len) {
@@ -1257,6 +1258,152 @@ __global__ __launch_bounds__(1024) void reduce_tables_groups_kernel(const T* __r
   const int b = blockIdx.y;
   reduce_tables_body<T>(partial + (size_t)grp.start[b] * len, grp.count[b], len,
                         total + (size_t)b * len, 0);
+}
+
+// ---- one "post" launch per fused layer call (round 6) --------------------------------------------
+// The train-batch step is made of ~360 launches of a few microseconds: a fused layer used to be
+// followed by its table sums and then - a separate C entry called by the host - by the GraphNorm
+// table kernel that consumes them (forward: 3 launches per layer, backward: 4).  The sums of one
+// column in a fixed order and the table formulas are unchanged (sliced_col_sum below is
+// reduce_tables_body's loop, the formulas are gn_fwd_tables_kernel's / gn_bwd_tables_kernel's of
+// graphnorm.hip): the same bits out of 2 launches per layer and direction.
+__device__ __forceinline__ double sliced_col_sum(const double* __restrict__ partial, int ntab, int len,
+                                                 int col, bool valid, double (*sl)[17]) {
+  const int cl = threadIdx.x & 15, slice = threadIdx.x >> 4;
+  double acc = 0;
+  if (valid) {
+    const int per = (ntab + 63) / 64;
+    const int lo = slice * per, hi = (lo + per < ntab) ? lo + per : ntab;
+    int k = lo;
+    for (; k + 4 <= hi; k += 4) {
+      const double a0 = partial[(size_t)k * len + col], a1 = partial[(size_t)(k + 1) * len + col];
+      const double a2 = partial[(size_t)(k + 2) * len + col], a3 = partial[(size_t)(k + 3) * len + col];
+      acc += a0; acc += a1; acc += a2; acc += a3;
+    }
+    for (; k < hi; ++k) acc += partial[(size_t)k * len + col];
+  }
+  __syncthreads();                                           // (the previous use of sl is over)
+  sl[slice][cl] = acc;
+  __syncthreads();
+  double t = 0;
+#pragma unroll
+  for (int k = 0; k < 64; ++k) t += sl[k][cl];               // fixed order: deterministic
+  return t;
+}
+
+// forward: per-graph totals [2N + 1] of the layer's output AND the tables of its GraphNorm.
+// grid (ceil(N / 16), num_graphs), 1024 threads = 16 channels x 64 slices.
+__global__ __launch_bounds__(1024) void fwd_post_kernel(const double* __restrict__ partial,
+                                                        FmlpGroups grp, int N,
+                                                        double* __restrict__ total,
+                                                        spt_gn_fwd_tables t) {
+  __shared__ double sl[64][17];
+  const int b = blockIdx.y, cl = threadIdx.x & 15, slice = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl, len = 2 * N + 1;
+  const bool cv = c < N;
+  const double* pb = partial + (size_t)grp.start[b] * len;
+  const int ntab = grp.count[b];
+  const double s1 = sliced_col_sum(pb, ntab, len, cv ? c : 0, cv, sl);
+  const double s2 = sliced_col_sum(pb, ntab, len, cv ? N + c : 0, cv, sl);
+  const double cnt = sliced_col_sum(pb, ntab, len, 2 * N, true, sl);
+  if (slice != 0) return;
+  if (total) {
+    double* tr = total + (size_t)b * len;
+    if (cv) {
+      tr[c] = s1;
+      tr[N + c] = s2;
+    }
+    if (blockIdx.x == 0 && cl == 0) tr[2 * N] = cnt;
+  }
+  if (!cv) return;
+  double n = cnt;
+  if (n < 1.0) n = 1.0;                       // scatter_mean: clamp(count, 1)
+  const double mu = s1 / n;
+  const double a = (double)t.mean_scale[c];
+  double var = s2 / n - (2.0 * a - a * a) * mu * mu;
+  if (var < 0.0) var = 0.0;
+  const double rs = 1.0 / sqrt(var + (double)t.eps);
+  const float mu32 = (float)mu, rs32 = (float)rs;
+  const int o = b * N + c;
+  t.mean[o] = mu32;
+  t.rstd[o] = rs32;
+  t.am[o] = (float)(a * (double)mu32);
+  t.scale[o] = (float)((double)t.weight[c] * (double)rs32);
+}
+
+// backward: blocks [0, nA) sum the weight-gradient partials (reduce_tables_kernel<float>); the
+// blocks behind them the statistics of the PREVIOUS layer's GraphNorm backward - plain totals
+// (`pn.c1 == nullptr`: (2K + 1 + 15) / 16 blocks per graph, as reduce_tables_groups_kernel), or 16
+// channels per block over all graphs with that norm's backward tables written on the spot.
+__global__ __launch_bounds__(1024) void bwd_post_kernel(const float* __restrict__ gwp, int ntab_w,
+                                                        int NK, float* __restrict__ gW, int accumulate,
+                                                        int nA, const double* __restrict__ pst,
+                                                        FmlpGroups grp, int K, int B,
+                                                        double* __restrict__ prev_total,
+                                                        spt_gn_bwd_tables pn) {
+  if ((int)blockIdx.x < nA) {
+    reduce_tables_body<float>(gwp, ntab_w, NK, gW, accumulate, (int)blockIdx.x);
+    return;
+  }
+  const int bx = (int)blockIdx.x - nA, len = 2 * K + 1;
+  if (!pn.c1) {
+    const int per_graph = (len + 15) / 16;
+    const int b = bx / per_graph;
+    reduce_tables_body<double>(pst + (size_t)grp.start[b] * len, grp.count[b], len,
+                               prev_total + (size_t)b * len, 0, bx - b * per_graph);
+    return;
+  }
+  __shared__ double sl[64][17];
+  const int cl = threadIdx.x & 15, slice = threadIdx.x >> 4;
+  const int c = bx * 16 + cl;
+  const bool cv = c < K;
+  const double w = cv ? (double)pn.weight[c] : 0.0, a = cv ? (double)pn.mean_scale[c] : 0.0;
+  double gw = 0.0, gb = 0.0, ga = 0.0;
+  for (int b = 0; b < B; ++b) {
+    const double* pb = pst + (size_t)grp.start[b] * len;
+    const int ntab = grp.count[b];
+    const double A = sliced_col_sum(pb, ntab, len, cv ? c : 0, cv, sl);
+    const double GO = sliced_col_sum(pb, ntab, len, cv ? K + c : 0, cv, sl);
+    const double cnt = sliced_col_sum(pb, ntab, len, 2 * K, true, sl);
+    if (slice != 0) continue;
+    if (prev_total) {
+      double* tr = prev_total + (size_t)b * len;
+      if (cv) {
+        tr[c] = A;
+        tr[K + c] = GO;
+      }
+      if (bx == 0 && cl == 0) tr[2 * K] = cnt;
+    }
+    if (!cv) continue;
+    double n = cnt;
+    if (n < 1.0) n = 1.0;
+    const double sd = (double)pn.rstd[b * K + c], mu = (double)pn.mean[b * K + c];
+    const double k2 = w * sd * sd * sd * GO / n;
+    const double sumdo = w * sd * A - k2 * n * mu * (1.0 - a);
+    pn.c1[b * K + c] = (float)(w * sd);
+    pn.c2[b * K + c] = (float)k2;
+    pn.c3[b * K + c] = (float)(a * sumdo / n);
+    gw += sd * GO;
+    gb += A;
+    ga += -mu * sumdo;
+  }
+  if (slice == 0 && cv) {
+    pn.gweight[c] = (float)gw;
+    pn.gbias[c] = (float)gb;
+    pn.gmean_scale[c] = (float)ga;
+  }
+}
+
+static void bwd_post_launch(const float* gwp, int ntab_w, int NK, float* gW, int accumulate,
+                            const double* pst, const FmlpGroups& grp, int K, int B,
+                            double* prev_total, const spt_gn_bwd_tables* pn, hipStream_t stream) {
+  const int nA = (NK + 15) / 16;
+  spt_gn_bwd_tables none = {};
+  int nB = 0;
+  if (pn && pn->c1) nB = (K + 15) / 16;
+  else if (prev_total) nB = ((2 * K + 1 + 15) / 16) * B;
+  bwd_post_kernel<<<nA + nB, 1024, 0, stream>>>(gwp, ntab_w, NK, gW, accumulate, nA, pst, grp, K, B,
+                                                prev_total, (pn && pn->c1) ? *pn : none);
 }
 
 static int grid_for_nw(int64_t rows, int per_cu, int nwv) {
@@ -1415,12 +1562,24 @@ static FmlpGroups fmlp_groups(const FmlpRuns& rt, int num_graphs, int per_run) {
 static int fmlp_fwd_impl(const char* fn, const float* x, const FmlpRuns& rt, int64_t max_rows,
                          int num_graphs, int K, const float* W, int N, const float* pre_am,
                          const float* pre_scale, const float* pre_bias, float pre_slope, float* h,
-                         double* total, int mode, void* ws, size_t ws_bytes, hipStream_t stream) {
+                         double* total, int mode, void* ws, size_t ws_bytes, hipStream_t stream,
+                         const spt_gn_fwd_tables* norm = nullptr) {
   const int g_fmlp_mode = fmlp_mode_of(mode);   // shadows the process default inside this call
   (void)fn;
   SPT_CHECK_ARG(K >= 1 && N >= 16, "bad shape");
   SPT_CHECK_ARG(spt_fused_linear_supported(K, N), "(K, N) not built");
-  SPT_CHECK_ARG(x && W && h && total && ws, "null pointer");
+  SPT_CHECK_ARG(x && W && h && (total || norm) && ws, "null pointer");
+  SPT_CHECK_ARG(!norm || (norm->weight && norm->mean_scale && norm->mean && norm->rstd && norm->am &&
+                          norm->scale), "incomplete norm tables");
+  // the per-graph totals, or (norm) totals + the GraphNorm's forward tables, in one launch
+  auto post = [&](const double* partial_, int gx__) {
+    if (norm)
+      fwd_post_kernel<<<dim3((N + 15) / 16, num_graphs), 1024, 0, stream>>>(
+          partial_, fmlp_groups(rt, num_graphs, gx__), N, total, *norm);
+    else
+      reduce_tables_groups_kernel<double><<<dim3((2 * N + 1 + 15) / 16, num_graphs), 1024, 0, stream>>>(
+          partial_, fmlp_groups(rt, num_graphs, gx__), 2 * N + 1, total);
+  };
   SPT_CHECK_ARG(ws_bytes >= spt_fused_linear_workspace_bytes(K, N), "workspace too small");
   SPT_CHECK_ARG(!pre_am || (pre_scale && pre_bias), "incomplete pre-normalisation tables");
   const int k4 = (K + 3) / 4, nbk = N / 16;
@@ -1459,8 +1618,7 @@ static int fmlp_fwd_impl(const char* fn, const float* x, const FmlpRuns& rt, int
   }
     SPT_FMLP_ST_SHAPES(XS)
 #undef XS
-    reduce_tables_groups_kernel<double><<<dim3((2 * N + 1 + 15) / 16, num_graphs), 1024, 0, stream>>>(
-        partial, fmlp_groups(rt, num_graphs, gx_), 2 * N + 1, total);
+    post(partial, gx_);
     SPT_CHECK_LAUNCH();
     return 0;
   }
@@ -1481,8 +1639,7 @@ static int fmlp_fwd_impl(const char* fn, const float* x, const FmlpRuns& rt, int
   }
   SPT_FMLP_SHAPES(X)
 #undef X
-  reduce_tables_groups_kernel<double><<<dim3((2 * N + 1 + 15) / 16, num_graphs), 1024, 0, stream>>>(
-      partial, fmlp_groups(rt, num_graphs, gx_), 2 * N + 1, total);
+  post(partial, gx_);
   SPT_CHECK_LAUNCH();
   return 0;
 }
@@ -1524,6 +1681,23 @@ extern "C" int spt_fused_linear_fwd_runs_f32(const float* x, int nruns, const in
   return fmlp_fwd_impl(__func__, x, rt, max_rows, num_graphs, K, W, N, pre_am, pre_scale, pre_bias,
                        pre_slope, h, total, mode, ws, ws_bytes, (hipStream_t)stream_);
 }
+// ... and the forward tables of the layer's GraphNorm written by the same call (round 6: the
+// totals' sum and spt_graphnorm_tables_f32 in one launch; `total` may be NULL then).
+extern "C" int spt_fused_linear_fwd_runs_gn_f32(const float* x, int nruns, const int64_t* run_r0,
+                                                const int64_t* run_r1, const int32_t* run_graph,
+                                                int num_graphs, int K, const float* W, int N,
+                                                const float* pre_am, const float* pre_scale,
+                                                const float* pre_bias, float pre_slope, float* h,
+                                                double* total, int mode, void* ws, size_t ws_bytes,
+                                                const spt_gn_fwd_tables* norm, spt_stream_t stream_) {
+  FmlpRuns rt;
+  int64_t max_rows;
+  const char* err = fmlp_make_runs(nruns, run_r0, run_r1, run_graph, num_graphs, &rt, &max_rows);
+  SPT_CHECK_ARG(!err, err ? err : "");
+  SPT_CHECK_ARG(norm, "null norm descriptor");
+  return fmlp_fwd_impl(__func__, x, rt, max_rows, num_graphs, K, W, N, pre_am, pre_scale, pre_bias,
+                       pre_slope, h, total, mode, ws, ws_bytes, (hipStream_t)stream_, norm);
+}
 
 static int fmlp_bwd_impl(bool pooled, const float* gy, const float* gout, const int32_t* arg,
                          const int32_t* perm, const int32_t* pos_seg, const float* h,
@@ -1533,9 +1707,16 @@ static int fmlp_bwd_impl(bool pooled, const float* gy, const float* gout, const 
                          int K, const float* pre_am, const float* pre_scale, const float* pre_bias,
                          float pre_slope, const float* W, float* gx, float* gW, int accumulate,
                          double* prev_total, int mode, void* ws, size_t ws_bytes,
-                         hipStream_t stream) {
+                         hipStream_t stream, const spt_gn_bwd_tables* prev_norm = nullptr) {
   const int g_fmlp_mode = fmlp_mode_of(mode);
   const bool g_fmlp_split_bf16 = g_fmlp_mode >= 1;
+  // (prev_norm: the previous layer's backward tables are written by this call's post launch; its
+  // statistics are then needed whether or not the caller wants the totals themselves)
+  const bool want_prev = prev_total || prev_norm;
+  SPT_CHECK_ARG(!prev_norm || (prev_norm->weight && prev_norm->mean_scale && prev_norm->mean &&
+                               prev_norm->rstd && prev_norm->c1 && prev_norm->c2 && prev_norm->c3 &&
+                               prev_norm->gweight && prev_norm->gbias && prev_norm->gmean_scale),
+                "incomplete norm tables");
   SPT_CHECK_ARG(K >= 1 && N >= 16, "bad shape");
   SPT_CHECK_ARG(h && am && scale && bias && c1 && c2 && c3 && xprev && W && gW && ws, "null pointer");
   SPT_CHECK_ARG(ws_bytes >= spt_fused_linear_workspace_bytes(K, N), "workspace too small");
@@ -1543,17 +1724,17 @@ static int fmlp_bwd_impl(bool pooled, const float* gy, const float* gout, const 
     SPT_CHECK_ARG(spt_fused_linear_pooled_supported_ex(K, N, g_fmlp_mode),
                   "(K, N) has no pooled kernel in this matrix mode");
     SPT_CHECK_ARG(gout && arg && perm && pos_seg && gx, "null pointer");
-    SPT_CHECK_ARG(!prev_total || pre_am, "previous-layer statistics need its tables");
+    SPT_CHECK_ARG(!want_prev || pre_am, "previous-layer statistics need its tables");
   } else {
     SPT_CHECK_ARG(spt_fused_linear_supported(K, N), "(K, N) not built");
     SPT_CHECK_ARG(gy, "null pointer");
-    SPT_CHECK_ARG(!prev_total || (gx && pre_am), "previous-layer statistics need gx and its tables");
+    SPT_CHECK_ARG(!want_prev || (gx && pre_am), "previous-layer statistics need gx and its tables");
   }
   const int k4 = (K + 3) / 4, nbk = N / 16;
   int gx_ = 1, nwv = 1;                        // blocks per run, waves per block
   float* gwp = (float*)ws;
   double* pst = (double*)((char*)ws + align_up((size_t)MAX_BWD_WAVES * N * K * 4, 256));
-  double* pstp = prev_total ? pst : nullptr;
+  double* pstp = want_prev ? pst : nullptr;
   const int nr = rt.n;
   auto cap_grid = [&](int g_, int nw_) {       // every run's waves own a record of the partial tables
     const int cap = MAX_BWD_WAVES / (nw_ * nr);
@@ -1691,11 +1872,11 @@ static int fmlp_bwd_impl(bool pooled, const float* gy, const float* gout, const 
 #undef X
 #undef XP
   SPT_CHECK_ARG(per_run > 0, "no kernel for this shape");
-  reduce_tables_kernel<float><<<(N * K + 15) / 16, 1024, 0, stream>>>(gwp, per_run * nr, N * K, gW,
-                                                                     accumulate);
-  if (prev_total)
-    reduce_tables_groups_kernel<double><<<dim3((2 * K + 1 + 15) / 16, num_graphs), 1024, 0, stream>>>(
-        pst, fmlp_groups(rt, num_graphs, per_run), 2 * K + 1, prev_total);
+  // ONE post launch: the weight gradient's sum, the previous layer's statistics and - prev_norm -
+  // that layer's backward tables (they were three launches: two here, gn_bwd_tables_kernel behind
+  // a second C entry)
+  bwd_post_launch(gwp, per_run * nr, N * K, gW, accumulate, pst, fmlp_groups(rt, num_graphs, per_run), K,
+                  num_graphs, prev_total, prev_norm, stream);
   SPT_CHECK_LAUNCH();
   return 0;
 }
@@ -1746,6 +1927,26 @@ extern "C" int spt_fused_linear_bwd_pooled_runs_f32(
   return fmlp_bwd_impl(true, nullptr, gout, arg, perm, pos_seg, h, rt, max_rows, num_graphs, N, am,
                        scale, bias, slope, c1, c2, c3, xprev, K, pre_am, pre_scale, pre_bias,
                        pre_slope, W, gx, gW, 0, prev_total, mode, ws, ws_bytes, (hipStream_t)stream_);
+}
+// ... with the PREVIOUS layer's GraphNorm-backward tables written by the same call (round 6:
+// spt_graphnorm_bwd_tables_f32 folded into the post launch; prev_total may be NULL then).
+extern "C" int spt_fused_linear_bwd_pooled_runs_gn_f32(
+    const float* gout, const int32_t* arg, const int32_t* perm, const int32_t* pos_seg,
+    const float* h, int nruns, const int64_t* run_p0, const int64_t* run_p1,
+    const int32_t* run_graph, int num_graphs, int N, const float* am, const float* scale,
+    const float* bias, float slope, const float* c1, const float* c2, const float* c3,
+    const float* xprev, int K, const float* pre_am, const float* pre_scale, const float* pre_bias,
+    float pre_slope, const float* W, float* gx, float* gW, double* prev_total, int mode, void* ws,
+    size_t ws_bytes, const spt_gn_bwd_tables* prev_norm, spt_stream_t stream_) {
+  FmlpRuns rt;
+  int64_t max_rows;
+  const char* err = fmlp_make_runs(nruns, run_p0, run_p1, run_graph, num_graphs, &rt, &max_rows);
+  SPT_CHECK_ARG(!err, err ? err : "");
+  SPT_CHECK_ARG(prev_norm, "null norm descriptor");
+  return fmlp_bwd_impl(true, nullptr, gout, arg, perm, pos_seg, h, rt, max_rows, num_graphs, N, am,
+                       scale, bias, slope, c1, c2, c3, xprev, K, pre_am, pre_scale, pre_bias,
+                       pre_slope, W, gx, gW, 0, prev_total, mode, ws, ws_bytes, (hipStream_t)stream_,
+                       prev_norm);
 }
 
 // Backward of one layer over the rows [r0, r1) of one graph.
@@ -1798,6 +1999,23 @@ extern "C" int spt_fused_linear_bwd_runs_f32(
   return fmlp_bwd_impl(false, gy, nullptr, nullptr, nullptr, nullptr, h, rt, max_rows, num_graphs, N,
                        am, scale, bias, slope, c1, c2, c3, xprev, K, pre_am, pre_scale, pre_bias,
                        pre_slope, W, gx, gW, 0, prev_total, mode, ws, ws_bytes, (hipStream_t)stream_);
+}
+extern "C" int spt_fused_linear_bwd_runs_gn_f32(
+    const float* gy, const float* h, int nruns, const int64_t* run_r0, const int64_t* run_r1,
+    const int32_t* run_graph, int num_graphs, int N, const float* am, const float* scale,
+    const float* bias, float slope, const float* c1, const float* c2, const float* c3,
+    const float* xprev, int K, const float* pre_am, const float* pre_scale, const float* pre_bias,
+    float pre_slope, const float* W, float* gx, float* gW, double* prev_total, int mode, void* ws,
+    size_t ws_bytes, const spt_gn_bwd_tables* prev_norm, spt_stream_t stream_) {
+  FmlpRuns rt;
+  int64_t max_rows;
+  const char* err = fmlp_make_runs(nruns, run_r0, run_r1, run_graph, num_graphs, &rt, &max_rows);
+  SPT_CHECK_ARG(!err, err ? err : "");
+  SPT_CHECK_ARG(prev_norm, "null norm descriptor");
+  return fmlp_bwd_impl(false, gy, nullptr, nullptr, nullptr, nullptr, h, rt, max_rows, num_graphs, N,
+                       am, scale, bias, slope, c1, c2, c3, xprev, K, pre_am, pre_scale, pre_bias,
+                       pre_slope, W, gx, gW, 0, prev_total, mode, ws, ws_bytes, (hipStream_t)stream_,
+                       prev_norm);
 }
 
 // ---- the top layer fused with the max-pool behind it (fused_pool.hip) -----------------------------
@@ -1890,7 +2108,7 @@ extern "C" int spt_fused_linear_fwd_pool_runs_f32(
   return 0;
 }
 
-extern "C" int spt_fused_linear_bwd_pool_runs_f32(
+static int fpool_bwd_entry(
     const float* gout, const float* raw, const int32_t* argpos, const int32_t* perm,
     const int32_t* pos_seg, const int64_t* seg_graph, int64_t num_seg, int nruns,
     const int64_t* run_p0, const int64_t* run_p1, const int32_t* run_graph, int num_graphs, int N,
@@ -1898,7 +2116,7 @@ extern "C" int spt_fused_linear_bwd_pool_runs_f32(
     const float* c2, const float* c3, const void* xprev, int K, const float* pre_am,
     const float* pre_scale, const float* pre_bias, float pre_slope, const float* W,
     const double* gram, float* gm, float* gx, float* gW, double* prev_total, int mode, void* ws,
-    size_t ws_bytes, spt_stream_t stream_) {
+    size_t ws_bytes, spt_stream_t stream_, const spt_gn_bwd_tables* prev_norm) {
   hipStream_t stream = (hipStream_t)stream_;
   FmlpRuns rt;
   int64_t max_rows;
@@ -1909,7 +2127,7 @@ extern "C" int spt_fused_linear_bwd_pool_runs_f32(
   SPT_CHECK_ARG(fpool_supported(K, N) && prec != 0 && (!x16 || prec == 1),
                 "(K, N) has no pool-fused kernel in this matrix mode");
   SPT_CHECK_ARG(gout && raw && argpos && pos_seg && am && scale && bias && c1 && c2 && c3 && xprev &&
-                pre_am && pre_scale && pre_bias && W && gram && gm && gx && gW && prev_total && ws,
+                pre_am && pre_scale && pre_bias && W && gram && gm && gx && gW && (prev_total || prev_norm) && ws,
                 "null pointer");
   SPT_CHECK_ARG(num_seg >= 0 && (num_graphs == 1 || seg_graph), "bad shape");
   SPT_CHECK_ARG(ws_bytes >= spt_fused_linear_pool_workspace_bytes(K, N), "workspace too small");
@@ -1922,10 +2140,37 @@ extern "C" int spt_fused_linear_bwd_pool_runs_f32(
                                        (const float*)xprev, pre_am, pre_scale, pre_bias, pre_slope, W, gm,
                                        Mbuf, c0buf, gx, gwp, pst, MAX_BWD_WAVES, stream);
   SPT_CHECK_ARG(per_run > 0, "no kernel for this variant");
-  reduce_tables_kernel<float><<<(N * K + 15) / 16, 1024, 0, stream>>>(gwp, per_run * rt.n, N * K, gW, 0);
-  reduce_tables_groups_kernel<double><<<dim3((2 * K + 1 + 15) / 16, num_graphs), 1024, 0, stream>>>(
-      pst, fmlp_groups(rt, num_graphs, per_run), 2 * K + 1, prev_total);
+  bwd_post_launch(gwp, per_run * rt.n, N * K, gW, 0, pst, fmlp_groups(rt, num_graphs, per_run), K,
+                  num_graphs, prev_total, prev_norm, stream);
   fpool_gw_dense_launch(K, gram, num_graphs, W, N, prec == 1, am, c2, c3, gW, stream);
   SPT_CHECK_LAUNCH();
   return 0;
+}
+extern "C" int spt_fused_linear_bwd_pool_runs_f32(
+    const float* gout, const float* raw, const int32_t* argpos, const int32_t* perm,
+    const int32_t* pos_seg, const int64_t* seg_graph, int64_t num_seg, int nruns,
+    const int64_t* run_p0, const int64_t* run_p1, const int32_t* run_graph, int num_graphs, int N,
+    const float* am, const float* scale, const float* bias, float slope, const float* c1,
+    const float* c2, const float* c3, const void* xprev, int K, const float* pre_am,
+    const float* pre_scale, const float* pre_bias, float pre_slope, const float* W,
+    const double* gram, float* gm, float* gx, float* gW, double* prev_total, int mode, void* ws,
+    size_t ws_bytes, spt_stream_t stream_) {
+  return fpool_bwd_entry(gout, raw, argpos, perm, pos_seg, seg_graph, num_seg, nruns, run_p0, run_p1, run_graph,
+                         num_graphs, N, am, scale, bias, slope, c1, c2, c3, xprev, K, pre_am, pre_scale,
+                         pre_bias, pre_slope, W, gram, gm, gx, gW, prev_total, mode, ws, ws_bytes, stream_, nullptr);
+}
+// ... with the PREVIOUS layer's GraphNorm-backward tables written by the post launch (round 6)
+extern "C" int spt_fused_linear_bwd_pool_runs_gn_f32(
+    const float* gout, const float* raw, const int32_t* argpos, const int32_t* perm,
+    const int32_t* pos_seg, const int64_t* seg_graph, int64_t num_seg, int nruns,
+    const int64_t* run_p0, const int64_t* run_p1, const int32_t* run_graph, int num_graphs, int N,
+    const float* am, const float* scale, const float* bias, float slope, const float* c1,
+    const float* c2, const float* c3, const void* xprev, int K, const float* pre_am,
+    const float* pre_scale, const float* pre_bias, float pre_slope, const float* W,
+    const double* gram, float* gm, float* gx, float* gW, double* prev_total, int mode, void* ws,
+    size_t ws_bytes, const spt_gn_bwd_tables* prev_norm, spt_stream_t stream_) {
+  SPT_CHECK_ARG(prev_norm, "null norm descriptor");
+  return fpool_bwd_entry(gout, raw, argpos, perm, pos_seg, seg_graph, num_seg, nruns, run_p0, run_p1, run_graph,
+                         num_graphs, N, am, scale, bias, slope, c1, c2, c3, xprev, K, pre_am, pre_scale,
+                         pre_bias, pre_slope, W, gram, gm, gx, gW, prev_total, mode, ws, ws_bytes, stream_, prev_norm);
 }

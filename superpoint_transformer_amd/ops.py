@@ -3,6 +3,7 @@
 Every function here launches a kernel of libspt_hip.so on torch's current
 stream; there is no eager-PyTorch path.
 """
+import ctypes
 import os
 
 import torch
@@ -1456,19 +1457,31 @@ def _fmlp_forward(x, batch, runs, eps_list, slope_list, params, apply_last=True,
             pa = ps = pb = None
             if pre is not None:
                 pa, ps, pb = pre
-            with _timed(f"fused_linear_fwd:{K}x{N}:{R}"):
-                st = _lib.lib.spt_fused_linear_fwd_runs_f32(
-                    _lib.ptr(cur), nr, c_r0, c_r1, c_g, B, K, _lib.ptr(Ws[l]), N,
-                    _lib.ptr(pa), _lib.ptr(ps), _lib.ptr(pb),
-                    float(slope_list[l - 1]) if l else 1.0, _lib.ptr(h),
-                    _lib.ptr(total), lmode, _lib.ptr(ws), ws.numel(), sp)
-            _lib.check(st, "spt_fused_linear_fwd_runs_f32")
             mean = torch.empty((B, N), dtype=torch.float32, device=dev)
             rstd, am, sc = (torch.empty_like(mean) for _ in range(3))
-            st = _lib.lib.spt_graphnorm_tables_f32(
-                _lib.ptr(total), B, N, _lib.ptr(gnw[l]), _lib.ptr(gms[l]), float(eps_list[l]),
-                _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(am), _lib.ptr(sc), sp)
-            _lib.check(st, "spt_graphnorm_tables_f32")
+            if FUSE_POST:
+                # the layer's totals AND its norm's tables out of one post launch
+                norm = _lib.GnFwdTables(_lib.ptr(gnw[l]), _lib.ptr(gms[l]), float(eps_list[l]),
+                                        _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(am), _lib.ptr(sc))
+                with _timed(f"fused_linear_fwd:{K}x{N}:{R}"):
+                    st = _lib.lib.spt_fused_linear_fwd_runs_gn_f32(
+                        _lib.ptr(cur), nr, c_r0, c_r1, c_g, B, K, _lib.ptr(Ws[l]), N,
+                        _lib.ptr(pa), _lib.ptr(ps), _lib.ptr(pb),
+                        float(slope_list[l - 1]) if l else 1.0, _lib.ptr(h),
+                        _lib.ptr(total), lmode, _lib.ptr(ws), ws.numel(), ctypes.addressof(norm), sp)
+                _lib.check(st, "spt_fused_linear_fwd_runs_gn_f32")
+            else:
+                with _timed(f"fused_linear_fwd:{K}x{N}:{R}"):
+                    st = _lib.lib.spt_fused_linear_fwd_runs_f32(
+                        _lib.ptr(cur), nr, c_r0, c_r1, c_g, B, K, _lib.ptr(Ws[l]), N,
+                        _lib.ptr(pa), _lib.ptr(ps), _lib.ptr(pb),
+                        float(slope_list[l - 1]) if l else 1.0, _lib.ptr(h),
+                        _lib.ptr(total), lmode, _lib.ptr(ws), ws.numel(), sp)
+                _lib.check(st, "spt_fused_linear_fwd_runs_f32")
+                st = _lib.lib.spt_graphnorm_tables_f32(
+                    _lib.ptr(total), B, N, _lib.ptr(gnw[l]), _lib.ptr(gms[l]), float(eps_list[l]),
+                    _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(am), _lib.ptr(sc), sp)
+                _lib.check(st, "spt_graphnorm_tables_f32")
             hs.append(h)
             tabs.append((mean, rstd, am, sc))
             cur, pre = h, (am, sc, gnb[l])
@@ -1485,7 +1498,21 @@ def _fmlp_forward(x, batch, runs, eps_list, slope_list, params, apply_last=True,
     return y, saved, hs[-1], (tabs[-1][2], tabs[-1][3], gnb[-1])
 
 
-def _fmlp_backward(saved, meta, gy, top_total=None, pooled=None):
+# Round 6: a fused layer's table sums and the GraphNorm table kernel that consumes them as ONE post
+# launch (spt_fused_linear_*_gn_f32: 2 launches per layer and direction instead of 3 / 4; the same
+# sums in the same order, the same formulas - tests pin the two routes on each other bitwise).
+FUSE_POST = os.environ.get("SPT_FUSE_POST", "1") != "0"
+
+
+def fuse_post(on=None):
+    global FUSE_POST
+    old = FUSE_POST
+    if on is not None:
+        FUSE_POST = bool(on)
+    return old
+
+
+def _fmlp_backward(saved, meta, gy, top_total=None, pooled=None, top_tabs=None):
     """Backward of the fused layer chain from the gradient of its (normalised) output.
     ``top_total``: statistics of the top GraphNorm's backward when the caller already has
     them (the max-pool route computes them from the pool's sparse gradient).
@@ -1512,7 +1539,9 @@ def _fmlp_backward(saved, meta, gy, top_total=None, pooled=None):
         # statistics of the top GraphNorm's backward need their own pass over (h_L, gy)
         N = Ws[-1].shape[0]
         mean, rstd, am, sc = tabs[-1]
-        if top_total is not None:
+        if top_tabs is not None:
+            total = None                 # the caller's post launch already wrote the top norm's tables
+        elif top_total is not None:
             total = top_total
         else:
             assert not store16, "bf16 storage: the top statistics come from the sparse route"
@@ -1523,22 +1552,35 @@ def _fmlp_backward(saved, meta, gy, top_total=None, pooled=None):
                 _lib.ptr(am), _lib.ptr(sc), _lib.ptr(gnb[-1]), float(slopes[-1]), _lib.ptr(total),
                 _lib.ptr(ws), ws.numel(), sp)
             _lib.check(st, "spt_graphnorm_bwd_stats_f32")
+        cur_tabs = top_tabs
         for l in range(L - 1, -1, -1):
             N, K = Ws[l].shape
             mean, rstd, am, sc = tabs[l]
-            c1, c2, c3 = (torch.empty((B, N), dtype=torch.float32, device=dev) for _ in range(3))
-            gw_n, gb_n, ga_n = (torch.empty(N, dtype=torch.float32, device=dev) for _ in range(3))
-            st = _lib.lib.spt_graphnorm_bwd_tables_f32(
-                _lib.ptr(total), B, N, _lib.ptr(gnw[l]), _lib.ptr(gms[l]), _lib.ptr(mean),
-                _lib.ptr(rstd), _lib.ptr(c1), _lib.ptr(c2), _lib.ptr(c3), _lib.ptr(gw_n),
-                _lib.ptr(gb_n), _lib.ptr(ga_n), sp)
-            _lib.check(st, "spt_graphnorm_bwd_tables_f32")
+            if cur_tabs is not None:
+                c1, c2, c3, gw_n, gb_n, ga_n = cur_tabs
+            else:
+                c1, c2, c3 = (torch.empty((B, N), dtype=torch.float32, device=dev) for _ in range(3))
+                gw_n, gb_n, ga_n = (torch.empty(N, dtype=torch.float32, device=dev) for _ in range(3))
+                st = _lib.lib.spt_graphnorm_bwd_tables_f32(
+                    _lib.ptr(total), B, N, _lib.ptr(gnw[l]), _lib.ptr(gms[l]), _lib.ptr(mean),
+                    _lib.ptr(rstd), _lib.ptr(c1), _lib.ptr(c2), _lib.ptr(c3), _lib.ptr(gw_n),
+                    _lib.ptr(gb_n), _lib.ptr(ga_n), sp)
+                _lib.check(st, "spt_graphnorm_bwd_tables_f32")
             xprev = hs[l - 1] if l else x2
             pre = tabs[l - 1] if l else None
             want_gx = l > 0 or need_gx0
             gx = torch.empty((R, K), dtype=torch.float32, device=dev) if want_gx else None
             gW = torch.empty((N, K), dtype=torch.float32, device=dev)
-            ptot = torch.empty((B, 2 * K + 1), dtype=torch.float64, device=dev) if l else None
+            # the previous layer's backward tables: written by THIS call's post launch (FUSE_POST),
+            # or by the next iteration's table call from the totals this call leaves
+            nxt_tabs, pn = None, None
+            if l and FUSE_POST:
+                nxt_tabs = (*(torch.empty((B, K), dtype=torch.float32, device=dev) for _ in range(3)),
+                            *(torch.empty(K, dtype=torch.float32, device=dev) for _ in range(3)))
+                pn = _lib.GnBwdTables(_lib.ptr(gnw[l - 1]), _lib.ptr(gms[l - 1]), _lib.ptr(tabs[l - 1][0]),
+                                      _lib.ptr(tabs[l - 1][1]), *[_lib.ptr(t) for t in nxt_tabs])
+            ptot = (torch.empty((B, 2 * K + 1), dtype=torch.float64, device=dev)
+                    if (l and pn is None) else None)
             ws = _workspace(_lib.lib.spt_fused_linear_workspace_bytes(K, N), dev)
             pa = ps = pb = None
             if pre is not None:
@@ -1546,28 +1588,34 @@ def _fmlp_backward(saved, meta, gy, top_total=None, pooled=None):
             lmode = (3 | _ST_H | (_ST_X if l else 0)) if store16 else fmode
             if pooled is not None and l == L - 1:
                 p_gout, p_arg, p_csr = pooled
-                with _timed(f"fused_linear_bwd_pooled:{K}x{N}:{R}"):
-                    st = _lib.lib.spt_fused_linear_bwd_pooled_runs_f32(
-                        _lib.ptr(p_gout), _lib.ptr(p_arg), _lib.ptr(p_csr.perm),
+                args = (_lib.ptr(p_gout), _lib.ptr(p_arg), _lib.ptr(p_csr.perm),
                         _lib.ptr(p_csr.pos_seg()), _lib.ptr(hs[l]), nr, c_r0, c_r1, c_g, B, N,
                         _lib.ptr(am), _lib.ptr(sc), _lib.ptr(gnb[l]), float(slopes[l]),
                         _lib.ptr(c1), _lib.ptr(c2), _lib.ptr(c3), _lib.ptr(xprev), K,
                         _lib.ptr(pa), _lib.ptr(ps), _lib.ptr(pb),
                         float(slopes[l - 1]) if l else 1.0, _lib.ptr(Ws[l]), _lib.ptr(gx),
-                        _lib.ptr(gW), _lib.ptr(ptot), lmode, _lib.ptr(ws), ws.numel(), sp)
+                        _lib.ptr(gW), _lib.ptr(ptot), lmode, _lib.ptr(ws), ws.numel())
+                with _timed(f"fused_linear_bwd_pooled:{K}x{N}:{R}"):
+                    if pn is not None:
+                        st = _lib.lib.spt_fused_linear_bwd_pooled_runs_gn_f32(*args, ctypes.addressof(pn), sp)
+                    else:
+                        st = _lib.lib.spt_fused_linear_bwd_pooled_runs_f32(*args, sp)
                 _lib.check(st, "spt_fused_linear_bwd_pooled_runs_f32")
             else:
-                st = _lib.lib.spt_fused_linear_bwd_runs_f32(
-                    _lib.ptr(g_cur), _lib.ptr(hs[l]), nr, c_r0, c_r1, c_g, B, N,
-                    _lib.ptr(am), _lib.ptr(sc), _lib.ptr(gnb[l]), float(slopes[l]),
-                    _lib.ptr(c1), _lib.ptr(c2), _lib.ptr(c3), _lib.ptr(xprev), K,
-                    _lib.ptr(pa), _lib.ptr(ps), _lib.ptr(pb),
-                    float(slopes[l - 1]) if l else 1.0, _lib.ptr(Ws[l]), _lib.ptr(gx),
-                    _lib.ptr(gW), _lib.ptr(ptot), lmode, _lib.ptr(ws), ws.numel(), sp)
+                args = (_lib.ptr(g_cur), _lib.ptr(hs[l]), nr, c_r0, c_r1, c_g, B, N,
+                        _lib.ptr(am), _lib.ptr(sc), _lib.ptr(gnb[l]), float(slopes[l]),
+                        _lib.ptr(c1), _lib.ptr(c2), _lib.ptr(c3), _lib.ptr(xprev), K,
+                        _lib.ptr(pa), _lib.ptr(ps), _lib.ptr(pb),
+                        float(slopes[l - 1]) if l else 1.0, _lib.ptr(Ws[l]), _lib.ptr(gx),
+                        _lib.ptr(gW), _lib.ptr(ptot), lmode, _lib.ptr(ws), ws.numel())
+                if pn is not None:
+                    st = _lib.lib.spt_fused_linear_bwd_runs_gn_f32(*args, ctypes.addressof(pn), sp)
+                else:
+                    st = _lib.lib.spt_fused_linear_bwd_runs_f32(*args, sp)
                 _lib.check(st, "spt_fused_linear_bwd_runs_f32")
             grads[4 * l], grads[4 * l + 1], grads[4 * l + 2], grads[4 * l + 3] = gW, gw_n, gb_n, ga_n
             if l:
-                g_cur, total = gx, ptot
+                g_cur, total, cur_tabs = gx, ptot, nxt_tabs
             else:
                 gx0 = gx
     return (None if gx0 is None else gx0.to(in_dtype)), grads
@@ -1768,23 +1816,37 @@ class _FusedMLPMaxPool(torch.autograd.Function):
             gm = torch.empty((S, N), dtype=torch.float32, device=dev)
             gx = torch.empty((R, K), dtype=torch.float32, device=dev)
             gW = torch.empty((N, K), dtype=torch.float32, device=dev)
-            ptot = torch.empty((B, 2 * K + 1), dtype=torch.float64, device=dev)
+            # the tables of the norm BELOW (layer L-2's backward) out of this call's post launch
+            Ls = L - 1
+            sub_tabs, pn, ptot = None, None, None
+            if FUSE_POST:
+                o = 2 + 5 * Ls
+                s_gnw, s_gms = saved_sub[o + Ls + Ls - 1], saved_sub[o + 3 * Ls + Ls - 1]
+                s_mean, s_rstd = saved_sub[2 + Ls + 4 * (Ls - 1)], saved_sub[2 + Ls + 4 * (Ls - 1) + 1]
+                sub_tabs = (*(torch.empty((B, K), dtype=torch.float32, device=dev) for _ in range(3)),
+                            *(torch.empty(K, dtype=torch.float32, device=dev) for _ in range(3)))
+                pn = _lib.GnBwdTables(_lib.ptr(s_gnw), _lib.ptr(s_gms), _lib.ptr(s_mean), _lib.ptr(s_rstd),
+                                      *[_lib.ptr(t) for t in sub_tabs])
+            else:
+                ptot = torch.empty((B, 2 * K + 1), dtype=torch.float64, device=dev)
             nb = _lib.lib.spt_fused_linear_pool_workspace_bytes(K, N)
             ws = _workspace(nb, dev)
-            with _timed(f"fused_linear_bwd_pool:{K}x{N}:{R}"):
-                st = _lib.lib.spt_fused_linear_bwd_pool_runs_f32(
-                    _lib.ptr(gout), _lib.ptr(raw), _lib.ptr(argpos), _lib.ptr(csr.perm),
+            args = (_lib.ptr(gout), _lib.ptr(raw), _lib.ptr(argpos), _lib.ptr(csr.perm),
                     _lib.ptr(csr.pos_seg()), _lib.ptr(ctx.seg_graph), S, nr, c_r0, c_r1, c_g, B, N,
                     _lib.ptr(am), _lib.ptr(sc), _lib.ptr(gnb), float(slopes[-1]), _lib.ptr(c1),
                     _lib.ptr(c2), _lib.ptr(c3), _lib.ptr(h_prev), K, _lib.ptr(pam), _lib.ptr(psc),
                     _lib.ptr(pbs), float(slopes[-2]), _lib.ptr(W), _lib.ptr(gram), _lib.ptr(gm),
-                    _lib.ptr(gx), _lib.ptr(gW), _lib.ptr(ptot), ctx.mode_top, _lib.ptr(ws),
-                    ws.numel(), sp)
+                    _lib.ptr(gx), _lib.ptr(gW), _lib.ptr(ptot), ctx.mode_top, _lib.ptr(ws), ws.numel())
+            with _timed(f"fused_linear_bwd_pool:{K}x{N}:{R}"):
+                if pn is not None:
+                    st = _lib.lib.spt_fused_linear_bwd_pool_runs_gn_f32(*args, ctypes.addressof(pn), sp)
+                else:
+                    st = _lib.lib.spt_fused_linear_bwd_pool_runs_f32(*args, sp)
             _lib.check(st, "spt_fused_linear_bwd_pool_runs_f32")
         # layers L-2 .. 0: the fused chain's own backward, entered with the gradient of its
-        # normalised output and the statistics of its top norm's backward
+        # normalised output and the statistics (or, FUSE_POST, the tables) of its top norm's backward
         meta_sub = (L - 1, runs, list(slopes[:L - 1]), in_dtype, need_gx0, fmode, store16)
-        gx0, grads = _fmlp_backward(saved_sub, meta_sub, gx, top_total=ptot)
+        gx0, grads = _fmlp_backward(saved_sub, meta_sub, gx, top_total=ptot, top_tabs=sub_tabs)
         grads = list(grads) + [gW, gw_n, gb_n, ga_n]
         return (gx0, None, None, None, None, None, None, *grads)
 

@@ -554,3 +554,63 @@ def test_fused_mlp_max_pool_with_and_without_the_raw_output(dev, materialised_po
     assert torch.allclose(gx1, gx0, rtol=1e-6, atol=1e-7 * float(gx0.abs().max()))
     for a, b in zip(gp1, gp0):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-6 * float(b.abs().max()))
+
+
+@pytest.mark.parametrize("dims,rows,B", [([12, 32, 64, 128], 40_001, 3), ([18, 32, 32], 60_000, -4),
+                                         ([132, 64, 64], 30_000, 1)])
+def test_post_launch_is_bitwise_the_separate_table_kernels(dims, rows, B, dev):
+    """Round 6: a fused layer's table sums and the GraphNorm table kernel behind them run as ONE
+    post launch (spt_fused_linear_*_gn_f32).  Same column sums in the same order, same formulas:
+    outputs, input gradient and every parameter gradient are bitwise those of the separate
+    kernels (ops.fuse_post(False)) - for the plain chain and for the pool-fused top layer."""
+    from superpoint_transformer_amd import nn as N, ops
+    g = torch.Generator().manual_seed(rows)
+    mlp = N.MLP(dims, norm=N.GraphNorm)
+    with torch.no_grad():
+        for p in mlp.parameters():
+            p.add_(0.1 * torch.randn(p.shape, generator=g))
+    x = torch.randn(rows, dims[0], generator=g)
+    if B < 0:
+        B = -B
+        cuts = [0, rows // 3 + 7, 2 * rows // 3 - 5, rows]
+        batch = torch.cat([torch.arange(b - a) * B // (b - a) for a, b in zip(cuts[:-1], cuts[1:])])
+        sorted_batch = False
+    else:
+        batch = (torch.arange(rows) * B // rows) if B > 1 else None
+        sorted_batch = True
+    gw = torch.randn(rows, dims[-1], generator=g)
+    nseg = 700
+    seg_graph = torch.arange(nseg) * B // nseg
+    si = torch.empty(rows, dtype=torch.long)
+    for b in range(B):
+        rmask = (batch == b) if batch is not None else torch.ones(rows, dtype=torch.bool)
+        segs = torch.nonzero(seg_graph == b).flatten()
+        si[rmask] = segs[torch.randint(0, segs.numel(), (int(rmask.sum()),), generator=g)]
+    gout = torch.randn(nseg, dims[-1], generator=g)
+
+    def run(fuse, pooled):
+        old = ops.fuse_post(fuse)
+        try:
+            m = copy.deepcopy(mlp).to(dev)
+            m.FUSE_MIN_ROWS = 0
+            xd = x.to(dev).requires_grad_()
+            bd = None if batch is None else batch.to(dev)
+            if pooled:
+                y = m.forward_max_pooled(xd, si.to(dev), nseg, batch=bd, batch_size=B,
+                                         seg_graph=seg_graph.to(dev) if B > 1 else None)
+                if y is None:
+                    return None
+                (y * gout.to(dev)).sum().backward()
+            else:
+                y = m(xd, batch=bd, batch_size=B)
+                (y * gw.to(dev)).sum().backward()
+            return [y.detach(), xd.grad] + [p.grad for p in m.parameters()]
+        finally:
+            ops.fuse_post(old)
+
+    for pooled in ([False, True] if (sorted_batch and dims[-1] in (64, 128)) else [False]):
+        a, b = run(True, pooled), run(False, pooled)
+        if a is None:
+            continue
+        for i, (u, v) in enumerate(zip(a, b)):
+            assert torch.equal(u, v), f"pooled={pooled}: tensor {i} differs by {float((u - v).abs().max()):.3e}"
