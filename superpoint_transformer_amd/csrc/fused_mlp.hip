@@ -1267,28 +1267,51 @@ __global__ __launch_bounds__(1024) void reduce_tables_groups_kernel(const T* __r
 // column in a fixed order and the table formulas are unchanged (sliced_col_sum below is
 // reduce_tables_body's loop, the formulas are gn_fwd_tables_kernel's / gn_bwd_tables_kernel's of
 // graphnorm.hip): the same bits out of 2 launches per layer and direction.
-__device__ __forceinline__ double sliced_col_sum(const double* __restrict__ partial, int ntab, int len,
-                                                 int col, bool valid, double (*sl)[17]) {
+// NV column sums side by side (one pass over the records: the loads of all columns are in flight
+// together - a sum is pure load latency, NV sums one after the other cost NV round-trip chains).
+// Per column the adds happen in reduce_tables_body's order: slices of ceil(ntab / 64) records,
+// then the 64 slice sums in ascending order.  col[v] < 0: column v is not wanted (returns 0).
+template <int NV>
+__device__ __forceinline__ void sliced_col_sums(const double* const (&base)[NV], const int (&ntab)[NV],
+                                                int len, const int (&col)[NV], double (*sl)[64][17],
+                                                double (&out)[NV]) {
   const int cl = threadIdx.x & 15, slice = threadIdx.x >> 4;
-  double acc = 0;
-  if (valid) {
-    const int per = (ntab + 63) / 64;
-    const int lo = slice * per, hi = (lo + per < ntab) ? lo + per : ntab;
-    int k = lo;
-    for (; k + 4 <= hi; k += 4) {
-      const double a0 = partial[(size_t)k * len + col], a1 = partial[(size_t)(k + 1) * len + col];
-      const double a2 = partial[(size_t)(k + 2) * len + col], a3 = partial[(size_t)(k + 3) * len + col];
-      acc += a0; acc += a1; acc += a2; acc += a3;
-    }
-    for (; k < hi; ++k) acc += partial[(size_t)k * len + col];
-  }
-  __syncthreads();                                           // (the previous use of sl is over)
-  sl[slice][cl] = acc;
-  __syncthreads();
-  double t = 0;
+  double acc[NV];
+  int lo[NV], hi[NV], kmax = 0;
 #pragma unroll
-  for (int k = 0; k < 64; ++k) t += sl[k][cl];               // fixed order: deterministic
-  return t;
+  for (int v = 0; v < NV; ++v) {
+    acc[v] = 0;
+    const int per = (ntab[v] + 63) / 64;
+    lo[v] = slice * per;
+    hi[v] = (lo[v] + per < ntab[v]) ? lo[v] + per : ntab[v];
+    if (col[v] < 0) hi[v] = lo[v];
+    const int n = hi[v] - lo[v];
+    kmax = n > kmax ? n : kmax;
+  }
+  for (int k = 0; k < kmax; ++k) {
+    double t[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+      t[v] = (lo[v] + k < hi[v]) ? base[v][(size_t)(lo[v] + k) * len + col[v]] : 0.0;
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+      if (lo[v] + k < hi[v]) acc[v] += t[v];                 // (record order: the plain loop's)
+  }
+#pragma unroll
+  for (int v = 0; v < NV; ++v) sl[v][slice][cl] = acc[v];
+  __syncthreads();
+#pragma unroll
+  for (int v = 0; v < NV; ++v) out[v] = 0;
+  if (slice == 0) {                                          // (only these threads use the totals)
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      double t = 0;
+#pragma unroll 8
+      for (int k = 0; k < 64; ++k) t += sl[v][k][cl];        // fixed order: deterministic
+      out[v] = t;
+    }
+  }
+  __syncthreads();                                           // (sl may be reused by the caller)
 }
 
 // forward: per-graph totals [2N + 1] of the layer's output AND the tables of its GraphNorm.
@@ -1297,15 +1320,17 @@ __global__ __launch_bounds__(1024) void fwd_post_kernel(const double* __restrict
                                                         FmlpGroups grp, int N,
                                                         double* __restrict__ total,
                                                         spt_gn_fwd_tables t) {
-  __shared__ double sl[64][17];
+  __shared__ double sl[3][64][17];
   const int b = blockIdx.y, cl = threadIdx.x & 15, slice = threadIdx.x >> 4;
   const int c = blockIdx.x * 16 + cl, len = 2 * N + 1;
   const bool cv = c < N;
   const double* pb = partial + (size_t)grp.start[b] * len;
-  const int ntab = grp.count[b];
-  const double s1 = sliced_col_sum(pb, ntab, len, cv ? c : 0, cv, sl);
-  const double s2 = sliced_col_sum(pb, ntab, len, cv ? N + c : 0, cv, sl);
-  const double cnt = sliced_col_sum(pb, ntab, len, 2 * N, true, sl);
+  const double* const base[3] = {pb, pb, pb};
+  const int ntab[3] = {grp.count[b], grp.count[b], grp.count[b]};
+  const int col[3] = {cv ? c : -1, cv ? N + c : -1, 2 * N};
+  double s3[3];
+  sliced_col_sums<3>(base, ntab, len, col, sl, s3);
+  const double s1 = s3[0], s2 = s3[1], cnt = s3[2];
   if (slice != 0) return;
   if (total) {
     double* tr = total + (size_t)b * len;
@@ -1334,7 +1359,9 @@ __global__ __launch_bounds__(1024) void fwd_post_kernel(const double* __restrict
 // backward: blocks [0, nA) sum the weight-gradient partials (reduce_tables_kernel<float>); the
 // blocks behind them the statistics of the PREVIOUS layer's GraphNorm backward - plain totals
 // (`pn.c1 == nullptr`: (2K + 1 + 15) / 16 blocks per graph, as reduce_tables_groups_kernel), or 16
-// channels per block over all graphs with that norm's backward tables written on the spot.
+// channels per block over all graphs (POST_GB of them side by side) with that norm's backward
+// tables written on the spot.
+constexpr int POST_GB = 2;   // (LDS: 3 x POST_GB x 8.7 KB next to the weight-gradient blocks: two workgroups per CU)
 __global__ __launch_bounds__(1024) void bwd_post_kernel(const float* __restrict__ gwp, int ntab_w,
                                                         int NK, float* __restrict__ gW, int accumulate,
                                                         int nA, const double* __restrict__ pst,
@@ -1353,39 +1380,53 @@ __global__ __launch_bounds__(1024) void bwd_post_kernel(const float* __restrict_
                                prev_total + (size_t)b * len, 0, bx - b * per_graph);
     return;
   }
-  __shared__ double sl[64][17];
+  __shared__ double sl[3 * POST_GB][64][17];
   const int cl = threadIdx.x & 15, slice = threadIdx.x >> 4;
   const int c = bx * 16 + cl;
   const bool cv = c < K;
   const double w = cv ? (double)pn.weight[c] : 0.0, a = cv ? (double)pn.mean_scale[c] : 0.0;
   double gw = 0.0, gb = 0.0, ga = 0.0;
-  for (int b = 0; b < B; ++b) {
-    const double* pb = pst + (size_t)grp.start[b] * len;
-    const int ntab = grp.count[b];
-    const double A = sliced_col_sum(pb, ntab, len, cv ? c : 0, cv, sl);
-    const double GO = sliced_col_sum(pb, ntab, len, cv ? K + c : 0, cv, sl);
-    const double cnt = sliced_col_sum(pb, ntab, len, 2 * K, true, sl);
-    if (slice != 0) continue;
-    if (prev_total) {
-      double* tr = prev_total + (size_t)b * len;
-      if (cv) {
-        tr[c] = A;
-        tr[K + c] = GO;
-      }
-      if (bx == 0 && cl == 0) tr[2 * K] = cnt;
+  for (int b0 = 0; b0 < B; b0 += POST_GB) {
+    const int nb = (B - b0 < POST_GB) ? B - b0 : POST_GB;
+    const double* base[3 * POST_GB];
+    int ntab[3 * POST_GB], col[3 * POST_GB];
+#pragma unroll
+    for (int j = 0; j < POST_GB; ++j) {
+      const int b = b0 + (j < nb ? j : 0);
+      const double* pb = pst + (size_t)grp.start[b] * len;
+      base[3 * j] = base[3 * j + 1] = base[3 * j + 2] = pb;
+      ntab[3 * j] = ntab[3 * j + 1] = ntab[3 * j + 2] = grp.count[b];
+      col[3 * j] = (j < nb && cv) ? c : -1;
+      col[3 * j + 1] = (j < nb && cv) ? K + c : -1;
+      col[3 * j + 2] = j < nb ? 2 * K : -1;
     }
-    if (!cv) continue;
-    double n = cnt;
-    if (n < 1.0) n = 1.0;
-    const double sd = (double)pn.rstd[b * K + c], mu = (double)pn.mean[b * K + c];
-    const double k2 = w * sd * sd * sd * GO / n;
-    const double sumdo = w * sd * A - k2 * n * mu * (1.0 - a);
-    pn.c1[b * K + c] = (float)(w * sd);
-    pn.c2[b * K + c] = (float)k2;
-    pn.c3[b * K + c] = (float)(a * sumdo / n);
-    gw += sd * GO;
-    gb += A;
-    ga += -mu * sumdo;
+    double s[3 * POST_GB];
+    sliced_col_sums<3 * POST_GB>(base, ntab, len, col, sl, s);
+    if (slice != 0) continue;
+    for (int j = 0; j < nb; ++j) {
+      const int b = b0 + j;
+      const double A = s[3 * j], GO = s[3 * j + 1], cnt = s[3 * j + 2];
+      if (prev_total) {
+        double* tr = prev_total + (size_t)b * len;
+        if (cv) {
+          tr[c] = A;
+          tr[K + c] = GO;
+        }
+        if (bx == 0 && cl == 0) tr[2 * K] = cnt;
+      }
+      if (!cv) continue;
+      double n = cnt;
+      if (n < 1.0) n = 1.0;
+      const double sd = (double)pn.rstd[b * K + c], mu = (double)pn.mean[b * K + c];
+      const double k2 = w * sd * sd * sd * GO / n;
+      const double sumdo = w * sd * A - k2 * n * mu * (1.0 - a);
+      pn.c1[b * K + c] = (float)(w * sd);
+      pn.c2[b * K + c] = (float)k2;
+      pn.c3[b * K + c] = (float)(a * sumdo / n);
+      gw += sd * GO;
+      gb += A;
+      ga += -mu * sumdo;
+    }
   }
   if (slice == 0 && cv) {
     pn.gweight[c] = (float)gw;
