@@ -40,23 +40,13 @@ __global__ __launch_bounds__(256) void csr_check_kernel(
 }
 
 // Round 6 (advisor, medium): adopt = check + the int32 casts the segment kernels read, in ONE launch.
-// The casts are CLAMPED (perm into [0, n), rowptr into [0, n] and never ahead of position j's own
-// chunk), so a stored CSR that fails the check cannot send a segment kernel outside its buffers
-// while the verdict is still on its way to the host (csr.adopt_csr(verify="deferred")).  A
-// workgroup owns a contiguous chunk of positions: two searches bound the segments the chunk
-// touches and every position's own search runs inside that window (5 steps instead of 19 at
-// 428 571 segments); the ascending comparison always runs (one neighbouring load).
-constexpr int ADOPT_CHUNK = 2048;
-
-__device__ __forceinline__ int64_t seg_of_pos(const int64_t* __restrict__ pointers, int64_t lo,
-                                              int64_t hi, int64_t j) {
-  while (lo < hi) {
-    const int64_t mid = (lo + hi + 1) >> 1;
-    if (pointers[mid] <= j) lo = mid; else hi = mid - 1;
-  }
-  return lo;
-}
-
+// The casts are CLAMPED (perm into [0, n), rowptr into [0, n]), so a stored CSR that fails the
+// check cannot send a segment kernel outside its buffers while the verdict is still on its way to
+// the host (csr.adopt_csr(verify="deferred")).  No search: position j holds point p, which CLAIMS
+// segment s = idx[p]; the claim is true iff j lies in [pointers[s], pointers[s + 1]) - with
+// monotone pointers (bit 0) the ranges are disjoint, so this is "idx[p] is the segment holding
+// position j" in three dependent loads per position instead of a 19-step binary search.  The
+// ascending comparison always runs (one neighbouring load).
 __global__ __launch_bounds__(256) void csr_adopt_kernel(
     const int64_t* __restrict__ idx, const int64_t* __restrict__ points,
     const int64_t* __restrict__ pointers, int64_t n, int64_t num_seg,
@@ -70,25 +60,22 @@ __global__ __launch_bounds__(256) void csr_adopt_kernel(
     if ((s == 0 && p != 0) || (s == num_seg && p != n)) bad |= 1;
     rowptr32[s] = (int32_t)(p < 0 ? 0 : (p > n ? n : p));
   }
-  const int64_t nchunks = (n + ADOPT_CHUNK - 1) / ADOPT_CHUNK;
-  for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
-    const int64_t j0 = c * ADOPT_CHUNK;
-    const int64_t j1 = j0 + ADOPT_CHUNK < n ? j0 + ADOPT_CHUNK : n;
-    // (wave-uniform searches: garbage pointers cannot lead them outside [0, num_seg))
-    const int64_t slo = seg_of_pos(pointers, 0, num_seg - 1, j0);
-    const int64_t shi = seg_of_pos(pointers, slo, num_seg - 1, j1 - 1);
-    for (int64_t j = j0 + threadIdx.x; j < j1; j += blockDim.x) {
-      const int64_t p = points[j];
-      const bool inr = p >= 0 && p < n;
-      perm32[j] = (int32_t)(inr ? p : (p < 0 ? 0 : n - 1));
-      if (!inr) {
-        bad |= 2;
-        continue;
-      }
-      const int64_t s = seg_of_pos(pointers, slo, shi, j);
-      if (!(pointers[s] <= j && j < pointers[s + 1]) || idx[p] != s) bad |= 4;
-      if (j > 0 && j > pointers[s] && points[j - 1] >= p) bad |= 8;
+  for (int64_t j = tid; j < n; j += nthreads) {
+    const int64_t p = points[j];
+    const bool inr = p >= 0 && p < n;
+    perm32[j] = (int32_t)(inr ? p : (p < 0 ? 0 : n - 1));
+    if (!inr) {
+      bad |= 2;
+      continue;
     }
+    const int64_t s = idx[p];
+    if (s < 0 || s >= num_seg) {
+      bad |= 4;
+      continue;
+    }
+    const int64_t a = pointers[s], b = pointers[s + 1];
+    if (!(a <= j && j < b)) bad |= 4;
+    else if (j > 0 && j > a && points[j - 1] >= p) bad |= 8;
   }
   if (bad) atomicOr(flag, bad);
 }
@@ -100,10 +87,9 @@ extern "C" int spt_csr_adopt_i64(const int64_t* idx, const int64_t* points, cons
                                  int32_t* flag, spt_stream_t stream_) {
   SPT_CHECK_ARG(n >= 0 && num_seg >= 1 && n < (int64_t)INT32_MAX, "bad shape");
   SPT_CHECK_ARG(pointers && flag && rowptr32 && (n == 0 || (idx && points && perm32)), "null pointer");
-  const int64_t chunks = spt::ceil_div(n, spt::ADOPT_CHUNK);
-  const int64_t blocks = chunks > spt::ceil_div(num_seg + 1, 256) ? chunks : spt::ceil_div(num_seg + 1, 256);
-  spt::csr_adopt_kernel<<<(int)(blocks < 1 ? 1 : (blocks > 256 * 32 ? 256 * 32 : blocks)), 256, 0,
-                          (hipStream_t)stream_>>>(idx, points, pointers, n, num_seg, perm32, rowptr32, flag);
+  const int64_t work = n > num_seg + 1 ? n : num_seg + 1;
+  spt::csr_adopt_kernel<<<spt::stream_grid(work, 256), 256, 0, (hipStream_t)stream_>>>(
+      idx, points, pointers, n, num_seg, perm32, rowptr32, flag);
   SPT_CHECK_LAUNCH();
   return 0;
 }
