@@ -1273,7 +1273,7 @@ __global__ __launch_bounds__(1024) void reduce_tables_groups_kernel(const T* __r
 // then the 64 slice sums in ascending order.  col[v] < 0: column v is not wanted (returns 0).
 template <int NV>
 __device__ __forceinline__ void sliced_col_sums(const double* const (&base)[NV], const int (&ntab)[NV],
-                                                int len, const int (&col)[NV], double (*sl)[64][17],
+                                                int len, const int (&col)[NV], double (*sl)[17],
                                                 double (&out)[NV]) {
   const int cl = threadIdx.x & 15, slice = threadIdx.x >> 4;
   double acc[NV];
@@ -1297,21 +1297,21 @@ __device__ __forceinline__ void sliced_col_sums(const double* const (&base)[NV],
     for (int v = 0; v < NV; ++v)
       if (lo[v] + k < hi[v]) acc[v] += t[v];                 // (record order: the plain loop's)
   }
+  // the slices meet through ONE [64][17] buffer, column after column (the loads above were the
+  // slow part; a kernel-wide 52 KB of LDS for six buffers halved the residency of the
+  // weight-gradient blocks of the same launch)
 #pragma unroll
-  for (int v = 0; v < NV; ++v) sl[v][slice][cl] = acc[v];
-  __syncthreads();
-#pragma unroll
-  for (int v = 0; v < NV; ++v) out[v] = 0;
-  if (slice == 0) {                                          // (only these threads use the totals)
-#pragma unroll
-    for (int v = 0; v < NV; ++v) {
-      double t = 0;
+  for (int v = 0; v < NV; ++v) {
+    sl[slice][cl] = acc[v];
+    __syncthreads();
+    double t = 0;
+    if (slice == 0) {                                        // (only these threads use the totals)
 #pragma unroll 8
-      for (int k = 0; k < 64; ++k) t += sl[v][k][cl];        // fixed order: deterministic
-      out[v] = t;
+      for (int k = 0; k < 64; ++k) t += sl[k][cl];           // fixed order: deterministic
     }
+    out[v] = t;
+    __syncthreads();
   }
-  __syncthreads();                                           // (sl may be reused by the caller)
 }
 
 // forward: per-graph totals [2N + 1] of the layer's output AND the tables of its GraphNorm.
@@ -1320,7 +1320,7 @@ __global__ __launch_bounds__(1024) void fwd_post_kernel(const double* __restrict
                                                         FmlpGroups grp, int N,
                                                         double* __restrict__ total,
                                                         spt_gn_fwd_tables t) {
-  __shared__ double sl[3][64][17];
+  __shared__ double sl[64][17];
   const int b = blockIdx.y, cl = threadIdx.x & 15, slice = threadIdx.x >> 4;
   const int c = blockIdx.x * 16 + cl, len = 2 * N + 1;
   const bool cv = c < N;
@@ -1361,8 +1361,8 @@ __global__ __launch_bounds__(1024) void fwd_post_kernel(const double* __restrict
 // (`pn.c1 == nullptr`: (2K + 1 + 15) / 16 blocks per graph, as reduce_tables_groups_kernel), or 16
 // channels per block over all graphs (POST_GB of them side by side) with that norm's backward
 // tables written on the spot.
-constexpr int POST_GB = 2;   // (LDS: 3 x POST_GB x 8.7 KB next to the weight-gradient blocks: two workgroups per CU)
-__global__ __launch_bounds__(1024) void bwd_post_kernel(const float* __restrict__ gwp, int ntab_w,
+constexpr int POST_GB = 2;
+__global__ __launch_bounds__(1024, 8) void bwd_post_kernel(const float* __restrict__ gwp, int ntab_w,
                                                         int NK, float* __restrict__ gW, int accumulate,
                                                         int nA, const double* __restrict__ pst,
                                                         FmlpGroups grp, int K, int B,
@@ -1380,7 +1380,7 @@ __global__ __launch_bounds__(1024) void bwd_post_kernel(const float* __restrict_
                                prev_total + (size_t)b * len, 0, bx - b * per_graph);
     return;
   }
-  __shared__ double sl[3 * POST_GB][64][17];
+  __shared__ double sl[64][17];
   const int cl = threadIdx.x & 15, slice = threadIdx.x >> 4;
   const int c = bx * 16 + cl;
   const bool cv = c < K;
@@ -1403,7 +1403,9 @@ __global__ __launch_bounds__(1024) void bwd_post_kernel(const float* __restrict_
     double s[3 * POST_GB];
     sliced_col_sums<3 * POST_GB>(base, ntab, len, col, sl, s);
     if (slice != 0) continue;
-    for (int j = 0; j < nb; ++j) {
+#pragma unroll
+    for (int j = 0; j < POST_GB; ++j) {                      // (compile-time indices: registers)
+      if (j >= nb) break;
       const int b = b0 + j;
       const double A = s[3 * j], GO = s[3 * j + 1], cnt = s[3 * j + 2];
       if (prev_total) {
