@@ -44,6 +44,24 @@ __device__ __forceinline__ float quad_sum(float v) {
   v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));
   return v;
 }
+// Four quad sums at once with the DPP operand folded into the add (round 6): the builtin's
+// v_mov_b32_dpp + v_add pairs get SLP-packed by the compiler into v_mov 0 / v_mov_dpp / v_pk_add
+// groups - 2.5 instructions per value and step; this is 1.  The s_nop covers the two wait states
+// between a VALU write and a DPP read of the same register (the hazard recogniser does not look
+// inside asm); the second step's sources are three instructions old by construction.
+__device__ __forceinline__ void quad_sum4(const float (&x)[4], float (&o)[4]) {
+  asm("s_nop 1\n\t"
+      "v_add_f32_dpp %0, %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %6, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %3, %7, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3])
+      : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]));
+}
 // lane ^ 16 / lane ^ 32 through gfx950's row / half swaps (VALU, no LDS permute)
 __device__ __forceinline__ float xor16(float v) {
   const unsigned u = __float_as_uint(v);
@@ -60,10 +78,35 @@ __device__ __forceinline__ float xg_sum(float v) {  // sum over the 4 lane group
   v += xor32(v);
   return v;
 }
-__device__ __forceinline__ float xg_max(float v) {
-  v = fmaxf(v, xor16(v));
-  v = fmaxf(v, xor32(v));
-  return v;
+// The same for the forward kernel (the backward kernels of this file sit at their register limit and
+// spill with another schedule).  permlane16_swap(u, u) returns {[r0 r0 r2 r2], [r1 r1 r3 r3]}
+// (rows of 16 lanes), permlane32_swap(u, u) {[lo lo], [hi hi]}: the two halves of the result ARE the
+// two operands of the step in every lane - no per-lane select (round 6; v + xor16(v) picked one of
+// them with a v_cndmask first; same sums bit for bit, the operands only swap sides in odd rows).
+__device__ __forceinline__ float xg_sum_sw(float v) {
+  const unsigned u = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const unsigned w = __float_as_uint(__uint_as_float(r[0]) + __uint_as_float(r[1]));
+  const auto t = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+  return __uint_as_float(t[0]) + __uint_as_float(t[1]);
+}
+// v_max_f32 as it is (fmaxf costs a canonicalising v_max x, x per operand)
+__device__ __forceinline__ float vmax(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float xg_max_sw(float v) {
+  const unsigned u = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const unsigned w = __float_as_uint(vmax(__uint_as_float(r[0]), __uint_as_float(r[1])));
+  const auto t = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+  return vmax(__uint_as_float(t[0]), __uint_as_float(t[1]));
 }
 
 __device__ __forceinline__ float qk_scale_of(int mode, float a, int deg) {
@@ -128,19 +171,26 @@ __device__ __forceinline__ void lds_dma4(const float* g, float* lds) {
 __device__ __forceinline__ void tile_issue(const float* __restrict__ qkv, int ld,
                                            const float* __restrict__ ea, int e_lane,
                                            int t_lane, int cnt, float* buf, int lane) {
+  // all six cross-lane reads first: one LDS round trip (interleaved with the conditional issues
+  // below, each ds_bpermute was waited for on its own - six round trips at the top of every tile)
+  int e2[2];
+  int64_t t4[4];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) e2[p] = __shfl(e_lane, p * 8 + (lane >> 3), 64);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) t4[i] = __shfl(t_lane, i * 4 + (lane >> 4), 64);
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
     const int u = p * 8 + (lane >> 3), ch = lane & 7;
-    const int e = __shfl(e_lane, u, 64);
     if (u < cnt)
-      lds_dma16(ea + (size_t)e * F + ((ch ^ (u & 7)) << 2), buf + p * 256);
+      lds_dma16(ea + (size_t)e2[p] * F + ((ch ^ (u & 7)) << 2), buf + p * 256);
   }
   float* kbuf = buf + EA_FLOATS;
   float* vbuf = kbuf + TE * ROW;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int u = i * 4 + (lane >> 4), ch = lane & 15;
-    const int64_t t = __shfl(t_lane, u, 64);
+    const int64_t t = t4[i];
     if (u < cnt) {
       lds_dma16(qkv + t * ld + 64 + ch * 4, kbuf + i * 256);
       lds_dma16(qkv + t * ld + 128 + ch * 4, vbuf + i * 256);
@@ -239,10 +289,12 @@ __device__ __forceinline__ void load_a_bf(const float* slab, int g, int c, bf16x
 template <bool LO>
 __device__ __forceinline__ void rpe_gemm_bf(const bf16x8& Ah, const bf16x8& Al,
                                             const bf16x8 (&Bh)[NB], const bf16x8 (&Bl)[NB],
-                                            const float (&init)[NB], f32x4 (&C)[NB]) {
+                                            const f32x4 (&init)[NB], f32x4 (&C)[NB]) {
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
-    C[b] = (f32x4){init[b], init[b], init[b], init[b]};
+    // the start value is a ready register quad (splat once per launch / per node, read as srcC
+    // by the first MFMA) - not four moves per accumulator and tile
+    C[b] = init[b];
     if constexpr (LO) {
       C[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, Bh[b], C[b], 0, 0, 0);
       C[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bl[b], C[b], 0, 0, 0);
@@ -464,7 +516,27 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_fwd_mfma_kernel(
   Pipe P;
   P.init(wave, nwaves, N, erowptr, eperm, tgt, qkv, ld, ea, slab_all[wid][0], slab_all[wid][1], lane);
 
-  float qs4[NB], m[NB], z[NB], acc[NB];
+  // Round 6 (the kernel was VALU-bound: ~590 VALU instructions per tile, 1.45 tiles per node):
+  //   * the accumulators' start values as ready register quads (bias splats once per launch, the
+  //     node's q * scale + bq once per node);
+  //   * the head dot products' quad sums as v_add_f32_dpp (quad_sum4);
+  //   * the softmax in the base-2 domain: the running maximum is kept as ms = max(p) * log2(e) and
+  //     a weight is exp2(fma(p, log2(e), -ms)) - one instruction less per exponential; every
+  //     weight, z and the rescaling of a node share the same ms, so its rounding cancels in
+  //     acc / z, and m = ms * ln(2) goes out for the backward (m + log z is the same logsumexp to
+  //     |m| 2^-24);
+  //   * out = acc * rcp(z + 1e-16) (1 ulp) instead of the IEEE division sequence.
+  constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+  //   * the value bias leaves the per-edge path: sum_e a_e (v_e + bv) = sum_e a_e v_e + bv z, so
+  //     out = acc / z + bv (the f32-pipe variant keeps it in the accumulator's start value);
+  f32x4 bk4v[NB], qs4v[NB], zero4v[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    bk4v[b] = (f32x4){bk4[b], bk4[b], bk4[b], bk4[b]};
+    qs4v[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    zero4v[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  float qs4[NB], m[NB], z[NB], acc[NB];       // m: the running maximum times log2(e)
   while (P.cur.valid) {
     wait_vmem_all();  // tile `cur`, nxt's indices and cur's q row have landed
     float qraw[NB];
@@ -482,6 +554,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_fwd_mfma_kernel(
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
         qs4[b] = fmaf(qraw[b], scale, bq4[b]);  // q_s*scale + bq
+        qs4v[b] = (f32x4){qs4[b], qs4[b], qs4[b], qs4[b]};
         m[b] = -INFINITY;
         z[b] = 0.f;
         acc[b] = 0.f;
@@ -492,9 +565,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_fwd_mfma_kernel(
       if constexpr (BF3) {
         bf16x8 Ah, Al;
         load_a_bf(slab, g, c, Ah, Al);
-        rpe_gemm_bf<LO>(Ah, Al, Bkh, Bkl, bk4, Ck);
-        rpe_gemm_bf<LO>(Ah, Al, Bqh, Bql, qs4, Cq);
-        rpe_gemm_bf<LO>(Ah, Al, Bvh, Bvl, bv4, Cv);
+        rpe_gemm_bf<LO>(Ah, Al, Bkh, Bkl, bk4v, Ck);
+        rpe_gemm_bf<LO>(Ah, Al, Bqh, Bql, qs4v, Cq);
+        rpe_gemm_bf<LO>(Ah, Al, Bvh, Bvl, zero4v, Cv);      // (the compiler folds the zeros into the MFMA's inline 0)
       } else {
         float A[8];
         load_a(slab, g, c, A);
@@ -507,37 +580,47 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_fwd_mfma_kernel(
       const float* vp = vslab + 4 * g * ROW + c;
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
+        // pairs of edges as packed f32 operations (v_pk_add / v_pk_mul / v_pk_fma: two lanes' worth
+        // per issue slot)
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 k01 = {kp[16 * b], kp[ROW + 16 * b]}, k23 = {kp[2 * ROW + 16 * b], kp[3 * ROW + 16 * b]};
+        const f32x2 t01 = (f32x2){Cq[b][0], Cq[b][1]} * ((f32x2){Ck[b][0], Ck[b][1]} + k01);
+        const f32x2 t23 = (f32x2){Cq[b][2], Cq[b][3]} * ((f32x2){Ck[b][2], Ck[b][3]} + k23);
+        const float qk[4] = {t01.x, t01.y, t23.x, t23.y};
         float p[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) p[r] = quad_sum(Cq[b][r] * (Ck[b][r] + kp[r * ROW + 16 * b]));
+        quad_sum4(qk, p);
         if (partial) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) p[r] = (4 * g + r < cnt) ? p[r] : -INFINITY;
         }
-        const float mt = xg_max(fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3])));  // tile max of this head
-        const float mn = fmaxf(m[b], mt);
-        const float corr = __expf(m[b] - mn);  // m = -inf on the first tile -> 0
-        float zs = 0.f, as = 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float pe = __expf(p[r] - mn);  // rows beyond cnt: exp(-inf) = 0
-          zs += pe;
-          as = fmaf(pe, Cv[b][r] + vp[r * ROW + 16 * b], as);
-        }
+        const float mt = xg_max_sw(vmax3(p[0], p[1], vmax(p[2], p[3])));  // tile max of this head
+        const float mn = vmax(m[b], mt * LOG2E);
+        const float corr = __builtin_amdgcn_exp2f(m[b] - mn);  // m = -inf on the first tile -> 0
+        f32x2 pe01, pe23;                                      // rows beyond cnt: 2^-inf = 0
+        pe01.x = __builtin_amdgcn_exp2f(fmaf(p[0], LOG2E, -mn));
+        pe01.y = __builtin_amdgcn_exp2f(fmaf(p[1], LOG2E, -mn));
+        pe23.x = __builtin_amdgcn_exp2f(fmaf(p[2], LOG2E, -mn));
+        pe23.y = __builtin_amdgcn_exp2f(fmaf(p[3], LOG2E, -mn));
+        const f32x2 v01 = (f32x2){Cv[b][0], Cv[b][1]} + (f32x2){vp[16 * b], vp[ROW + 16 * b]};
+        const f32x2 v23 = (f32x2){Cv[b][2], Cv[b][3]} + (f32x2){vp[2 * ROW + 16 * b], vp[3 * ROW + 16 * b]};
+        const f32x2 w2 = __builtin_elementwise_fma(pe23, v23, pe01 * v01);
+        const f32x2 z2 = pe01 + pe23;
         // z / acc stay per-lane-group partial sums until the node ends
-        z[b] = fmaf(z[b], corr, zs);
-        acc[b] = fmaf(acc[b], corr, as);
+        z[b] = fmaf(z[b], corr, z2.x + z2.y);
+        acc[b] = fmaf(acc[b], corr, w2.x + w2.y);
         m[b] = mn;
       }
     }
     if (cur.t0 + TE >= cur.end) {  // last tile of the node
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
-        const float zt = xg_sum(z[b]);
-        const float at = xg_sum(acc[b]);
-        if (g == 0) out[cur.s * 64 + 16 * b + c] = at / (zt + 1e-16f);
+        const float zt = xg_sum_sw(z[b]);
+        const float at = xg_sum_sw(acc[b]);
+        // (a node without edges keeps out = 0: no weight mass, no bias)
+        const float bvn = (BF3 && cur.end > cur.start) ? bv4[b] : 0.f;
+        if (g == 0) out[cur.s * 64 + 16 * b + c] = fmaf(at, __builtin_amdgcn_rcpf(zt + 1e-16f), bvn);
         if (g == 0 && (c & 3) == 0 && mbuf) {
-          mbuf[cur.s * 16 + 4 * b + (c >> 2)] = m[b];
+          mbuf[cur.s * 16 + 4 * b + (c >> 2)] = m[b] * LN2;
           zbuf[cur.s * 16 + 4 * b + (c >> 2)] = zt;
         }
       }

@@ -43,6 +43,7 @@ constexpr int NBW = 2;            // 16-column blocks of each projection owned b
 constexpr int WAVES = 8;          // per workgroup: 4 tile streams x 2 head halves, one workgroup per CU
 constexpr int LD = 192;           // qkv row length
 constexpr int REC = 160;          // floats of a node's record: 2 head halves x [qs 32 | gout 32 | dm 16]
+constexpr int REC16 = 96;         // the bf16 mode's record, in floats: 2 head halves x [qs 32 bf16 | gout 32 bf16 | dm 16 f32]
 constexpr int IDS = 64;           // ints of a tile record: edge rows | targets | sources | source-order positions
 
 // LDS map, in floats.  Per wave:
@@ -70,7 +71,7 @@ constexpr int WB_ELEMS = 192 * WB_LD;
 // Outstanding VMEM operations per iteration, in issue order:
 //   leader  : [top] ids of tile k+2 (1), k / v rows of tile k's targets (4), edge_attr rows of tile k+1 (2)
 //             [core] dq rows (2)  [mid] source records of tile k+1 (5)  [tail] dk / dv atomics (0..16)
-//   follower: [top] k / v rows (4), old d edge_attr rows of tile k (2)
+//   follower: [top] k / v rows (4), old d edge_attr rows of tile k (2; accumulating calls only)
 //             [core] dq rows (2)  [mid] source records of tile k+1 (5)
 //             [tail] d edge_attr rows (2), dk / dv atomics (0..16)
 constexpr int N_DQ = 2;                 // dq stores per tile and wave (f32 rows; bf16 rows: 1)
@@ -152,6 +153,10 @@ __device__ __forceinline__ float qk_scale_of(int mode, float a, int deg) {
 //     delta = <gout, out> of the head, ml = m + log(z + 1e-16) (softmax weight = exp(p - ml))
 //   scl[node] = the node's qk scale (0 for a node without edges)
 // One thread per (node, head).  Also zero-fills the k / v columns of gqkv (dk / dv arrive by atomics).
+//   B16 (the bf16 mode, round 6): q * scale and gout as bf16 - 384 bytes per node instead of 640,
+//   gathered once per edge: rec[node][hh] = [qs 32 bf16 | gout 32 bf16 | dm 16 f32] (192 bytes);
+//   (delta, ml) stay f32 (the softmax weight is exp(p - ml)).
+template <bool B16>
 __global__ __launch_bounds__(256) void attn_bwd_to_prep_kernel(
     const float* __restrict__ qkv, const float* __restrict__ gout, const float* __restrict__ out,
     const float* __restrict__ m, const float* __restrict__ z, const int32_t* __restrict__ erowptr,
@@ -169,12 +174,27 @@ __global__ __launch_bounds__(256) void attn_bwd_to_prep_kernel(
   const int deg = erowptr[node + 1] - erowptr[node];
   const float scale = deg > 0 ? qk_scale_of(scale_mode, scale_a, deg) : 0.f;
   const float4 q4 = *reinterpret_cast<const float4*>(qkv + node * LD + 4 * h);
-  float* r = rec + node * REC + hh * 80;
-  *reinterpret_cast<float4*>(r + 16 * bl + 4 * g) =
-      make_float4(q4.x * scale, q4.y * scale, q4.z * scale, q4.w * scale);
-  *reinterpret_cast<float4*>(r + 32 + 16 * bl + 4 * g) = g4;
-  r[64 + 4 * g + bl] = delta;
-  r[64 + 4 * g + 2 + bl] = ml;
+  if constexpr (B16) {
+    float* r = rec + node * REC16 + hh * 48;
+    auto pk = [](float a, float b2) {
+      const __bf16 ha = (__bf16)a, hb = (__bf16)b2;
+      return (unsigned)__builtin_bit_cast(unsigned short, ha) |
+             ((unsigned)__builtin_bit_cast(unsigned short, hb) << 16);
+    };
+    unsigned* r16 = reinterpret_cast<unsigned*>(r);          // 2 bf16 per word
+    *reinterpret_cast<u32x2*>(r16 + (16 * bl + 4 * g) / 2) =
+        (u32x2){pk(q4.x * scale, q4.y * scale), pk(q4.z * scale, q4.w * scale)};
+    *reinterpret_cast<u32x2*>(r16 + 16 + (16 * bl + 4 * g) / 2) = (u32x2){pk(g4.x, g4.y), pk(g4.z, g4.w)};
+    r[32 + 4 * g + bl] = delta;
+    r[32 + 4 * g + 2 + bl] = ml;
+  } else {
+    float* r = rec + node * REC + hh * 80;
+    *reinterpret_cast<float4*>(r + 16 * bl + 4 * g) =
+        make_float4(q4.x * scale, q4.y * scale, q4.z * scale, q4.w * scale);
+    *reinterpret_cast<float4*>(r + 32 + 16 * bl + 4 * g) = g4;
+    r[64 + 4 * g + bl] = delta;
+    r[64 + 4 * g + 2 + bl] = ml;
+  }
   if (h == 0) scl[node] = scale;
   *reinterpret_cast<float4*>(gqkv + node * LD + 64 + 4 * h) = make_float4(0.f, 0.f, 0.f, 0.f);
   *reinterpret_cast<float4*>(gqkv + node * LD + 128 + 4 * h) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -318,6 +338,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_bwd_to_kernel(
   // the bf16 mode streams its dq rows as bf16: 64 bytes per edge and wave, ONE store per tile
   constexpr bool DQ16 = PREC == 1;
   constexpr int NDQ = DQ16 ? 1 : N_DQ;
+  // ... and gathers its source records as bf16 (q * scale | gout: 128 bytes per edge and wave
+  // instead of 256; (delta, ml) stay f32): three requests per tile instead of five
+  constexpr bool R16 = PREC == 1;
+  constexpr int NG = R16 ? 3 : N_GATHER;
   __shared__ __attribute__((aligned(16))) float lds_wave[WAVES][L_END];
   __shared__ __attribute__((aligned(16))) float lds_pair[WAVES / 2][P_END];
   __shared__ __attribute__((aligned(16))) __bf16 wb_hi[WB_ELEMS];
@@ -334,7 +358,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_bwd_to_kernel(
   const int hh = wid & 1;                   // head half: blocks b = 2 hh + bl of every projection
   const bool leader = hh == 0;              // leader: fetches the pair's edge_attr rows and tile ids;
                                             // follower: combines and writes the pair's d edge_attr
-  const bool acc = gea_acc != 0;
+  const bool acc = (gea_acc & 1) != 0;
+  // bit 1 (SPT_TO_READ_OLD=1, measurement switch): fetch what gedge_attr holds even when the call
+  // does not accumulate (the behaviour before round 6)
+  const bool rd_old = acc || (gea_acc & 2) != 0;
 
   // ---- operands ---------------------------------------------------------------------------
   auto Wof = [&](int p) { return p == 0 ? Wk : (p == 1 ? Wq : Wv); };
@@ -423,17 +450,33 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_bwd_to_kernel(
     auto issue_gather = [&](int slot) {
       const int* ids = ids_ring + slot * IDS;
       float* G = L + L_G;
+      if constexpr (R16) {
+        // (qs | gout) bf16: 8 chunks of 16 bytes per edge at position chunk ^ (edge % 8), 8 edges per
+        // instruction; the second instruction's block starts 128 bytes further (edges e and e + 8
+        // would otherwise sit on the same banks)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int e = 4 * j + g;
-        const int ch = c ^ e;
-        const int64_t sc = ids[32 + e];
-        lds_dma16(rec + sc * REC + hh * 80 + 4 * ch, G + j * 256);
-      }
-      {
+        for (int j = 0; j < 2; ++j) {
+          const int e = 8 * j + (lane >> 3);
+          const int ch = (lane & 7) ^ (e & 7);
+          const int64_t sc = ids[32 + e];
+          lds_dma16(rec + sc * REC16 + hh * 48 + 4 * ch, G + j * 288);
+        }
         const int e = lane >> 2, x = ((lane & 3) - (e >> 2)) & 3;
         const int64_t sc = ids[32 + e];
-        lds_dma16(rec + sc * REC + hh * 80 + 64 + 4 * x, L + L_GD);
+        lds_dma16(rec + sc * REC16 + hh * 48 + 32 + 4 * x, L + L_GD);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int e = 4 * j + g;
+          const int ch = c ^ e;
+          const int64_t sc = ids[32 + e];
+          lds_dma16(rec + sc * REC + hh * 80 + 4 * ch, G + j * 256);
+        }
+        {
+          const int e = lane >> 2, x = ((lane & 3) - (e >> 2)) & 3;
+          const int64_t sc = ids[32 + e];
+          lds_dma16(rec + sc * REC + hh * 80 + 64 + 4 * x, L + L_GD);
+        }
       }
     };
     // k / v rows of the tile's TARGETS, straight into registers (consecutive edges share their
@@ -449,8 +492,19 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_bwd_to_kernel(
       asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(nv[0]) : "v"(vv) : "memory");
       asm volatile("global_load_dwordx4 %0, %1, off offset:64" : "=v"(nv[1]) : "v"(vv) : "memory");
     };
-#define SPT_TO_NODE_WAIT(N)                                                              \
-  asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(nk[0]), "+v"(nk[1]), "+v"(nv[0]), "+v"(nv[1])::"memory")
+#define SPT_TO_NODE_WAIT_SEL(SEL)                                                        \
+  asm volatile("v_readfirstlane_b32 vcc_lo, %4\n\t"                                       \
+               "s_cmp_lg_u32 vcc_lo, 0\n\t"                                              \
+               "s_cbranch_scc1 1f\n\t"                                                   \
+               "s_waitcnt vmcnt(0)\n\t"                                                  \
+               "s_branch 2f\n"                                                           \
+               "1:\n\t"                                                                  \
+               "s_waitcnt vmcnt(2)\n"                                                    \
+               "2:"                                                                      \
+               : "+v"(nk[0]), "+v"(nk[1]), "+v"(nv[0]), "+v"(nv[1])                      \
+               : "v"(SEL)                                                                \
+               : "memory", "scc", "vcc")
+    const int wait2 = (leader || rd_old) ? 1 : 0;
 
     // ---- prologue ------------------------------------------------------------------------------
     if (leader) {
@@ -472,7 +526,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_bwd_to_kernel(
       if (leader) {
         // edge_attr rows of tile k and the ids of tile k + 1 have landed; behind them in the queue:
         // the dq rows of tile k - 1, the gathers of tile k, dk / dv atomics
-        wait_vm<NDQ + N_GATHER>();
+        wait_vm<NDQ + NG>();
         flag_set(flg + F_EA, k + 1);
       } else {
         flag_wait(flg + F_EA, k + 1);
@@ -503,8 +557,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_bwd_to_kernel(
       const int t_c = ids[16 + c];                                    // target node of edge c
       wait_lds();                                 // the edge_attr slab is consumed
       // Both roles put exactly TWO requests behind the target rows (leader: the next tile's
-      // edge_attr rows; follower: what gedge_attr holds for this tile), so that ONE unbranched
-      // counted wait serves both
+      // edge_attr rows; follower of an accumulating call: what gedge_attr holds for this tile), so
+      // that one counted wait serves both
       if (leader) {
         flag_wait(flg + F_DONE, k - 1);
         issue_ids(t + 2 * t_step, s2);
@@ -514,7 +568,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_bwd_to_kernel(
       } else {
         flag_set(flg + F_TOP, k + 1);
         issue_node(s0);
-        issue_old(s0);
+        // (round 6: only an accumulating call reads what gedge_attr holds - 128 bytes per edge
+        // that the first block of a stage's backward used to fetch for nothing)
+        if (rd_old) issue_old(s0);
       }
 
       // ---- recompute GEMM, transposed: C[o = 16 b + 4 g + r][e = c] ---------------------------
@@ -564,7 +620,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_bwd_to_kernel(
       // ---- per-edge gradients, in place: Ck <- dk, Cq <- dq, Cv <- dv -------------------------
       // the gathered source records and the target rows of tile k have landed; behind them in the
       // queue: two requests of this tile's top (see there)
-      SPT_TO_NODE_WAIT(2);
+      // ONE asm statement for both counts (a follower that does not accumulate has nothing behind
+      // its target rows): with the two waits in two branches the compiler copied the row registers
+      // into the statement's operands BEFORE the wait of one branch - registers with loads pending
+      SPT_TO_NODE_WAIT_SEL(wait2);
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       {
         const float* G = L + L_G + c * 64;
@@ -579,8 +638,21 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_bwd_to_kernel(
         for (int bl = 0; bl < NBW; ++bl) {
           const f32x4 kt = nk[bl];
           const f32x4 vt = nv[bl];
-          const f32x4 qr = *reinterpret_cast<const f32x4*>(G + 4 * ((4 * bl + g) ^ c));
-          const f32x4 gs = *reinterpret_cast<const f32x4*>(G + 4 * ((8 + 4 * bl + g) ^ c));
+          f32x4 qr, gs;
+          if constexpr (R16) {
+            // edge c: block 8 (c / 8) x 128 B (+ 128 B for the second block), 16-byte chunk
+            // 2 bl + g / 2 (qs) / 4 + 2 bl + g / 2 (gout) at position chunk ^ (c % 8), half g % 2
+            const unsigned* Gb = reinterpret_cast<const unsigned*>(L + L_G) + (c >> 3) * 288 + (c & 7) * 32;
+            const u32x2 qw = *reinterpret_cast<const u32x2*>(Gb + 4 * ((2 * bl + (g >> 1)) ^ (c & 7)) + 2 * (g & 1));
+            const u32x2 gw = *reinterpret_cast<const u32x2*>(Gb + 4 * ((4 + 2 * bl + (g >> 1)) ^ (c & 7)) + 2 * (g & 1));
+            qr = (f32x4){__uint_as_float(qw.x << 16), __uint_as_float(qw.x & 0xffff0000u),
+                         __uint_as_float(qw.y << 16), __uint_as_float(qw.y & 0xffff0000u)};
+            gs = (f32x4){__uint_as_float(gw.x << 16), __uint_as_float(gw.x & 0xffff0000u),
+                         __uint_as_float(gw.y << 16), __uint_as_float(gw.y & 0xffff0000u)};
+          } else {
+            qr = *reinterpret_cast<const f32x4*>(G + 4 * ((4 * bl + g) ^ c));
+            gs = *reinterpret_cast<const f32x4*>(G + 4 * ((8 + 4 * bl + g) ^ c));
+          }
           float kk[4], q[4], v[4];
 #pragma unroll
           for (int d = 0; d < 4; ++d) {
@@ -730,7 +802,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_bwd_to_kernel(
         // stores and the next tile's gathers - but the compiler branches around a dq store whose
         // lanes are all masked (f32 rows: the second store of a last tile with <= 8 edges), so
         // only NDQ - 1 of them are counted on there (the bf16 row store always has live lanes)
-        wait_vm<N_GATHER + (DQ16 ? NDQ : NDQ - 1)>();
+        if (rd_old) wait_vm<NG + (DQ16 ? NDQ : NDQ - 1)>();
         if (acc) {
           C2[0] += *reinterpret_cast<const f32x4*>(P + P_GEA + lane * 4);
           C2[1] += *reinterpret_cast<const f32x4*>(P + P_GEA + 256 + lane * 4);
@@ -756,7 +828,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_bwd_to_kernel(
       if (!leader) flag_set(flg + F_DONE, k + 1);
       lds_order();
     }
-#undef SPT_TO_NODE_WAIT
+#undef SPT_TO_NODE_WAIT_SEL
   }
   // per-pair partial tables [192 rows][F + 1]: each wave of the pair writes its 96 rows
   if (partial) {
@@ -842,8 +914,12 @@ int attn_bwd_to_launch(const float* qkv, int64_t n, const int32_t* erowptr, cons
   int32_t* ids4 = (int32_t*)w;
   w += align_up((size_t)ntiles * to::IDS * 4, 256);
   float* dqt = (float*)w;
-  to::attn_bwd_to_prep_kernel<<<(int)ceil_div(n * 16, 256), 256, 0, stream>>>(
-      qkv, gout, out, m, z, erowptr, n, scale_mode, scale_a, rec, scl, gqkv);
+  if (prec == 3)
+    to::attn_bwd_to_prep_kernel<false><<<(int)ceil_div(n * 16, 256), 256, 0, stream>>>(
+        qkv, gout, out, m, z, erowptr, n, scale_mode, scale_a, rec, scl, gqkv);
+  else
+    to::attn_bwd_to_prep_kernel<true><<<(int)ceil_div(n * 16, 256), 256, 0, stream>>>(
+        qkv, gout, out, m, z, erowptr, n, scale_mode, scale_a, rec, scl, gqkv);
   if (!tile_ids) {
     attn_pack_tile_ids_to_launch(eperm, tgt, src, tperm, e, ids4, stream);
     tile_ids = ids4;
@@ -854,6 +930,8 @@ int attn_bwd_to_launch(const float* qkv, int64_t n, const int32_t* erowptr, cons
   const int grid = (int)ceil_div(pairs, to::WAVES / 2);
   // XCD bands where the grid is the full one (a multiple of 8) and a band outlasts a few sweeps
   const int bands = attn_xcd_bands() && grid % 8 == 0 && ntiles >= 8 * pairs;
+  static const int read_old = [] { const char* e = getenv("SPT_TO_READ_OLD"); return e ? atoi(e) != 0 : 0; }();
+  gea_acc = (gea_acc != 0 ? 1 : 0) | (read_old ? 2 : 0);
   if (prec == 3)
     to::attn_bwd_to_kernel<3><<<grid, to::WAVES * 64, 0, stream>>>(
         qkv, e, tile_ids, ntiles, tpw, ea, Wk, bk, Wq, bq, Wv, bv, rec, gqkv, gea, gea_acc, dqt, partial, bands);

@@ -1228,6 +1228,17 @@ __device__ __forceinline__ void reduce_tables_body(const T* __restrict__ partial
     const int per = (ntab + 63) / 64;
     const int lo = slice * per, hi = (lo + per < ntab) ? lo + per : ntab;
     int k = lo;
+    // eight records (four doubles) in flight, then four, then one (more spills under the 64-register cap): the loop is pure load latency (4 096 per-wave
+    // tables of a train batch's level-0 layers = 64 records per slice: 16 round trips at four in
+    // flight, 30 us per call); the adds keep the plain loop's order
+    constexpr int UNR = sizeof(T) == 4 ? 8 : 4;
+    for (; k + UNR <= hi; k += UNR) {
+      T a[UNR];
+#pragma unroll
+      for (int j = 0; j < UNR; ++j) a[j] = partial[(size_t)(k + j) * len + col];
+#pragma unroll
+      for (int j = 0; j < UNR; ++j) acc += a[j];
+    }
     for (; k + 4 <= hi; k += 4) {
       const T a0 = partial[(size_t)k * len + col], a1 = partial[(size_t)(k + 1) * len + col];
       const T a2 = partial[(size_t)(k + 2) * len + col], a3 = partial[(size_t)(k + 3) * len + col];
@@ -1288,7 +1299,26 @@ __device__ __forceinline__ void sliced_col_sums(const double* const (&base)[NV],
     const int n = hi[v] - lo[v];
     kmax = n > kmax ? n : kmax;
   }
-  for (int k = 0; k < kmax; ++k) {
+  // UNR records of every column in flight (12 loads per round trip; one record at a time was
+  // 16-32 round trips per slice at a train batch's table counts; more than 12 doubles in flight
+  // spill under the 64-register cap of these 1 024-thread blocks)
+  constexpr int UNR = NV <= 3 ? 4 : 1;
+  int k = 0;
+  if constexpr (UNR > 1)
+  for (; k + UNR <= kmax; k += UNR) {
+    double t[NV][UNR];
+#pragma unroll
+    for (int j = 0; j < UNR; ++j)
+#pragma unroll
+      for (int v = 0; v < NV; ++v)
+        t[v][j] = (lo[v] + k + j < hi[v]) ? base[v][(size_t)(lo[v] + k + j) * len + col[v]] : 0.0;
+#pragma unroll
+    for (int j = 0; j < UNR; ++j)
+#pragma unroll
+      for (int v = 0; v < NV; ++v)
+        if (lo[v] + k + j < hi[v]) acc[v] += t[v][j];        // (record order: the plain loop's)
+  }
+  for (; k < kmax; ++k) {
     double t[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v)

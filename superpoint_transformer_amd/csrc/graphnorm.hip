@@ -194,7 +194,15 @@ __global__ __launch_bounds__(256) void gn_reduce_partials_kernel(
   if (col < row_len) {
     const int per = (nblocks + 15) / 16;
     const int lo = slice * per, hi = (lo + per < nblocks) ? lo + per : nblocks;
-    for (int k = lo; k < hi; ++k) acc += partial[((size_t)k * B + b) * row_len + col];
+    int k = lo;
+    for (; k + 8 <= hi; k += 8) {                  // eight partials in flight, added in order
+      double a[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] = partial[((size_t)(k + j) * B + b) * row_len + col];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc += a[j];
+    }
+    for (; k < hi; ++k) acc += partial[((size_t)k * B + b) * row_len + col];
   }
   sl[slice][cl] = acc;
   __syncthreads();
@@ -222,7 +230,21 @@ __device__ __forceinline__ void gn_sliced_sums(const double* __restrict__ partia
   for (int v = 0; v < NV; ++v) acc[v] = 0.0;
   const int per = (nblocks + 15) / 16;
   const int lo = slice * per, hi = (lo + per < nblocks) ? lo + per : nblocks;
-  for (int k = lo; k < hi; ++k) {
+  int k = lo;
+  constexpr int UNR = NV <= 3 ? 4 : 1;             // (twelve columns are twelve loads in flight already)
+  if constexpr (UNR > 1)
+  for (; k + UNR <= hi; k += UNR) {                // four blocks' rows in flight, added in order
+    double t[NV][UNR];
+#pragma unroll
+    for (int j = 0; j < UNR; ++j)
+#pragma unroll
+      for (int v = 0; v < NV; ++v) t[v][j] = v < nv ? partial[(size_t)(k + j) * stride + off[v]] : 0.0;
+#pragma unroll
+    for (int j = 0; j < UNR; ++j)
+#pragma unroll
+      for (int v = 0; v < NV; ++v) acc[v] += t[v][j];
+  }
+  for (; k < hi; ++k) {
     double t[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) t[v] = v < nv ? partial[(size_t)k * stride + off[v]] : 0.0;

@@ -388,6 +388,13 @@ __global__ __launch_bounds__(1024) void sum_tables_kernel(const float* __restric
     const int per = (ntab + 63) / 64;
     const int lo = slice * per, hi = (lo + per < ntab) ? lo + per : ntab;
     int k = lo;
+    for (; k + 16 <= hi; k += 16) {                 // sixteen records in flight, added in order
+      float a[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) a[j] = partial[(size_t)(k + j) * len + col];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc += a[j];
+    }
     for (; k + 4 <= hi; k += 4) {
       const float a0 = partial[(size_t)k * len + col], a1 = partial[(size_t)(k + 1) * len + col];
       const float a2 = partial[(size_t)(k + 2) * len + col], a3 = partial[(size_t)(k + 3) * len + col];
