@@ -118,7 +118,7 @@ __device__ __forceinline__ void rpe(const float (&w)[PL][F], const float (&b)[PL
 
 __device__ __forceinline__ float qk_scale_of(int mode, float a, int deg) {
   // src/utils/nn.py:83-127: D = (dim // num_heads)^-0.5, G = deg(s)^-0.5
-  const float g = 1.0f / sqrtf((float)deg);
+  const float g = __builtin_amdgcn_rsqf((float)deg);   // v_rsq_f32 (1 ulp; the same in every attention kernel)
   if (mode == 0) return a * g;   // 'd.g' (default), 'g' with a = 1
   if (mode == 1) return a + g;   // 'd+g'
   return a;                      // 'd' or a user constant

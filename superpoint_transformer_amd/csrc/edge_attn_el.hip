@@ -168,7 +168,7 @@ __device__ __forceinline__ void split_bf16(const float (&x)[NV], V& hi, V& lo) {
 }
 
 __device__ __forceinline__ float qk_scale_of(int mode, float a, int deg) {
-  const float g = 1.0f / sqrtf((float)deg);
+  const float g = __builtin_amdgcn_rsqf((float)deg);   // v_rsq_f32 (1 ulp; the same in every attention kernel)
   if (mode == 0) return a * g;
   if (mode == 1) return a + g;
   return a;

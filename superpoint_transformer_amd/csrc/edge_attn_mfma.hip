@@ -110,7 +110,7 @@ __device__ __forceinline__ float xg_max_sw(float v) {
 }
 
 __device__ __forceinline__ float qk_scale_of(int mode, float a, int deg) {
-  const float g = 1.0f / sqrtf((float)deg);
+  const float g = __builtin_amdgcn_rsqf((float)deg);   // v_rsq_f32 (1 ulp; the same in every attention kernel)
   if (mode == 0) return a * g;
   if (mode == 1) return a + g;
   return a;
@@ -536,6 +536,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_fwd_mfma_kernel(
     qs4v[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
     zero4v[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
+  const float bvg = g == 0 ? bv4[0] : (g == 1 ? bv4[1] : (g == 2 ? bv4[2] : bv4[3]));
   float qs4[NB], m[NB], z[NB], acc[NB];       // m: the running maximum times log2(e)
   while (P.cur.valid) {
     wait_vmem_all();  // tile `cur`, nxt's indices and cur's q row have landed
@@ -612,17 +613,30 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_fwd_mfma_kernel(
       }
     }
     if (cur.t0 + TE >= cur.end) {  // last tile of the node
-#pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        const float zt = xg_sum_sw(z[b]);
-        const float at = xg_sum_sw(acc[b]);
-        // (a node without edges keeps out = 0: no weight mass, no bias)
-        const float bvn = (BF3 && cur.end > cur.start) ? bv4[b] : 0.f;
-        if (g == 0) out[cur.s * 64 + 16 * b + c] = fmaf(at, __builtin_amdgcn_rcpf(zt + 1e-16f), bvn);
-        if (g == 0 && (c & 3) == 0 && mbuf) {
-          mbuf[cur.s * 16 + 4 * b + (c >> 2)] = m[b] * LN2;
-          zbuf[cur.s * 16 + 4 * b + (c >> 2)] = zt;
-        }
+      // Reduce-scatter over the four lane groups (round 6): block b's totals are only needed where
+      // they are stored - lane group b writes out[s][16 b + c], i.e. the wave writes the node's
+      // 256-byte row with ONE instruction.  permlane16_swap(X0, X1) -> {[X0.r0 X1.r0 X0.r2 X1.r2],
+      // [X0.r1 X1.r1 X0.r3 X1.r3]}: their sum holds X0's (rows 0, 2) and X1's (rows 1, 3) partial
+      // sums of two groups; the same between the two pair sums with permlane32_swap leaves block
+      // g's total in lane group g - 3 swaps + 3 adds for four values and no register copies
+      // (8 instructions PER VALUE with the all-to-all sums, 4 x 16-lane stores).
+      auto rscat = [](float x0, float x1, float x2, float x3) {
+        const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x0), __float_as_uint(x1), false, false);
+        const auto bq = __builtin_amdgcn_permlane16_swap(__float_as_uint(x2), __float_as_uint(x3), false, false);
+        const float p01 = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+        const float p23 = __uint_as_float(bq[0]) + __uint_as_float(bq[1]);
+        const auto t = __builtin_amdgcn_permlane32_swap(__float_as_uint(p01), __float_as_uint(p23), false, false);
+        return __uint_as_float(t[0]) + __uint_as_float(t[1]);
+      };
+      const float zt = rscat(z[0], z[1], z[2], z[3]);          // lane group g: block g
+      const float at = rscat(acc[0], acc[1], acc[2], acc[3]);
+      const float mg = g == 0 ? m[0] : (g == 1 ? m[1] : (g == 2 ? m[2] : m[3]));
+      // (a node without edges keeps out = 0: no weight mass, no bias)
+      const float bvn = (BF3 && cur.end > cur.start) ? bvg : 0.f;
+      out[cur.s * 64 + lane] = fmaf(at, __builtin_amdgcn_rcpf(zt + 1e-16f), bvn);
+      if ((c & 3) == 0 && mbuf) {
+        mbuf[cur.s * 16 + 4 * g + (c >> 2)] = mg * LN2;
+        zbuf[cur.s * 16 + 4 * g + (c >> 2)] = zt;
       }
     }
     P.rotate();
@@ -1511,7 +1525,13 @@ void attn_fwd_mfma_launch(const float* qkv, int64_t n, const int32_t* erowptr,
                           const float* Wv, const float* bv, int scale_mode, float scale_a,
                           float* out, float* m, float* z, int split_bf16, hipStream_t stream) {
   const int64_t blocks = ceil_div(n, mfma::WAVES);
-  const int grid = (int)(blocks < 256 * 2 * 4 ? blocks : 256 * 2 * 4);
+  // 2 048 workgroups (four resident rounds of two per CU) at scene sizes; ONE round (512) up to
+  // 131 072 nodes (<= 64 nodes per wave): every workgroup pays the prologue - the weight fragments
+  // of three projections, ~100 registers of loads and splits per wave - and a second round that
+  // is not full leaves most CUs idle behind it (a train batch's 14 500-node level: 72 -> 51 us
+  // with 512 workgroups instead of 2 048, `profiles/r06*_sceneT_captured_kernel_stats.csv`)
+  const int64_t want = n <= 131072 ? 512 : 256 * 2 * 4;
+  const int grid = (int)(blocks < want ? blocks : want);
   // XCD bands only where the grid is the capped one (a multiple of 8) and a band outlasts a round
   const int bands = attn_xcd_bands() && grid == 256 * 2 * 4 && n >= 8 * (int64_t)grid * mfma::WAVES;
   if (split_bf16 == 3)
