@@ -8,6 +8,7 @@
 // centres accumulate in f64, so they are at least as accurate as the f32
 // scatter they replace.
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.hpp"
 
@@ -259,12 +260,69 @@ __global__ __launch_bounds__(256) void usn_assemble_kernel(
   }
 }
 
+// Round 6: the same rows, 256 (wide rows: 64 / 32) at a time per workgroup in two phases.  Phase 1: one THREAD per row
+// forms the row's header chunk [diam | normalised pos] (idx -> centre / diameter: two dependent
+// round trips, all 256 lanes busy with them instead of every third one) into LDS; phase 2: one
+// thread per 16-byte output chunk as before - the header out of LDS, the copies of x from loads
+// that were issued BEFORE phase 1 (they travel under its two round trips).  Same values bit for
+// bit (the same expressions per element).
+template <int CC4>
+__global__ __launch_bounds__(256) void usn_assemble_rows_kernel(
+    const float* __restrict__ pos, const int64_t* __restrict__ idx,
+    const float* __restrict__ center, const float* __restrict__ diam,
+    const float* __restrict__ x, int64_t n, float* __restrict__ out) {
+  constexpr int R = CC4 <= 4 ? 256 : (CC4 <= 20 ? 64 : 32), CX4 = CC4 - 1;   // ~4 chunks per thread
+  constexpr int PER = (R * CC4 + 255) / 256;             // output chunks per thread and block of rows
+  __shared__ float4 hdr[R];
+  const int t = threadIdx.x;
+  const int64_t nblk = (n + R - 1) / R;
+  for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const int64_t row0 = blk * R;
+    const int rows = (int)((n - row0) < R ? (n - row0) : R);
+    // the x chunks of this thread's output chunks: requested first
+    float4 xv[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int q = t + 256 * k;
+      const int r = q / CC4, j = q - r * CC4;
+      // (unconditional: a header chunk / a chunk past the end reads a valid chunk it never uses)
+      const int rc = r < rows ? r : rows - 1, jc = j > 0 ? j - 1 : 0;
+      xv[k] = *(reinterpret_cast<const float4*>(x) + ((row0 + rc) * CX4 + jc));
+    }
+    if (t < rows) {
+      const int64_t i = row0 + t;
+      const int64_t sg = idx ? idx[i] : 0;
+      const f3 p = *reinterpret_cast<const f3*>(pos + i * 3);
+      const f3 ce = *reinterpret_cast<const f3*>(center + sg * 3);
+      const float dm = diam[sg], d = dm + 1e-2f;
+      hdr[t] = make_float4(dm, (p.x - ce.x) / d, (p.y - ce.y) / d, (p.z - ce.z) / d);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int q = t + 256 * k;
+      const int r = q / CC4, j = q - r * CC4;
+      if (q < rows * CC4) {
+        float4 v = xv[k];
+        if (j == 0) v = hdr[r];                          // (values, not a select between two address spaces)
+        *(reinterpret_cast<float4*>(out) + (row0 * CC4 + q)) = v;
+      }
+    }
+    __syncthreads();                                     // hdr is rewritten by the next block of rows
+  }
+}
+
 }  // namespace spt
 
 using namespace spt;
 
 // slices per segment of the split statistics (few huge segments): ~2 048 rows per block, the whole
 // launch within 4 096 blocks and 65 535 segments
+// SPT_USN_ROWS=0: the one-thread-per-chunk assemble kernel of round 3 (A/B switch)
+static bool usn_rows_kernel() {
+  static const bool on = [] { const char* e = getenv("SPT_USN_ROWS"); return e ? atoi(e) != 0 : true; }();
+  return on;
+}
 static int usn_slices(int64_t n, int64_t num_seg) {
   if (num_seg < 1 || num_seg > 65535) return 1;
   const int64_t avg = n / num_seg;
@@ -366,7 +424,15 @@ static int usn_launch(const float* pos, const int64_t* idx, const int32_t* perm,
   {
     const int64_t chunks = n * (cx / 4 + 1);
     const bool i32 = chunks + (int64_t)256 * 4096 < ((int64_t)1 << 32);   // 32-bit index arithmetic
-    if (i32 && cx == 8)
+    const int64_t rblk = ceil_div(n, (int64_t)(cx == 8 ? 256 : (cx == 64 ? 64 : 32)));
+    const int rgrid = (int)(rblk < 256 * 16 ? rblk : 256 * 16);
+    if (cx == 8 && usn_rows_kernel())
+      usn_assemble_rows_kernel<3><<<rgrid, 256, 0, stream>>>(pos, idx, center, diam, x, n, xcat);
+    else if (cx == 64 && usn_rows_kernel())
+      usn_assemble_rows_kernel<17><<<rgrid, 256, 0, stream>>>(pos, idx, center, diam, x, n, xcat);
+    else if (cx == 128 && usn_rows_kernel())
+      usn_assemble_rows_kernel<33><<<rgrid, 256, 0, stream>>>(pos, idx, center, diam, x, n, xcat);
+    else if (i32 && cx == 8)
       usn_assemble_kernel<uint32_t, 3><<<stream_grid(chunks, 256), 256, 0, stream>>>(
           pos, idx, center, diam, x, cx / 4, n, xcat);
     else if (i32 && cx == 64)
