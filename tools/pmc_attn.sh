@@ -1,7 +1,7 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-OUT=gpurun_out/r06k_pmc_attention_sq.txt
+OUT=gpurun_out/${PMC_ATTN_OUT:-r06k_pmc_attention_sq.txt}
 : > $OUT
 i=0
 for G in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM SQ_INSTS_VALU" \
