@@ -250,8 +250,10 @@ def make_nag(scene="S", seed=1234, device="cpu", sizes=None, point_dim=8,
         pos0, b0, si0 = pos0[o0], b0[o0], si0[o0]
     elif order != "storage":
         raise ValueError("order must be 'storage', 'morton' or 'grouped'")
-    if b > 1:
-        # what NAGBatch.from_nag_list knows on the host (Batch.ptr): the clouds' node ranges
+    if b >= 1:
+        # what NAGBatch.from_nag_list knows on the host (Batch.ptr): the clouds' node ranges (a batch
+        # of ONE cloud has them too - data.py from_nag_list; without them every step would read the
+        # id range of each batch vector back from the device before the folded pre-norm kernels)
         for bt in (b0, b1, b2):
             bt._spt_host_ptr = [0] + torch.cumsum(torch.bincount(bt, minlength=b), 0).tolist()
     ns1 = torch.bincount(si0, minlength=n1)
