@@ -74,8 +74,14 @@ constexpr int WB_ELEMS = 192 * WB_LD;
 //   follower: [top] k / v rows (4), old d edge_attr rows of tile k (2; accumulating calls only)
 //             [core] dq rows (2)  [mid] source records of tile k+1 (5)
 //             [tail] d edge_attr rows (2), dk / dv atomics (0..16)
-constexpr int N_DQ = 2;                 // dq stores per tile and wave (f32 rows; bf16 rows: 1)
-constexpr int N_GATHER = 5;
+// measurement builds (tools/build_variant.sh to_skip<bits> edge_attn_to.hip ... -DSPT_TO_SKIP=<bits>,
+// tools/to_variants.sh; the results are wrong by design, the default 0 changes nothing):
+// 1 no dk / dv atomics, 2 no target rows, 4 no dq stores, 8 no record gathers, 16 no d edge_attr stores
+#ifndef SPT_TO_SKIP
+#define SPT_TO_SKIP 0
+#endif
+constexpr int N_DQ = (SPT_TO_SKIP & 4) ? 0 : 2;   // dq stores per tile and wave (f32 rows; bf16 rows: 1)
+constexpr int N_GATHER = (SPT_TO_SKIP & 8) ? 0 : 5;
 
 __device__ __forceinline__ void lds_dma16(const float* g, float* lds) {
   const unsigned a = __builtin_amdgcn_readfirstlane(
@@ -337,11 +343,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_bwd_to_kernel(
   constexpr bool LO = PREC == 3;
   // the bf16 mode streams its dq rows as bf16: 64 bytes per edge and wave, ONE store per tile
   constexpr bool DQ16 = PREC == 1;
-  constexpr int NDQ = DQ16 ? 1 : N_DQ;
+  constexpr int NDQ = (SPT_TO_SKIP & 4) ? 0 : (DQ16 ? 1 : N_DQ);
   // ... and gathers its source records as bf16 (q * scale | gout: 128 bytes per edge and wave
   // instead of 256; (delta, ml) stay f32): three requests per tile instead of five
   constexpr bool R16 = PREC == 1;
-  constexpr int NG = R16 ? 3 : N_GATHER;
+  constexpr int NG = (SPT_TO_SKIP & 8) ? 0 : (R16 ? 3 : N_GATHER);
   __shared__ __attribute__((aligned(16))) float lds_wave[WAVES][L_END];
   __shared__ __attribute__((aligned(16))) float lds_pair[WAVES / 2][P_END];
   __shared__ __attribute__((aligned(16))) __bf16 wb_hi[WB_ELEMS];
@@ -448,6 +454,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_bwd_to_kernel(
     // chunks per edge at position chunk ^ edge (4 edges per instruction), (delta, ml) as 4 chunks
     // per edge at position (chunk + edge / 4) % 4 (16 edges in one instruction)
     auto issue_gather = [&](int slot) {
+      if constexpr ((SPT_TO_SKIP & 8) != 0) return;
       const int* ids = ids_ring + slot * IDS;
       float* G = L + L_G;
       if constexpr (R16) {
@@ -483,6 +490,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_bwd_to_kernel(
     // target: L1 hits; asm: invisible to the compiler's wait-count pass, waited for by hand)
     f32x4 nk[NBW], nv[NBW];
     auto issue_node = [&](int slot) {
+      if constexpr ((SPT_TO_SKIP & 2) != 0) return;
       const int* ids = ids_ring + slot * IDS;
       const int64_t tc = ids[16 + c];
       const float* kk = qkv + tc * LD + 64 + 32 * hh + 4 * g;
@@ -693,7 +701,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_bwd_to_kernel(
           };
           const u32x4 w4 = {pk(v0[0], v0[1]), pk(v0[2], v0[3]), pk(v1[0], v1[1]), pk(v1[2], v1[3])};
           const int64_t sp = ids[48 + e];
-          if (t * TE + e < E)
+          if (t * TE + e < E && !(SPT_TO_SKIP & 4))
             __builtin_nontemporal_store(
                 w4, reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(dqt) + sp * 64 + 32 * hh + 8 * cp));
         } else {
@@ -704,7 +712,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_bwd_to_kernel(
             const f32x4 v4 = *reinterpret_cast<const f32x4*>(Gq + j * 256 + lane * 4);
             const int64_t sp = ids[48 + e];
             // rows beyond the edge list own no row (masked per lane: the instruction still issues)
-            if (t * TE + e < E)
+            if (t * TE + e < E && !(SPT_TO_SKIP & 4))
               __builtin_nontemporal_store(v4, reinterpret_cast<f32x4*>(dqt + sp * 64 + 32 * hh + 4 * x));
           }
         }
@@ -802,13 +810,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_bwd_to_kernel(
         // stores and the next tile's gathers - but the compiler branches around a dq store whose
         // lanes are all masked (f32 rows: the second store of a last tile with <= 8 edges), so
         // only NDQ - 1 of them are counted on there (the bf16 row store always has live lanes)
-        if (rd_old) wait_vm<NG + (DQ16 ? NDQ : NDQ - 1)>();
+        if (rd_old) wait_vm<NG + (NDQ == 0 ? 0 : (DQ16 ? NDQ : NDQ - 1))>();
         if (acc) {
           C2[0] += *reinterpret_cast<const f32x4*>(P + P_GEA + lane * 4);
           C2[1] += *reinterpret_cast<const f32x4*>(P + P_GEA + 256 + lane * 4);
         }
         float* row = gea + (int64_t)ids[c] * F + 4 * g;
-        if (t * TE + c < E) {
+        if (t * TE + c < E && !(SPT_TO_SKIP & 16)) {
           *reinterpret_cast<f32x4*>(row) = C2[0];
           *reinterpret_cast<f32x4*>(row + 16) = C2[1];
         }
@@ -816,7 +824,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void attn_bwd_to_kernel(
       // dk / dv of the tile's TARGET nodes; the only data-dependent memory instructions: issued last
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        if (4 * g + r < nn) {
+        if (4 * g + r < nn && !(SPT_TO_SKIP & 1)) {
           float* row = gqkv + (int64_t)nd4[r] * LD + 32 * hh + c;
 #pragma unroll
           for (int bl = 0; bl < NBW; ++bl) {
