@@ -370,6 +370,17 @@ int spt_attn_mirror_prepare(const int64_t* edge_index, const int32_t* eperm, int
 int spt_attn_pack_tile_ids_mirror(const int32_t* eperm, const int32_t* tgt_sorted,
                                   const int32_t* src_sorted, const int32_t* inv, int64_t e,
                                   int64_t pairs, int32_t* tile_ids, spt_stream_t stream);
+/* Round 6: operand layout of the head-group decomposition that runs wider head layouts on the
+ * built 16 x (qk 4, value 4) kernels (H = 16 G heads of value dim 4 J; SPT-128 of
+ * configs/experiment/semantic/kitti360.yaml:22-27: G = 1, J = 2 - src/nn/attention.py:202-315 is
+ * linear in the value dims, so the passes are exact).  qkv rows are [q 64 G | k 64 G | v H x 4 J].
+ * spt_attn_split_pack_f32: qa [G J, n, 192] <- per pass p = g J + j the columns
+ *   [q_g | k_g | v_g[:, 4 j .. 4 j + 3]] of every row (what one index gather + one transposing copy did);
+ * spt_attn_split_grad_f32: gqkv [n, 128 G + 64 G J] <- the passes' gradients gqa [G J, n, 192], the
+ *   q / k columns summed over the J slices of their head group in ascending j, the v columns copied
+ *   (what a sum, three permuting copies and a cat did).  16-byte aligned pointers. */
+int spt_attn_split_pack_f32(const float* qkv, int64_t n, int G, int J, float* qa, spt_stream_t stream);
+int spt_attn_split_grad_f32(const float* gqa, int64_t n, int G, int J, float* gqkv, spt_stream_t stream);
 int spt_edge_attn_bwd_f32(const float* qkv, int64_t n, int H, int D, int Dv,
                           const int32_t* erowptr, const int32_t* eperm,
                           const int32_t* tgt_sorted, int64_t e,

@@ -65,6 +65,8 @@ SIGNATURES = {
     "spt_attn_pack_tile_ids_m": (_int, [_p, _p, _p, _p, _i64, _int, _p, _p]),
     "spt_attn_mirror_prepare": (_int, [_p, _p, _i64, _i64, _p, _p, _p]),
     "spt_attn_pack_tile_ids_mirror": (_int, [_p, _p, _p, _p, _i64, _i64, _p, _p]),
+    "spt_attn_split_pack_f32": (_int, [_p, _i64, _int, _int, _p, _p]),
+    "spt_attn_split_grad_f32": (_int, [_p, _i64, _int, _int, _p, _p]),
     "spt_edge_attn_bwd_f32": (_int, [_p, _i64, _int, _int, _int, _p, _p, _p, _i64, _p, _int,
                                      _p, _p, _p, _p, _p, _p, _int, _f32, _p, _p, _p, _p,
                                      _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),

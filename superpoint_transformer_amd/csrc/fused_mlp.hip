@@ -203,7 +203,9 @@ __device__ __forceinline__ void load_table(float* dst, const float* __restrict__
     if (am) { am += (size_t)gph_ * K; sc += (size_t)gph_ * K; }               \
     partial += (size_t)run_ * gridDim.x * (2 * (N_) + 1);                     \
   }
-#define SPT_FMLP_RUN_BWD(N_, NW_)                                             \
+#define SPT_FMLP_RUN_BWD(N_, NW_) SPT_FMLP_RUN_BWD_T(N_, NW_, NW_)
+/* TPB_: weight-gradient tables a workgroup writes (NW_ per-wave tables, or 1 when it sums them first) */
+#define SPT_FMLP_RUN_BWD_T(N_, NW_, TPB_)                                     \
   if (rt.n > 0) {                                                             \
     const int run_ = blockIdx.y, gph_ = rt.g[run_];                           \
     r0 = rt.r0[run_];                                                         \
@@ -211,7 +213,7 @@ __device__ __forceinline__ void load_table(float* dst, const float* __restrict__
     am += (size_t)gph_ * (N_); sc += (size_t)gph_ * (N_);                     \
     c1 += (size_t)gph_ * (N_); c2 += (size_t)gph_ * (N_); c3 += (size_t)gph_ * (N_); \
     if (pam) { pam += (size_t)gph_ * K; psc += (size_t)gph_ * K; }            \
-    gw_partial += (size_t)run_ * gridDim.x * (NW_) * (N_) * K;                \
+    gw_partial += (size_t)run_ * gridDim.x * (TPB_) * (N_) * K;               \
     if (pstat_partial) pstat_partial += (size_t)run_ * gridDim.x * (NW_) * (2 * K + 1); \
   }
 
@@ -881,6 +883,14 @@ __global__ __launch_bounds__(WAVES_X3 * 64, 2) void fwd_kernel_x3(
 // bandwidth.  Needs K % 4 == 0 (16-byte row chunks) and one wave per SIMD (the prefetch
 // registers do not fit twice into 256).
 // H16 / X16 (bf16 mode's storage option): h / xprev hold bf16 values (gy, gx stay f32).
+// Round 6: the weight-gradient tables of a workgroup's waves are summed in LDS (wave 0, 1, ... in
+// turn: a fixed order) and leave as ONE table per workgroup where the staging buffer of the x tiles
+// holds N rows (every built shape but N = 128 on 4-wave workgroups).  The per-wave tables
+// were 4 - 8 x the bytes: at the train batch a 35 000-row layer wrote 72 MB of partial tables for
+// 18 MB of input and its post launch read them back (0.39 ms of a 6.2 ms step in 13 post launches).
+__host__ __device__ constexpr bool fmlp_bf_wg_reduce(int K4, int NBK, int NW) {
+  return NBK * 16 <= NW * TR && K4 > 0;          // N rows of the tiles' row stride fit the buffer
+}
 template <int K4, int NBK, bool NEED_GX, int NW, bool LO, bool POOLED = false, bool PIPE = false,
           bool H16 = false, bool X16 = false>
 __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_kernel_bf(
@@ -896,7 +906,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_kernel_bf(
   constexpr int KP = K4 * 4, KB = (KP + 15) / 16, KPP = KB * 16, N = NBK * 16;
   constexpr int NS = (N + 31) / 32, NP32 = NS * 32;
   constexpr int LDG = NP32 + 4, LDX = KPP + 4, LDT = NP32 + 8;
-  SPT_FMLP_RUN_BWD(N, NW)
+  constexpr bool WGR = fmlp_bf_wg_reduce(K4, NBK, NW);
+  SPT_FMLP_RUN_BWD_T(N, NW, (WGR ? 1 : NW))
   __shared__ __attribute__((aligned(16))) float g_lds[NW][TR * LDG];   // gh tile
   __shared__ __attribute__((aligned(16))) float x_lds[NW][TR * LDX];   // RAW h_prev tile
   __shared__ __attribute__((aligned(16))) __bf16 wt_hi[NEED_GX ? KPP * LDT : 8];
@@ -1187,16 +1198,45 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_kernel_bf(
            (unsigned long)prof[1], (unsigned long)prof[2], (unsigned long)prof[3],
            (unsigned long)prof[4], (unsigned long)prof[5]);
 #endif
-  float* gwp = gw_partial + (size_t)wave * N * K;
+  if constexpr (WGR) {
+    // waves 1 .. NW - 1 hand their tables to wave 0 through the (now free) x tile buffer, one after
+    // the other: plain stores by the giver, plain loads + adds by wave 0 (both pipeline; a
+    // read-modify-write per element in LDS measured +50 us on a 100 us kernel), fixed order
+    __syncthreads();                              // every wave is through its tiles
+    float* red = &x_lds[0][0];                    // [N][LDX]: row stride = 4 (mod 16) floats, no bank conflicts
+    for (int w = 1; w < NW; ++w) {
+      if (wid == w) {
 #pragma unroll
-  for (int nb = 0; nb < NBK; ++nb)
+        for (int nb = 0; nb < NBK; ++nb)
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb)
+          for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int k = 16 * kb + c;
-        if (k < K) gwp[(size_t)(16 * nb + 4 * g + r) * K + k] = C3[nb][kb][r];
+            for (int r = 0; r < 4; ++r) red[(16 * nb + 4 * g + r) * LDX + 16 * kb + c] = C3[nb][kb][r];
       }
+      __syncthreads();
+      if (wid == 0) {
+#pragma unroll
+        for (int nb = 0; nb < NBK; ++nb)
+#pragma unroll
+          for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) C3[nb][kb][r] += red[(16 * nb + 4 * g + r) * LDX + 16 * kb + c];
+      }
+      __syncthreads();
+    }
+  }
+  if (!WGR || wid == 0) {
+    float* gwp = gw_partial + (size_t)(WGR ? (int64_t)blockIdx.x : wave) * N * K;
+#pragma unroll
+    for (int nb = 0; nb < NBK; ++nb)
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int k = 16 * kb + c;
+          if (k < K) gwp[(size_t)(16 * nb + 4 * g + r) * K + k] = C3[nb][kb][r];
+        }
+  }
   if (pstat_partial) {
     double* pp = pstat_partial + (size_t)wave * (2 * K + 1);
 #pragma unroll
@@ -1508,7 +1548,7 @@ int fmlp_dma_bwd_launch(bool pooled, bool lo, const float* gy, const float* h, F
                         const float* pbs, float pslope, const float* W, float* gx,
                         float* gw_partial, double* pstat_partial, const int32_t* perm,
                         const int32_t* pos_seg, const float* gout, const int32_t* arg,
-                        hipStream_t stream, bool s16 = false);
+                        hipStream_t stream, bool s16 = false, int* gw_tabs = nullptr);
 }  // namespace spt
 
 using namespace spt;
@@ -1821,6 +1861,7 @@ static int fmlp_bwd_impl(bool pooled, const float* gy, const float* gout, const 
     constexpr int NWB = (a * b > 128) ? 4 : (big ? 8 : 4);                                       \
     gx_ = cap_grid(grid_for_nw(max_rows, (a * b > 128) ? 1 : (big ? ((a * b <= 32) ? 2 : 1) : 4), NWB), NWB); \
     nwv = NWB;                                                                                   \
+    gw_tabs = gx_ * (fmlp_bf_wg_reduce(a, b, NWB) ? 1 : NWB);                                    \
     const dim3 grid((unsigned)gx_, (unsigned)nr);                                                \
     if (g_fmlp_mode == 3)                                                                        \
       bwd_kernel_bf<a, b, true, NWB, false, true><<<grid, NWB * 64, 0, stream>>>(                \
@@ -1843,9 +1884,11 @@ static int fmlp_bwd_impl(bool pooled, const float* gy, const float* gout, const 
     if (g_fmlp_split_bf16) {                                                                     \
       gx_ = cap_grid(grid_for_nw(max_rows, (a * b > 128) ? 1 : (big ? ((a * b <= 32) ? 2 : 1) : 4), NWB), NWB); \
       nwv = NWB;                                                                                 \
+      gw_tabs = gx_ * (fmlp_bf_wg_reduce(a, b, NWB) ? 1 : NWB);                                  \
     } else {                                                                                     \
       gx_ = cap_grid(grid_for_nw(max_rows, big ? ((a * b <= 32) ? 2 : 1) : 4, NWV), NWV);        \
       nwv = NWV;                                                                                 \
+      gw_tabs = gx_ * NWV;                                                                       \
     }                                                                                            \
     const dim3 grid((unsigned)gx_, (unsigned)nr);                                                \
     if (g_fmlp_mode == 3 && gx)                                                                  \
@@ -1873,7 +1916,9 @@ static int fmlp_bwd_impl(bool pooled, const float* gy, const float* gout, const 
           gy, h, 0, 0, am, scale, bias, slope, c1, c2, c3, xprev, K, pre_am, pre_scale,          \
           pre_bias, pre_slope, W, nullptr, gwp, nullptr, rt);                                    \
   }
-  int per_run = 0;                              // wave records per run
+  int per_run = 0;                              // wave records per run (statistics tables)
+  int gw_tabs = 0;                              // weight-gradient tables per run (one per wave, or
+                                                // one per workgroup: fmlp_bf_wg_reduce)
   const bool h16 = mode >= 0 && (mode & SPT_FMLP_H_BF16), x16 = mode >= 0 && (mode & SPT_FMLP_X_BF16);
   if (h16 || x16) {
     SPT_CHECK_ARG(g_fmlp_mode == 3 && h16 && spt_fused_linear_storage_supported(K, N) &&
@@ -1885,6 +1930,7 @@ static int fmlp_bwd_impl(bool pooled, const float* gy, const float* gout, const 
     constexpr int NWB = (a * b > 128) ? 4 : (big ? 8 : 4);                                       \
     gx_ = cap_grid(grid_for_nw(max_rows, (a * b > 128) ? 1 : (big ? ((a * b <= 32) ? 2 : 1) : 4), NWB), NWB); \
     nwv = NWB;                                                                                   \
+    gw_tabs = gx_ * (fmlp_bf_wg_reduce(a, b, NWB) ? 1 : NWB);                                    \
     const dim3 grid((unsigned)gx_, (unsigned)nr);                                                \
     if (x16)                                                                                     \
       bwd_kernel_bf<a, b, true, NWB, false, true, false, true, true><<<grid, NWB * 64, 0, stream>>>( \
@@ -1902,6 +1948,7 @@ static int fmlp_bwd_impl(bool pooled, const float* gy, const float* gout, const 
     constexpr int NWB = (a * b > 128) ? 4 : NWV;                                                 \
     gx_ = cap_grid(grid_for_nw(max_rows, (a * b > 128) ? 1 : (big ? ((a * b <= 32) ? 2 : 1) : 4), NWB), NWB); \
     nwv = NWB;                                                                                   \
+    gw_tabs = gx_ * (fmlp_bf_wg_reduce(a, b, NWB) ? 1 : NWB);                                    \
     const dim3 grid((unsigned)gx_, (unsigned)nr);                                                \
     if (gx && x16)                                                                               \
       bwd_kernel_bf<a, b, true, NWB, false, false, false, true, true><<<grid, NWB * 64, 0, stream>>>( \
@@ -1923,7 +1970,7 @@ static int fmlp_bwd_impl(bool pooled, const float* gy, const float* gout, const 
     if (x16 && gx && fmlp_dma_of(mode) && fmlp_dma_supported(K, N)) {
       per_run = fmlp_dma_bwd_launch(pooled, false, gy, h, rt, max_rows, N, am, scale, bias, slope, c1,
                                     c2, c3, xprev, K, pre_am, pre_scale, pre_bias, pre_slope, W, gx,
-                                    gwp, pstp, perm, pos_seg, gout, arg, stream, true);
+                                    gwp, pstp, perm, pos_seg, gout, arg, stream, true, &gw_tabs);
     } else {
       SPT_FMLP_ST_POOLED_SHAPES(XSP)
       SPT_FMLP_ST_SHAPES(XSD)
@@ -1934,7 +1981,7 @@ static int fmlp_bwd_impl(bool pooled, const float* gy, const float* gout, const 
   } else if (g_fmlp_split_bf16 && gx && fmlp_dma_of(mode) && fmlp_dma_supported(K, N)) {
     per_run = fmlp_dma_bwd_launch(pooled, g_fmlp_mode != 3, gy, h, rt, max_rows, N, am, scale, bias,
                                   slope, c1, c2, c3, xprev, K, pre_am, pre_scale, pre_bias, pre_slope,
-                                  W, gx, gwp, pstp, perm, pos_seg, gout, arg, stream);
+                                  W, gx, gwp, pstp, perm, pos_seg, gout, arg, stream, false, &gw_tabs);
   } else if (pooled) {
     SPT_FMLP_POOLED_SHAPES(XP)
     per_run = gx_ * nwv;
@@ -1948,7 +1995,7 @@ static int fmlp_bwd_impl(bool pooled, const float* gy, const float* gout, const 
   // ONE post launch: the weight gradient's sum, the previous layer's statistics and - prev_norm -
   // that layer's backward tables (they were three launches: two here, gn_bwd_tables_kernel behind
   // a second C entry)
-  bwd_post_launch(gwp, per_run * nr, N * K, gW, accumulate, pst, fmlp_groups(rt, num_graphs, per_run), K,
+  bwd_post_launch(gwp, gw_tabs * nr, N * K, gW, accumulate, pst, fmlp_groups(rt, num_graphs, per_run), K,
                   num_graphs, prev_total, prev_norm, stream);
   SPT_CHECK_LAUNCH();
   return 0;

@@ -144,7 +144,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void bwd_dma_kernel(
     am += (size_t)gph_ * N; sc += (size_t)gph_ * N;
     c1 += (size_t)gph_ * N; c2 += (size_t)gph_ * N; c3 += (size_t)gph_ * N;
     if (pam) { pam += (size_t)gph_ * K; psc += (size_t)gph_ * K; }
-    gw_partial += (size_t)run_ * gridDim.x * NW * N * K;
+    gw_partial += (size_t)run_ * gridDim.x * N * K;          // one table per workgroup (epilogue)
     if (pstat_partial) pstat_partial += (size_t)run_ * gridDim.x * NW * (2 * K + 1);
   }
   constexpr int HI = TR * NC / 64, XI = TR * KC / 64;   // DMA instructions per tile (h, x)
@@ -482,14 +482,45 @@ __global__ __launch_bounds__(NW * 64, OCC) void bwd_dma_kernel(
     load_ids(t + 2 * nwaves);
   }
   wait_vm0();
-  float* gwp = gw_partial + (size_t)wave * N * K;
+  // Round 6: ONE weight-gradient table per workgroup - waves 1 .. NW - 1 hand theirs to wave 0
+  // through the (now free) tile buffers, one after the other (plain stores, plain loads + adds; the
+  // order of fused_mlp.hip's bwd_kernel_bf, whose tables this kernel's equal bit for bit)
+  {
+    constexpr int LDR = K + 4;                    // row stride = 4 (mod 16) floats: no bank conflicts
+    static_assert(N * LDR <= NW * (W_H + W_X + 2 * W_G), "the table fits the tile buffers");
+    __syncthreads();                              // every wave is through its tiles
+    float* red = &lw[0][0];
+    for (int w = 1; w < NW; ++w) {
+      if (wid == w) {
 #pragma unroll
-  for (int nb = 0; nb < NBK; ++nb)
+        for (int nb = 0; nb < NBK; ++nb)
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb)
+          for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        gwp[(size_t)(16 * nb + 4 * g + r) * K + 16 * kb + c] = C3[nb][kb][r];
+            for (int r = 0; r < 4; ++r) red[(16 * nb + 4 * g + r) * LDR + 16 * kb + c] = C3[nb][kb][r];
+      }
+      __syncthreads();
+      if (wid == 0) {
+#pragma unroll
+        for (int nb = 0; nb < NBK; ++nb)
+#pragma unroll
+          for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) C3[nb][kb][r] += red[(16 * nb + 4 * g + r) * LDR + 16 * kb + c];
+      }
+      __syncthreads();
+    }
+  }
+  if (wid == 0) {
+    float* gwp = gw_partial + (size_t)blockIdx.x * N * K;
+#pragma unroll
+    for (int nb = 0; nb < NBK; ++nb)
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          gwp[(size_t)(16 * nb + 4 * g + r) * K + 16 * kb + c] = C3[nb][kb][r];
+  }
   if (pstat_partial) {
     double* pp = pstat_partial + (size_t)wave * (2 * K + 1);
 #pragma unroll
@@ -512,8 +543,9 @@ bool fmlp_dma_supported(int K, int N) {
 }
 
 // Launches the layer's backward; returns the number of per-wave partial tables written
-// (gw_partial: [waves][N x K], pstat_partial: [waves][2 K + 1] or null), 0 if (K, N) is not built.
-// returns the number of wave records PER RUN written to the partial tables (0: shape not built)
+// (gw_partial: [workgroups][N x K], pstat_partial: [waves][2 K + 1] or null), 0 if (K, N) is not built.
+// returns the number of wave records PER RUN written to the statistics tables (0: shape not built);
+// *gw_tabs = the weight-gradient tables per run (one per workgroup)
 int fmlp_dma_bwd_launch(bool pooled, bool lo, const float* gy, const float* h, FmlpRuns rt,
                         int64_t max_rows, int N, const float* am, const float* sc, const float* bs,
                         float slope, const float* c1, const float* c2, const float* c3,
@@ -521,7 +553,7 @@ int fmlp_dma_bwd_launch(bool pooled, bool lo, const float* gy, const float* h, F
                         const float* pbs, float pslope, const float* W, float* gx,
                         float* gw_partial, double* pstat_partial, const int32_t* perm,
                         const int32_t* pos_seg, const float* gout, const int32_t* arg,
-                        hipStream_t stream, bool s16) {
+                        hipStream_t stream, bool s16, int* gw_tabs) {
   using namespace fdma;
   const int64_t tiles = (max_rows + TR - 1) / TR;
   const int nr = rt.n < 1 ? 1 : rt.n;
@@ -557,6 +589,7 @@ int fmlp_dma_bwd_launch(bool pooled, bool lo, const float* gy, const float* h, F
       bwd_dma_kernel<KK, NN, NWV, OCC, false, false><<<grid, NWV * 64, 0, stream>>>(                    \
           gy, h, 0, 0, am, sc, bs, slope, c1, c2, c3, xprev, pam, psc, pbs, pslope, W, gx,         \
           gw_partial, pstat_partial, perm, pos_seg, gout, arg, rt);                                \
+    if (gw_tabs) *gw_tabs = (int)blocks;                                                           \
     return (int)blocks * NWV;                                                                      \
   }
   SPT_DMA_CASE(64, 128, 8, 1, 2)

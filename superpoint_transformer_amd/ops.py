@@ -706,8 +706,10 @@ class _EdgeAttentionSplit(torch.autograd.Function):
         if ecsr.n != n or ea.shape[0] != ecsr.e:
             raise ValueError("qkv / edge_attr rows do not match the graph")
         P, Dv, F = G * J, 4 * J, 32
-        cols = _EdgeAttentionSplit._cols(H, G, J, dev)
-        qa = q2[:, cols.view(-1)].view(n, P, 192).transpose(0, 1).contiguous()       # [P, n, 192]
+        qa = torch.empty((P, n, 192), dtype=torch.float32, device=dev)               # [P, n, 192]
+        with torch.cuda.device(dev):
+            st = _lib.lib.spt_attn_split_pack_f32(_lib.ptr(q2), n, G, J, _lib.ptr(qa), _lib.stream_ptr(dev))
+        _lib.check(st, "spt_attn_split_pack_f32")
         Wk2, Wq2 = _f32c(Wk), _f32c(Wq)
         bk2, bq2 = _f32c(bk), _f32c(bq)
         Wva = _f32c(Wv).view(G, 16, J, 4, F).permute(0, 2, 1, 3, 4).contiguous()      # [G, J, 64, F]
@@ -798,11 +800,10 @@ class _EdgeAttentionSplit(torch.autograd.Function):
                     _lib.check(st, "spt_edge_attn_bwd_ex_f32")
                     acc = 1
         # q / k (and their encoders') gradients: the sum over a head group's J value slices
-        g5 = gqa.view(G, J, n, 192)
-        gqk = g5[..., :128].sum(1) if J > 1 else g5[:, 0, :, :128]             # [G, n, 128]
-        gqkv = torch.cat([gqk[..., :64].permute(1, 0, 2).reshape(n, QK),
-                          gqk[..., 64:].permute(1, 0, 2).reshape(n, QK),
-                          g5[..., 128:].reshape(G, J, n, 16, 4).permute(2, 0, 3, 1, 4).reshape(n, H * Dv)], 1)
+        gqkv = torch.empty((n, 2 * QK + H * Dv), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            st = _lib.lib.spt_attn_split_grad_f32(_lib.ptr(gqa), n, G, J, _lib.ptr(gqkv), _lib.stream_ptr(dev))
+        _lib.check(st, "spt_attn_split_grad_f32")
 
         def over_j(t, tail):
             if t is None:

@@ -469,6 +469,39 @@ def test_wider_head_layouts_decompose_onto_the_matrix_pipe_kernels(H, Dv, dev):
         assert (a - r).abs().max().item() <= 1e-5 + 2e-4 * r.abs().max().item()
 
 
+@pytest.mark.parametrize("G,J", [(1, 2), (2, 1), (2, 2), (1, 3)])
+def test_split_operand_kernels_equal_the_index_and_cat_formulation(G, J, dev):
+    """spt_attn_split_pack_f32 / spt_attn_split_grad_f32 (the operand slabs of the head-group
+    passes and the gradient's way back, one kernel each) against the torch formulation they
+    replace: one index gather per pass layout, a sum over the value slices, permutes and a cat.
+    Copies bit for bit; the q / k sums bit for bit for two slices (a + b), 1 ulp-level for three."""
+    from superpoint_transformer_amd import _lib, ops
+    gen = torch.Generator().manual_seed(100 * G + J)
+    n, H = 777, 16 * G
+    QK, Dv, P = 4 * H, 4 * J, G * J
+    qkv = torch.randn(n, 2 * QK + H * Dv, generator=gen).to(dev)
+    cols = ops._EdgeAttentionSplit._cols(H, G, J, dev)
+    ref = qkv[:, cols.view(-1)].view(n, P, 192).transpose(0, 1).contiguous()
+    qa = torch.full((P, n, 192), float("nan"), device=dev)
+    st = _lib.lib.spt_attn_split_pack_f32(_lib.ptr(qkv), n, G, J, _lib.ptr(qa), _lib.stream_ptr(dev))
+    _lib.check(st, "spt_attn_split_pack_f32")
+    assert torch.equal(qa, ref)
+    gqa = torch.randn(P, n, 192, generator=gen).to(dev)
+    g5 = gqa.view(G, J, n, 192)
+    gqk = g5[..., :128].sum(1) if J > 1 else g5[:, 0, :, :128]
+    gref = torch.cat([gqk[..., :64].permute(1, 0, 2).reshape(n, QK),
+                      gqk[..., 64:].permute(1, 0, 2).reshape(n, QK),
+                      g5[..., 128:].reshape(G, J, n, 16, 4).permute(2, 0, 3, 1, 4).reshape(n, H * Dv)], 1)
+    got = torch.full((n, 2 * QK + H * Dv), float("nan"), device=dev)
+    st = _lib.lib.spt_attn_split_grad_f32(_lib.ptr(gqa), n, G, J, _lib.ptr(got), _lib.stream_ptr(dev))
+    _lib.check(st, "spt_attn_split_grad_f32")
+    assert torch.equal(got[:, 2 * QK:], gref[:, 2 * QK:])
+    if J <= 2:
+        assert torch.equal(got, gref)
+    else:
+        assert (got - gref).abs().max().item() <= 1e-6
+
+
 @pytest.mark.parametrize("D,Dv,F", [(2, 1, 16), (4, 2, 32), (2, 4, 18)])
 def test_narrower_head_layouts_are_zero_padded_onto_the_matrix_pipe_kernels(D, Dv, F, dev):
     """The nano family (configs/model/semantic/nano-2.yaml: 16 heads of qk_dim 2, value dim 1,
