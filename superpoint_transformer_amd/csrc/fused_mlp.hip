@@ -2163,7 +2163,8 @@ int fpool_bwd_launch(bool lo, bool x16, const float* gout, const float* raw, con
                      const float* c1, const float* c2, const float* c3, const float* xprev,
                      const float* pam, const float* psc, const float* pbs, float pslope,
                      const float* W, float* gm, float* Mbuf, float* c0buf, float* gx,
-                     float* gw_partial, double* pstat_partial, int max_waves, hipStream_t stream);
+                     float* gw_partial, double* pstat_partial, int max_waves, hipStream_t stream,
+                     int* gw_tabs);
 void fpool_gw_dense_launch(int K, const double* gram, int B, const float* W, int N, int bfw,
                            const float* am, const float* c2, const float* c3, float* gW,
                            hipStream_t stream);
@@ -2255,12 +2256,13 @@ static int fpool_bwd_entry(
   double* pst = (double*)((char*)ws + align_up((size_t)MAX_BWD_WAVES * N * K * 4, 256));
   float* Mbuf = (float*)((char*)ws + align_up(spt_fused_linear_workspace_bytes(K, N), 256));
   float* c0buf = Mbuf + (size_t)FMLP_MAX_RUNS * K * K;
+  int gw_tabs = 0;
   const int per_run = fpool_bwd_launch(prec != 1, x16, gout, raw, argpos, perm, pos_seg, seg_graph, num_seg,
                                        rt, max_rows, num_graphs, K, N, am, scale, bias, slope, c1, c2, c3,
                                        (const float*)xprev, pre_am, pre_scale, pre_bias, pre_slope, W, gm,
-                                       Mbuf, c0buf, gx, gwp, pst, MAX_BWD_WAVES, stream);
+                                       Mbuf, c0buf, gx, gwp, pst, MAX_BWD_WAVES, stream, &gw_tabs);
   SPT_CHECK_ARG(per_run > 0, "no kernel for this variant");
-  bwd_post_launch(gwp, per_run * rt.n, N * K, gW, 0, pst, fmlp_groups(rt, num_graphs, per_run), K,
+  bwd_post_launch(gwp, gw_tabs * rt.n, N * K, gW, 0, pst, fmlp_groups(rt, num_graphs, per_run), K,
                   num_graphs, prev_total, prev_norm, stream);
   fpool_gw_dense_launch(K, gram, num_graphs, W, N, prec == 1, am, c2, c3, gW, stream);
   SPT_CHECK_LAUNCH();

@@ -767,7 +767,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_pool_kernel(
   psc += (size_t)gph * K;
   Mg += (size_t)gph * K * K;
   c0g += (size_t)gph * K;
-  gw_partial += (size_t)run * gridDim.x * (NW / 2) * N * K;
+  // weight-gradient tables: ONE per workgroup (round 6, summed over the workgroup's wave pairs in
+  // the epilogue) in front, one scratch record per wave pair behind them (the loop's dummy stores)
+  float* gw_scratch = gw_partial + (size_t)gridDim.y * gridDim.x * N * K +
+                      (size_t)run * gridDim.x * (NW / 2) * N * K;
+  gw_partial += (size_t)run * gridDim.x * N * K;
   pstat_partial += (size_t)run * gridDim.x * (NW / 2) * (2 * K + 1);
   float* gl = g_lds[wid];
   float* xl = x_lds[wid];
@@ -861,9 +865,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_pool_kernel(
   // its back edge: entering with the same sequence in flight as an iteration leaves behind - the
   // requests above, then as many stores as a tile's gx - keeps every count in the loop exact
   // (otherwise each wait for a prefetched row also drains the previous tile's 4 KBH stores).
-  // The stores go to this pair's own gW record, which is written for real at the end.
+  // The stores go to this pair's own scratch record behind the weight-gradient tables.
   {
-    float* scratch = gw_partial + (size_t)pair * N * K + (size_t)hf * (N / 2) * K;
+    float* scratch = gw_scratch + (size_t)pair * N * K + (size_t)hf * (N / 2) * K;
 #pragma unroll
     for (int i = 0; i < 4 * KBH; ++i) scratch[lane + 64 * i] = 0.f;
   }
@@ -1057,15 +1061,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_pool_kernel(
   for (; t < nfull; t += npairs) tile(std::true_type{}, t);
   if (t < ntiles) tile(std::false_type{}, t);
   }
-  // one record per PAIR: each wave writes its rows of gW and its columns of the statistics
-  float* gwp = gw_partial + (size_t)pair * N * K;
-#pragma unroll
-  for (int nb = 0; nb < NBH; ++nb)
-#pragma unroll
-    for (int kb = 0; kb < KB; ++kb)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        gwp[(size_t)(16 * (nb0 + nb) + 4 * g + r) * K + 16 * kb + c] = C3[nb][kb][r];
   double* pp = pstat_partial + (size_t)pair * (2 * K + 1);
 #pragma unroll
   for (int kb = 0; kb < KBH; ++kb) {
@@ -1077,6 +1072,49 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_pool_kernel(
     }
   }
   if (lane == 0 && hf == 0) pp[2 * K] = (pair == 0) ? (double)(r1 - r0) : 0.0;
+  // gW: one table per WORKGROUP - the pairs 1 .. NW / 2 - 1 hand their tables (each wave its rows)
+  // to pair 0 through the free S-tile buffer, one pair after the other (plain stores, plain loads +
+  // adds, fixed order); statistics: one record per pair, each wave its columns
+  {
+    constexpr int LDR = K + 4;                    // row stride = 4 (mod 16) floats: no bank conflicts
+    static_assert(N * LDR <= NW * TR * LDG, "the table fits the S-tile buffers");
+    const int pr = wid >> 1;
+    __syncthreads();                              // every wave is through its tiles
+    float* red = &g_lds[0][0];
+#pragma unroll 1
+    for (int p = 1; p < NW / 2; ++p) {
+      if (pr == p) {
+#pragma unroll
+        for (int nb = 0; nb < NBH; ++nb)
+#pragma unroll
+          for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              red[(16 * (nb0 + nb) + 4 * g + r) * LDR + 16 * kb + c] = C3[nb][kb][r];
+      }
+      __syncthreads();
+      if (pr == 0) {
+#pragma unroll
+        for (int nb = 0; nb < NBH; ++nb)
+#pragma unroll
+          for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              C3[nb][kb][r] += red[(16 * (nb0 + nb) + 4 * g + r) * LDR + 16 * kb + c];
+      }
+      __syncthreads();
+    }
+    if (pr == 0) {
+      float* gwp = gw_partial + (size_t)blockIdx.x * N * K;
+#pragma unroll
+      for (int nb = 0; nb < NBH; ++nb)
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            gwp[(size_t)(16 * (nb0 + nb) + 4 * g + r) * K + 16 * kb + c] = C3[nb][kb][r];
+    }
+  }
 }
 
 }  // namespace fpool
@@ -1171,7 +1209,8 @@ int fpool_bwd_launch(bool lo, bool x16, const float* gout, const float* raw, con
                      const float* c1, const float* c2, const float* c3, const float* xprev,
                      const float* pam, const float* psc, const float* pbs, float pslope,
                      const float* W, float* gm, float* Mbuf, float* c0buf, float* gx,
-                     float* gw_partial, double* pstat_partial, int max_waves, hipStream_t stream) {
+                     float* gw_partial, double* pstat_partial, int max_waves, hipStream_t stream,
+                     int* gw_tabs) {
   if (num_seg > 0)
     fpool::pool_bwd_gm_kernel<<<(int)ceil_div(num_seg * N / 4, 256), 256, 0, stream>>>(
         gout, raw, seg_graph, num_seg, N, am, sc, bs, slope, c1, gm);
@@ -1183,7 +1222,8 @@ int fpool_bwd_launch(bool lo, bool x16, const float* gout, const float* raw, con
   const int64_t tiles = (max_rows + fpool::TR - 1) / fpool::TR;
   int64_t blocks = (tiles + NW / 2 - 1) / (NW / 2);         // a tile is walked by a pair of waves
   int64_t cap = (K * N > 4096) ? 256 : 512;               // 64 -> 128: one 8-wave workgroup per CU
-  const int64_t cap_ws = max_waves / ((NW / 2) * rt.n);    // one record per wave PAIR
+  // the workspace holds one table per workgroup and one scratch record per wave PAIR
+  const int64_t cap_ws = max_waves / ((NW / 2 + 1) * rt.n);
   if (cap > cap_ws) cap = cap_ws;
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
@@ -1207,7 +1247,8 @@ int fpool_bwd_launch(bool lo, bool x16, const float* gout, const float* raw, con
   }
   SPT_FPOOL_SHAPES(X)
 #undef X
-  return (int)blocks * (NW / 2);
+  if (gw_tabs) *gw_tabs = (int)blocks;                     // weight-gradient tables per run
+  return (int)blocks * (NW / 2);                           // statistics records per run
 }
 
 void fpool_gw_dense_launch(int K, const double* gram, int B, const float* W, int N, int bfw,
