@@ -775,6 +775,13 @@ int spt_edge_affinity_features_bwd_f32(const float* x, const float* gout, int64_
 int spt_skinny_linear_supported(int K, int N);
 int spt_skinny_linear_f32(const float* x, int64_t rows, int K, const float* W, const float* bias,
                           int N, float* y, spt_stream_t stream);
+/* Round 6: y [rows, N] = x [rows, K] Wt [K, N] - the same product with the weight given as the
+ * TRANSPOSE of what spt_skinny_linear_f32 takes: the input gradient dX = G W of a Linear reads the
+ * layer's own weight W [N_out = K, N_in = N] (what autograd of src/nn/attention.py:202-215 /
+ * src/nn/mlp.py:43-56 computes) instead of a transposed copy made per backward call.  Same K as
+ * above, N % 4 == 0 and N >= 64, Wt 16-byte aligned; no bias. */
+int spt_skinny_linear_wt_f32(const float* x, int64_t rows, int K, const float* Wt, int N, float* y,
+                             spt_stream_t stream);
 /* Weight gradient of the same Linear: gw[N,K] = gy[rows,N]^T x[rows,K] (src/nn/attention.py's qkv /
  * out_proj under autograd), a reduction over 10^5..10^7 rows.  K in {32, 64, 128, 132, 260} (above
  * 64: 64-column slabs of x, the last one narrower), N a multiple of 64;

@@ -199,6 +199,7 @@ SIGNATURES = {
     "spt_skinny_dw_workspace_bytes": (_sz, [_int, _int]),
     "spt_skinny_dw_f32": (_int, [_p, _p, _i64, _int, _int, _p, _p, _p, _sz, _p]),
     "spt_skinny_linear_f32": (_int, [_p, _i64, _int, _p, _p, _int, _p, _p]),
+    "spt_skinny_linear_wt_f32": (_int, [_p, _i64, _int, _p, _int, _p, _p]),
     "spt_skinny_pre_supported": (_int, [_int, _int, _int]),
     "spt_skinny_linear_pre_f32": (_int, [_p, _i64, _int, _p, _p, _int, _p, _p, _p, _p, _p, _int, _p, _p]),
     "spt_skinny_dw_pre_f32": (_int, [_p, _p, _i64, _int, _int, _p, _p, _p, _p, _p, _p, _int, _p, _sz, _p]),

@@ -39,13 +39,35 @@ __device__ __forceinline__ void wave_sync_lds() {
 // (same fmaf), so the normalised [rows, K] tensor is never materialised.  Tables of PB graphs
 // live in LDS.  RES: y = (x W^T + b) + res (the block's residual `shortcut + out_proj(.)`).
 constexpr int PRE_MAX = 1024;  // floats per coefficient table in LDS (num_graphs x K)
+// Round 6: the slab of W given as the TRANSPOSE of what the product needs (`Wt` [K][ldwt] row-major:
+// slab row rr, column k <- Wt[k][n0 + rr]) - dX = G W of a Linear's backward reads the layer's own
+// weight [N_out = K here][N_in = ldwt] instead of a transposed copy made by a torch launch per
+// backward call (14 per SPT-64 step, 34 per SPT-128 step).  Coalesced float4 loads along a row of
+// Wt, four LDS writes each; N % 4 == 0 and ldwt % 4 == 0 (16-byte aligned rows).
+template <int NBS, int K, int LDA>
+__device__ __forceinline__ void stage_slab_transposed(const float* __restrict__ Wt, int ldwt, int n0,
+                                                      int N, float* wl, int tid, int nthreads) {
+  constexpr int R4 = 4 * NBS;                           // float4 per slab row of Wt
+  for (int q = tid; q < K * R4; q += nthreads) {
+    const int k = q / R4, r4 = q - k * R4;
+    const int n = n0 + 4 * r4;
+    const float4 v = n < N ? *reinterpret_cast<const float4*>(Wt + (size_t)k * ldwt + n)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+    float* d = wl + (4 * r4) * LDA + k;
+    d[0] = v.x;
+    d[LDA] = v.y;
+    d[2 * LDA] = v.z;
+    d[3 * LDA] = v.w;
+  }
+}
+
 template <int K4, int NBS = 4, bool PRE = false, bool RES = false>
 __global__ __launch_bounds__(WAVES * 64, (K4 < 32 || (K4 == 32 && !PRE)) ? 2 : 1) void skinny_linear_kernel(
     const float* __restrict__ x, int64_t rows, const float* __restrict__ W,
     const float* __restrict__ bias, int N, float* __restrict__ y,
     const float* __restrict__ pam = nullptr, const float* __restrict__ psc = nullptr,
     const float* __restrict__ pbs = nullptr, const int64_t* __restrict__ batch = nullptr, int PB = 1,
-    const float* __restrict__ res = nullptr) {
+    const float* __restrict__ res = nullptr, int ldwt = 0) {
   constexpr int K = 4 * K4, LDA = K + 4, V = K4 / 4;   // V float4 per lane per tile
   __shared__ __attribute__((aligned(16))) float a_lds[WAVES][TR * LDA];
   __shared__ __attribute__((aligned(16))) float ptab[PRE ? 2 * PRE_MAX + K : 4];   // am | sc | bias
@@ -66,12 +88,16 @@ __global__ __launch_bounds__(WAVES * 64, (K4 < 32 || (K4 == 32 && !PRE)) ? 2 : 1
   {
     float* wl = &a_lds[0][0];                           // [16 NBS][LDA]
     constexpr int WV = 16 * NBS * K4;                   // float4 of the slab
-    for (int q = threadIdx.x; q < WV; q += WAVES * 64) {
-      const int rr = q / K4, k4 = q - rr * K4;
-      const bool nv = n0 + rr < N;
-      const float4 wv = nv ? *reinterpret_cast<const float4*>(W + (size_t)(n0 + rr) * K + 4 * k4)
-                           : make_float4(0.f, 0.f, 0.f, 0.f);
-      *reinterpret_cast<float4*>(wl + rr * LDA + 4 * k4) = wv;
+    if (ldwt > 0) {
+      stage_slab_transposed<NBS, K, LDA>(W, ldwt, n0, N, wl, threadIdx.x, WAVES * 64);
+    } else {
+      for (int q = threadIdx.x; q < WV; q += WAVES * 64) {
+        const int rr = q / K4, k4 = q - rr * K4;
+        const bool nv = n0 + rr < N;
+        const float4 wv = nv ? *reinterpret_cast<const float4*>(W + (size_t)(n0 + rr) * K + 4 * k4)
+                             : make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(wl + rr * LDA + 4 * k4) = wv;
+      }
     }
     __syncthreads();
 #pragma unroll
@@ -178,7 +204,7 @@ constexpr int WAVES_L = 8;
 template <int K4, int NWL = WAVES_L>
 __global__ __launch_bounds__(NWL * 64, (NWL >= 4 ? NWL / 4 : 1)) void skinny_linear_wlds_kernel(
     const float* __restrict__ x, int64_t rows, const float* __restrict__ W,
-    const float* __restrict__ bias, int N, float* __restrict__ y) {
+    const float* __restrict__ bias, int N, float* __restrict__ y, int ldwt = 0) {
   constexpr int K = 4 * K4, LDA = K + 4, NCH = TR * K4, V = (NCH + 63) / 64, NBS = 4;
   __shared__ __attribute__((aligned(16))) float w_lds[16 * NBS * LDA];
   __shared__ __attribute__((aligned(16))) float a_lds[NWL][TR * LDA];
@@ -187,11 +213,15 @@ __global__ __launch_bounds__(NWL * 64, (NWL >= 4 ? NWL / 4 : 1)) void skinny_lin
   const int g = lane >> 4, c = lane & 15;
   const int n0 = blockIdx.y * (16 * NBS);
   float* al = a_lds[wid];
-  for (int q = threadIdx.x; q < 16 * NBS * K4; q += NWL * 64) {
-    const int rr = q / K4, k4 = q - rr * K4;
-    *reinterpret_cast<float4*>(w_lds + rr * LDA + 4 * k4) =
-        (n0 + rr < N) ? *reinterpret_cast<const float4*>(W + (size_t)(n0 + rr) * K + 4 * k4)
-                      : make_float4(0.f, 0.f, 0.f, 0.f);
+  if (ldwt > 0) {
+    stage_slab_transposed<NBS, K, LDA>(W, ldwt, n0, N, w_lds, threadIdx.x, NWL * 64);
+  } else {
+    for (int q = threadIdx.x; q < 16 * NBS * K4; q += NWL * 64) {
+      const int rr = q / K4, k4 = q - rr * K4;
+      *reinterpret_cast<float4*>(w_lds + rr * LDA + 4 * k4) =
+          (n0 + rr < N) ? *reinterpret_cast<const float4*>(W + (size_t)(n0 + rr) * K + 4 * k4)
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   }
   float bb[NBS];
 #pragma unroll
@@ -588,17 +618,38 @@ extern "C" int spt_skinny_linear_f32(const float* x, int64_t rows, int K, const 
 // spt_graphnorm_stats_f32; pre_am NULL = plain x) and the block's residual folded into its out_proj
 // (`residual` [rows, N] or NULL: y = (x W^T + b) + residual) - src/nn/transformer.py:231-234.
 // K in {32, 64, 128}, N a multiple of 64 for either option.
+static int skinny_linear_impl(const float* x, int64_t rows, int K, const float* W, const float* bias,
+                              int N, float* y, const float* pre_am, const float* pre_scale,
+                              const float* pre_bias, const int64_t* batch, int num_graphs,
+                              const float* residual, int ldwt, spt_stream_t stream_);
 extern "C" int spt_skinny_linear_pre_f32(const float* x, int64_t rows, int K, const float* W,
                                          const float* bias, int N, float* y, const float* pre_am,
                                          const float* pre_scale, const float* pre_bias,
                                          const int64_t* batch, int num_graphs,
                                          const float* residual, spt_stream_t stream_) {
+  return skinny_linear_impl(x, rows, K, W, bias, N, y, pre_am, pre_scale, pre_bias, batch, num_graphs,
+                            residual, 0, stream_);
+}
+// y = x Wt (no transpose: Wt [K, N] row-major, e.g. dX = G W with the layer's own weight
+// [N_out = K, N_in = N]); same shapes as spt_skinny_linear_f32 with N % 4 == 0, N >= 64.
+extern "C" int spt_skinny_linear_wt_f32(const float* x, int64_t rows, int K, const float* Wt, int N,
+                                        float* y, spt_stream_t stream_) {
+  SPT_CHECK_ARG(N % 4 == 0 && N >= SLAB, "transposed weight: N % 4 == 0 and N >= 64");
+  SPT_CHECK_ARG(((uintptr_t)Wt) % 16 == 0, "Wt must be 16-byte aligned");
+  return skinny_linear_impl(x, rows, K, Wt, nullptr, N, y, nullptr, nullptr, nullptr, nullptr, 1, nullptr,
+                            N, stream_);
+}
+static int skinny_linear_impl(const float* x, int64_t rows, int K, const float* W, const float* bias,
+                              int N, float* y, const float* pre_am, const float* pre_scale,
+                              const float* pre_bias, const int64_t* batch, int num_graphs,
+                              const float* residual, int ldwt, spt_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SPT_CHECK_ARG(rows >= 0, "bad shape");
   SPT_CHECK_ARG(spt_skinny_linear_supported(K, N), "(K, N) not built");
   if (rows == 0) return 0;
   SPT_CHECK_ARG(x && W && y, "null pointer");
   const bool pre = pre_am != nullptr, resid = residual != nullptr;
+  SPT_CHECK_ARG(ldwt == 0 || (!pre && !resid && N > 16), "transposed weight: the plain product only");
   SPT_CHECK_ARG(!pre || (pre_scale && pre_bias && spt_skinny_pre_supported(K, N, num_graphs)),
                 "pre-normalisation: incomplete tables, unbuilt shape or num_graphs * K too large");
   SPT_CHECK_ARG(!resid || spt_skinny_pre_supported(K, N, 1), "residual epilogue: unbuilt shape");
@@ -639,15 +690,15 @@ extern "C" int spt_skinny_linear_pre_f32(const float* x, int64_t rows, int K, co
     return 0;
   }
   switch (K) {
-    case 32:  skinny_linear_kernel<8><<<grid, WAVES * 64, 0, stream>>>(x, rows, W, bias, N, y); break;
-    case 64:  skinny_linear_kernel<16><<<grid, WAVES * 64, 0, stream>>>(x, rows, W, bias, N, y); break;
-    case 128: skinny_linear_kernel<32><<<grid, WAVES * 64, 0, stream>>>(x, rows, W, bias, N, y); break;
+    case 32:  skinny_linear_kernel<8><<<grid, WAVES * 64, 0, stream>>>(x, rows, W, bias, N, y, nullptr, nullptr, nullptr, nullptr, 1, nullptr, ldwt); break;
+    case 64:  skinny_linear_kernel<16><<<grid, WAVES * 64, 0, stream>>>(x, rows, W, bias, N, y, nullptr, nullptr, nullptr, nullptr, 1, nullptr, ldwt); break;
+    case 128: skinny_linear_kernel<32><<<grid, WAVES * 64, 0, stream>>>(x, rows, W, bias, N, y, nullptr, nullptr, nullptr, nullptr, 1, nullptr, ldwt); break;
     case 256: {                                          // dX of the 128-wide blocks' qkv Linear (256 -> 128):
       int64_t b4 = ceil_div(tiles, (int64_t)4);          // 4-wave workgroups, slab + tiles = 133 KB of LDS
       const int64_t cap4 = (int64_t)256 / slabs > 1 ? (int64_t)256 / slabs : 1;
       if (b4 > cap4) b4 = cap4;
       skinny_linear_wlds_kernel<64, 4><<<dim3((unsigned)b4, (unsigned)slabs), 4 * 64, 0, stream>>>(
-          x, rows, W, bias, N, y);
+          x, rows, W, bias, N, y, ldwt);
       break;
     }
     case 260: {                                          // 4-wave workgroups: slab + tiles = 135 KB of LDS
@@ -655,7 +706,7 @@ extern "C" int spt_skinny_linear_pre_f32(const float* x, int64_t rows, int K, co
       const int64_t cap4 = (int64_t)256 / slabs > 1 ? (int64_t)256 / slabs : 1;
       if (b4 > cap4) b4 = cap4;
       skinny_linear_wlds_kernel<65, 4><<<dim3((unsigned)b4, (unsigned)slabs), 4 * 64, 0, stream>>>(
-          x, rows, W, bias, N, y);
+          x, rows, W, bias, N, y, ldwt);
       break;
     }
     default: {
@@ -664,10 +715,10 @@ extern "C" int spt_skinny_linear_pre_f32(const float* x, int64_t rows, int K, co
       if (b8 > cap8) b8 = cap8;
       if (K == 132)
         skinny_linear_wlds_kernel<33><<<dim3((unsigned)b8, (unsigned)slabs), WAVES_L * 64, 0, stream>>>(
-            x, rows, W, bias, N, y);
+            x, rows, W, bias, N, y, ldwt);
       else
         skinny_linear_wlds_kernel<48><<<dim3((unsigned)b8, (unsigned)slabs), WAVES_L * 64, 0, stream>>>(
-            x, rows, W, bias, N, y);
+            x, rows, W, bias, N, y, ldwt);
       break;
     }
   }

@@ -921,6 +921,27 @@ def _skinny_launch(x, weight, bias):
     return y
 
 
+def _input_grad(g, weight):
+    """dX = G W of a Linear (``weight`` [N_out, N_in] as the layer holds it): the skinny kernel reads
+    the weight transposed while it stages the slab (``spt_skinny_linear_wt_f32``) - no transposed
+    copy per backward call -, else the transposed copy on the same kernel, else the library."""
+    n_out, n_in = weight.shape
+    if (g.is_cuda and g.dtype == torch.float32 and weight.dtype == torch.float32 and g.dim() == 2
+            and g.shape[0] >= _SKINNY_MIN_ROWS and n_in % 4 == 0 and n_in >= 64
+            and _lib.lib.spt_skinny_linear_supported(n_out, n_in)):
+        g = g.contiguous()
+        w = weight.detach().contiguous()
+        rows = g.shape[0]
+        y = torch.empty((rows, n_in), dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            st = _lib.lib.spt_skinny_linear_wt_f32(_lib.ptr(g), rows, n_out, _lib.ptr(w), n_in,
+                                                   _lib.ptr(y), _lib.stream_ptr(g.device))
+        _lib.check(st, "spt_skinny_linear_wt_f32")
+        return y
+    wt = weight.detach().t().contiguous()           # [K, N]: dX = G (W^T)^T
+    return _skinny_launch(g, wt, None) if _skinny_ok(g, wt) else g @ weight
+
+
 def _dw_batched(g, x):
     """dW = G^T X reduces over millions of rows into a <=192x192 output, a shape the
     library runs on a handful of workgroups - so it is issued as a BATCHED GEMM over row
@@ -1002,8 +1023,7 @@ class _TallLinear(torch.autograd.Function):
             return gx, gw, gb
         gx = None
         if ctx.needs_input_grad[0]:
-            wt = weight.detach().t().contiguous()           # [K, N]: dX = G (W^T)^T
-            gx = _skinny_launch(g, wt, None) if _skinny_ok(g, wt) else g @ weight
+            gx = _input_grad(g, weight)
         gw = gb = None
         want_gb = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
@@ -1143,8 +1163,7 @@ class _NormLinear(torch.autograd.Function):
         dev = xd.device
         gy = gy.contiguous()
         # gradient wrt the normalised rows: dX of the Linear
-        wt = wd.t().contiguous()
-        gxn = _skinny_launch(gy, wt, None) if _skinny_ok(gy, wt) else gy @ wd
+        gxn = _input_grad(gy, wd)
         # weight / bias gradient against the rows normalised on the fly
         gw = torch.empty((n, d), dtype=torch.float32, device=dev)
         gb = torch.empty(n, dtype=torch.float32, device=dev) if has_bias else None

@@ -101,3 +101,30 @@ def test_narrow_head_linear_autograd_matches_float64(rows, K, N, dev):
     tol = 2e-6 * rows ** 0.5 * float(go.abs().max()) * float(x.abs().max())
     assert (gw.double() - rw).abs().max() < tol + 1e-6 * float(rw.abs().max())
     assert (gb.double() - rb).abs().max() < tol + 1e-6 * float(rb.abs().max())
+
+
+@pytest.mark.parametrize("rows", [1, 17, 4099, 70001])
+@pytest.mark.parametrize("n_out,n_in", [(192, 64), (64, 64), (128, 128), (256, 128), (64, 132), (128, 132),
+                                        (128, 260), (32, 64), (192, 128), (128, 256)])
+def test_input_gradient_reads_the_weight_transposed_bit_for_bit(rows, n_out, n_in, dev):
+    """dX = G W with the layer's own weight [n_out, n_in] (spt_skinny_linear_wt_f32: the slab is
+    transposed while it is staged) equals the same kernel on a transposed COPY bit for bit - the
+    copy was one torch launch per Linear and backward call."""
+    from superpoint_transformer_amd import _lib, ops
+    g = torch.Generator().manual_seed(rows + n_out + 7 * n_in)
+    go = torch.randn(rows, n_out, generator=g).to(dev)
+    w = (torch.randn(n_out, n_in, generator=g) * 0.2).to(dev)
+    if not _lib.lib.spt_skinny_linear_supported(n_out, n_in):
+        pytest.skip("shape not built")
+    ref = ops._skinny_launch(go, w.t().contiguous(), None)
+    y = torch.full((rows, n_in), float("nan"), device=dev)
+    st = _lib.lib.spt_skinny_linear_wt_f32(_lib.ptr(go), rows, n_out, _lib.ptr(w), n_in, _lib.ptr(y),
+                                           _lib.stream_ptr(dev))
+    _lib.check(st, "spt_skinny_linear_wt_f32")
+    assert torch.equal(y, ref)
+    old = ops._SKINNY_MIN_ROWS
+    ops._SKINNY_MIN_ROWS = 1
+    try:
+        assert torch.equal(ops._input_grad(go, w), ref)
+    finally:
+        ops._SKINNY_MIN_ROWS = old
