@@ -805,6 +805,29 @@ int spt_skinny_dw_pre_f32(const float* gy, const float* x, int64_t rows, int N, 
                           float* gb, const float* pre_am, const float* pre_scale,
                           const float* pre_bias, const int64_t* batch, int num_graphs, void* ws,
                           size_t ws_bytes, spt_stream_t stream);
+/* Round 6: matrix mode of the tall-skinny Linears (K = 32 / 64 and the K = 192 input gradient; the
+ * other widths stay on the f32 pipe in every mode).  They ran on v_mfma_f32_16x16x4_f32 in every
+ * mode; like the attention and the fused layers they now follow the mode the reference ships
+ * (configs/train.yaml:60-61 float32_matmul_precision: high):
+ *   0  f32 pipe (the f32-exact mode)
+ *   1  (default) split bf16: the forward as the f32-EXACT six-product 3-way split, the input and
+ *      weight gradients as hi*hi + lo*hi + hi*lo (three products)
+ *   3  operands rounded to bf16 (the bf16 mode)
+ * spt_skinny_use_split_bf16 sets the process-wide default and returns the previous one (< 0: query);
+ * the _m entries take the mode per call (< 0: that default).  _pre_m = spt_skinny_linear_pre_f32 (a
+ * forward: pre-norm / residual options), _wt_m = spt_skinny_linear_wt_f32 (an input gradient),
+ * _dw_pre_m = spt_skinny_dw_pre_f32 (a weight gradient). */
+int spt_skinny_use_split_bf16(int mode);
+int spt_skinny_linear_pre_m_f32(const float* x, int64_t rows, int K, const float* W, const float* bias,
+                                int N, float* y, const float* pre_am, const float* pre_scale,
+                                const float* pre_bias, const int64_t* batch, int num_graphs,
+                                const float* residual, int mode, spt_stream_t stream);
+int spt_skinny_linear_wt_m_f32(const float* x, int64_t rows, int K, const float* Wt, int N, float* y,
+                               int mode, spt_stream_t stream);
+int spt_skinny_dw_pre_m_f32(const float* gy, const float* x, int64_t rows, int N, int K, float* gw,
+                            float* gb, const float* pre_am, const float* pre_scale,
+                            const float* pre_bias, const int64_t* batch, int num_graphs, int mode,
+                            void* ws, size_t ws_bytes, spt_stream_t stream);
 int spt_skinny_dw_supported(int K, int N);
 size_t spt_skinny_dw_workspace_bytes(int K, int N);
 int spt_skinny_dw_f32(const float* gy, const float* x, int64_t rows, int N, int K, float* gw,

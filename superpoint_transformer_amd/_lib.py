@@ -203,6 +203,10 @@ SIGNATURES = {
     "spt_skinny_pre_supported": (_int, [_int, _int, _int]),
     "spt_skinny_linear_pre_f32": (_int, [_p, _i64, _int, _p, _p, _int, _p, _p, _p, _p, _p, _int, _p, _p]),
     "spt_skinny_dw_pre_f32": (_int, [_p, _p, _i64, _int, _int, _p, _p, _p, _p, _p, _p, _int, _p, _sz, _p]),
+    "spt_skinny_use_split_bf16": (_int, [_int]),
+    "spt_skinny_linear_pre_m_f32": (_int, [_p, _i64, _int, _p, _p, _int, _p, _p, _p, _p, _p, _int, _p, _int, _p]),
+    "spt_skinny_linear_wt_m_f32": (_int, [_p, _i64, _int, _p, _int, _p, _int, _p]),
+    "spt_skinny_dw_pre_m_f32": (_int, [_p, _p, _i64, _int, _int, _p, _p, _p, _p, _p, _p, _int, _int, _p, _sz, _p]),
     "spt_index_inverse": (_int, [_p, _i64, _i64, _p, _p]),
     "spt_select_edges_workspace_bytes": (_sz, [_i64]),
     "spt_select_edges": (_int, [_p, _i64, _i64, _p, _i64, _p, _i64, _p, _p, _p, _sz, _p]),

@@ -23,6 +23,50 @@ constexpr int TR = 16;      // rows per tile (MFMA M)
 constexpr int WAVES = 4;
 constexpr int SLAB = 64;    // output columns per wave (4 MFMA column blocks)
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+// Round 6: the products on the bf16 matrix pipe, like every other GEMM of the default mode
+// (precision.py: the reference ships float32_matmul_precision: high, configs/train.yaml:60-61).
+// PR = planes-and-products scheme of a kernel instance:
+//   0  f32 pipe (v_mfma_f32_16x16x4_f32; the f32-exact mode, and every shape without a bf16 instance)
+//   1  operands rounded to bf16, one product                                  (the bf16 mode)
+//   3  x = hi + lo, w = hi + lo: lo*hi + hi*lo + hi*hi (~2^-17 per product)   (the default mode's backward)
+//   6  3-way splits, six products, smallest first: f32-exact                  (the default mode's forward)
+// A 16 x K x 64 tile step on the f32 pipe costs 8 x 32 cycles per 32 columns of K; the bf16 pipe
+// 16 cycles per product: 1 / 16, 3 / 16 or 6 / 16 of it.
+__host__ __device__ constexpr int skinny_planes(int PR) { return PR == 6 ? 3 : (PR == 3 ? 2 : 1); }
+template <int NPL>
+__device__ __forceinline__ void split_planes(const float (&x)[8], bf16x8 (&p)[NPL]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const __bf16 a = (__bf16)x[i];
+    p[0][i] = a;
+    if constexpr (NPL >= 2) {
+      const float r1 = x[i] - (float)a;                 // exact
+      const __bf16 b = (__bf16)r1;
+      p[1][i] = b;
+      if constexpr (NPL >= 3) p[2][i] = (__bf16)(r1 - (float)b);   // exact, fits bf16
+    }
+  }
+}
+// C += x w over one 32-column step, planes x[0] (hi) .. and w[0] (hi) ..
+template <int PR>
+__device__ __forceinline__ f32x4 mfma_planes(const bf16x8 (&x)[skinny_planes(PR)],
+                                             const bf16x8 (&w)[skinny_planes(PR)], f32x4 c) {
+  if constexpr (PR == 6) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x[2], w[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x[0], w[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x[1], w[1], c, 0, 0, 0);
+  }
+  if constexpr (PR >= 3) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x[1], w[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x[0], w[1], c, 0, 0, 0);
+  }
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(x[0], w[0], c, 0, 0, 0);
+}
+
 __device__ __forceinline__ void wave_sync_lds() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -39,6 +83,18 @@ __device__ __forceinline__ void wave_sync_lds() {
 // (same fmaf), so the normalised [rows, K] tensor is never materialised.  Tables of PB graphs
 // live in LDS.  RES: y = (x W^T + b) + res (the block's residual `shortcut + out_proj(.)`).
 constexpr int PRE_MAX = 1024;  // floats per coefficient table in LDS (num_graphs x K)
+// -DSPT_SKINNY_NO_MFMA (measurement build, tools/build_variant.sh: wrong results by design): the
+// products replaced by one add per MFMA - what the kernels cost without the f32 matrix pipe
+#ifdef SPT_SKINNY_NO_MFMA
+__device__ __forceinline__ f32x4 skinny_fake_mfma(float a, float b, f32x4 c) {
+  c[0] += a * b;
+  return c;
+}
+#define SPT_SKINNY_MFMA(a, b, c) skinny_fake_mfma(a, b, c)
+#else
+#define SPT_SKINNY_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0)
+#endif
+
 // Round 6: the slab of W given as the TRANSPOSE of what the product needs (`Wt` [K][ldwt] row-major:
 // slab row rr, column k <- Wt[k][n0 + rr]) - dX = G W of a Linear's backward reads the layer's own
 // weight [N_out = K here][N_in = ldwt] instead of a transposed copy made by a torch launch per
@@ -61,7 +117,7 @@ __device__ __forceinline__ void stage_slab_transposed(const float* __restrict__ 
   }
 }
 
-template <int K4, int NBS = 4, bool PRE = false, bool RES = false>
+template <int K4, int NBS = 4, bool PRE = false, bool RES = false, int PR = 0>
 __global__ __launch_bounds__(WAVES * 64, (K4 < 32 || (K4 == 32 && !PRE)) ? 2 : 1) void skinny_linear_kernel(
     const float* __restrict__ x, int64_t rows, const float* __restrict__ W,
     const float* __restrict__ bias, int N, float* __restrict__ y,
@@ -83,7 +139,10 @@ __global__ __launch_bounds__(WAVES * 64, (K4 < 32 || (K4 == 32 && !PRE)) ? 2 : 1
   // LDS reads.  (Per-lane dword loads straight from global - 16 rows x 16 B per instruction, K4 x
   // NBS instructions per wave - cost more than the tile's MFMAs at train-batch row counts, where
   // a wave only sees one or two tiles.)
-  float B[NBS][K4];                                     // lane (g, c): W[n0 + 16 nb + c][4 st + g]
+  constexpr int KS = K / 32, NPL = skinny_planes(PR);
+  static_assert(PR == 0 || K % 32 == 0, "bf16 instances: whole 32-column steps");
+  float B[PR == 0 ? NBS : 1][PR == 0 ? K4 : 1];         // lane (g, c): W[n0 + 16 nb + c][4 st + g]
+  bf16x8 Bp[PR == 0 ? 1 : NBS][PR == 0 ? 1 : KS][NPL];  // lane (g, c): W[n0 + 16 nb + c][32 ks + 8 g ..]
   float bb[NBS];
   {
     float* wl = &a_lds[0][0];                           // [16 NBS][LDA]
@@ -102,8 +161,18 @@ __global__ __launch_bounds__(WAVES * 64, (K4 < 32 || (K4 == 32 && !PRE)) ? 2 : 1
     __syncthreads();
 #pragma unroll
     for (int nb = 0; nb < NBS; ++nb) {
+      if constexpr (PR == 0) {
 #pragma unroll
-      for (int st = 0; st < K4; ++st) B[nb][st] = wl[(16 * nb + c) * LDA + 4 * st + g];
+        for (int st = 0; st < K4; ++st) B[nb][st] = wl[(16 * nb + c) * LDA + 4 * st + g];
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const float4 w0 = *reinterpret_cast<const float4*>(wl + (16 * nb + c) * LDA + 32 * ks + 8 * g);
+          const float4 w1 = *reinterpret_cast<const float4*>(wl + (16 * nb + c) * LDA + 32 * ks + 8 * g + 4);
+          const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+          split_planes<NPL>(wv, Bp[nb][ks]);
+        }
+      }
       bb[nb] = (bias && n0 + 16 * nb + c < N) ? bias[n0 + 16 * nb + c] : 0.f;
     }
     if constexpr (PRE) {
@@ -167,17 +236,30 @@ __global__ __launch_bounds__(WAVES * 64, (K4 < 32 || (K4 == 32 && !PRE)) ? 2 : 1
     }
     wave_sync_lds();
     if (t + nwaves < ntiles) fetch(t + nwaves);         // in flight during the MFMAs
-    float A[K4];
-#pragma unroll
-    for (int st = 0; st < K4; ++st) A[st] = al[c * LDA + 4 * st + g];
     f32x4 C[NBS];
 #pragma unroll
     for (int nb = 0; nb < NBS; ++nb) C[nb] = (f32x4){bb[nb], bb[nb], bb[nb], bb[nb]};
+    if constexpr (PR == 0) {
+      float A[K4];
 #pragma unroll
-    for (int st = 0; st < K4; ++st)
+      for (int st = 0; st < K4; ++st) A[st] = al[c * LDA + 4 * st + g];
 #pragma unroll
-      for (int nb = 0; nb < NBS; ++nb)
-        C[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[st], B[nb][st], C[nb], 0, 0, 0);
+      for (int st = 0; st < K4; ++st)
+#pragma unroll
+        for (int nb = 0; nb < NBS; ++nb)
+          C[nb] = SPT_SKINNY_MFMA(A[st], B[nb][st], C[nb]);
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const float4 a0 = *reinterpret_cast<const float4*>(al + c * LDA + 32 * ks + 8 * g);
+        const float4 a1 = *reinterpret_cast<const float4*>(al + c * LDA + 32 * ks + 8 * g + 4);
+        const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        bf16x8 Ap[NPL];
+        split_planes<NPL>(av, Ap);
+#pragma unroll
+        for (int nb = 0; nb < NBS; ++nb) C[nb] = mfma_planes<PR>(Ap, Bp[nb][ks], C[nb]);
+      }
+    }
     const int64_t row0 = t * TR;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -201,24 +283,33 @@ constexpr int WAVES_L = 8;
 // the KITTI-360 width's node MLPs, configs/experiment/semantic/kitti360.yaml:22-27 - 264 B-operand
 // registers otherwise): any K a multiple of 4 (a tile is TR K / 4 16-byte chunks, the last wave-load
 // of a tile partly idle), NWL waves per workgroup so that slab + tiles fit the LDS.
-template <int K4, int NWL = WAVES_L>
+// PR > 0 (round 6, K % 32 == 0): the slab is kept as bf16 planes (hi | lo, rows of K + 8 values:
+// conflict-free 16-byte reads) and every product runs on the bf16 pipe (see skinny_planes above).
+template <int K4, int NWL = WAVES_L, int PR = 0>
 __global__ __launch_bounds__(NWL * 64, (NWL >= 4 ? NWL / 4 : 1)) void skinny_linear_wlds_kernel(
     const float* __restrict__ x, int64_t rows, const float* __restrict__ W,
     const float* __restrict__ bias, int N, float* __restrict__ y, int ldwt = 0) {
   constexpr int K = 4 * K4, LDA = K + 4, NCH = TR * K4, V = (NCH + 63) / 64, NBS = 4;
-  __shared__ __attribute__((aligned(16))) float w_lds[16 * NBS * LDA];
+  constexpr int NPL = skinny_planes(PR), LDW = K + 8, KS = K / 32;
+  static_assert(PR == 0 || (K % 32 == 0 && NPL <= 2), "bf16 instances: whole 32-column steps, hi | lo");
+  // (one buffer: the f32 slab while it is staged, the bf16 planes afterwards - 2 x 2 (K + 8) bytes
+  // per row against 4 (K + 4))
+  __shared__ __attribute__((aligned(16))) float w_lds[16 * NBS * LDA + (PR ? 16 * NBS * 4 : 0)];
   __shared__ __attribute__((aligned(16))) float a_lds[NWL][TR * LDA];
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, c = lane & 15;
   const int n0 = blockIdx.y * (16 * NBS);
   float* al = a_lds[wid];
+  // PR > 0: the f32 slab is staged in the (still unused) tile buffers and leaves as bf16 planes
+  static_assert(PR == 0 || NWL * TR >= 16 * NBS, "the slab fits the tile buffers");
+  float* slab = PR ? &a_lds[0][0] : w_lds;
   if (ldwt > 0) {
-    stage_slab_transposed<NBS, K, LDA>(W, ldwt, n0, N, w_lds, threadIdx.x, NWL * 64);
+    stage_slab_transposed<NBS, K, LDA>(W, ldwt, n0, N, slab, threadIdx.x, NWL * 64);
   } else {
     for (int q = threadIdx.x; q < 16 * NBS * K4; q += NWL * 64) {
       const int rr = q / K4, k4 = q - rr * K4;
-      *reinterpret_cast<float4*>(w_lds + rr * LDA + 4 * k4) =
+      *reinterpret_cast<float4*>(slab + rr * LDA + 4 * k4) =
           (n0 + rr < N) ? *reinterpret_cast<const float4*>(W + (size_t)(n0 + rr) * K + 4 * k4)
                         : make_float4(0.f, 0.f, 0.f, 0.f);
     }
@@ -227,6 +318,21 @@ __global__ __launch_bounds__(NWL * 64, (NWL >= 4 ? NWL / 4 : 1)) void skinny_lin
 #pragma unroll
   for (int nb = 0; nb < NBS; ++nb) bb[nb] = (bias && n0 + 16 * nb + c < N) ? bias[n0 + 16 * nb + c] : 0.f;
   __syncthreads();
+  __bf16* wpl = reinterpret_cast<__bf16*>(w_lds);       // [NPL][16 NBS][LDW]
+  if constexpr (PR != 0) {
+    for (int q = threadIdx.x; q < 16 * NBS * (K / 8); q += NWL * 64) {
+      const int rr = q / (K / 8), k8 = q - rr * (K / 8);
+      const float4 w0 = *reinterpret_cast<const float4*>(slab + rr * LDA + 8 * k8);
+      const float4 w1 = *reinterpret_cast<const float4*>(slab + rr * LDA + 8 * k8 + 4);
+      const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+      bf16x8 pl[NPL];
+      split_planes<NPL>(wv, pl);
+#pragma unroll
+      for (int p = 0; p < NPL; ++p)
+        *reinterpret_cast<bf16x8*>(wpl + (size_t)p * 16 * NBS * LDW + rr * LDW + 8 * k8) = pl[p];
+    }
+    __syncthreads();
+  }
   const float* wl = w_lds + c * LDA + g;                // + 16 nb LDA + 4 st
 
   const int64_t ntiles = (rows + TR - 1) / TR;
@@ -257,12 +363,32 @@ __global__ __launch_bounds__(NWL * 64, (NWL >= 4 ? NWL / 4 : 1)) void skinny_lin
     f32x4 C[NBS];
 #pragma unroll
     for (int nb = 0; nb < NBS; ++nb) C[nb] = (f32x4){bb[nb], bb[nb], bb[nb], bb[nb]};
+    if constexpr (PR == 0) {
 #pragma unroll
-    for (int st = 0; st < K4; ++st) {
-      const float a = al[c * LDA + 4 * st + g];
+      for (int st = 0; st < K4; ++st) {
+        const float a = al[c * LDA + 4 * st + g];
 #pragma unroll
-      for (int nb = 0; nb < NBS; ++nb)
-        C[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wl[16 * nb * LDA + 4 * st], C[nb], 0, 0, 0);
+        for (int nb = 0; nb < NBS; ++nb)
+          C[nb] = SPT_SKINNY_MFMA(a, wl[16 * nb * LDA + 4 * st], C[nb]);
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const float4 a0 = *reinterpret_cast<const float4*>(al + c * LDA + 32 * ks + 8 * g);
+        const float4 a1 = *reinterpret_cast<const float4*>(al + c * LDA + 32 * ks + 8 * g + 4);
+        const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        bf16x8 Ap[NPL];
+        split_planes<NPL>(av, Ap);
+#pragma unroll
+        for (int nb = 0; nb < NBS; ++nb) {
+          bf16x8 Bp[NPL];
+#pragma unroll
+          for (int p = 0; p < NPL; ++p)
+            Bp[p] = *reinterpret_cast<const bf16x8*>(wpl + (size_t)p * 16 * NBS * LDW +
+                                                     (16 * nb + c) * LDW + 32 * ks + 8 * g);
+          C[nb] = mfma_planes<PR>(Ap, Bp, C[nb]);
+        }
+      }
     }
     const int64_t row0 = t * TR;
 #pragma unroll
@@ -284,7 +410,11 @@ __global__ __launch_bounds__(NWL * 64, (NWL >= 4 ? NWL / 4 : 1)) void skinny_lin
 // once; a second kernel sums the per-wave partials in a fixed order (deterministic).
 // PRE: x is normalised on the way in exactly like skinny_linear_kernel<.., PRE> does (the weight
 // gradient of a Linear behind an on-the-fly pre-norm needs the NORMALISED rows).
-template <int K4, bool PRE = false>
+// PR (round 6): 0 = f32 pipe (rows 4 st + g of the tile per v_mfma_f32_16x16x4_f32); 1 / 3 = the bf16
+// pipe with the tile's 16 rows as ONE contraction step (v_mfma_f32_16x16x16_bf16: lane (g, c) holds
+// rows 4 g .. 4 g + 3 of column c of both operands), operands rounded (1) or split hi + lo with the
+// three products lo*hi + hi*lo + hi*hi (3).  The bias gradient sums the unrounded values.
+template <int K4, bool PRE = false, int PR = 0>
 __global__ __launch_bounds__(WAVES * 64, 2) void skinny_dw_kernel(
     const float* __restrict__ gy, const float* __restrict__ x, int64_t rows, int N, int KF,
     float* __restrict__ partial, const float* __restrict__ pam = nullptr,
@@ -368,19 +498,57 @@ __global__ __launch_bounds__(WAVES * 64, 2) void skinny_dw_kernel(
     }
     wave_sync_lds();
     if (t + nwaves < ntiles) fetch(t + nwaves);         // in flight during the MFMAs
+    if constexpr (PR == 0) {
 #pragma unroll
-    for (int st = 0; st < TR / 4; ++st) {               // rows 4 st + g of the tile
-      float A[4], B[KB];
+      for (int st = 0; st < TR / 4; ++st) {             // rows 4 st + g of the tile
+        float A[4], B[KB];
 #pragma unroll
-      for (int nb = 0; nb < 4; ++nb) A[nb] = gl[(4 * st + g) * LDG + 16 * nb + c];
+        for (int nb = 0; nb < 4; ++nb) A[nb] = gl[(4 * st + g) * LDG + 16 * nb + c];
 #pragma unroll
-      for (int kb = 0; kb < KB; ++kb) B[kb] = xl[(4 * st + g) * LDX + 16 * kb + c];
+        for (int kb = 0; kb < KB; ++kb) B[kb] = xl[(4 * st + g) * LDX + 16 * kb + c];
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+          bsum[nb] += A[nb];
+#pragma unroll
+          for (int kb = 0; kb < KB; ++kb)
+            C[nb][kb] = SPT_SKINNY_MFMA(A[nb], B[kb], C[nb][kb]);
+        }
+      }
+    } else {
+      s16x4 Ah[4], Al[4];
 #pragma unroll
       for (int nb = 0; nb < 4; ++nb) {
-        bsum[nb] += A[nb];
+        float a[4];
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb)
-          C[nb][kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[nb], B[kb], C[nb][kb], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) a[j] = gl[(4 * g + j) * LDG + 16 * nb + c];
+        bsum[nb] += (a[0] + a[1]) + (a[2] + a[3]);
+        bf16x4 h, l;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          h[j] = (__bf16)a[j];
+          l[j] = (__bf16)(a[j] - (float)h[j]);
+        }
+        Ah[nb] = __builtin_bit_cast(s16x4, h);
+        Al[nb] = __builtin_bit_cast(s16x4, l);
+      }
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        bf16x4 h, l;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float b = xl[(4 * g + j) * LDX + 16 * kb + c];
+          h[j] = (__bf16)b;
+          l[j] = (__bf16)(b - (float)h[j]);
+        }
+        const s16x4 Bh = __builtin_bit_cast(s16x4, h), Bl = __builtin_bit_cast(s16x4, l);
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+          if constexpr (PR == 3) {
+            C[nb][kb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(Al[nb], Bh, C[nb][kb], 0, 0, 0);
+            C[nb][kb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(Ah[nb], Bl, C[nb][kb], 0, 0, 0);
+          }
+          C[nb][kb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(Ah[nb], Bh, C[nb][kb], 0, 0, 0);
+        }
       }
     }
   }
@@ -541,6 +709,19 @@ extern "C" int spt_skinny_dw_supported(int K, int N) {
 extern "C" size_t spt_skinny_dw_workspace_bytes(int K, int N) {
   return (size_t)DW_BLOCKS * WAVES * N * (K + 1) * sizeof(float);
 }
+// matrix mode of the skinny Linears: 0 f32 pipe, 1 (default) split bf16 - forward f32-exact (six
+// products), input / weight gradients three products -, 3 bf16.  Process-wide default (< 0: query);
+// the _m entries take the mode per call (< 0 there: this default).
+static std::atomic<int> g_skinny_mode{[] { const char* e = getenv("SPT_SKINNY_MODE"); return e ? atoi(e) : 1; }()};
+extern "C" int spt_skinny_use_split_bf16(int mode) {
+  const int prev = g_skinny_mode;
+  if (mode >= 0) g_skinny_mode = (mode == 3) ? 3 : (mode != 0 ? 1 : 0);
+  return prev;
+}
+static inline int skinny_mode_of(int mode) { return mode < 0 ? (int)g_skinny_mode : ((mode & 3) == 3 ? 3 : ((mode & 3) ? 1 : 0)); }
+static inline int skinny_pr_fwd(int mode) { const int m = skinny_mode_of(mode); return m == 0 ? 0 : (m == 3 ? 1 : 6); }
+static inline int skinny_pr_bwd(int mode) { const int m = skinny_mode_of(mode); return m == 0 ? 0 : (m == 3 ? 1 : 3); }
+
 // gw[N, K] = gy[rows, N]^T x[rows, K]  (the weight gradient of y = x W^T + b); gb[N] = column
 // sums of gy (the bias gradient), or null
 extern "C" int spt_skinny_dw_f32(const float* gy, const float* x, int64_t rows, int N, int K,
@@ -561,6 +742,16 @@ extern "C" int spt_skinny_dw_pre_f32(const float* gy, const float* x, int64_t ro
                                      const float* pre_scale, const float* pre_bias,
                                      const int64_t* batch, int num_graphs, void* ws,
                                      size_t ws_bytes, spt_stream_t stream_) {
+  return spt_skinny_dw_pre_m_f32(gy, x, rows, N, K, gw, gb, pre_am, pre_scale, pre_bias, batch,
+                                 num_graphs, -1, ws, ws_bytes, stream_);
+}
+// The same with the matrix mode per call (spt_skinny_use_split_bf16's values; < 0: the default)
+extern "C" int spt_skinny_dw_pre_m_f32(const float* gy, const float* x, int64_t rows, int N, int K,
+                                       float* gw, float* gb, const float* pre_am,
+                                       const float* pre_scale, const float* pre_bias,
+                                       const int64_t* batch, int num_graphs, int mode, void* ws,
+                                       size_t ws_bytes, spt_stream_t stream_) {
+  const int pr = skinny_pr_bwd(mode);
   hipStream_t stream = (hipStream_t)stream_;
   SPT_CHECK_ARG(rows >= 0, "bad shape");
   SPT_CHECK_ARG(spt_skinny_dw_supported(K, N), "(K, N) not built");
@@ -582,18 +773,20 @@ extern "C" int spt_skinny_dw_pre_f32(const float* gy, const float* x, int64_t ro
   if (bx > cap) bx = cap;
   const dim3 grid((unsigned)bx, (unsigned)slabs, (unsigned)kslabs);
   float* partial = (float*)ws;
+#define SPT_DW(K4, PRE_, PR_)                                                                       \
+  skinny_dw_kernel<K4, PRE_, PR_><<<grid, WAVES * 64, 0, stream>>>(gy, x, rows, N, K, partial, pre_am, \
+                                                                   pre_scale, pre_bias, batch, num_graphs);
+#define SPT_DWS(K4, PRE_)                                                                           \
+  if (pr == 3) { SPT_DW(K4, PRE_, 3) } else if (pr == 1) { SPT_DW(K4, PRE_, 1) } else { SPT_DW(K4, PRE_, 0) }
   if (pre) {
-    if (K == 32)
-      skinny_dw_kernel<8, true><<<grid, WAVES * 64, 0, stream>>>(gy, x, rows, N, K, partial, pre_am,
-                                                                 pre_scale, pre_bias, batch, num_graphs);
-    else
-      skinny_dw_kernel<16, true><<<grid, WAVES * 64, 0, stream>>>(gy, x, rows, N, K, partial, pre_am,
-                                                                  pre_scale, pre_bias, batch, num_graphs);
+    if (K == 32) { SPT_DWS(8, true) } else { SPT_DWS(16, true) }
   } else if (K == 32) {
-    skinny_dw_kernel<8><<<grid, WAVES * 64, 0, stream>>>(gy, x, rows, N, K, partial);
+    SPT_DWS(8, false)
   } else {
-    skinny_dw_kernel<16><<<grid, WAVES * 64, 0, stream>>>(gy, x, rows, N, K, partial);
+    SPT_DWS(16, false)
   }
+#undef SPT_DWS
+#undef SPT_DW
   sum_tables_kernel<<<(N * (K + 1) + 15) / 16, 1024, 0, stream>>>(partial, (int)bx * WAVES, N * (K + 1),
                                                                   N * K, gw, gb);
   SPT_CHECK_LAUNCH();
@@ -621,28 +814,41 @@ extern "C" int spt_skinny_linear_f32(const float* x, int64_t rows, int K, const 
 static int skinny_linear_impl(const float* x, int64_t rows, int K, const float* W, const float* bias,
                               int N, float* y, const float* pre_am, const float* pre_scale,
                               const float* pre_bias, const int64_t* batch, int num_graphs,
-                              const float* residual, int ldwt, spt_stream_t stream_);
+                              const float* residual, int ldwt, int pr, spt_stream_t stream_);
 extern "C" int spt_skinny_linear_pre_f32(const float* x, int64_t rows, int K, const float* W,
                                          const float* bias, int N, float* y, const float* pre_am,
                                          const float* pre_scale, const float* pre_bias,
                                          const int64_t* batch, int num_graphs,
                                          const float* residual, spt_stream_t stream_) {
   return skinny_linear_impl(x, rows, K, W, bias, N, y, pre_am, pre_scale, pre_bias, batch, num_graphs,
-                            residual, 0, stream_);
+                            residual, 0, skinny_pr_fwd(-1), stream_);
+}
+// The same with the matrix mode per call (precision.py: the mode word of the op's forward)
+extern "C" int spt_skinny_linear_pre_m_f32(const float* x, int64_t rows, int K, const float* W,
+                                           const float* bias, int N, float* y, const float* pre_am,
+                                           const float* pre_scale, const float* pre_bias,
+                                           const int64_t* batch, int num_graphs,
+                                           const float* residual, int mode, spt_stream_t stream_) {
+  return skinny_linear_impl(x, rows, K, W, bias, N, y, pre_am, pre_scale, pre_bias, batch, num_graphs,
+                            residual, 0, skinny_pr_fwd(mode), stream_);
 }
 // y = x Wt (no transpose: Wt [K, N] row-major, e.g. dX = G W with the layer's own weight
 // [N_out = K, N_in = N]); same shapes as spt_skinny_linear_f32 with N % 4 == 0, N >= 64.
-extern "C" int spt_skinny_linear_wt_f32(const float* x, int64_t rows, int K, const float* Wt, int N,
-                                        float* y, spt_stream_t stream_) {
+extern "C" int spt_skinny_linear_wt_m_f32(const float* x, int64_t rows, int K, const float* Wt, int N,
+                                          float* y, int mode, spt_stream_t stream_) {
   SPT_CHECK_ARG(N % 4 == 0 && N >= SLAB, "transposed weight: N % 4 == 0 and N >= 64");
   SPT_CHECK_ARG(((uintptr_t)Wt) % 16 == 0, "Wt must be 16-byte aligned");
   return skinny_linear_impl(x, rows, K, Wt, nullptr, N, y, nullptr, nullptr, nullptr, nullptr, 1, nullptr,
-                            N, stream_);
+                            N, skinny_pr_bwd(mode), stream_);
+}
+extern "C" int spt_skinny_linear_wt_f32(const float* x, int64_t rows, int K, const float* Wt, int N,
+                                        float* y, spt_stream_t stream_) {
+  return spt_skinny_linear_wt_m_f32(x, rows, K, Wt, N, y, -1, stream_);
 }
 static int skinny_linear_impl(const float* x, int64_t rows, int K, const float* W, const float* bias,
                               int N, float* y, const float* pre_am, const float* pre_scale,
                               const float* pre_bias, const int64_t* batch, int num_graphs,
-                              const float* residual, int ldwt, spt_stream_t stream_) {
+                              const float* residual, int ldwt, int pr, spt_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SPT_CHECK_ARG(rows >= 0, "bad shape");
   SPT_CHECK_ARG(spt_skinny_linear_supported(K, N), "(K, N) not built");
@@ -661,21 +867,25 @@ static int skinny_linear_impl(const float* x, int64_t rows, int K, const float* 
   if (bx > cap) bx = cap;
   const dim3 grid((unsigned)bx, (unsigned)slabs);
   if (pre || resid) {
-#define SPT_SKINNY_PR(K4)                                                                          \
+#define SPT_SKINNY_PR(K4, PR_)                                                                     \
   if (pre && resid)                                                                                \
-    skinny_linear_kernel<K4, 4, true, true><<<grid, WAVES * 64, 0, stream>>>(                      \
+    skinny_linear_kernel<K4, 4, true, true, PR_><<<grid, WAVES * 64, 0, stream>>>(                 \
         x, rows, W, bias, N, y, pre_am, pre_scale, pre_bias, batch, num_graphs, residual);         \
   else if (pre)                                                                                    \
-    skinny_linear_kernel<K4, 4, true, false><<<grid, WAVES * 64, 0, stream>>>(                     \
+    skinny_linear_kernel<K4, 4, true, false, PR_><<<grid, WAVES * 64, 0, stream>>>(                \
         x, rows, W, bias, N, y, pre_am, pre_scale, pre_bias, batch, num_graphs, nullptr);          \
   else                                                                                             \
-    skinny_linear_kernel<K4, 4, false, true><<<grid, WAVES * 64, 0, stream>>>(                     \
+    skinny_linear_kernel<K4, 4, false, true, PR_><<<grid, WAVES * 64, 0, stream>>>(                \
         x, rows, W, bias, N, y, nullptr, nullptr, nullptr, nullptr, 1, residual);
+#define SPT_SKINNY_PRS(K4)                                                                         \
+  if (pr == 6) { SPT_SKINNY_PR(K4, 6) } else if (pr == 3) { SPT_SKINNY_PR(K4, 3) }                 \
+  else if (pr == 1) { SPT_SKINNY_PR(K4, 1) } else { SPT_SKINNY_PR(K4, 0) }
     switch (K) {
-      case 32:  SPT_SKINNY_PR(8) break;
-      case 64:  SPT_SKINNY_PR(16) break;
-      default:  SPT_SKINNY_PR(32) break;
+      case 32:  SPT_SKINNY_PRS(8) break;
+      case 64:  SPT_SKINNY_PRS(16) break;
+      default:  SPT_SKINNY_PR(32, 0) break;            // (K = 128: the f32 pipe in every mode)
     }
+#undef SPT_SKINNY_PRS
 #undef SPT_SKINNY_PR
     SPT_CHECK_LAUNCH();
     return 0;
@@ -690,8 +900,16 @@ static int skinny_linear_impl(const float* x, int64_t rows, int K, const float* 
     return 0;
   }
   switch (K) {
-    case 32:  skinny_linear_kernel<8><<<grid, WAVES * 64, 0, stream>>>(x, rows, W, bias, N, y, nullptr, nullptr, nullptr, nullptr, 1, nullptr, ldwt); break;
-    case 64:  skinny_linear_kernel<16><<<grid, WAVES * 64, 0, stream>>>(x, rows, W, bias, N, y, nullptr, nullptr, nullptr, nullptr, 1, nullptr, ldwt); break;
+#define SPT_SKINNY_PL(K4, PR_)                                                                     \
+  skinny_linear_kernel<K4, 4, false, false, PR_><<<grid, WAVES * 64, 0, stream>>>(                 \
+      x, rows, W, bias, N, y, nullptr, nullptr, nullptr, nullptr, 1, nullptr, ldwt);
+#define SPT_SKINNY_PLS(K4)                                                                         \
+  if (pr == 6) { SPT_SKINNY_PL(K4, 6) } else if (pr == 3) { SPT_SKINNY_PL(K4, 3) }                 \
+  else if (pr == 1) { SPT_SKINNY_PL(K4, 1) } else { SPT_SKINNY_PL(K4, 0) }
+    case 32:  SPT_SKINNY_PLS(8) break;
+    case 64:  SPT_SKINNY_PLS(16) break;
+#undef SPT_SKINNY_PLS
+#undef SPT_SKINNY_PL
     case 128: skinny_linear_kernel<32><<<grid, WAVES * 64, 0, stream>>>(x, rows, W, bias, N, y, nullptr, nullptr, nullptr, nullptr, 1, nullptr, ldwt); break;
     case 256: {                                          // dX of the 128-wide blocks' qkv Linear (256 -> 128):
       int64_t b4 = ceil_div(tiles, (int64_t)4);          // 4-wave workgroups, slab + tiles = 133 KB of LDS
@@ -717,8 +935,15 @@ static int skinny_linear_impl(const float* x, int64_t rows, int K, const float* 
         skinny_linear_wlds_kernel<33><<<dim3((unsigned)b8, (unsigned)slabs), WAVES_L * 64, 0, stream>>>(
             x, rows, W, bias, N, y, ldwt);
       else
-        skinny_linear_wlds_kernel<48><<<dim3((unsigned)b8, (unsigned)slabs), WAVES_L * 64, 0, stream>>>(
-            x, rows, W, bias, N, y, ldwt);
+      {
+        const dim3 g8((unsigned)b8, (unsigned)slabs);
+        if (pr >= 3)                                    // (a forward call's six products: three here)
+          skinny_linear_wlds_kernel<48, WAVES_L, 3><<<g8, WAVES_L * 64, 0, stream>>>(x, rows, W, bias, N, y, ldwt);
+        else if (pr == 1)
+          skinny_linear_wlds_kernel<48, WAVES_L, 1><<<g8, WAVES_L * 64, 0, stream>>>(x, rows, W, bias, N, y, ldwt);
+        else
+          skinny_linear_wlds_kernel<48><<<g8, WAVES_L * 64, 0, stream>>>(x, rows, W, bias, N, y, ldwt);
+      }
       break;
     }
   }

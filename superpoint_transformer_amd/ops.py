@@ -906,22 +906,23 @@ def _skinny_ok(x, weight):
             and _lib.lib.spt_skinny_linear_supported(weight.shape[1], weight.shape[0]))
 
 
-def _skinny_launch(x, weight, bias):
-    """y = x W^T + b on the MFMA skinny-GEMM kernel (csrc/skinny_linear.hip)."""
+def _skinny_launch(x, weight, bias, mode=-1):
+    """y = x W^T + b on the MFMA skinny-GEMM kernel (csrc/skinny_linear.hip); ``mode``: the matrix
+    mode word of the call (``precision.skinny_mode()``; -1 = the library's default)."""
     x = x.contiguous()
     weight = weight.contiguous()
     rows, k = x.shape
     n = weight.shape[0]
     y = torch.empty((rows, n), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        st = _lib.lib.spt_skinny_linear_f32(
+        st = _lib.lib.spt_skinny_linear_pre_m_f32(
             _lib.ptr(x), rows, k, _lib.ptr(weight), _lib.ptr(bias), n, _lib.ptr(y),
-            _lib.stream_ptr(x.device))
-    _lib.check(st, "spt_skinny_linear_f32")
+            None, None, None, None, 1, None, int(mode), _lib.stream_ptr(x.device))
+    _lib.check(st, "spt_skinny_linear_pre_m_f32")
     return y
 
 
-def _input_grad(g, weight):
+def _input_grad(g, weight, mode=-1):
     """dX = G W of a Linear (``weight`` [N_out, N_in] as the layer holds it): the skinny kernel reads
     the weight transposed while it stages the slab (``spt_skinny_linear_wt_f32``) - no transposed
     copy per backward call -, else the transposed copy on the same kernel, else the library."""
@@ -934,12 +935,12 @@ def _input_grad(g, weight):
         rows = g.shape[0]
         y = torch.empty((rows, n_in), dtype=torch.float32, device=g.device)
         with torch.cuda.device(g.device):
-            st = _lib.lib.spt_skinny_linear_wt_f32(_lib.ptr(g), rows, n_out, _lib.ptr(w), n_in,
-                                                   _lib.ptr(y), _lib.stream_ptr(g.device))
-        _lib.check(st, "spt_skinny_linear_wt_f32")
+            st = _lib.lib.spt_skinny_linear_wt_m_f32(_lib.ptr(g), rows, n_out, _lib.ptr(w), n_in,
+                                                     _lib.ptr(y), int(mode), _lib.stream_ptr(g.device))
+        _lib.check(st, "spt_skinny_linear_wt_m_f32")
         return y
     wt = weight.detach().t().contiguous()           # [K, N]: dX = G (W^T)^T
-    return _skinny_launch(g, wt, None) if _skinny_ok(g, wt) else g @ weight
+    return _skinny_launch(g, wt, None, mode) if _skinny_ok(g, wt) else g @ weight
 
 
 def _dw_batched(g, x):
@@ -966,7 +967,7 @@ def _skinny_dw_ok(g, x):
             and _lib.lib.spt_skinny_dw_supported(x.shape[1], g.shape[1]))
 
 
-def _skinny_dw(g, x, want_bias=False):
+def _skinny_dw(g, x, want_bias=False, mode=-1):
     """dW = G^T X (and, from the same pass, db = column sums of G) on the MFMA kernel of
     csrc/skinny_linear.hip (per-wave partials, fixed-order sum)."""
     g, x = g.contiguous(), x.detach().contiguous()
@@ -977,10 +978,10 @@ def _skinny_dw(g, x, want_bias=False):
     nb = _lib.lib.spt_skinny_dw_workspace_bytes(k, n)
     ws = _workspace(nb, x.device)
     with torch.cuda.device(x.device):
-        st = _lib.lib.spt_skinny_dw_f32(_lib.ptr(g), _lib.ptr(x), rows, n, k, _lib.ptr(gw),
-                                        _lib.ptr(gb), _lib.ptr(ws), ws.numel(),
-                                        _lib.stream_ptr(x.device))
-    _lib.check(st, "spt_skinny_dw_f32")
+        st = _lib.lib.spt_skinny_dw_pre_m_f32(_lib.ptr(g), _lib.ptr(x), rows, n, k, _lib.ptr(gw),
+                                              _lib.ptr(gb), None, None, None, None, 1, int(mode),
+                                              _lib.ptr(ws), ws.numel(), _lib.stream_ptr(x.device))
+    _lib.check(st, "spt_skinny_dw_pre_m_f32")
     return (gw, gb) if want_bias else gw
 
 
@@ -994,8 +995,10 @@ class _TallLinear(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        ctx.smode = _precision.skinny_mode()      # the backward runs in the mode of the forward
         if _skinny_ok(x, weight):
-            return _skinny_launch(x.detach(), weight.detach(), None if bias is None else bias.detach())
+            return _skinny_launch(x.detach(), weight.detach(), None if bias is None else bias.detach(),
+                                  ctx.smode)
         return torch.nn.functional.linear(x, weight, bias)
 
     @staticmethod
@@ -1022,13 +1025,14 @@ class _TallLinear(torch.autograd.Function):
             _lib.check(st, "spt_narrow_linear_bwd_f32")
             return gx, gw, gb
         gx = None
+        smode = getattr(ctx, "smode", -1)
         if ctx.needs_input_grad[0]:
-            gx = _input_grad(g, weight)
+            gx = _input_grad(g, weight, smode)
         gw = gb = None
         want_gb = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             if _skinny_dw_ok(g, x):
-                gw = _skinny_dw(g, x, want_gb)
+                gw = _skinny_dw(g, x, want_gb, smode)
                 if want_gb:
                     gw, gb = gw
             else:
@@ -1056,17 +1060,18 @@ class _ResidualLinear(torch.autograd.Function):
     def forward(ctx, x, weight, bias, residual):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        ctx.smode = _precision.skinny_mode()
         xd, wd = x.detach().contiguous(), weight.detach().contiguous()
         rows, k = xd.shape
         n = wd.shape[0]
         y = torch.empty((rows, n), dtype=torch.float32, device=xd.device)
         with torch.cuda.device(xd.device):
-            st = _lib.lib.spt_skinny_linear_pre_f32(
+            st = _lib.lib.spt_skinny_linear_pre_m_f32(
                 _lib.ptr(xd), rows, k, _lib.ptr(wd),
                 _lib.ptr(None if bias is None else bias.detach().contiguous()), n, _lib.ptr(y),
                 None, None, None, None, 1, _lib.ptr(residual.detach().contiguous()),
-                _lib.stream_ptr(xd.device))
-        _lib.check(st, "spt_skinny_linear_pre_f32")
+                ctx.smode, _lib.stream_ptr(xd.device))
+        _lib.check(st, "spt_skinny_linear_pre_m_f32")
         return y
 
     @staticmethod
@@ -1141,12 +1146,14 @@ class _NormLinear(torch.autograd.Function):
                 _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(am), _lib.ptr(sc), _lib.ptr(ws),
                 ws.numel(), _lib.stream_ptr(dev))
             _lib.check(st, "spt_graphnorm_stats_f32")
-            st = _lib.lib.spt_skinny_linear_pre_f32(
+            smode = _precision.skinny_mode()
+            st = _lib.lib.spt_skinny_linear_pre_m_f32(
                 _lib.ptr(xd), rows, d, _lib.ptr(wd), _lib.ptr(bd), n, _lib.ptr(y), _lib.ptr(am),
-                _lib.ptr(sc), _lib.ptr(b), _lib.ptr(batch), B, None, _lib.stream_ptr(dev))
-        _lib.check(st, "spt_skinny_linear_pre_f32")
+                _lib.ptr(sc), _lib.ptr(b), _lib.ptr(batch), B, None, smode, _lib.stream_ptr(dev))
+        _lib.check(st, "spt_skinny_linear_pre_m_f32")
         ctx.save_for_backward(xd, batch, w, b, a, mean, rstd, am, sc, wd)
         ctx.meta = (B, bias is not None)
+        ctx.smode = smode                          # the backward runs in the mode of the forward
         # an unused output arrives as None in the backward instead of a dense zero [rows, C]
         # tensor that the norm's backward kernel would read for nothing
         ctx.set_materialize_grads(False)
@@ -1163,17 +1170,17 @@ class _NormLinear(torch.autograd.Function):
         dev = xd.device
         gy = gy.contiguous()
         # gradient wrt the normalised rows: dX of the Linear
-        gxn = _input_grad(gy, wd)
+        gxn = _input_grad(gy, wd, ctx.smode)
         # weight / bias gradient against the rows normalised on the fly
         gw = torch.empty((n, d), dtype=torch.float32, device=dev)
         gb = torch.empty(n, dtype=torch.float32, device=dev) if has_bias else None
         ws = _workspace(_lib.lib.spt_skinny_dw_workspace_bytes(d, n), dev)
         with torch.cuda.device(dev):
-            st = _lib.lib.spt_skinny_dw_pre_f32(
+            st = _lib.lib.spt_skinny_dw_pre_m_f32(
                 _lib.ptr(gy), _lib.ptr(xd), rows, n, d, _lib.ptr(gw), _lib.ptr(gb), _lib.ptr(am),
-                _lib.ptr(sc), _lib.ptr(b), _lib.ptr(batch), B, _lib.ptr(ws), ws.numel(),
+                _lib.ptr(sc), _lib.ptr(b), _lib.ptr(batch), B, ctx.smode, _lib.ptr(ws), ws.numel(),
                 _lib.stream_ptr(dev))
-        _lib.check(st, "spt_skinny_dw_pre_f32")
+        _lib.check(st, "spt_skinny_dw_pre_m_f32")
         # the norm's backward, with the residual branch's gradient added in its apply pass
         gx = torch.empty_like(xd)
         g_w, g_b, g_a = (torch.empty(d, dtype=torch.float32, device=dev) for _ in range(3))

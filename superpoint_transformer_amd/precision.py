@@ -8,8 +8,9 @@ switch, configs/trainer/gpu.yaml:7-10).
                      product - next to ``precision: 32`` (configs/trainer/gpu.yaml:7-10).  Here:
                      attention split-bf16 = that bf16x3 scheme (hi*hi + lo*hi + hi*lo, ~2^-17
                      relative per product: 17 of f32's 24 bits, 7 more than TF32's 10); fused MLP
-                     layers: forward as the f32-EXACT 3-way split (6 bf16 products: tighter than
-                     "high" asks for), backward split-bf16.  Every f32 parity bar of tests/ holds
+                     layers and (round 6) the tall-skinny Linears of the attention blocks: forward
+                     as the f32-EXACT 3-way split (6 bf16 products: tighter than "high" asks for),
+                     backward split-bf16.  Every f32 parity bar of tests/ holds
                      in this mode (the bars are set on tolerances, not on this knob).
 ``"bf16"``           what ``torch.autocast(bfloat16)`` does to the reference's Linear layers:
                      operands rounded to bf16, f32 accumulate, and - for the point MLP, whose
@@ -35,7 +36,7 @@ import os
 
 from . import _lib
 
-_MODES = {"f32": (2, 1), "bf16": (3, 3), "f32-exact": (1, 0)}   # (attention, fused MLP)
+_MODES = {"f32": (2, 1, 1), "bf16": (3, 3, 3), "f32-exact": (1, 0, 0)}   # (attention, fused MLP, skinny Linears)
 _default = "f32"
 _active = contextvars.ContextVar("spt_matrix_precision", default=None)
 
@@ -49,9 +50,10 @@ def set_matrix_precision(mode):
     """Process-wide default (the library's setters); returns the previous mode name."""
     global _default
     _check(mode)
-    a, m = _MODES[mode]
+    a, m, k = _MODES[mode]
     _lib.lib.spt_attn_use_mfma(a)
     _lib.lib.spt_fused_linear_use_split_bf16(m)
+    _lib.lib.spt_skinny_use_split_bf16(k)
     prev, _default = _default, mode
     return prev
 
@@ -89,6 +91,14 @@ def attention_backward_order(order):
         yield
     finally:
         _order.reset(token)
+
+
+def skinny_mode():
+    """Mode word for the ``spt_skinny_*_m_f32`` entries (the attention block's qkv / out_proj Linears,
+    the FFN, the heads' input gradients): -1 (the library's default) unless a per-call precision is
+    active."""
+    mode = _active.get()
+    return -1 if mode is None else _MODES[mode][2]
 
 
 def fused_mode():

@@ -589,9 +589,10 @@ def test_edge_lane_backward_stays_inside_an_exact_workspace_when_edges_are_fewer
     ref = O.self_attention(x64, ei, ea64, p, H, D)
     (ref * gw.double()).sum().backward()
     _check(out, ref, "out")
-    _check(xd.grad, x64.grad, "g_x")
-    # (36 000 edge rows: the extreme element of the split-bf16 products sits at 1.5e-5 in both
-    # orders alike, a hair over the element-wise bar the small graphs above meet: tensor scale here)
+    # (60 000 node rows / 36 000 edge rows: the extreme element of the split-bf16 products - the
+    # attention's and, since round 6, the qkv Linear's input gradient - sits at 1.3e-5 .. 1.5e-5 in
+    # both orders alike, a hair over the element-wise bar the small graphs above meet: tensor scale here)
+    _check(xd.grad, x64.grad, "g_x", rel_to_max=True)
     _check(ead.grad, ea64.grad, "g_edge_attr", rel_to_max=True)
     for k, v in blk.named_parameters():
         _check(v.grad, p[k].grad, "g_" + k, rel_to_max=True)
