@@ -671,8 +671,9 @@ def main():
             "dtype": {"f32": "f32 (the reference's shipped matmul class - configs/train.yaml:60-61 "
                              "`float32_matmul_precision: high` = TF32 / bf16x3 next to `precision: 32` - as "
                              "bf16x3: matrix products on the bf16 pipe with split operands, attention and the "
-                             "fused layers' backward hi*hi + lo*hi + hi*lo, the fused layers' forward the "
-                             "f32-exact 3-way split with 6 products; f32 accumulate, storage and statistics)",
+                             "backward of the fused layers and of the attention blocks' Linears hi*hi + lo*hi + "
+                             "hi*lo, the forward of the fused layers and of those Linears the f32-exact 3-way "
+                             "split with 6 products; f32 accumulate, storage and statistics)",
                       "f32-exact": "f32 (f32 matrix pipe: the reference under `float32_matmul_precision: highest`)",
                       "bf16": ("bf16 (matrix operands and the point MLP's stored layer outputs; f32 "
                                "accumulate, statistics, gradients, segment / attention tensors)"
