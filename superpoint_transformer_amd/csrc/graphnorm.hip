@@ -19,7 +19,10 @@ namespace spt {
 
 constexpr int GN_THREADS = 256;
 constexpr int GN_MAX_BLOCKS = 1024;
-constexpr int GN_UNR = 4;
+#ifndef SPT_GN_UNR
+#define SPT_GN_UNR 4
+#endif
+constexpr int GN_UNR = SPT_GN_UNR;
 
 struct GnShape {
   int vec, lpr_log2, rpb;  // floats per lane, lanes per row (log2), rows per block-iteration
