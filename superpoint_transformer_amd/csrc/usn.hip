@@ -55,7 +55,11 @@ __device__ __forceinline__ double row_weight(const float* wf, const int64_t* wi,
   return 1.0;
 }
 
-__device__ __forceinline__ void box_finish(const Box& b, int cnt, float* center, float* diam) {
+// cd4 (nullable): the same four values once more as ONE 16-byte record [cx, cy, cz, diameter] per
+// segment - the assemble pass gathers them per row, and two gathers (12 + 4 bytes from two arrays)
+// are two 64-byte sectors per row where the tables do not fit an XCD's L2 (round 6)
+__device__ __forceinline__ void box_finish(const Box& b, int cnt, float* center, float* diam,
+                                           float4* cd4 = nullptr) {
   // norm.py:118-126: empty segment -> min = max = 0 -> diameter 0, centre 0;
   // weighted mean divides by the weight sum, 0 replaced by 1 (scatter.py:35)
   float d = 0.f;
@@ -67,6 +71,7 @@ __device__ __forceinline__ void box_finish(const Box& b, int cnt, float* center,
 #pragma unroll
   for (int k = 0; k < 3; ++k) center[k] = (float)(b.sx[k] / den);
   *diam = d;
+  if (cd4) *cd4 = make_float4(center[0], center[1], center[2], d);
 }
 
 // One lane group of 2^g_log2 lanes per segment.
@@ -74,7 +79,7 @@ __global__ __launch_bounds__(256) void usn_stats_group_kernel(
     const float* __restrict__ pos, const int32_t* __restrict__ perm,
     const int32_t* __restrict__ rowptr, const float* __restrict__ wf,
     const int64_t* __restrict__ wi, int64_t num_seg, int g_log2,
-    float* __restrict__ center, float* __restrict__ diam) {
+    float* __restrict__ center, float* __restrict__ diam, float4* __restrict__ cd4 = nullptr) {
   const int lane = threadIdx.x & 63;
   const int g = 1 << g_log2;
   const int spw = 64 >> g_log2;
@@ -116,7 +121,7 @@ __global__ __launch_bounds__(256) void usn_stats_group_kernel(
         if (ok[u]) box_add(b, px[u], py[u], pz[u], pw[u]);
     }
     for (int o = 1; o < g; o <<= 1) box_merge_xor(b, o);
-    if (sv && lg == 0) box_finish(b, end - start, center + s * 3, diam + s);
+    if (sv && lg == 0) box_finish(b, end - start, center + s * 3, diam + s, cd4 ? cd4 + s : nullptr);
   }
 }
 
@@ -270,7 +275,8 @@ template <int CC4>
 __global__ __launch_bounds__(256) void usn_assemble_rows_kernel(
     const float* __restrict__ pos, const int64_t* __restrict__ idx,
     const float* __restrict__ center, const float* __restrict__ diam,
-    const float* __restrict__ x, int64_t n, float* __restrict__ out) {
+    const float* __restrict__ x, int64_t n, float* __restrict__ out,
+    const float4* __restrict__ cd4 = nullptr) {
   constexpr int R = CC4 <= 4 ? 256 : (CC4 <= 20 ? 64 : 32), CX4 = CC4 - 1;   // ~4 chunks per thread
   constexpr int PER = (R * CC4 + 255) / 256;             // output chunks per thread and block of rows
   __shared__ float4 hdr[R];
@@ -293,8 +299,17 @@ __global__ __launch_bounds__(256) void usn_assemble_rows_kernel(
       const int64_t i = row0 + t;
       const int64_t sg = idx ? idx[i] : 0;
       const f3 p = *reinterpret_cast<const f3*>(pos + i * 3);
-      const f3 ce = *reinterpret_cast<const f3*>(center + sg * 3);
-      const float dm = diam[sg], d = dm + 1e-2f;
+      f3 ce;
+      float dm;
+      if (cd4) {                                         // one 16-byte gather per row
+        const float4 t4 = cd4[sg];
+        ce.x = t4.x; ce.y = t4.y; ce.z = t4.z;
+        dm = t4.w;
+      } else {
+        ce = *reinterpret_cast<const f3*>(center + sg * 3);
+        dm = diam[sg];
+      }
+      const float d = dm + 1e-2f;
       hdr[t] = make_float4(dm, (p.x - ce.x) / d, (p.y - ce.y) / d, (p.z - ce.z) / d);
     }
     __syncthreads();
@@ -403,6 +418,7 @@ static int usn_launch(const float* pos, const int64_t* idx, const int32_t* perm,
   SPT_CHECK_ARG(idx || num_seg == 1, "idx may be null only for a single segment");
   const int64_t avg = n / num_seg;
   const int P = usn_slices(n, num_seg);
+  float4* cd4 = nullptr;
   if (avg >= 2048 && P > 1 && ws && ws_bytes >= (size_t)num_seg * P * sizeof(Box)) {
     usn_stats_split_kernel<<<dim3(P, (unsigned)num_seg), 256, 0, stream>>>(
         pos, perm, rowptr, w_f32, w_i64, P, (Box*)ws);
@@ -417,8 +433,11 @@ static int usn_launch(const float* pos, const int64_t* idx, const int32_t* perm,
     while (g_log2 < 6 && (((int64_t)4) << g_log2) <= avg) ++g_log2;  // ~4+ rows per lane
     const int spw = 64 >> g_log2;
     const int grid = stream_grid(ceil_div(num_seg, spw), 4);
+    // the packed [centre | diameter] records for the assemble pass, in the (here unused) workspace
+    if (xcat && idx && ws && ws_bytes >= (size_t)num_seg * sizeof(float4) + 256 && usn_rows_kernel())
+      cd4 = reinterpret_cast<float4*>(((uintptr_t)ws + 255) & ~(uintptr_t)255);
     usn_stats_group_kernel<<<grid, 256, 0, stream>>>(pos, perm, rowptr, w_f32, w_i64,
-                                                     num_seg, g_log2, center, diam);
+                                                     num_seg, g_log2, center, diam, cd4);
   }
   if (n > 0 && xcat)
   {
@@ -427,11 +446,11 @@ static int usn_launch(const float* pos, const int64_t* idx, const int32_t* perm,
     const int64_t rblk = ceil_div(n, (int64_t)(cx == 8 ? 256 : (cx == 64 ? 64 : 32)));
     const int rgrid = (int)(rblk < 256 * 16 ? rblk : 256 * 16);
     if (cx == 8 && usn_rows_kernel())
-      usn_assemble_rows_kernel<3><<<rgrid, 256, 0, stream>>>(pos, idx, center, diam, x, n, xcat);
+      usn_assemble_rows_kernel<3><<<rgrid, 256, 0, stream>>>(pos, idx, center, diam, x, n, xcat, cd4);
     else if (cx == 64 && usn_rows_kernel())
-      usn_assemble_rows_kernel<17><<<rgrid, 256, 0, stream>>>(pos, idx, center, diam, x, n, xcat);
+      usn_assemble_rows_kernel<17><<<rgrid, 256, 0, stream>>>(pos, idx, center, diam, x, n, xcat, cd4);
     else if (cx == 128 && usn_rows_kernel())
-      usn_assemble_rows_kernel<33><<<rgrid, 256, 0, stream>>>(pos, idx, center, diam, x, n, xcat);
+      usn_assemble_rows_kernel<33><<<rgrid, 256, 0, stream>>>(pos, idx, center, diam, x, n, xcat, cd4);
     else if (i32 && cx == 8)
       usn_assemble_kernel<uint32_t, 3><<<stream_grid(chunks, 256), 256, 0, stream>>>(
           pos, idx, center, diam, x, cx / 4, n, xcat);
