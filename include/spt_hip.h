@@ -1064,7 +1064,9 @@ int spt_csr_adopt_i64(const int64_t* idx, const int64_t* points, const int64_t* 
  *             first row attaining the raw extremum (n_rows for an empty segment, like
  *             spt_segcsr_reduce_f32; the reference's arg except on ties of y between rows of
  *             different h); argpos [num_seg, N] int32 = the CSR position of that row (arg =
- *             perm[argpos]: what the backward scatters by); raw [num_seg, N] = h of the arg row; gram [num_graphs, K K + K + 1] f64
+ *             perm[argpos]: what the backward scatters by; arg may be NULL (round 6): a caller that only
+ *             runs the fused backward needs the positions alone, and the row ids cost one scattered
+ *             4-byte read per (segment, channel)); raw [num_seg, N] = h of the arg row; gram [num_graphs, K K + K + 1] f64
  *             = (sum_i y_i y_i^T | sum_i y_i | rows) of the layer's activated INPUT per graph, from
  *             which the norm's statistics are evaluated (total [num_graphs, 2N+1], nullable, receives
  *             them in spt_fused_linear_fwd_*'s layout) and its tables mean / rstd / am / scale

@@ -2204,7 +2204,7 @@ extern "C" int spt_fused_linear_fwd_pool_runs_f32(
   SPT_CHECK_ARG(fpool_supported(K, N) && prec != 0 && (!in16 || prec == 1),
                 "(K, N) has no pool-fused kernel in this matrix mode");
   SPT_CHECK_ARG(x && pos_seg && rowptr && W && gn_weight && gn_bias && gn_mean_scale && pre_am &&
-                pre_scale && pre_bias && out && arg && argpos && raw && gram && mean && rstd && am && scale && ws,
+                pre_scale && pre_bias && out && argpos && raw && gram && mean && rstd && am && scale && ws,
                 "null pointer");
   SPT_CHECK_ARG(num_seg >= 0 && n_rows >= 0 && (num_graphs == 1 || seg_graph), "bad shape");
   SPT_CHECK_ARG(ws_bytes >= spt_fused_linear_pool_workspace_bytes(K, N), "workspace too small");

@@ -590,7 +590,7 @@ __global__ __launch_bounds__(256) void pool_apply_kernel(
   if (a1 <= a0) {                                        // empty: segcsr's convention
     out[t] = 0.f;
     raw[t] = 0.f;
-    arg[t] = (int32_t)n_rows;
+    if (arg) arg[t] = (int32_t)n_rows;
     argpos[t] = (int32_t)n_rows;
     return;
   }
@@ -618,7 +618,9 @@ __global__ __launch_bounds__(256) void pool_apply_kernel(
     argpos[t] = pos;
   }
   // (no row won - every value NaN: the sentinel of an empty segment)
-  arg[t] = (pos >= a0 && pos < a1) ? (perm ? perm[pos] : pos) : (int32_t)n_rows;
+  // arg (the winner's ORIGINAL row: one scattered 4-byte read of perm per (segment, channel)) is
+  // optional - the fused backward works on argpos (round 6: a training step passes NULL)
+  if (arg) arg[t] = (pos >= a0 && pos < a1) ? (perm ? perm[pos] : pos) : (int32_t)n_rows;
   float y = fmaf(h - am[gph * N + c], sc[gph * N + c], bs[c]);   // gn_apply_fwd_kernel's expression
   y = y > 0.f ? y : y * slope;
   out[t] = y;

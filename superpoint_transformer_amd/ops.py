@@ -1776,7 +1776,10 @@ class _FusedMLPMaxPool(torch.autograd.Function):
         S = csr.num_seg
         nr, c_r0, c_r1, c_g = runs.c_arrays()
         out = torch.empty((S, N), dtype=torch.float32, device=dev)
-        arg = torch.empty((S, N), dtype=torch.int32, device=dev)
+        # (the winners' ORIGINAL rows are not asked for: the fused backward and the sparse
+        # statistics work on the CSR positions - `arg` would cost one scattered read of perm per
+        # (segment, channel): 55 M of them at scene S, 0.17 ms)
+        arg = None
         argpos = torch.empty((S, N), dtype=torch.int32, device=dev)
         raw = torch.empty((S, N), dtype=torch.float32, device=dev)
         glen = int(_lib.lib.spt_fused_linear_pool_gram_len(K))
@@ -1798,7 +1801,7 @@ class _FusedMLPMaxPool(torch.autograd.Function):
         _lib.check(st, "spt_fused_linear_fwd_pool_runs_f32")
         ctx.pool_fused = True
         ctx.n_sub = len(saved_sub)
-        ctx.save_for_backward(arg, raw, gram, mean, rstd, am, sc, W, gnw, gnb, gms, h_prev, pam, psc,
+        ctx.save_for_backward(argpos, raw, gram, mean, rstd, am, sc, W, gnw, gnb, gms, h_prev, pam, psc,
                               pbs, argpos, *saved_sub)
         ctx.csr = csr
         ctx.seg_graph = seg_graph
@@ -1828,6 +1831,7 @@ class _FusedMLPMaxPool(torch.autograd.Function):
             rows = _const_tensor(runs.rows_per_graph(), torch.int64, dev)
             nbs = _lib.lib.spt_graphnorm_bwd_stats_sparse_workspace_bytes(S, N, B)
             ws = _workspace(nbs, dev)
+            # (`arg` = the CSR positions: the raw variant reads it for the empty-segment sentinel only)
             st = _lib.lib.spt_graphnorm_bwd_stats_sparse_raw_f32(
                 _lib.ptr(raw), _lib.ptr(gout), _lib.ptr(arg), _lib.ptr(ctx.seg_graph),
                 _lib.ptr(rows), S, R, N, B, _lib.ptr(am), _lib.ptr(sc), _lib.ptr(gnb),

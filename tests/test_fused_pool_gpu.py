@@ -74,7 +74,13 @@ def _run(mlp, x, batch, seg_graph, si, gout, nseg, B, dev, fused):
         arg = None
         if fused:
             assert getattr(node, "pool_fused", False), "the pool-fused route did not run"
-            arg = node.saved_tensors[0].cpu().long()
+            # (round 6: the step keeps the winners' CSR POSITIONS only - the kernel's `arg` output is
+            # optional and not asked for; the winner's original row is perm[position], as the kernel
+            # writes it when asked - test_forward_entry... below checks that identity on the C entry)
+            ap = node.saved_tensors[0].long()
+            perm = node.csr.perm.long()
+            nrows = x.shape[0]
+            arg = torch.where(ap < nrows, perm[ap.clamp(max=nrows - 1)], torch.full_like(ap, nrows)).cpu()
             big = [t for t in node.saved_tensors
                    if t is not None and t.dim() == 2 and t.shape[0] == x.shape[0]]
             # saved per-row tensors: the MLP's input and the raw outputs of layers 0 .. L-2 (the last
@@ -293,6 +299,15 @@ def test_gram_statistics_equal_the_sums_over_the_output(dev):
     same = (arg.cpu().long() == pa)
     assert float(same.float().mean()) > 0.999
     assert torch.equal(view.perm.long()[argpos.long()], arg.long())
+    # arg is optional (what a training step passes since round 6): same out / raw / argpos without it
+    out2, raw2, argpos2 = torch.empty_like(out), torch.empty_like(raw), torch.empty_like(argpos)
+    st = _lib.lib.spt_fused_linear_fwd_pool_runs_f32(
+        P(xd), P(view.perm), P(view.pos_seg()), P(view.rowptr), None, nseg, rows, 1, r0, r1, g0, 1, K,
+        P(Wd), N, P(gnwd), P(gnbd), P(gmsd), 1e-5, 0.01, P(pamd), P(pscd), P(pbsd), 0.2, P(out2), None,
+        P(argpos2), P(raw2), P(gram), P(total), P(mean), P(rstd), P(am), P(sc), 1, P(ws), ws.numel(),
+        _lib.stream_ptr(dev))
+    _lib.check(st, "spt_fused_linear_fwd_pool_runs_f32")
+    assert torch.equal(out2, out) and torch.equal(raw2, raw) and torch.equal(argpos2, argpos)
     assert bool(torch.isfinite(y).all())
 
 
