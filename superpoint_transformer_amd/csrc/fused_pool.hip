@@ -582,48 +582,67 @@ __global__ __launch_bounds__(256) void pool_apply_kernel(
     const float* __restrict__ W, const float* __restrict__ pam, const float* __restrict__ psc,
     const float* __restrict__ pbs, float pslope, int bfw, float* __restrict__ raw,
     int32_t* __restrict__ argpos, int32_t* __restrict__ arg, float* __restrict__ out) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= num_seg * N) return;
-  const int64_t s = t / N;
-  const int c = (int)(t - s * N);
+  // (round 6: four channels per thread - 16-byte reads of raw / argpos, 16-byte writes of out / arg;
+  //  N % 4 == 0.  The per-element arithmetic is unchanged.)
+  const int64_t t4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (t4 >= num_seg * N) return;
+  const int64_t s = t4 / N;
+  const int c0 = (int)(t4 - s * N);
   const int a0 = rowptr[s], a1 = rowptr[s + 1];
   if (a1 <= a0) {                                        // empty: segcsr's convention
-    out[t] = 0.f;
-    raw[t] = 0.f;
-    if (arg) arg[t] = (int32_t)n_rows;
-    argpos[t] = (int32_t)n_rows;
+    const int32_t nr = (int32_t)n_rows;
+    *reinterpret_cast<float4*>(out + t4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(raw + t4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (arg) *reinterpret_cast<int4*>(arg + t4) = make_int4(nr, nr, nr, nr);
+    *reinterpret_cast<int4*>(argpos + t4) = make_int4(nr, nr, nr, nr);
     return;
   }
   const int64_t gph = seg_graph ? seg_graph[s] : 0;
-  float h = raw[t];
-  int pos = argpos[t];
-  if (gnw[c] == 0.f) {
-    pos = a0;
-    const int row = perm ? perm[a0] : a0;
-    double acc = 0.0;
-    for (int k = 0; k < K; ++k) {
-      float v = IN16 ? __uint_as_float((unsigned)reinterpret_cast<const uint16_t*>(x)[(int64_t)row * K + k] << 16)
-                     : x[(int64_t)row * K + k];
-      v = fmaf(v - pam[gph * K + k], psc[gph * K + k], pbs[k]);
-      v = v > 0.f ? v : v * pslope;
-      float w = W[(size_t)c * K + k];
-      if (bfw) {
-        w = (float)(__bf16)w;
-        v = (float)(__bf16)v;
+  const float4 h4 = *reinterpret_cast<const float4*>(raw + t4);
+  const int4 p4 = *reinterpret_cast<const int4*>(argpos + t4);
+  const float4 w4 = *reinterpret_cast<const float4*>(gnw + c0);
+  const float4 am4 = *reinterpret_cast<const float4*>(am + gph * N + c0);
+  const float4 sc4 = *reinterpret_cast<const float4*>(sc + gph * N + c0);
+  const float4 bs4 = *reinterpret_cast<const float4*>(bs + c0);
+  float hh[4] = {h4.x, h4.y, h4.z, h4.w};
+  int pp[4] = {p4.x, p4.y, p4.z, p4.w};
+  const float gw[4] = {w4.x, w4.y, w4.z, w4.w};
+  const float aa[4] = {am4.x, am4.y, am4.z, am4.w}, ss[4] = {sc4.x, sc4.y, sc4.z, sc4.w};
+  const float bb[4] = {bs4.x, bs4.y, bs4.z, bs4.w};
+  float yy[4];
+  int ar[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    if (gw[e] == 0.f) {
+      const int c = c0 + e;
+      pp[e] = a0;
+      const int row = perm ? perm[a0] : a0;
+      double acc = 0.0;
+      for (int k = 0; k < K; ++k) {
+        float v = IN16 ? __uint_as_float((unsigned)reinterpret_cast<const uint16_t*>(x)[(int64_t)row * K + k] << 16)
+                       : x[(int64_t)row * K + k];
+        v = fmaf(v - pam[gph * K + k], psc[gph * K + k], pbs[k]);
+        v = v > 0.f ? v : v * pslope;
+        float w = W[(size_t)c * K + k];
+        if (bfw) {
+          w = (float)(__bf16)w;
+          v = (float)(__bf16)v;
+        }
+        acc += (double)v * (double)w;
       }
-      acc += (double)v * (double)w;
+      hh[e] = (float)acc;
+      raw[t4 + e] = hh[e];
+      argpos[t4 + e] = pp[e];
     }
-    h = (float)acc;
-    raw[t] = h;
-    argpos[t] = pos;
+    // (no row won - every value NaN: the sentinel of an empty segment)
+    // arg (the winner's ORIGINAL row: one scattered 4-byte read of perm per (segment, channel)) is
+    // optional - the fused backward works on argpos (round 6: a training step passes NULL)
+    if (arg) ar[e] = (pp[e] >= a0 && pp[e] < a1) ? (perm ? perm[pp[e]] : pp[e]) : (int32_t)n_rows;
+    float y = fmaf(hh[e] - aa[e], ss[e], bb[e]);         // gn_apply_fwd_kernel's expression
+    yy[e] = y > 0.f ? y : y * slope;
   }
-  // (no row won - every value NaN: the sentinel of an empty segment)
-  // arg (the winner's ORIGINAL row: one scattered 4-byte read of perm per (segment, channel)) is
-  // optional - the fused backward works on argpos (round 6: a training step passes NULL)
-  if (arg) arg[t] = (pos >= a0 && pos < a1) ? (perm ? perm[pos] : pos) : (int32_t)n_rows;
-  float y = fmaf(h - am[gph * N + c], sc[gph * N + c], bs[c]);   // gn_apply_fwd_kernel's expression
-  y = y > 0.f ? y : y * slope;
-  out[t] = y;
+  if (arg) *reinterpret_cast<int4*>(arg + t4) = make_int4(ar[0], ar[1], ar[2], ar[3]);
+  *reinterpret_cast<float4*>(out + t4) = make_float4(yy[0], yy[1], yy[2], yy[3]);
 }
 
 // ---- backward, preparation ------------------------------------------------------------------------
@@ -1192,7 +1211,7 @@ void fpool_apply_launch(int K, bool in16, const int32_t* rowptr, const int32_t* 
                         int32_t* argpos, int32_t* arg, float* out, hipStream_t stream) {
   const int64_t total = num_seg * N;
   if (total <= 0) return;
-  const int grid = (int)ceil_div(total, 256);
+  const int grid = (int)ceil_div(total, 1024);            // four channels per thread
 #define XA(k, i16)                                                                                 \
   fpool::pool_apply_kernel<k, i16><<<grid, 256, 0, stream>>>(rowptr, perm, seg_graph, num_seg, N,  \
                                                              n_rows, am, sc, bs, slope, gnw, x, W, \
