@@ -814,28 +814,49 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_sparse_kernel(
     if (s2 != 0.0) atomicAdd(&tab[(size_t)(cur - b_lo) * row_len + d + c], s2);
     s1 = s2 = 0.0;
   };
-  for (int64_t s = (int64_t)blockIdx.x * spb + sub; s < num_seg; s += (int64_t)gridDim.x * spb) {
-    const int b = seg_graph ? (int)seg_graph[s] : 0;
-    if (b < b_lo || b >= b_lo + Bc) continue;   // another launch's graph
-    if (b != cur) {
-      flush();
-      cur = b;
-      t_am = am[(size_t)b * d + c];
-      t_sc = scale[(size_t)b * d + c];
+  // four segments per trip: their (graph, arg, gradient, value) loads are requested together (round
+  // 6: the loop was one 4-byte load per array and iteration - pure latency at 55 M elements)
+  const int64_t stride = (int64_t)gridDim.x * spb;
+  for (int64_t s0 = (int64_t)blockIdx.x * spb + sub; s0 < num_seg; s0 += 4 * stride) {
+    bool ok[4];
+    int bv[4];
+    int64_t iv[4];
+    float gv[4], xr[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t s = s0 + u * stride;
+      ok[u] = s < num_seg;
+      const int64_t sc_ = ok[u] ? s : s0;                 // (a valid segment: unconditional loads)
+      bv[u] = seg_graph ? (int)seg_graph[sc_] : 0;
+      iv[u] = arg[sc_ * d + c];
+      gv[u] = gout[sc_ * d + c];
+      xr[u] = RAWV ? x[sc_ * d + c] : 0.f;
     }
-    const int64_t i = arg[s * d + c];
-    if (i < 0 || i >= n) continue;         // empty segment: sentinel n
-    const float xv = RAWV ? x[s * d + c]
-                     : (X16 ? __uint_as_float((unsigned)reinterpret_cast<const uint16_t*>(x)[i * d + c] << 16)
-                            : x[i * d + c]);
-    const float o = xv - t_am;
-    float g = gout[s * d + c];
-    if (slope != 1.f) {
-      const float y = fmaf(o, t_sc, t_bs);
-      g = (y > 0.f) ? g : g * slope;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (!ok[u]) continue;
+      const int b = bv[u];
+      if (b < b_lo || b >= b_lo + Bc) continue;   // another launch's graph
+      if (b != cur) {
+        flush();
+        cur = b;
+        t_am = am[(size_t)b * d + c];
+        t_sc = scale[(size_t)b * d + c];
+      }
+      const int64_t i = iv[u];
+      if (i < 0 || i >= n) continue;         // empty segment: sentinel n
+      const float xv = RAWV ? xr[u]
+                       : (X16 ? __uint_as_float((unsigned)reinterpret_cast<const uint16_t*>(x)[i * d + c] << 16)
+                              : x[i * d + c]);
+      const float o = xv - t_am;
+      float g = gv[u];
+      if (slope != 1.f) {
+        const float y = fmaf(o, t_sc, t_bs);
+        g = (y > 0.f) ? g : g * slope;
+      }
+      s1 += (double)g;
+      s2 += (double)g * (double)o;
     }
-    s1 += (double)g;
-    s2 += (double)g * (double)o;
   }
   flush();
   __syncthreads();
