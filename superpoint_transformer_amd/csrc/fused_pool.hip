@@ -695,7 +695,9 @@ __global__ __launch_bounds__(256) void pool_bwd_coef_kernel(
     Ac[i] = fmaf(k2, am[b * N + i], -c3[b * N + i]);
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < K * K + K; i += blockDim.x) {
+  // (round 6: blockIdx.y slices the K K + K outputs - one workgroup per graph took 65 us for the
+  //  4 160 128-term sums of the 64 -> 128 layer; same sums per output)
+  for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < K * K + K; i += gridDim.y * blockDim.x) {
     double acc = 0.0;
     if (i < K * K) {
       const int j = i / K, k = i - j * K;
@@ -1236,9 +1238,9 @@ int fpool_bwd_launch(bool lo, bool x16, const float* gout, const float* raw, con
     fpool::pool_bwd_gm_kernel<<<(int)ceil_div(num_seg * N / 4, 256), 256, 0, stream>>>(
         gout, raw, seg_graph, num_seg, N, am, sc, bs, slope, c1, gm);
   if (K == 64)
-    fpool::pool_bwd_coef_kernel<64><<<num_graphs, 256, 2 * N * sizeof(float), stream>>>(W, N, am, c2, c3, Mbuf, c0buf);
+    fpool::pool_bwd_coef_kernel<64><<<dim3(num_graphs, (64 * 64 + 64 + 255) / 256), 256, 2 * N * sizeof(float), stream>>>(W, N, am, c2, c3, Mbuf, c0buf);
   else
-    fpool::pool_bwd_coef_kernel<32><<<num_graphs, 256, 2 * N * sizeof(float), stream>>>(W, N, am, c2, c3, Mbuf, c0buf);
+    fpool::pool_bwd_coef_kernel<32><<<dim3(num_graphs, (32 * 32 + 32 + 255) / 256), 256, 2 * N * sizeof(float), stream>>>(W, N, am, c2, c3, Mbuf, c0buf);
   constexpr int NW = 8;
   const int64_t tiles = (max_rows + fpool::TR - 1) / fpool::TR;
   int64_t blocks = (tiles + NW / 2 - 1) / (NW / 2);         // a tile is walked by a pair of waves
