@@ -792,8 +792,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_pool_kernel(
   c0g += (size_t)gph * K;
   // weight-gradient tables: ONE per workgroup (round 6, summed over the workgroup's wave pairs in
   // the epilogue) in front, one scratch record per wave pair behind them (the loop's dummy stores)
+  constexpr int SCR = 4 * (K / 32) * 64;                 // floats a wave's dummy stores touch
   float* gw_scratch = gw_partial + (size_t)gridDim.y * gridDim.x * N * K +
-                      (size_t)run * gridDim.x * (NW / 2) * N * K;
+                      (size_t)run * gridDim.x * (NW / 2) * 2 * SCR;
   gw_partial += (size_t)run * gridDim.x * N * K;
   pstat_partial += (size_t)run * gridDim.x * (NW / 2) * (2 * K + 1);
   float* gl = g_lds[wid];
@@ -890,7 +891,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_pool_kernel(
   // (otherwise each wait for a prefetched row also drains the previous tile's 4 KBH stores).
   // The stores go to this pair's own scratch record behind the weight-gradient tables.
   {
-    float* scratch = gw_scratch + (size_t)pair * N * K + (size_t)hf * (N / 2) * K;
+    float* scratch = gw_scratch + ((size_t)pair * 2 + hf) * SCR;
 #pragma unroll
     for (int i = 0; i < 4 * KBH; ++i) scratch[lane + 64 * i] = 0.f;
   }
@@ -1245,8 +1246,9 @@ int fpool_bwd_launch(bool lo, bool x16, const float* gout, const float* raw, con
   const int64_t tiles = (max_rows + fpool::TR - 1) / fpool::TR;
   int64_t blocks = (tiles + NW / 2 - 1) / (NW / 2);         // a tile is walked by a pair of waves
   int64_t cap = (K * N > 4096) ? 256 : 512;               // 64 -> 128: one 8-wave workgroup per CU
-  // the workspace holds one table per workgroup and one scratch record per wave PAIR
-  const int64_t cap_ws = max_waves / ((NW / 2 + 1) * rt.n);
+  // the workspace (max_waves tables) holds one table per workgroup and a 4 KB scratch record per
+  // wave pair behind them: the old bound of one table per pair still covers both
+  const int64_t cap_ws = max_waves / ((NW / 2) * rt.n);
   if (cap > cap_ws) cap = cap_ws;
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
