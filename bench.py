@@ -222,8 +222,9 @@ def preprocess_leg(scene, n_points, dev, reps=5):
                                   "candidate passes saturate the CU's LDS pipe (DESIGN 7.3 item 8)",
                     "bytes_per_launch": int(knn_b), "achieved": round(knn_gbs, 1), "unit": "GB/s",
                     "frac_hbm": round(knn_gbs / HBM_PEAK_GBS, 4),
-                    "valu_busy": pmc.get("knn_valu_busy") if pmc else None,
-                    "valu_busy_source": pmc.get("source") if pmc else None},
+                    "valu_busy": (pmc.get("knn_valu_busy_r05") or pmc.get("knn_valu_busy")) if pmc else None,
+                    "valu_busy_source": (pmc.get("source_r05") if pmc.get("knn_valu_busy_r05")
+                                         else pmc.get("source")) if pmc else None},
             "geof": {"kernel": "spt::point_geof_dense_kernel", "bound": "hbm",
                      "bytes_per_launch": int(geof_b), "achieved": round(geof_gbs, 1), "unit": "GB/s",
                      "peak": HBM_PEAK_GBS, "frac": round(geof_gbs / HBM_PEAK_GBS, 4)}}
