@@ -43,6 +43,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+// measurement builds (tools/build_variant.sh fp_skip<bits> fused_pool.hip -DSPT_FPOOL_SKIP=<bits>; wrong
+// results by design, default 0 changes nothing): forward 1 no Gram statistics, 2 no segment max,
+// 4 no product (the MFMAs of h' = y W'^T)
+#ifndef SPT_FPOOL_SKIP
+#define SPT_FPOOL_SKIP 0
+#endif
 constexpr int TR = 16;           // rows per MFMA tile
 constexpr int NWF = 8;           // waves per workgroup (the W planes are shared through LDS)
 constexpr int ARG_NONE = 0x7fffffff;
@@ -329,7 +335,7 @@ __global__ __launch_bounds__(NWF * 64, 2) void fwd_pool_kernel(
 #pragma unroll
     for (int nb = 0; nb < NBK; ++nb) C[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
+    for (int ks = 0; ks < ((SPT_FPOOL_SKIP & 4) ? 0 : KS); ++ks) {
       const float4 a0 = *reinterpret_cast<const float4*>(al + c * LDA + 32 * ks + 8 * g);
       const float4 a1 = *reinterpret_cast<const float4*>(al + c * LDA + 32 * ks + 8 * g + 4);
       const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
@@ -366,7 +372,7 @@ __global__ __launch_bounds__(NWF * 64, 2) void fwd_pool_kernel(
     }
     // ---- G += y_prev^T y_prev (contraction = the tile's rows: the 4 rows a lane group holds of
     // one column are one packed operand), column sums of y_prev ---------------------------------
-    {
+    if constexpr (!(SPT_FPOOL_SKIP & 1)) {
       bf16x4 Yh[KB], Yl[KB];
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb) {
@@ -417,7 +423,7 @@ __global__ __launch_bounds__(NWF * 64, 2) void fwd_pool_kernel(
     }
     const int seg_cur = seg_a;
     // ---- segment max of the raw tile ---------------------------------------------------------
-    {
+    if constexpr (!(SPT_FPOOL_SKIP & 2)) {
       const int pos0 = (int)p + 4 * g;                            // position of the lane's row r = 0
       int row = 0;
       while (row < cnt) {
