@@ -334,40 +334,56 @@ __global__ __launch_bounds__(NWF * 64, 2) void fwd_pool_kernel(
     f32x4 C[NBK];
 #pragma unroll
     for (int nb = 0; nb < NBK; ++nb) C[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < ((SPT_FPOOL_SKIP & 4) ? 0 : KS); ++ks) {
-      const float4 a0 = *reinterpret_cast<const float4*>(al + c * LDA + 32 * ks + 8 * g);
-      const float4 a1 = *reinterpret_cast<const float4*>(al + c * LDA + 32 * ks + 8 * g + 4);
-      const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-      bf16x8 x1, x2, x3;
-      if constexpr (PREC == 3) {
-        split3<8>(av, x1, x2, x3);
-      } else if constexpr (PREC == 2) {
-        split2<8>(av, x1, x2);
-      } else {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) x1[i] = (__bf16)av[i];
-      }
-#pragma unroll
-      for (int nb = 0; nb < NBK; ++nb) {
+    // (round 6: the W fragment of step i + 1 - a (k-step, column block) pair - is requested BEFORE
+    //  the MFMAs of step i: left to the scheduler every fragment was read right in front of its own
+    //  MFMAs and waited for, 16 exposed LDS round trips per tile - about as long as the MFMAs
+    //  themselves at two waves per SIMD.  LA + 1 fragment register sets rotate.)
+    if constexpr (!(SPT_FPOOL_SKIP & 4)) {
+      constexpr int NSTEP = KS * NBK;
+      constexpr int LA = NPL == 3 ? 2 : (NPL == 2 ? 3 : 6);  // steps of look-ahead (~100 MFMA cycles)
+      bf16x8 wf[LA + 1][NPL];
+      auto ldw = [&](int step, bf16x8 (&w)[NPL]) {
+        const int ks = step / NBK, nb = step - ks * NBK;
         const int wo = (16 * nb + c) * LDW + 32 * ks + 8 * g;
-        const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(&wpl[0][wo]);
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) w[pl] = *reinterpret_cast<const bf16x8*>(&wpl[pl][wo]);
+      };
+#pragma unroll
+      for (int i = 0; i < LA; ++i) ldw(i, wf[i]);
+      bf16x8 x1, x2, x3;
+#pragma unroll
+      for (int step = 0; step < NSTEP; ++step) {
+        const int ks = step / NBK, nb = step - ks * NBK;
+        if (nb == 0) {
+          const float4 a0 = *reinterpret_cast<const float4*>(al + c * LDA + 32 * ks + 8 * g);
+          const float4 a1 = *reinterpret_cast<const float4*>(al + c * LDA + 32 * ks + 8 * g + 4);
+          const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+          if constexpr (PREC == 3) {
+            split3<8>(av, x1, x2, x3);
+          } else if constexpr (PREC == 2) {
+            split2<8>(av, x1, x2);
+          } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x1[i] = (__bf16)av[i];
+          }
+        }
+        if (step + LA < NSTEP) ldw(step + LA, wf[(step + LA) % (LA + 1)]);
+        __builtin_amdgcn_sched_barrier(0);
+        const bf16x8 (&w)[NPL] = wf[step % (LA + 1)];
         f32x4 acc = C[nb];
         if constexpr (PREC == 3) {
-          const bf16x8 w2 = *reinterpret_cast<const bf16x8*>(&wpl[1][wo]);
-          const bf16x8 w3 = *reinterpret_cast<const bf16x8*>(&wpl[NPL - 1][wo]);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x3, w1, acc, 0, 0, 0);   // smallest terms first
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1, w3, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x2, w2, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x2, w1, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1, w2, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x3, w[0], acc, 0, 0, 0);   // smallest terms first
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1, w[NPL - 1], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x2, w[NPL > 1 ? 1 : 0], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x2, w[0], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1, w[NPL > 1 ? 1 : 0], acc, 0, 0, 0);
         } else if constexpr (PREC == 2) {
-          const bf16x8 w2 = *reinterpret_cast<const bf16x8*>(&wpl[NPL - 1][wo]);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x2, w1, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1, w2, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x2, w[0], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1, w[NPL - 1], acc, 0, 0, 0);
         }
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1, w1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1, w[0], acc, 0, 0, 0);
         C[nb] = acc;
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     // ---- G += y_prev^T y_prev (contraction = the tile's rows: the 4 rows a lane group holds of
