@@ -1026,58 +1026,63 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_pool_kernel(
         const float z = c0l[16 * (kb0 + kb) + c];
         CX[kb] = (f32x4){z, z, z, z};
       }
-#pragma unroll
-      for (int sg = 0; sg < NS; ++sg) {
-        const float4 a0 = *reinterpret_cast<const float4*>(gl + c * LDG + 32 * sg + 8 * g);
-        const float4 a1 = *reinterpret_cast<const float4*>(gl + c * LDG + 32 * sg + 8 * g + 4);
-        const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-        bf16x8 ah, alo;
-        if constexpr (LO) {
-          split2<8>(av, ah, alo);
-        } else {
-#pragma unroll
-          for (int i = 0; i < 8; ++i) ah[i] = (__bf16)av[i];
-        }
-#pragma unroll
-        for (int kb = 0; kb < KBH; ++kb) {
+      // (round 6: the B fragments - W^T planes, then M planes - are requested LA steps ahead of
+      //  their MFMAs, as in the forward: one list of NS KBH + KS KBH (step, column block) pairs)
+      constexpr int NPLB = LO ? 2 : 1, LAB = 2;
+      constexpr int NST1 = NS * KBH, NST = NST1 + KS * KBH;
+      bf16x8 bf[LAB + 1][NPLB];
+      auto ldb = [&](int step, bf16x8 (&b)[NPLB]) {
+        if (step < NST1) {
+          const int sg = step / KBH, kb = step - sg * KBH;
           const int wo = (16 * (kb0 + kb) + c) * LDT + 32 * sg + 8 * g;
-          const bf16x8 bh = *reinterpret_cast<const bf16x8*>(wt_hi + wo);
-          f32x4 acc = CX[kb];
-          if constexpr (LO) {
-            const bf16x8 bl = *reinterpret_cast<const bf16x8*>(wt_lo + wo);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo, bh, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc, 0, 0, 0);
-          }
-          CX[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc, 0, 0, 0);
-        }
-      }
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const float4 a0 = *reinterpret_cast<const float4*>(xl + c * LDX + 32 * ks + 8 * g);
-        const float4 a1 = *reinterpret_cast<const float4*>(xl + c * LDX + 32 * ks + 8 * g + 4);
-        const float rv[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-        float av[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) av[i] = ynorm(rv[i], 32 * ks + 8 * g + i, c < cnt);
-        bf16x8 ah, alo;
-        if constexpr (LO) {
-          split2<8>(av, ah, alo);
+          b[0] = *reinterpret_cast<const bf16x8*>(wt_hi + wo);
+          if constexpr (LO) b[NPLB - 1] = *reinterpret_cast<const bf16x8*>(wt_lo + wo);
         } else {
-#pragma unroll
-          for (int i = 0; i < 8; ++i) ah[i] = (__bf16)av[i];
-        }
-#pragma unroll
-        for (int kb = 0; kb < KBH; ++kb) {
+          const int st = step - NST1, ks = st / KBH, kb = st - ks * KBH;
           const int mo = (16 * (kb0 + kb) + c) * LDM + 32 * ks + 8 * g;
-          const bf16x8 bh = *reinterpret_cast<const bf16x8*>(mt_hi + mo);
-          f32x4 acc = CX[kb];
-          if constexpr (LO) {
-            const bf16x8 bl = *reinterpret_cast<const bf16x8*>(mt_lo + mo);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo, bh, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc, 0, 0, 0);
-          }
-          CX[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc, 0, 0, 0);
+          b[0] = *reinterpret_cast<const bf16x8*>(mt_hi + mo);
+          if constexpr (LO) b[NPLB - 1] = *reinterpret_cast<const bf16x8*>(mt_lo + mo);
         }
+      };
+#pragma unroll
+      for (int i = 0; i < LAB; ++i) ldb(i, bf[i]);
+      bf16x8 ah, alo;
+#pragma unroll
+      for (int step = 0; step < NST; ++step) {
+        const bool first = step < NST1;
+        const int sub = first ? step : step - NST1;
+        const int blk = sub / KBH, kb = sub - blk * KBH;    // blk = sg (S W) or ks (y_prev M)
+        if (kb == 0) {
+          float av[8];
+          if (first) {
+            const float4 a0 = *reinterpret_cast<const float4*>(gl + c * LDG + 32 * blk + 8 * g);
+            const float4 a1 = *reinterpret_cast<const float4*>(gl + c * LDG + 32 * blk + 8 * g + 4);
+            av[0] = a0.x; av[1] = a0.y; av[2] = a0.z; av[3] = a0.w;
+            av[4] = a1.x; av[5] = a1.y; av[6] = a1.z; av[7] = a1.w;
+          } else {
+            const float4 a0 = *reinterpret_cast<const float4*>(xl + c * LDX + 32 * blk + 8 * g);
+            const float4 a1 = *reinterpret_cast<const float4*>(xl + c * LDX + 32 * blk + 8 * g + 4);
+            const float rv[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) av[i] = ynorm(rv[i], 32 * blk + 8 * g + i, c < cnt);
+          }
+          if constexpr (LO) {
+            split2<8>(av, ah, alo);
+          } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ah[i] = (__bf16)av[i];
+          }
+        }
+        if (step + LAB < NST) ldb(step + LAB, bf[(step + LAB) % (LAB + 1)]);
+        __builtin_amdgcn_sched_barrier(0);
+        const bf16x8 (&b)[NPLB] = bf[step % (LAB + 1)];
+        f32x4 acc = CX[kb];
+        if constexpr (LO) {
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo, b[0], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, b[NPLB - 1], acc, 0, 0, 0);
+        }
+        CX[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, b[0], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
