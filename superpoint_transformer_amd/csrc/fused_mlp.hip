@@ -1149,19 +1149,36 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_kernel_bf(
       f32x4 CX[KB];
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb) CX[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      // (round 6: the W^T fragments are requested LAB steps ahead of their MFMAs - one list of
+      //  (32-column step, k block) pairs, rotating register sets; the compiler read each fragment
+      //  right in front of its MFMAs and waited for it, which the K = 132 instance - one wave per
+      //  SIMD - has nothing to hide behind.  Same products in the same order.)
+      // (where the other instances sit at two or more waves per SIMD the fragment is read in front
+      //  of its MFMAs as before: LAB = 0)
+      constexpr int LAB = (NW == 4 && K4 > 16) ? 2 : 0, NSTG = NS * KB;
+      bf16x8 bfh[LAB + 1], bfl[LAB + 1];
+      auto ldb = [&](int step, bf16x8& bh, bf16x8& bl) {
+        const int sg = step / KB, kb = step - sg * KB;
+        bh = *reinterpret_cast<const bf16x8*>(wt_hi + (16 * kb + c) * LDT + 32 * sg + 8 * g);
+        if constexpr (LO) bl = *reinterpret_cast<const bf16x8*>(wt_lo + (16 * kb + c) * LDT + 32 * sg + 8 * g);
+        else bl = bh;
+      };
 #pragma unroll
-      for (int sg = 0; sg < NS; ++sg) {
-        const float4 a0 = *reinterpret_cast<const float4*>(gl + c * LDG + 32 * sg + 8 * g);
-        const float4 a1 = *reinterpret_cast<const float4*>(gl + c * LDG + 32 * sg + 8 * g + 4);
-        const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-        bf16x8 ah, alo;
-        split_bf16<8>(av, ah, alo);
+      for (int i = 0; i < LAB && i < NSTG; ++i) ldb(i, bfh[i], bfl[i]);
+      bf16x8 ah, alo;
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {
-          const bf16x8 bh = *reinterpret_cast<const bf16x8*>(wt_hi + (16 * kb + c) * LDT + 32 * sg + 8 * g);
-          const bf16x8 bl = *reinterpret_cast<const bf16x8*>(wt_lo + (16 * kb + c) * LDT + 32 * sg + 8 * g);
-          CX[kb] = mfma3_32<LO>(ah, alo, bh, bl, CX[kb]);
+      for (int step = 0; step < NSTG; ++step) {
+        const int sg = step / KB, kb = step - sg * KB;
+        if (kb == 0) {
+          const float4 a0 = *reinterpret_cast<const float4*>(gl + c * LDG + 32 * sg + 8 * g);
+          const float4 a1 = *reinterpret_cast<const float4*>(gl + c * LDG + 32 * sg + 8 * g + 4);
+          const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+          split_bf16<8>(av, ah, alo);
         }
+        if (step + LAB < NSTG) ldb(step + LAB, bfh[(step + LAB) % (LAB + 1)], bfl[(step + LAB) % (LAB + 1)]);
+        if constexpr (LAB > 0) __builtin_amdgcn_sched_barrier(0);
+        CX[kb] = mfma3_32<LO>(ah, alo, bfh[step % (LAB + 1)], bfl[step % (LAB + 1)], CX[kb]);
+        if constexpr (LAB > 0) __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -1891,7 +1908,18 @@ static int fmlp_bwd_impl(bool pooled, const float* gy, const float* gout, const 
       gw_tabs = gx_ * NWV;                                                                       \
     }                                                                                            \
     const dim3 grid((unsigned)gx_, (unsigned)nr);                                                \
-    if (g_fmlp_mode == 3 && gx)                                                                  \
+    /* round 6: the one-wave-per-SIMD instances (K = 132) prefetch the next tile's raw rows into */ \
+    /* registers (PIPE): nothing else hides their two memory round trips per tile                */ \
+    constexpr bool PIPE_ = (a * b > 128);           /* (whole 16-byte row chunks: K % 4 == 0) */  \
+    if (PIPE_ && K % 4 == 0 && g_fmlp_mode == 3 && gx)                                           \
+      bwd_kernel_bf<a, b, true, NWB, false, false, PIPE_><<<grid, NWB * 64, 0, stream>>>(        \
+          gy, h, 0, 0, am, scale, bias, slope, c1, c2, c3, xprev, K, pre_am, pre_scale,          \
+          pre_bias, pre_slope, W, gx, gwp, pstp, rt);                                            \
+    else if (PIPE_ && K % 4 == 0 && g_fmlp_split_bf16 && gx)                                     \
+      bwd_kernel_bf<a, b, true, NWB, true, false, PIPE_><<<grid, NWB * 64, 0, stream>>>(         \
+          gy, h, 0, 0, am, scale, bias, slope, c1, c2, c3, xprev, K, pre_am, pre_scale,          \
+          pre_bias, pre_slope, W, gx, gwp, pstp, rt);                                            \
+    else if (g_fmlp_mode == 3 && gx)                                                             \
       bwd_kernel_bf<a, b, true, NWB, false><<<grid, NWB * 64, 0, stream>>>(                      \
           gy, h, 0, 0, am, scale, bias, slope, c1, c2, c3, xprev, K, pre_am, pre_scale,          \
           pre_bias, pre_slope, W, gx, gwp, pstp, rt);                                            \
