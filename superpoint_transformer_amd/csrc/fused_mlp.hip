@@ -799,12 +799,53 @@ __global__ __launch_bounds__(WAVES_X3 * 64, 2) void fwd_kernel_x3(
   const int64_t ntiles = (r1 - r0 + TR - 1) / TR;
   const int64_t wave = (int64_t)blockIdx.x * WAVES_X3 + wid;
   const int64_t nwaves = (int64_t)gridDim.x * WAVES_X3;
+  // Round 6: rows of whole 16-byte chunks (K % 4 == 0) are PREFETCHED - the next tile's chunks are
+  // requested into registers right after this tile has been staged and travel under its MFMAs and
+  // stores (the staging loop was load -> transform -> ds_write per tile: at two waves per SIMD the
+  // round trip showed, most where a launch has few tiles per wave).  Same values, same transform.
+  constexpr int CHP = KP / 4, NITP = (TR * CHP + 63) / 64;
+  const bool pref = (K & 3) == 0 && K == KP;
+  float4 pv[NITP];
+  auto prefetch = [&](int64_t t) {
+    const int64_t row0 = r0 + t * TR;
+    const int cnt = (t < ntiles) ? (int)((r1 - row0) < TR ? (r1 - row0) : TR) : 0;
+#pragma unroll
+    for (int j = 0; j < NITP; ++j) {
+      const int q = lane + 64 * j, rr = q / CHP, k = (q - rr * CHP) << 2;
+      // (clamped in-range address for the masked-out chunks: unconditional loads stay back to back)
+      const bool ok = q < TR * CHP && rr < cnt;
+      const float4 v = *reinterpret_cast<const float4*>(x + (ok ? (row0 + rr) * K + k : r0 * K));
+      pv[j] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  if (pref && wave < ntiles) prefetch(wave);
   for (int64_t t = wave; t < ntiles; t += nwaves) {
     const int64_t row0 = r0 + t * TR;
     const int cnt = (int)((r1 - row0) < TR ? (r1 - row0) : TR);
     wave_sync_lds();
-    stage_tile<KP32, LDA, KP32>(x, row0, cnt, K, pre, tab, slope, al, nullptr, lane);
+    if (pref) {
+#pragma unroll
+      for (int j = 0; j < NITP; ++j) {
+        const int q = lane + 64 * j, rr = q / CHP, k = (q - rr * CHP) << 2;
+        if (q < TR * CHP) {
+          float4 w = pv[j];
+          if (pre && rr < cnt) {
+            const float4 a = *reinterpret_cast<const float4*>(tab + k);
+            const float4 s4 = *reinterpret_cast<const float4*>(tab + KP32 + k);
+            const float4 b = *reinterpret_cast<const float4*>(tab + 2 * KP32 + k);
+            w.x = fmaf(w.x - a.x, s4.x, b.x); w.y = fmaf(w.y - a.y, s4.y, b.y);
+            w.z = fmaf(w.z - a.z, s4.z, b.z); w.w = fmaf(w.w - a.w, s4.w, b.w);
+            w.x = w.x > 0.f ? w.x : w.x * slope; w.y = w.y > 0.f ? w.y : w.y * slope;
+            w.z = w.z > 0.f ? w.z : w.z * slope; w.w = w.w > 0.f ? w.w : w.w * slope;
+          }
+          *reinterpret_cast<float4*>(al + rr * LDA + k) = w;
+        }
+      }
+    } else {
+      stage_tile<KP32, LDA, KP32>(x, row0, cnt, K, pre, tab, slope, al, nullptr, lane);
+    }
     wave_sync_lds();
+    if (pref) prefetch(t + nwaves);
     f32x4 C[NBK];
 #pragma unroll
     for (int nb = 0; nb < NBK; ++nb) C[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
