@@ -45,7 +45,8 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 // measurement builds (tools/build_variant.sh fp_skip<bits> fused_pool.hip -DSPT_FPOOL_SKIP=<bits>; wrong
 // results by design, default 0 changes nothing): forward 1 no Gram statistics, 2 no segment max,
-// 4 no product (the MFMAs of h' = y W'^T)
+// 4 no product (the MFMAs of h' = y W'^T); backward 8 no weight-gradient product, 16 no input-gradient
+// products, 32 no statistics of the previous norm
 #ifndef SPT_FPOOL_SKIP
 #define SPT_FPOOL_SKIP 0
 #endif
@@ -980,7 +981,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_pool_kernel(
       return ok ? v : 0.f;
     };
     // ---- gW[this half's rows] += S^T y_prev -------------------------------------------------------
-    {
+    if constexpr (!(SPT_FPOOL_SKIP & 8)) {
       bf16x4 Xh[KB], Xl[KB];
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb) {
@@ -1048,7 +1049,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_pool_kernel(
       for (int i = 0; i < LAB; ++i) ldb(i, bf[i]);
       bf16x8 ah, alo;
 #pragma unroll
-      for (int step = 0; step < NST; ++step) {
+      for (int step = 0; step < ((SPT_FPOOL_SKIP & 16) ? 0 : NST); ++step) {
         const bool first = step < NST1;
         const int sub = first ? step : step - NST1;
         const int blk = sub / KBH, kb = sub - blk * KBH;    // blk = sg (S W) or ks (y_prev M)
@@ -1100,8 +1101,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_pool_kernel(
               const float y = fmaf(o, pt[K + k], pt[2 * K + k]);
               gg = (y > 0.f) ? gg : gg * pslope;
             }
-            p1[kb] += (double)gg;
-            p2[kb] += (double)gg * (double)o;
+            if constexpr (!(SPT_FPOOL_SKIP & 32)) {
+              p1[kb] += (double)gg;
+              p2[kb] += (double)gg * (double)o;
+            }
           }
         }
       }
