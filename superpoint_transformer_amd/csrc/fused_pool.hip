@@ -50,6 +50,9 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 #ifndef SPT_FPOOL_SKIP
 #define SPT_FPOOL_SKIP 0
 #endif
+#ifndef SPT_FPOOL_WPAD   // measurement builds: 8 = the row padding of the weight planes before round 6
+#define SPT_FPOOL_WPAD 16
+#endif
 constexpr int TR = 16;           // rows per MFMA tile
 constexpr int NWF = 8;           // waves per workgroup (the W planes are shared through LDS)
 constexpr int ARG_NONE = 0x7fffffff;
@@ -204,8 +207,8 @@ __global__ __launch_bounds__(NWF * 64, 2) void fwd_pool_kernel(
   // (profiles/r06y_pmc_fpool_sq.txt: SQ_LDS_BANK_CONFLICT 195.6 M -> 15.4 M cycles per call, LDS
   // cycles 582 M -> 401 M; the backward 283.9 M -> 103.9 M.  The kernels' TIME did not move - they
   // wait on dependent round trips, not on LDS throughput)
-  constexpr int LDW = K + 16;
-  static_assert(LDW % 32 == 16, "conflict-free B fragments");
+  constexpr int LDW = K + SPT_FPOOL_WPAD;
+  static_assert(LDW % 32 == 16 || SPT_FPOOL_WPAD != 16, "conflict-free B fragments");
   constexpr int NPL = PREC == 3 ? 3 : (PREC == 2 ? 2 : 1);
   constexpr int NGB = KB * (KB + 1) / 2;                 // upper-triangular 16 x 16 blocks of G
   constexpr int GLEN = K * K + K + 1;
@@ -802,8 +805,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void bwd_pool_kernel(
   constexpr int KB = K / 16, NBK = N / 16, NS = N / 32, KS = K / 32;
   constexpr int NBH = NBK / 2, KBH = KB / 2;             // a wave's half of the outputs
   constexpr int LDG = N + 4, LDX = K + 4;
-  constexpr int LDT = N + 16, LDM = K + 16;              // = 16 (mod 32): see fwd_pool_kernel's LDW
-  static_assert(LDT % 32 == 16 && LDM % 32 == 16, "conflict-free B fragments");
+  constexpr int LDT = N + SPT_FPOOL_WPAD, LDM = K + SPT_FPOOL_WPAD;   // = 16 (mod 32): see fwd_pool_kernel's LDW
+  static_assert((LDT % 32 == 16 && LDM % 32 == 16) || SPT_FPOOL_WPAD != 16, "conflict-free B fragments");
   constexpr int CPL = N / 64;                            // channels a lane scatters per segment
   static_assert(K % 32 == 0 && N % 64 == 0 && NW % 2 == 0, "shape");
   __shared__ __attribute__((aligned(16))) float g_lds[NW][TR * LDG];   // S tile
